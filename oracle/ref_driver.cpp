@@ -1,0 +1,171 @@
+// oracle/ref_driver.cpp -- TEST INFRASTRUCTURE (never linked or loaded by the product path).
+//
+// A small C-ABI shim around the REAL reference library built by oracle/ref.mk
+// (oracle/_ref/libembree4.so).  It is compiled against the reference's own
+// headers where they lie under /root/reference/include (no copy) and lets the
+// Python tests / bench.py drive the reference through ctypes:
+//   * as the parity checker for the HIP path (tests/, __graft_entry__.smoke),
+//   * as the "reference" CPU baseline (bench.py cpu_baseline leg): worker
+//     threads loop rtcIntersect1 / rtcOccluded1 over contiguous 1024-ray blocks
+//     with FTZ|DAZ set, exactly the blocking of the reference's own
+//     ParallelIntersectBenchmark (tutorials/verify/verify.cpp:5728-5755) and
+//     the MXCSR advice of README.md:10319-10340.
+// Built into oracle/_ref/libref_driver.so (git-ignored, travels with gpurun).
+#include <embree4/rtcore.h>
+#include <xmmintrin.h>
+#include <pmmintrin.h>
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+namespace {
+struct RefScene {
+  RTCDevice device = nullptr;
+  RTCScene scene = nullptr;
+};
+double now() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+template <typename F>
+double run_blocks(unsigned M, int threads, F&& body) {
+  const unsigned BLOCK = 1024;  // verify.cpp:5733 (numRays / 1024 blocks)
+  const unsigned nblocks = (M + BLOCK - 1) / BLOCK;
+  if (threads < 1) threads = 1;
+  std::atomic<unsigned> next(0);
+  auto worker = [&]() {
+    _MM_SET_FLUSH_ZERO_MODE(_MM_FLUSH_ZERO_ON);
+    _MM_SET_DENORMALS_ZERO_MODE(_MM_DENORMALS_ZERO_ON);
+    for (;;) {
+      unsigned b = next.fetch_add(1);
+      if (b >= nblocks) break;
+      unsigned lo = b * BLOCK, hi = lo + BLOCK < M ? lo + BLOCK : M;
+      body(lo, hi);
+    }
+  };
+  double t0 = now();
+  std::vector<std::thread> pool;
+  for (int i = 1; i < threads; i++) pool.emplace_back(worker);
+  worker();
+  for (auto& t : pool) t.join();
+  return now() - t0;
+}
+}  // namespace
+
+extern "C" {
+
+__attribute__((visibility("default"))) void* refd_new(const char* cfg) {
+  RefScene* s = new RefScene;
+  s->device = rtcNewDevice(cfg);
+  if (!s->device) { delete s; return nullptr; }
+  s->scene = rtcNewScene(s->device);
+  return s;
+}
+
+__attribute__((visibility("default"))) void refd_set_flags(void* h, int flags, int quality) {
+  RefScene* s = (RefScene*)h;
+  rtcSetSceneFlags(s->scene, (RTCSceneFlags)flags);
+  rtcSetSceneBuildQuality(s->scene, (RTCBuildQuality)quality);
+}
+
+// copies the arrays into library-owned buffers (rtcSetNewGeometryBuffer pads them)
+__attribute__((visibility("default"))) unsigned refd_add_mesh(void* h, const float* verts, unsigned nv,
+                                                              const unsigned* idx, unsigned nt, unsigned mask) {
+  RefScene* s = (RefScene*)h;
+  RTCGeometry g = rtcNewGeometry(s->device, RTC_GEOMETRY_TYPE_TRIANGLE);
+  float* v = (float*)rtcSetNewGeometryBuffer(g, RTC_BUFFER_TYPE_VERTEX, 0, RTC_FORMAT_FLOAT3, 12, nv);
+  unsigned* t = (unsigned*)rtcSetNewGeometryBuffer(g, RTC_BUFFER_TYPE_INDEX, 0, RTC_FORMAT_UINT3, 12, nt);
+  if (v && nv) memcpy(v, verts, (size_t)nv * 12);
+  if (t && nt) memcpy(t, idx, (size_t)nt * 12);
+  rtcSetGeometryMask(g, mask);
+  rtcCommitGeometry(g);
+  unsigned id = rtcAttachGeometry(s->scene, g);
+  rtcReleaseGeometry(g);
+  return id;
+}
+
+__attribute__((visibility("default"))) double refd_commit(void* h) {
+  RefScene* s = (RefScene*)h;
+  double t0 = now();
+  rtcCommitScene(s->scene);
+  return now() - t0;
+}
+
+__attribute__((visibility("default"))) int refd_error(void* h) {
+  RefScene* s = (RefScene*)h;
+  return (int)rtcGetDeviceError(s ? s->device : nullptr);
+}
+
+__attribute__((visibility("default"))) void refd_bounds(void* h, float* out8) {
+  RefScene* s = (RefScene*)h;
+  RTCBounds b;
+  rtcGetSceneBounds(s->scene, &b);
+  memcpy(out8, &b, 32);
+}
+
+__attribute__((visibility("default"))) double refd_intersect1(void* h, RTCRayHit* rh, unsigned M, int threads) {
+  RefScene* s = (RefScene*)h;
+  return run_blocks(M, threads, [&](unsigned lo, unsigned hi) {
+    for (unsigned i = lo; i < hi; i++) rtcIntersect1(s->scene, &rh[i]);
+  });
+}
+
+__attribute__((visibility("default"))) double refd_occluded1(void* h, RTCRay* r, unsigned M, int threads) {
+  RefScene* s = (RefScene*)h;
+  return run_blocks(M, threads, [&](unsigned lo, unsigned hi) {
+    for (unsigned i = lo; i < hi; i++) rtcOccluded1(s->scene, &r[i]);
+  });
+}
+
+// packet entry points, driven from AoS input for convenience: gathers K rays
+// into an RTCRayHitK, calls rtcIntersectK with all-valid mask (-1 = active,
+// kernels/bvh/bvh_intersector_hybrid.cpp:127), scatters back.
+#define REFD_PACKET(K, ALIGN)                                                                     \
+  __attribute__((visibility("default"))) double refd_intersect##K(void* h, RTCRayHit* rh,         \
+                                                                  unsigned M, int threads) {      \
+    RefScene* s = (RefScene*)h;                                                                   \
+    return run_blocks(M, threads, [&](unsigned lo, unsigned hi) {                                 \
+      for (unsigned b = lo; b < hi; b += K) {                                                     \
+        alignas(ALIGN) RTCRayHit##K p;                                                            \
+        alignas(ALIGN) int valid[K];                                                              \
+        for (unsigned k = 0; k < K; k++) {                                                        \
+          unsigned i = b + k;                                                                     \
+          valid[k] = i < hi ? -1 : 0;                                                             \
+          const RTCRayHit& r = rh[i < hi ? i : hi - 1];                                           \
+          p.ray.org_x[k] = r.ray.org_x; p.ray.org_y[k] = r.ray.org_y; p.ray.org_z[k] = r.ray.org_z; \
+          p.ray.tnear[k] = r.ray.tnear;                                                           \
+          p.ray.dir_x[k] = r.ray.dir_x; p.ray.dir_y[k] = r.ray.dir_y; p.ray.dir_z[k] = r.ray.dir_z; \
+          p.ray.time[k] = r.ray.time; p.ray.tfar[k] = r.ray.tfar; p.ray.mask[k] = r.ray.mask;     \
+          p.ray.id[k] = r.ray.id; p.ray.flags[k] = r.ray.flags;                                   \
+          p.hit.geomID[k] = r.hit.geomID; p.hit.primID[k] = r.hit.primID;                         \
+          p.hit.instID[0][k] = r.hit.instID[0];                                                   \
+        }                                                                                         \
+        rtcIntersect##K(valid, s->scene, &p);                                                     \
+        for (unsigned k = 0; k < K && b + k < hi; k++) {                                          \
+          RTCRayHit& r = rh[b + k];                                                               \
+          if (p.hit.geomID[k] == RTC_INVALID_GEOMETRY_ID) continue;                               \
+          r.ray.tfar = p.ray.tfar[k];                                                             \
+          r.hit.Ng_x = p.hit.Ng_x[k]; r.hit.Ng_y = p.hit.Ng_y[k]; r.hit.Ng_z = p.hit.Ng_z[k];     \
+          r.hit.u = p.hit.u[k]; r.hit.v = p.hit.v[k];                                             \
+          r.hit.primID = p.hit.primID[k]; r.hit.geomID = p.hit.geomID[k];                         \
+          r.hit.instID[0] = p.hit.instID[0][k];                                                   \
+        }                                                                                         \
+      }                                                                                           \
+    });                                                                                           \
+  }
+REFD_PACKET(4, 16)
+REFD_PACKET(8, 32)
+
+__attribute__((visibility("default"))) void refd_free(void* h) {
+  RefScene* s = (RefScene*)h;
+  if (!s) return;
+  if (s->scene) rtcReleaseScene(s->scene);
+  if (s->device) rtcReleaseDevice(s->device);
+  delete s;
+}
+
+__attribute__((visibility("default"))) unsigned refd_sizeof_rayhit() { return (unsigned)sizeof(RTCRayHit); }
+__attribute__((visibility("default"))) unsigned refd_hw_threads() { return std::thread::hardware_concurrency(); }
+}

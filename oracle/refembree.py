@@ -1,0 +1,105 @@
+"""ctypes front-end of oracle/_ref/libref_driver.so -- TEST INFRASTRUCTURE.
+
+Drives the REAL reference (Embree 4.4.1 built by oracle/ref.mk from the
+sources under /root/reference).  Only tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg may import this module; the product never does.
+"""
+import ctypes
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "_ref", "libref_driver.so")
+
+
+def available():
+    return os.path.exists(_LIB)
+
+
+_lib = None
+
+
+def _load():
+    global _lib
+    if _lib is None:
+        L = ctypes.CDLL(_LIB)
+        L.refd_new.restype = ctypes.c_void_p
+        L.refd_new.argtypes = [ctypes.c_char_p]
+        L.refd_set_flags.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+        L.refd_add_mesh.restype = ctypes.c_uint
+        L.refd_add_mesh.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint,
+                                    ctypes.c_void_p, ctypes.c_uint, ctypes.c_uint]
+        L.refd_commit.restype = ctypes.c_double
+        L.refd_commit.argtypes = [ctypes.c_void_p]
+        L.refd_error.restype = ctypes.c_int
+        L.refd_error.argtypes = [ctypes.c_void_p]
+        L.refd_bounds.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        for name in ("refd_intersect1", "refd_occluded1", "refd_intersect4", "refd_intersect8"):
+            f = getattr(L, name)
+            f.restype = ctypes.c_double
+            f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint, ctypes.c_int]
+        L.refd_free.argtypes = [ctypes.c_void_p]
+        L.refd_hw_threads.restype = ctypes.c_uint
+        _lib = L
+    return _lib
+
+
+def hw_threads():
+    return int(_load().refd_hw_threads())
+
+
+class RefScene:
+    """One device + one scene of the real reference."""
+
+    def __init__(self, cfg="", flags=0, quality=1):
+        L = _load()
+        self._h = L.refd_new(cfg.encode())
+        if not self._h:
+            raise RuntimeError("reference rtcNewDevice failed")
+        if flags or quality != 1:
+            L.refd_set_flags(self._h, flags, quality)
+        self.commit_seconds = None
+
+    def add_mesh(self, verts, tris, mask=1):
+        v = np.ascontiguousarray(verts, np.float32).reshape(-1, 3)
+        t = np.ascontiguousarray(tris, np.uint32).reshape(-1, 3)
+        return _load().refd_add_mesh(self._h, v.ctypes.data, v.shape[0], t.ctypes.data, t.shape[0], mask)
+
+    def commit(self):
+        self.commit_seconds = _load().refd_commit(self._h)
+        return self.commit_seconds
+
+    def bounds(self):
+        b = np.zeros(8, np.float32)
+        _load().refd_bounds(self._h, b.ctypes.data)
+        return b[0:3].copy(), b[4:7].copy()
+
+    def _run(self, fn, arr, threads):
+        assert arr.flags["C_CONTIGUOUS"]
+        return getattr(_load(), fn)(self._h, arr.ctypes.data, arr.shape[0], threads)
+
+    def intersect1(self, rayhits, threads=1):
+        return self._run("refd_intersect1", rayhits, threads)
+
+    def intersect4(self, rayhits, threads=1):
+        return self._run("refd_intersect4", rayhits, threads)
+
+    def intersect8(self, rayhits, threads=1):
+        return self._run("refd_intersect8", rayhits, threads)
+
+    def occluded1(self, rays, threads=1):
+        return self._run("refd_occluded1", rays, threads)
+
+    def error(self):
+        return _load().refd_error(self._h)
+
+    def close(self):
+        if self._h:
+            _load().refd_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
