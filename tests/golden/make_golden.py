@@ -1,0 +1,106 @@
+"""Generates the committed fixtures under tests/golden/ from the reference.
+
+Run HERE (the container that mounts /root/reference and has oracle/_ref built by
+`make -f oracle/ref.mk`); the fixtures travel to the GPU box, this script's inputs do not.
+
+  python tests/golden/make_golden.py
+
+Outputs
+  cornell_box.npz        verts/tris of tutorials/models/cornell_box.obj ('v' and 'f' records only,
+                         negative indices resolved, quads fan-triangulated (0,1,2),(0,2,3)) -> 34 tris
+  ref_cube_1k.npz        config 1: the real reference's rtcIntersect1/rtcOccluded1 results for the 32x32
+                         camera rays on cube+plane (tutorials/triangle_geometry)
+  ref_cornell_4k.npz     config 2 at 64x64: real-reference results on the Cornell box
+  ref_soup_8k.npz        8192 incoherent rays on a seeded 3,000-triangle soup (two geometries,
+                         masks 1 and 2, ray masks alternating) incl. occluded results
+  ref_trianglehit.npz    TriangleHitTest (tutorials/verify/verify.cpp:2462-2547) inputs + real-reference outputs
+"""
+import os
+import sys
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from embree_amd import workloads as W            # noqa: E402
+from embree_amd.rtypes import make_rayhits, rays_of  # noqa: E402
+from oracle import refembree                      # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference"
+
+
+def parse_obj(path):
+    verts, tris = [], []
+    for line in open(path):
+        p = line.split()
+        if not p:
+            continue
+        if p[0] == "v":
+            verts.append([float(x) for x in p[1:4]])
+        elif p[0] == "f":
+            idx = []
+            for tok in p[1:]:
+                i = int(tok.split("/")[0])
+                idx.append(i - 1 if i > 0 else len(verts) + i)
+            for k in range(1, len(idx) - 1):
+                tris.append([idx[0], idx[k], idx[k + 1]])
+    return np.array(verts, np.float32), np.array(tris, np.uint32)
+
+
+def trace_ref(meshes, rayhits, masks=None, occl=True):
+    s = refembree.RefScene("threads=1")
+    for i, (v, t) in enumerate(meshes):
+        s.add_mesh(v, t, 1 if masks is None else masks[i])
+    s.commit()
+    rh = rayhits.copy()
+    s.intersect1(rh)
+    out = dict(rays=rayhits, hits=rh)
+    if occl:
+        r = rays_of(rayhits)
+        s.occluded1(r)
+        out["occluded_tfar"] = r["tfar"].copy()
+    lo, hi = s.bounds()
+    out["bounds_lo"], out["bounds_hi"] = lo, hi
+    s.close()
+    return out
+
+
+def soup(n, seed):
+    rng = np.random.default_rng(seed)
+    c = rng.random((n, 3), dtype=np.float32)
+    v = (c[:, None, :] + (rng.random((n, 3, 3), dtype=np.float32) - 0.5) * 0.08).reshape(-1, 3)
+    t = np.arange(3 * n, dtype=np.uint32).reshape(-1, 3)
+    return v.astype(np.float32), t
+
+
+def main():
+    v, t = parse_obj(os.path.join(REF, "tutorials/models/cornell_box.obj"))
+    assert t.shape[0] == 34, t.shape
+    np.savez_compressed(os.path.join(OUT, "cornell_box.npz"), verts=v, tris=t)
+
+    np.savez_compressed(os.path.join(OUT, "ref_cube_1k.npz"), **trace_ref(W.cube_and_plane(), W.cube_camera_rays()))
+    np.savez_compressed(os.path.join(OUT, "ref_cornell_4k.npz"), **trace_ref(W.cornell_box(), W.cornell_camera_rays(64, 64)))
+
+    a, b = soup(2000, 11), soup(1000, 12)
+    rays = W.incoherent_rays(8192, [0.5, 0.5, 0.5], seed=5)
+    rays["mask"] = np.where(np.arange(8192) % 3 == 0, 1, np.where(np.arange(8192) % 3 == 1, 2, 3)).astype(np.uint32)
+    d = trace_ref([a, b], rays, masks=[1, 2])
+    d.update(v0=a[0], t0=a[1], v1=b[0], t1=b[1])
+    np.savez_compressed(os.path.join(OUT, "ref_soup_8k.npz"), **d)
+
+    # TriangleHitTest: one triangle (0,0,0),(1,0,0),(0,1,0); rays from (0,0,-1) to (u,v,0)
+    tv = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32)
+    tt = np.array([[0, 1, 2]], np.uint32)
+    uu, vv = np.meshgrid(np.arange(16, dtype=np.float32), np.arange(16, dtype=np.float32))
+    u = (0.01 + 0.9 * uu.ravel() / 16).astype(np.float32)
+    w = (0.01 + 0.9 * vv.ravel() / 16).astype(np.float32) * (1 - u)
+    tgt = np.stack([u, w, np.zeros_like(u)], -1)
+    org = np.tile(np.array([[0, 0, -1]], np.float32), (256, 1))
+    d = trace_ref([(tv, tt)], make_rayhits(org, tgt - org))
+    d.update(u0=u, v0=w)
+    np.savez_compressed(os.path.join(OUT, "ref_trianglehit.npz"), **d)
+    print("golden fixtures written to", OUT)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,63 @@
+"""Shared comparison logic of the parity tests.
+
+Bar (BASELINE.json north_star): t and Ng within 1e-4 relative, primID/geomID bit-exact.
+Exact-tie rule: two correct tracers may legally report different
+IDs when a ray hits two triangles at the same t (shared edges, coplanar duplicates); such a
+ray is accepted iff the t the *checker* computes for the triangle the tested path reported
+equals the checker's own t within the same tolerance.  Ties are counted and returned.
+"""
+import numpy as np
+
+from embree_amd.rtypes import INVALID_ID
+
+RTOL = 1e-4
+
+
+def _rel(a, b):
+    return np.abs(a - b) <= RTOL * np.maximum(np.abs(a), np.abs(b)) + 1e-30
+
+
+def compare_closest(got, want, rays_in=None, tri_t=None, max_tie_frac=5e-3, label=""):
+    """got/want: traced RTCRayHit arrays.  tri_t(rays_in, geomID, primID) -> t of a named triangle."""
+    n = got.shape[0]
+    g_hit = got["geomID"] != INVALID_ID
+    w_hit = want["geomID"] != INVALID_ID
+    same_ids = (got["geomID"] == want["geomID"]) & (got["primID"] == want["primID"])
+    suspect = ~same_ids
+    ties = 0
+    bad = np.zeros(n, bool)
+    if suspect.any():
+        idx = np.nonzero(suspect)[0]
+        if tri_t is None or rays_in is None:
+            bad[idx] = True
+        else:
+            both = idx[g_hit[idx] & w_hit[idx]]
+            t_named = tri_t(rays_in[both], got["geomID"][both], got["primID"][both])
+            ok = _rel(t_named, want["tfar"][both]) & _rel(got["tfar"][both], want["tfar"][both])
+            ties = int(ok.sum())
+            bad[both[~ok]] = True
+            bad[idx[~(g_hit[idx] & w_hit[idx])]] = True     # hit/miss disagreement is never a tie
+    assert not bad.any(), f"{label}: {int(bad.sum())}/{n} rays differ (first {np.nonzero(bad)[0][:8]})"
+    assert ties <= max(2, max_tie_frac * n), f"{label}: too many ties {ties}/{n}"
+    m = same_ids & w_hit
+    assert _rel(got["tfar"][m], want["tfar"][m]).all(), f"{label}: tfar outside {RTOL}"
+    for f in ("Ng_x", "Ng_y", "Ng_z"):
+        ng_scale = np.sqrt(want["Ng_x"][m] ** 2 + want["Ng_y"][m] ** 2 + want["Ng_z"][m] ** 2)
+        assert (np.abs(got[f][m] - want[f][m]) <= RTOL * ng_scale + 1e-30).all(), f"{label}: {f} outside {RTOL}"
+    assert (np.abs(got["u"][m] - want["u"][m]) <= 1e-4).all() and (np.abs(got["v"][m] - want["v"][m]) <= 1e-4).all()
+    # a miss leaves the whole record untouched (doc/src/api/rtcIntersect1.md)
+    miss = ~w_hit & ~g_hit
+    if rays_in is not None and miss.any():
+        assert (got[miss].tobytes() == rays_in[miss].tobytes()), f"{label}: a missed ray was modified"
+    return dict(rays=n, hits=int(w_hit.sum()), ties=ties)
+
+
+def compare_occluded(got_tfar, want_tfar, rays_tfar_in, max_flip_frac=0.0, label=""):
+    """Occluded: tfar == -inf iff occluded, untouched otherwise (doc/src/api/rtcOccluded1.md)."""
+    g = np.isneginf(got_tfar)
+    w = np.isneginf(want_tfar)
+    flips = int((g != w).sum())
+    assert flips <= max_flip_frac * g.shape[0], f"{label}: {flips} occlusion results differ"
+    keep = ~g
+    assert (got_tfar[keep] == rays_tfar_in[keep]).all(), f"{label}: unoccluded ray was modified"
+    return dict(rays=g.shape[0], occluded=int(w.sum()), flips=flips)

@@ -1,0 +1,162 @@
+"""Pins the CPU restatement (oracle/restate.c) against the reference.
+
+1. committed golden vectors produced by the REAL reference (tests/golden/make_golden.py),
+2. the reference's own known-answer tests (TriangleHitTest verify.cpp:2462-2547, minimal.cpp),
+3. when oracle/_ref is present (this container, and the GPU box via gpurun): live, bit-level
+   comparison against the real reference on seeded scenes.
+"""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from embree_amd import workloads as W
+from embree_amd.rtypes import make_rayhits, rays_of, INVALID_ID
+from tests.helpers import compare_closest, compare_occluded
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def restate():
+    from oracle import restate as R
+    if not R.available():
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
+    return R
+
+
+def _oracle_trace(R, meshes, rays, masks=None):
+    s = R.OracleScene()
+    for i, (v, t) in enumerate(meshes):
+        s.add_mesh(v, t, 1 if masks is None else masks[i])
+    s.commit()
+    rh = rays.copy()
+    s.intersect1(rh)
+    r = rays_of(rays)
+    s.occluded1(r)
+    return s, rh, r["tfar"].copy()
+
+
+def _bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+@pytest.mark.parametrize("name,meshes", [("ref_cube_1k.npz", W.cube_and_plane), ("ref_cornell_4k.npz", W.cornell_box)])
+def test_oracle_matches_golden_bit_exact(restate, golden_dir, name, meshes):
+    g = np.load(os.path.join(golden_dir, name))
+    s, rh, occ = _oracle_trace(restate, meshes(), g["rays"])
+    want = g["hits"]
+    # same tree-building algorithm + same arithmetic => identical bits, including tie resolution
+    for f in ("tfar", "u", "v", "Ng_x", "Ng_y", "Ng_z", "primID", "geomID", "instID"):
+        assert (_bits(rh[f]) == _bits(want[f])).all(), f
+    assert (_bits(occ) == _bits(g["occluded_tfar"])).all()
+    lo, hi = s.bounds()
+    assert (lo == g["bounds_lo"]).all() and (hi == g["bounds_hi"]).all()
+
+
+def test_oracle_soup_masks(restate, golden_dir):
+    g = np.load(os.path.join(golden_dir, "ref_soup_8k.npz"))
+    meshes = [(g["v0"], g["t0"]), (g["v1"], g["t1"])]
+    s, rh, occ = _oracle_trace(restate, meshes, g["rays"], masks=[1, 2])
+    want = g["hits"]
+    for f in ("tfar", "u", "v", "Ng_x", "primID", "geomID"):
+        assert (_bits(rh[f]) == _bits(want[f])).all(), f
+    assert (_bits(occ) == _bits(g["occluded_tfar"])).all()
+    # RayMasksTest semantics (verify.cpp:2626): a ray with mask m only sees geometries with (mask & m) != 0
+    hit = want["geomID"] != INVALID_ID
+    geom_mask = np.where(want["geomID"][hit] == 0, 1, 2)
+    assert ((geom_mask & g["rays"]["mask"][hit]) != 0).all()
+
+
+def test_triangle_hit_known_answer(restate, golden_dir):
+    """TriangleHitTest: geomID 0, primID 0, |u-u0|,|v-v0|,|t-1| <= 16 ulp, Ng == (0,0,1) +- 16 ulp."""
+    g = np.load(os.path.join(golden_dir, "ref_trianglehit.npz"))
+    tv = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32)
+    s, rh, _ = _oracle_trace(restate, [(tv, np.array([[0, 1, 2]], np.uint32))], g["rays"])
+    ulp = np.finfo(np.float32).eps
+    assert (rh["geomID"] == 0).all() and (rh["primID"] == 0).all()
+    assert (np.abs(rh["u"] - g["u0"]) <= 16 * ulp).all()
+    assert (np.abs(rh["v"] - g["v0"]) <= 16 * ulp).all()
+    assert (np.abs(rh["tfar"] - 1.0) <= 16 * ulp).all()
+    assert (np.abs(rh["Ng_x"]) <= 16 * ulp).all() and (np.abs(rh["Ng_y"]) <= 16 * ulp).all()
+    assert (np.abs(rh["Ng_z"] - 1.0) <= 16 * ulp).all()
+    assert (_bits(rh["tfar"]) == _bits(g["hits"]["tfar"])).all()
+
+
+def test_minimal_known_answer(restate):
+    """tutorials/minimal/minimal.cpp: triangle (0,0,0),(1,0,0),(0,1,0); ray (0.33,0.33,-1)->(0,0,1) hits
+    geom 0 prim 0 at tfar 1; ray from (1.00,1.00,-1) misses."""
+    tv = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32)
+    rays = make_rayhits([[0.33, 0.33, -1], [1.0, 1.0, -1]], [[0, 0, 1], [0, 0, 1]])
+    s, rh, occ = _oracle_trace(restate, [(tv, np.array([[0, 1, 2]], np.uint32))], rays)
+    assert rh["geomID"][0] == 0 and rh["primID"][0] == 0 and abs(rh["tfar"][0] - 1.0) <= 2e-7   # prints as 1.000000
+    assert rh["geomID"][1] == INVALID_ID and np.isinf(rh["tfar"][1])
+    assert np.isneginf(occ[0]) and np.isinf(occ[1]) and occ[1] > 0
+
+
+def test_edge_cases(restate):
+    """EmptySceneTest (verify.cpp:1054), invalid primitives skipped (scene_triangle_mesh.h:195-215),
+    tfar < 0 early-out for occluded (bvh_intersector1.cpp:128), tnear/tfar interval."""
+    R = restate
+    s = R.OracleScene()
+    s.commit()
+    rh = make_rayhits([[0, 0, -1]], [[0, 0, 1]])
+    before = rh.copy()
+    s.intersect1(rh)
+    assert rh.tobytes() == before.tobytes()
+    # out-of-range index, NaN vertex and huge vertex are skipped; the valid one is found
+    v = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [np.nan, 0, 0], [3e18, 0, 0]], np.float32)
+    t = np.array([[0, 1, 7], [0, 1, 3], [0, 1, 4], [0, 1, 2]], np.uint32)
+    s2 = R.OracleScene()
+    s2.add_mesh(v, t)
+    s2.commit()
+    assert s2.counts()["prims"] == 1
+    rh = make_rayhits([[0.2, 0.2, -1]] * 4, [[0, 0, 1]] * 4)
+    rh["tnear"] = [0, 1.5, 0, 0]
+    rh["tfar"] = [np.inf, np.inf, 0.5, 1.0]
+    s2.intersect1(rh)
+    assert list(rh["primID"]) == [3, INVALID_ID, INVALID_ID, 3]      # tfar is inclusive, tnear strict
+    r = rays_of(make_rayhits([[0.2, 0.2, -1]] * 2, [[0, 0, 1]] * 2))
+    r["tfar"] = [-1.0, 5.0]
+    s2.occluded1(r)
+    assert r["tfar"][0] == -1.0 and np.isneginf(r["tfar"][1])
+
+
+def _have_ref():
+    from oracle import refembree
+    return refembree.available()
+
+
+@pytest.mark.skipif(not _have_ref(), reason="oracle/_ref not built (make -f oracle/ref.mk)")
+def test_oracle_vs_live_reference_sphere(restate):
+    """Live check against the real reference on the workload generator scenes (small crown)."""
+    from oracle import refembree
+    meshes = W.synthetic_crown(num_phi=12)
+    prim = W.crown_camera_rays(meshes, 96, 96)
+    R = refembree.RefScene("threads=2")
+    O = restate.OracleScene()
+    for v, t in meshes:
+        R.add_mesh(v, t)
+        O.add_mesh(v, t)
+    R.commit()
+    O.commit()
+    a, b = prim.copy(), prim.copy()
+    R.intersect1(a, threads=2)
+    O.intersect1(b)
+    st = compare_closest(b, a, prim, O.triangle_t, label="primary")
+    bounce = W.diffuse_bounce_rays(a, meshes)
+    a2, b2 = bounce.copy(), bounce.copy()
+    R.intersect1(a2, threads=2)
+    O.intersect1(b2)
+    st2 = compare_closest(b2, a2, bounce, O.triangle_t, label="bounce")
+    assert st["hits"] > 0.9 * st["rays"] and st2["hits"] > 0.9 * st2["rays"]
+    sh = W.shadow_rays(a2[:512], meshes, samples=4)
+    ra, rb = sh.copy(), sh.copy()
+    R.occluded1(ra)
+    O.occluded1(rb)
+    compare_occluded(rb["tfar"], ra["tfar"], sh["tfar"], label="shadow")
+    # packet entry points of the reference agree with its single-ray path up to exact ties (Appendix A.5)
+    a8 = prim.copy()
+    R.intersect8(a8)
+    compare_closest(a8, a, prim, O.triangle_t, label="packet8")
