@@ -1,0 +1,356 @@
+"""Thin ctypes binding of libembree4_mi355.so -- the same C ABI an Embree application links.
+
+The Python layer only forwards to the C entry points of include/embree4/rtcore.h (names,
+argument meaning and error behaviour are the reference's) and of include/embree_amd_hip.h.
+There is no Python/CPU implementation of any part of the path: if the HIP library cannot be
+loaded or no GPU is present, calls fail loudly.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .rtypes import RAY_DTYPE, RAYHIT_DTYPE
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libembree4_mi355.so")
+
+RTC_ERROR_NONE, RTC_ERROR_UNKNOWN, RTC_ERROR_INVALID_ARGUMENT, RTC_ERROR_INVALID_OPERATION = 0, 1, 2, 3
+RTC_ERROR_OUT_OF_MEMORY, RTC_ERROR_UNSUPPORTED_CPU, RTC_ERROR_CANCELLED = 4, 5, 6
+RTC_GEOMETRY_TYPE_TRIANGLE, RTC_GEOMETRY_TYPE_QUAD = 0, 1
+RTC_BUFFER_TYPE_INDEX, RTC_BUFFER_TYPE_VERTEX, RTC_BUFFER_TYPE_VERTEX_ATTRIBUTE = 0, 1, 2
+RTC_FORMAT_UINT3, RTC_FORMAT_FLOAT3 = 0x5003, 0x9003
+RTC_SCENE_FLAG_ROBUST = 4
+
+# every symbol include/embree4/rtcore.h and include/embree_amd_hip.h declare (checked by tests/test_abi.py)
+RTC_SYMBOLS = """rtcNewDevice rtcRetainDevice rtcReleaseDevice rtcGetDeviceProperty rtcSetDeviceProperty rtcGetErrorString
+rtcGetDeviceError rtcGetDeviceLastErrorMessage rtcSetDeviceErrorFunction rtcSetDeviceMemoryMonitorFunction
+rtcNewBuffer rtcNewSharedBuffer rtcGetBufferData rtcRetainBuffer rtcReleaseBuffer
+rtcNewGeometry rtcRetainGeometry rtcReleaseGeometry rtcCommitGeometry rtcEnableGeometry rtcDisableGeometry
+rtcSetGeometryTimeStepCount rtcSetGeometryVertexAttributeCount rtcSetGeometryMask rtcSetGeometryBuildQuality
+rtcSetGeometryBuffer rtcSetSharedGeometryBuffer rtcSetSharedGeometryBufferHostDevice rtcSetNewGeometryBuffer
+rtcGetGeometryBufferData rtcUpdateGeometryBuffer rtcSetGeometryUserData rtcGetGeometryUserData
+rtcSetGeometryIntersectFilterFunction rtcSetGeometryOccludedFilterFunction
+rtcNewScene rtcGetSceneDevice rtcRetainScene rtcReleaseScene rtcGetSceneTraversable rtcAttachGeometry
+rtcAttachGeometryByID rtcDetachGeometry rtcGetGeometry rtcGetGeometryThreadSafe rtcCommitScene rtcJoinCommitScene
+rtcSetSceneProgressMonitorFunction rtcSetSceneBuildQuality rtcSetSceneFlags rtcGetSceneFlags rtcGetSceneBounds
+rtcIntersect1 rtcIntersect4 rtcIntersect8 rtcIntersect16 rtcOccluded1 rtcOccluded4 rtcOccluded8 rtcOccluded16
+rtcTraversableIntersect1 rtcTraversableIntersect4 rtcTraversableIntersect8 rtcTraversableIntersect16
+rtcTraversableOccluded1 rtcTraversableOccluded4 rtcTraversableOccluded8 rtcTraversableOccluded16
+rtcIntersect1M rtcOccluded1M rtcIntersect1MDevice rtcOccluded1MDevice""".split()
+MI355_SYMBOLS = """mi355_default_build_params mi355_last_error mi355_device_count mi355_device_name mi355_bvh_build
+mi355_bvh_destroy mi355_bvh_get_info mi355_bvh_download mi355_trace_closest mi355_trace_any
+mi355_trace_closest_packet mi355_trace_any_packet mi355_trace_stats mi355_malloc mi355_free mi355_memcpy_h2d
+mi355_memcpy_d2h mi355_synchronize""".split()
+
+
+class BuildParams(C.Structure):
+    _fields_ = [("sah_block_shift", C.c_uint32), ("min_leaf", C.c_uint32), ("max_leaf", C.c_uint32),
+                ("small_threshold", C.c_uint32), ("trav_cost", C.c_float), ("int_cost", C.c_float),
+                ("reserved", C.c_uint32 * 2)]
+
+
+class BvhInfo(C.Structure):
+    _fields_ = [("num_triangles", C.c_uint64), ("num_nodes", C.c_uint64), ("num_leaves", C.c_uint64),
+                ("num_binary_nodes", C.c_uint64), ("bytes_nodes", C.c_uint64), ("bytes_triangles", C.c_uint64),
+                ("bounds_lower", C.c_float * 3), ("bounds_upper", C.c_float * 3), ("sah", C.c_float),
+                ("build_ms", C.c_float), ("root_ref", C.c_uint32), ("top_levels", C.c_uint32),
+                ("max_leaf", C.c_uint32), ("depth", C.c_uint32)]
+
+    def as_dict(self):
+        d = {k: getattr(self, k) for k, _ in self._fields_ if not k.startswith("bounds")}
+        d["bounds_lower"] = list(self.bounds_lower)
+        d["bounds_upper"] = list(self.bounds_upper)
+        return d
+
+
+class RTCBounds(C.Structure):
+    _fields_ = [("lower_x", C.c_float), ("lower_y", C.c_float), ("lower_z", C.c_float), ("align0", C.c_float),
+                ("upper_x", C.c_float), ("upper_y", C.c_float), ("upper_z", C.c_float), ("align1", C.c_float)]
+
+
+NODE_DTYPE = np.dtype([("org", "<f4", (3,)), ("exp", "u1", (3,)), ("count", "u1"), ("child", "<u4", (8, 3)),
+                       ("pad", "<u4", (4,))])
+TRI_DTYPE = np.dtype([("v0", "<f4", (3,)), ("e1", "<f4", (3,)), ("e2", "<f4", (3,)), ("primID", "<u4"),
+                      ("geomID", "<u4"), ("mask", "<u4")])
+assert NODE_DTYPE.itemsize == 128 and TRI_DTYPE.itemsize == 48
+
+_lib = None
+
+
+def load():
+    """Load the HIP library (building it first if the sources are newer). Raises if that is impossible."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        from . import build as _build
+        _build.build()
+    L = C.CDLL(LIB_PATH)
+    vp, u32, sz = C.c_void_p, C.c_uint32, C.c_size_t
+    L.rtcNewDevice.restype = vp
+    L.rtcNewDevice.argtypes = [C.c_char_p]
+    L.rtcReleaseDevice.argtypes = [vp]
+    L.rtcGetDeviceError.restype = C.c_int
+    L.rtcGetDeviceError.argtypes = [vp]
+    L.rtcGetDeviceLastErrorMessage.restype = C.c_char_p
+    L.rtcGetDeviceLastErrorMessage.argtypes = [vp]
+    L.rtcGetDeviceProperty.restype = C.c_ssize_t
+    L.rtcGetDeviceProperty.argtypes = [vp, C.c_int]
+    L.rtcGetErrorString.restype = C.c_char_p
+    L.rtcGetErrorString.argtypes = [C.c_int]
+    L.rtcNewGeometry.restype = vp
+    L.rtcNewGeometry.argtypes = [vp, C.c_int]
+    for f in ("rtcReleaseGeometry", "rtcCommitGeometry", "rtcEnableGeometry", "rtcDisableGeometry", "rtcRetainGeometry"):
+        getattr(L, f).argtypes = [vp]
+    L.rtcSetGeometryMask.argtypes = [vp, u32]
+    L.rtcSetGeometryVertexAttributeCount.argtypes = [vp, u32]
+    L.rtcSetSharedGeometryBuffer.argtypes = [vp, C.c_int, u32, C.c_int, vp, sz, sz, sz]
+    L.rtcSetSharedGeometryBufferHostDevice.argtypes = [vp, C.c_int, u32, C.c_int, vp, vp, sz, sz, sz]
+    L.rtcSetNewGeometryBuffer.restype = vp
+    L.rtcSetNewGeometryBuffer.argtypes = [vp, C.c_int, u32, C.c_int, sz, sz]
+    L.rtcGetGeometryBufferData.restype = vp
+    L.rtcGetGeometryBufferData.argtypes = [vp, C.c_int, u32]
+    L.rtcUpdateGeometryBuffer.argtypes = [vp, C.c_int, u32]
+    L.rtcSetGeometryIntersectFilterFunction.argtypes = [vp, vp]
+    L.rtcNewScene.restype = vp
+    L.rtcNewScene.argtypes = [vp]
+    for f in ("rtcReleaseScene", "rtcCommitScene", "rtcJoinCommitScene", "rtcRetainScene"):
+        getattr(L, f).argtypes = [vp]
+    L.rtcAttachGeometry.restype = u32
+    L.rtcAttachGeometry.argtypes = [vp, vp]
+    L.rtcAttachGeometryByID.argtypes = [vp, vp, u32]
+    L.rtcDetachGeometry.argtypes = [vp, u32]
+    L.rtcGetGeometry.restype = vp
+    L.rtcGetGeometry.argtypes = [vp, u32]
+    L.rtcSetSceneFlags.argtypes = [vp, C.c_int]
+    L.rtcGetSceneFlags.restype = C.c_int
+    L.rtcGetSceneFlags.argtypes = [vp]
+    L.rtcSetSceneBuildQuality.argtypes = [vp, C.c_int]
+    L.rtcGetSceneBounds.argtypes = [vp, C.POINTER(RTCBounds)]
+    L.rtcIntersect1.argtypes = [vp, vp, vp]
+    L.rtcOccluded1.argtypes = [vp, vp, vp]
+    for k in (4, 8, 16):
+        getattr(L, "rtcIntersect%d" % k).argtypes = [vp, vp, vp, vp]
+        getattr(L, "rtcOccluded%d" % k).argtypes = [vp, vp, vp, vp]
+    L.rtcIntersect1M.argtypes = [vp, vp, u32, sz, vp]
+    L.rtcOccluded1M.argtypes = [vp, vp, u32, sz, vp]
+    L.rtcIntersect1MDevice.argtypes = [vp, vp, u32, sz, vp, vp]
+    L.rtcOccluded1MDevice.argtypes = [vp, vp, u32, sz, vp, vp]
+    L.rtcGetSceneBVH_mi355.restype = vp
+    L.rtcGetSceneBVH_mi355.argtypes = [vp]
+    L.mi355_last_error.restype = C.c_char_p
+    L.mi355_device_count.restype = C.c_int
+    L.mi355_device_name.argtypes = [C.c_int, C.c_char_p, sz]
+    L.mi355_bvh_get_info.argtypes = [vp, C.POINTER(BvhInfo)]
+    L.mi355_bvh_download.argtypes = [vp, vp, sz, vp, sz]
+    L.mi355_trace_closest.argtypes = [vp, vp, u32, sz, vp]
+    L.mi355_trace_any.argtypes = [vp, vp, u32, sz, vp]
+    L.mi355_trace_stats.argtypes = [vp, vp, u32, sz, C.c_int, C.POINTER(C.c_uint64)]
+    L.mi355_malloc.argtypes = [C.c_int, sz, C.POINTER(vp)]
+    L.mi355_free.argtypes = [vp]
+    L.mi355_memcpy_h2d.argtypes = [vp, vp, sz]
+    L.mi355_memcpy_d2h.argtypes = [vp, vp, sz]
+    L.mi355_synchronize.argtypes = [vp]
+    L.mi355_default_build_params.argtypes = [C.POINTER(BuildParams)]
+    _lib = L
+    return L
+
+
+class RTCErrorException(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("RTCError %d: %s" % (code, msg))
+        self.code = code
+
+
+class Device:
+    """rtcNewDevice(config).  `check()` raises the pending per-thread error, like polling rtcGetDeviceError."""
+
+    def __init__(self, config=""):
+        self.L = load()
+        self.h = self.L.rtcNewDevice(config.encode())
+        if not self.h:
+            code = self.L.rtcGetDeviceError(None)
+            raise RTCErrorException(code, (self.L.rtcGetDeviceLastErrorMessage(None) or b"").decode())
+
+    def get_error(self):
+        return self.L.rtcGetDeviceError(self.h)
+
+    def last_message(self):
+        return (self.L.rtcGetDeviceLastErrorMessage(self.h) or b"").decode()
+
+    def check(self):
+        e = self.get_error()
+        if e != RTC_ERROR_NONE:
+            raise RTCErrorException(e, self.last_message())
+
+    def name(self):
+        buf = C.create_string_buffer(256)
+        self.L.mi355_device_name(0, buf, 256)
+        return buf.value.decode()
+
+    def release(self):
+        if self.h:
+            self.L.rtcReleaseDevice(self.h)
+            self.h = None
+
+
+class DeviceArray:
+    """Raw HIP device allocation (mi355_malloc) with numpy upload/download."""
+
+    def __init__(self, nbytes, gpu=0):
+        self.L = load()
+        p = C.c_void_p()
+        if self.L.mi355_malloc(gpu, nbytes, C.byref(p)) != 0:
+            raise RuntimeError("mi355_malloc: " + self.L.mi355_last_error().decode())
+        self.ptr, self.nbytes = p.value, nbytes
+
+    @classmethod
+    def from_numpy(cls, a, gpu=0):
+        a = np.ascontiguousarray(a)
+        d = cls(a.nbytes, gpu)
+        d.upload(a)
+        return d
+
+    def upload(self, a):
+        a = np.ascontiguousarray(a)
+        assert a.nbytes <= self.nbytes
+        if self.L.mi355_memcpy_h2d(self.ptr, a.ctypes.data, a.nbytes) != 0:
+            raise RuntimeError("mi355_memcpy_h2d: " + self.L.mi355_last_error().decode())
+
+    def download(self, dtype, count=None):
+        dt = np.dtype(dtype)
+        n = self.nbytes // dt.itemsize if count is None else count
+        out = np.empty(n, dt)
+        if self.L.mi355_memcpy_d2h(out.ctypes.data, self.ptr, out.nbytes) != 0:
+            raise RuntimeError("mi355_memcpy_d2h: " + self.L.mi355_last_error().decode())
+        return out
+
+    def free(self):
+        if self.ptr:
+            self.L.mi355_free(self.ptr)
+            self.ptr = None
+
+
+class Scene:
+    """rtcNewScene + helpers that follow the tutorials' idiom (attach, release, commit)."""
+
+    def __init__(self, device, flags=0):
+        self.dev, self.L = device, device.L
+        self.h = self.L.rtcNewScene(device.h)
+        device.check()
+        if flags:
+            self.L.rtcSetSceneFlags(self.h, flags)
+        self._keep = []
+
+    def add_triangle_mesh(self, verts, tris, mask=None, shared=True, device_resident=False):
+        """rtcNewGeometry(TRIANGLE) + vertex/index buffers + commit + attach + release -> geomID."""
+        L = self.L
+        v = np.ascontiguousarray(verts, np.float32).reshape(-1, 3)
+        t = np.ascontiguousarray(tris, np.uint32).reshape(-1, 3)
+        g = L.rtcNewGeometry(self.dev.h, RTC_GEOMETRY_TYPE_TRIANGLE)
+        self.dev.check()
+        if device_resident:
+            dv, dt = DeviceArray.from_numpy(np.concatenate([v.ravel(), np.zeros(4, np.float32)])), DeviceArray.from_numpy(t)
+            self._keep += [dv, dt]
+            L.rtcSetSharedGeometryBufferHostDevice(g, RTC_BUFFER_TYPE_VERTEX, 0, RTC_FORMAT_FLOAT3, None, dv.ptr, 0, 12, v.shape[0])
+            L.rtcSetSharedGeometryBufferHostDevice(g, RTC_BUFFER_TYPE_INDEX, 0, RTC_FORMAT_UINT3, None, dt.ptr, 0, 12, t.shape[0])
+        elif shared:
+            vp = np.concatenate([v.ravel(), np.zeros(4, np.float32)])      # 16-byte readable padding (README: shared buffers)
+            self._keep += [vp, t]
+            L.rtcSetSharedGeometryBuffer(g, RTC_BUFFER_TYPE_VERTEX, 0, RTC_FORMAT_FLOAT3, vp.ctypes.data, 0, 12, v.shape[0])
+            L.rtcSetSharedGeometryBuffer(g, RTC_BUFFER_TYPE_INDEX, 0, RTC_FORMAT_UINT3, t.ctypes.data, 0, 12, t.shape[0])
+        else:
+            pv = L.rtcSetNewGeometryBuffer(g, RTC_BUFFER_TYPE_VERTEX, 0, RTC_FORMAT_FLOAT3, 12, v.shape[0])
+            pt = L.rtcSetNewGeometryBuffer(g, RTC_BUFFER_TYPE_INDEX, 0, RTC_FORMAT_UINT3, 12, t.shape[0])
+            self.dev.check()
+            if v.size:
+                C.memmove(pv, v.ctypes.data, v.nbytes)
+            if t.size:
+                C.memmove(pt, t.ctypes.data, t.nbytes)
+        if mask is not None:
+            L.rtcSetGeometryMask(g, mask)
+        L.rtcCommitGeometry(g)
+        gid = L.rtcAttachGeometry(self.h, g)
+        L.rtcReleaseGeometry(g)
+        self.dev.check()
+        return gid
+
+    def commit(self):
+        self.L.rtcCommitScene(self.h)
+        self.dev.check()
+
+    def bounds(self):
+        b = RTCBounds()
+        self.L.rtcGetSceneBounds(self.h, C.byref(b))
+        self.dev.check()
+        return (np.array([b.lower_x, b.lower_y, b.lower_z], np.float32), np.array([b.upper_x, b.upper_y, b.upper_z], np.float32))
+
+    def bvh(self):
+        return self.L.rtcGetSceneBVH_mi355(self.h)
+
+    def info(self):
+        i = BvhInfo()
+        self.L.mi355_bvh_get_info(self.bvh(), C.byref(i))
+        return i.as_dict()
+
+    def download_bvh(self):
+        i = self.info()
+        nodes = np.zeros(i["num_nodes"], NODE_DTYPE)
+        tris = np.zeros(i["num_triangles"], TRI_DTYPE)
+        rc = self.L.mi355_bvh_download(self.bvh(), nodes.ctypes.data, nodes.nbytes, tris.ctypes.data, tris.nbytes)
+        if rc:
+            raise RuntimeError(self.L.mi355_last_error().decode())
+        return nodes, tris
+
+    # -- queries on host arrays (numpy, modified in place) --
+    def intersect1(self, rayhit_record):
+        self.L.rtcIntersect1(self.h, rayhit_record.ctypes.data, None)
+        self.dev.check()
+
+    def occluded1(self, ray_record):
+        self.L.rtcOccluded1(self.h, ray_record.ctypes.data, None)
+        self.dev.check()
+
+    def intersect1M(self, rayhits):
+        assert rayhits.dtype == RAYHIT_DTYPE and rayhits.flags["C_CONTIGUOUS"]
+        self.L.rtcIntersect1M(self.h, rayhits.ctypes.data, rayhits.shape[0], 96, None)
+        self.dev.check()
+
+    def occluded1M(self, rays):
+        assert rays.dtype == RAY_DTYPE and rays.flags["C_CONTIGUOUS"]
+        self.L.rtcOccluded1M(self.h, rays.ctypes.data, rays.shape[0], 48, None)
+        self.dev.check()
+
+    # -- queries on device memory --
+    def intersect1M_device(self, dptr, count, stride=96, stream=None):
+        self.L.rtcIntersect1MDevice(self.h, dptr, count, stride, None, stream)
+        self.dev.check()
+
+    def occluded1M_device(self, dptr, count, stride=48, stream=None):
+        self.L.rtcOccluded1MDevice(self.h, dptr, count, stride, None, stream)
+        self.dev.check()
+
+    def trace_stats(self, dptr, count, stride, any_hit=False):
+        out = (C.c_uint64 * 8)()
+        rc = self.L.mi355_trace_stats(self.bvh(), dptr, count, stride, int(any_hit), out)
+        if rc:
+            raise RuntimeError(self.L.mi355_last_error().decode())
+        return dict(nodes=out[0], leaves=out[1], tris=out[2], rays=out[3], spills=out[4], max_depth=out[5])
+
+    def release(self):
+        if self.h:
+            self.L.rtcReleaseScene(self.h)
+            self.h = None
+            for k in self._keep:
+                if isinstance(k, DeviceArray):
+                    k.free()
+            self._keep = []
+
+
+def make_scene(device, meshes, masks=None, **kw):
+    s = Scene(device)
+    for i, (v, t) in enumerate(meshes):
+        s.add_triangle_mesh(v, t, None if masks is None else masks[i], **kw)
+    s.commit()
+    return s

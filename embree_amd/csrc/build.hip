@@ -1,0 +1,801 @@
+// build.hip -- GPU construction of the 8-wide quantised BVH (scene commit) for gfx950.
+//
+// Replaces BVHNBuilderSAH<8,Triangle4>::build (kernels/bvh/bvh_builder_sah.cpp:112-193) and what it
+// calls: createPrimRefArray (kernels/builders/primrefgen.cpp:35-57, TriangleMesh::buildBounds
+// kernels/common/scene_triangle_mesh.h:195-215), the binned-SAH heuristic (kernels/builders/
+// heuristic_binning.h:16-111 BinMapping, :210-257 bin, :339-386 best; heuristic_binning_array_aligned.h
+// :141-176 split, :50-65 fallback), BuilderT::recurse (kernels/builders/bvh_builder_sah.h:214-308)
+// and CreateLeaf / TriangleM::fill (bvh_builder_sah.cpp:32-55, kernels/geometry/triangle.h:98-120).
+//
+// The reference recurses depth-first on host threads.  Here the same decisions are taken by five
+// data-parallel stages, all on the GPU:
+//   K1 primref_gen    1 thread / triangle: validity test, AABB, compaction, scene + centroid bounds
+//   K2 top phase      level-synchronous binary binned-SAH splits of every segment > small_threshold:
+//                     setup (bin mapping, chunk table) -> bin (LDS-staged histograms of 2048-triangle
+//                     chunks, merged with ordered-uint atomics) -> split (one wavefront per segment
+//                     evaluates all 3x31 candidates) -> partition (block-aggregated scatter into the
+//                     ping-pong buffer + child centroid bounds) -> emit (children -> next level / small list)
+//   K3 small phase    one wavefront finishes each sub-tree of <= small_threshold triangles on its own:
+//                     bins in LDS, explicit stack (larger child pushed), splits down to min_leaf
+//   K4 wide collapse  top-down, one thread per 8-wide node: the reference's greedy "split the child
+//                     with the largest half-area until 8 children" + leaf-vs-split SAH test evaluated
+//                     on the binary tree, children sorted by size, bounds quantised to 8 bits
+//   K5 tri_records    leaf-ordered TriRec array (v0, e1, e2, ids, mask)
+// Bin bounds/counts are combined with integer min/max/add, so the tree TOPOLOGY does not depend on
+// thread timing; leaves are sorted by (primID, geomID) like heuristic.deterministic_order
+// (heuristic_binning_array_aligned.h:178-182).  The tree need not equal the reference's tree:
+// t/u/v/Ng/IDs of a closest hit do not depend on tree shape.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <vector>
+#include "bvh_common.h"
+#include "internal.h"
+
+namespace {
+
+constexpr uint32_t NIL = 0xFFFFFFFFu;
+constexpr int NBINS = 32;                       // NUM_OBJECT_BINS, kernels/builders/bvh_builder_sah.h:10
+constexpr int BINW = 7;                         // lo.xyz, hi.xyz (ordered uint), count
+constexpr int BINS_WORDS = 3 * NBINS * BINW;    // 672 words = 2688 B per segment
+constexpr uint32_t CHUNK = 2048;                // triangles per top-phase workgroup
+constexpr uint32_t ENC_POS_INF = 0xFF800000u;   // enc(+inf)
+constexpr uint32_t ENC_NEG_INF = 0x007FFFFFu;   // enc(-inf)
+
+struct PrimRef { float lo[3]; uint32_t geom; float hi[3]; uint32_t prim; };   // kernels/builders/primref.h:11-107 (geom = table index)
+struct GeomDesc { const char* verts; const char* idx; uint32_t vstride, istride, nv, nt, geomID, mask, primOffset, pad; };
+struct BNode { float lo[3]; uint32_t begin; float hi[3]; uint32_t end; uint32_t left, right; float splitSah; uint32_t pad; };
+struct Seg {
+  uint32_t begin, end, bnode, flags;            // flags bit0: fallback (median) split
+  float cmin[3]; uint32_t dim;
+  float cmax[3]; uint32_t pos;
+  float ofs[3]; uint32_t nb;
+  float scale[3]; uint32_t nL;
+  uint32_t childL, childR, curL, curR;
+  uint32_t acc[2][12];                          // per side: centroid lo/hi (6) + geometry lo/hi (6), ordered uint
+};
+struct SmallEntry { uint32_t begin, end, bnode, buf; float cmin[3], cmax[3]; };
+struct Chunk { uint32_t seg, begin, end; };
+struct WideItem { uint32_t bnode, node; };
+struct Counters {
+  uint32_t numPrims, numBNodes, numSegsNext, numChunks, numSmall, numWide, numWideNext, numLeaves;
+  uint32_t bounds[12];                          // scene geom lo/hi + centroid lo/hi (ordered uint)
+  uint32_t overflow, rootRef, pad0, pad1;
+  float sahSum;
+};
+struct Params { uint32_t shift, minLeaf, maxLeaf, small; float travCost, intCost; };
+
+// order-preserving float <-> uint so that integer atomicMin/Max reduce floats exactly
+__device__ __forceinline__ uint32_t enc(float f) { uint32_t u = __float_as_uint(f); return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u); }
+__device__ __forceinline__ float dec(uint32_t u) { return __uint_as_float(u ^ ((u >> 31) ? 0x80000000u : 0xFFFFFFFFu)); }
+__device__ __forceinline__ float half_area3(float dx, float dy, float dz) { return fmaf(dx, dy + dz, dy * dz); }  // common/math/vec3fa.h:349
+__device__ __forceinline__ bool valid_f(float x) { return x > -1.844E18f && x < 1.844E18f; }  // isvalid, FLT_LARGE constants.h:21
+
+__device__ __forceinline__ PrimRef load_prim(const PrimRef* p) {
+  const float4 a = ((const float4*)p)[0], b = ((const float4*)p)[1];
+  PrimRef r; r.lo[0] = a.x; r.lo[1] = a.y; r.lo[2] = a.z; r.geom = __float_as_uint(a.w);
+  r.hi[0] = b.x; r.hi[1] = b.y; r.hi[2] = b.z; r.prim = __float_as_uint(b.w); return r;
+}
+__device__ __forceinline__ void store_prim(PrimRef* p, const PrimRef& r) {
+  ((float4*)p)[0] = make_float4(r.lo[0], r.lo[1], r.lo[2], __uint_as_float(r.geom));
+  ((float4*)p)[1] = make_float4(r.hi[0], r.hi[1], r.hi[2], __uint_as_float(r.prim));
+}
+
+// ---------------------------------------------------------------------------------- K1 primref_gen
+__global__ __launch_bounds__(256) void primref_gen(const GeomDesc* geoms, uint32_t numGeoms, uint32_t totalPrims,
+                                                   PrimRef* out, Counters* ctr) {
+  __shared__ uint32_t s_acc[12];
+  __shared__ uint32_t s_wcnt[4], s_base;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  if (tid < 12) s_acc[tid] = (tid % 6 < 3) ? ENC_POS_INF : ENC_NEG_INF;
+  __syncthreads();
+  const uint32_t p = blockIdx.x * 256u + tid;
+  bool ok = false; PrimRef r{};
+  if (p < totalPrims) {
+    uint32_t lo = 0, hi = numGeoms - 1;                       // last geometry with primOffset <= p
+    while (lo < hi) { uint32_t mid = (lo + hi + 1) >> 1; if (geoms[mid].primOffset <= p) lo = mid; else hi = mid - 1; }
+    const GeomDesc g = geoms[lo];
+    const uint32_t j = p - g.primOffset;
+    const uint32_t* tri = (const uint32_t*)(g.idx + (size_t)j * g.istride);
+    const uint32_t i0 = tri[0], i1 = tri[1], i2 = tri[2];
+    if (i0 < g.nv && i1 < g.nv && i2 < g.nv) {
+      const float* a = (const float*)(g.verts + (size_t)i0 * g.vstride);
+      const float* b = (const float*)(g.verts + (size_t)i1 * g.vstride);
+      const float* c = (const float*)(g.verts + (size_t)i2 * g.vstride);
+      ok = true;
+      for (int d = 0; d < 3; d++) {
+        const float x = a[d], y = b[d], z = c[d];
+        ok = ok && valid_f(x) && valid_f(y) && valid_f(z);
+        r.lo[d] = fminf(fminf(x, y), z); r.hi[d] = fmaxf(fmaxf(x, y), z);
+      }
+      r.geom = lo; r.prim = j;
+    }
+  }
+  const unsigned long long m = __ballot(ok);
+  if (lane == 0) s_wcnt[wave] = (uint32_t)__popcll(m);
+  if (ok) {
+    for (int d = 0; d < 3; d++) {
+      atomicMin(&s_acc[d], enc(r.lo[d])); atomicMax(&s_acc[3 + d], enc(r.hi[d]));
+      const float c2 = r.lo[d] + r.hi[d];                      // centroid proxy = lower+upper, never halved (priminfo.h:46-52)
+      atomicMin(&s_acc[6 + d], enc(c2)); atomicMax(&s_acc[9 + d], enc(c2));
+    }
+  }
+  __syncthreads();
+  if (tid == 0) { const uint32_t n = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3]; s_base = n ? atomicAdd(&ctr->numPrims, n) : 0u; }
+  __syncthreads();
+  if (ok) {
+    uint32_t off = s_base; for (uint32_t w = 0; w < wave; w++) off += s_wcnt[w];
+    off += (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    store_prim(out + off, r);
+  }
+  if (tid < 12 && s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3] > 0) {
+    if (tid % 6 < 3) atomicMin(&ctr->bounds[tid], s_acc[tid]); else atomicMax(&ctr->bounds[tid], s_acc[tid]);
+  }
+}
+
+// -------------------------------------------------------------------------------- binning helpers
+struct Mapping { float ofs[3], scale[3]; uint32_t nb; };
+// BinMapping(pinfo): num = min(32, 4 + 0.05 n), scale = 0.99 num / diag (0 if diag <= 1e-34)  heuristic_binning.h:46-55
+__device__ __forceinline__ Mapping make_mapping(uint32_t n, const float* cmin, const float* cmax) {
+  Mapping m; const uint32_t num = (uint32_t)(4.0f + 0.05f * (float)n); m.nb = num < (uint32_t)NBINS ? num : (uint32_t)NBINS;
+  for (int d = 0; d < 3; d++) {
+    const float diag = fmaxf(1E-34f, cmax[d] - cmin[d]);
+    m.scale[d] = diag > 1E-34f ? (0.99f * (float)m.nb) / diag : 0.0f;
+    m.ofs[d] = cmin[d];
+  }
+  return m;
+}
+__device__ __forceinline__ int bin_unsafe(float c2, float ofs, float scale) { return (int)floorf((c2 - ofs) * scale); }
+__device__ __forceinline__ int bin_clamped(float c2, float ofs, float scale, uint32_t nb) {
+  int i = bin_unsafe(c2, ofs, scale); i = i < 0 ? 0 : i; return i > (int)nb - 1 ? (int)nb - 1 : i;
+}
+__device__ __forceinline__ void bins_clear(uint32_t* bins, uint32_t tid, uint32_t nthreads) {
+  for (uint32_t w = tid; w < (uint32_t)BINS_WORDS; w += nthreads) { const uint32_t k = w % BINW; bins[w] = k < 3 ? ENC_POS_INF : (k < 6 ? ENC_NEG_INF : 0u); }
+}
+__device__ __forceinline__ void bins_add(uint32_t* bins, const Mapping& m, const PrimRef& r) {   // BinInfoT::bin, heuristic_binning.h:210-257
+  for (int d = 0; d < 3; d++) {
+    const int b = bin_clamped(r.lo[d] + r.hi[d], m.ofs[d], m.scale[d], m.nb);
+    uint32_t* e = bins + (d * NBINS + b) * BINW;
+    atomicMin(&e[0], enc(r.lo[0])); atomicMin(&e[1], enc(r.lo[1])); atomicMin(&e[2], enc(r.lo[2]));
+    atomicMax(&e[3], enc(r.hi[0])); atomicMax(&e[4], enc(r.hi[1])); atomicMax(&e[5], enc(r.hi[2]));
+    atomicAdd(&e[6], 1u);
+  }
+}
+
+struct SplitResult { float sah; int dim, pos; uint32_t nL; float llo[3], lhi[3], rlo[3], rhi[3]; };
+
+// BinInfoT::best (heuristic_binning.h:339-386) evaluated candidate-parallel by ONE wavefront: lane c
+// handles (axis = c/32, pos = c%32); the reference's "first strict minimum per axis, then first better
+// axis" equals the lexicographic minimum of (sah, axis, pos).  Result lands in `res` (LDS).
+__device__ void sah_best_wave(const uint32_t* bins, const Mapping& m, uint32_t shift, SplitResult* res, uint32_t lane) {
+  float bestSah = __builtin_inff(); uint32_t bestC = NIL; uint32_t bestNL = 0;
+  float bl[3] = {0, 0, 0}, bh[3] = {0, 0, 0}, rl[3] = {0, 0, 0}, rh[3] = {0, 0, 0};
+  const uint32_t add = (1u << shift) - 1u;
+  for (uint32_t c = lane; c < 3u * NBINS; c += 64u) {
+    const uint32_t axis = c >> 5, pos = c & 31u;
+    if (pos == 0u || pos >= m.nb || m.scale[axis] == 0.0f) continue;   // mapping.invalid(dim) :375, pos != 0 :379
+    float llo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, lhi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+    float rlo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, rhi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+    uint32_t lN = 0, rN = 0;
+    for (uint32_t b = 0; b < m.nb; b++) {
+      const uint32_t* e = bins + (axis * NBINS + b) * BINW;
+      const uint32_t cnt = e[6];
+      if (cnt == 0u) continue;
+      if (b < pos) { lN += cnt; for (int d = 0; d < 3; d++) { llo[d] = fminf(llo[d], dec(e[d])); lhi[d] = fmaxf(lhi[d], dec(e[3 + d])); } }
+      else         { rN += cnt; for (int d = 0; d < 3; d++) { rlo[d] = fminf(rlo[d], dec(e[d])); rhi[d] = fmaxf(rhi[d], dec(e[3 + d])); } }
+    }
+    if (lN == 0u || rN == 0u) continue;                          // empty side: the reference's sah is NaN there and never selected
+    const float lA = half_area3(lhi[0] - llo[0], lhi[1] - llo[1], lhi[2] - llo[2]);
+    const float rA = half_area3(rhi[0] - rlo[0], rhi[1] - rlo[1], rhi[2] - rlo[2]);
+    const float sah = fmaf(lA, (float)((lN + add) >> shift), rA * (float)((rN + add) >> shift));   // :367
+    if (sah < bestSah) {                                         // c ascending per lane -> keeps the lower candidate on ties
+      bestSah = sah; bestC = c; bestNL = lN;
+      for (int d = 0; d < 3; d++) { bl[d] = llo[d]; bh[d] = lhi[d]; rl[d] = rlo[d]; rh[d] = rhi[d]; }
+    }
+  }
+  // wave argmin of (sah, c): sah >= 0 so its bit pattern is order preserving
+  unsigned long long key = (bestC == NIL) ? ~0ull : (((unsigned long long)__float_as_uint(bestSah) << 32) | bestC);
+  unsigned long long k = key;
+  for (int o = 32; o >= 1; o >>= 1) { const unsigned long long other = __shfl_xor(k, o, 64); k = other < k ? other : k; }
+  if (lane == 0) { res->sah = __builtin_inff(); res->dim = -1; res->pos = 0; res->nL = 0; }
+  if (k != ~0ull && key == k) {                                  // exactly one lane owns the minimum (c is unique)
+    res->sah = bestSah; res->dim = (int)(bestC >> 5); res->pos = (int)(bestC & 31u); res->nL = bestNL;
+    for (int d = 0; d < 3; d++) { res->llo[d] = bl[d]; res->lhi[d] = bh[d]; res->rlo[d] = rl[d]; res->rhi[d] = rh[d]; }
+  }
+}
+
+// ------------------------------------------------------------------------------------ K2 top phase
+__global__ __launch_bounds__(256) void top_setup(Seg* segs, uint32_t numSegs, uint32_t* bins, Chunk* chunks, Counters* ctr) {
+  __shared__ uint32_t s_base;
+  const uint32_t s = blockIdx.x, tid = threadIdx.x;
+  Seg* sg = segs + s;
+  const uint32_t begin = sg->begin, end = sg->end, n = end - begin;
+  bins_clear(bins + (size_t)s * BINS_WORDS, tid, 256u);
+  const uint32_t nch = (n + CHUNK - 1u) / CHUNK;
+  if (tid == 0) {
+    const Mapping m = make_mapping(n, sg->cmin, sg->cmax);
+    for (int d = 0; d < 3; d++) { sg->ofs[d] = m.ofs[d]; sg->scale[d] = m.scale[d]; }
+    sg->nb = m.nb;
+    s_base = atomicAdd(&ctr->numChunks, nch);
+  }
+  __syncthreads();
+  for (uint32_t c = tid; c < nch; c += 256u) {
+    Chunk ck; ck.seg = s; ck.begin = begin + c * CHUNK; ck.end = min(ck.begin + CHUNK, end);
+    chunks[s_base + c] = ck;
+  }
+}
+
+__global__ __launch_bounds__(256) void top_bin(const Seg* segs, const Chunk* chunks, const PrimRef* src, uint32_t* bins) {
+  __shared__ uint32_t s_bins[BINS_WORDS];
+  const uint32_t tid = threadIdx.x;
+  const Chunk ck = chunks[blockIdx.x];
+  const Seg* sg = segs + ck.seg;
+  Mapping m; for (int d = 0; d < 3; d++) { m.ofs[d] = sg->ofs[d]; m.scale[d] = sg->scale[d]; } m.nb = sg->nb;
+  bins_clear(s_bins, tid, 256u);
+  __syncthreads();
+  for (uint32_t i = ck.begin + tid; i < ck.end; i += 256u) bins_add(s_bins, m, load_prim(src + i));
+  __syncthreads();
+  uint32_t* g = bins + (size_t)ck.seg * BINS_WORDS;
+  for (uint32_t w = tid; w < (uint32_t)BINS_WORDS; w += 256u) {      // BinInfoT::merge :312-321
+    const uint32_t k = w % BINW, cnt = s_bins[w - k + 6];
+    if (cnt == 0u) continue;
+    if (k < 3) atomicMin(&g[w], s_bins[w]); else if (k < 6) atomicMax(&g[w], s_bins[w]); else atomicAdd(&g[w], s_bins[w]);
+  }
+}
+
+__global__ __launch_bounds__(64) void top_split(Seg* segs, const uint32_t* bins, BNode* bnodes, Counters* ctr, Params prm, uint32_t forceFallback) {
+  __shared__ SplitResult s_res;
+  const uint32_t s = blockIdx.x, lane = threadIdx.x;
+  Seg* sg = segs + s;
+  Mapping m; for (int d = 0; d < 3; d++) { m.ofs[d] = sg->ofs[d]; m.scale[d] = sg->scale[d]; } m.nb = sg->nb;
+  sah_best_wave(bins + (size_t)s * BINS_WORDS, m, prm.shift, &s_res, lane);
+  __syncthreads();
+  if (lane == 0) {
+    const uint32_t begin = sg->begin, end = sg->end, n = end - begin;
+    SplitResult r = s_res;
+    const bool fallback = (r.dim < 0) || forceFallback;        // split invalid -> median split (split_template :144-147)
+    const uint32_t nL = fallback ? ((begin + end) / 2u - begin) : r.nL;
+    const uint32_t base = atomicAdd(&ctr->numBNodes, 2u);
+    BNode* par = bnodes + sg->bnode;
+    par->left = base; par->right = base + 1u; par->splitSah = r.sah;
+    BNode L{}, R{};
+    L.begin = begin; L.end = begin + nL; R.begin = begin + nL; R.end = end;
+    L.left = L.right = R.left = R.right = NIL; L.splitSah = R.splitSah = __builtin_inff();
+    for (int d = 0; d < 3; d++) { L.lo[d] = r.llo[d]; L.hi[d] = r.lhi[d]; R.lo[d] = r.rlo[d]; R.hi[d] = r.rhi[d]; }
+    bnodes[base] = L; bnodes[base + 1u] = R;
+    sg->flags = fallback ? 1u : 0u; sg->dim = fallback ? 0u : (uint32_t)r.dim; sg->pos = (uint32_t)r.pos; sg->nL = nL;
+    sg->childL = base; sg->childR = base + 1u; sg->curL = begin; sg->curR = begin + nL;
+    for (int side = 0; side < 2; side++) for (int k = 0; k < 12; k++) sg->acc[side][k] = (k % 6 < 3) ? ENC_POS_INF : ENC_NEG_INF;
+    (void)n;
+  }
+}
+
+__global__ __launch_bounds__(256) void top_partition(Seg* segs, const Chunk* chunks, const PrimRef* src, PrimRef* dst) {
+  __shared__ uint32_t s_cnt[8][4][2], s_off[8][4][2], s_acc[2][12], s_baseL, s_baseR;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const Chunk ck = chunks[blockIdx.x];
+  Seg* sg = segs + ck.seg;
+  const bool fallback = (sg->flags & 1u) != 0u;
+  const uint32_t dim = sg->dim, pos = sg->pos, mid = sg->begin + sg->nL;
+  const float ofs = sg->ofs[dim], scale = sg->scale[dim];
+  if (tid < 24) s_acc[tid / 12][tid % 12] = (tid % 6 < 3) ? ENC_POS_INF : ENC_NEG_INF;
+  __syncthreads();
+  PrimRef pr[8]; uint32_t sideBits = 0, validBits = 0; unsigned long long lm[8], rm[8];
+#pragma unroll
+  for (int r = 0; r < 8; r++) {
+    const uint32_t i = ck.begin + (uint32_t)r * 256u + tid;
+    const bool v = i < ck.end;
+    if (v) pr[r] = load_prim(src + i);
+    bool left = false;
+    if (v) {
+      const float c2 = pr[r].lo[dim] + pr[r].hi[dim];
+      left = fallback ? (i < mid) : (bin_unsafe(c2, ofs, scale) < (int)pos);     // isLeft: bin_unsafe(center2) < pos (:161)
+      const int side = left ? 0 : 1;
+      for (int d = 0; d < 3; d++) {                                              // extend_center2 of the child (:168)
+        const float cc = pr[r].lo[d] + pr[r].hi[d];
+        atomicMin(&s_acc[side][d], enc(cc)); atomicMax(&s_acc[side][3 + d], enc(cc));
+      }
+      if (fallback) for (int d = 0; d < 3; d++) { atomicMin(&s_acc[side][6 + d], enc(pr[r].lo[d])); atomicMax(&s_acc[side][9 + d], enc(pr[r].hi[d])); }
+    }
+    lm[r] = __ballot(v && left); rm[r] = __ballot(v && !left);
+    if (lane == 0) { s_cnt[r][wave][0] = (uint32_t)__popcll(lm[r]); s_cnt[r][wave][1] = (uint32_t)__popcll(rm[r]); }
+    if (v) validBits |= 1u << r;
+    if (left) sideBits |= 1u << r;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    uint32_t l = 0, rr = 0;
+    for (int r = 0; r < 8; r++) for (int w = 0; w < 4; w++) { s_off[r][w][0] = l; s_off[r][w][1] = rr; l += s_cnt[r][w][0]; rr += s_cnt[r][w][1]; }
+    s_baseL = l ? atomicAdd(&sg->curL, l) : 0u; s_baseR = rr ? atomicAdd(&sg->curR, rr) : 0u;
+  }
+  __syncthreads();
+  const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int r = 0; r < 8; r++) {
+    if (!(validBits & (1u << r))) continue;
+    const bool left = (sideBits >> r) & 1u;
+    const uint32_t o = left ? s_baseL + s_off[r][wave][0] + (uint32_t)__popcll(lm[r] & lt)
+                            : s_baseR + s_off[r][wave][1] + (uint32_t)__popcll(rm[r] & lt);
+    store_prim(dst + o, pr[r]);
+  }
+  if (tid < 24) {
+    const uint32_t side = tid / 12, k = tid % 12, v = s_acc[side][k];
+    if (k % 6 < 3) { if (v != ENC_POS_INF) atomicMin(&sg->acc[side][k], v); } else { if (v != ENC_NEG_INF) atomicMax(&sg->acc[side][k], v); }
+  }
+}
+
+__global__ void top_emit(const Seg* segs, uint32_t numSegs, BNode* bnodes, Seg* next, SmallEntry* small, Counters* ctr,
+                         Params prm, uint32_t dstBuf, uint32_t maxNext, uint32_t maxSmall) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= numSegs) return;
+  const Seg* sg = segs + s;
+  for (int side = 0; side < 2; side++) {
+    const uint32_t b = side ? sg->begin + sg->nL : sg->begin, e = side ? sg->end : sg->begin + sg->nL;
+    const uint32_t child = side ? sg->childR : sg->childL;
+    float cmin[3], cmax[3];
+    for (int d = 0; d < 3; d++) { cmin[d] = dec(sg->acc[side][d]); cmax[d] = dec(sg->acc[side][3 + d]); }
+    if (sg->flags & 1u) for (int d = 0; d < 3; d++) { bnodes[child].lo[d] = dec(sg->acc[side][6 + d]); bnodes[child].hi[d] = dec(sg->acc[side][9 + d]); }
+    if (e - b <= prm.small) {
+      const uint32_t k = atomicAdd(&ctr->numSmall, 1u);
+      if (k >= maxSmall) { ctr->overflow = 1u; continue; }
+      SmallEntry se; se.begin = b; se.end = e; se.bnode = child; se.buf = dstBuf;
+      for (int d = 0; d < 3; d++) { se.cmin[d] = cmin[d]; se.cmax[d] = cmax[d]; }
+      small[k] = se;
+    } else {
+      const uint32_t k = atomicAdd(&ctr->numSegsNext, 1u);
+      if (k >= maxNext) { ctr->overflow = 1u; continue; }
+      Seg ns{}; ns.begin = b; ns.end = e; ns.bnode = child;
+      for (int d = 0; d < 3; d++) { ns.cmin[d] = cmin[d]; ns.cmax[d] = cmax[d]; }
+      next[k] = ns;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------- K3 small phase
+struct StackEntry { uint32_t begin, end, bnode, buf; float cmin[3], cmax[3]; };
+
+__global__ __launch_bounds__(64) void small_build(const SmallEntry* entries, PrimRef* bufA, PrimRef* bufB, BNode* bnodes,
+                                                  uint2* finalIds, Counters* ctr, Params prm) {
+  __shared__ uint32_t s_bins[BINS_WORDS];
+  __shared__ SplitResult s_res;
+  __shared__ uint32_t s_acc[2][12];
+  __shared__ StackEntry s_stack[24];
+  __shared__ uint32_t s_alloc;
+  const uint32_t lane = threadIdx.x;
+  const SmallEntry e0 = entries[blockIdx.x];
+  StackEntry cur; cur.begin = e0.begin; cur.end = e0.end; cur.bnode = e0.bnode; cur.buf = e0.buf;
+  for (int d = 0; d < 3; d++) { cur.cmin[d] = e0.cmin[d]; cur.cmax[d] = e0.cmax[d]; }
+  uint32_t sp = 0;
+  for (uint32_t iter = 0; iter < (1u << 20); iter++) {         // the cap is a safety net only: <= 2*small_threshold iterations are possible
+    const uint32_t n = cur.end - cur.begin;
+    PrimRef* src = cur.buf ? bufB : bufA;
+    PrimRef* dst = cur.buf ? bufA : bufB;
+    if (n <= prm.minLeaf) {
+      // binary leaf (the reference never splits sets of <= minLeafSize, bvh_builder_sah.h:253): fix the final order
+      for (uint32_t i = lane; i < n; i += 64u) { const PrimRef r = load_prim(src + cur.begin + i); finalIds[cur.begin + i] = make_uint2(r.geom, r.prim); }
+      if (sp == 0) break;
+      __syncthreads();
+      cur = s_stack[--sp];
+      __syncthreads();
+      continue;
+    }
+    const Mapping m = make_mapping(n, cur.cmin, cur.cmax);
+    bins_clear(s_bins, lane, 64u);
+    if (lane < 24) s_acc[lane / 12][lane % 12] = (lane % 6 < 3) ? ENC_POS_INF : ENC_NEG_INF;
+    __syncthreads();
+    for (uint32_t i = lane; i < n; i += 64u) bins_add(s_bins, m, load_prim(src + cur.begin + i));
+    __syncthreads();
+    sah_best_wave(s_bins, m, prm.shift, &s_res, lane);
+    __syncthreads();
+    const SplitResult r = s_res;
+    const bool fallback = r.dim < 0;
+    const uint32_t mid = fallback ? (cur.begin + cur.end) / 2u : cur.begin + r.nL;
+    const uint32_t dim = fallback ? 0u : (uint32_t)r.dim;
+    // partition into the other buffer (wave-synchronous compaction)
+    uint32_t curL = cur.begin, curR = mid;
+    for (uint32_t i0 = 0; i0 < n; i0 += 64u) {
+      const uint32_t i = cur.begin + i0 + lane;
+      const bool v = i < cur.end;
+      PrimRef p{}; bool left = false;
+      if (v) {
+        p = load_prim(src + i);
+        left = fallback ? (i < mid) : (bin_unsafe(p.lo[dim] + p.hi[dim], m.ofs[dim], m.scale[dim]) < r.pos);
+        const int side = left ? 0 : 1;
+        for (int d = 0; d < 3; d++) {
+          const float cc = p.lo[d] + p.hi[d];
+          atomicMin(&s_acc[side][d], enc(cc)); atomicMax(&s_acc[side][3 + d], enc(cc));
+          if (fallback) { atomicMin(&s_acc[side][6 + d], enc(p.lo[d])); atomicMax(&s_acc[side][9 + d], enc(p.hi[d])); }
+        }
+      }
+      const unsigned long long lm = __ballot(v && left), rm = __ballot(v && !left), lt = (1ull << lane) - 1ull;
+      if (v) store_prim(dst + (left ? curL + (uint32_t)__popcll(lm & lt) : curR + (uint32_t)__popcll(rm & lt)), p);
+      curL += (uint32_t)__popcll(lm); curR += (uint32_t)__popcll(rm);
+    }
+    if (lane == 0) s_alloc = atomicAdd(&ctr->numBNodes, 2u);
+    __syncthreads();
+    const uint32_t base = s_alloc;
+    StackEntry L, R;
+    L.begin = cur.begin; L.end = mid; L.bnode = base; L.buf = cur.buf ^ 1u;
+    R.begin = mid; R.end = cur.end; R.bnode = base + 1u; R.buf = cur.buf ^ 1u;
+    for (int d = 0; d < 3; d++) {
+      L.cmin[d] = dec(s_acc[0][d]); L.cmax[d] = dec(s_acc[0][3 + d]);
+      R.cmin[d] = dec(s_acc[1][d]); R.cmax[d] = dec(s_acc[1][3 + d]);
+    }
+    if (lane == 0) {
+      BNode* par = bnodes + cur.bnode;
+      par->left = base; par->right = base + 1u; par->splitSah = r.sah;
+      BNode bl{}, br{};
+      bl.begin = L.begin; bl.end = L.end; br.begin = R.begin; br.end = R.end;
+      bl.left = bl.right = br.left = br.right = NIL; bl.splitSah = br.splitSah = __builtin_inff();
+      for (int d = 0; d < 3; d++) {
+        bl.lo[d] = fallback ? dec(s_acc[0][6 + d]) : r.llo[d]; bl.hi[d] = fallback ? dec(s_acc[0][9 + d]) : r.lhi[d];
+        br.lo[d] = fallback ? dec(s_acc[1][6 + d]) : r.rlo[d]; br.hi[d] = fallback ? dec(s_acc[1][9 + d]) : r.rhi[d];
+      }
+      bnodes[base] = bl; bnodes[base + 1u] = br;
+    }
+    // continue with the smaller child, push the larger: the stack stays <= log2(small_threshold) deep
+    const bool leftSmaller = (L.end - L.begin) <= (R.end - R.begin);
+    __syncthreads();
+    if (lane == 0) s_stack[sp] = leftSmaller ? R : L;
+    sp++;
+    cur = leftSmaller ? L : R;
+    __syncthreads();
+  }
+}
+
+// -------------------------------------------------------------------------------- K4 wide collapse
+__device__ __forceinline__ float bnode_area(const BNode& b) { return half_area3(b.hi[0] - b.lo[0], b.hi[1] - b.lo[1], b.hi[2] - b.lo[2]); }
+
+// leaf-vs-split decision of BuilderT::recurse (bvh_builder_sah.h:229-236)
+__device__ __forceinline__ bool make_leaf(const BNode& b, const Params& prm) {
+  const uint32_t n = b.end - b.begin;
+  if (n <= prm.minLeaf || b.left == NIL) return true;
+  if (n > prm.maxLeaf) return false;
+  const float A = bnode_area(b);
+  const float leafSAH = prm.intCost * (A * (float)((n + (1u << prm.shift) - 1u) >> prm.shift));
+  const float splitSAH = prm.travCost * A + prm.intCost * b.splitSah;
+  return leafSAH <= splitSAH;
+}
+// heuristic.deterministic_order: sort the leaf's triangles by (primID << 32 | geomID)
+__device__ void sort_leaf(uint2* ids, uint32_t b, uint32_t e) {
+  for (uint32_t i = b + 1; i < e; i++) {
+    const uint2 x = ids[i]; const unsigned long long kx = ((unsigned long long)x.y << 32) | x.x;
+    uint32_t j = i;
+    while (j > b) { const uint2 y = ids[j - 1]; if ((((unsigned long long)y.y << 32) | y.x) <= kx) break; ids[j] = y; j--; }
+    ids[j] = x;
+  }
+}
+
+__global__ void wide_root(const BNode* bnodes, uint2* finalIds, WideItem* items, Counters* ctr, Params prm) {
+  const BNode b = bnodes[0];
+  if (make_leaf(b, prm)) {
+    sort_leaf(finalIds, b.begin, b.end);
+    ctr->rootRef = mi355_leaf_ref(b.begin, b.end - b.begin);
+    ctr->numLeaves = 1; ctr->numWide = 0; ctr->numWideNext = 0;
+    ctr->sahSum = prm.intCost * (float)((b.end - b.begin + (1u << prm.shift) - 1u) >> prm.shift);
+  } else {
+    items[0].bnode = 0; items[0].node = 0;
+    ctr->rootRef = 0; ctr->numWide = 1; ctr->numWideNext = 0; ctr->numLeaves = 0; ctr->sahSum = 0.0f;
+  }
+}
+
+__global__ __launch_bounds__(64) void wide_level(const WideItem* items, uint32_t numItems, const BNode* bnodes, QNode* nodes,
+                                                 uint2* finalIds, WideItem* next, Counters* ctr, Params prm, uint32_t maxNodes, float rootArea) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= numItems) return;
+  const WideItem it = items[t];
+  const BNode root = bnodes[it.bnode];
+  uint32_t ch[8]; uint32_t nch = 2; ch[0] = root.left; ch[1] = root.right;
+  // greedy: split the child with the largest half-area until 8 children (bvh_builder_sah.h:247-272)
+  while (nch < 8u) {
+    float bestArea = -__builtin_inff(); int best = -1;
+    for (uint32_t i = 0; i < nch; i++) {
+      const BNode c = bnodes[ch[i]];
+      if (c.end - c.begin <= prm.minLeaf || c.left == NIL) continue;
+      const float ar = bnode_area(c);
+      if (ar > bestArea) { bestArea = ar; best = (int)i; }
+    }
+    if (best < 0) break;
+    const BNode c = bnodes[ch[best]];
+    ch[best] = c.left; ch[nch++] = c.right;
+  }
+  // sort children by size, largest first (std::sort(..., std::greater), :275); stable on ties
+  uint32_t cnt[8];
+  for (uint32_t i = 0; i < nch; i++) { const BNode c = bnodes[ch[i]]; cnt[i] = c.end - c.begin; }
+  for (uint32_t i = 1; i < nch; i++) {
+    const uint32_t x = ch[i], cx = cnt[i]; uint32_t j = i;
+    while (j > 0 && cnt[j - 1] < cx) { ch[j] = ch[j - 1]; cnt[j] = cnt[j - 1]; j--; }
+    ch[j] = x; cnt[j] = cx;
+  }
+  float lo[8][3], hi[8][3]; uint32_t ref[8];
+  float olo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, ohi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+  float sah = 0.0f;
+  for (uint32_t i = 0; i < nch; i++) {
+    const BNode c = bnodes[ch[i]];
+    for (int d = 0; d < 3; d++) { lo[i][d] = c.lo[d]; hi[i][d] = c.hi[d]; olo[d] = fminf(olo[d], c.lo[d]); ohi[d] = fmaxf(ohi[d], c.hi[d]); }
+    const float A = bnode_area(c);
+    if (make_leaf(c, prm)) {
+      sort_leaf(finalIds, c.begin, c.end);
+      ref[i] = mi355_leaf_ref(c.begin, c.end - c.begin);
+      atomicAdd(&ctr->numLeaves, 1u);
+      sah += prm.intCost * A * (float)((c.end - c.begin + (1u << prm.shift) - 1u) >> prm.shift);
+    } else {
+      const uint32_t idx = atomicAdd(&ctr->numWide, 1u);
+      if (idx >= maxNodes) { ctr->overflow = 2u; ref[i] = MI355_EMPTY_REF; continue; }
+      ref[i] = idx;
+      const uint32_t k = atomicAdd(&ctr->numWideNext, 1u);
+      next[k].bnode = ch[i]; next[k].node = idx;
+      sah += prm.travCost * A;
+    }
+  }
+  if (rootArea > 0.0f) atomicAdd(&ctr->sahSum, sah / rootArea);
+  // quantise: plane = org + q * 2^(e-127), lower rounded down, upper rounded up, verified in fp32
+  QNode qn; memset(&qn, 0, sizeof(qn));
+  uint32_t ex[3];
+  for (int d = 0; d < 3; d++) {
+    qn.org[d] = olo[d];
+    const float ext = ohi[d] - olo[d];
+    int e = 1;                                               // biased exponent, scale = 2^(e-127)
+    if (ext > 0.0f) { int fe; frexpf(ext / 255.0f, &fe); e = fe + 127; if (e < 1) e = 1; if (e > 254) e = 254; }
+    for (;;) {                                               // grow the scale until every upper plane fits in 8 bits
+      const float s = __uint_as_float((uint32_t)e << 23);
+      bool fits = true;
+      for (uint32_t i = 0; i < nch; i++) {
+        float q = ceilf((hi[i][d] - olo[d]) / s);
+        while (fmaf(q, s, olo[d]) < hi[i][d]) q += 1.0f;
+        if (q > 255.0f) { fits = false; break; }
+      }
+      if (fits || e >= 254) break;
+      e++;
+    }
+    ex[d] = (uint32_t)e;
+    qn.exp[d] = (uint8_t)e;
+  }
+  qn.count = (uint8_t)nch;
+  for (uint32_t i = 0; i < 8u; i++) {
+    uint32_t ql[3] = {255, 255, 255}, qh[3] = {0, 0, 0}; uint32_t r = MI355_EMPTY_REF;
+    if (i < nch) {
+      r = ref[i];
+      for (int d = 0; d < 3; d++) {
+        const float s = __uint_as_float(ex[d] << 23);
+        float a = floorf((lo[i][d] - olo[d]) / s); if (a < 0.0f) a = 0.0f; if (a > 255.0f) a = 255.0f;
+        while (a > 0.0f && fmaf(a, s, olo[d]) > lo[i][d]) a -= 1.0f;
+        float b = ceilf((hi[i][d] - olo[d]) / s); if (b < 0.0f) b = 0.0f;
+        while (b < 255.0f && fmaf(b, s, olo[d]) < hi[i][d]) b += 1.0f;
+        if (b > 255.0f) b = 255.0f;
+        ql[d] = (uint32_t)a; qh[d] = (uint32_t)b;
+      }
+    }
+    qn.child[i][0] = ql[0] | (ql[1] << 8) | (ql[2] << 16) | (qh[0] << 24);
+    qn.child[i][1] = qh[1] | (qh[2] << 8);
+    qn.child[i][2] = r;
+  }
+  nodes[it.node] = qn;
+}
+
+// --------------------------------------------------------------------------------- K5 tri_records
+__global__ __launch_bounds__(256) void tri_records(const uint2* finalIds, uint32_t n, const GeomDesc* geoms, TriRec* out) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  const uint2 id = finalIds[i];
+  const GeomDesc g = geoms[id.x];
+  const uint32_t* tri = (const uint32_t*)(g.idx + (size_t)id.y * g.istride);
+  const float* a = (const float*)(g.verts + (size_t)tri[0] * g.vstride);
+  const float* b = (const float*)(g.verts + (size_t)tri[1] * g.vstride);
+  const float* c = (const float*)(g.verts + (size_t)tri[2] * g.vstride);
+  float4* o = (float4*)(out + i);
+  // TriangleM ctor: e1 = v0 - v1, e2 = v2 - v0 (kernels/geometry/triangle.h:40-41)
+  o[0] = make_float4(a[0], a[1], a[2], a[0] - b[0]);
+  o[1] = make_float4(a[1] - b[1], a[2] - b[2], c[0] - a[0], c[1] - a[1]);
+  o[2] = make_float4(c[2] - a[2], __uint_as_float(id.y), __uint_as_float(g.geomID), __uint_as_float(g.mask));
+}
+
+template <typename T> struct DevBuf {
+  T* p = nullptr;
+  ~DevBuf() { if (p) hipFree(p); }
+  hipError_t alloc(size_t n) { return hipMalloc((void**)&p, (n ? n : 1) * sizeof(T)); }
+};
+
+}  // namespace
+
+namespace mi355 {
+
+static thread_local std::string g_err;
+int set_error(hipError_t e, const char* what) {
+  g_err = std::string(what ? what : "") + ": " + hipGetErrorString(e);
+  return e == hipSuccess ? 1 : (int)e;
+}
+
+TraceScratch* Bvh::scratch_for(hipStream_t s) {
+  std::lock_guard<std::mutex> lk(mtx);
+  auto it = scratch.find(s);
+  if (it != scratch.end()) return &it->second;
+  TraceScratch sc;
+  if (hipMalloc((void**)&sc.counter, 256) != hipSuccess) return nullptr;
+  if (hipMalloc(&sc.spill, trace_spill_bytes(numCUs)) != hipSuccess) return nullptr;
+  if (hipMalloc((void**)&sc.stats, 64) != hipSuccess) return nullptr;
+  return &(scratch[s] = sc);
+}
+Bvh::~Bvh() {
+  hipSetDevice(device);
+  for (auto& kv : scratch) { hipFree(kv.second.counter); hipFree(kv.second.spill); hipFree(kv.second.stats); }
+  if (d_nodes) hipFree(d_nodes);
+  if (d_tris) hipFree(d_tris);
+}
+
+static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, const mi355_build_params* bp, hipStream_t st, Bvh** out) {
+  HIP_TRY(hipSetDevice(device));
+  hipDeviceProp_t prop; HIP_TRY(hipGetDeviceProperties(&prop, device));
+  Bvh* bvh = new Bvh; bvh->device = device; bvh->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  struct Guard { Bvh*& b; bool ok = false; ~Guard() { if (!ok) { delete b; b = nullptr; } } } guard{bvh};
+
+  Params prm; prm.shift = bp->sah_block_shift; prm.minLeaf = bp->min_leaf ? bp->min_leaf : 1u;
+  prm.maxLeaf = bp->max_leaf > MI355_MAX_LEAF ? MI355_MAX_LEAF : bp->max_leaf; if (prm.maxLeaf < prm.minLeaf) prm.maxLeaf = prm.minLeaf;
+  if (prm.minLeaf > MI355_MAX_LEAF) prm.minLeaf = prm.maxLeaf = MI355_MAX_LEAF;
+  prm.small = bp->small_threshold < 64u ? 64u : (bp->small_threshold > 65536u ? 65536u : bp->small_threshold); prm.travCost = bp->trav_cost; prm.intCost = bp->int_cost;
+
+  std::vector<GeomDesc> gd; uint64_t total = 0;
+  for (uint32_t i = 0; i < numMeshes; i++) {
+    const mi355_mesh& m = meshes[i];
+    if (m.num_triangles == 0) continue;
+    if (m.vertex_stride < 12 || (m.vertex_stride & 3) || m.index_stride < 12 || (m.index_stride & 3)) return set_error(hipErrorInvalidValue, "buffer stride");
+    GeomDesc g{}; g.verts = (const char*)m.d_vertices; g.idx = (const char*)m.d_indices; g.vstride = (uint32_t)m.vertex_stride; g.istride = (uint32_t)m.index_stride;
+    g.nv = m.num_vertices; g.nt = m.num_triangles; g.geomID = m.geom_id; g.mask = m.mask; g.primOffset = (uint32_t)total;
+    total += m.num_triangles; gd.push_back(g);
+  }
+  if (total >= (1ull << 26)) return set_error(hipErrorInvalidValue, "more than 2^26 triangles are not supported by the 32-bit leaf reference");
+  mi355_bvh_info& info = bvh->info; memset(&info, 0, sizeof(info));
+  info.max_leaf = prm.maxLeaf; info.root_ref = MI355_EMPTY_REF;
+  for (int d = 0; d < 3; d++) { info.bounds_lower[d] = INFINITY; info.bounds_upper[d] = -INFINITY; }
+  if (total == 0) { guard.ok = true; *out = bvh; return 0; }
+  const uint32_t N = (uint32_t)total;
+
+  DevBuf<GeomDesc> dGeoms; HIP_TRY(dGeoms.alloc(gd.size()));
+  HIP_TRY(hipMemcpyAsync(dGeoms.p, gd.data(), gd.size() * sizeof(GeomDesc), hipMemcpyHostToDevice, st));
+  const uint32_t maxSegs = N / prm.small + 1024u, maxSmall = 8u * (N / prm.small) + 1024u, maxChunks = N / CHUNK + maxSegs + 16u;
+  const uint32_t maxWide = N + 64u;
+  DevBuf<PrimRef> bufA, bufB; DevBuf<uint2> finalIds; DevBuf<BNode> bnodes; DevBuf<Seg> segs0, segs1; DevBuf<uint32_t> bins;
+  DevBuf<Chunk> chunks; DevBuf<SmallEntry> small; DevBuf<Counters> ctr; DevBuf<WideItem> w0, w1; DevBuf<QNode> wnodes;
+  HIP_TRY(bufA.alloc(N)); HIP_TRY(bufB.alloc(N)); HIP_TRY(finalIds.alloc(N)); HIP_TRY(bnodes.alloc(2ull * N + 2));
+  HIP_TRY(segs0.alloc(maxSegs)); HIP_TRY(segs1.alloc(maxSegs)); HIP_TRY(bins.alloc((size_t)maxSegs * BINS_WORDS));
+  HIP_TRY(chunks.alloc(maxChunks)); HIP_TRY(small.alloc(maxSmall)); HIP_TRY(ctr.alloc(1));
+  HIP_TRY(w0.alloc(maxWide)); HIP_TRY(w1.alloc(maxWide)); HIP_TRY(wnodes.alloc(maxWide));
+
+  hipEvent_t ev0, ev1; HIP_TRY(hipEventCreate(&ev0)); HIP_TRY(hipEventCreate(&ev1));
+  struct EvGuard { hipEvent_t a, b; ~EvGuard() { hipEventDestroy(a); hipEventDestroy(b); } } evg{ev0, ev1};
+  HIP_TRY(hipEventRecord(ev0, st));
+
+  Counters h{}; for (int k = 0; k < 12; k++) h.bounds[k] = (k % 6 < 3) ? ENC_POS_INF : ENC_NEG_INF; h.rootRef = MI355_EMPTY_REF;
+  HIP_TRY(hipMemcpyAsync(ctr.p, &h, sizeof(h), hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(primref_gen, dim3((N + 255u) / 256u), dim3(256), 0, st, dGeoms.p, (uint32_t)gd.size(), N, bufA.p, ctr.p);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(&h, ctr.p, sizeof(h), hipMemcpyDeviceToHost, st)); HIP_TRY(hipStreamSynchronize(st));
+  const uint32_t n = h.numPrims;
+  auto decf = [](uint32_t u) { uint32_t v = u ^ ((u >> 31) ? 0x80000000u : 0xFFFFFFFFu); float f; memcpy(&f, &v, 4); return f; };
+  if (n == 0) { guard.ok = true; *out = bvh; return 0; }
+  float glo[3], ghi[3], clo[3], chi[3];
+  for (int d = 0; d < 3; d++) { glo[d] = decf(h.bounds[d]); ghi[d] = decf(h.bounds[3 + d]); clo[d] = decf(h.bounds[6 + d]); chi[d] = decf(h.bounds[9 + d]); }
+  for (int d = 0; d < 3; d++) { info.bounds_lower[d] = glo[d]; info.bounds_upper[d] = ghi[d]; }
+  info.num_triangles = n;
+
+  // root binary node + first work item
+  BNode rootB{}; for (int d = 0; d < 3; d++) { rootB.lo[d] = glo[d]; rootB.hi[d] = ghi[d]; } rootB.begin = 0; rootB.end = n; rootB.left = rootB.right = NIL; rootB.splitSah = INFINITY;
+  HIP_TRY(hipMemcpyAsync(bnodes.p, &rootB, sizeof(rootB), hipMemcpyHostToDevice, st));
+  h.numBNodes = 1; h.numSegsNext = 0; h.numChunks = 0; h.numSmall = 0;
+  uint32_t numSegs = 0, numSmall = 0;
+  if (n > prm.small) {
+    Seg s0{}; s0.begin = 0; s0.end = n; s0.bnode = 0; for (int d = 0; d < 3; d++) { s0.cmin[d] = clo[d]; s0.cmax[d] = chi[d]; }
+    HIP_TRY(hipMemcpyAsync(segs0.p, &s0, sizeof(s0), hipMemcpyHostToDevice, st)); numSegs = 1;
+  } else {
+    SmallEntry se{}; se.begin = 0; se.end = n; se.bnode = 0; se.buf = 0; for (int d = 0; d < 3; d++) { se.cmin[d] = clo[d]; se.cmax[d] = chi[d]; }
+    HIP_TRY(hipMemcpyAsync(small.p, &se, sizeof(se), hipMemcpyHostToDevice, st)); h.numSmall = 1;
+  }
+  HIP_TRY(hipMemcpyAsync(ctr.p, &h, sizeof(h), hipMemcpyHostToDevice, st));
+
+  // ---- top phase: one pass over the data per binary level
+  uint32_t level = 0;
+  Seg* cur = segs0.p; Seg* nxt = segs1.p;
+  while (numSegs > 0) {
+    PrimRef* src = (level & 1u) ? bufB.p : bufA.p; PrimRef* dst = (level & 1u) ? bufA.p : bufB.p;
+    hipLaunchKernelGGL(top_setup, dim3(numSegs), dim3(256), 0, st, cur, numSegs, bins.p, chunks.p, ctr.p);
+    uint32_t numChunks = 0;
+    HIP_TRY(hipMemcpyAsync(&numChunks, &ctr.p->numChunks, 4, hipMemcpyDeviceToHost, st)); HIP_TRY(hipStreamSynchronize(st));
+    if (numChunks > maxChunks) return set_error(hipErrorOutOfMemory, "chunk table overflow");
+    hipLaunchKernelGGL(top_bin, dim3(numChunks), dim3(256), 0, st, cur, chunks.p, src, bins.p);
+    hipLaunchKernelGGL(top_split, dim3(numSegs), dim3(64), 0, st, cur, bins.p, bnodes.p, ctr.p, prm, level >= 96u ? 1u : 0u);
+    hipLaunchKernelGGL(top_partition, dim3(numChunks), dim3(256), 0, st, cur, chunks.p, src, dst);
+    hipLaunchKernelGGL(top_emit, dim3((numSegs + 255u) / 256u), dim3(256), 0, st, cur, numSegs, bnodes.p, nxt, small.p, ctr.p, prm,
+                       (level & 1u) ? 0u : 1u, maxSegs, maxSmall);
+    HIP_TRY(hipGetLastError());
+    uint32_t tmp[2];
+    HIP_TRY(hipMemcpyAsync(tmp, &ctr.p->numSegsNext, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(tmp + 1, &ctr.p->overflow, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (tmp[1]) return set_error(hipErrorOutOfMemory, "top-phase work list overflow (pathological input)");
+    numSegs = tmp[0];
+    HIP_TRY(hipMemsetAsync(&ctr.p->numSegsNext, 0, 8, st));      // numSegsNext + numChunks
+    Seg* t = cur; cur = nxt; nxt = t; level++;
+  }
+  info.top_levels = level;
+  HIP_TRY(hipMemcpyAsync(&numSmall, &ctr.p->numSmall, 4, hipMemcpyDeviceToHost, st)); HIP_TRY(hipStreamSynchronize(st));
+  if (numSmall > maxSmall) return set_error(hipErrorOutOfMemory, "small list overflow");
+
+  // ---- small phase
+  if (numSmall) hipLaunchKernelGGL(small_build, dim3(numSmall), dim3(64), 0, st, small.p, bufA.p, bufB.p, bnodes.p, finalIds.p, ctr.p, prm);
+  HIP_TRY(hipGetLastError());
+
+  // ---- wide collapse, level by level
+  const float rootArea = fmaf(ghi[0] - glo[0], (ghi[1] - glo[1]) + (ghi[2] - glo[2]), (ghi[1] - glo[1]) * (ghi[2] - glo[2]));
+  hipLaunchKernelGGL(wide_root, dim3(1), dim3(1), 0, st, bnodes.p, finalIds.p, w0.p, ctr.p, prm);
+  uint32_t numItems = 0, depth = 0;
+  HIP_TRY(hipMemcpyAsync(&numItems, &ctr.p->numWide, 4, hipMemcpyDeviceToHost, st)); HIP_TRY(hipStreamSynchronize(st));
+  WideItem* wc = w0.p; WideItem* wn = w1.p;
+  while (numItems > 0) {
+    hipLaunchKernelGGL(wide_level, dim3((numItems + 63u) / 64u), dim3(64), 0, st, wc, numItems, bnodes.p, wnodes.p, finalIds.p, wn, ctr.p, prm, maxWide, rootArea);
+    HIP_TRY(hipGetLastError());
+    uint32_t tmp[2];
+    HIP_TRY(hipMemcpyAsync(tmp, &ctr.p->numWideNext, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(tmp + 1, &ctr.p->overflow, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (tmp[1]) return set_error(hipErrorOutOfMemory, "wide node pool overflow");
+    numItems = tmp[0];
+    HIP_TRY(hipMemsetAsync(&ctr.p->numWideNext, 0, 4, st));
+    WideItem* t = wc; wc = wn; wn = t; depth++;
+  }
+  HIP_TRY(hipMemcpyAsync(&h, ctr.p, sizeof(h), hipMemcpyDeviceToHost, st)); HIP_TRY(hipStreamSynchronize(st));
+
+  // ---- final arrays (exact size) + triangle records
+  const uint32_t numNodes = h.numWide;
+  HIP_TRY(hipMalloc(&bvh->d_tris, (size_t)n * sizeof(TriRec) + 128));
+  if (numNodes) {
+    HIP_TRY(hipMalloc(&bvh->d_nodes, (size_t)numNodes * sizeof(QNode)));
+    HIP_TRY(hipMemcpyAsync(bvh->d_nodes, wnodes.p, (size_t)numNodes * sizeof(QNode), hipMemcpyDeviceToDevice, st));
+  }
+  hipLaunchKernelGGL(tri_records, dim3((n + 255u) / 256u), dim3(256), 0, st, finalIds.p, n, dGeoms.p, (TriRec*)bvh->d_tris);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(ev1, st)); HIP_TRY(hipEventSynchronize(ev1));
+  float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
+  bvh->root = h.rootRef;
+  info.root_ref = h.rootRef; info.num_nodes = numNodes; info.num_leaves = h.numLeaves; info.num_binary_nodes = h.numBNodes;
+  info.bytes_nodes = (uint64_t)numNodes * sizeof(QNode); info.bytes_triangles = (uint64_t)n * sizeof(TriRec);
+  info.sah = h.sahSum + (numNodes ? prm.travCost : 0.0f); info.build_ms = ms; info.depth = depth;
+  guard.ok = true; *out = bvh;
+  return 0;
+}
+
+}  // namespace mi355
+
+extern "C" {
+
+void mi355_default_build_params(mi355_build_params* p) {
+  memset(p, 0, sizeof(*p));
+  p->sah_block_shift = 2; p->min_leaf = 4; p->max_leaf = 28; p->small_threshold = 1024; p->trav_cost = 1.0f; p->int_cost = 1.0f;
+}
+const char* mi355_last_error(void) { return mi355::g_err.c_str(); }
+int mi355_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
+int mi355_device_name(int device, char* out, size_t n) {
+  hipDeviceProp_t prop; HIP_TRY(hipGetDeviceProperties(&prop, device));
+  snprintf(out, n, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount); return 0;
+}
+int mi355_bvh_build(int device, const mi355_mesh* meshes, uint32_t num_meshes, const mi355_build_params* params, void* stream, mi355_bvh_t* out) {
+  mi355_build_params def; if (!params) { mi355_default_build_params(&def); params = &def; }
+  mi355::Bvh* b = nullptr;
+  const int rc = mi355::build_impl(device, meshes, num_meshes, params, (hipStream_t)stream, &b);
+  *out = (mi355_bvh_t)b; return rc;
+}
+void mi355_bvh_destroy(mi355_bvh_t bvh) { delete (mi355::Bvh*)bvh; }
+int mi355_bvh_get_info(mi355_bvh_t bvh, mi355_bvh_info* info) { *info = ((mi355::Bvh*)bvh)->info; return 0; }
+int mi355_bvh_download(mi355_bvh_t bvh, void* nodes, size_t nb, void* tris, size_t tb) {
+  mi355::Bvh* b = (mi355::Bvh*)bvh; HIP_TRY(hipSetDevice(b->device));
+  if (nodes && nb) { if (nb > b->info.bytes_nodes) nb = b->info.bytes_nodes; if (nb) HIP_TRY(hipMemcpy(nodes, b->d_nodes, nb, hipMemcpyDeviceToHost)); }
+  if (tris && tb) { if (tb > b->info.bytes_triangles) tb = b->info.bytes_triangles; if (tb) HIP_TRY(hipMemcpy(tris, b->d_tris, tb, hipMemcpyDeviceToHost)); }
+  return 0;
+}
+int mi355_malloc(int device, size_t bytes, void** d) { HIP_TRY(hipSetDevice(device)); HIP_TRY(hipMalloc(d, bytes ? bytes : 1)); return 0; }
+int mi355_free(void* d) { HIP_TRY(hipFree(d)); return 0; }
+int mi355_memcpy_h2d(void* d, const void* h, size_t n) { HIP_TRY(hipMemcpy(d, h, n, hipMemcpyHostToDevice)); return 0; }
+int mi355_memcpy_d2h(void* h, const void* d, size_t n) { HIP_TRY(hipMemcpy(h, d, n, hipMemcpyDeviceToHost)); return 0; }
+int mi355_synchronize(void* stream) { HIP_TRY(hipStreamSynchronize((hipStream_t)stream)); return 0; }
+}

@@ -1,0 +1,40 @@
+// internal.h -- host-side objects shared by build.hip, trace.hip and rtcore_api.cpp.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <map>
+#include <mutex>
+#include <string>
+#include "../../include/embree_amd_hip.h"
+
+namespace mi355 {
+
+int set_error(hipError_t e, const char* what);          // records text for mi355_last_error(), returns (int)e
+#define HIP_TRY(expr)                                                             \
+  do {                                                                            \
+    hipError_t _e = (expr);                                                       \
+    if (_e != hipSuccess) return ::mi355::set_error(_e, #expr);                   \
+  } while (0)
+
+struct TraceScratch {
+  uint32_t* counter = nullptr;   // ray cursor of the persistent kernel
+  void* spill = nullptr;         // stack spill area
+  uint64_t* stats = nullptr;     // 8 counters for the counting build
+};
+
+struct Bvh {
+  int device = 0;
+  int numCUs = 256;
+  void* d_nodes = nullptr;       // QNode[numNodes]
+  void* d_tris = nullptr;        // TriRec[numTris]
+  uint32_t root = 0xFFFFFFFFu;
+  mi355_bvh_info info{};
+  std::mutex mtx;
+  std::map<hipStream_t, TraceScratch> scratch;
+  TraceScratch* scratch_for(hipStream_t s);
+  ~Bvh();
+};
+
+size_t trace_spill_bytes(int numCUs);
+
+}  // namespace mi355

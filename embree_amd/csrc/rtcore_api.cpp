@@ -1,0 +1,589 @@
+// rtcore_api.cpp -- the Embree-4 C API (include/embree4/rtcore.h) on top of the HIP core.
+//
+// Mirrors, for triangle meshes only, the reference's API shim and object model:
+//   kernels/common/rtcore.cpp   entry points, argument defaults, error capture (RTC_CATCH_BEGIN/END, rtcore.h:23-68)
+//   kernels/common/device.cpp   per-device, per-thread, first-error-wins error state (:265-330), config string
+//   kernels/common/scene.cpp    attach/detach with lowest-free-ID pool (:717-741), commit state machine (:919-1043)
+//   kernels/common/scene_triangle_mesh.cpp  buffer rules (:35-80)
+//   kernels/common/geometry.cpp default mask 1 (:48), enable/disable, commit
+// Errors never cross the ABI as exceptions; unsupported features record RTC_ERROR_INVALID_OPERATION exactly
+// like a reference build with the feature compiled out (rtcore.cpp:1553-1555).
+// There is NO CPU fallback: every ray query and every commit runs on the GPU or reports an error.
+#include <hip/hip_runtime.h>
+#include <atomic>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <set>
+#include <string>
+#include <vector>
+#include "../../include/embree4/rtcore.h"
+#include "../../include/embree_amd_hip.h"
+
+namespace {
+
+struct rtc_error {
+  RTCError code; std::string msg;
+  rtc_error(RTCError c, const char* m) : code(c), msg(m) {}
+};
+#define THROW(code, msg) throw rtc_error(code, msg)
+
+struct ErrState { RTCError error = RTC_ERROR_NONE; std::string msg; };
+thread_local ErrState g_threadError;                       // errors without a device (failed rtcNewDevice)
+
+struct RefCounted {
+  std::atomic<int> refs{1};
+  virtual ~RefCounted() {}
+  void retain() { refs.fetch_add(1); }
+  void release() { if (refs.fetch_sub(1) == 1) delete this; }
+};
+
+struct Device : RefCounted {
+  int gpu = 0;
+  int verbose = 0;
+  bool benchmark = false;
+  mi355_build_params build;
+  RTCErrorFunction errorFn = nullptr; void* errorFnPtr = nullptr;
+  RTCMemoryMonitorFunction memFn = nullptr; void* memFnPtr = nullptr;
+  std::mutex errMutex;
+  std::map<size_t, ErrState> errors;                     // per thread (keyed by a thread-local token)
+  std::string name;
+  static size_t threadToken() { static thread_local char t; return (size_t)&t; }
+  ErrState& err() { std::lock_guard<std::mutex> lk(errMutex); return errors[threadToken()]; }
+};
+
+void process_error(Device* dev, RTCError code, const char* str) {     // Device::process_error, device.cpp:312-330
+  if (!dev) { if (g_threadError.error == RTC_ERROR_NONE) { g_threadError.error = code; g_threadError.msg = str ? str : ""; } return; }
+  if (dev->verbose >= 1) fprintf(stderr, "Embree(MI355X): %s%s%s%s\n", rtcGetErrorString(code), str ? ", (" : "", str ? str : "", str ? ")" : "");
+  if (dev->errorFn) dev->errorFn(dev->errorFnPtr, code, str);
+  ErrState& e = dev->err();
+  if (e.error == RTC_ERROR_NONE) { e.error = code; if (str && *str) e.msg = str; }
+}
+
+#define CATCH_BEGIN try {
+#define CATCH_END(dev)                                                                         \
+  } catch (const rtc_error& e) { process_error(dev, e.code, e.msg.c_str());                    \
+  } catch (const std::bad_alloc&) { process_error(dev, RTC_ERROR_OUT_OF_MEMORY, "out of memory"); \
+  } catch (const std::exception& e) { process_error(dev, RTC_ERROR_UNKNOWN, e.what());          \
+  } catch (...) { process_error(dev, RTC_ERROR_UNKNOWN, "unknown exception caught"); }
+
+void hip_check(hipError_t e, const char* what) {
+  if (e == hipSuccess) return;
+  std::string m = std::string(what) + ": " + hipGetErrorString(e);
+  THROW(e == hipErrorOutOfMemory ? RTC_ERROR_OUT_OF_MEMORY : RTC_ERROR_UNKNOWN, m.c_str());
+}
+void core_check(int rc, const char* what) {
+  if (rc == 0) return;
+  std::string m = std::string(what) + ": " + mi355_last_error();
+  THROW(rc == (int)hipErrorOutOfMemory ? RTC_ERROR_OUT_OF_MEMORY : RTC_ERROR_UNKNOWN, m.c_str());
+}
+
+struct Buffer : RefCounted {
+  Device* device; size_t bytes; char* host = nullptr; bool ownsHost = false;
+  char* dev = nullptr; bool ownsDev = false; bool devDirty = true;
+  Buffer(Device* d, size_t n, void* shared, void* sharedDev = nullptr) : device(d), bytes(n) {
+    d->retain();
+    if (shared) host = (char*)shared;
+    else { host = (char*)aligned_alloc(64, ((n + 16 + 63) / 64) * 64); if (!host) throw std::bad_alloc(); ownsHost = true; memset(host, 0, n); }
+    if (sharedDev) { dev = (char*)sharedDev; devDirty = false; }
+  }
+  ~Buffer() override { if (ownsHost) free(host); if (ownsDev && dev) { hipSetDevice(device->gpu); hipFree(dev); } device->release(); }
+  void upload() {                                           // the reference's SYCL path copies in rtcCommitBuffer/rtcCommitGeometry too
+    if (!devDirty && dev) return;
+    hip_check(hipSetDevice(device->gpu), "hipSetDevice");
+    if (!dev) { hip_check(hipMalloc((void**)&dev, bytes + 16), "hipMalloc(geometry buffer)"); ownsDev = true; }
+    if (bytes) hip_check(hipMemcpy(dev, host, bytes, hipMemcpyHostToDevice), "hipMemcpy(geometry buffer)");
+    devDirty = false;
+  }
+};
+
+struct BufferView { Buffer* buf = nullptr; size_t offset = 0, stride = 0; unsigned num = 0; };
+
+struct Geometry : RefCounted {
+  Device* device; RTCGeometryType type;
+  BufferView vertices, indices;
+  std::map<unsigned, Buffer*> attribs;                     // vertex attributes: kept alive for the caller, unused by the kernels
+  unsigned mask = 1;                                        // Geometry ctor, geometry.cpp:48
+  bool enabled = true, modified = true, committed = false;
+  void* userPtr = nullptr;
+  std::atomic<int> attached{0};
+  Geometry(Device* d, RTCGeometryType t) : device(d), type(t) { d->retain(); }
+  ~Geometry() override {
+    if (vertices.buf) vertices.buf->release();
+    if (indices.buf) indices.buf->release();
+    for (auto& kv : attribs) kv.second->release();
+    device->release();
+  }
+  void setBuffer(RTCBufferType t, unsigned slot, RTCFormat fmt, Buffer* b, size_t off, size_t stride, size_t num) {
+    if (((size_t)(b->host) + off) & 3 || (stride & 3)) THROW(RTC_ERROR_INVALID_OPERATION, "data must be 4 bytes aligned");
+    if (num > 0xFFFFFFFFull) THROW(RTC_ERROR_INVALID_ARGUMENT, "buffer too large");
+    if (stride > 0xFFFFFFFFull) THROW(RTC_ERROR_INVALID_ARGUMENT, "stride too large");
+    BufferView* v = nullptr;
+    if (t == RTC_BUFFER_TYPE_VERTEX) {
+      if (fmt != RTC_FORMAT_FLOAT3) THROW(RTC_ERROR_INVALID_OPERATION, "invalid vertex buffer format");
+      if (stride * num > 16ull * 1024 * 1024 * 1024) THROW(RTC_ERROR_INVALID_OPERATION, "vertex buffer can be at most 16GB large");
+      if (slot != 0) THROW(RTC_ERROR_INVALID_ARGUMENT, "invalid vertex buffer slot");
+      v = &vertices;
+    } else if (t == RTC_BUFFER_TYPE_INDEX) {
+      if (slot != 0) THROW(RTC_ERROR_INVALID_ARGUMENT, "invalid buffer slot");
+      if (fmt != RTC_FORMAT_UINT3) THROW(RTC_ERROR_INVALID_OPERATION, "invalid index buffer format");
+      v = &indices;
+    } else if (t == RTC_BUFFER_TYPE_VERTEX_ATTRIBUTE) {
+      if (fmt < RTC_FORMAT_FLOAT || fmt > RTC_FORMAT_FLOAT16) THROW(RTC_ERROR_INVALID_OPERATION, "invalid vertex attribute buffer format");
+      b->retain();                                          // accepted and kept alive, unused on the GPU path (no rtcInterpolate)
+      if (attribs.count(slot)) attribs[slot]->release();
+      attribs[slot] = b;
+      return;
+    } else THROW(RTC_ERROR_INVALID_ARGUMENT, "unknown buffer type");
+    if (stride < 12) THROW(RTC_ERROR_INVALID_OPERATION, "stride smaller than the element");
+    if (num && off + stride * (num - 1) + 12 > b->bytes) THROW(RTC_ERROR_INVALID_ARGUMENT, "buffer too small for view");
+    b->retain();
+    if (v->buf) v->buf->release();
+    v->buf = b; v->offset = off; v->stride = stride; v->num = (unsigned)num;
+    modified = true; committed = false;
+  }
+};
+
+struct Scene : RefCounted {
+  Device* device;
+  std::mutex mtx;
+  std::map<unsigned, Geometry*> geoms;
+  RTCSceneFlags flags = RTC_SCENE_FLAG_NONE; RTCBuildQuality quality = RTC_BUILD_QUALITY_MEDIUM;
+  mi355_bvh_t bvh = nullptr; bool committed = false, modified = true;
+  RTCBounds bounds;
+  RTCProgressMonitorFunction progress = nullptr; void* progressPtr = nullptr;
+  // host-pointer query staging (device memory), one per calling thread
+  struct Staging { char* d = nullptr; size_t cap = 0; };
+  std::map<size_t, Staging> staging;
+  Scene(Device* d) : device(d) { d->retain(); setEmptyBounds(); }
+  void setEmptyBounds() {
+    bounds.lower_x = bounds.lower_y = bounds.lower_z = INFINITY; bounds.upper_x = bounds.upper_y = bounds.upper_z = -INFINITY;
+    bounds.align0 = bounds.align1 = 0;
+  }
+  ~Scene() override {
+    for (auto& kv : geoms) { kv.second->attached--; kv.second->release(); }
+    hipSetDevice(device->gpu);
+    if (bvh) mi355_bvh_destroy(bvh);
+    for (auto& kv : staging) if (kv.second.d) hipFree(kv.second.d);
+    device->release();
+  }
+  char* stage(size_t bytes) {
+    std::lock_guard<std::mutex> lk(mtx);
+    Staging& s = staging[Device::threadToken()];
+    if (s.cap < bytes) {
+      hip_check(hipSetDevice(device->gpu), "hipSetDevice");
+      if (s.d) hipFree(s.d);
+      s.cap = bytes < 4096 ? 4096 : bytes + bytes / 4;
+      s.d = nullptr;
+      hip_check(hipMalloc((void**)&s.d, s.cap), "hipMalloc(ray staging)");
+    }
+    return s.d;
+  }
+  void commit() {
+    std::lock_guard<std::mutex> lk(mtx);
+    std::vector<mi355_mesh> meshes;
+    for (auto& kv : geoms) {                                 // std::map => ascending geomID
+      Geometry* g = kv.second;
+      if (!g->enabled) continue;
+      if (!g->vertices.buf || !g->indices.buf) continue;     // a mesh without buffers has no primitives
+      if (!g->committed) THROW(RTC_ERROR_INVALID_OPERATION, "geometry attached to the scene was modified but not committed");
+      mi355_mesh m;
+      m.d_vertices = g->vertices.buf->dev + g->vertices.offset; m.vertex_stride = g->vertices.stride; m.num_vertices = g->vertices.num;
+      m.d_indices = g->indices.buf->dev + g->indices.offset; m.index_stride = g->indices.stride; m.num_triangles = g->indices.num;
+      m.geom_id = kv.first; m.mask = g->mask;
+      meshes.push_back(m);
+    }
+    if (progress && !progress(progressPtr, 0.0)) THROW(RTC_ERROR_CANCELLED, "progress monitor forced termination");
+    mi355_bvh_t nb = nullptr;
+    core_check(mi355_bvh_build(device->gpu, meshes.data(), (uint32_t)meshes.size(), &device->build, nullptr, &nb), "BVH build");
+    if (bvh) mi355_bvh_destroy(bvh);
+    bvh = nb;
+    mi355_bvh_info info; mi355_bvh_get_info(bvh, &info);
+    setEmptyBounds();
+    if (info.num_triangles) {
+      bounds.lower_x = info.bounds_lower[0]; bounds.lower_y = info.bounds_lower[1]; bounds.lower_z = info.bounds_lower[2];
+      bounds.upper_x = info.bounds_upper[0]; bounds.upper_y = info.bounds_upper[1]; bounds.upper_z = info.bounds_upper[2];
+    }
+    if (device->verbose >= 2 || device->benchmark)           // BVHN::postBuild prints BENCHMARK_BUILD, bvh.cpp:175-179
+      printf("BENCHMARK_BUILD %.3f ms %.3f Mprims/s sah %.4f nodes %llu tris %llu bytes %llu\n", info.build_ms,
+             info.build_ms > 0 ? info.num_triangles / (info.build_ms * 1e3) : 0.0, info.sah, (unsigned long long)info.num_nodes,
+             (unsigned long long)info.num_triangles, (unsigned long long)(info.bytes_nodes + info.bytes_triangles));
+    if (progress) progress(progressPtr, 1.0);
+    committed = true; modified = false;
+  }
+};
+
+Device* dev_of(RTCDevice h) { if (!h) THROW(RTC_ERROR_INVALID_ARGUMENT, "invalid argument"); return (Device*)h; }
+Scene* scene_of(RTCScene h) { if (!h) THROW(RTC_ERROR_INVALID_ARGUMENT, "invalid argument"); return (Scene*)h; }
+Geometry* geom_of(RTCGeometry h) { if (!h) THROW(RTC_ERROR_INVALID_ARGUMENT, "invalid argument"); return (Geometry*)h; }
+
+// State::parseString (kernels/common/state.cpp:224): comma/space separated key=value list
+void parse_config(Device* d, const char* cfg) {
+  if (!cfg) return;
+  std::string s(cfg); size_t i = 0;
+  while (i < s.size()) {
+    size_t j = s.find_first_of(", ", i); if (j == std::string::npos) j = s.size();
+    std::string tok = s.substr(i, j - i); i = j + 1;
+    if (tok.empty()) continue;
+    size_t eq = tok.find('='); std::string k = tok.substr(0, eq), v = eq == std::string::npos ? "" : tok.substr(eq + 1);
+    if (k == "verbose") d->verbose = atoi(v.c_str());
+    else if (k == "benchmark") d->benchmark = atoi(v.c_str()) != 0;
+    else if (k == "gpu") d->gpu = atoi(v.c_str());
+    else if (k == "max_leaf" || k == "max_triangles_per_leaf") d->build.max_leaf = (uint32_t)atoi(v.c_str());
+    else if (k == "min_leaf") d->build.min_leaf = (uint32_t)atoi(v.c_str());
+    else if (k == "leaf_block_shift") d->build.sah_block_shift = (uint32_t)atoi(v.c_str());
+    else if (k == "small_threshold") d->build.small_threshold = (uint32_t)atoi(v.c_str());
+    // CPU-only keys of the reference (threads, isa, tri_accel, hugepages, ...) are accepted and ignored
+  }
+}
+
+void check_query_args(const RTCFilterFunctionN filter, const void* callback) {
+  if (filter || callback) THROW(RTC_ERROR_INVALID_OPERATION, "filter / user-geometry callbacks cannot run on the GPU path");
+}
+mi355_bvh_t committed_bvh(Scene* s) {
+  if (!s->committed || !s->bvh) THROW(RTC_ERROR_INVALID_OPERATION, "scene not committed");   // missing_rtcCommit, scene.cpp:66
+  return s->bvh;
+}
+
+// host-pointer AoS query: upload, trace, download the mutable parts
+void host_query(Scene* s, void* data, unsigned M, size_t stride, bool any) {
+  if (M == 0) return;
+  mi355_bvh_t b = committed_bvh(s);
+  const size_t rec = any ? 48 : 96;
+  if (stride < rec) THROW(RTC_ERROR_INVALID_ARGUMENT, "byteStride smaller than the ray record");
+  hip_check(hipSetDevice(s->device->gpu), "hipSetDevice");
+  const bool repack = (stride & 15) || ((size_t)data & 15);
+  if (repack) THROW(RTC_ERROR_INVALID_ARGUMENT, "ray records must be 16-byte aligned (include/embree4/rtcore.h)");
+  const size_t bytes = (size_t)(M - 1) * stride + rec;
+  char* d = s->stage(bytes);
+  hip_check(hipMemcpy(d, data, bytes, hipMemcpyHostToDevice), "hipMemcpy(rays H2D)");
+  core_check(any ? mi355_trace_any(b, d, M, stride, nullptr) : mi355_trace_closest(b, d, M, stride, nullptr), "trace");
+  hip_check(hipMemcpy(data, d, bytes, hipMemcpyDeviceToHost), "hipMemcpy(rays D2H)");
+}
+void host_packet_query(Scene* s, const int* valid, void* packet, unsigned K, bool any) {
+  mi355_bvh_t b = committed_bvh(s);
+  const size_t pbytes = (size_t)K * 4 * (any ? 12 : 21);
+  hip_check(hipSetDevice(s->device->gpu), "hipSetDevice");
+  char* d = s->stage(pbytes + 64 + K * 4);
+  hip_check(hipMemcpy(d, packet, pbytes, hipMemcpyHostToDevice), "hipMemcpy(packet H2D)");
+  int* dv = (int*)(d + ((pbytes + 63) / 64) * 64);
+  hip_check(hipMemcpy(dv, valid, K * 4, hipMemcpyHostToDevice), "hipMemcpy(valid H2D)");
+  core_check(any ? mi355_trace_any_packet(b, dv, d, K, 1, pbytes, nullptr) : mi355_trace_closest_packet(b, dv, d, K, 1, pbytes, nullptr), "trace packet");
+  hip_check(hipMemcpy(packet, d, pbytes, hipMemcpyDeviceToHost), "hipMemcpy(packet D2H)");
+}
+
+}  // namespace
+
+// ============================================================================================ device
+RTC_API RTCDevice rtcNewDevice(const char* config) {
+  Device* d = nullptr;
+  CATCH_BEGIN
+  d = new Device;
+  mi355_default_build_params(&d->build);
+  parse_config(d, config);
+  const int n = mi355_device_count();
+  if (n <= 0) THROW(RTC_ERROR_UNSUPPORTED_CPU, "no HIP device found: this library has no CPU fallback");
+  if (d->gpu < 0 || d->gpu >= n) THROW(RTC_ERROR_INVALID_ARGUMENT, "gpu ordinal out of range");
+  char nm[256]; if (mi355_device_name(d->gpu, nm, sizeof(nm)) == 0) d->name = nm;
+  if (d->verbose >= 1) printf("Embree(MI355X) %s on %s\n", RTC_VERSION_STRING, d->name.c_str());
+  return (RTCDevice)d;
+  CATCH_END(nullptr)
+  if (d) d->release();
+  return nullptr;
+}
+RTC_API void rtcRetainDevice(RTCDevice h) { CATCH_BEGIN dev_of(h)->retain(); CATCH_END((Device*)h) }
+RTC_API void rtcReleaseDevice(RTCDevice h) { CATCH_BEGIN dev_of(h)->release(); CATCH_END(nullptr) }
+RTC_API ssize_t rtcGetDeviceProperty(RTCDevice h, enum RTCDeviceProperty prop) {
+  CATCH_BEGIN
+  dev_of(h);
+  switch (prop) {
+    case RTC_DEVICE_PROPERTY_VERSION: return RTC_VERSION;
+    case RTC_DEVICE_PROPERTY_VERSION_MAJOR: return RTC_VERSION_MAJOR;
+    case RTC_DEVICE_PROPERTY_VERSION_MINOR: return RTC_VERSION_MINOR;
+    case RTC_DEVICE_PROPERTY_VERSION_PATCH: return RTC_VERSION_PATCH;
+    case RTC_DEVICE_PROPERTY_NATIVE_RAY4_SUPPORTED: case RTC_DEVICE_PROPERTY_NATIVE_RAY8_SUPPORTED:
+    case RTC_DEVICE_PROPERTY_NATIVE_RAY16_SUPPORTED: return 1;
+    case RTC_DEVICE_PROPERTY_RAY_MASK_SUPPORTED: return 1;
+    case RTC_DEVICE_PROPERTY_TRIANGLE_GEOMETRY_SUPPORTED: return 1;
+    case RTC_DEVICE_PROPERTY_HIP_DEVICE: return 1;
+    case RTC_DEVICE_PROPERTY_BACKFACE_CULLING_ENABLED: case RTC_DEVICE_PROPERTY_BACKFACE_CULLING_CURVES_ENABLED:
+    case RTC_DEVICE_PROPERTY_BACKFACE_CULLING_SPHERES_ENABLED: case RTC_DEVICE_PROPERTY_FILTER_FUNCTION_SUPPORTED:
+    case RTC_DEVICE_PROPERTY_IGNORE_INVALID_RAYS_ENABLED: case RTC_DEVICE_PROPERTY_COMPACT_POLYS_ENABLED:
+    case RTC_DEVICE_PROPERTY_QUAD_GEOMETRY_SUPPORTED: case RTC_DEVICE_PROPERTY_SUBDIVISION_GEOMETRY_SUPPORTED:
+    case RTC_DEVICE_PROPERTY_CURVE_GEOMETRY_SUPPORTED: case RTC_DEVICE_PROPERTY_USER_GEOMETRY_SUPPORTED:
+    case RTC_DEVICE_PROPERTY_POINT_GEOMETRY_SUPPORTED: case RTC_DEVICE_PROPERTY_TASKING_SYSTEM:
+    case RTC_DEVICE_PROPERTY_JOIN_COMMIT_SUPPORTED: case RTC_DEVICE_PROPERTY_PARALLEL_COMMIT_SUPPORTED:
+    case RTC_DEVICE_PROPERTY_CPU_DEVICE: case RTC_DEVICE_PROPERTY_SYCL_DEVICE: return 0;
+    default: THROW(RTC_ERROR_INVALID_ARGUMENT, "unknown readable property");
+  }
+  CATCH_END((Device*)h)
+  return 0;
+}
+RTC_API void rtcSetDeviceProperty(RTCDevice h, const enum RTCDeviceProperty, ssize_t) {
+  CATCH_BEGIN dev_of(h); THROW(RTC_ERROR_INVALID_ARGUMENT, "unknown writable property"); CATCH_END((Device*)h)
+}
+RTC_API const char* rtcGetErrorString(enum RTCError e) {
+  switch (e) {
+    case RTC_ERROR_NONE: return "No error";
+    case RTC_ERROR_UNKNOWN: return "Unknown error";
+    case RTC_ERROR_INVALID_ARGUMENT: return "Invalid argument";
+    case RTC_ERROR_INVALID_OPERATION: return "Invalid operation";
+    case RTC_ERROR_OUT_OF_MEMORY: return "Out of memory";
+    case RTC_ERROR_UNSUPPORTED_CPU: return "Unsupported CPU";
+    case RTC_ERROR_CANCELLED: return "Cancelled";
+    case RTC_ERROR_LEVEL_ZERO_RAYTRACING_SUPPORT_MISSING: return "Level Zero raytracing support missing";
+    default: return "Invalid error code";
+  }
+}
+RTC_API enum RTCError rtcGetDeviceError(RTCDevice h) {        // returns and clears (device.cpp:273-279)
+  if (!h) { RTCError e = g_threadError.error; g_threadError.error = RTC_ERROR_NONE; return e; }
+  ErrState& e = ((Device*)h)->err(); RTCError c = e.error; e.error = RTC_ERROR_NONE; return c;
+}
+RTC_API const char* rtcGetDeviceLastErrorMessage(RTCDevice h) {
+  if (!h) return g_threadError.msg.c_str();
+  return ((Device*)h)->err().msg.c_str();
+}
+RTC_API void rtcSetDeviceErrorFunction(RTCDevice h, RTCErrorFunction fn, void* p) { CATCH_BEGIN Device* d = dev_of(h); d->errorFn = fn; d->errorFnPtr = p; CATCH_END((Device*)h) }
+RTC_API void rtcSetDeviceMemoryMonitorFunction(RTCDevice h, RTCMemoryMonitorFunction fn, void* p) { CATCH_BEGIN Device* d = dev_of(h); d->memFn = fn; d->memFnPtr = p; CATCH_END((Device*)h) }
+
+// ============================================================================================ buffer
+RTC_API RTCBuffer rtcNewBuffer(RTCDevice h, size_t bytes) {
+  CATCH_BEGIN return (RTCBuffer) new Buffer(dev_of(h), bytes, nullptr); CATCH_END((Device*)h) return nullptr;
+}
+RTC_API RTCBuffer rtcNewSharedBuffer(RTCDevice h, void* ptr, size_t bytes) {
+  CATCH_BEGIN if (!ptr && bytes) THROW(RTC_ERROR_INVALID_ARGUMENT, "invalid argument"); return (RTCBuffer) new Buffer(dev_of(h), bytes, ptr); CATCH_END((Device*)h) return nullptr;
+}
+RTC_API void* rtcGetBufferData(RTCBuffer b) { if (!b) return nullptr; return ((Buffer*)b)->host; }
+RTC_API void rtcRetainBuffer(RTCBuffer b) { if (b) ((Buffer*)b)->retain(); }
+RTC_API void rtcReleaseBuffer(RTCBuffer b) { if (b) ((Buffer*)b)->release(); }
+
+// ========================================================================================== geometry
+RTC_API RTCGeometry rtcNewGeometry(RTCDevice h, enum RTCGeometryType type) {
+  CATCH_BEGIN
+  Device* d = dev_of(h);
+  if (type != RTC_GEOMETRY_TYPE_TRIANGLE) THROW(RTC_ERROR_INVALID_OPERATION, "only RTC_GEOMETRY_TYPE_TRIANGLE is supported by the MI355X core");
+  return (RTCGeometry) new Geometry(d, type);
+  CATCH_END((Device*)h)
+  return nullptr;
+}
+#define GEOM_DEV(h) ((h) ? ((Geometry*)(h))->device : nullptr)
+RTC_API void rtcRetainGeometry(RTCGeometry h) { CATCH_BEGIN geom_of(h)->retain(); CATCH_END(GEOM_DEV(h)) }
+RTC_API void rtcReleaseGeometry(RTCGeometry h) { CATCH_BEGIN geom_of(h)->release(); CATCH_END(nullptr) }
+RTC_API void rtcCommitGeometry(RTCGeometry h) {
+  CATCH_BEGIN
+  Geometry* g = geom_of(h);
+  if (g->vertices.buf) g->vertices.buf->upload();
+  if (g->indices.buf) g->indices.buf->upload();
+  g->committed = true;
+  CATCH_END(GEOM_DEV(h))
+}
+RTC_API void rtcEnableGeometry(RTCGeometry h) { CATCH_BEGIN geom_of(h)->enabled = true; CATCH_END(GEOM_DEV(h)) }
+RTC_API void rtcDisableGeometry(RTCGeometry h) { CATCH_BEGIN geom_of(h)->enabled = false; CATCH_END(GEOM_DEV(h)) }
+RTC_API void rtcSetGeometryTimeStepCount(RTCGeometry h, unsigned n) {
+  CATCH_BEGIN geom_of(h); if (n != 1) THROW(RTC_ERROR_INVALID_OPERATION, "motion blur is not supported by the MI355X core"); CATCH_END(GEOM_DEV(h))
+}
+RTC_API void rtcSetGeometryVertexAttributeCount(RTCGeometry h, unsigned) { CATCH_BEGIN geom_of(h); CATCH_END(GEOM_DEV(h)) }
+RTC_API void rtcSetGeometryMask(RTCGeometry h, unsigned mask) { CATCH_BEGIN Geometry* g = geom_of(h); g->mask = mask; g->committed = false; CATCH_END(GEOM_DEV(h)) }
+RTC_API void rtcSetGeometryBuildQuality(RTCGeometry h, enum RTCBuildQuality q) {
+  CATCH_BEGIN geom_of(h);
+  if (q != RTC_BUILD_QUALITY_LOW && q != RTC_BUILD_QUALITY_MEDIUM && q != RTC_BUILD_QUALITY_HIGH && q != RTC_BUILD_QUALITY_REFIT) THROW(RTC_ERROR_INVALID_OPERATION, "invalid build quality");
+  CATCH_END(GEOM_DEV(h))
+}
+RTC_API void rtcSetGeometryBuffer(RTCGeometry h, enum RTCBufferType type, unsigned slot, enum RTCFormat fmt, RTCBuffer buffer,
+                                  size_t byteOffset, size_t byteStride, size_t itemCount) {
+  CATCH_BEGIN
+  Geometry* g = geom_of(h); if (!buffer) THROW(RTC_ERROR_INVALID_ARGUMENT, "invalid argument");
+  Buffer* b = (Buffer*)buffer;
+  if (g->device != b->device) THROW(RTC_ERROR_INVALID_ARGUMENT, "inputs are from different devices");
+  g->setBuffer(type, slot, fmt, b, byteOffset, byteStride, itemCount);
+  CATCH_END(GEOM_DEV(h))
+}
+RTC_API void rtcSetSharedGeometryBuffer(RTCGeometry h, enum RTCBufferType type, unsigned slot, enum RTCFormat fmt, const void* ptr,
+                                        size_t byteOffset, size_t byteStride, size_t itemCount) {
+  CATCH_BEGIN
+  Geometry* g = geom_of(h);
+  Buffer* b = new Buffer(g->device, itemCount * byteStride, (char*)ptr + byteOffset);
+  try { g->setBuffer(type, slot, fmt, b, 0, byteStride, itemCount); } catch (...) { b->release(); throw; }
+  b->release();
+  CATCH_END(GEOM_DEV(h))
+}
+// device-resident geometry: the reference's own entry point for GPU devices (rtcore.cpp, rtcSetSharedGeometryBufferHostDevice):
+// dptr is HIP device memory on the device's GPU; no upload happens in rtcCommitGeometry.
+RTC_API void rtcSetSharedGeometryBufferHostDevice(RTCGeometry h, enum RTCBufferType type, unsigned slot, enum RTCFormat fmt,
+                                                  const void* ptr, const void* dptr, size_t byteOffset, size_t byteStride, size_t itemCount) {
+  CATCH_BEGIN
+  Geometry* g = geom_of(h);
+  if (!dptr) THROW(RTC_ERROR_INVALID_ARGUMENT, "device pointer may not be NULL");
+  Buffer* b = new Buffer(g->device, itemCount * byteStride, ptr ? (char*)ptr + byteOffset : (char*)16, (char*)dptr + byteOffset);
+  try { g->setBuffer(type, slot, fmt, b, 0, byteStride, itemCount); } catch (...) { b->release(); throw; }
+  b->release();
+  CATCH_END(GEOM_DEV(h))
+}
+RTC_API void* rtcSetNewGeometryBuffer(RTCGeometry h, enum RTCBufferType type, unsigned slot, enum RTCFormat fmt, size_t byteStride, size_t itemCount) {
+  CATCH_BEGIN
+  Geometry* g = geom_of(h);
+  size_t bytes = itemCount * byteStride;
+  if (type == RTC_BUFFER_TYPE_VERTEX || type == RTC_BUFFER_TYPE_VERTEX_ATTRIBUTE) bytes += (16 - (byteStride % 16)) % 16;   // rtcore.cpp:1932-1935
+  Buffer* b = new Buffer(g->device, bytes, nullptr);
+  try { g->setBuffer(type, slot, fmt, b, 0, byteStride, itemCount); } catch (...) { b->release(); throw; }
+  void* p = b->host; b->release();
+  return p;
+  CATCH_END(GEOM_DEV(h))
+  return nullptr;
+}
+RTC_API void* rtcGetGeometryBufferData(RTCGeometry h, enum RTCBufferType type, unsigned slot) {
+  CATCH_BEGIN
+  Geometry* g = geom_of(h); if (slot != 0) THROW(RTC_ERROR_INVALID_ARGUMENT, "invalid buffer slot");
+  BufferView* v = type == RTC_BUFFER_TYPE_VERTEX ? &g->vertices : type == RTC_BUFFER_TYPE_INDEX ? &g->indices : nullptr;
+  if (!v) THROW(RTC_ERROR_INVALID_ARGUMENT, "unknown buffer type");
+  return v->buf ? v->buf->host + v->offset : nullptr;
+  CATCH_END(GEOM_DEV(h))
+  return nullptr;
+}
+RTC_API void rtcUpdateGeometryBuffer(RTCGeometry h, enum RTCBufferType type, unsigned slot) {
+  CATCH_BEGIN
+  Geometry* g = geom_of(h); if (slot != 0) THROW(RTC_ERROR_INVALID_ARGUMENT, "invalid buffer slot");
+  BufferView* v = type == RTC_BUFFER_TYPE_VERTEX ? &g->vertices : type == RTC_BUFFER_TYPE_INDEX ? &g->indices : nullptr;
+  if (!v) THROW(RTC_ERROR_INVALID_ARGUMENT, "unknown buffer type");
+  if (v->buf && v->buf->ownsDev) v->buf->devDirty = true;
+  if (v->buf && !v->buf->dev) v->buf->devDirty = true;
+  g->modified = true; g->committed = false;
+  CATCH_END(GEOM_DEV(h))
+}
+RTC_API void rtcSetGeometryUserData(RTCGeometry h, void* p) { CATCH_BEGIN geom_of(h)->userPtr = p; CATCH_END(GEOM_DEV(h)) }
+RTC_API void* rtcGetGeometryUserData(RTCGeometry h) { CATCH_BEGIN return geom_of(h)->userPtr; CATCH_END(GEOM_DEV(h)) return nullptr; }
+RTC_API void rtcSetGeometryIntersectFilterFunction(RTCGeometry h, RTCFilterFunctionN f) {
+  CATCH_BEGIN geom_of(h); if (f) THROW(RTC_ERROR_INVALID_OPERATION, "filter functions cannot run on the GPU path"); CATCH_END(GEOM_DEV(h))
+}
+RTC_API void rtcSetGeometryOccludedFilterFunction(RTCGeometry h, RTCFilterFunctionN f) {
+  CATCH_BEGIN geom_of(h); if (f) THROW(RTC_ERROR_INVALID_OPERATION, "filter functions cannot run on the GPU path"); CATCH_END(GEOM_DEV(h))
+}
+
+// ============================================================================================= scene
+#define SCENE_DEV(h) ((h) ? ((Scene*)(h))->device : nullptr)
+RTC_API RTCScene rtcNewScene(RTCDevice h) { CATCH_BEGIN return (RTCScene) new Scene(dev_of(h)); CATCH_END((Device*)h) return nullptr; }
+RTC_API RTCDevice rtcGetSceneDevice(RTCScene h) { CATCH_BEGIN Scene* s = scene_of(h); s->device->retain(); return (RTCDevice)s->device; CATCH_END(SCENE_DEV(h)) return nullptr; }
+RTC_API void rtcRetainScene(RTCScene h) { CATCH_BEGIN scene_of(h)->retain(); CATCH_END(SCENE_DEV(h)) }
+RTC_API void rtcReleaseScene(RTCScene h) { CATCH_BEGIN scene_of(h)->release(); CATCH_END(nullptr) }
+RTC_API RTCTraversable rtcGetSceneTraversable(RTCScene h) { return (RTCTraversable)h; }
+RTC_API unsigned int rtcAttachGeometry(RTCScene h, RTCGeometry hg) {
+  CATCH_BEGIN
+  Scene* s = scene_of(h); Geometry* g = geom_of(hg);
+  if (s->device != g->device) THROW(RTC_ERROR_INVALID_ARGUMENT, "inputs are from different devices");
+  std::lock_guard<std::mutex> lk(s->mtx);
+  unsigned id = 0; for (auto& kv : s->geoms) { if (kv.first != id) break; id++; }     // IDPool: lowest free ID (scene.cpp:717-741)
+  g->retain(); g->attached++; s->geoms[id] = g; s->modified = true;
+  return id;
+  CATCH_END(SCENE_DEV(h))
+  return RTC_INVALID_GEOMETRY_ID;
+}
+RTC_API void rtcAttachGeometryByID(RTCScene h, RTCGeometry hg, unsigned id) {
+  CATCH_BEGIN
+  Scene* s = scene_of(h); Geometry* g = geom_of(hg);
+  if (id == RTC_INVALID_GEOMETRY_ID) THROW(RTC_ERROR_INVALID_ARGUMENT, "invalid geometry ID");
+  if (s->device != g->device) THROW(RTC_ERROR_INVALID_ARGUMENT, "inputs are from different devices");
+  std::lock_guard<std::mutex> lk(s->mtx);
+  if (s->geoms.count(id)) THROW(RTC_ERROR_INVALID_OPERATION, "trying to bind geometry to already reserved ID");
+  g->retain(); g->attached++; s->geoms[id] = g; s->modified = true;
+  CATCH_END(SCENE_DEV(h))
+}
+RTC_API void rtcDetachGeometry(RTCScene h, unsigned id) {
+  CATCH_BEGIN
+  Scene* s = scene_of(h);
+  std::lock_guard<std::mutex> lk(s->mtx);
+  auto it = s->geoms.find(id);
+  if (it == s->geoms.end()) THROW(RTC_ERROR_INVALID_OPERATION, "invalid geometry ID");
+  it->second->attached--; it->second->release(); s->geoms.erase(it); s->modified = true;
+  CATCH_END(SCENE_DEV(h))
+}
+RTC_API RTCGeometry rtcGetGeometry(RTCScene h, unsigned id) {
+  CATCH_BEGIN
+  Scene* s = scene_of(h); std::lock_guard<std::mutex> lk(s->mtx);
+  auto it = s->geoms.find(id); if (it == s->geoms.end()) THROW(RTC_ERROR_INVALID_ARGUMENT, "invalid geometry ID");
+  return (RTCGeometry)it->second;
+  CATCH_END(SCENE_DEV(h))
+  return nullptr;
+}
+RTC_API RTCGeometry rtcGetGeometryThreadSafe(RTCScene h, unsigned id) { return rtcGetGeometry(h, id); }
+RTC_API void rtcCommitScene(RTCScene h) { CATCH_BEGIN scene_of(h)->commit(); CATCH_END(SCENE_DEV(h)) }
+RTC_API void rtcJoinCommitScene(RTCScene h) { rtcCommitScene(h); }      // the GPU does the work; joining threads have nothing to add
+RTC_API void rtcSetSceneProgressMonitorFunction(RTCScene h, RTCProgressMonitorFunction f, void* p) { CATCH_BEGIN Scene* s = scene_of(h); s->progress = f; s->progressPtr = p; CATCH_END(SCENE_DEV(h)) }
+RTC_API void rtcSetSceneBuildQuality(RTCScene h, enum RTCBuildQuality q) {
+  CATCH_BEGIN Scene* s = scene_of(h);
+  if (q != RTC_BUILD_QUALITY_LOW && q != RTC_BUILD_QUALITY_MEDIUM && q != RTC_BUILD_QUALITY_HIGH) THROW(RTC_ERROR_INVALID_OPERATION, "invalid build quality");
+  s->quality = q;                                          // every quality is served by the binned-SAH builder
+  CATCH_END(SCENE_DEV(h))
+}
+RTC_API void rtcSetSceneFlags(RTCScene h, enum RTCSceneFlags f) { CATCH_BEGIN scene_of(h)->flags = f; CATCH_END(SCENE_DEV(h)) }
+RTC_API enum RTCSceneFlags rtcGetSceneFlags(RTCScene h) { CATCH_BEGIN return scene_of(h)->flags; CATCH_END(SCENE_DEV(h)) return RTC_SCENE_FLAG_NONE; }
+RTC_API void rtcGetSceneBounds(RTCScene h, struct RTCBounds* o) {
+  CATCH_BEGIN Scene* s = scene_of(h); if (!o) THROW(RTC_ERROR_INVALID_ARGUMENT, "invalid destination pointer");
+  if (!s->committed) THROW(RTC_ERROR_INVALID_OPERATION, "scene not committed");
+  *o = s->bounds;
+  CATCH_END(SCENE_DEV(h))
+}
+
+// ============================================================================================ queries
+RTC_API void rtcIntersect1(RTCScene h, struct RTCRayHit* rh, struct RTCIntersectArguments* a) {
+  CATCH_BEGIN Scene* s = scene_of(h); if (a) check_query_args(a->filter, (const void*)a->intersect); host_query(s, rh, 1, sizeof(RTCRayHit), false); CATCH_END(SCENE_DEV(h))
+}
+RTC_API void rtcOccluded1(RTCScene h, struct RTCRay* r, struct RTCOccludedArguments* a) {
+  CATCH_BEGIN Scene* s = scene_of(h); if (a) check_query_args(a->filter, (const void*)a->occluded); host_query(s, r, 1, sizeof(RTCRay), true); CATCH_END(SCENE_DEV(h))
+}
+#define PACKET_ENTRY(K)                                                                                                     \
+  RTC_API void rtcIntersect##K(const int* valid, RTCScene h, struct RTCRayHit##K* rh, struct RTCIntersectArguments* a) {    \
+    CATCH_BEGIN Scene* s = scene_of(h); if (a) check_query_args(a->filter, (const void*)a->intersect);                      \
+    host_packet_query(s, valid, rh, K, false); CATCH_END(SCENE_DEV(h)) }                                                    \
+  RTC_API void rtcOccluded##K(const int* valid, RTCScene h, struct RTCRay##K* r, struct RTCOccludedArguments* a) {          \
+    CATCH_BEGIN Scene* s = scene_of(h); if (a) check_query_args(a->filter, (const void*)a->occluded);                       \
+    host_packet_query(s, valid, r, K, true); CATCH_END(SCENE_DEV(h)) }                                                      \
+  RTC_API void rtcTraversableIntersect##K(const int* valid, RTCTraversable t, struct RTCRayHit##K* rh, struct RTCIntersectArguments* a) { rtcIntersect##K(valid, (RTCScene)t, rh, a); } \
+  RTC_API void rtcTraversableOccluded##K(const int* valid, RTCTraversable t, struct RTCRay##K* r, struct RTCOccludedArguments* a) { rtcOccluded##K(valid, (RTCScene)t, r, a); }
+PACKET_ENTRY(4)
+PACKET_ENTRY(8)
+PACKET_ENTRY(16)
+RTC_API void rtcTraversableIntersect1(RTCTraversable t, struct RTCRayHit* rh, struct RTCIntersectArguments* a) { rtcIntersect1((RTCScene)t, rh, a); }
+RTC_API void rtcTraversableOccluded1(RTCTraversable t, struct RTCRay* r, struct RTCOccludedArguments* a) { rtcOccluded1((RTCScene)t, r, a); }
+
+RTC_API void rtcIntersect1M(RTCScene h, struct RTCRayHit* rh, unsigned M, size_t stride, struct RTCIntersectArguments* a) {
+  CATCH_BEGIN Scene* s = scene_of(h); if (a) check_query_args(a->filter, (const void*)a->intersect); host_query(s, rh, M, stride, false); CATCH_END(SCENE_DEV(h))
+}
+RTC_API void rtcOccluded1M(RTCScene h, struct RTCRay* r, unsigned M, size_t stride, struct RTCOccludedArguments* a) {
+  CATCH_BEGIN Scene* s = scene_of(h); if (a) check_query_args(a->filter, (const void*)a->occluded); host_query(s, r, M, stride, true); CATCH_END(SCENE_DEV(h))
+}
+RTC_API void rtcIntersect1MDevice(RTCScene h, void* d_rh, unsigned M, size_t stride, struct RTCIntersectArguments* a, void* stream) {
+  CATCH_BEGIN Scene* s = scene_of(h); if (a) check_query_args(a->filter, (const void*)a->intersect);
+  core_check(mi355_trace_closest(committed_bvh(s), d_rh, M, stride, stream), "trace"); CATCH_END(SCENE_DEV(h))
+}
+RTC_API void rtcOccluded1MDevice(RTCScene h, void* d_r, unsigned M, size_t stride, struct RTCOccludedArguments* a, void* stream) {
+  CATCH_BEGIN Scene* s = scene_of(h); if (a) check_query_args(a->filter, (const void*)a->occluded);
+  core_check(mi355_trace_any(committed_bvh(s), d_r, M, stride, stream), "trace"); CATCH_END(SCENE_DEV(h))
+}
+// extension used by tests/bench: the core BVH handle behind a committed scene (NULL if not committed)
+extern "C" __attribute__((visibility("default"))) mi355_bvh_t rtcGetSceneBVH_mi355(RTCScene h) { return h ? ((Scene*)h)->bvh : nullptr; }
+
+// ================================================================= entry points outside the triangle path
+// exported so that applications linking the full Embree API resolve; each records RTC_ERROR_INVALID_OPERATION
+#define UNSUPPORTED_GEOM(name, ...) RTC_API void name(RTCGeometry h, ##__VA_ARGS__) { process_error(GEOM_DEV(h), RTC_ERROR_INVALID_OPERATION, #name " is not supported by the MI355X triangle core"); }
+UNSUPPORTED_GEOM(rtcSetGeometryTimeRange, float, float)
+UNSUPPORTED_GEOM(rtcSetGeometryMaxRadiusScale, float)
+UNSUPPORTED_GEOM(rtcSetGeometryEnableFilterFunctionFromArguments, bool)
+UNSUPPORTED_GEOM(rtcSetGeometryPointQueryFunction, void*)
+UNSUPPORTED_GEOM(rtcSetGeometryUserPrimitiveCount, unsigned)
+UNSUPPORTED_GEOM(rtcSetGeometryBoundsFunction, void*, void*)
+UNSUPPORTED_GEOM(rtcSetGeometryIntersectFunction, void*)
+UNSUPPORTED_GEOM(rtcSetGeometryOccludedFunction, void*)
+UNSUPPORTED_GEOM(rtcSetGeometryInstancedScene, RTCScene)
+UNSUPPORTED_GEOM(rtcSetGeometryTransform, unsigned, enum RTCFormat, const void*)
+UNSUPPORTED_GEOM(rtcSetGeometryTessellationRate, float)
+UNSUPPORTED_GEOM(rtcSetGeometryTopologyCount, unsigned)
+UNSUPPORTED_GEOM(rtcSetGeometrySubdivisionMode, unsigned, int)
+UNSUPPORTED_GEOM(rtcSetGeometryVertexAttributeTopology, unsigned, unsigned)
+UNSUPPORTED_GEOM(rtcSetGeometryDisplacementFunction, void*)
+RTC_API bool rtcPointQuery(RTCScene h, void*, void*, void*, void*) { process_error(SCENE_DEV(h), RTC_ERROR_INVALID_OPERATION, "rtcPointQuery is not supported by the MI355X triangle core"); return false; }
+RTC_API void rtcCollide(RTCScene h, RTCScene, void*, void*) { process_error(SCENE_DEV(h), RTC_ERROR_INVALID_OPERATION, "rtcCollide is not supported by the MI355X triangle core"); }
+RTC_API void rtcInterpolate(const void*) { process_error(nullptr, RTC_ERROR_INVALID_OPERATION, "rtcInterpolate is not supported by the MI355X triangle core"); }
+RTC_API void rtcGetSceneLinearBounds(RTCScene h, void*) { process_error(SCENE_DEV(h), RTC_ERROR_INVALID_OPERATION, "rtcGetSceneLinearBounds is not supported by the MI355X triangle core"); }

@@ -328,6 +328,11 @@ RTC_API void rtcSetGeometryBuffer(RTCGeometry geometry, enum RTCBufferType type,
 RTC_API void rtcSetSharedGeometryBuffer(RTCGeometry geometry, enum RTCBufferType type, unsigned int slot,
                                         enum RTCFormat format, const void* ptr, size_t byteOffset,
                                         size_t byteStride, size_t itemCount);
+/* device-resident geometry: dptr is HIP device memory on the device's GPU; no upload happens at commit.
+   [ref: rtcore_geometry.h:175, the reference's entry point for its own GPU (SYCL) device] */
+RTC_API void rtcSetSharedGeometryBufferHostDevice(RTCGeometry geometry, enum RTCBufferType type, unsigned int slot,
+                                                  enum RTCFormat format, const void* ptr, const void* dptr,
+                                                  size_t byteOffset, size_t byteStride, size_t itemCount);
 RTC_API void* rtcSetNewGeometryBuffer(RTCGeometry geometry, enum RTCBufferType type, unsigned int slot,
                                       enum RTCFormat format, size_t byteStride, size_t itemCount);
 RTC_API void* rtcGetGeometryBufferData(RTCGeometry geometry, enum RTCBufferType type, unsigned int slot);

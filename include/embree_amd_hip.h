@@ -1,0 +1,103 @@
+/* embree_amd_hip.h -- the thin C ABI between the host object model and the HIP kernels.
+ *
+ * Plain pointers and sizes only (no C++ / torch types).  Everything that touches the GPU
+ * goes through these entry points; include/embree4/rtcore.h (the Embree-4 C API) is built
+ * on top of them in embree_amd/csrc/rtcore_api.cpp.  Both sets live in libembree4_mi355.so.
+ *
+ * What each entry point replaces in the reference (paths relative to the reference root):
+ *   mi355_bvh_build        BVHNBuilderSAH<8,Triangle4>::build      kernels/bvh/bvh_builder_sah.cpp:112-193
+ *                          (createPrimRefArray builders/primrefgen.cpp:35-57, BuilderT::recurse
+ *                          builders/bvh_builder_sah.h:214-308, CreateLeaf bvh_builder_sah.cpp:32-55)
+ *   mi355_trace_closest    BVHNIntersector1<8,..>::intersect       kernels/bvh/bvh_intersector1.cpp:32-114
+ *   mi355_trace_any        BVHNIntersector1<8,..>::occluded        kernels/bvh/bvh_intersector1.cpp:117-197
+ *   mi355_trace_*_packet   BVHNIntersectorKHybrid::intersect/occluded  kernels/bvh/bvh_intersector_hybrid.cpp:106-369,600-783
+ *   mi355_trace_stats      STAT3 counters                          kernels/common/stat.h:9-19
+ * All functions return 0 on success or a hipError_t value (>0); mi355_last_error() gives text.
+ */
+#ifndef EMBREE_AMD_HIP_H
+#define EMBREE_AMD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI355_API __attribute__((visibility("default")))
+
+typedef struct mi355_bvh* mi355_bvh_t;
+
+/* One triangle mesh, buffers RESIDENT ON THE DEVICE (the host object model uploads them in
+   rtcCommitGeometry, or the application passes device memory directly).
+   Layout rules are the reference's (TriangleMesh::setBuffer, kernels/common/scene_triangle_mesh.cpp:35-80):
+   vertices float3 with byte stride >= 12 (4-byte aligned), indices uint3 with byte stride >= 12. */
+typedef struct mi355_mesh {
+  const void* d_vertices; size_t vertex_stride; uint32_t num_vertices;
+  const void* d_indices;  size_t index_stride;  uint32_t num_triangles;
+  uint32_t geom_id;       /* value reported in RTCHit.geomID */
+  uint32_t mask;          /* geometry mask, tested against RTCRay.mask (default 1, kernels/common/geometry.cpp:48) */
+} mi355_mesh;
+
+typedef struct mi355_build_params {
+  uint32_t sah_block_shift;  /* SAH cost counts ceil(n / 2^shift) leaf blocks; reference: 2 (Triangle4).  default 2 */
+  uint32_t min_leaf;         /* never split sets of <= min_leaf triangles; reference: 4.                    default 4 */
+  uint32_t max_leaf;         /* largest leaf; reference: 28 (7 Triangle4 blocks); encoding limit 32.        default 28 */
+  uint32_t small_threshold;  /* sub-trees of <= this many triangles are finished by one wavefront in LDS.   default 1024 */
+  float    trav_cost;        /* reference travCost = 1 */
+  float    int_cost;         /* reference intCost  = 1 */
+  uint32_t reserved[2];
+} mi355_build_params;
+
+typedef struct mi355_bvh_info {
+  uint64_t num_triangles;    /* valid triangles in the tree (invalid ones are skipped like the reference) */
+  uint64_t num_nodes;        /* 8-wide quantised inner nodes (128 B each) */
+  uint64_t num_leaves;
+  uint64_t num_binary_nodes; /* intermediate binary SAH tree */
+  uint64_t bytes_nodes, bytes_triangles;
+  float    bounds_lower[3], bounds_upper[3];
+  float    sah;              /* (sum inner area*travCost + sum leaf area*blocks*intCost) / root area */
+  float    build_ms;         /* GPU time of the last build (hipEvent), excluding host->device uploads */
+  uint32_t root_ref, top_levels, max_leaf, depth;
+} mi355_bvh_info;
+
+MI355_API void mi355_default_build_params(mi355_build_params* p);
+MI355_API const char* mi355_last_error(void);
+MI355_API int mi355_device_count(void);
+MI355_API int mi355_device_name(int device, char* out, size_t n);
+
+/* Build: blocking. `stream` is a hipStream_t or NULL. */
+MI355_API int mi355_bvh_build(int device, const mi355_mesh* meshes, uint32_t num_meshes,
+                              const mi355_build_params* params, void* stream, mi355_bvh_t* out);
+MI355_API void mi355_bvh_destroy(mi355_bvh_t bvh);
+MI355_API int mi355_bvh_get_info(mi355_bvh_t bvh, mi355_bvh_info* info);
+/* Copies the tree to host memory for validation (tests): nodes = num_nodes*128 B, tris = num_triangles*48 B. */
+MI355_API int mi355_bvh_download(mi355_bvh_t bvh, void* nodes, size_t nodes_bytes, void* tris, size_t tris_bytes);
+
+/* Ray queries on DEVICE-resident AoS arrays (RTCRayHit = 96 B / RTCRay = 48 B records, byte_stride apart).
+   Asynchronous on `stream`.  Per-ray contract = rtcIntersect1 / rtcOccluded1. */
+MI355_API int mi355_trace_closest(mi355_bvh_t bvh, void* d_rayhit, uint32_t count, size_t byte_stride, void* stream);
+MI355_API int mi355_trace_any(mi355_bvh_t bvh, void* d_ray, uint32_t count, size_t byte_stride, void* stream);
+/* SoA packets RTCRayHitK / RTCRayK (K = 4, 8, 16) on the device; d_valid = K ints per packet (-1 = active)
+   or NULL for all-active; num_packets packets, packet_stride bytes apart. */
+MI355_API int mi355_trace_closest_packet(mi355_bvh_t bvh, const int* d_valid, void* d_rayhitK, uint32_t K,
+                                         uint32_t num_packets, size_t packet_stride, void* stream);
+MI355_API int mi355_trace_any_packet(mi355_bvh_t bvh, const int* d_valid, void* d_rayK, uint32_t K,
+                                     uint32_t num_packets, size_t packet_stride, void* stream);
+/* Counting build of the same kernels (blocking): out[0]=inner nodes visited, out[1]=leaf visits,
+   out[2]=triangle records fetched, out[3]=rays, out[4]=stack entries spilled to global memory,
+   out[5]=max stack depth.  any_hit != 0 selects the occlusion kernel.  The rays ARE traced (results written). */
+MI355_API int mi355_trace_stats(mi355_bvh_t bvh, void* d_rays, uint32_t count, size_t byte_stride, int any_hit,
+                                uint64_t out[8]);
+
+/* raw device memory helpers for hosts without a HIP binding (ctypes tests / bench) */
+MI355_API int mi355_malloc(int device, size_t bytes, void** d_ptr);
+MI355_API int mi355_free(void* d_ptr);
+MI355_API int mi355_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes);
+MI355_API int mi355_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes);
+MI355_API int mi355_synchronize(void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
