@@ -40,8 +40,9 @@ rtcTraversableOccluded1 rtcTraversableOccluded4 rtcTraversableOccluded8 rtcTrave
 rtcIntersect1M rtcOccluded1M rtcIntersect1MDevice rtcOccluded1MDevice""".split()
 MI355_SYMBOLS = """mi355_default_build_params mi355_last_error mi355_device_count mi355_device_name mi355_bvh_build
 mi355_bvh_destroy mi355_bvh_get_info mi355_bvh_download mi355_trace_closest mi355_trace_any
-mi355_trace_closest_packet mi355_trace_any_packet mi355_trace_stats mi355_malloc mi355_free mi355_memcpy_h2d
-mi355_memcpy_d2h mi355_synchronize""".split()
+mi355_trace_closest_packet mi355_trace_any_packet mi355_trace_stats mi355_trace_timed mi355_malloc mi355_free mi355_memcpy_h2d
+mi355_memcpy_d2h mi355_synchronize mi355_device_synchronize mi355_memcpy_d2d_async mi355_stream_create
+mi355_stream_destroy mi355_event_create mi355_event_record mi355_event_elapsed_ms mi355_event_destroy""".split()
 
 
 class BuildParams(C.Structure):
@@ -86,7 +87,9 @@ def load():
     if not os.path.exists(LIB_PATH):
         from . import build as _build
         _build.build()
-    L = C.CDLL(LIB_PATH)
+    # RTLD_NOW (+ -z now at link time): every hip* symbol binds to the ROCm runtime this library was linked
+    # against at load time, before any other package could bring a second HIP runtime into the process
+    L = C.CDLL(LIB_PATH, mode=os.RTLD_NOW | os.RTLD_LOCAL)
     vp, u32, sz = C.c_void_p, C.c_uint32, C.c_size_t
     L.rtcNewDevice.restype = vp
     L.rtcNewDevice.argtypes = [C.c_char_p]
@@ -146,6 +149,7 @@ def load():
     L.mi355_bvh_download.argtypes = [vp, vp, sz, vp, sz]
     L.mi355_trace_closest.argtypes = [vp, vp, u32, sz, vp]
     L.mi355_trace_any.argtypes = [vp, vp, u32, sz, vp]
+    L.mi355_trace_timed.argtypes = [vp, vp, u32, sz, C.c_int, vp, vp, vp]
     L.mi355_trace_stats.argtypes = [vp, vp, u32, sz, C.c_int, C.POINTER(C.c_uint64)]
     L.mi355_malloc.argtypes = [C.c_int, sz, C.POINTER(vp)]
     L.mi355_free.argtypes = [vp]
@@ -153,6 +157,14 @@ def load():
     L.mi355_memcpy_d2h.argtypes = [vp, vp, sz]
     L.mi355_synchronize.argtypes = [vp]
     L.mi355_default_build_params.argtypes = [C.POINTER(BuildParams)]
+    L.mi355_device_synchronize.argtypes = [C.c_int]
+    L.mi355_memcpy_d2d_async.argtypes = [vp, vp, sz, vp]
+    L.mi355_stream_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.mi355_stream_destroy.argtypes = [vp]
+    L.mi355_event_create.argtypes = [C.POINTER(vp)]
+    L.mi355_event_record.argtypes = [vp, vp]
+    L.mi355_event_elapsed_ms.argtypes = [vp, vp, C.POINTER(C.c_float)]
+    L.mi355_event_destroy.argtypes = [vp]
     _lib = L
     return L
 
@@ -168,6 +180,10 @@ class Device:
 
     def __init__(self, config=""):
         self.L = load()
+        self.gpu = 0
+        for tok in config.replace(" ", ",").split(","):
+            if tok.startswith("gpu="):
+                self.gpu = int(tok[4:])
         self.h = self.L.rtcNewDevice(config.encode())
         if not self.h:
             code = self.L.rtcGetDeviceError(None)
@@ -186,7 +202,7 @@ class Device:
 
     def name(self):
         buf = C.create_string_buffer(256)
-        self.L.mi355_device_name(0, buf, 256)
+        self.L.mi355_device_name(self.gpu, buf, 256)
         return buf.value.decode()
 
     def release(self):
@@ -251,7 +267,8 @@ class Scene:
         g = L.rtcNewGeometry(self.dev.h, RTC_GEOMETRY_TYPE_TRIANGLE)
         self.dev.check()
         if device_resident:
-            dv, dt = DeviceArray.from_numpy(np.concatenate([v.ravel(), np.zeros(4, np.float32)])), DeviceArray.from_numpy(t)
+            dv = DeviceArray.from_numpy(np.concatenate([v.ravel(), np.zeros(4, np.float32)]), self.dev.gpu)
+            dt = DeviceArray.from_numpy(t, self.dev.gpu)
             self._keep += [dv, dt]
             L.rtcSetSharedGeometryBufferHostDevice(g, RTC_BUFFER_TYPE_VERTEX, 0, RTC_FORMAT_FLOAT3, None, dv.ptr, 0, 12, v.shape[0])
             L.rtcSetSharedGeometryBufferHostDevice(g, RTC_BUFFER_TYPE_INDEX, 0, RTC_FORMAT_UINT3, None, dt.ptr, 0, 12, t.shape[0])

@@ -798,4 +798,12 @@ int mi355_free(void* d) { HIP_TRY(hipFree(d)); return 0; }
 int mi355_memcpy_h2d(void* d, const void* h, size_t n) { HIP_TRY(hipMemcpy(d, h, n, hipMemcpyHostToDevice)); return 0; }
 int mi355_memcpy_d2h(void* h, const void* d, size_t n) { HIP_TRY(hipMemcpy(h, d, n, hipMemcpyDeviceToHost)); return 0; }
 int mi355_synchronize(void* stream) { HIP_TRY(hipStreamSynchronize((hipStream_t)stream)); return 0; }
+int mi355_device_synchronize(int device) { HIP_TRY(hipSetDevice(device)); HIP_TRY(hipDeviceSynchronize()); return 0; }
+int mi355_memcpy_d2d_async(void* d, const void* s, size_t n, void* stream) { HIP_TRY(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, (hipStream_t)stream)); return 0; }
+int mi355_stream_create(int device, void** stream) { HIP_TRY(hipSetDevice(device)); hipStream_t s; HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking)); *stream = (void*)s; return 0; }
+int mi355_stream_destroy(void* stream) { HIP_TRY(hipStreamDestroy((hipStream_t)stream)); return 0; }
+int mi355_event_create(void** e) { hipEvent_t ev; HIP_TRY(hipEventCreate(&ev)); *e = (void*)ev; return 0; }
+int mi355_event_record(void* e, void* stream) { HIP_TRY(hipEventRecord((hipEvent_t)e, (hipStream_t)stream)); return 0; }
+int mi355_event_elapsed_ms(void* a, void* b, float* ms) { HIP_TRY(hipEventSynchronize((hipEvent_t)b)); HIP_TRY(hipEventElapsedTime(ms, (hipEvent_t)a, (hipEvent_t)b)); return 0; }
+int mi355_event_destroy(void* e) { HIP_TRY(hipEventDestroy((hipEvent_t)e)); return 0; }
 }

@@ -335,7 +335,8 @@ __global__ void packet_scatter(PacketArgs p, int withHit) {
 // ------------------------------------------------------------------------------------- host side
 namespace mi355 {
 
-static int launch_trace(Bvh* b, void* d_rays, uint32_t count, size_t stride, bool any, hipStream_t s, uint64_t* statsOut) {
+static int launch_trace(Bvh* b, void* d_rays, uint32_t count, size_t stride, bool any, hipStream_t s, uint64_t* statsOut,
+                        hipEvent_t evStart = nullptr, hipEvent_t evStop = nullptr) {
   if (count == 0) return 0;
   if (stride < (any ? 48u : 96u) || (stride & 15u) || ((uintptr_t)d_rays & 15u)) return set_error(hipErrorInvalidValue, "ray array must be 16-byte aligned with a 16-byte-multiple stride");
   HIP_TRY(hipSetDevice(b->device));
@@ -360,8 +361,10 @@ static int launch_trace(Bvh* b, void* d_rays, uint32_t count, size_t stride, boo
     HIP_TRY(hipStreamSynchronize(s));
     return 0;
   }
+  if (evStart) HIP_TRY(hipEventRecord(evStart, s));
   if (any) hipLaunchKernelGGL((trace_kernel<true, false>), dim3(blocks), dim3(BLOCK), 0, s, a);
   else     hipLaunchKernelGGL((trace_kernel<false, false>), dim3(blocks), dim3(BLOCK), 0, s, a);
+  if (evStop) HIP_TRY(hipEventRecord(evStop, s));
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -398,6 +401,9 @@ int mi355_trace_closest(mi355_bvh_t bvh, void* d, uint32_t n, size_t stride, voi
 }
 int mi355_trace_any(mi355_bvh_t bvh, void* d, uint32_t n, size_t stride, void* stream) {
   return mi355::launch_trace((mi355::Bvh*)bvh, d, n, stride, true, (hipStream_t)stream, nullptr);
+}
+int mi355_trace_timed(mi355_bvh_t bvh, void* d, uint32_t n, size_t stride, int any_hit, void* stream, void* ev_start, void* ev_stop) {
+  return mi355::launch_trace((mi355::Bvh*)bvh, d, n, stride, any_hit != 0, (hipStream_t)stream, nullptr, (hipEvent_t)ev_start, (hipEvent_t)ev_stop);
 }
 int mi355_trace_stats(mi355_bvh_t bvh, void* d, uint32_t n, size_t stride, int any_hit, uint64_t out[8]) {
   for (int i = 0; i < 8; i++) out[i] = 0;

@@ -78,6 +78,10 @@ MI355_API int mi355_bvh_download(mi355_bvh_t bvh, void* nodes, size_t nodes_byte
    Asynchronous on `stream`.  Per-ray contract = rtcIntersect1 / rtcOccluded1. */
 MI355_API int mi355_trace_closest(mi355_bvh_t bvh, void* d_rayhit, uint32_t count, size_t byte_stride, void* stream);
 MI355_API int mi355_trace_any(mi355_bvh_t bvh, void* d_ray, uint32_t count, size_t byte_stride, void* stream);
+/* Same launch with a HIP event recorded on `stream` immediately before and after the traversal kernel
+   (after the 4-byte cursor reset), so that the interval is the kernel alone.  any_hit selects the kernel. */
+MI355_API int mi355_trace_timed(mi355_bvh_t bvh, void* d_rays, uint32_t count, size_t byte_stride, int any_hit,
+                                void* stream, void* ev_start, void* ev_stop);
 /* SoA packets RTCRayHitK / RTCRayK (K = 4, 8, 16) on the device; d_valid = K ints per packet (-1 = active)
    or NULL for all-active; num_packets packets, packet_stride bytes apart. */
 MI355_API int mi355_trace_closest_packet(mi355_bvh_t bvh, const int* d_valid, void* d_rayhitK, uint32_t K,
@@ -95,7 +99,16 @@ MI355_API int mi355_malloc(int device, size_t bytes, void** d_ptr);
 MI355_API int mi355_free(void* d_ptr);
 MI355_API int mi355_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes);
 MI355_API int mi355_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes);
-MI355_API int mi355_synchronize(void* stream);
+MI355_API int mi355_synchronize(void* stream);            /* hipStreamSynchronize (NULL = default stream) */
+MI355_API int mi355_device_synchronize(int device);         /* hipDeviceSynchronize */
+MI355_API int mi355_memcpy_d2d_async(void* d_dst, const void* d_src, size_t bytes, void* stream);
+MI355_API int mi355_stream_create(int device, void** stream);
+MI355_API int mi355_stream_destroy(void* stream);
+/* HIP events for timing a region ON THE STREAM THE KERNELS RUN ON (bench.py roofline leg) */
+MI355_API int mi355_event_create(void** event);
+MI355_API int mi355_event_record(void* event, void* stream);
+MI355_API int mi355_event_elapsed_ms(void* start, void* stop, float* ms);   /* synchronises on `stop` */
+MI355_API int mi355_event_destroy(void* event);
 
 #ifdef __cplusplus
 }
