@@ -424,7 +424,7 @@ def test_full_size_properties(api, dev, crown_full):
     NgGot = np.stack([got["Ng_x"][idx], got["Ng_y"][idx], got["Ng_z"][idx]], -1)
     assert np.abs(NgGot - Ng).max() <= 1e-4 * np.abs(Ng).max() + 1e-12
     P = O + tt[:, None] * D
-    w = np.linalg.solve(np.stack([e1, e2, Ng], -1), P - tri[:, 0])
+    w = np.linalg.solve(np.stack([e1, e2, Ng], -1), (P - tri[:, 0])[..., None])[..., 0]
     assert np.abs(w[:, 0] - got["u"][idx]).max() < 1e-3 and np.abs(w[:, 1] - got["v"][idx]).max() < 1e-3
     # (2) idempotence: tracing the result again (tfar = hit distance, inclusive) changes nothing
     again = got.copy()
