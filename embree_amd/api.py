@@ -353,7 +353,8 @@ class Scene:
         rc = self.L.mi355_trace_stats(self.bvh(), dptr, count, stride, int(any_hit), out)
         if rc:
             raise RuntimeError(self.L.mi355_last_error().decode())
-        return dict(nodes=out[0], leaves=out[1], tris=out[2], rays=out[3], spills=out[4], max_depth=out[5])
+        return dict(nodes=out[0], leaves=out[1], tris=out[2], rays=out[3], spills=out[4], max_depth=out[5],
+                    wave_iters=out[6], both_branches=out[7])
 
     def release(self):
         if self.h:

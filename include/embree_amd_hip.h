@@ -90,7 +90,7 @@ MI355_API int mi355_trace_any_packet(mi355_bvh_t bvh, const int* d_valid, void* 
                                      uint32_t num_packets, size_t packet_stride, void* stream);
 /* Counting build of the same kernels (blocking): out[0]=inner nodes visited, out[1]=leaf visits,
    out[2]=triangle records fetched, out[3]=rays, out[4]=stack entries spilled to global memory,
-   out[5]=max stack depth.  any_hit != 0 selects the occlusion kernel.  The rays ARE traced (results written). */
+   out[5]=max stack depth, out[6]=wave loop iterations, out[7]=iterations in which a wave ran both the node and the leaf branch.  any_hit != 0 selects the occlusion kernel.  The rays ARE traced (results written). */
 MI355_API int mi355_trace_stats(mi355_bvh_t bvh, void* d_rays, uint32_t count, size_t byte_stride, int any_hit,
                                 uint64_t out[8]);
 

@@ -1,0 +1,68 @@
+"""A/B timing helper for the GPU box (not a pytest file).
+  [MI355_TRACE_VARIANT=1|2] [MI355_TRACE_BLOCKS_PER_CU=n] python tests/gpu_perf.py [--config k=v,..] [--phi 158] [--any]
+Prints kernel time (HIP events around the kernel), visit statistics and a checksum of the results."""
+import argparse
+import ctypes as C
+import hashlib
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from embree_amd import api, workloads as W                       # noqa: E402
+from embree_amd.rtypes import RAYHIT_DTYPE, RAY_DTYPE, rays_of   # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--config", default="")
+ap.add_argument("--phi", type=int, default=158)
+ap.add_argument("--reps", type=int, default=10)
+ap.add_argument("--any", action="store_true")
+ap.add_argument("--primary", action="store_true")
+ap.add_argument("--tag", default="")
+a = ap.parse_args()
+L = api.load()
+dev = api.Device(a.config)
+meshes = W.synthetic_crown(num_phi=a.phi)
+s = api.Scene(dev)
+for v, t in meshes:
+    s.add_triangle_mesh(v, t, device_resident=True)
+s.commit()
+s.commit()
+info = s.info()
+prim = W.crown_camera_rays(meshes, 1024, 1024)
+d = api.DeviceArray.from_numpy(prim)
+s.intersect1M_device(d.ptr, prim.shape[0])
+L.mi355_device_synchronize(0)
+tr = d.download(RAYHIT_DTYPE)
+rays = prim if a.primary else W.diffuse_bounce_rays(tr, meshes)
+if a.any:
+    rays = rays_of(rays)
+M, rec = rays.shape[0], rays.dtype.itemsize
+pristine = api.DeviceArray.from_numpy(rays)
+work = api.DeviceArray(rays.nbytes)
+e0, e1 = C.c_void_p(), C.c_void_p()
+L.mi355_event_create(C.byref(e0))
+L.mi355_event_create(C.byref(e1))
+ms = []
+for i in range(a.reps + 2):
+    L.mi355_memcpy_d2d_async(work.ptr, pristine.ptr, rays.nbytes, None)
+    rc = L.mi355_trace_timed(s.bvh(), work.ptr, M, rec, int(a.any), None, e0, e1)
+    assert rc == 0, L.mi355_last_error()
+    t = C.c_float()
+    L.mi355_event_elapsed_ms(e0, e1, C.byref(t))
+    if i >= 2:
+        ms.append(t.value)
+res = work.download(rays.dtype)
+L.mi355_memcpy_d2d_async(work.ptr, pristine.ptr, rays.nbytes, None)
+st = s.trace_stats(work.ptr, M, rec, a.any)
+alg = M * 48 + (0 if a.any else int((res["geomID"] != 0xFFFFFFFF).sum()) * 52) + st["nodes"] * 128 + st["tris"] * 48
+best = min(ms)
+print("PERF %-28s variant=%s cfg='%s' build=%.2fms nodes=%d leaves=%d | kernel min %.3f avg %.3f ms -> %.1f Mrays/s | "
+      "alg %.0f B/ray %.0f GB/s frac %.3f | per ray: nodes %.2f leaves %.2f tris %.2f | wave_iters %d both %.2f spills %d depth %d | md5 %s"
+      % (a.tag, os.environ.get("MI355_TRACE_VARIANT", "2"), a.config, info["build_ms"], info["num_nodes"], info["num_leaves"], best,
+         float(np.mean(ms)), M / best / 1e3, alg / M, alg / best / 1e6, alg / best / 1e6 / 8000.0, st["nodes"] / M, st["leaves"] / M,
+         st["tris"] / M, st["wave_iters"], st["both_branches"] / max(1, st["wave_iters"]), st["spills"], st["max_depth"],
+         hashlib.md5(res.tobytes()).hexdigest()[:10]), flush=True)
