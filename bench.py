@@ -17,7 +17,7 @@ uses torch.distributed (gloo) on the host.
 
 Printed JSON (rank 0, one line): metric/value/... as the driver contract, plus
   roofline      achieved = ALGORITHMIC bytes per launch / average kernel time measured with HIP events on the
-                launch stream.  bytes = rays*(48 read + 52 written on hit) + visited nodes*128 + fetched
+                launch stream.  bytes = rays*(48 read + 52 written on hit) + visited nodes*80 + fetched
                 triangle records*48 (visit counts from the counting build of the same kernel, same rays).
   cpu_baseline  the REAL reference (oracle/_ref, Embree 4.4.1 AVX2) looping rtcIntersect1 over the same
                 rays on all host threads (kind "reference"), or the scalar C restatement on a sample (kind "port").
@@ -90,7 +90,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--rays", type=int, default=1 << 20)
     ap.add_argument("--phi", type=int, default=158, help="sphere tessellation of the synthetic crown (158 -> 4.76M triangles)")
-    ap.add_argument("--config", default="", help="extra rtcNewDevice config, e.g. leaf_block_shift=3,max_leaf=8")
+    ap.add_argument("--config", default="", help="extra rtcNewDevice config, e.g. max_leaf=2,int_cost=0.5")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     args = ap.parse_args()
 
@@ -155,7 +155,7 @@ def main():
     result = dstat.download(RAYHIT_DTYPE)
     dstat.free()
     nhit = int((result["geomID"] != INVALID_ID).sum())
-    alg_bytes = M * 48 + nhit * 52 + st["nodes"] * 128 + st["tris"] * 48
+    alg_bytes = M * 48 + nhit * 52 + st["nodes"] * 80 + st["tris"] * 48
 
     def barrier():
         if dist:
@@ -208,7 +208,8 @@ def main():
                          "frac": round(alg_bytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
                          "kernel": "trace_kernel<closest>", "kernel_ms_avg": round(avg_ms, 4), "kernel_ms_min": round(float(np.min(kernel_ms)), 4),
                          "algorithmic_bytes_per_launch": int(alg_bytes),
-                         "per_ray": {"nodes": round(st["nodes"] / M, 2), "leaf_visits": round(st["leaves"] / M, 2),
+                         "per_ray": {"nodes": round(st["nodes"] / M, 2), "node_step_simd_util": round(st["nodes"] / max(1, 64 * st["node_blocks"]), 3),
+                                     "tri_step_simd_util": round(st["tris"] / max(1, 64 * st["tri_blocks"]), 3),
                                      "triangles": round(st["tris"] / M, 2), "bytes": round(alg_bytes / M, 1)}},
             "build": {"metric": "BVH build Mprims/s", "gpu_build_ms": round(float(np.min(build_ms)), 3),
                       "mprims_per_s_gpu": round(ntri / (float(np.min(build_ms)) * 1e-3) / 1e6, 1),

@@ -70,11 +70,11 @@ class RTCBounds(C.Structure):
                 ("upper_x", C.c_float), ("upper_y", C.c_float), ("upper_z", C.c_float), ("align1", C.c_float)]
 
 
-NODE_DTYPE = np.dtype([("org", "<f4", (3,)), ("exp", "u1", (3,)), ("count", "u1"), ("child", "<u4", (8, 3)),
-                       ("pad", "<u4", (4,))])
+NODE_DTYPE = np.dtype([("org", "<f4", (3,)), ("exp", "u1", (3,)), ("imask", "u1"), ("childBase", "<u4"), ("triBase", "<u4"),
+                       ("meta", "u1", (8,)), ("qlo", "u1", (3, 8)), ("qhi", "u1", (3, 8))])
 TRI_DTYPE = np.dtype([("v0", "<f4", (3,)), ("e1", "<f4", (3,)), ("e2", "<f4", (3,)), ("primID", "<u4"),
                       ("geomID", "<u4"), ("mask", "<u4")])
-assert NODE_DTYPE.itemsize == 128 and TRI_DTYPE.itemsize == 48
+assert NODE_DTYPE.itemsize == 80 and TRI_DTYPE.itemsize == 48
 
 _lib = None
 
@@ -353,8 +353,8 @@ class Scene:
         rc = self.L.mi355_trace_stats(self.bvh(), dptr, count, stride, int(any_hit), out)
         if rc:
             raise RuntimeError(self.L.mi355_last_error().decode())
-        return dict(nodes=out[0], leaves=out[1], tris=out[2], rays=out[3], spills=out[4], max_depth=out[5],
-                    wave_iters=out[6], both_branches=out[7])
+        return dict(nodes=out[0], tris=out[1], rays=out[2], spills=out[3], max_depth=out[4], wave_iters=out[5],
+                    node_blocks=out[6], tri_blocks=out[7])
 
     def release(self):
         if self.h:

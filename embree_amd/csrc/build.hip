@@ -62,7 +62,7 @@ struct WideItem { uint32_t bnode, node; };
 struct Counters {
   uint32_t numPrims, numBNodes, numSegsNext, numChunks, numSmall, numWide, numWideNext, numLeaves;
   uint32_t bounds[12];                          // scene geom lo/hi + centroid lo/hi (ordered uint)
-  uint32_t overflow, rootRef, pad0, pad1;
+  uint32_t overflow, rootRef, numTrisOut, pad1;
   float sahSum;
 };
 struct Params { uint32_t shift, minLeaf, maxLeaf, small; float travCost, intCost; };
@@ -468,71 +468,98 @@ __device__ void sort_leaf(uint2* ids, uint32_t b, uint32_t e) {
   }
 }
 
-__global__ void wide_root(const BNode* bnodes, uint2* finalIds, WideItem* items, Counters* ctr, Params prm) {
-  const BNode b = bnodes[0];
-  if (make_leaf(b, prm)) {
-    sort_leaf(finalIds, b.begin, b.end);
-    ctr->rootRef = mi355_leaf_ref(b.begin, b.end - b.begin);
-    ctr->numLeaves = 1; ctr->numWide = 0; ctr->numWideNext = 0;
-    ctr->sahSum = prm.intCost * (float)((b.end - b.begin + (1u << prm.shift) - 1u) >> prm.shift);
-  } else {
-    items[0].bnode = 0; items[0].node = 0;
-    ctr->rootRef = 0; ctr->numWide = 1; ctr->numWideNext = 0; ctr->numLeaves = 0; ctr->sahSum = 0.0f;
-  }
+__global__ void wide_root(WideItem* items, Counters* ctr) {
+  items[0].bnode = 0; items[0].node = 0;                       // the root is always CNode 0
+  ctr->rootRef = 0; ctr->numWide = 1; ctr->numWideNext = 0; ctr->numLeaves = 0; ctr->numTrisOut = 0; ctr->sahSum = 0.0f;
 }
 
-__global__ __launch_bounds__(64) void wide_level(const WideItem* items, uint32_t numItems, const BNode* bnodes, QNode* nodes,
-                                                 uint2* finalIds, WideItem* next, Counters* ctr, Params prm, uint32_t maxNodes, float rootArea) {
+// One thread per 8-wide node.  Children: the reference's greedy "split the child with the largest half-area until 8
+// children" (bvh_builder_sah.h:247-272) on the binary tree; each child becomes a leaf slot (<= 3 triangles, decided by
+// the leaf-vs-split SAH test) or an inner slot.  New for the lane-per-ray traversal: children are PLACED in the slot
+// whose octant fits their position (greedy assignment on dot(child centre - node centre, octant signs)), inner
+// children get consecutive node indices in slot order and the triangles of all leaf slots one consecutive TriRec range.
+__global__ __launch_bounds__(64) void wide_level(const WideItem* items, uint32_t numItems, const BNode* bnodes, CNode* nodes,
+                                                 uint2* finalIds, uint2* outIds, WideItem* next, Counters* ctr, Params prm,
+                                                 uint32_t maxNodes, float rootArea) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= numItems) return;
   const WideItem it = items[t];
   const BNode root = bnodes[it.bnode];
-  uint32_t ch[8]; uint32_t nch = 2; ch[0] = root.left; ch[1] = root.right;
-  // greedy: split the child with the largest half-area until 8 children (bvh_builder_sah.h:247-272)
-  while (nch < 8u) {
-    float bestArea = -__builtin_inff(); int best = -1;
-    for (uint32_t i = 0; i < nch; i++) {
-      const BNode c = bnodes[ch[i]];
-      if (c.end - c.begin <= prm.minLeaf || c.left == NIL) continue;
-      const float ar = bnode_area(c);
-      if (ar > bestArea) { bestArea = ar; best = (int)i; }
+  uint32_t ch[8]; uint32_t nch;
+  if (root.left == NIL || make_leaf(root, prm)) { nch = 1; ch[0] = it.bnode; }     // only the tree root can be a leaf itself
+  else {
+    nch = 2; ch[0] = root.left; ch[1] = root.right;
+    while (nch < 8u) {
+      float bestArea = -__builtin_inff(); int best = -1;
+      for (uint32_t i = 0; i < nch; i++) {
+        const BNode c = bnodes[ch[i]];
+        if (c.end - c.begin <= prm.minLeaf || c.left == NIL) continue;
+        const float ar = bnode_area(c);
+        if (ar > bestArea) { bestArea = ar; best = (int)i; }
+      }
+      if (best < 0) break;
+      const BNode c = bnodes[ch[best]];
+      ch[best] = c.left; ch[nch++] = c.right;
     }
-    if (best < 0) break;
-    const BNode c = bnodes[ch[best]];
-    ch[best] = c.left; ch[nch++] = c.right;
   }
-  // sort children by size, largest first (std::sort(..., std::greater), :275); stable on ties
-  uint32_t cnt[8];
-  for (uint32_t i = 0; i < nch; i++) { const BNode c = bnodes[ch[i]]; cnt[i] = c.end - c.begin; }
-  for (uint32_t i = 1; i < nch; i++) {
-    const uint32_t x = ch[i], cx = cnt[i]; uint32_t j = i;
-    while (j > 0 && cnt[j - 1] < cx) { ch[j] = ch[j - 1]; cnt[j] = cnt[j - 1]; j--; }
-    ch[j] = x; cnt[j] = cx;
-  }
-  float lo[8][3], hi[8][3]; uint32_t ref[8];
+  float lo[8][3], hi[8][3]; bool leaf[8]; uint32_t cb[8], ce[8];
   float olo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, ohi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
   float sah = 0.0f;
   for (uint32_t i = 0; i < nch; i++) {
     const BNode c = bnodes[ch[i]];
     for (int d = 0; d < 3; d++) { lo[i][d] = c.lo[d]; hi[i][d] = c.hi[d]; olo[d] = fminf(olo[d], c.lo[d]); ohi[d] = fmaxf(ohi[d], c.hi[d]); }
+    cb[i] = c.begin; ce[i] = c.end;
+    leaf[i] = make_leaf(c, prm);
     const float A = bnode_area(c);
-    if (make_leaf(c, prm)) {
-      sort_leaf(finalIds, c.begin, c.end);
-      ref[i] = mi355_leaf_ref(c.begin, c.end - c.begin);
-      atomicAdd(&ctr->numLeaves, 1u);
-      sah += prm.intCost * A * (float)((c.end - c.begin + (1u << prm.shift) - 1u) >> prm.shift);
-    } else {
-      const uint32_t idx = atomicAdd(&ctr->numWide, 1u);
-      if (idx >= maxNodes) { ctr->overflow = 2u; ref[i] = MI355_EMPTY_REF; continue; }
-      ref[i] = idx;
-      const uint32_t k = atomicAdd(&ctr->numWideNext, 1u);
-      next[k].bnode = ch[i]; next[k].node = idx;
-      sah += prm.travCost * A;
-    }
+    sah += leaf[i] ? prm.intCost * A * (float)((c.end - c.begin + (1u << prm.shift) - 1u) >> prm.shift) : prm.travCost * A;
   }
   if (rootArea > 0.0f) atomicAdd(&ctr->sahSum, sah / rootArea);
-  // quantise: plane = org + q * 2^(e-127), lower rounded down, upper rounded up, verified in fp32
-  QNode qn; memset(&qn, 0, sizeof(qn));
+
+  // ---- slot assignment: repeatedly take the (child, slot) pair with the largest dot(centre offset, octant signs)
+  uint32_t slotOf[8], childAt[8];
+  for (int s = 0; s < 8; s++) childAt[s] = NIL;
+  {
+    uint32_t freeSlots = 0xFFu, todo = (1u << nch) - 1u;
+    float cx[8][3];
+    for (uint32_t i = 0; i < nch; i++) for (int d = 0; d < 3; d++) cx[i][d] = (lo[i][d] + hi[i][d]) - (olo[d] + ohi[d]);   // 2 x centre offset
+    for (uint32_t k = 0; k < nch; k++) {
+      float best = -__builtin_inff(); uint32_t bi = 0, bs = 0;
+      for (uint32_t i = 0; i < nch; i++) {
+        if (!((todo >> i) & 1u)) continue;
+        for (uint32_t s = 0; s < 8u; s++) {
+          if (!((freeSlots >> s) & 1u)) continue;
+          const float c = ((s & 1u) ? cx[i][0] : -cx[i][0]) + ((s & 2u) ? cx[i][1] : -cx[i][1]) + ((s & 4u) ? cx[i][2] : -cx[i][2]);
+          if (c > best || best == -__builtin_inff()) { best = c; bi = i; bs = s; }
+        }
+      }
+      slotOf[bi] = bs; childAt[bs] = bi; todo &= ~(1u << bi); freeSlots &= ~(1u << bs);
+    }
+  }
+  // ---- numbering: inner children consecutive in slot order, leaf triangles consecutive in slot order
+  uint32_t imask = 0, nInner = 0, nTri = 0, triOfs[8];
+  for (uint32_t s = 0; s < 8u; s++) {
+    const uint32_t i = childAt[s]; if (i == NIL) continue;
+    if (leaf[i]) { triOfs[s] = nTri; nTri += ce[i] - cb[i]; } else { imask |= 1u << s; nInner++; }
+  }
+  uint32_t childBase = 0, triBase = 0;
+  if (nInner) {
+    childBase = atomicAdd(&ctr->numWide, nInner);
+    if (childBase + nInner > maxNodes) { ctr->overflow = 2u; return; }
+    const uint32_t k = atomicAdd(&ctr->numWideNext, nInner);
+    uint32_t j = 0;
+    for (uint32_t s = 0; s < 8u; s++) if ((imask >> s) & 1u) { next[k + j].bnode = ch[childAt[s]]; next[k + j].node = childBase + j; j++; }
+  }
+  if (nTri) {
+    triBase = atomicAdd(&ctr->numTrisOut, nTri);
+    atomicAdd(&ctr->numLeaves, nch - nInner);
+    for (uint32_t s = 0; s < 8u; s++) {
+      const uint32_t i = childAt[s]; if (i == NIL || !leaf[i]) continue;
+      sort_leaf(finalIds, cb[i], ce[i]);
+      for (uint32_t j = cb[i]; j < ce[i]; j++) outIds[triBase + triOfs[s] + (j - cb[i])] = finalIds[j];
+    }
+  }
+  // ---- quantise: plane = org + q * 2^(e-127), lower rounded down, upper rounded up, verified in fp32
+  CNode qn; memset(&qn, 0, sizeof(qn));
   uint32_t ex[3];
   for (int d = 0; d < 3; d++) {
     qn.org[d] = olo[d];
@@ -553,26 +580,24 @@ __global__ __launch_bounds__(64) void wide_level(const WideItem* items, uint32_t
     ex[d] = (uint32_t)e;
     qn.exp[d] = (uint8_t)e;
   }
-  qn.count = (uint8_t)nch;
-  for (uint32_t i = 0; i < 8u; i++) {
-    uint32_t ql[3] = {255, 255, 255}, qh[3] = {0, 0, 0}; uint32_t r = MI355_EMPTY_REF;
-    if (i < nch) {
-      r = ref[i];
-      for (int d = 0; d < 3; d++) {
-        const float s = __uint_as_float(ex[d] << 23);
-        float a = floorf((lo[i][d] - olo[d]) / s); if (a < 0.0f) a = 0.0f; if (a > 255.0f) a = 255.0f;
-        while (a > 0.0f && fmaf(a, s, olo[d]) > lo[i][d]) a -= 1.0f;
-        float b = ceilf((hi[i][d] - olo[d]) / s); if (b < 0.0f) b = 0.0f;
-        while (b < 255.0f && fmaf(b, s, olo[d]) < hi[i][d]) b += 1.0f;
-        if (b > 255.0f) b = 255.0f;
-        ql[d] = (uint32_t)a; qh[d] = (uint32_t)b;
-      }
+  qn.imask = (uint8_t)imask; qn.childBase = childBase; qn.triBase = triBase;
+  for (uint32_t s = 0; s < 8u; s++) {
+    const uint32_t i = childAt[s];
+    if (i == NIL) { for (int d = 0; d < 3; d++) { qn.qlo[d][s] = 255; qn.qhi[d][s] = 0; } qn.meta[s] = 0; continue; }
+    for (int d = 0; d < 3; d++) {
+      const float sc = __uint_as_float(ex[d] << 23);
+      float a = floorf((lo[i][d] - olo[d]) / sc); if (a < 0.0f) a = 0.0f; if (a > 255.0f) a = 255.0f;
+      while (a > 0.0f && fmaf(a, sc, olo[d]) > lo[i][d]) a -= 1.0f;
+      float b = ceilf((hi[i][d] - olo[d]) / sc); if (b < 0.0f) b = 0.0f;
+      while (b < 255.0f && fmaf(b, sc, olo[d]) < hi[i][d]) b += 1.0f;
+      if (b > 255.0f) b = 255.0f;
+      qn.qlo[d][s] = (uint8_t)a; qn.qhi[d][s] = (uint8_t)b;
     }
-    qn.child[i][0] = ql[0] | (ql[1] << 8) | (ql[2] << 16) | (qh[0] << 24);
-    qn.child[i][1] = qh[1] | (qh[2] << 8);
-    qn.child[i][2] = r;
+    if (leaf[i]) qn.meta[s] = (uint8_t)((((1u << (ce[i] - cb[i])) - 1u) << 5) | triOfs[s]);
+    else qn.meta[s] = (uint8_t)((1u << 5) | (24u + s));
   }
-  nodes[it.node] = qn;
+  uint4* dst = (uint4*)(nodes + it.node); const uint4* src = (const uint4*)&qn;
+  for (int k = 0; k < 5; k++) dst[k] = src[k];
 }
 
 // --------------------------------------------------------------------------------- K5 tri_records
@@ -614,7 +639,7 @@ TraceScratch* Bvh::scratch_for(hipStream_t s) {
   if (it != scratch.end()) return &it->second;
   TraceScratch sc;
   if (hipMalloc((void**)&sc.counter, 256) != hipSuccess) return nullptr;
-  if (hipMalloc(&sc.spill, trace_spill_bytes(numCUs)) != hipSuccess) return nullptr;
+  if (hipMalloc(&sc.spill, trace_spill_bytes(numCUs, info.depth)) != hipSuccess) return nullptr;
   if (hipMalloc((void**)&sc.stats, 64) != hipSuccess) return nullptr;
   return &(scratch[s] = sc);
 }
@@ -645,7 +670,7 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
     g.nv = m.num_vertices; g.nt = m.num_triangles; g.geomID = m.geom_id; g.mask = m.mask; g.primOffset = (uint32_t)total;
     total += m.num_triangles; gd.push_back(g);
   }
-  if (total >= (1ull << 26)) return set_error(hipErrorInvalidValue, "more than 2^26 triangles are not supported by the 32-bit leaf reference");
+  if (total >= (1ull << 31)) return set_error(hipErrorInvalidValue, "more than 2^31 triangles are not supported by the 32-bit triangle index");
   mi355_bvh_info& info = bvh->info; memset(&info, 0, sizeof(info));
   info.max_leaf = prm.maxLeaf; info.root_ref = MI355_EMPTY_REF;
   for (int d = 0; d < 3; d++) { info.bounds_lower[d] = INFINITY; info.bounds_upper[d] = -INFINITY; }
@@ -657,11 +682,11 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
   const uint32_t maxSegs = N / prm.small + 1024u, maxSmall = 8u * (N / prm.small) + 1024u, maxChunks = N / CHUNK + maxSegs + 16u;
   const uint32_t maxWide = N + 64u;
   DevBuf<PrimRef> bufA, bufB; DevBuf<uint2> finalIds; DevBuf<BNode> bnodes; DevBuf<Seg> segs0, segs1; DevBuf<uint32_t> bins;
-  DevBuf<Chunk> chunks; DevBuf<SmallEntry> small; DevBuf<Counters> ctr; DevBuf<WideItem> w0, w1; DevBuf<QNode> wnodes;
+  DevBuf<Chunk> chunks; DevBuf<SmallEntry> small; DevBuf<Counters> ctr; DevBuf<WideItem> w0, w1; DevBuf<CNode> wnodes; DevBuf<uint2> outIds;
   HIP_TRY(bufA.alloc(N)); HIP_TRY(bufB.alloc(N)); HIP_TRY(finalIds.alloc(N)); HIP_TRY(bnodes.alloc(2ull * N + 2));
   HIP_TRY(segs0.alloc(maxSegs)); HIP_TRY(segs1.alloc(maxSegs)); HIP_TRY(bins.alloc((size_t)maxSegs * BINS_WORDS));
   HIP_TRY(chunks.alloc(maxChunks)); HIP_TRY(small.alloc(maxSmall)); HIP_TRY(ctr.alloc(1));
-  HIP_TRY(w0.alloc(maxWide)); HIP_TRY(w1.alloc(maxWide)); HIP_TRY(wnodes.alloc(maxWide));
+  HIP_TRY(w0.alloc(maxWide)); HIP_TRY(w1.alloc(maxWide)); HIP_TRY(wnodes.alloc(maxWide)); HIP_TRY(outIds.alloc(N));
 
   hipEvent_t ev0, ev1; HIP_TRY(hipEventCreate(&ev0)); HIP_TRY(hipEventCreate(&ev1));
   struct EvGuard { hipEvent_t a, b; ~EvGuard() { hipEventDestroy(a); hipEventDestroy(b); } } evg{ev0, ev1};
@@ -728,12 +753,12 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
 
   // ---- wide collapse, level by level
   const float rootArea = fmaf(ghi[0] - glo[0], (ghi[1] - glo[1]) + (ghi[2] - glo[2]), (ghi[1] - glo[1]) * (ghi[2] - glo[2]));
-  hipLaunchKernelGGL(wide_root, dim3(1), dim3(1), 0, st, bnodes.p, finalIds.p, w0.p, ctr.p, prm);
+  hipLaunchKernelGGL(wide_root, dim3(1), dim3(1), 0, st, w0.p, ctr.p);
   uint32_t numItems = 0, depth = 0;
   HIP_TRY(hipMemcpyAsync(&numItems, &ctr.p->numWide, 4, hipMemcpyDeviceToHost, st)); HIP_TRY(hipStreamSynchronize(st));
   WideItem* wc = w0.p; WideItem* wn = w1.p;
   while (numItems > 0) {
-    hipLaunchKernelGGL(wide_level, dim3((numItems + 63u) / 64u), dim3(64), 0, st, wc, numItems, bnodes.p, wnodes.p, finalIds.p, wn, ctr.p, prm, maxWide, rootArea);
+    hipLaunchKernelGGL(wide_level, dim3((numItems + 63u) / 64u), dim3(64), 0, st, wc, numItems, bnodes.p, wnodes.p, finalIds.p, outIds.p, wn, ctr.p, prm, maxWide, rootArea);
     HIP_TRY(hipGetLastError());
     uint32_t tmp[2];
     HIP_TRY(hipMemcpyAsync(tmp, &ctr.p->numWideNext, 4, hipMemcpyDeviceToHost, st));
@@ -750,16 +775,16 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
   const uint32_t numNodes = h.numWide;
   HIP_TRY(hipMalloc(&bvh->d_tris, (size_t)n * sizeof(TriRec) + 128));
   if (numNodes) {
-    HIP_TRY(hipMalloc(&bvh->d_nodes, (size_t)numNodes * sizeof(QNode)));
-    HIP_TRY(hipMemcpyAsync(bvh->d_nodes, wnodes.p, (size_t)numNodes * sizeof(QNode), hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMalloc(&bvh->d_nodes, (size_t)numNodes * sizeof(CNode)));
+    HIP_TRY(hipMemcpyAsync(bvh->d_nodes, wnodes.p, (size_t)numNodes * sizeof(CNode), hipMemcpyDeviceToDevice, st));
   }
-  hipLaunchKernelGGL(tri_records, dim3((n + 255u) / 256u), dim3(256), 0, st, finalIds.p, n, dGeoms.p, (TriRec*)bvh->d_tris);
+  hipLaunchKernelGGL(tri_records, dim3((n + 255u) / 256u), dim3(256), 0, st, outIds.p, n, dGeoms.p, (TriRec*)bvh->d_tris);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(ev1, st)); HIP_TRY(hipEventSynchronize(ev1));
   float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
   bvh->root = h.rootRef;
   info.root_ref = h.rootRef; info.num_nodes = numNodes; info.num_leaves = h.numLeaves; info.num_binary_nodes = h.numBNodes;
-  info.bytes_nodes = (uint64_t)numNodes * sizeof(QNode); info.bytes_triangles = (uint64_t)n * sizeof(TriRec);
+  info.bytes_nodes = (uint64_t)numNodes * sizeof(CNode); info.bytes_triangles = (uint64_t)n * sizeof(TriRec);
   info.sah = h.sahSum + (numNodes ? prm.travCost : 0.0f); info.build_ms = ms; info.depth = depth;
   guard.ok = true; *out = bvh;
   return 0;
@@ -771,7 +796,7 @@ extern "C" {
 
 void mi355_default_build_params(mi355_build_params* p) {
   memset(p, 0, sizeof(*p));
-  p->sah_block_shift = 2; p->min_leaf = 4; p->max_leaf = 28; p->small_threshold = 1024; p->trav_cost = 1.0f; p->int_cost = 1.0f;
+  p->sah_block_shift = 0; p->min_leaf = 1; p->max_leaf = 3; p->small_threshold = 1024; p->trav_cost = 1.0f; p->int_cost = 1.0f;
 }
 const char* mi355_last_error(void) { return mi355::g_err.c_str(); }
 int mi355_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }

@@ -25,7 +25,7 @@ struct TraceScratch {
 struct Bvh {
   int device = 0;
   int numCUs = 256;
-  void* d_nodes = nullptr;       // QNode[numNodes]
+  void* d_nodes = nullptr;       // CNode[numNodes]
   void* d_tris = nullptr;        // TriRec[numTris]
   uint32_t root = 0xFFFFFFFFu;
   mi355_bvh_info info{};
@@ -35,6 +35,7 @@ struct Bvh {
   ~Bvh();
 };
 
-size_t trace_spill_bytes(int numCUs);
+#define MI355_MAX_BLOCKS_PER_CU 8
+size_t trace_spill_bytes(int numCUs, uint32_t depth);   // stack spill area of one persistent launch (trace.hip)
 
 }  // namespace mi355

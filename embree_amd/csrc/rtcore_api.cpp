@@ -236,6 +236,8 @@ void parse_config(Device* d, const char* cfg) {
     else if (k == "min_leaf") d->build.min_leaf = (uint32_t)atoi(v.c_str());
     else if (k == "leaf_block_shift") d->build.sah_block_shift = (uint32_t)atoi(v.c_str());
     else if (k == "small_threshold") d->build.small_threshold = (uint32_t)atoi(v.c_str());
+    else if (k == "int_cost") d->build.int_cost = (float)atof(v.c_str());
+    else if (k == "trav_cost") d->build.trav_cost = (float)atof(v.c_str());
     // CPU-only keys of the reference (threads, isa, tri_accel, hugepages, ...) are accepted and ignored
   }
 }

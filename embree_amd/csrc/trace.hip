@@ -9,141 +9,115 @@
 // triangle_intersector_moeller.h:69-111) and Intersect1EpilogM / Occluded1EpilogM
 // (kernels/geometry/intersector_epilog.h:235-368).
 //
-// MI355X mapping -- "one ray per octet":
-//   The reference runs one ray across the 8 lanes of an AVX register (8 children tested at once,
-//   4-8 triangles at once).  A 64-lane wavefront is 8 such units: lanes 8k..8k+7 form an *octet*
-//   that owns one ray; lane j tests child j of the 8-wide node / triangle j of the leaf.
-//     * node fetch  = each octet reads ONE 128-byte line (16 B header broadcast + 12 B per lane):
-//                     coalesced, 1 line per ray-step instead of 64 divergent lines per instruction
-//     * child order = each hit lane ranks its entry distance against the other 7 with DPP
-//                     quad_perm / row_half_mirror moves (no LDS, no sorting network, no branches);
-//                     rank 0 is descended, ranks 1.. are scattered to the stack in one ds_write
-//     * stack       = per-octet, 32 entries in LDS (+96 spill entries in HBM), popped with a
-//                     broadcast ds_read; entries carry the entry distance for culling
-//     * leaves      = up to 8 triangles tested in parallel, octet-min picks the winner
-//     * persistent threads: a wave pulls chunks of rays from a global counter and re-fills
-//                     finished octets immediately (ballot + popcount), so a long ray stalls 7
-//                     neighbours at most, never 63
-//   All arithmetic is fp32; the triangle test keeps the reference's FMA pattern (compiled with
-//   -ffp-contract=off so only the explicit fmaf()s fuse).  MFMA is not used: there is no dense
-//   contraction anywhere on this path.
+// MI355X mapping -- one ray per lane, persistent waves:
+//   * a wave owns 64 rays; every lane walks its own ray through the 8-wide compressed tree of bvh_common.h.
+//     A node visit is five 16-byte loads per lane (80-byte node) and ~230 VALU instructions for the wave
+//     (8 slab tests on dequantised planes: v_cvt_f32_ubyte + v_fma per plane, v_max3/v_min3 per child);
+//     a triangle visit is three 16-byte loads and the reference's Moeller-Trumbore arithmetic.
+//   * traversal order needs no sort: children are stored in the slot matching their octant, so the hit bits of
+//     a node, XOR-ed with the ray's octant, are already front to back.  The hits of one node are a 32-bit word
+//     (8 inner-node bits, 24 triangle bits); the per-lane stack holds {child base, hit word} pairs = one entry
+//     per tree level at most, 16 entries per lane in LDS ([entry][lane] so that lanes never bank-conflict),
+//     deeper levels spill to HBM (sized from the depth the builder reports, so it can never overflow).
+//   * persistent threads: a wave pulls ray indices from a global cursor whenever >= REFILL_MIN lanes are idle
+//     (one atomic per refill); triangle tests are postponed until >= TRI_MIN lanes have one pending, which keeps
+//     the two divergent code blocks (node step, triangle step) reasonably full.
+//   All arithmetic is fp32; the triangle test keeps the reference's operation order and FMA placement (compiled
+//   with -ffp-contract=off so only the explicit fmaf()s fuse).  MFMA is not used: no dense contraction here.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <map>
+#include <mutex>
+#include <utility>
 #include "bvh_common.h"
 #include "../../include/embree_amd_hip.h"
 #include "internal.h"
 
 namespace {
 
-constexpr int BLOCK = 256;                 // 4 waves
-constexpr int OCT_PER_BLOCK = BLOCK / 8;   // 32 rays in flight per block
-constexpr int STACK_LDS = 32;              // entries per octet kept in LDS
-constexpr int STACK_ROW = STACK_LDS + 1;   // +1 entry pad: octets pop different banks
-constexpr int STACK_GLB = 96;              // spill entries per octet in HBM
-constexpr int CHUNK = 16;                  // rays a wave reserves per atomic (2 per octet)
-constexpr uint32_t DONE = 0xFFFFFFFEu;     // octet has no current ray
-constexpr uint32_t ITER_CAP = 1u << 24;
-
-// ---- DPP moves inside an 8-lane octet -------------------------------------------------------
-#define QUAD_PERM(a, b, c, d) ((a) | ((b) << 2) | ((c) << 4) | ((d) << 6))
-constexpr int DPP_X1 = QUAD_PERM(1, 0, 3, 2);  // lane ^ 1
-constexpr int DPP_X2 = QUAD_PERM(2, 3, 0, 1);  // lane ^ 2
-constexpr int DPP_X3 = QUAD_PERM(3, 2, 1, 0);  // lane ^ 3
-constexpr int DPP_HM = 0x141;                  // row_half_mirror: lane -> 7 - lane (within 8)
-
-template <int CTRL>
-__device__ __forceinline__ uint32_t dpp_u(uint32_t v) {
-  return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
-}
-template <int CTRL>
-__device__ __forceinline__ float dpp_f(float v) { return __uint_as_float(dpp_u<CTRL>(__float_as_uint(v))); }
-
-__device__ __forceinline__ float oct_min(float v) {
-  v = fminf(v, dpp_f<DPP_X1>(v));
-  v = fminf(v, dpp_f<DPP_X2>(v));
-  v = fminf(v, dpp_f<DPP_HM>(v));
-  return v;
-}
-// number of the other 7 lanes of the octet whose key is smaller than mine
-__device__ __forceinline__ uint32_t oct_rank(uint32_t key) {
-  const uint32_t k7 = dpp_u<DPP_HM>(key);
-  uint32_t r = 0;
-  r += dpp_u<DPP_X1>(key) < key;
-  r += dpp_u<DPP_X2>(key) < key;
-  r += dpp_u<DPP_X3>(key) < key;
-  r += k7 < key;
-  r += dpp_u<DPP_X1>(k7) < key;
-  r += dpp_u<DPP_X2>(k7) < key;
-  r += dpp_u<DPP_X3>(k7) < key;
-  return r;
-}
+constexpr int BLOCK = 256;                 // 4 independent waves (no barriers); LDS = 4 x 16 x 64 x 8 B = 32 KiB
+constexpr int STACK_LDS = 16;              // stack entries per lane kept in LDS
+constexpr uint32_t ITER_CAP = 1u << 24;    // safety net only: a corrupt tree must not hang the GPU
+constexpr uint32_t REFILL_MIN_DEFAULT = 16;  // fetch new rays once this many lanes of a wave are idle   (env MI355_REFILL_MIN)
+constexpr uint32_t TRI_MIN_DEFAULT = 12;     // run the triangle block once this many lanes have one pending (env MI355_TRI_MIN)
 
 __device__ __forceinline__ float rcp_nr(float a) {  // v_rcp_f32 + one Newton step (reference: RCPPS + Newton, vfloat4_sse2.h:304)
   float r = __builtin_amdgcn_rcpf(a);
   return fmaf(r, fmaf(-a, r, 1.0f), r);
 }
 __device__ __forceinline__ float xor_sign(float a, uint32_t s) { return __uint_as_float(__float_as_uint(a) ^ s); }
+template <int J> __device__ __forceinline__ float ubyte(uint32_t w) { return (float)((w >> (8 * J)) & 0xFFu); }   // v_cvt_f32_ubyteJ
 
 struct TraceArgs {
-  const QNode* nodes;
-  const TriRec* tris;
-  uint32_t root;
+  const uint4* nodes;    // CNode[] as 5 x uint4
+  const float4* tris;    // TriRec[] as 3 x float4
+  uint32_t hasRoot;
   char* rays;            // AoS records
   uint32_t count;
   uint32_t stride;
   uint32_t* counter;     // global ray cursor (zeroed before launch)
-  uint2* spill;          // [gridDim.x * OCT_PER_BLOCK][STACK_GLB]
+  uint2* spill;          // [gridDim.x * BLOCK][spillPerLane]
+  uint32_t spillPerLane;
+  uint32_t refillMin, triMin;
   unsigned long long* stats;  // optional counters
 };
 
+// slab test of the 4 children whose quantised planes sit in one dword per plane; returns their contribution to the hit word.
+// The reference's fast node test compares exact fp32 planes (intersectNode<8>, node_intersector1.h:484-531); here the planes
+// are dequantised with two extra roundings, so the comparison gets 4 ulp of slack: a ray through the exact corner of a box
+// (cube corner of tutorials/triangle_geometry) must not lose the box to rounding.  Conservative = never wrong, only slower.
+__device__ __forceinline__ uint32_t test4(uint32_t nx, uint32_t ny, uint32_t nz, uint32_t fx, uint32_t fy, uint32_t fz, uint32_t meta4,
+                                          uint32_t octinv4, float adx, float ady, float adz, float bx, float by, float bz,
+                                          float tmin0, float tmax0) {
+  // meta byte: inner = 001 11sss (bits 3 and 4 set), leaf = ccc ooooo with offset <= 23, empty = 0
+  const uint32_t isInner4 = (meta4 & (meta4 << 1)) & 0x10101010u;
+  const uint32_t innerMask4 = (isInner4 >> 4) * 7u;                   // 0x07 in the bytes of inner slots
+  const uint32_t bitIndex4 = meta4 ^ (octinv4 & innerMask4);          // low 5 bits: position in the hit word
+  const uint32_t childBits4 = (meta4 >> 5) & 0x07070707u;             // inner: 1, leaf: unary triangle count, empty: 0
+  uint32_t hits = 0;
+#define MI355_CHILD(J)                                                                                         \
+  {                                                                                                            \
+    const float tnx = fmaf(ubyte<J>(nx), adx, bx), tny = fmaf(ubyte<J>(ny), ady, by), tnz = fmaf(ubyte<J>(nz), adz, bz); \
+    const float tfx = fmaf(ubyte<J>(fx), adx, bx), tfy = fmaf(ubyte<J>(fy), ady, by), tfz = fmaf(ubyte<J>(fz), adz, bz); \
+    const float tN = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, tmin0));                                                \
+    const float tF = fminf(fminf(tfx, tfy), fminf(tfz, tmax0));                                                \
+    const uint32_t cb = (childBits4 >> (8 * J)) & 0xFFu, bi = (bitIndex4 >> (8 * J)) & 0x1Fu;                  \
+    hits |= (tN <= tF * 1.00000048f) ? (cb << bi) : 0u;   /* 4 ulp of slack: see note above test4 */             \
+  }
+  MI355_CHILD(0) MI355_CHILD(1) MI355_CHILD(2) MI355_CHILD(3)
+#undef MI355_CHILD
+  return hits;
+}
+
 template <bool ANY, bool STATS>
 __global__ __launch_bounds__(BLOCK) void trace_kernel(TraceArgs a) {
-  __shared__ uint2 s_stack[OCT_PER_BLOCK * STACK_ROW];
+  __shared__ uint2 s_stack[BLOCK / 64][STACK_LDS][64];
 
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = tid & 63u;
-  const uint32_t sub = tid & 7u;          // child / triangle slot of this lane
-  const uint32_t oct = tid >> 3;          // octet within the block
-  const uint32_t octShift = lane & ~7u;   // position of this octet's byte in a 64-bit ballot
-  uint2* const myStack = s_stack + oct * STACK_ROW;
-  uint2* const mySpill = a.spill + ((size_t)blockIdx.x * OCT_PER_BLOCK + oct) * STACK_GLB;
+  uint2* const stk = &s_stack[tid >> 6][0][lane];                        // entry e of this lane: stk[e * 64]
+  uint2* const spill = a.spill + (size_t)(blockIdx.x * BLOCK + tid) * a.spillPerLane;
 
-  // wave-uniform ray chunk
-  uint32_t chunkNext = 0, chunkEnd = 0;
-  bool exhausted = false;
+  bool active = false, exhausted = false;
+  uint32_t rayIdx = 0, rmask = 0, octinv4 = 0, sp = 0;
+  uint32_t ngBase = 0, ngHits = 0, tgBase = 0, tgHits = 0;              // node group / triangle group of the current node
+  float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0, rdx = 0, rdy = 0, rdz = 0, tnear = 0, tnearTrav = 0, tfar = 0;
+  float hNgx = 0, hNgy = 0, hNgz = 0, hu = 0, hv = 0; uint32_t hprim = 0, hgeom = MI355_EMPTY_REF;
+  uint32_t stNodes = 0, stTris = 0, stRays = 0, stSpill = 0, stDepth = 0, stIter = 0, stNodeBlk = 0, stTriBlk = 0;
 
-  // per-octet state (replicated in its 8 lanes)
-  uint32_t cur = DONE, sp = 0, rayIdx = 0, rmask = 0;
-  float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0, rdx = 0, rdy = 0, rdz = 0;
-  float tnear = 0, tnearTrav = 0, tfar = 0;
-  bool retired = false, haveHit = false;
-  uint32_t winLane = 0;
-  // per-lane record of the last hit this lane committed
-  float hNgx = 0, hNgy = 0, hNgz = 0, hu = 0, hv = 0;
-  uint32_t hprim = 0, hgeom = 0;
-  // statistics (per lane, only sub==0 counts octet events)
-  uint32_t stNodes = 0, stLeaves = 0, stTris = 0, stRays = 0, stSpill = 0, stDepth = 0;
-
-  // the iteration cap is a safety net only (a corrupt tree must not hang the GPU); ~1e3-1e5 iterations are normal
   for (uint32_t iter = 0; iter < ITER_CAP; iter++) {
-    // ------------------------------------------------------------------ refill idle octets (all 64 lanes are active here)
+    // ------------------------------------------------------------------ 1. hand new rays to idle lanes
     {
-      bool idle = (cur == DONE) && !retired;
-      unsigned long long idleMask = __ballot(idle && sub == 0);
-      while (idleMask != 0ull) {
-        if (chunkNext >= chunkEnd) {
-          if (exhausted) break;
-          uint32_t base = 0;
-          if (lane == 0u) base = atomicAdd(a.counter, (uint32_t)CHUNK);
-          base = __builtin_amdgcn_readfirstlane(base);
-          if (base >= a.count) { exhausted = true; break; }
-          chunkNext = base;
-          chunkEnd = min(base + (uint32_t)CHUNK, a.count);
-        }
-        const uint32_t avail = chunkEnd - chunkNext;
-        const uint32_t myRank = (uint32_t)__popcll(idleMask & ((1ull << octShift) - 1ull));
-        if (idle && myRank < avail) {
-          rayIdx = chunkNext + myRank;
+      const unsigned long long idleMask = __ballot(!active);
+      const uint32_t nIdle = (uint32_t)__popcll(idleMask);
+      if (!exhausted && nIdle >= a.refillMin) {
+        uint32_t base = 0;
+        if (lane == 0u) base = atomicAdd(a.counter, nIdle);
+        base = __builtin_amdgcn_readfirstlane(base);
+        const uint32_t mine = base + (uint32_t)__popcll(idleMask & ((1ull << lane) - 1ull));
+        if (!active && mine < a.count) {
+          rayIdx = mine;
           const float4* rp = (const float4*)(a.rays + (size_t)rayIdx * a.stride);
           const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2];
           ox = r0.x; oy = r0.y; oz = r0.z; tnear = r0.w;
@@ -155,138 +129,120 @@ __global__ __launch_bounds__(BLOCK) void trace_kernel(TraceArgs a) {
           rdy = rcp_nr(fabsf(dy) < 1e-18f ? 1e-18f : dy);
           rdz = rcp_nr(fabsf(dz) < 1e-18f ? 1e-18f : dz);
           tnearTrav = fmaxf(tnear, 0.0f);
-          sp = 0; haveHit = false; winLane = 0;
-          cur = a.root;
-          if (a.root == MI355_EMPTY_REF) cur = DONE;           // empty scene: nothing is written
-          if (ANY && tfar < 0.0f) cur = DONE;                   // already occluded, bvh_intersector1.cpp:128
-          if (STATS && sub == 0) stRays++;
-          idle = (cur == DONE);                                 // a ray that finished instantly frees the octet again
+          // a ray travelling towards +x meets the children on the -x side first: priority of slot s = s ^ octinv
+          octinv4 = ((rdx < 0.0f ? 0u : 1u) | (rdy < 0.0f ? 0u : 2u) | (rdz < 0.0f ? 0u : 4u)) * 0x01010101u;
+          sp = 0; hgeom = MI355_EMPTY_REF;
+          ngBase = 0; ngHits = 0x80000000u; tgBase = 0; tgHits = 0;       // "the root is the one hit child of a virtual node"
+          active = a.hasRoot != 0u && !(ANY && tfar < 0.0f);              // empty scene / already occluded (bvh_intersector1.cpp:128)
+          if (STATS) stRays++;
         }
-        chunkNext += min(avail, (uint32_t)__popcll(idleMask));
-        idleMask = __ballot(idle && sub == 0);
+        if (base + nIdle >= a.count) exhausted = true;
       }
-      if (idle) retired = true;
+      if (__ballot(active) == 0ull) { if (exhausted) break; else continue; }
     }
-    if (__ballot(!retired) == 0ull) break;
+    if (STATS && lane == 0u) stIter++;
 
-    bool needPop = false;
-    if (!retired && cur != DONE) {
-      if (!mi355_is_leaf(cur)) {
-        // -------------------------------------------------------------- inner node: 8 children, one per lane
-        const char* np = (const char*)(a.nodes + cur);
-        const float4 hdr = *(const float4*)np;                       // org.xyz, exps (same address in all 8 lanes)
-        const uint32_t* cp = (const uint32_t*)(np + 16 + 12 * sub);  // my child: 12 B
-        const uint32_t w0 = cp[0], w1 = cp[1], cref = cp[2];
-        const uint32_t ex = __float_as_uint(hdr.w);
-        const float sx = __uint_as_float((ex & 0xFFu) << 23);
-        const float sy = __uint_as_float(((ex >> 8) & 0xFFu) << 23);
-        const float sz = __uint_as_float(((ex >> 16) & 0xFFu) << 23);
-        // t(q) = (org + q*s - O) * rdir = q*(s*rdir) + (org-O)*rdir
-        const float ax = sx * rdx, ay = sy * rdy, az = sz * rdz;
-        const float bx = (hdr.x - ox) * rdx, by = (hdr.y - oy) * rdy, bz = (hdr.z - oz) * rdz;
-        const float t0x = fmaf((float)(w0 & 0xFFu), ax, bx), t1x = fmaf((float)(w0 >> 24), ax, bx);
-        const float t0y = fmaf((float)((w0 >> 8) & 0xFFu), ay, by), t1y = fmaf((float)(w1 & 0xFFu), ay, by);
-        const float t0z = fmaf((float)((w0 >> 16) & 0xFFu), az, bz), t1z = fmaf((float)((w1 >> 8) & 0xFFu), az, bz);
-        const float tN = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), tnearTrav));
-        const float tF = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), fmaxf(tfar, 0.0f)));
-        const bool hit = (tN <= tF) && (cref != MI355_EMPTY_REF);
-        if (STATS && sub == 0) stNodes++;
-        const uint32_t hitBits = (uint32_t)(__ballot(hit) >> octShift) & 0xFFu;
-        if (hitBits == 0u) {
-          needPop = true;
-        } else {
-          // order hit children by entry distance (ties: lower slot first); the low 3 bits of the key are
-          // the slot, so keys are unique and <= the true distance (still a valid culling bound)
-          const uint32_t key = hit ? ((__float_as_uint(tN) & ~7u) | sub) : 0xFFFFFFFFu;
-          const uint32_t rank = oct_rank(key);
-          const uint32_t nhit = (uint32_t)__popc(hitBits);
-          // nearest child next; the others go to the stack, farthest deepest (traverseClosestHit,
-          // kernels/bvh/bvh_traverser1.h:311-433; any-hit keeps the same order instead of index order)
-          if (hit && rank != 0u) {
-            const uint32_t slot = sp + (nhit - 1u - rank);
-            const uint2 e = make_uint2(cref, key);
-            if (slot < (uint32_t)STACK_LDS) myStack[slot] = e;
-            else if (slot < (uint32_t)(STACK_LDS + STACK_GLB)) { mySpill[slot - STACK_LDS] = e; if (STATS) stSpill++; }
-          }
-          // broadcast the nearest child's ref: it is the hit lane with rank 0
-          const uint32_t first = (uint32_t)__builtin_ctz((uint32_t)(__ballot(hit && rank == 0u) >> octShift) & 0xFFu);
-          cur = __shfl(cref, (int)(octShift + first), 64);
-          sp = min(sp + nhit - 1u, (uint32_t)(STACK_LDS + STACK_GLB));
-          if (STATS) stDepth = max(stDepth, sp);
-        }
+    // ------------------------------------------------------------------ 2. nothing pending: pop a node group or finish the ray
+    if (active && tgHits == 0u && ngHits <= 0x00FFFFFFu) {
+      if (sp != 0u) {
+        sp--;
+        uint2 e = stk[min(sp, (uint32_t)(STACK_LDS - 1)) * 64u];
+        if (__builtin_expect(sp >= (uint32_t)STACK_LDS, 0)) e = spill[sp - STACK_LDS];
+        ngBase = e.x; ngHits = e.y;
       } else {
-        // -------------------------------------------------------------- leaf: up to 8 triangles per round
-        const uint32_t first = mi355_leaf_first(cur), cnt = mi355_leaf_count(cur);
-        if (STATS && sub == 0) stLeaves++;
-        bool occluded = false;
-        for (uint32_t base = 0; base < cnt; base += 8u) {
-          const uint32_t j = base + sub;
-          const bool tv = j < cnt;
-          const float4* tp = (const float4*)(a.tris + first + (tv ? j : 0u));
-          const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
-          if (STATS && tv) stTris++;
-          const float v0x = q0.x, v0y = q0.y, v0z = q0.z;
-          const float e1x = q0.w, e1y = q1.x, e1z = q1.y;
-          const float e2x = q1.z, e2y = q1.w, e2z = q2.x;
-          const uint32_t tprim = __float_as_uint(q2.y), tgeom = __float_as_uint(q2.z), tmask = __float_as_uint(q2.w);
-          // Moeller-Trumbore, same operation order and FMA placement as the reference
-          // (triangle_intersector_moeller.h:79-108; cross/dot: common/math/vec3.h:204,209)
-          const float Ngx = fmaf(e2y, e1z, -(e2z * e1y));
-          const float Ngy = fmaf(e2z, e1x, -(e2x * e1z));
-          const float Ngz = fmaf(e2x, e1y, -(e2y * e1x));
-          const float Cx = v0x - ox, Cy = v0y - oy, Cz = v0z - oz;
-          const float Rx = fmaf(Cy, dz, -(Cz * dy));
-          const float Ry = fmaf(Cz, dx, -(Cx * dz));
-          const float Rz = fmaf(Cx, dy, -(Cy * dx));
-          const float den = fmaf(Ngx, dx, fmaf(Ngy, dy, Ngz * dz));
-          const float absDen = fabsf(den);
-          const uint32_t sgn = __float_as_uint(den) & 0x80000000u;
-          const float U = xor_sign(fmaf(Rx, e2x, fmaf(Ry, e2y, Rz * e2z)), sgn);
-          const float V = xor_sign(fmaf(Rx, e1x, fmaf(Ry, e1y, Rz * e1z)), sgn);
-          const float T = xor_sign(fmaf(Ngx, Cx, fmaf(Ngy, Cy, Ngz * Cz)), sgn);
-          bool ok = tv && (den != 0.0f) && (U >= 0.0f) && (V >= 0.0f) && (U + V <= absDen);
-          ok = ok && (absDen * tnear < T) && (T <= absDen * tfar);    // strict at tnear, inclusive at tfar
-          ok = ok && ((tmask & rmask) != 0u);                            // EMBREE_RAY_MASK, intersector_epilog.h:256-262
-          if (ANY) {
-            if ((__ballot(ok) >> octShift) & 0xFFull) { occluded = true; break; }
-          } else {
-            const float rcpd = rcp_nr(absDen);
-            const float t = T * rcpd;
-            const float tc = ok ? t : __builtin_inff();
-            const float tmin = oct_min(tc);
-            const uint32_t winBits = (uint32_t)(__ballot(ok && tc == tmin) >> octShift) & 0xFFu;
-            if (winBits != 0u) {                                         // select_min: lowest lane among the minimum
-              const uint32_t w = (uint32_t)__builtin_ctz(winBits);
-              tfar = tmin; winLane = w; haveHit = true;
-              if (sub == w) { hNgx = Ngx; hNgy = Ngy; hNgz = Ngz; hu = U * rcpd; hv = V * rcpd; hprim = tprim; hgeom = tgeom; }
-            }
-          }
+        if (!ANY && hgeom != MI355_EMPTY_REF) {
+          char* rp = a.rays + (size_t)rayIdx * a.stride;
+          *(float*)(rp + 32) = tfar;
+          *(float4*)(rp + 48) = make_float4(hNgx, hNgy, hNgz, hu);
+          *(uint4*)(rp + 64) = make_uint4(__float_as_uint(hv), hprim, hgeom, MI355_EMPTY_REF);
+          *(uint32_t*)(rp + 80) = MI355_EMPTY_REF;
         }
-        if (ANY && occluded) {
-          if (sub == 0) *(float*)(a.rays + (size_t)rayIdx * a.stride + 32) = -__builtin_inff();
-          cur = DONE;
-        } else {
-          needPop = true;
-        }
+        active = false;
       }
+    }
 
-      // ---------------------------------------------------------------- pop (with distance culling)
-      while (needPop) {
-        if (sp == 0u) {
-          // ray finished: the lane that committed the last hit writes the record
-          if (!ANY && haveHit && sub == winLane) {
-            char* rp = a.rays + (size_t)rayIdx * a.stride;
-            *(float*)(rp + 32) = tfar;
-            *(float4*)(rp + 48) = make_float4(hNgx, hNgy, hNgz, hu);
-            *(uint4*)(rp + 64) = make_uint4(__float_as_uint(hv), hprim, hgeom, MI355_EMPTY_REF);
-            *(uint32_t*)(rp + 80) = MI355_EMPTY_REF;
+    // ------------------------------------------------------------------ 3. node step: open the nearest pending inner child
+    const bool doNode = active && tgHits == 0u && ngHits > 0x00FFFFFFu;
+    const bool anyNode = __ballot(doNode) != 0ull;
+    if (doNode) {
+      const uint32_t bit = 31u - (uint32_t)__clz((int)ngHits);
+      ngHits &= ~(1u << bit);
+      if (ngHits > 0x00FFFFFFu) {                                        // siblings left: keep the group for later
+        const uint2 e = make_uint2(ngBase, ngHits);
+        if (sp < (uint32_t)STACK_LDS) stk[sp * 64u] = e;
+        else { if (sp - STACK_LDS < a.spillPerLane) spill[sp - STACK_LDS] = e; if (STATS) stSpill++; }
+        sp++;
+        if (STATS) stDepth = max(stDepth, sp);
+      }
+      const uint32_t slot = (bit ^ octinv4) & 7u;
+      const uint32_t rel = (uint32_t)__popc(ngHits & ~(0xFFFFFFFFu << slot));   // low byte of the group word = imask
+      const uint4* np = a.nodes + (size_t)(ngBase + rel) * 5u;
+      const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
+      if (STATS) stNodes++;
+      // plane(q) = org + q * 2^(e-127);  t(q) = (plane - O) * rdir = q * (scale * rdir) + (org - O) * rdir
+      const float adx = __uint_as_float((n0.w & 0xFFu) << 23) * rdx;
+      const float ady = __uint_as_float(((n0.w >> 8) & 0xFFu) << 23) * rdy;
+      const float adz = __uint_as_float(((n0.w >> 16) & 0xFFu) << 23) * rdz;
+      const float bx = (__uint_as_float(n0.x) - ox) * rdx, by = (__uint_as_float(n0.y) - oy) * rdy, bz = (__uint_as_float(n0.z) - oz) * rdz;
+      // near / far planes by direction sign (TravRay nearX/farX, node_intersector1.h:40-57)
+      const bool sx = rdx < 0.0f, sy = rdy < 0.0f, sz = rdz < 0.0f;
+      const uint32_t nx0 = sx ? n3.z : n2.x, nx1 = sx ? n3.w : n2.y, fx0 = sx ? n2.x : n3.z, fx1 = sx ? n2.y : n3.w;
+      const uint32_t ny0 = sy ? n4.x : n2.z, ny1 = sy ? n4.y : n2.w, fy0 = sy ? n2.z : n4.x, fy1 = sy ? n2.w : n4.y;
+      const uint32_t nz0 = sz ? n4.z : n3.x, nz1 = sz ? n4.w : n3.y, fz0 = sz ? n3.x : n4.z, fz1 = sz ? n3.y : n4.w;
+      const float tmax0 = fmaxf(tfar, 0.0f);
+      const uint32_t hits = test4(nx0, ny0, nz0, fx0, fy0, fz0, n1.z, octinv4, adx, ady, adz, bx, by, bz, tnearTrav, tmax0) |
+                            test4(nx1, ny1, nz1, fx1, fy1, fz1, n1.w, octinv4, adx, ady, adz, bx, by, bz, tnearTrav, tmax0);
+      ngBase = n1.x; ngHits = (hits & 0xFF000000u) | (n0.w >> 24);
+      tgBase = n1.y; tgHits = hits & 0x00FFFFFFu;
+    }
+    if (STATS && lane == 0u && anyNode) stNodeBlk++;
+
+    // ------------------------------------------------------------------ 4. triangle steps (postponed while few lanes have one pending)
+    bool first = true;
+    for (;;) {
+      const bool doTri = active && tgHits != 0u;
+      const uint32_t nTri = (uint32_t)__popcll(__ballot(doTri));
+      if (nTri == 0u) break;
+      if (nTri < a.triMin && (anyNode || !first)) break;
+      first = false;
+      if (STATS && lane == 0u) stTriBlk++;
+      if (doTri) {
+        const uint32_t k = (uint32_t)__builtin_ctz(tgHits);
+        tgHits &= tgHits - 1u;
+        const float4* tp = a.tris + (size_t)(tgBase + k) * 3u;
+        const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
+        if (STATS) stTris++;
+        const float v0x = q0.x, v0y = q0.y, v0z = q0.z;
+        const float e1x = q0.w, e1y = q1.x, e1z = q1.y;
+        const float e2x = q1.z, e2y = q1.w, e2z = q2.x;
+        const uint32_t tprim = __float_as_uint(q2.y), tgeom = __float_as_uint(q2.z), tmask = __float_as_uint(q2.w);
+        // Moeller-Trumbore, same operation order and FMA placement as the reference
+        // (triangle_intersector_moeller.h:79-108; cross/dot: common/math/vec3.h:204,209)
+        const float Ngx = fmaf(e2y, e1z, -(e2z * e1y));
+        const float Ngy = fmaf(e2z, e1x, -(e2x * e1z));
+        const float Ngz = fmaf(e2x, e1y, -(e2y * e1x));
+        const float Cx = v0x - ox, Cy = v0y - oy, Cz = v0z - oz;
+        const float Rx = fmaf(Cy, dz, -(Cz * dy));
+        const float Ry = fmaf(Cz, dx, -(Cx * dz));
+        const float Rz = fmaf(Cx, dy, -(Cy * dx));
+        const float den = fmaf(Ngx, dx, fmaf(Ngy, dy, Ngz * dz));
+        const float absDen = fabsf(den);
+        const uint32_t sgn = __float_as_uint(den) & 0x80000000u;
+        const float U = xor_sign(fmaf(Rx, e2x, fmaf(Ry, e2y, Rz * e2z)), sgn);
+        const float V = xor_sign(fmaf(Rx, e1x, fmaf(Ry, e1y, Rz * e1z)), sgn);
+        const float T = xor_sign(fmaf(Ngx, Cx, fmaf(Ngy, Cy, Ngz * Cz)), sgn);
+        bool ok = (den != 0.0f) && (U >= 0.0f) && (V >= 0.0f) && (U + V <= absDen);
+        ok = ok && (absDen * tnear < T) && (T <= absDen * tfar);    // strict at tnear, inclusive at tfar
+        ok = ok && ((tmask & rmask) != 0u);                            // EMBREE_RAY_MASK, intersector_epilog.h:256-262
+        if (ok) {
+          if (ANY) {                                                   // Occluded1EpilogM: tfar = -inf, done
+            *(float*)(a.rays + (size_t)rayIdx * a.stride + 32) = -__builtin_inff();
+            active = false; tgHits = 0; ngHits = 0; sp = 0;
+          } else {                                                     // Intersect1EpilogM: t,u,v = T,U,V * rcp(absDen)
+            const float rcpd = rcp_nr(absDen);
+            tfar = T * rcpd; hu = U * rcpd; hv = V * rcpd;
+            hNgx = Ngx; hNgy = Ngy; hNgz = Ngz; hprim = tprim; hgeom = tgeom;
           }
-          cur = DONE;
-          needPop = false;
-        } else {
-          sp--;
-          const uint2 e = (sp < (uint32_t)STACK_LDS) ? myStack[sp] : mySpill[sp - STACK_LDS];
-          if (ANY || !(__uint_as_float(e.y) > tfar)) { cur = e.x; needPop = false; }   // pop skips dist > ray.tfar (:79)
         }
       }
     }
@@ -294,11 +250,13 @@ __global__ __launch_bounds__(BLOCK) void trace_kernel(TraceArgs a) {
 
   if (STATS) {
     atomicAdd(&a.stats[0], (unsigned long long)stNodes);
-    atomicAdd(&a.stats[1], (unsigned long long)stLeaves);
-    atomicAdd(&a.stats[2], (unsigned long long)stTris);
-    atomicAdd(&a.stats[3], (unsigned long long)stRays);
-    atomicAdd(&a.stats[4], (unsigned long long)stSpill);
-    atomicMax(&a.stats[5], (unsigned long long)stDepth);
+    atomicAdd(&a.stats[1], (unsigned long long)stTris);
+    atomicAdd(&a.stats[2], (unsigned long long)stRays);
+    atomicAdd(&a.stats[3], (unsigned long long)stSpill);
+    atomicMax(&a.stats[4], (unsigned long long)stDepth);
+    atomicAdd(&a.stats[5], (unsigned long long)stIter);
+    atomicAdd(&a.stats[6], (unsigned long long)stNodeBlk);
+    atomicAdd(&a.stats[7], (unsigned long long)stTriBlk);
   }
 }
 
@@ -335,41 +293,67 @@ __global__ void packet_scatter(PacketArgs p, int withHit) {
 // ------------------------------------------------------------------------------------- host side
 namespace mi355 {
 
+typedef void (*TraceFn)(TraceArgs);
+static uint32_t env_u32(const char* name, uint32_t def, uint32_t lo, uint32_t hi) {
+  const char* e = getenv(name); if (!e) return def;
+  const long v = atol(e); return v < (long)lo || v > (long)hi ? def : (uint32_t)v;
+}
+static TraceFn pick_kernel(bool any, bool stats) {
+  return any ? (stats ? trace_kernel<true, true> : trace_kernel<true, false>) : (stats ? trace_kernel<false, true> : trace_kernel<false, false>);
+}
+// persistent grid = exactly the blocks that are resident at once (a larger grid would run a second, ragged round)
+static uint32_t resident_blocks(Bvh* b, TraceFn fn) {
+  static std::mutex m; static std::map<std::pair<int, TraceFn>, uint32_t> cache;
+  std::lock_guard<std::mutex> lk(m);
+  auto key = std::make_pair(b->device, fn);
+  auto it = cache.find(key);
+  if (it != cache.end()) return it->second;
+  int perCU = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, (const void*)fn, BLOCK, 0) != hipSuccess || perCU < 1) perCU = 4;
+  if (perCU > MI355_MAX_BLOCKS_PER_CU) perCU = MI355_MAX_BLOCKS_PER_CU;
+  const char* e = getenv("MI355_TRACE_BLOCKS_PER_CU");
+  if (e && atoi(e) > 0 && atoi(e) <= MI355_MAX_BLOCKS_PER_CU) perCU = atoi(e);
+  return cache[key] = (uint32_t)b->numCUs * (uint32_t)perCU;
+}
+
+uint32_t trace_spill_per_lane(uint32_t depth) { return depth + 2u > (uint32_t)STACK_LDS ? depth + 2u - (uint32_t)STACK_LDS : 0u; }
+size_t trace_spill_bytes(int numCUs, uint32_t depth) {
+  return (size_t)numCUs * MI355_MAX_BLOCKS_PER_CU * BLOCK * trace_spill_per_lane(depth) * sizeof(uint2) + 256;
+}
+
 static int launch_trace(Bvh* b, void* d_rays, uint32_t count, size_t stride, bool any, hipStream_t s, uint64_t* statsOut,
                         hipEvent_t evStart = nullptr, hipEvent_t evStop = nullptr) {
   if (count == 0) return 0;
   if (stride < (any ? 48u : 96u) || (stride & 15u) || ((uintptr_t)d_rays & 15u)) return set_error(hipErrorInvalidValue, "ray array must be 16-byte aligned with a 16-byte-multiple stride");
   HIP_TRY(hipSetDevice(b->device));
-  // persistent grid: enough blocks to fill the chip (8 blocks of 256 threads per CU), never more than the rays need
-  const uint32_t maxBlocks = (uint32_t)b->numCUs * 8u;
-  uint32_t blocks = (count + OCT_PER_BLOCK - 1) / OCT_PER_BLOCK;
+  const TraceFn fn = pick_kernel(any, statsOut != nullptr);
+  const uint32_t maxBlocks = resident_blocks(b, fn);
+  uint32_t blocks = (count + BLOCK - 1) / BLOCK;
   if (blocks > maxBlocks) blocks = maxBlocks;
   TraceScratch* sc = b->scratch_for(s);
   if (!sc) return set_error(hipErrorOutOfMemory, "trace scratch allocation failed");
   HIP_TRY(hipMemsetAsync(sc->counter, 0, sizeof(uint32_t), s));
   TraceArgs a;
-  a.nodes = (const QNode*)b->d_nodes; a.tris = (const TriRec*)b->d_tris; a.root = b->root;
+  a.nodes = (const uint4*)b->d_nodes; a.tris = (const float4*)b->d_tris; a.hasRoot = b->root != MI355_EMPTY_REF ? 1u : 0u;
   a.rays = (char*)d_rays; a.count = count; a.stride = (uint32_t)stride;
-  a.counter = sc->counter; a.spill = (uint2*)sc->spill; a.stats = nullptr;
+  a.counter = sc->counter; a.spill = (uint2*)sc->spill; a.spillPerLane = trace_spill_per_lane(b->info.depth); a.stats = nullptr;
+  static const uint32_t refillMin = env_u32("MI355_REFILL_MIN", REFILL_MIN_DEFAULT, 1, 64), triMin = env_u32("MI355_TRI_MIN", TRI_MIN_DEFAULT, 1, 64);
+  a.refillMin = refillMin; a.triMin = triMin;
   if (statsOut) {
     HIP_TRY(hipMemsetAsync(sc->stats, 0, 8 * sizeof(uint64_t), s));
     a.stats = (unsigned long long*)sc->stats;
-    if (any) hipLaunchKernelGGL((trace_kernel<true, true>), dim3(blocks), dim3(BLOCK), 0, s, a);
-    else     hipLaunchKernelGGL((trace_kernel<false, true>), dim3(blocks), dim3(BLOCK), 0, s, a);
+    hipLaunchKernelGGL(fn, dim3(blocks), dim3(BLOCK), 0, s, a);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(statsOut, sc->stats, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     return 0;
   }
   if (evStart) HIP_TRY(hipEventRecord(evStart, s));
-  if (any) hipLaunchKernelGGL((trace_kernel<true, false>), dim3(blocks), dim3(BLOCK), 0, s, a);
-  else     hipLaunchKernelGGL((trace_kernel<false, false>), dim3(blocks), dim3(BLOCK), 0, s, a);
+  hipLaunchKernelGGL(fn, dim3(blocks), dim3(BLOCK), 0, s, a);
   if (evStop) HIP_TRY(hipEventRecord(evStop, s));
   HIP_TRY(hipGetLastError());
   return 0;
 }
-
-size_t trace_spill_bytes(int numCUs) { return (size_t)numCUs * 8u * OCT_PER_BLOCK * STACK_GLB * sizeof(uint2); }
 
 static int launch_packets(Bvh* b, const int* d_valid, void* d_pk, uint32_t K, uint32_t n, size_t pstride, bool any, hipStream_t s) {
   if (n == 0) return 0;

@@ -40,9 +40,9 @@ typedef struct mi355_mesh {
 } mi355_mesh;
 
 typedef struct mi355_build_params {
-  uint32_t sah_block_shift;  /* SAH cost counts ceil(n / 2^shift) leaf blocks; reference: 2 (Triangle4).  default 2 */
-  uint32_t min_leaf;         /* never split sets of <= min_leaf triangles; reference: 4.                    default 4 */
-  uint32_t max_leaf;         /* largest leaf; reference: 28 (7 Triangle4 blocks); encoding limit 32.        default 28 */
+  uint32_t sah_block_shift;  /* SAH cost counts ceil(n / 2^shift) leaf blocks; reference: 2 (Triangle4).  default 0 */
+  uint32_t min_leaf;         /* never split sets of <= min_leaf triangles; reference: 4.            default 1, max 3 */
+  uint32_t max_leaf;         /* largest leaf slot; reference: 28 (7 Triangle4 blocks); encoding limit 3.  default 3 */
   uint32_t small_threshold;  /* sub-trees of <= this many triangles are finished by one wavefront in LDS.   default 1024 */
   float    trav_cost;        /* reference travCost = 1 */
   float    int_cost;         /* reference intCost  = 1 */
@@ -51,7 +51,7 @@ typedef struct mi355_build_params {
 
 typedef struct mi355_bvh_info {
   uint64_t num_triangles;    /* valid triangles in the tree (invalid ones are skipped like the reference) */
-  uint64_t num_nodes;        /* 8-wide quantised inner nodes (128 B each) */
+  uint64_t num_nodes;        /* 8-wide quantised inner nodes (80 B each) */
   uint64_t num_leaves;
   uint64_t num_binary_nodes; /* intermediate binary SAH tree */
   uint64_t bytes_nodes, bytes_triangles;
@@ -71,7 +71,7 @@ MI355_API int mi355_bvh_build(int device, const mi355_mesh* meshes, uint32_t num
                               const mi355_build_params* params, void* stream, mi355_bvh_t* out);
 MI355_API void mi355_bvh_destroy(mi355_bvh_t bvh);
 MI355_API int mi355_bvh_get_info(mi355_bvh_t bvh, mi355_bvh_info* info);
-/* Copies the tree to host memory for validation (tests): nodes = num_nodes*128 B, tris = num_triangles*48 B. */
+/* Copies the tree to host memory for validation (tests): nodes = num_nodes*80 B, tris = num_triangles*48 B. */
 MI355_API int mi355_bvh_download(mi355_bvh_t bvh, void* nodes, size_t nodes_bytes, void* tris, size_t tris_bytes);
 
 /* Ray queries on DEVICE-resident AoS arrays (RTCRayHit = 96 B / RTCRay = 48 B records, byte_stride apart).
@@ -88,9 +88,11 @@ MI355_API int mi355_trace_closest_packet(mi355_bvh_t bvh, const int* d_valid, vo
                                          uint32_t num_packets, size_t packet_stride, void* stream);
 MI355_API int mi355_trace_any_packet(mi355_bvh_t bvh, const int* d_valid, void* d_rayK, uint32_t K,
                                      uint32_t num_packets, size_t packet_stride, void* stream);
-/* Counting build of the same kernels (blocking): out[0]=inner nodes visited, out[1]=leaf visits,
-   out[2]=triangle records fetched, out[3]=rays, out[4]=stack entries spilled to global memory,
-   out[5]=max stack depth, out[6]=wave loop iterations, out[7]=iterations in which a wave ran both the node and the leaf branch.  any_hit != 0 selects the occlusion kernel.  The rays ARE traced (results written). */
+/* Counting build of the same kernels (blocking): out[0]=inner nodes visited (80 B each), out[1]=triangle records
+   fetched (48 B each), out[2]=rays, out[3]=stack entries spilled to global memory, out[4]=max stack depth,
+   out[5]=wave loop iterations, out[6]=node-step blocks executed (per wave), out[7]=triangle-step blocks executed
+   (per wave); out[0] / (64 * out[6]) is the SIMD utilisation of the node step.  any_hit != 0 selects the occlusion
+   kernel.  The rays ARE traced (results written). */
 MI355_API int mi355_trace_stats(mi355_bvh_t bvh, void* d_rays, uint32_t count, size_t byte_stride, int any_hit,
                                 uint64_t out[8]);
 

@@ -1,28 +1,27 @@
-"""Structural validation of a downloaded MI355X BVH (QNode / TriRec arrays, see embree_amd/csrc/bvh_common.h).
+"""Structural validation of a downloaded MI355X BVH (CNode / TriRec arrays, see embree_amd/csrc/bvh_common.h).
 
 Checks what the traversal kernel relies on:
-  * every valid input triangle appears in exactly one leaf, with v0/e1/e2/ids/mask as TriangleM::fill would store them
-  * leaf ranges tile [0, num_triangles) without overlap; every leaf holds 1..max_leaf triangles
-  * every node is referenced exactly once; child slots are filled from 0 and `count` matches
+  * every valid input triangle appears in exactly one leaf slot, with v0/e1/e2/ids/mask as TriangleM::fill would store them
+  * the root is node 0; every other node is referenced exactly once, through childBase + rank of its slot in imask
+  * meta bytes: inner slots (1 << 5) | (24 + slot) and the imask bit set; leaf slots unary count (1..max_leaf) << 5 | offset,
+    offsets of a node's leaf slots tile [0, #triangles of the node) in slot order, <= 24 triangles per node; empty slots 0
   * each child's DECODED quantised box contains all triangles below it (conservative quantisation)
 """
+import sys
+
 import numpy as np
 
-LEAF = 0x80000000
 EMPTY = 0xFFFFFFFF
 
 
 def decode_child_boxes(node):
-    scale = (node["exp"].astype(np.uint32) << 23).view(np.float32)          # 2^(e-127)
-    w = node["child"]
-    qlo = np.stack([w[:, 0] & 0xFF, (w[:, 0] >> 8) & 0xFF, (w[:, 0] >> 16) & 0xFF], -1).astype(np.float32)
-    qhi = np.stack([w[:, 0] >> 24, w[:, 1] & 0xFF, (w[:, 1] >> 8) & 0xFF], -1).astype(np.float32)
-    lo = (node["org"][None, :] + qlo * scale[None, :]).astype(np.float32)
-    hi = (node["org"][None, :] + qhi * scale[None, :]).astype(np.float32)
-    return lo, hi, w[:, 2]
+    scale = (node["exp"].astype(np.uint32) << 23).view(np.float32)          # 2^(e-127), one per axis
+    lo = (node["org"][None, :] + node["qlo"].T.astype(np.float32) * scale[None, :]).astype(np.float32)   # [slot][axis]
+    hi = (node["org"][None, :] + node["qhi"].T.astype(np.float32) * scale[None, :]).astype(np.float32)
+    return lo, hi
 
 
-def validate(nodes, tris, root_ref, meshes, masks=None, geom_ids=None, max_leaf=32):
+def validate(nodes, tris, root_ref, meshes, masks=None, geom_ids=None, max_leaf=3):
     n_tris = tris.shape[0]
     # --- triangle records against the input meshes
     expect = {}
@@ -49,6 +48,7 @@ def validate(nodes, tris, root_ref, meshes, masks=None, geom_ids=None, max_leaf=
     if n_tris == 0:
         assert root_ref == EMPTY
         return dict(nodes=0, leaves=0, depth=0)
+    assert root_ref == 0 and nodes.shape[0] >= 1
     tv1 = tris["v0"] - tris["e1"]
     tv2 = tris["v0"] + tris["e2"]
     tlo = np.minimum(np.minimum(tris["v0"], tv1), tv2)
@@ -60,36 +60,48 @@ def validate(nodes, tris, root_ref, meshes, masks=None, geom_ids=None, max_leaf=
     node_seen = np.zeros(nodes.shape[0], np.int32)
     stats = dict(nodes=0, leaves=0, depth=0)
 
-    def visit(ref, depth):
-        """returns (lo, hi) actual bounds of everything below ref"""
+    def visit(idx, depth):
+        """returns (lo, hi) actual bounds of everything below node idx"""
         stats["depth"] = max(stats["depth"], depth)
-        if ref & LEAF:
-            first, cnt = (ref & 0x7FFFFFFF) >> 5, (ref & 31) + 1
-            assert cnt <= max_leaf and first + cnt <= n_tris, f"leaf ref {ref:#x}"
-            covered[first:first + cnt] += 1
-            ids = (tris["primID"][first:first + cnt].astype(np.uint64) << 32) | tris["geomID"][first:first + cnt]
-            assert (np.diff(ids.astype(np.int64)) > 0).all() or cnt == 1, "leaf not sorted by (primID, geomID)"
-            stats["leaves"] += 1
-            return tlo[first:first + cnt].min(0), thi[first:first + cnt].max(0)
-        assert ref < nodes.shape[0], f"node ref {ref} out of range"
-        node_seen[ref] += 1
+        assert idx < nodes.shape[0], f"node index {idx} out of range"
+        node_seen[idx] += 1
         stats["nodes"] += 1
-        nd = nodes[ref]
-        lo, hi, refs = decode_child_boxes(nd)
-        cnt = int(nd["count"])
-        assert 2 <= cnt <= 8, f"node {ref} count {cnt}"
-        assert (refs[:cnt] != EMPTY).all() and (refs[cnt:] == EMPTY).all(), f"node {ref} slots"
+        nd = nodes[idx]
+        lo, hi = decode_child_boxes(nd)
+        imask = int(nd["imask"])
         blo, bhi = np.full(3, np.inf, np.float32), np.full(3, -np.inf, np.float32)
-        for i in range(cnt):
-            clo, chi = visit(int(refs[i]), depth + 1)
-            assert (lo[i] <= clo + slack).all() and (hi[i] >= chi - slack).all(), \
-                f"node {ref} child {i}: decoded box {lo[i]}..{hi[i]} does not contain {clo}..{chi}"
+        next_ofs, rank, used = 0, 0, 0
+        for s in range(8):
+            m = int(nd["meta"][s])
+            if m == 0:
+                assert not (imask >> s) & 1, f"node {idx} slot {s}: empty slot flagged inner"
+                continue
+            used += 1
+            if (imask >> s) & 1:
+                assert m == (1 << 5) | (24 + s), f"node {idx} slot {s}: inner meta {m:#x}"
+                clo, chi = visit(int(nd["childBase"]) + rank, depth + 1)
+                rank += 1
+            else:
+                bits, ofs = m >> 5, m & 31
+                assert bits in (1, 3, 7), f"node {idx} slot {s}: unary count {bits:#b}"
+                cnt = {1: 1, 3: 2, 7: 3}[bits]
+                assert cnt <= max_leaf and ofs == next_ofs and ofs + cnt <= 24, f"node {idx} slot {s}: leaf offset {ofs} count {cnt}"
+                next_ofs += cnt
+                first = int(nd["triBase"]) + ofs
+                assert first + cnt <= n_tris
+                covered[first:first + cnt] += 1
+                ids = (tris["primID"][first:first + cnt].astype(np.uint64) << 32) | tris["geomID"][first:first + cnt]
+                assert cnt == 1 or (np.diff(ids.astype(np.int64)) > 0).all(), "leaf not sorted by (primID, geomID)"
+                stats["leaves"] += 1
+                clo, chi = tlo[first:first + cnt].min(0), thi[first:first + cnt].max(0)
+            assert (lo[s] <= clo + slack).all() and (hi[s] >= chi - slack).all(), \
+                f"node {idx} slot {s}: decoded box {lo[s]}..{hi[s]} does not contain {clo}..{chi}"
             blo, bhi = np.minimum(blo, clo), np.maximum(bhi, chi)
+        assert used >= 1, f"node {idx} has no children"
         return blo, bhi
 
-    import sys
     sys.setrecursionlimit(10000)
-    visit(int(root_ref), 0)
+    visit(0, 1)
     assert (covered == 1).all(), f"{int((covered != 1).sum())} triangles not covered exactly once"
     assert (node_seen == 1).all(), f"{int((node_seen != 1).sum())} nodes not referenced exactly once"
     return stats

@@ -45,7 +45,7 @@ def check_scene(dev, name, meshes, rays, masks=None, validate=True, **kw):
     t0 = time.time()
     s.intersect1M(got)
     log(f"    rtcIntersect1M {1e3 * (time.time() - t0):.1f} ms wall")
-    st = compare_closest(got, want, rays, o.triangle_t, label=name)
+    st = compare_closest(got, want, rays, o.triangle_t, max_tie_frac=0.02, label=name)   # symmetric cameras graze cube edges exactly
     log(f"    closest parity OK: {st}")
     r0 = rays_of(rays)
     wr, gr = r0.copy(), r0.copy()
@@ -55,7 +55,7 @@ def check_scene(dev, name, meshes, rays, masks=None, validate=True, **kw):
     log(f"    occluded parity OK: {st}")
     d = api.DeviceArray.from_numpy(rays)
     stats = s.trace_stats(d.ptr, rays.shape[0], 96)
-    log(f"    stats/ray: nodes {stats['nodes'] / rays.shape[0]:.2f} leaves {stats['leaves'] / rays.shape[0]:.2f} "
+    log(f"    stats/ray: nodes {stats['nodes'] / rays.shape[0]:.2f} "
         f"tris {stats['tris'] / rays.shape[0]:.2f} spills {stats['spills']} maxdepth {stats['max_depth']}")
     got2 = d.download(RAYHIT_DTYPE)
     assert got2.tobytes() == got.tobytes(), "stats build of the kernel gives different results"
@@ -122,7 +122,7 @@ def stage_perf(dev):
             log(f"    {name} closest: {1e3 * dt:.3f} ms -> {rays.shape[0] / dt / 1e6:.1f} Mrays/s (host clock)")
         d.upload(rays)
         st = s.trace_stats(d.ptr, rays.shape[0], 96)
-        log(f"    {name} stats/ray: nodes {st['nodes'] / rays.shape[0]:.2f} leaves {st['leaves'] / rays.shape[0]:.2f} "
+        log(f"    {name} stats/ray: nodes {st['nodes'] / rays.shape[0]:.2f} "
             f"tris {st['tris'] / rays.shape[0]:.2f} spills {st['spills']} maxdepth {st['max_depth']}")
     d.free()
     s.release()

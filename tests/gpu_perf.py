@@ -58,11 +58,11 @@ for i in range(a.reps + 2):
 res = work.download(rays.dtype)
 L.mi355_memcpy_d2d_async(work.ptr, pristine.ptr, rays.nbytes, None)
 st = s.trace_stats(work.ptr, M, rec, a.any)
-alg = M * 48 + (0 if a.any else int((res["geomID"] != 0xFFFFFFFF).sum()) * 52) + st["nodes"] * 128 + st["tris"] * 48
+alg = M * 48 + (0 if a.any else int((res["geomID"] != 0xFFFFFFFF).sum()) * 52) + st["nodes"] * 80 + st["tris"] * 48
 best = min(ms)
-print("PERF %-28s variant=%s cfg='%s' build=%.2fms nodes=%d leaves=%d | kernel min %.3f avg %.3f ms -> %.1f Mrays/s | "
-      "alg %.0f B/ray %.0f GB/s frac %.3f | per ray: nodes %.2f leaves %.2f tris %.2f | wave_iters %d both %.2f spills %d depth %d | md5 %s"
-      % (a.tag, os.environ.get("MI355_TRACE_VARIANT", "2"), a.config, info["build_ms"], info["num_nodes"], info["num_leaves"], best,
-         float(np.mean(ms)), M / best / 1e3, alg / M, alg / best / 1e6, alg / best / 1e6 / 8000.0, st["nodes"] / M, st["leaves"] / M,
-         st["tris"] / M, st["wave_iters"], st["both_branches"] / max(1, st["wave_iters"]), st["spills"], st["max_depth"],
-         hashlib.md5(res.tobytes()).hexdigest()[:10]), flush=True)
+print("PERF %-24s cfg='%s' build=%.2fms nodes=%d leaves=%d depth=%d sah=%.1f | kernel min %.3f avg %.3f ms -> %.1f Mrays/s | "
+      "alg %.0f B/ray %.0f GB/s frac %.3f | per ray: nodes %.2f tris %.2f | wave_iters %d util node %.2f tri %.2f | spills %d stack %d | md5 %s"
+      % (a.tag, a.config, info["build_ms"], info["num_nodes"], info["num_leaves"], info["depth"], info["sah"], best,
+         float(np.mean(ms)), M / best / 1e3, alg / M, alg / best / 1e6, alg / best / 1e6 / 8000.0, st["nodes"] / M,
+         st["tris"] / M, st["wave_iters"], st["nodes"] / max(1, 64 * st["node_blocks"]), st["tris"] / max(1, 64 * st["tri_blocks"]),
+         st["spills"], st["max_depth"], hashlib.md5(res.tobytes()).hexdigest()[:10]), flush=True)

@@ -1,6 +1,7 @@
 #!/bin/bash
 # PMC passes for the trace kernel (run on the GPU box). Counters are collected in their own runs
 # (no --kernel-trace/--stats mixed with --pmc), one pass per counter group.  Usage: tools/pmc_run.sh <outdir> <cmd...>
+# (the command runs with cwd=/tmp: give script paths as /root/repo/...)
 OUT=$1; shift
 R=$PWD
 mkdir -p $OUT
