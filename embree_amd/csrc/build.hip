@@ -638,9 +638,9 @@ TraceScratch* Bvh::scratch_for(hipStream_t s) {
   auto it = scratch.find(s);
   if (it != scratch.end()) return &it->second;
   TraceScratch sc;
-  if (hipMalloc((void**)&sc.counter, 256) != hipSuccess) return nullptr;
+  if (hipMalloc((void**)&sc.counter, 4096) != hipSuccess) return nullptr;
   if (hipMalloc(&sc.spill, trace_spill_bytes(numCUs, info.depth)) != hipSuccess) return nullptr;
-  if (hipMalloc((void**)&sc.stats, 64) != hipSuccess) return nullptr;
+  if (hipMalloc((void**)&sc.stats, 128) != hipSuccess) return nullptr;
   return &(scratch[s] = sc);
 }
 Bvh::~Bvh() {

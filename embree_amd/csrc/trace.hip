@@ -9,19 +9,20 @@
 // triangle_intersector_moeller.h:69-111) and Intersect1EpilogM / Occluded1EpilogM
 // (kernels/geometry/intersector_epilog.h:235-368).
 //
-// MI355X mapping -- one ray per lane, persistent waves:
+// MI355X mapping -- one ray per lane, persistent waves, triangle tests pooled per wave:
 //   * a wave owns 64 rays; every lane walks its own ray through the 8-wide compressed tree of bvh_common.h.
-//     A node visit is five 16-byte loads per lane (80-byte node) and ~230 VALU instructions for the wave
+//     A node visit is five 16-byte loads per lane (80-byte node) and ~250 VALU instructions for the wave
 //     (8 slab tests on dequantised planes: v_cvt_f32_ubyte + v_fma per plane, v_max3/v_min3 per child);
 //     a triangle visit is three 16-byte loads and the reference's Moeller-Trumbore arithmetic.
 //   * traversal order needs no sort: children are stored in the slot matching their octant, so the hit bits of
 //     a node, XOR-ed with the ray's octant, are already front to back.  The hits of one node are a 32-bit word
 //     (8 inner-node bits, 24 triangle bits); the per-lane stack holds {child base, hit word} pairs = one entry
-//     per tree level at most, 16 entries per lane in LDS ([entry][lane] so that lanes never bank-conflict),
+//     per tree level at most, 12 entries per lane in LDS ([entry][lane] so that lanes never bank-conflict),
 //     deeper levels spill to HBM (sized from the depth the builder reports, so it can never overflow).
-//   * persistent threads: a wave pulls ray indices from a global cursor whenever >= REFILL_MIN lanes are idle
-//     (one atomic per refill); triangle tests are postponed until >= TRI_MIN lanes have one pending, which keeps
-//     the two divergent code blocks (node step, triangle step) reasonably full.
+//   * the kernel is VALU-issue bound (profiles/r01_pmc_trace.md), so what matters is how many lanes each wave
+//     instruction serves.  Triangle tests therefore do not run in the lane that found them: triangle bits go
+//     to a per-wave LDS ring and are tested 64 at a time by all lanes (see trace_kernel_q below).
+//   * persistent threads: rays are handed out in blocks of REFILL_MIN through 8 cache-line-separated cursors.
 //   All arithmetic is fp32; the triangle test keeps the reference's operation order and FMA placement (compiled
 //   with -ffp-contract=off so only the explicit fmaf()s fuse).  MFMA is not used: no dense contraction here.
 #include <hip/hip_runtime.h>
@@ -36,11 +37,9 @@
 
 namespace {
 
-constexpr int BLOCK = 256;                 // 4 independent waves (no barriers); LDS = 4 x 16 x 64 x 8 B = 32 KiB
-constexpr int STACK_LDS = 16;              // stack entries per lane kept in LDS
+constexpr int BLOCK = 256;                 // 4 independent waves (no barriers); LDS = 4 x 7.5 KiB
 constexpr uint32_t ITER_CAP = 1u << 24;    // safety net only: a corrupt tree must not hang the GPU
-constexpr uint32_t REFILL_MIN_DEFAULT = 16;  // fetch new rays once this many lanes of a wave are idle   (env MI355_REFILL_MIN)
-constexpr uint32_t TRI_MIN_DEFAULT = 12;     // run the triangle block once this many lanes have one pending (env MI355_TRI_MIN)
+constexpr uint32_t REFILL_MIN_DEFAULT = 32;  // rays are handed out in blocks of this many, once that many lanes are free (env MI355_REFILL_MIN)
 
 __device__ __forceinline__ float rcp_nr(float a) {  // v_rcp_f32 + one Newton step (reference: RCPPS + Newton, vfloat4_sse2.h:304)
   float r = __builtin_amdgcn_rcpf(a);
@@ -59,7 +58,7 @@ struct TraceArgs {
   uint32_t* counter;     // global ray cursor (zeroed before launch)
   uint2* spill;          // [gridDim.x * BLOCK][spillPerLane]
   uint32_t spillPerLane;
-  uint32_t refillMin, triMin;
+  uint32_t refillMin, pushRounds, numCursors;
   unsigned long long* stats;  // optional counters
 };
 
@@ -90,101 +89,243 @@ __device__ __forceinline__ uint32_t test4(uint32_t nx, uint32_t ny, uint32_t nz,
   return hits;
 }
 
+// =============================================================================================
+// Triangle tests leave the lane that found them.
+//   If a lane that hits leaf slots had to run its triangle tests itself before opening the next node, the node block and
+//   the triangle block would each run with 30-40 % of the lanes (measured: 695 Mrays/s, profiles/r01_trace_history.md).
+//   Instead the hit word's triangle bits are expanded into a per-wave LDS ring of {triangle, owner lane} pairs and the lane
+//   goes on traversing; whenever 64 pairs are queued the whole wave tests them, one pair per lane, fetching the owner's ray
+//   with ds_bpermute.  An accepted hit is published with one 64-bit LDS atomic-min on best[owner] = {t bits : triangle index};
+//   owners re-read their best[] entry each iteration (that is their current tfar).  A ray retires once its traversal is
+//   done AND the ring has drained past its last pair; u/v/Ng/IDs are recomputed from the winning triangle at that point.
+//   Closest hit = minimum t over ALL accepted candidates, ties to the lower triangle index: independent of scheduling.
+constexpr int QSTACK_LDS = 12;             // stack entries per lane in LDS
+constexpr uint32_t QCAP = 128;             // ring capacity (pairs) per wave
+constexpr uint32_t PUSH_ROUNDS_DEFAULT = 5;  // triangle bits a lane may queue per iteration (the rest waits one iteration; env MI355_PUSH_ROUNDS)
+constexpr uint32_t NUM_CURSORS = 8;        // ray cursors per launch (one per XCD)
+constexpr uint32_t CURSOR_STRIDE = 64;     // words between cursors: each one in its own 256-byte block
+
 template <bool ANY, bool STATS>
-__global__ __launch_bounds__(BLOCK) void trace_kernel(TraceArgs a) {
-  __shared__ uint2 s_stack[BLOCK / 64][STACK_LDS][64];
+__global__ __launch_bounds__(BLOCK) void trace_kernel_q(TraceArgs a) {
+  __shared__ uint2 s_stack[BLOCK / 64][QSTACK_LDS][64];
+  __shared__ uint2 s_queue[BLOCK / 64][QCAP];
+  __shared__ unsigned long long s_best[BLOCK / 64][64];
 
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = tid & 63u;
-  uint2* const stk = &s_stack[tid >> 6][0][lane];                        // entry e of this lane: stk[e * 64]
+  uint2* const stk = &s_stack[tid >> 6][0][lane];
+  uint2* const queue = &s_queue[tid >> 6][0];
+  unsigned long long* const best = &s_best[tid >> 6][0];
   uint2* const spill = a.spill + (size_t)(blockIdx.x * BLOCK + tid) * a.spillPerLane;
 
-  bool active = false, exhausted = false;
-  uint32_t rayIdx = 0, rmask = 0, octinv4 = 0, sp = 0;
-  uint32_t ngBase = 0, ngHits = 0, tgBase = 0, tgHits = 0;              // node group / triangle group of the current node
+  bool active = false, travDone = false, exhausted = false;
+  uint32_t rayIdx = 0, rmask = 0, octinv4 = 0, sp = 0, lastTicket = 0;
+  uint32_t ngBase = 0, ngHits = 0, tgBase = 0, tgHits = 0;
+  uint32_t qHead = 0, qTail = 0;                                         // wave-uniform ring cursors (monotonic)
+  uint32_t cursor = blockIdx.x % a.numCursors, dryCursors = 0;            // wave-uniform: which ray cursor this wave pulls from
+  uint32_t resV = 0; bool resValid = false;                              // the block reserved ahead (lane 0 holds the atomic's result)
   float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0, rdx = 0, rdy = 0, rdz = 0, tnear = 0, tnearTrav = 0, tfar = 0;
-  float hNgx = 0, hNgy = 0, hNgz = 0, hu = 0, hv = 0; uint32_t hprim = 0, hgeom = MI355_EMPTY_REF;
   uint32_t stNodes = 0, stTris = 0, stRays = 0, stSpill = 0, stDepth = 0, stIter = 0, stNodeBlk = 0, stTriBlk = 0;
+  uint32_t stIdle = 0, stWaitBatch = 0, stWaitDrain = 0, stBlocked = 0, stEmpty = 0, stCulled = 0;
 
   for (uint32_t iter = 0; iter < ITER_CAP; iter++) {
-    // ------------------------------------------------------------------ 1. hand new rays to idle lanes
+    // ------------------------------------------------------------------ 1. retire finished rays, hand out new ones
+    // Ray indices are handed out in blocks of G = refillMin consecutive rays.  Block B belongs to cursor B % numCursors, so
+    // neighbouring blocks go to different cursors = different XCDs (a wave pulls from cursor blockIdx % 8 = its XCD): one
+    // global atomic word saturates at ~88 dequeues/us (MI355X_MICROARCH.md "dequeue"), eight do not -- provided each
+    // cursor sits in its own cache line (eight cursors inside one 32-byte sector measured 30 % SLOWER than one cursor).
+    // A wave always holds ONE block reserved ahead of time (the atomic for the next block is issued while the rays of this
+    // one are being loaded), and the loads of the retiring rays' winning triangles are issued together with the loads of the
+    // new rays, so a refill costs one memory round trip, not three.  A wave whose cursor runs dry moves on to the next
+    // cursor; every ray is handed out exactly once; a wave never exits while it holds a block that exists.
     {
-      const unsigned long long idleMask = __ballot(!active);
-      const uint32_t nIdle = (uint32_t)__popcll(idleMask);
-      if (!exhausted && nIdle >= a.refillMin) {
-        uint32_t base = 0;
-        if (lane == 0u) base = atomicAdd(a.counter, nIdle);
-        base = __builtin_amdgcn_readfirstlane(base);
-        const uint32_t mine = base + (uint32_t)__popcll(idleMask & ((1ull << lane) - 1ull));
-        if (!active && mine < a.count) {
-          rayIdx = mine;
-          const float4* rp = (const float4*)(a.rays + (size_t)rayIdx * a.stride);
-          const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2];
-          ox = r0.x; oy = r0.y; oz = r0.z; tnear = r0.w;
-          dx = r1.x; dy = r1.y; dz = r1.z;
-          tfar = r2.x; rmask = __float_as_uint(r2.y);
-          // TravRay: rdir = rcp_safe(dir) (|d| < 1e-18 -> +1e-18), tnear/tfar clamped to >= 0 for traversal
-          // kernels/bvh/node_intersector1.h:29-57, common/math/vec3fa.h:167-172, bvh_intersector1.cpp:65
-          rdx = rcp_nr(fabsf(dx) < 1e-18f ? 1e-18f : dx);
-          rdy = rcp_nr(fabsf(dy) < 1e-18f ? 1e-18f : dy);
-          rdz = rcp_nr(fabsf(dz) < 1e-18f ? 1e-18f : dz);
-          tnearTrav = fmaxf(tnear, 0.0f);
-          // a ray travelling towards +x meets the children on the -x side first: priority of slot s = s ^ octinv
-          octinv4 = ((rdx < 0.0f ? 0u : 1u) | (rdy < 0.0f ? 0u : 2u) | (rdz < 0.0f ? 0u : 4u)) * 0x01010101u;
-          sp = 0; hgeom = MI355_EMPTY_REF;
-          ngBase = 0; ngHits = 0x80000000u; tgBase = 0; tgHits = 0;       // "the root is the one hit child of a virtual node"
-          active = a.hasRoot != 0u && !(ANY && tfar < 0.0f);              // empty scene / already occluded (bvh_intersector1.cpp:128)
-          if (STATS) stRays++;
+      const bool retirable = active && travDone && (int)(qHead - lastTicket) >= 0;
+      const unsigned long long freeMask = __ballot(retirable || !active);
+      const bool anyBusy = __ballot(active && !retirable) != 0ull;
+      if ((uint32_t)__popcll(freeMask) >= a.refillMin || !anyBusy) {
+        const uint32_t G = a.refillMin;
+        // (a) retiring rays: read the winner, issue the loads of its triangle record
+        uint32_t htri = MI355_EMPTY_REF;
+        float4 q0 = make_float4(0, 0, 0, 0), q1 = q0, q2 = q0;
+        if (retirable) {
+          htri = (uint32_t)best[lane];
+          if (!ANY && htri != MI355_EMPTY_REF) { const float4* tp = a.tris + (size_t)htri * 3u; q0 = tp[0]; q1 = tp[1]; q2 = tp[2]; }
         }
-        if (base + nIdle >= a.count) exhausted = true;
+        bool retiredDone = false, more = true;
+        while (more) {
+          // (b) claim the reserved block for free lanes: the first round overlaps its ray loads with the triangle loads of (a)
+          const unsigned long long freeLanes = retiredDone ? __ballot(!active) : freeMask;
+          const bool canGrab = !exhausted && (uint32_t)__popcll(freeLanes) >= G;
+          bool got = false; uint32_t newIdx = 0; float4 r0 = q0, r1 = q0, r2 = q0;
+          if (canGrab) {
+            while (!exhausted) {
+              if (!resValid) { if (lane == 0u) resV = atomicAdd(a.counter + cursor * CURSOR_STRIDE, 1u); resValid = true; }
+              const uint32_t base = __builtin_amdgcn_readfirstlane(resV);
+              const unsigned long long firstRay = ((unsigned long long)base * a.numCursors + cursor) * G;
+              resValid = false;
+              if (firstRay >= a.count) {                                 // this cursor is dry: try the next one
+                cursor = (cursor + 1u) % a.numCursors;
+                if (++dryCursors >= a.numCursors) exhausted = true;
+                continue;
+              }
+              const uint32_t rank = (uint32_t)__popcll(freeLanes & ((1ull << lane) - 1ull));
+              got = ((freeLanes >> lane) & 1ull) != 0ull && rank < G && firstRay + rank < a.count;
+              if (got) {
+                newIdx = (uint32_t)firstRay + rank;
+                const float4* rp = (const float4*)(a.rays + (size_t)newIdx * a.stride);
+                r0 = rp[0]; r1 = rp[1]; r2 = rp[2];
+              }
+              if (lane == 0u) resV = atomicAdd(a.counter + cursor * CURSOR_STRIDE, 1u);   // reserve the next block while these loads fly
+              resValid = true;
+              break;
+            }
+          }
+          // (c) write the retiring rays' results (uses the OLD ray registers)
+          if (!retiredDone) {
+            retiredDone = true;
+            if (retirable) {
+              if (htri != MI355_EMPTY_REF) {
+                char* rp = a.rays + (size_t)rayIdx * a.stride;
+                if (ANY) *(float*)(rp + 32) = -__builtin_inff();        // Occluded1EpilogM: tfar = -inf
+                else {
+                  // recompute the winner's t, u, v, Ng (same arithmetic as the test in step 4; Intersect1EpilogM, intersector_epilog.h:235-300)
+                  const float e1x = q0.w, e1y = q1.x, e1z = q1.y, e2x = q1.z, e2y = q1.w, e2z = q2.x;
+                  const float Ngx = fmaf(e2y, e1z, -(e2z * e1y)), Ngy = fmaf(e2z, e1x, -(e2x * e1z)), Ngz = fmaf(e2x, e1y, -(e2y * e1x));
+                  const float Cx = q0.x - ox, Cy = q0.y - oy, Cz = q0.z - oz;
+                  const float Rx = fmaf(Cy, dz, -(Cz * dy)), Ry = fmaf(Cz, dx, -(Cx * dz)), Rz = fmaf(Cx, dy, -(Cy * dx));
+                  const float den = fmaf(Ngx, dx, fmaf(Ngy, dy, Ngz * dz));
+                  const uint32_t sgn = __float_as_uint(den) & 0x80000000u;
+                  const float U = xor_sign(fmaf(Rx, e2x, fmaf(Ry, e2y, Rz * e2z)), sgn);
+                  const float V = xor_sign(fmaf(Rx, e1x, fmaf(Ry, e1y, Rz * e1z)), sgn);
+                  const float T = xor_sign(fmaf(Ngx, Cx, fmaf(Ngy, Cy, Ngz * Cz)), sgn);
+                  const float rcpd = rcp_nr(fabsf(den));
+                  *(float*)(rp + 32) = T * rcpd;
+                  *(float4*)(rp + 48) = make_float4(Ngx, Ngy, Ngz, U * rcpd);
+                  *(uint4*)(rp + 64) = make_uint4(__float_as_uint(V * rcpd), __float_as_uint(q2.y), __float_as_uint(q2.z), MI355_EMPTY_REF);
+                  *(uint32_t*)(rp + 80) = MI355_EMPTY_REF;
+                }
+              }
+              active = false;
+            }
+          }
+          // (d) start the new rays
+          if (got) {
+            rayIdx = newIdx;
+            ox = r0.x; oy = r0.y; oz = r0.z; tnear = r0.w;
+            dx = r1.x; dy = r1.y; dz = r1.z;
+            tfar = r2.x; rmask = __float_as_uint(r2.y);
+            // TravRay: rdir = rcp_safe(dir) (|d| < 1e-18 -> +1e-18), tnear/tfar clamped to >= 0 for traversal
+            // kernels/bvh/node_intersector1.h:29-57, common/math/vec3fa.h:167-172, bvh_intersector1.cpp:65
+            rdx = rcp_nr(fabsf(dx) < 1e-18f ? 1e-18f : dx);
+            rdy = rcp_nr(fabsf(dy) < 1e-18f ? 1e-18f : dy);
+            rdz = rcp_nr(fabsf(dz) < 1e-18f ? 1e-18f : dz);
+            tnearTrav = fmaxf(tnear, 0.0f);
+            // a ray travelling towards +x meets the children on the -x side first: priority of slot s = s ^ octinv
+            octinv4 = ((rdx < 0.0f ? 0u : 1u) | (rdy < 0.0f ? 0u : 2u) | (rdz < 0.0f ? 0u : 4u)) * 0x01010101u;
+            sp = 0; ngBase = 0; ngHits = 0x80000000u; tgBase = 0; tgHits = 0;   // "the root is the one hit child of a virtual node"
+            lastTicket = qHead; travDone = false;
+            best[lane] = ((unsigned long long)__float_as_uint(tfar) << 32) | 0xFFFFFFFFull;
+            active = a.hasRoot != 0u && !(ANY && tfar < 0.0f);            // empty scene / already occluded (bvh_intersector1.cpp:128)
+            if (STATS) stRays++;
+          }
+          more = canGrab && !exhausted;                                   // more free lanes than one block (launch start, small G)
+        }
       }
       if (__ballot(active) == 0ull) { if (exhausted) break; else continue; }
     }
     if (STATS && lane == 0u) stIter++;
 
-    // ------------------------------------------------------------------ 2. nothing pending: pop a node group or finish the ray
-    if (active && tgHits == 0u && ngHits <= 0x00FFFFFFu) {
-      if (sp != 0u) {
-        sp--;
-        uint2 e = stk[min(sp, (uint32_t)(STACK_LDS - 1)) * 64u];
-        if (__builtin_expect(sp >= (uint32_t)STACK_LDS, 0)) e = spill[sp - STACK_LDS];
-        ngBase = e.x; ngHits = e.y;
-      } else {
-        if (!ANY && hgeom != MI355_EMPTY_REF) {
-          char* rp = a.rays + (size_t)rayIdx * a.stride;
-          *(float*)(rp + 32) = tfar;
-          *(float4*)(rp + 48) = make_float4(hNgx, hNgy, hNgz, hu);
-          *(uint4*)(rp + 64) = make_uint4(__float_as_uint(hv), hprim, hgeom, MI355_EMPTY_REF);
-          *(uint32_t*)(rp + 80) = MI355_EMPTY_REF;
-        }
-        active = false;
+    // ------------------------------------------------------------------ 2. current tfar = what the testers published; pop / finish traversal
+    if (active && !travDone) {
+      const unsigned long long b = best[lane];
+      tfar = __uint_as_float((uint32_t)(b >> 32));
+      if (ANY && (uint32_t)b != MI355_EMPTY_REF) { travDone = true; lastTicket = qHead; tgHits = 0; ngHits = 0; sp = 0; }   // occluded: nothing left to wait for
+      else if (tgHits == 0u && ngHits <= 0x00FFFFFFu) {
+        if (sp != 0u) {
+          sp--;
+          uint2 e = stk[min(sp, (uint32_t)(QSTACK_LDS - 1)) * 64u];
+          if (__builtin_expect(sp >= (uint32_t)QSTACK_LDS, 0)) e = spill[sp - QSTACK_LDS];
+          ngBase = e.x; ngHits = e.y;
+        } else travDone = true;                                     // lastTicket already names this ray's last queued pair
       }
     }
 
-    // ------------------------------------------------------------------ 3. node step: open the nearest pending inner child
-    const bool doNode = active && tgHits == 0u && ngHits > 0x00FFFFFFu;
-    const bool anyNode = __ballot(doNode) != 0ull;
+    // ------------------------------------------------------------------ 3a. node step, first half: pick the child, issue its loads
+    const bool doNode = active && !travDone && tgHits == 0u && ngHits > 0x00FFFFFFu;
+    uint4 n0 = make_uint4(0, 0, 0, 0), n1 = n0, n2 = n0, n3 = n0, n4 = n0;
     if (doNode) {
       const uint32_t bit = 31u - (uint32_t)__clz((int)ngHits);
       ngHits &= ~(1u << bit);
-      if (ngHits > 0x00FFFFFFu) {                                        // siblings left: keep the group for later
+      if (ngHits > 0x00FFFFFFu) {
         const uint2 e = make_uint2(ngBase, ngHits);
-        if (sp < (uint32_t)STACK_LDS) stk[sp * 64u] = e;
-        else { if (sp - STACK_LDS < a.spillPerLane) spill[sp - STACK_LDS] = e; if (STATS) stSpill++; }
+        if (sp < (uint32_t)QSTACK_LDS) stk[sp * 64u] = e;
+        else { if (sp - QSTACK_LDS < a.spillPerLane) spill[sp - QSTACK_LDS] = e; if (STATS) stSpill++; }
         sp++;
         if (STATS) stDepth = max(stDepth, sp);
       }
       const uint32_t slot = (bit ^ octinv4) & 7u;
-      const uint32_t rel = (uint32_t)__popc(ngHits & ~(0xFFFFFFFFu << slot));   // low byte of the group word = imask
+      const uint32_t rel = (uint32_t)__popc(ngHits & ~(0xFFFFFFFFu << slot));
       const uint4* np = a.nodes + (size_t)(ngBase + rel) * 5u;
-      const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
+      n0 = np[0]; n1 = np[1]; n2 = np[2]; n3 = np[3]; n4 = np[4];   // issued here, consumed after the triangle block: one memory round trip per iteration
+    }
+
+    // ------------------------------------------------------------------ 4. test queued pairs (queued in earlier iterations), 64 at a time (fewer only when nothing else can run)
+    const bool anyTraversing = __ballot(active && !travDone) != 0ull;
+    for (;;) {
+      const uint32_t count = qTail - qHead;
+      if (count == 0u || (count < 64u && anyTraversing)) break;
+      const uint32_t n = min(count, 64u);
+      const bool mine = lane < n;
+      const uint2 e = queue[(qHead + (mine ? lane : 0u)) & (QCAP - 1u)];
+      const int owner = (int)e.y;
+      // the owner's ray (all 64 lanes execute the permutes; lanes without a pair read pair 0's owner and drop the result)
+      const float gox = __shfl(ox, owner, 64), goy = __shfl(oy, owner, 64), goz = __shfl(oz, owner, 64);
+      const float gdx = __shfl(dx, owner, 64), gdy = __shfl(dy, owner, 64), gdz = __shfl(dz, owner, 64);
+      const float gtnear = __shfl(tnear, owner, 64);
+      const uint32_t grmask = (uint32_t)__shfl((int)rmask, owner, 64);
+      if (STATS && lane == 0u) stTriBlk++;
+      if (mine) {
+        const float gtfar = __uint_as_float((uint32_t)(best[owner] >> 32));
+        const float4* tp = a.tris + (size_t)e.x * 3u;
+        const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
+        if (STATS) stTris++;
+        const float v0x = q0.x, v0y = q0.y, v0z = q0.z;
+        const float e1x = q0.w, e1y = q1.x, e1z = q1.y;
+        const float e2x = q1.z, e2y = q1.w, e2z = q2.x;
+        const uint32_t tmask = __float_as_uint(q2.w);
+        // Moeller-Trumbore, same operation order and FMA placement as the reference
+        // (triangle_intersector_moeller.h:79-108; cross/dot: common/math/vec3.h:204,209)
+        const float Ngx = fmaf(e2y, e1z, -(e2z * e1y));
+        const float Ngy = fmaf(e2z, e1x, -(e2x * e1z));
+        const float Ngz = fmaf(e2x, e1y, -(e2y * e1x));
+        const float Cx = v0x - gox, Cy = v0y - goy, Cz = v0z - goz;
+        const float Rx = fmaf(Cy, gdz, -(Cz * gdy));
+        const float Ry = fmaf(Cz, gdx, -(Cx * gdz));
+        const float Rz = fmaf(Cx, gdy, -(Cy * gdx));
+        const float den = fmaf(Ngx, gdx, fmaf(Ngy, gdy, Ngz * gdz));
+        const float absDen = fabsf(den);
+        const uint32_t sgn = __float_as_uint(den) & 0x80000000u;
+        const float U = xor_sign(fmaf(Rx, e2x, fmaf(Ry, e2y, Rz * e2z)), sgn);
+        const float V = xor_sign(fmaf(Rx, e1x, fmaf(Ry, e1y, Rz * e1z)), sgn);
+        const float T = xor_sign(fmaf(Ngx, Cx, fmaf(Ngy, Cy, Ngz * Cz)), sgn);
+        bool ok = (den != 0.0f) && (U >= 0.0f) && (V >= 0.0f) && (U + V <= absDen);
+        ok = ok && (absDen * gtnear < T) && (T <= absDen * gtfar);  // strict at tnear, inclusive at tfar
+        ok = ok && ((tmask & grmask) != 0u);                           // EMBREE_RAY_MASK, intersector_epilog.h:256-262
+        if (ok) {
+          const float t = T * rcp_nr(absDen);
+          atomicMin(&best[owner], ((unsigned long long)__float_as_uint(t) << 32) | e.x);
+        }
+      }
+      qHead += n;
+    }
+
+    // ------------------------------------------------------------------ 3b. node step, second half: 8 slab tests
+    if (doNode) {
       if (STATS) stNodes++;
-      // plane(q) = org + q * 2^(e-127);  t(q) = (plane - O) * rdir = q * (scale * rdir) + (org - O) * rdir
       const float adx = __uint_as_float((n0.w & 0xFFu) << 23) * rdx;
       const float ady = __uint_as_float(((n0.w >> 8) & 0xFFu) << 23) * rdy;
       const float adz = __uint_as_float(((n0.w >> 16) & 0xFFu) << 23) * rdz;
       const float bx = (__uint_as_float(n0.x) - ox) * rdx, by = (__uint_as_float(n0.y) - oy) * rdy, bz = (__uint_as_float(n0.z) - oz) * rdz;
-      // near / far planes by direction sign (TravRay nearX/farX, node_intersector1.h:40-57)
       const bool sx = rdx < 0.0f, sy = rdy < 0.0f, sz = rdz < 0.0f;
       const uint32_t nx0 = sx ? n3.z : n2.x, nx1 = sx ? n3.w : n2.y, fx0 = sx ? n2.x : n3.z, fx1 = sx ? n2.y : n3.w;
       const uint32_t ny0 = sy ? n4.x : n2.z, ny1 = sy ? n4.y : n2.w, fy0 = sy ? n2.z : n4.x, fy1 = sy ? n2.w : n4.y;
@@ -194,57 +335,30 @@ __global__ __launch_bounds__(BLOCK) void trace_kernel(TraceArgs a) {
                             test4(nx1, ny1, nz1, fx1, fy1, fz1, n1.w, octinv4, adx, ady, adz, bx, by, bz, tnearTrav, tmax0);
       ngBase = n1.x; ngHits = (hits & 0xFF000000u) | (n0.w >> 24);
       tgBase = n1.y; tgHits = hits & 0x00FFFFFFu;
+      if (STATS && hits == 0u) stEmpty++;
     }
-    if (STATS && lane == 0u && anyNode) stNodeBlk++;
+    if (STATS) {
+      const bool anyNode = __ballot(doNode) != 0ull;
+      if (lane == 0u && anyNode) stNodeBlk++;
+      // lane-iteration census: where do the lanes that are NOT opening a node spend this iteration?
+      if (!active) stIdle++; else if (travDone) { if ((int)(qHead - lastTicket) >= 0) stWaitBatch++; else stWaitDrain++; } else if (!doNode) stBlocked++;
+    }
 
-    // ------------------------------------------------------------------ 4. triangle steps (postponed while few lanes have one pending)
-    bool first = true;
-    for (;;) {
-      const bool doTri = active && tgHits != 0u;
-      const uint32_t nTri = (uint32_t)__popcll(__ballot(doTri));
-      if (nTri == 0u) break;
-      if (nTri < a.triMin && (anyNode || !first)) break;
-      first = false;
-      if (STATS && lane == 0u) stTriBlk++;
-      if (doTri) {
+    // ------------------------------------------------------------------ 5. queue triangle bits: one pair per lane and round
+    for (uint32_t r = 0; r < a.pushRounds; r++) {
+      const bool has = tgHits != 0u;                                     // only active, traversing lanes hold triangle bits
+      const unsigned long long m = __ballot(has);
+      if (m == 0ull) break;
+      const uint32_t n = (uint32_t)__popcll(m);
+      if (QCAP - (qTail - qHead) < n) break;                             // no room: the drain below makes some, the bits wait
+      if (has) {
         const uint32_t k = (uint32_t)__builtin_ctz(tgHits);
         tgHits &= tgHits - 1u;
-        const float4* tp = a.tris + (size_t)(tgBase + k) * 3u;
-        const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
-        if (STATS) stTris++;
-        const float v0x = q0.x, v0y = q0.y, v0z = q0.z;
-        const float e1x = q0.w, e1y = q1.x, e1z = q1.y;
-        const float e2x = q1.z, e2y = q1.w, e2z = q2.x;
-        const uint32_t tprim = __float_as_uint(q2.y), tgeom = __float_as_uint(q2.z), tmask = __float_as_uint(q2.w);
-        // Moeller-Trumbore, same operation order and FMA placement as the reference
-        // (triangle_intersector_moeller.h:79-108; cross/dot: common/math/vec3.h:204,209)
-        const float Ngx = fmaf(e2y, e1z, -(e2z * e1y));
-        const float Ngy = fmaf(e2z, e1x, -(e2x * e1z));
-        const float Ngz = fmaf(e2x, e1y, -(e2y * e1x));
-        const float Cx = v0x - ox, Cy = v0y - oy, Cz = v0z - oz;
-        const float Rx = fmaf(Cy, dz, -(Cz * dy));
-        const float Ry = fmaf(Cz, dx, -(Cx * dz));
-        const float Rz = fmaf(Cx, dy, -(Cy * dx));
-        const float den = fmaf(Ngx, dx, fmaf(Ngy, dy, Ngz * dz));
-        const float absDen = fabsf(den);
-        const uint32_t sgn = __float_as_uint(den) & 0x80000000u;
-        const float U = xor_sign(fmaf(Rx, e2x, fmaf(Ry, e2y, Rz * e2z)), sgn);
-        const float V = xor_sign(fmaf(Rx, e1x, fmaf(Ry, e1y, Rz * e1z)), sgn);
-        const float T = xor_sign(fmaf(Ngx, Cx, fmaf(Ngy, Cy, Ngz * Cz)), sgn);
-        bool ok = (den != 0.0f) && (U >= 0.0f) && (V >= 0.0f) && (U + V <= absDen);
-        ok = ok && (absDen * tnear < T) && (T <= absDen * tfar);    // strict at tnear, inclusive at tfar
-        ok = ok && ((tmask & rmask) != 0u);                            // EMBREE_RAY_MASK, intersector_epilog.h:256-262
-        if (ok) {
-          if (ANY) {                                                   // Occluded1EpilogM: tfar = -inf, done
-            *(float*)(a.rays + (size_t)rayIdx * a.stride + 32) = -__builtin_inff();
-            active = false; tgHits = 0; ngHits = 0; sp = 0;
-          } else {                                                     // Intersect1EpilogM: t,u,v = T,U,V * rcp(absDen)
-            const float rcpd = rcp_nr(absDen);
-            tfar = T * rcpd; hu = U * rcpd; hv = V * rcpd;
-            hNgx = Ngx; hNgy = Ngy; hNgz = Ngz; hprim = tprim; hgeom = tgeom;
-          }
-        }
+        const uint32_t pos = qTail + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        queue[pos & (QCAP - 1u)] = make_uint2(tgBase + k, lane);
+        lastTicket = pos + 1u;
       }
+      qTail += n;
     }
   }
 
@@ -257,6 +371,12 @@ __global__ __launch_bounds__(BLOCK) void trace_kernel(TraceArgs a) {
     atomicAdd(&a.stats[5], (unsigned long long)stIter);
     atomicAdd(&a.stats[6], (unsigned long long)stNodeBlk);
     atomicAdd(&a.stats[7], (unsigned long long)stTriBlk);
+    atomicAdd(&a.stats[8], (unsigned long long)stIdle);
+    atomicAdd(&a.stats[9], (unsigned long long)stWaitBatch);
+    atomicAdd(&a.stats[10], (unsigned long long)stWaitDrain);
+    atomicAdd(&a.stats[11], (unsigned long long)stBlocked);
+    atomicAdd(&a.stats[12], (unsigned long long)stEmpty);
+    atomicAdd(&a.stats[13], (unsigned long long)stCulled);
   }
 }
 
@@ -299,7 +419,7 @@ static uint32_t env_u32(const char* name, uint32_t def, uint32_t lo, uint32_t hi
   const long v = atol(e); return v < (long)lo || v > (long)hi ? def : (uint32_t)v;
 }
 static TraceFn pick_kernel(bool any, bool stats) {
-  return any ? (stats ? trace_kernel<true, true> : trace_kernel<true, false>) : (stats ? trace_kernel<false, true> : trace_kernel<false, false>);
+  return any ? (stats ? trace_kernel_q<true, true> : trace_kernel_q<true, false>) : (stats ? trace_kernel_q<false, true> : trace_kernel_q<false, false>);
 }
 // persistent grid = exactly the blocks that are resident at once (a larger grid would run a second, ragged round)
 static uint32_t resident_blocks(Bvh* b, TraceFn fn) {
@@ -316,7 +436,7 @@ static uint32_t resident_blocks(Bvh* b, TraceFn fn) {
   return cache[key] = (uint32_t)b->numCUs * (uint32_t)perCU;
 }
 
-uint32_t trace_spill_per_lane(uint32_t depth) { return depth + 2u > (uint32_t)STACK_LDS ? depth + 2u - (uint32_t)STACK_LDS : 0u; }
+uint32_t trace_spill_per_lane(uint32_t depth) { return depth + 2u > (uint32_t)QSTACK_LDS ? depth + 2u - (uint32_t)QSTACK_LDS : 0u; }   // one entry per level at most
 size_t trace_spill_bytes(int numCUs, uint32_t depth) {
   return (size_t)numCUs * MI355_MAX_BLOCKS_PER_CU * BLOCK * trace_spill_per_lane(depth) * sizeof(uint2) + 256;
 }
@@ -332,19 +452,21 @@ static int launch_trace(Bvh* b, void* d_rays, uint32_t count, size_t stride, boo
   if (blocks > maxBlocks) blocks = maxBlocks;
   TraceScratch* sc = b->scratch_for(s);
   if (!sc) return set_error(hipErrorOutOfMemory, "trace scratch allocation failed");
-  HIP_TRY(hipMemsetAsync(sc->counter, 0, sizeof(uint32_t), s));
+  HIP_TRY(hipMemsetAsync(sc->counter, 0, NUM_CURSORS * CURSOR_STRIDE * sizeof(uint32_t), s));
   TraceArgs a;
   a.nodes = (const uint4*)b->d_nodes; a.tris = (const float4*)b->d_tris; a.hasRoot = b->root != MI355_EMPTY_REF ? 1u : 0u;
   a.rays = (char*)d_rays; a.count = count; a.stride = (uint32_t)stride;
   a.counter = sc->counter; a.spill = (uint2*)sc->spill; a.spillPerLane = trace_spill_per_lane(b->info.depth); a.stats = nullptr;
-  static const uint32_t refillMin = env_u32("MI355_REFILL_MIN", REFILL_MIN_DEFAULT, 1, 64), triMin = env_u32("MI355_TRI_MIN", TRI_MIN_DEFAULT, 1, 64);
-  a.refillMin = refillMin; a.triMin = triMin;
+  static const uint32_t refillMin = env_u32("MI355_REFILL_MIN", REFILL_MIN_DEFAULT, 1, 64);
+  static const uint32_t pushRounds = env_u32("MI355_PUSH_ROUNDS", PUSH_ROUNDS_DEFAULT, 1, 24);
+  static const uint32_t numCursors = env_u32("MI355_NUM_CURSORS", NUM_CURSORS, 1, NUM_CURSORS);
+  a.refillMin = refillMin; a.pushRounds = pushRounds; a.numCursors = numCursors;
   if (statsOut) {
-    HIP_TRY(hipMemsetAsync(sc->stats, 0, 8 * sizeof(uint64_t), s));
+    HIP_TRY(hipMemsetAsync(sc->stats, 0, 16 * sizeof(uint64_t), s));
     a.stats = (unsigned long long*)sc->stats;
     hipLaunchKernelGGL(fn, dim3(blocks), dim3(BLOCK), 0, s, a);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(statsOut, sc->stats, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(statsOut, sc->stats, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     return 0;
   }
@@ -389,8 +511,8 @@ int mi355_trace_any(mi355_bvh_t bvh, void* d, uint32_t n, size_t stride, void* s
 int mi355_trace_timed(mi355_bvh_t bvh, void* d, uint32_t n, size_t stride, int any_hit, void* stream, void* ev_start, void* ev_stop) {
   return mi355::launch_trace((mi355::Bvh*)bvh, d, n, stride, any_hit != 0, (hipStream_t)stream, nullptr, (hipEvent_t)ev_start, (hipEvent_t)ev_stop);
 }
-int mi355_trace_stats(mi355_bvh_t bvh, void* d, uint32_t n, size_t stride, int any_hit, uint64_t out[8]) {
-  for (int i = 0; i < 8; i++) out[i] = 0;
+int mi355_trace_stats(mi355_bvh_t bvh, void* d, uint32_t n, size_t stride, int any_hit, uint64_t out[16]) {
+  for (int i = 0; i < 16; i++) out[i] = 0;
   return mi355::launch_trace((mi355::Bvh*)bvh, d, n, stride, any_hit != 0, nullptr, out);
 }
 int mi355_trace_closest_packet(mi355_bvh_t bvh, const int* v, void* d, uint32_t K, uint32_t n, size_t ps, void* stream) {

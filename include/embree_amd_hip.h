@@ -91,10 +91,11 @@ MI355_API int mi355_trace_any_packet(mi355_bvh_t bvh, const int* d_valid, void* 
 /* Counting build of the same kernels (blocking): out[0]=inner nodes visited (80 B each), out[1]=triangle records
    fetched (48 B each), out[2]=rays, out[3]=stack entries spilled to global memory, out[4]=max stack depth,
    out[5]=wave loop iterations, out[6]=node-step blocks executed (per wave), out[7]=triangle-step blocks executed
-   (per wave); out[0] / (64 * out[6]) is the SIMD utilisation of the node step.  any_hit != 0 selects the occlusion
-   kernel.  The rays ARE traced (results written). */
+   (per wave); out[0] / (64 * out[6]) is the SIMD utilisation of the node step; out[8..11] = lane-iterations spent
+   without a ray / waiting for the retire batch / waiting for the triangle queue to drain / blocked on unqueued
+   triangle bits.  any_hit != 0 selects the occlusion kernel.  The rays ARE traced (results written). */
 MI355_API int mi355_trace_stats(mi355_bvh_t bvh, void* d_rays, uint32_t count, size_t byte_stride, int any_hit,
-                                uint64_t out[8]);
+                                uint64_t out[16]);
 
 /* raw device memory helpers for hosts without a HIP binding (ctypes tests / bench) */
 MI355_API int mi355_malloc(int device, size_t bytes, void** d_ptr);

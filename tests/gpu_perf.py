@@ -22,6 +22,7 @@ ap.add_argument("--reps", type=int, default=10)
 ap.add_argument("--any", action="store_true")
 ap.add_argument("--primary", action="store_true")
 ap.add_argument("--tag", default="")
+ap.add_argument("--retrace", action="store_true", help="trace once, then time the same rays with tfar preset to the hit distance (perfect-culling bound)")
 a = ap.parse_args()
 L = api.load()
 dev = api.Device(a.config)
@@ -38,6 +39,14 @@ s.intersect1M_device(d.ptr, prim.shape[0])
 L.mi355_device_synchronize(0)
 tr = d.download(RAYHIT_DTYPE)
 rays = prim if a.primary else W.diffuse_bounce_rays(tr, meshes)
+if a.retrace:
+    d2 = api.DeviceArray.from_numpy(rays)
+    s.intersect1M_device(d2.ptr, rays.shape[0])
+    L.mi355_device_synchronize(0)
+    t2 = d2.download(RAYHIT_DTYPE)
+    rays = rays.copy()
+    rays["tfar"] = np.where(t2["geomID"] != 0xFFFFFFFF, t2["tfar"] * np.float32(1.000001), rays["tfar"])
+    d2.free()
 if a.any:
     rays = rays_of(rays)
 M, rec = rays.shape[0], rays.dtype.itemsize
@@ -66,3 +75,7 @@ print("PERF %-24s cfg='%s' build=%.2fms nodes=%d leaves=%d depth=%d sah=%.1f | k
          float(np.mean(ms)), M / best / 1e3, alg / M, alg / best / 1e6, alg / best / 1e6 / 8000.0, st["nodes"] / M,
          st["tris"] / M, st["wave_iters"], st["nodes"] / max(1, 64 * st["node_blocks"]), st["tris"] / max(1, 64 * st["tri_blocks"]),
          st["spills"], st["max_depth"], hashlib.md5(res.tobytes()).hexdigest()[:10]), flush=True)
+li = 64.0 * max(1, st["wave_iters"])
+print("     lane-iterations: node %.3f idle %.3f wait_batch %.3f wait_drain %.3f blocked %.3f" % (st["nodes"] / li, st["lanes_idle"] / li,
+      st["lanes_wait_batch"] / li, st["lanes_wait_drain"] / li, st["lanes_blocked"] / li) +
+      " | per ray: nodes with no hit %.2f, groups culled at pop %.2f" % (st["empty_nodes"] / M, st["culled_groups"] / M), flush=True)

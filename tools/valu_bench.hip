@@ -1,0 +1,87 @@
+// valu_bench.hip -- issue cost of the VALU instructions the traversal kernels are made of, on gfx950.
+// For each opcode: 8 independent dependency chains, 64 instructions per loop trip, W waves per SIMD (W = 1, 2, 4);
+// prints shader cycles (s_memtime) per wave-instruction per SIMD.  Build: hipcc --offload-arch=gfx950 -O3 tools/valu_bench.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+#define REP8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
+#define REP64(X) REP8(X) REP8(X) REP8(X) REP8(X) REP8(X) REP8(X) REP8(X) REP8(X)
+
+template <int OP>
+__global__ __launch_bounds__(256) void k(float* out, int iters, long long* cyc) {
+  float a[8]; v2f p[8]; unsigned u[8];
+  const float b = 1.0f + threadIdx.x * 1e-9f, c = 1e-9f; const v2f pb = {b, b}, pc = {c, c};
+  for (int i = 0; i < 8; i++) { a[i] = threadIdx.x + i; p[i] = (v2f){a[i], a[i] + 1.f}; u[i] = threadIdx.x * 2654435761u + i; }
+  const long long t0 = __builtin_readcyclecounter();
+  for (int it = 0; it < iters; it++) {
+    if (OP == 0) {
+#define X(i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+      REP64(X)
+#undef X
+    } else if (OP == 1) {
+#define X(i) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[i]) : "v"(pb), "v"(pc));
+      REP64(X)
+#undef X
+    } else if (OP == 2) {
+#define X(i) asm volatile("v_cvt_f32_ubyte1 %0, %1" : "=v"(a[i]) : "v"(u[i]));
+      REP64(X)
+#undef X
+    } else if (OP == 3) {
+#define X(i) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+      REP64(X)
+#undef X
+    } else if (OP == 4) {
+#define X(i) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(u[i]) : "v"(u[(i + 1) & 7]) : );
+      REP64(X)
+#undef X
+    } else if (OP == 5) {
+#define X(i) asm volatile("v_bfe_u32 %0, %0, 3, 9" : "+v"(u[i]));
+      REP64(X)
+#undef X
+    } else if (OP == 6) {
+#define X(i) asm volatile("v_lshl_or_b32 %0, %0, 1, %1" : "+v"(u[i]) : "v"(u[(i + 1) & 7]));
+      REP64(X)
+#undef X
+    } else if (OP == 7) {
+#define X(i) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+      REP64(X)
+#undef X
+    } else if (OP == 8) {
+#define X(i) asm volatile("v_cmp_le_f32 vcc, %0, %1" : : "v"(a[i]), "v"(b) : "vcc");
+      REP64(X)
+#undef X
+    } else if (OP == 9) {
+#define X(i) asm volatile("v_and_b32 %0, %0, %1" : "+v"(u[i]) : "v"(u[(i + 1) & 7]));
+      REP64(X)
+#undef X
+    }
+  }
+  const long long t1 = __builtin_readcyclecounter();
+  float s = 0; unsigned su = 0;
+  for (int i = 0; i < 8; i++) { s += a[i] + p[i].x + p[i].y; su += u[i]; }
+  out[blockIdx.x * 256 + threadIdx.x] = s + su;
+  if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
+}
+
+int main() {
+  const char* names[] = {"v_fma_f32", "v_pk_fma_f32", "v_cvt_f32_ubyte1", "v_max3_f32", "v_cndmask_b32", "v_bfe_u32", "v_lshl_or_b32", "v_mul_f32", "v_cmp_le_f32", "v_and_b32"};
+  void (*fns[])(float*, int, long long*) = {k<0>, k<1>, k<2>, k<3>, k<4>, k<5>, k<6>, k<7>, k<8>, k<9>};
+  float* out; long long* cyc; hipMalloc(&out, 256 * 8 * 256 * 4); hipMalloc(&cyc, 256 * 8 * 4 * 8);
+  const int iters = 2000;
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int op = 0; op < 10; op++)
+    for (int w : {1, 2, 4}) {
+      const int blocks = 256 * w;
+      hipLaunchKernelGGL(fns[op], dim3(blocks), dim3(256), 0, 0, out, 10, cyc);
+      hipEventRecord(e0); hipLaunchKernelGGL(fns[op], dim3(blocks), dim3(256), 0, 0, out, iters, cyc); hipEventRecord(e1);
+      hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1);
+      std::vector<long long> h(blocks * 4); hipMemcpy(h.data(), cyc, h.size() * 8, hipMemcpyDeviceToHost);
+      double avg = 0; for (auto v : h) avg += v; avg /= h.size();
+      const double instr = (double)iters * 64;
+      printf("VALU %-18s waves/SIMD %d: %.2f shader-clk per instr per wave, %.2f clk per instr per SIMD | wall %.3f ms -> %.2f clk/instr/SIMD at 2.4 GHz\n",
+             names[op], w, avg / instr, avg / instr / w, ms, ms * 1e-3 * 2.4e9 / (instr * w));
+    }
+  return 0;
+}
