@@ -37,6 +37,17 @@ from embree_amd import api, workloads as W                    # noqa: E402  (loa
 from embree_amd.rtypes import RAYHIT_DTYPE, INVALID_ID         # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md (6.29 TB/s measured copy rate)
+PMC_JSON = os.path.join(ROOT, "profiles", "pmc_bench_latest.json")   # written by tools/pmc_summary.py from rocprofv3 --pmc passes of THIS command
+
+
+def pmc_traffic():
+    """HBM bytes per launch of the traversal kernel from the committed PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE), or None."""
+    try:
+        d = json.load(open(PMC_JSON))
+        return int(d["hbm_traffic_bytes_per_launch"])
+    except Exception:
+        return None
+
 
 
 def log(*a):
@@ -205,8 +216,8 @@ def main():
                        "rays_per_gpu": M, "triangles": ntri, "parallelism": "rays sharded x%d, BVH replicated, no collective" % world,
                        "device_config": args.config},
             "roofline": {"bound": "hbm", "achieved": round(alg_bytes / (avg_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(alg_bytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
-                         "kernel": "trace_kernel<closest>", "kernel_ms_avg": round(avg_ms, 4), "kernel_ms_min": round(float(np.min(kernel_ms)), 4),
+                         "frac": round(alg_bytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(),
+                         "kernel": "trace_kernel_q<closest>", "kernel_ms_avg": round(avg_ms, 4), "kernel_ms_min": round(float(np.min(kernel_ms)), 4),
                          "algorithmic_bytes_per_launch": int(alg_bytes),
                          "per_ray": {"nodes": round(st["nodes"] / M, 2), "node_step_simd_util": round(st["nodes"] / max(1, 64 * st["node_blocks"]), 3),
                                      "tri_step_simd_util": round(st["tris"] / max(1, 64 * st["tri_blocks"]), 3),

@@ -796,7 +796,7 @@ extern "C" {
 
 void mi355_default_build_params(mi355_build_params* p) {
   memset(p, 0, sizeof(*p));
-  p->sah_block_shift = 0; p->min_leaf = 1; p->max_leaf = 3; p->small_threshold = 1024; p->trav_cost = 1.0f; p->int_cost = 1.0f;
+  p->sah_block_shift = 0; p->min_leaf = 2; p->max_leaf = 3; p->small_threshold = 1024; p->trav_cost = 1.0f; p->int_cost = 1.0f;
 }
 const char* mi355_last_error(void) { return mi355::g_err.c_str(); }
 int mi355_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }

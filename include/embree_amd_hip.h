@@ -41,7 +41,7 @@ typedef struct mi355_mesh {
 
 typedef struct mi355_build_params {
   uint32_t sah_block_shift;  /* SAH cost counts ceil(n / 2^shift) leaf blocks; reference: 2 (Triangle4).  default 0 */
-  uint32_t min_leaf;         /* never split sets of <= min_leaf triangles; reference: 4.            default 1, max 3 */
+  uint32_t min_leaf;         /* never split sets of <= min_leaf triangles; reference: 4.            default 2, max 3 */
   uint32_t max_leaf;         /* largest leaf slot; reference: 28 (7 Triangle4 blocks); encoding limit 3.  default 3 */
   uint32_t small_threshold;  /* sub-trees of <= this many triangles are finished by one wavefront in LDS.   default 1024 */
   float    trav_cost;        /* reference travCost = 1 */
