@@ -19,8 +19,9 @@
 //                     bins in LDS, explicit stack (larger child pushed), splits down to min_leaf
 //   K4 wide collapse  top-down, one thread per 8-wide node: the reference's greedy "split the child
 //                     with the largest half-area until 8 children" + leaf-vs-split SAH test evaluated
-//                     on the binary tree, children sorted by size, bounds quantised to 8 bits
-//   K5 tri_records    leaf-ordered TriRec array (v0, e1, e2, ids, mask)
+//                     on the binary tree; children placed in the slot matching their octant, inner
+//                     children / leaf triangles numbered consecutively, bounds quantised to 8 bits
+//   K5 tri_records    TriRec array in node order (v0, e1, e2, ids, mask)
 // Bin bounds/counts are combined with integer min/max/add, so the tree TOPOLOGY does not depend on
 // thread timing; leaves are sorted by (primID, geomID) like heuristic.deterministic_order
 // (heuristic_binning_array_aligned.h:178-182).  The tree need not equal the reference's tree:
