@@ -61,7 +61,7 @@ struct SmallEntry { uint32_t begin, end, bnode, buf; float cmin[3], cmax[3]; };
 struct Chunk { uint32_t seg, begin, end; };
 struct WideItem { uint32_t bnode, node; };
 struct Counters {
-  uint32_t numPrims, numBNodes, numSegsNext, numChunks, numSmall, numWide, numWideNext, numLeaves;
+  uint32_t numPrims, numBLeaves, numSegsNext, numChunks, numSmall, numWide, numWideNext, numLeaves;
   uint32_t bounds[12];                          // scene geom lo/hi + centroid lo/hi (ordered uint)
   uint32_t overflow, rootRef, numTrisOut, pad1;
   float sahSum;
@@ -258,16 +258,16 @@ __global__ __launch_bounds__(64) void top_split(Seg* segs, const uint32_t* bins,
     SplitResult r = s_res;
     const bool fallback = (r.dim < 0) || forceFallback;        // split invalid -> median split (split_template :144-147)
     const uint32_t nL = fallback ? ((begin + end) / 2u - begin) : r.nL;
-    const uint32_t base = atomicAdd(&ctr->numBNodes, 2u);
+    const uint32_t idL = sg->bnode + 1u, idR = sg->bnode + 2u * nL;   // implicit pre-order numbering (see K3)
     BNode* par = bnodes + sg->bnode;
-    par->left = base; par->right = base + 1u; par->splitSah = r.sah;
+    par->left = idL; par->right = idR; par->splitSah = r.sah;
     BNode L{}, R{};
     L.begin = begin; L.end = begin + nL; R.begin = begin + nL; R.end = end;
     L.left = L.right = R.left = R.right = NIL; L.splitSah = R.splitSah = __builtin_inff();
     for (int d = 0; d < 3; d++) { L.lo[d] = r.llo[d]; L.hi[d] = r.lhi[d]; R.lo[d] = r.rlo[d]; R.hi[d] = r.rhi[d]; }
-    bnodes[base] = L; bnodes[base + 1u] = R;
+    bnodes[idL] = L; bnodes[idR] = R;
     sg->flags = fallback ? 1u : 0u; sg->dim = fallback ? 0u : (uint32_t)r.dim; sg->pos = (uint32_t)r.pos; sg->nL = nL;
-    sg->childL = base; sg->childR = base + 1u; sg->curL = begin; sg->curR = begin + nL;
+    sg->childL = idL; sg->childR = idR; sg->curL = begin; sg->curR = begin + nL;
     for (int side = 0; side < 2; side++) for (int k = 0; k < 12; k++) sg->acc[side][k] = (k % 6 < 3) ? ENC_POS_INF : ENC_NEG_INF;
     (void)n;
   }
@@ -355,15 +355,182 @@ __global__ void top_emit(const Seg* segs, uint32_t numSegs, BNode* bnodes, Seg* 
 }
 
 // ---------------------------------------------------------------------------------- K3 small phase
+// One wavefront finishes a sub-tree of <= small_threshold triangles.  Two modes:
+//   * segments of more than MICRO triangles: the wave splits ONE segment at a time (bins in LDS, ping-pong partition
+//     through HBM/L2, explicit stack), exactly like the top phase but without leaving the CU;
+//   * segments of <= MICRO (= 64) triangles -- 94 % of all binary nodes of a scene -- are finished by micro_subtree():
+//     one triangle per lane, and ALL segments of a level are split in the same pass (per-segment bins, candidate
+//     evaluation, argmin and partition all live in LDS; segments are contiguous lane ranges).  A wave instruction thus
+//     serves up to 32 splits instead of one: the first version of this kernel spent 35 of the 45 ms of a 4.8 M triangle
+//     commit walking those tiny segments one by one (profiles/r01_bench_kernel_stats_v2.md).
+// Binary node numbering is implicit -- the children of node k over nL + nR triangles are k + 1 and k + 2 nL (pre-order,
+// a sub-tree of n triangles owns ids [k, k + 2n - 1)) -- so no global counter is touched and the numbering is the same
+// on every run.
 struct StackEntry { uint32_t begin, end, bnode, buf; float cmin[3], cmax[3]; };
+constexpr uint32_t MICRO = 64;
+
+// zero-identity encodings for LDS atomicMax accumulators that are cleared with plain zero stores
+__device__ __forceinline__ uint32_t zlo(float f) { return ~enc(f); }          // max of zlo = min of f
+__device__ __forceinline__ float unzlo(uint32_t u) { return dec(~u); }
+__device__ __forceinline__ uint32_t zhi(float f) { return enc(f); }           // enc(x) > 0 for every float
+__device__ __forceinline__ float unzhi(uint32_t u) { return dec(u); }
+__device__ __forceinline__ float sel3(uint32_t d, float a, float b, float c) { return d == 0u ? a : (d == 1u ? b : c); }
+
+// R: per-wave LDS scratch of 64 * W words (W = 28 words per triangle when min_leaf >= 2, 42 for min_leaf = 1):
+//   bins of the segment starting at lane b live at R + b * W as [axis][bin][7] (3 * nb * 7 <= n * W words for every
+//   splittable n); once the candidates are evaluated the same memory holds the split records (16 words per segment at
+//   R + b * 16) and the exchange buffer the partition moves the triangles through (10 x 64 words at R + 1024).
+__device__ void micro_subtree(uint32_t* R, uint32_t W, uint32_t (*s_cb)[64][6], unsigned long long* s_key, const PrimRef* src,
+                              uint32_t gbegin, uint32_t n0, uint32_t rootNode, const float* cmin0, const float* cmax0,
+                              BNode* bnodes, uint2* finalIds, Counters* ctr, const Params& prm, uint32_t lane) {
+  PrimRef p{};
+  if (lane < n0) p = load_prim(src + gbegin + lane);
+  uint32_t segB = 0, segE = n0, node = rootNode;
+  bool act = lane < n0 && n0 > prm.minLeaf;
+  if (lane < 6u) s_cb[0][0][lane] = lane < 3u ? zlo(cmin0[lane]) : zhi(cmax0[lane - 3u]);
+  __syncthreads();
+  const uint32_t addBlk = (1u << prm.shift) - 1u;
+  uint32_t pp = 0;
+  for (uint32_t level = 0; level < 64u; level++) {
+    if (__ballot(act) == 0ull) break;
+    // ---- L0: bin mapping of my segment (BinMapping, heuristic_binning.h:46-55); clear bins, keys, next level's centroid bounds
+    const uint32_t n = segE - segB;
+    float ofs[3] = {0, 0, 0}, scale[3] = {0, 0, 0}; uint32_t nb = 4;
+    if (act) {
+      float cmin[3], cmax[3];
+      for (int d = 0; d < 3; d++) { cmin[d] = unzlo(s_cb[pp][segB][d]); cmax[d] = unzhi(s_cb[pp][segB][3 + d]); }
+      const Mapping m = make_mapping(n, cmin, cmax);
+      for (int d = 0; d < 3; d++) { ofs[d] = m.ofs[d]; scale[d] = m.scale[d]; }
+      nb = m.nb;
+    }
+    __syncthreads();                                             // everybody has read s_cb[pp] and is done with the exchange buffer
+    for (uint32_t i = 0; i < W; i++) R[i * 64u + lane] = 0u;
+    s_key[lane] = ~0ull;
+    for (int k = 0; k < 6; k++) s_cb[pp ^ 1u][lane][k] = 0u;
+    __syncthreads();
+    // ---- L1: bin (BinInfoT::bin, heuristic_binning.h:210-257)
+    uint32_t* const sb = R + segB * W;
+    if (act) {
+      for (int d = 0; d < 3; d++) {
+        const int b = bin_clamped(p.lo[d] + p.hi[d], ofs[d], scale[d], nb);
+        uint32_t* e = sb + ((uint32_t)d * nb + (uint32_t)b) * 7u;
+        atomicMax(&e[0], zlo(p.lo[0])); atomicMax(&e[1], zlo(p.lo[1])); atomicMax(&e[2], zlo(p.lo[2]));
+        atomicMax(&e[3], zhi(p.hi[0])); atomicMax(&e[4], zhi(p.hi[1])); atomicMax(&e[5], zhi(p.hi[2]));
+        atomicAdd(&e[6], 1u);
+      }
+    }
+    __syncthreads();
+    // ---- L2: candidates (BinInfoT::best :339-386): lane j of a segment evaluates candidates j, j + n, ...;
+    //      candidate c = axis * (nb - 1) + (pos - 1), so the minimum of (sah, c) is the reference's choice
+    float bestSah = __builtin_inff(); uint32_t bestC = NIL, bestNL = 0;
+    float bl[3] = {0, 0, 0}, bh[3] = {0, 0, 0}, rl[3] = {0, 0, 0}, rh[3] = {0, 0, 0};
+    if (act) {
+      const uint32_t nb1 = nb - 1u, ncand = 3u * nb1;
+      for (uint32_t c = lane - segB; c < ncand; c += n) {
+        const uint32_t axis = (c >= nb1 ? 1u : 0u) + (c >= 2u * nb1 ? 1u : 0u), pos = c - axis * nb1 + 1u;
+        if (sel3(axis, scale[0], scale[1], scale[2]) == 0.0f) continue;          // mapping.invalid(dim) :375
+        float llo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, lhi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+        float rlo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, rhi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+        uint32_t lN = 0, rN = 0;
+        for (uint32_t b = 0; b < nb; b++) {
+          const uint32_t* e = sb + (axis * nb + b) * 7u;
+          const uint32_t cnt = e[6];
+          if (cnt == 0u) continue;
+          if (b < pos) { lN += cnt; for (int d = 0; d < 3; d++) { llo[d] = fminf(llo[d], unzlo(e[d])); lhi[d] = fmaxf(lhi[d], unzhi(e[3 + d])); } }
+          else         { rN += cnt; for (int d = 0; d < 3; d++) { rlo[d] = fminf(rlo[d], unzlo(e[d])); rhi[d] = fmaxf(rhi[d], unzhi(e[3 + d])); } }
+        }
+        if (lN == 0u || rN == 0u) continue;
+        const float lA = half_area3(lhi[0] - llo[0], lhi[1] - llo[1], lhi[2] - llo[2]);
+        const float rA = half_area3(rhi[0] - rlo[0], rhi[1] - rlo[1], rhi[2] - rlo[2]);
+        const float sah = fmaf(lA, (float)((lN + addBlk) >> prm.shift), rA * (float)((rN + addBlk) >> prm.shift));
+        if (sah < bestSah) {
+          bestSah = sah; bestC = c; bestNL = lN;
+          for (int d = 0; d < 3; d++) { bl[d] = llo[d]; bh[d] = lhi[d]; rl[d] = rlo[d]; rh[d] = rhi[d]; }
+        }
+      }
+    }
+    const unsigned long long key = bestC == NIL ? ~0ull : (((unsigned long long)__float_as_uint(bestSah) << 32) | bestC);
+    if (act && key != ~0ull) atomicMin(&s_key[segB], key);
+    __syncthreads();                                             // bins are dead from here on: R now holds split records + exchange buffer
+    const unsigned long long win = act ? s_key[segB] : 0ull;
+    const bool fb = act && win == ~0ull;                          // no valid candidate -> median split (split_template :144-147)
+    uint32_t* const rec = R + segB * 16u;
+    if (act && !fb && key == win) {
+      const uint32_t nb1 = nb - 1u, axis = (bestC >= nb1 ? 1u : 0u) + (bestC >= 2u * nb1 ? 1u : 0u), pos = bestC - axis * nb1 + 1u;
+      rec[0] = axis | (pos << 8); rec[1] = bestNL; rec[2] = __float_as_uint(bestSah);
+      for (int d = 0; d < 3; d++) { rec[4 + d] = __float_as_uint(bl[d]); rec[7 + d] = __float_as_uint(bh[d]); rec[10 + d] = __float_as_uint(rl[d]); rec[13 + d] = __float_as_uint(rh[d]); }
+    }
+    if (fb && lane == segB) {
+      rec[0] = 1u << 16; rec[1] = (gbegin + segB + gbegin + segE) / 2u - (gbegin + segB); rec[2] = __float_as_uint(__builtin_inff());
+      for (int k = 4; k < 16; k++) rec[k] = 0u;
+    }
+    __syncthreads();
+    if (__ballot(fb) != 0ull) {                                   // child geometry bounds of a median split: reduce over the triangles
+      if (fb) {
+        const uint32_t o = lane < segB + rec[1] ? 4u : 10u;
+        for (int d = 0; d < 3; d++) { atomicMax(&rec[o + d], zlo(p.lo[d])); atomicMax(&rec[o + 3 + d], zhi(p.hi[d])); }
+      }
+      __syncthreads();
+    }
+    // ---- L4: partition (heuristic_binning_array_aligned.h:150-176): new lane of my triangle, child centroid bounds, node records
+    bool left = false; uint32_t nL = 0;
+    if (act) {
+      const uint32_t w0 = rec[0], dim = w0 & 3u, pos = (w0 >> 8) & 0xFFu; nL = rec[1];
+      const float c2 = sel3(dim, p.lo[0] + p.hi[0], p.lo[1] + p.hi[1], p.lo[2] + p.hi[2]);
+      left = (w0 >> 16) ? (lane < segB + nL) : (bin_unsafe(c2, sel3(dim, ofs[0], ofs[1], ofs[2]), sel3(dim, scale[0], scale[1], scale[2])) < (int)pos);
+    }
+    const unsigned long long segMask = act ? ((n >= 64u ? ~0ull : ((1ull << n) - 1ull)) << segB) : 0ull;
+    const unsigned long long lm = __ballot(act && left) & segMask, rm = __ballot(act && !left) & segMask, lt = (1ull << lane) - 1ull;
+    if (act) {
+      const uint32_t nSegB = left ? segB : segB + nL, nSegE = left ? segB + nL : segE, nNode = left ? node + 1u : node + 2u * nL;
+      const uint32_t npos = left ? segB + (uint32_t)__popcll(lm & lt) : segB + nL + (uint32_t)__popcll(rm & lt);
+      for (int d = 0; d < 3; d++) { const float cc = p.lo[d] + p.hi[d]; atomicMax(&s_cb[pp ^ 1u][nSegB][d], zlo(cc)); atomicMax(&s_cb[pp ^ 1u][nSegB][3 + d], zhi(cc)); }
+      uint32_t* X = R + 1024u + npos;
+      X[0] = __float_as_uint(p.lo[0]); X[64] = __float_as_uint(p.lo[1]); X[128] = __float_as_uint(p.lo[2]); X[192] = p.geom;
+      X[256] = __float_as_uint(p.hi[0]); X[320] = __float_as_uint(p.hi[1]); X[384] = __float_as_uint(p.hi[2]); X[448] = p.prim;
+      X[512] = nSegB | (nSegE << 8); X[576] = nNode;
+      if (lane == segB) {                                        // one lane per segment: my links, my children's boxes and ranges
+        const bool isfb = (rec[0] >> 16) != 0u;
+        float cb[12];
+        for (int k = 0; k < 12; k++) cb[k] = isfb ? ((k % 6) < 3 ? unzlo(rec[4 + k]) : unzhi(rec[4 + k])) : __uint_as_float(rec[4 + k]);
+        const uint32_t L = node + 1u, Rr = node + 2u * nL;
+        ((uint4*)(bnodes + node))[2] = make_uint4(L, Rr, rec[2], 0u);
+        ((float4*)(bnodes + L))[0] = make_float4(cb[0], cb[1], cb[2], __uint_as_float(gbegin + segB));
+        ((float4*)(bnodes + L))[1] = make_float4(cb[3], cb[4], cb[5], __uint_as_float(gbegin + segB + nL));
+        ((float4*)(bnodes + Rr))[0] = make_float4(cb[6], cb[7], cb[8], __uint_as_float(gbegin + segB + nL));
+        ((float4*)(bnodes + Rr))[1] = make_float4(cb[9], cb[10], cb[11], __uint_as_float(gbegin + segE));
+      }
+    }
+    __syncthreads();
+    // ---- L5: pick up the triangle that moved to my lane
+    if (act) {
+      const uint32_t* X = R + 1024u + lane;
+      p.lo[0] = __uint_as_float(X[0]); p.lo[1] = __uint_as_float(X[64]); p.lo[2] = __uint_as_float(X[128]); p.geom = X[192];
+      p.hi[0] = __uint_as_float(X[256]); p.hi[1] = __uint_as_float(X[320]); p.hi[2] = __uint_as_float(X[384]); p.prim = X[448];
+      segB = X[512] & 0xFFu; segE = X[512] >> 8; node = X[576];
+      act = segE - segB > prm.minLeaf;
+    }
+    pp ^= 1u;
+  }
+  // every remaining segment is a binary leaf (the reference never splits sets of <= minLeafSize, bvh_builder_sah.h:253)
+  if (lane < n0) {
+    finalIds[gbegin + lane] = make_uint2(p.geom, p.prim);
+    if (lane == segB) ((uint4*)(bnodes + node))[2] = make_uint4(NIL, NIL, __float_as_uint(__builtin_inff()), 0u);
+  }
+  const unsigned long long leaves = __ballot(lane < n0 && lane == segB);
+  if (lane == 0u) atomicAdd(&ctr->numBLeaves, (uint32_t)__popcll(leaves));
+  __syncthreads();
+}
 
 __global__ __launch_bounds__(64) void small_build(const SmallEntry* entries, PrimRef* bufA, PrimRef* bufB, BNode* bnodes,
-                                                  uint2* finalIds, Counters* ctr, Params prm) {
-  __shared__ uint32_t s_bins[BINS_WORDS];
+                                                  uint2* finalIds, Counters* ctr, Params prm, uint32_t W) {
+  extern __shared__ uint32_t s_R[];                            // max(BINS_WORDS, 64 * W) words: bins / micro scratch
   __shared__ SplitResult s_res;
   __shared__ uint32_t s_acc[2][12];
   __shared__ StackEntry s_stack[24];
-  __shared__ uint32_t s_alloc;
+  __shared__ uint32_t s_cb[2][64][6];
+  __shared__ unsigned long long s_key[64];
+  uint32_t* const s_bins = s_R;
   const uint32_t lane = threadIdx.x;
   const SmallEntry e0 = entries[blockIdx.x];
   StackEntry cur; cur.begin = e0.begin; cur.end = e0.end; cur.bnode = e0.bnode; cur.buf = e0.buf;
@@ -373,11 +540,9 @@ __global__ __launch_bounds__(64) void small_build(const SmallEntry* entries, Pri
     const uint32_t n = cur.end - cur.begin;
     PrimRef* src = cur.buf ? bufB : bufA;
     PrimRef* dst = cur.buf ? bufA : bufB;
-    if (n <= prm.minLeaf) {
-      // binary leaf (the reference never splits sets of <= minLeafSize, bvh_builder_sah.h:253): fix the final order
-      for (uint32_t i = lane; i < n; i += 64u) { const PrimRef r = load_prim(src + cur.begin + i); finalIds[cur.begin + i] = make_uint2(r.geom, r.prim); }
+    if (n <= MICRO) {
+      micro_subtree(s_R, W, s_cb, s_key, src, cur.begin, n, cur.bnode, cur.cmin, cur.cmax, bnodes, finalIds, ctr, prm, lane);
       if (sp == 0) break;
-      __syncthreads();
       cur = s_stack[--sp];
       __syncthreads();
       continue;
@@ -414,19 +579,18 @@ __global__ __launch_bounds__(64) void small_build(const SmallEntry* entries, Pri
       if (v) store_prim(dst + (left ? curL + (uint32_t)__popcll(lm & lt) : curR + (uint32_t)__popcll(rm & lt)), p);
       curL += (uint32_t)__popcll(lm); curR += (uint32_t)__popcll(rm);
     }
-    if (lane == 0) s_alloc = atomicAdd(&ctr->numBNodes, 2u);
     __syncthreads();
-    const uint32_t base = s_alloc;
+    const uint32_t idL = cur.bnode + 1u, idR = cur.bnode + 2u * (mid - cur.begin);
     StackEntry L, R;
-    L.begin = cur.begin; L.end = mid; L.bnode = base; L.buf = cur.buf ^ 1u;
-    R.begin = mid; R.end = cur.end; R.bnode = base + 1u; R.buf = cur.buf ^ 1u;
+    L.begin = cur.begin; L.end = mid; L.bnode = idL; L.buf = cur.buf ^ 1u;
+    R.begin = mid; R.end = cur.end; R.bnode = idR; R.buf = cur.buf ^ 1u;
     for (int d = 0; d < 3; d++) {
       L.cmin[d] = dec(s_acc[0][d]); L.cmax[d] = dec(s_acc[0][3 + d]);
       R.cmin[d] = dec(s_acc[1][d]); R.cmax[d] = dec(s_acc[1][3 + d]);
     }
     if (lane == 0) {
       BNode* par = bnodes + cur.bnode;
-      par->left = base; par->right = base + 1u; par->splitSah = r.sah;
+      par->left = idL; par->right = idR; par->splitSah = r.sah;
       BNode bl{}, br{};
       bl.begin = L.begin; bl.end = L.end; br.begin = R.begin; br.end = R.end;
       bl.left = bl.right = br.left = br.right = NIL; bl.splitSah = br.splitSah = __builtin_inff();
@@ -434,7 +598,7 @@ __global__ __launch_bounds__(64) void small_build(const SmallEntry* entries, Pri
         bl.lo[d] = fallback ? dec(s_acc[0][6 + d]) : r.llo[d]; bl.hi[d] = fallback ? dec(s_acc[0][9 + d]) : r.lhi[d];
         br.lo[d] = fallback ? dec(s_acc[1][6 + d]) : r.rlo[d]; br.hi[d] = fallback ? dec(s_acc[1][9 + d]) : r.rhi[d];
       }
-      bnodes[base] = bl; bnodes[base + 1u] = br;
+      bnodes[idL] = bl; bnodes[idR] = br;
     }
     // continue with the smaller child, push the larger: the stack stays <= log2(small_threshold) deep
     const bool leftSmaller = (L.end - L.begin) <= (R.end - R.begin);
@@ -709,7 +873,7 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
   // root binary node + first work item
   BNode rootB{}; for (int d = 0; d < 3; d++) { rootB.lo[d] = glo[d]; rootB.hi[d] = ghi[d]; } rootB.begin = 0; rootB.end = n; rootB.left = rootB.right = NIL; rootB.splitSah = INFINITY;
   HIP_TRY(hipMemcpyAsync(bnodes.p, &rootB, sizeof(rootB), hipMemcpyHostToDevice, st));
-  h.numBNodes = 1; h.numSegsNext = 0; h.numChunks = 0; h.numSmall = 0;
+  h.numBLeaves = 0; h.numSegsNext = 0; h.numChunks = 0; h.numSmall = 0;
   uint32_t numSegs = 0, numSmall = 0;
   if (n > prm.small) {
     Seg s0{}; s0.begin = 0; s0.end = n; s0.bnode = 0; for (int d = 0; d < 3; d++) { s0.cmin[d] = clo[d]; s0.cmax[d] = chi[d]; }
@@ -749,7 +913,9 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
   if (numSmall > maxSmall) return set_error(hipErrorOutOfMemory, "small list overflow");
 
   // ---- small phase
-  if (numSmall) hipLaunchKernelGGL(small_build, dim3(numSmall), dim3(64), 0, st, small.p, bufA.p, bufB.p, bnodes.p, finalIds.p, ctr.p, prm);
+  const uint32_t microW = prm.minLeaf >= 2u ? 28u : 42u;       // LDS words per triangle of the micro mode (see micro_subtree)
+  const size_t smallLds = sizeof(uint32_t) * (64u * microW > (uint32_t)BINS_WORDS ? 64u * microW : (uint32_t)BINS_WORDS);
+  if (numSmall) hipLaunchKernelGGL(small_build, dim3(numSmall), dim3(64), smallLds, st, small.p, bufA.p, bufB.p, bnodes.p, finalIds.p, ctr.p, prm, microW);
   HIP_TRY(hipGetLastError());
 
   // ---- wide collapse, level by level
@@ -784,7 +950,7 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
   HIP_TRY(hipEventRecord(ev1, st)); HIP_TRY(hipEventSynchronize(ev1));
   float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
   bvh->root = h.rootRef;
-  info.root_ref = h.rootRef; info.num_nodes = numNodes; info.num_leaves = h.numLeaves; info.num_binary_nodes = h.numBNodes;
+  info.root_ref = h.rootRef; info.num_nodes = numNodes; info.num_leaves = h.numLeaves; info.num_binary_nodes = 2ull * h.numBLeaves - 1ull;
   info.bytes_nodes = (uint64_t)numNodes * sizeof(CNode); info.bytes_triangles = (uint64_t)n * sizeof(TriRec);
   info.sah = h.sahSum + (numNodes ? prm.travCost : 0.0f); info.build_ms = ms; info.depth = depth;
   guard.ok = true; *out = bvh;
