@@ -63,7 +63,8 @@ struct WideItem { uint32_t bnode, node; };
 struct Counters {
   uint32_t numPrims, numBLeaves, numSegsNext, numChunks, numSmall, numWide, numWideNext, numLeaves;
   uint32_t bounds[12];                          // scene geom lo/hi + centroid lo/hi (ordered uint)
-  uint32_t overflow, rootRef, numTrisOut, pad1;
+  uint32_t overflow, rootRef, numTrisOut, numInvalid;
+  uint32_t numSegs, topLevels, numWideCur, wideDepth;      // level loops are driven from the device: no host readback per level
   float sahSum;
 };
 struct Params { uint32_t shift, minLeaf, maxLeaf, small; float travCost, intCost; };
@@ -84,23 +85,47 @@ __device__ __forceinline__ void store_prim(PrimRef* p, const PrimRef& r) {
   ((float4*)p)[1] = make_float4(r.hi[0], r.hi[1], r.hi[2], __uint_as_float(r.prim));
 }
 
+// ---- wave64 reductions on ordered-uint codes (DPP: quad_perm, row_shr:4/8, row_bcast:15/31); the result is valid in lane 63.
+// LDS/L2 atomics of a wave that all hit the same word are executed one lane after the other (measured: ~1 lane-atomic per
+// clock per CU on mesh-ordered input, where neighbouring triangles fall into the same bin), so the lanes are combined
+// in registers first and one lane issues the atomic.
+template <int CTRL, int ROWMASK> __device__ __forceinline__ uint32_t dpp_u(uint32_t old, uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, ROWMASK, 0xF, false);
+}
+__device__ __forceinline__ uint32_t wave_umin63(uint32_t v) {
+  v = min(v, dpp_u<0xB1, 0xF>(v, v)); v = min(v, dpp_u<0x4E, 0xF>(v, v)); v = min(v, dpp_u<0x114, 0xF>(v, v));
+  v = min(v, dpp_u<0x118, 0xF>(v, v)); v = min(v, dpp_u<0x142, 0xA>(v, v)); v = min(v, dpp_u<0x143, 0xC>(v, v));
+  return v;
+}
+__device__ __forceinline__ uint32_t wave_umax63(uint32_t v) {
+  v = max(v, dpp_u<0xB1, 0xF>(v, v)); v = max(v, dpp_u<0x4E, 0xF>(v, v)); v = max(v, dpp_u<0x114, 0xF>(v, v));
+  v = max(v, dpp_u<0x118, 0xF>(v, v)); v = max(v, dpp_u<0x142, 0xA>(v, v)); v = max(v, dpp_u<0x143, 0xC>(v, v));
+  return v;
+}
+
 // ---------------------------------------------------------------------------------- K1 primref_gen
+// Triangle p of the concatenated geometries lands at out[p]: no compaction counter (a returning global atomic per
+// block costs ~11 ns each, 0.2 ms for a 4.8 M triangle scene, and makes the order depend on block timing).  Invalid
+// triangles (index out of range, non-finite or huge coordinate) are marked geom = NIL and counted; only if there are
+// any does primref_compact squeeze them out afterwards (stable, so the order is still the input order).
 __global__ __launch_bounds__(256) void primref_gen(const GeomDesc* geoms, uint32_t numGeoms, uint32_t totalPrims,
                                                    PrimRef* out, Counters* ctr) {
   __shared__ uint32_t s_acc[12];
-  __shared__ uint32_t s_wcnt[4], s_base;
-  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u;
   if (tid < 12) s_acc[tid] = (tid % 6 < 3) ? ENC_POS_INF : ENC_NEG_INF;
   __syncthreads();
-  const uint32_t p = blockIdx.x * 256u + tid;
-  bool ok = false; PrimRef r{};
-  if (p < totalPrims) {
-    uint32_t lo = 0, hi = numGeoms - 1;                       // last geometry with primOffset <= p
-    while (lo < hi) { uint32_t mid = (lo + hi + 1) >> 1; if (geoms[mid].primOffset <= p) lo = mid; else hi = mid - 1; }
-    const GeomDesc g = geoms[lo];
+  uint32_t acc[12]; for (int k = 0; k < 12; k++) acc[k] = (k % 6 < 3) ? 0xFFFFFFFFu : 0u;
+  uint32_t gi = 0, nInvalid = 0; GeomDesc g = geoms[0];
+  for (uint32_t p = blockIdx.x * 256u + tid; p < totalPrims; p += gridDim.x * 256u) {
+    if (p - g.primOffset >= g.nt) {                             // not in the cached geometry: last geometry with primOffset <= p
+      uint32_t lo = 0, hi = numGeoms - 1;
+      while (lo < hi) { uint32_t mid = (lo + hi + 1) >> 1; if (geoms[mid].primOffset <= p) lo = mid; else hi = mid - 1; }
+      gi = lo; g = geoms[lo];
+    }
     const uint32_t j = p - g.primOffset;
     const uint32_t* tri = (const uint32_t*)(g.idx + (size_t)j * g.istride);
     const uint32_t i0 = tri[0], i1 = tri[1], i2 = tri[2];
+    bool ok = false; PrimRef r{};
     if (i0 < g.nv && i1 < g.nv && i2 < g.nv) {
       const float* a = (const float*)(g.verts + (size_t)i0 * g.vstride);
       const float* b = (const float*)(g.verts + (size_t)i1 * g.vstride);
@@ -111,29 +136,52 @@ __global__ __launch_bounds__(256) void primref_gen(const GeomDesc* geoms, uint32
         ok = ok && valid_f(x) && valid_f(y) && valid_f(z);
         r.lo[d] = fminf(fminf(x, y), z); r.hi[d] = fmaxf(fmaxf(x, y), z);
       }
-      r.geom = lo; r.prim = j;
     }
+    r.geom = ok ? gi : NIL; r.prim = j;
+    store_prim(out + p, r);
+    if (ok) {
+      for (int d = 0; d < 3; d++) {
+        const uint32_t l = enc(r.lo[d]), h = enc(r.hi[d]), c2 = enc(r.lo[d] + r.hi[d]);   // centroid proxy = lower+upper, never halved (priminfo.h:46-52)
+        acc[d] = min(acc[d], l); acc[3 + d] = max(acc[3 + d], h); acc[6 + d] = min(acc[6 + d], c2); acc[9 + d] = max(acc[9 + d], c2);
+      }
+    } else nInvalid++;
   }
+  for (int k = 0; k < 12; k++) {
+    const uint32_t x = (k % 6 < 3) ? wave_umin63(acc[k]) : wave_umax63(acc[k]);
+    if (lane == 63u) { if (k % 6 < 3) atomicMin(&s_acc[k], x); else atomicMax(&s_acc[k], x); }
+  }
+  const unsigned long long bad = __ballot(nInvalid != 0u);
+  if (bad != 0ull && nInvalid) atomicAdd(&ctr->numInvalid, nInvalid);
+  __syncthreads();
+  if (tid < 12) { if (tid % 6 < 3) atomicMin(&ctr->bounds[tid], s_acc[tid]); else atomicMax(&ctr->bounds[tid], s_acc[tid]); }
+}
+
+// rare path: stable compaction of the valid PrimRefs (tile = 256 consecutive entries)
+__global__ __launch_bounds__(256) void compact_count(const PrimRef* in, uint32_t n, uint32_t* tileCount) {
+  const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+  const bool ok = p < n && in[p].geom != NIL;
+  const int c = __syncthreads_count(ok);
+  if (threadIdx.x == 0) tileCount[blockIdx.x] = (uint32_t)c;
+}
+__global__ __launch_bounds__(1024) void compact_scan(uint32_t* tileCount, uint32_t numTiles, Counters* ctr) {
+  __shared__ uint32_t s_part[1024];
+  const uint32_t tid = threadIdx.x, per = (numTiles + 1023u) / 1024u, b = tid * per, e = min(b + per, numTiles);
+  uint32_t sum = 0; for (uint32_t i = b; i < e; i++) sum += tileCount[i];
+  s_part[tid] = sum; __syncthreads();
+  if (tid == 0) { uint32_t run = 0; for (int i = 0; i < 1024; i++) { const uint32_t t = s_part[i]; s_part[i] = run; run += t; } ctr->numPrims = run; }
+  __syncthreads();
+  uint32_t run = s_part[tid]; for (uint32_t i = b; i < e; i++) { const uint32_t t = tileCount[i]; tileCount[i] = run; run += t; }
+}
+__global__ __launch_bounds__(256) void compact_scatter(const PrimRef* in, uint32_t n, const uint32_t* tileOfs, PrimRef* out) {
+  __shared__ uint32_t s_w[4];
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, p = blockIdx.x * 256u + tid;
+  PrimRef r{}; bool ok = false;
+  if (p < n) { r = load_prim(in + p); ok = r.geom != NIL; }
   const unsigned long long m = __ballot(ok);
-  if (lane == 0) s_wcnt[wave] = (uint32_t)__popcll(m);
-  if (ok) {
-    for (int d = 0; d < 3; d++) {
-      atomicMin(&s_acc[d], enc(r.lo[d])); atomicMax(&s_acc[3 + d], enc(r.hi[d]));
-      const float c2 = r.lo[d] + r.hi[d];                      // centroid proxy = lower+upper, never halved (priminfo.h:46-52)
-      atomicMin(&s_acc[6 + d], enc(c2)); atomicMax(&s_acc[9 + d], enc(c2));
-    }
-  }
+  if (lane == 0) s_w[wave] = (uint32_t)__popcll(m);
   __syncthreads();
-  if (tid == 0) { const uint32_t n = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3]; s_base = n ? atomicAdd(&ctr->numPrims, n) : 0u; }
-  __syncthreads();
-  if (ok) {
-    uint32_t off = s_base; for (uint32_t w = 0; w < wave; w++) off += s_wcnt[w];
-    off += (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-    store_prim(out + off, r);
-  }
-  if (tid < 12 && s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3] > 0) {
-    if (tid % 6 < 3) atomicMin(&ctr->bounds[tid], s_acc[tid]); else atomicMax(&ctr->bounds[tid], s_acc[tid]);
-  }
+  uint32_t off = tileOfs[blockIdx.x]; for (uint32_t w = 0; w < wave; w++) off += s_w[w];
+  if (ok) store_prim(out + off + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)), r);
 }
 
 // -------------------------------------------------------------------------------- binning helpers
@@ -162,6 +210,41 @@ __device__ __forceinline__ void bins_add(uint32_t* bins, const Mapping& m, const
     atomicMin(&e[0], enc(r.lo[0])); atomicMin(&e[1], enc(r.lo[1])); atomicMin(&e[2], enc(r.lo[2]));
     atomicMax(&e[3], enc(r.hi[0])); atomicMax(&e[4], enc(r.hi[1])); atomicMax(&e[5], enc(r.hi[2]));
     atomicAdd(&e[6], 1u);
+  }
+}
+
+// wave-cooperative version: every lane of the wave calls it (valid = this lane holds a triangle).  Per axis, the lanes that
+// share the bin of the first pending lane are reduced in registers and lane 63 issues their 7 atomics; this is repeated once
+// for what is left, the rest goes lane by lane.
+__device__ __forceinline__ void bins_add_wave(uint32_t* bins, const Mapping& m, const PrimRef& r, bool valid, uint32_t lane) {
+  uint32_t c[6];
+  for (int k = 0; k < 3; k++) { c[k] = enc(r.lo[k]); c[3 + k] = enc(r.hi[k]); }
+  for (int d = 0; d < 3; d++) {
+    int b = valid ? bin_clamped(r.lo[d] + r.hi[d], m.ofs[d], m.scale[d], m.nb) : -1;
+    unsigned long long rem = __ballot(b >= 0);
+    for (int round = 0; round < 2; round++) {
+      if (__popcll(rem) < 12) break;
+      const int b0 = __builtin_amdgcn_readlane(b, __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(rem)));
+      const bool mt = b == b0;
+      const unsigned long long mm = __ballot(mt);
+      if (__popcll(mm) < 6) break;
+      uint32_t v[6];
+      for (int k = 0; k < 3; k++) { v[k] = wave_umin63(mt ? c[k] : 0xFFFFFFFFu); v[3 + k] = wave_umax63(mt ? c[3 + k] : 0u); }
+      if (lane == 63u) {
+        uint32_t* e = bins + (d * NBINS + b0) * BINW;
+        atomicMin(&e[0], v[0]); atomicMin(&e[1], v[1]); atomicMin(&e[2], v[2]);
+        atomicMax(&e[3], v[3]); atomicMax(&e[4], v[4]); atomicMax(&e[5], v[5]);
+        atomicAdd(&e[6], (uint32_t)__popcll(mm));
+      }
+      if (mt) b = -1;
+      rem &= ~mm;
+    }
+    if (b >= 0) {
+      uint32_t* e = bins + (d * NBINS + b) * BINW;
+      atomicMin(&e[0], c[0]); atomicMin(&e[1], c[1]); atomicMin(&e[2], c[2]);
+      atomicMax(&e[3], c[3]); atomicMax(&e[4], c[4]); atomicMax(&e[5], c[5]);
+      atomicAdd(&e[6], 1u);
+    }
   }
 }
 
@@ -208,9 +291,10 @@ __device__ void sah_best_wave(const uint32_t* bins, const Mapping& m, uint32_t s
 }
 
 // ------------------------------------------------------------------------------------ K2 top phase
-__global__ __launch_bounds__(256) void top_setup(Seg* segs, uint32_t numSegs, uint32_t* bins, Chunk* chunks, Counters* ctr) {
+__global__ __launch_bounds__(256) void top_setup(Seg* segs, uint32_t* bins, Chunk* chunks, Counters* ctr) {
   __shared__ uint32_t s_base;
   const uint32_t s = blockIdx.x, tid = threadIdx.x;
+  if (s >= ctr->numSegs) return;                                // the grid is an upper bound (2^level segments at most)
   Seg* sg = segs + s;
   const uint32_t begin = sg->begin, end = sg->end, n = end - begin;
   bins_clear(bins + (size_t)s * BINS_WORDS, tid, 256u);
@@ -228,15 +312,20 @@ __global__ __launch_bounds__(256) void top_setup(Seg* segs, uint32_t numSegs, ui
   }
 }
 
-__global__ __launch_bounds__(256) void top_bin(const Seg* segs, const Chunk* chunks, const PrimRef* src, uint32_t* bins) {
+__global__ __launch_bounds__(256) void top_bin(const Seg* segs, const Chunk* chunks, const PrimRef* src, uint32_t* bins, const Counters* ctr) {
   __shared__ uint32_t s_bins[BINS_WORDS];
   const uint32_t tid = threadIdx.x;
+  if (blockIdx.x >= ctr->numChunks) return;
   const Chunk ck = chunks[blockIdx.x];
   const Seg* sg = segs + ck.seg;
   Mapping m; for (int d = 0; d < 3; d++) { m.ofs[d] = sg->ofs[d]; m.scale[d] = sg->scale[d]; } m.nb = sg->nb;
   bins_clear(s_bins, tid, 256u);
   __syncthreads();
-  for (uint32_t i = ck.begin + tid; i < ck.end; i += 256u) bins_add(s_bins, m, load_prim(src + i));
+  for (uint32_t i0 = ck.begin; i0 < ck.end; i0 += 256u) {       // block-uniform trip count
+    const uint32_t i = i0 + tid; const bool v = i < ck.end;
+    PrimRef r{}; if (v) r = load_prim(src + i);
+    bins_add_wave(s_bins, m, r, v, tid & 63u);
+  }
   __syncthreads();
   uint32_t* g = bins + (size_t)ck.seg * BINS_WORDS;
   for (uint32_t w = tid; w < (uint32_t)BINS_WORDS; w += 256u) {      // BinInfoT::merge :312-321
@@ -249,6 +338,7 @@ __global__ __launch_bounds__(256) void top_bin(const Seg* segs, const Chunk* chu
 __global__ __launch_bounds__(64) void top_split(Seg* segs, const uint32_t* bins, BNode* bnodes, Counters* ctr, Params prm, uint32_t forceFallback) {
   __shared__ SplitResult s_res;
   const uint32_t s = blockIdx.x, lane = threadIdx.x;
+  if (s >= ctr->numSegs) return;
   Seg* sg = segs + s;
   Mapping m; for (int d = 0; d < 3; d++) { m.ofs[d] = sg->ofs[d]; m.scale[d] = sg->scale[d]; } m.nb = sg->nb;
   sah_best_wave(bins + (size_t)s * BINS_WORDS, m, prm.shift, &s_res, lane);
@@ -273,9 +363,10 @@ __global__ __launch_bounds__(64) void top_split(Seg* segs, const uint32_t* bins,
   }
 }
 
-__global__ __launch_bounds__(256) void top_partition(Seg* segs, const Chunk* chunks, const PrimRef* src, PrimRef* dst) {
+__global__ __launch_bounds__(256) void top_partition(Seg* segs, const Chunk* chunks, const PrimRef* src, PrimRef* dst, const Counters* ctr) {
   __shared__ uint32_t s_cnt[8][4][2], s_off[8][4][2], s_acc[2][12], s_baseL, s_baseR;
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  if (blockIdx.x >= ctr->numChunks) return;
   const Chunk ck = chunks[blockIdx.x];
   Seg* sg = segs + ck.seg;
   const bool fallback = (sg->flags & 1u) != 0u;
@@ -284,6 +375,7 @@ __global__ __launch_bounds__(256) void top_partition(Seg* segs, const Chunk* chu
   if (tid < 24) s_acc[tid / 12][tid % 12] = (tid % 6 < 3) ? ENC_POS_INF : ENC_NEG_INF;
   __syncthreads();
   PrimRef pr[8]; uint32_t sideBits = 0, validBits = 0; unsigned long long lm[8], rm[8];
+  uint32_t aL[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u}, aR[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
 #pragma unroll
   for (int r = 0; r < 8; r++) {
     const uint32_t i = ck.begin + (uint32_t)r * 256u + tid;
@@ -294,9 +386,9 @@ __global__ __launch_bounds__(256) void top_partition(Seg* segs, const Chunk* chu
       const float c2 = pr[r].lo[dim] + pr[r].hi[dim];
       left = fallback ? (i < mid) : (bin_unsafe(c2, ofs, scale) < (int)pos);     // isLeft: bin_unsafe(center2) < pos (:161)
       const int side = left ? 0 : 1;
-      for (int d = 0; d < 3; d++) {                                              // extend_center2 of the child (:168)
-        const float cc = pr[r].lo[d] + pr[r].hi[d];
-        atomicMin(&s_acc[side][d], enc(cc)); atomicMax(&s_acc[side][3 + d], enc(cc));
+      for (int d = 0; d < 3; d++) {                                              // extend_center2 of the child (:168), thread-private first
+        const uint32_t cc = enc(pr[r].lo[d] + pr[r].hi[d]);
+        if (left) { aL[d] = min(aL[d], cc); aL[3 + d] = max(aL[3 + d], cc); } else { aR[d] = min(aR[d], cc); aR[3 + d] = max(aR[3 + d], cc); }
       }
       if (fallback) for (int d = 0; d < 3; d++) { atomicMin(&s_acc[side][6 + d], enc(pr[r].lo[d])); atomicMax(&s_acc[side][9 + d], enc(pr[r].hi[d])); }
     }
@@ -304,6 +396,10 @@ __global__ __launch_bounds__(256) void top_partition(Seg* segs, const Chunk* chu
     if (lane == 0) { s_cnt[r][wave][0] = (uint32_t)__popcll(lm[r]); s_cnt[r][wave][1] = (uint32_t)__popcll(rm[r]); }
     if (v) validBits |= 1u << r;
     if (left) sideBits |= 1u << r;
+  }
+  for (int k = 0; k < 6; k++) {                                                  // wave-reduce the private bounds, one lane publishes
+    const uint32_t x = k < 3 ? wave_umin63(aL[k]) : wave_umax63(aL[k]), y = k < 3 ? wave_umin63(aR[k]) : wave_umax63(aR[k]);
+    if (lane == 63u) { if (k < 3) { atomicMin(&s_acc[0][k], x); atomicMin(&s_acc[1][k], y); } else { atomicMax(&s_acc[0][k], x); atomicMax(&s_acc[1][k], y); } }
   }
   __syncthreads();
   if (tid == 0) {
@@ -327,10 +423,10 @@ __global__ __launch_bounds__(256) void top_partition(Seg* segs, const Chunk* chu
   }
 }
 
-__global__ void top_emit(const Seg* segs, uint32_t numSegs, BNode* bnodes, Seg* next, SmallEntry* small, Counters* ctr,
+__global__ void top_emit(const Seg* segs, BNode* bnodes, Seg* next, SmallEntry* small, Counters* ctr,
                          Params prm, uint32_t dstBuf, uint32_t maxNext, uint32_t maxSmall) {
   const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= numSegs) return;
+  if (s >= ctr->numSegs) return;
   const Seg* sg = segs + s;
   for (int side = 0; side < 2; side++) {
     const uint32_t b = side ? sg->begin + sg->nL : sg->begin, e = side ? sg->end : sg->begin + sg->nL;
@@ -352,6 +448,12 @@ __global__ void top_emit(const Seg* segs, uint32_t numSegs, BNode* bnodes, Seg* 
       next[k] = ns;
     }
   }
+}
+
+__global__ void top_advance(Counters* ctr, uint32_t maxNext) {      // end of a top level: next level's work list becomes current
+  if (ctr->numSegs) ctr->topLevels++;
+  if (ctr->numSegsNext > maxNext) ctr->overflow = 1u;
+  ctr->numSegs = ctr->numSegsNext < maxNext ? ctr->numSegsNext : maxNext; ctr->numSegsNext = 0; ctr->numChunks = 0;
 }
 
 // ---------------------------------------------------------------------------------- K3 small phase
@@ -551,7 +653,11 @@ __global__ __launch_bounds__(64) void small_build(const SmallEntry* entries, Pri
     bins_clear(s_bins, lane, 64u);
     if (lane < 24) s_acc[lane / 12][lane % 12] = (lane % 6 < 3) ? ENC_POS_INF : ENC_NEG_INF;
     __syncthreads();
-    for (uint32_t i = lane; i < n; i += 64u) bins_add(s_bins, m, load_prim(src + cur.begin + i));
+    for (uint32_t i0 = 0; i0 < n; i0 += 64u) {
+      const bool v = i0 + lane < n;
+      PrimRef r{}; if (v) r = load_prim(src + cur.begin + i0 + lane);
+      bins_add_wave(s_bins, m, r, v, lane);
+    }
     __syncthreads();
     sah_best_wave(s_bins, m, prm.shift, &s_res, lane);
     __syncthreads();
@@ -561,6 +667,7 @@ __global__ __launch_bounds__(64) void small_build(const SmallEntry* entries, Pri
     const uint32_t dim = fallback ? 0u : (uint32_t)r.dim;
     // partition into the other buffer (wave-synchronous compaction)
     uint32_t curL = cur.begin, curR = mid;
+    uint32_t aL[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u}, aR[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
     for (uint32_t i0 = 0; i0 < n; i0 += 64u) {
       const uint32_t i = cur.begin + i0 + lane;
       const bool v = i < cur.end;
@@ -570,14 +677,18 @@ __global__ __launch_bounds__(64) void small_build(const SmallEntry* entries, Pri
         left = fallback ? (i < mid) : (bin_unsafe(p.lo[dim] + p.hi[dim], m.ofs[dim], m.scale[dim]) < r.pos);
         const int side = left ? 0 : 1;
         for (int d = 0; d < 3; d++) {
-          const float cc = p.lo[d] + p.hi[d];
-          atomicMin(&s_acc[side][d], enc(cc)); atomicMax(&s_acc[side][3 + d], enc(cc));
+          const uint32_t cc = enc(p.lo[d] + p.hi[d]);
+          if (left) { aL[d] = min(aL[d], cc); aL[3 + d] = max(aL[3 + d], cc); } else { aR[d] = min(aR[d], cc); aR[3 + d] = max(aR[3 + d], cc); }
           if (fallback) { atomicMin(&s_acc[side][6 + d], enc(p.lo[d])); atomicMax(&s_acc[side][9 + d], enc(p.hi[d])); }
         }
       }
       const unsigned long long lm = __ballot(v && left), rm = __ballot(v && !left), lt = (1ull << lane) - 1ull;
       if (v) store_prim(dst + (left ? curL + (uint32_t)__popcll(lm & lt) : curR + (uint32_t)__popcll(rm & lt)), p);
       curL += (uint32_t)__popcll(lm); curR += (uint32_t)__popcll(rm);
+    }
+    for (int k = 0; k < 6; k++) {
+      const uint32_t x = k < 3 ? wave_umin63(aL[k]) : wave_umax63(aL[k]), y = k < 3 ? wave_umin63(aR[k]) : wave_umax63(aR[k]);
+      if (lane == 63u) { s_acc[0][k] = x; s_acc[1][k] = y; }
     }
     __syncthreads();
     const uint32_t idL = cur.bnode + 1u, idR = cur.bnode + 2u * (mid - cur.begin);
@@ -635,7 +746,7 @@ __device__ void sort_leaf(uint2* ids, uint32_t b, uint32_t e) {
 
 __global__ void wide_root(WideItem* items, Counters* ctr) {
   items[0].bnode = 0; items[0].node = 0;                       // the root is always CNode 0
-  ctr->rootRef = 0; ctr->numWide = 1; ctr->numWideNext = 0; ctr->numLeaves = 0; ctr->numTrisOut = 0; ctr->sahSum = 0.0f;
+  ctr->rootRef = 0; ctr->numWide = 1; ctr->numWideCur = 1; ctr->wideDepth = 0; ctr->numWideNext = 0; ctr->numLeaves = 0; ctr->numTrisOut = 0; ctr->sahSum = 0.0f;
 }
 
 // One thread per 8-wide node.  Children: the reference's greedy "split the child with the largest half-area until 8
@@ -643,12 +754,8 @@ __global__ void wide_root(WideItem* items, Counters* ctr) {
 // the leaf-vs-split SAH test) or an inner slot.  New for the lane-per-ray traversal: children are PLACED in the slot
 // whose octant fits their position (greedy assignment on dot(child centre - node centre, octant signs)), inner
 // children get consecutive node indices in slot order and the triangles of all leaf slots one consecutive TriRec range.
-__global__ __launch_bounds__(64) void wide_level(const WideItem* items, uint32_t numItems, const BNode* bnodes, CNode* nodes,
-                                                 uint2* finalIds, uint2* outIds, WideItem* next, Counters* ctr, Params prm,
-                                                 uint32_t maxNodes, float rootArea) {
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= numItems) return;
-  const WideItem it = items[t];
+__device__ void wide_item(const WideItem it, const BNode* bnodes, CNode* nodes, uint2* finalIds, uint2* outIds, WideItem* next,
+                          Counters* ctr, const Params& prm, uint32_t maxNodes, float rootArea) {
   const BNode root = bnodes[it.bnode];
   uint32_t ch[8]; uint32_t nch;
   if (root.left == NIL || make_leaf(root, prm)) { nch = 1; ch[0] = it.bnode; }     // only the tree root can be a leaf itself
@@ -765,6 +872,18 @@ __global__ __launch_bounds__(64) void wide_level(const WideItem* items, uint32_t
   for (int k = 0; k < 5; k++) dst[k] = src[k];
 }
 
+// grid-stride over the current level's items; the item count lives on the device (no host readback per level)
+__global__ __launch_bounds__(64) void wide_level(const WideItem* items, const BNode* bnodes, CNode* nodes, uint2* finalIds, uint2* outIds,
+                                                 WideItem* next, Counters* ctr, Params prm, uint32_t maxNodes, float rootArea) {
+  const uint32_t numItems = ctr->numWideCur;
+  for (uint32_t t = blockIdx.x * 64u + threadIdx.x; t < numItems; t += gridDim.x * 64u)
+    wide_item(items[t], bnodes, nodes, finalIds, outIds, next, ctr, prm, maxNodes, rootArea);
+}
+__global__ void wide_advance(Counters* ctr) {
+  if (ctr->numWideCur) ctr->wideDepth++;
+  ctr->numWideCur = ctr->numWideNext; ctr->numWideNext = 0;
+}
+
 // --------------------------------------------------------------------------------- K5 tri_records
 __global__ __launch_bounds__(256) void tri_records(const uint2* finalIds, uint32_t n, const GeomDesc* geoms, TriRec* out) {
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
@@ -859,9 +978,21 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
 
   Counters h{}; for (int k = 0; k < 12; k++) h.bounds[k] = (k % 6 < 3) ? ENC_POS_INF : ENC_NEG_INF; h.rootRef = MI355_EMPTY_REF;
   HIP_TRY(hipMemcpyAsync(ctr.p, &h, sizeof(h), hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(primref_gen, dim3((N + 255u) / 256u), dim3(256), 0, st, dGeoms.p, (uint32_t)gd.size(), N, bufA.p, ctr.p);
+  const uint32_t genBlocks = (N + 255u) / 256u < 4096u ? (N + 255u) / 256u : 4096u;
+  hipLaunchKernelGGL(primref_gen, dim3(genBlocks), dim3(256), 0, st, dGeoms.p, (uint32_t)gd.size(), N, bufA.p, ctr.p);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(&h, ctr.p, sizeof(h), hipMemcpyDeviceToHost, st)); HIP_TRY(hipStreamSynchronize(st));
+  h.numPrims = N - h.numInvalid;
+  if (h.numInvalid) {                                          // rare: squeeze the invalid triangles out (stable)
+    const uint32_t tiles = (N + 255u) / 256u;
+    DevBuf<uint32_t> tileCount; HIP_TRY(tileCount.alloc(tiles));
+    hipLaunchKernelGGL(compact_count, dim3(tiles), dim3(256), 0, st, bufA.p, N, tileCount.p);
+    hipLaunchKernelGGL(compact_scan, dim3(1), dim3(1024), 0, st, tileCount.p, tiles, ctr.p);
+    hipLaunchKernelGGL(compact_scatter, dim3(tiles), dim3(256), 0, st, bufA.p, N, tileCount.p, bufB.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(bufA.p, bufB.p, (size_t)h.numPrims * sizeof(PrimRef), hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+  }
   const uint32_t n = h.numPrims;
   auto decf = [](uint32_t u) { uint32_t v = u ^ ((u >> 31) ? 0x80000000u : 0xFFFFFFFFu); float f; memcpy(&f, &v, 4); return f; };
   if (n == 0) { guard.ok = true; *out = bvh; return 0; }
@@ -873,7 +1004,7 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
   // root binary node + first work item
   BNode rootB{}; for (int d = 0; d < 3; d++) { rootB.lo[d] = glo[d]; rootB.hi[d] = ghi[d]; } rootB.begin = 0; rootB.end = n; rootB.left = rootB.right = NIL; rootB.splitSah = INFINITY;
   HIP_TRY(hipMemcpyAsync(bnodes.p, &rootB, sizeof(rootB), hipMemcpyHostToDevice, st));
-  h.numBLeaves = 0; h.numSegsNext = 0; h.numChunks = 0; h.numSmall = 0;
+  h.numBLeaves = 0; h.numSegsNext = 0; h.numChunks = 0; h.numSmall = 0; h.numSegs = n > prm.small ? 1u : 0u; h.topLevels = 0;
   uint32_t numSegs = 0, numSmall = 0;
   if (n > prm.small) {
     Seg s0{}; s0.begin = 0; s0.end = n; s0.bnode = 0; for (int d = 0; d < 3; d++) { s0.cmin[d] = clo[d]; s0.cmax[d] = chi[d]; }
@@ -884,32 +1015,37 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
   }
   HIP_TRY(hipMemcpyAsync(ctr.p, &h, sizeof(h), hipMemcpyHostToDevice, st));
 
-  // ---- top phase: one pass over the data per binary level
+  // ---- top phase: one pass over the data per binary level.  Work-list sizes stay on the device: every kernel is launched with
+  //      an upper bound of its grid (<= 2^level segments, <= N/CHUNK + #segments chunks) and surplus blocks exit at once, so
+  //      the levels are enqueued back to back; the host looks at the counters only where the level count is not implied by N.
   uint32_t level = 0;
   Seg* cur = segs0.p; Seg* nxt = segs1.p;
-  while (numSegs > 0) {
+  auto enqueue_top_level = [&]() {
     PrimRef* src = (level & 1u) ? bufB.p : bufA.p; PrimRef* dst = (level & 1u) ? bufA.p : bufB.p;
-    hipLaunchKernelGGL(top_setup, dim3(numSegs), dim3(256), 0, st, cur, numSegs, bins.p, chunks.p, ctr.p);
-    uint32_t numChunks = 0;
-    HIP_TRY(hipMemcpyAsync(&numChunks, &ctr.p->numChunks, 4, hipMemcpyDeviceToHost, st)); HIP_TRY(hipStreamSynchronize(st));
-    if (numChunks > maxChunks) return set_error(hipErrorOutOfMemory, "chunk table overflow");
-    hipLaunchKernelGGL(top_bin, dim3(numChunks), dim3(256), 0, st, cur, chunks.p, src, bins.p);
-    hipLaunchKernelGGL(top_split, dim3(numSegs), dim3(64), 0, st, cur, bins.p, bnodes.p, ctr.p, prm, level >= 96u ? 1u : 0u);
-    hipLaunchKernelGGL(top_partition, dim3(numChunks), dim3(256), 0, st, cur, chunks.p, src, dst);
-    hipLaunchKernelGGL(top_emit, dim3((numSegs + 255u) / 256u), dim3(256), 0, st, cur, numSegs, bnodes.p, nxt, small.p, ctr.p, prm,
+    const uint32_t segBound = level < 31u && (1u << level) < maxSegs ? (1u << level) : maxSegs;
+    const uint32_t chunkBound = n / CHUNK + segBound + 1u;
+    hipLaunchKernelGGL(top_setup, dim3(segBound), dim3(256), 0, st, cur, bins.p, chunks.p, ctr.p);
+    hipLaunchKernelGGL(top_bin, dim3(chunkBound), dim3(256), 0, st, cur, chunks.p, src, bins.p, ctr.p);
+    hipLaunchKernelGGL(top_split, dim3(segBound), dim3(64), 0, st, cur, bins.p, bnodes.p, ctr.p, prm, level >= 96u ? 1u : 0u);
+    hipLaunchKernelGGL(top_partition, dim3(chunkBound), dim3(256), 0, st, cur, chunks.p, src, dst, ctr.p);
+    hipLaunchKernelGGL(top_emit, dim3((segBound + 255u) / 256u), dim3(256), 0, st, cur, bnodes.p, nxt, small.p, ctr.p, prm,
                        (level & 1u) ? 0u : 1u, maxSegs, maxSmall);
-    HIP_TRY(hipGetLastError());
-    uint32_t tmp[2];
-    HIP_TRY(hipMemcpyAsync(tmp, &ctr.p->numSegsNext, 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(tmp + 1, &ctr.p->overflow, 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    if (tmp[1]) return set_error(hipErrorOutOfMemory, "top-phase work list overflow (pathological input)");
-    numSegs = tmp[0];
-    HIP_TRY(hipMemsetAsync(&ctr.p->numSegsNext, 0, 8, st));      // numSegsNext + numChunks
+    hipLaunchKernelGGL(top_advance, dim3(1), dim3(1), 0, st, ctr.p, maxSegs);
     Seg* t = cur; cur = nxt; nxt = t; level++;
-  }
-  info.top_levels = level;
-  HIP_TRY(hipMemcpyAsync(&numSmall, &ctr.p->numSmall, 4, hipMemcpyDeviceToHost, st)); HIP_TRY(hipStreamSynchronize(st));
+  };
+  if (numSegs) {
+    uint32_t sure = 1; while (sure < 40u && ((uint64_t)prm.small << sure) < n) sure++;   // the largest segment halves at best: that many levels exist
+    for (uint32_t i = 0; i < sure; i++) enqueue_top_level();
+    for (;;) {
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipMemcpyAsync(&h, ctr.p, sizeof(h), hipMemcpyDeviceToHost, st)); HIP_TRY(hipStreamSynchronize(st));
+      if (h.overflow) return set_error(hipErrorOutOfMemory, "top-phase work list overflow (pathological input)");
+      if (h.numSegs == 0) break;
+      enqueue_top_level(); enqueue_top_level();
+    }
+  } else { HIP_TRY(hipMemcpyAsync(&h, ctr.p, sizeof(h), hipMemcpyDeviceToHost, st)); HIP_TRY(hipStreamSynchronize(st)); }
+  info.top_levels = h.topLevels;
+  numSmall = h.numSmall;
   if (numSmall > maxSmall) return set_error(hipErrorOutOfMemory, "small list overflow");
 
   // ---- small phase
@@ -921,22 +1057,25 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
   // ---- wide collapse, level by level
   const float rootArea = fmaf(ghi[0] - glo[0], (ghi[1] - glo[1]) + (ghi[2] - glo[2]), (ghi[1] - glo[1]) * (ghi[2] - glo[2]));
   hipLaunchKernelGGL(wide_root, dim3(1), dim3(1), 0, st, w0.p, ctr.p);
-  uint32_t numItems = 0, depth = 0;
-  HIP_TRY(hipMemcpyAsync(&numItems, &ctr.p->numWide, 4, hipMemcpyDeviceToHost, st)); HIP_TRY(hipStreamSynchronize(st));
   WideItem* wc = w0.p; WideItem* wn = w1.p;
-  while (numItems > 0) {
-    hipLaunchKernelGGL(wide_level, dim3((numItems + 63u) / 64u), dim3(64), 0, st, wc, numItems, bnodes.p, wnodes.p, finalIds.p, outIds.p, wn, ctr.p, prm, maxWide, rootArea);
+  uint32_t wlevel = 0;
+  auto enqueue_wide_level = [&]() {
+    uint64_t bound = 1; for (uint32_t i = 0; i < wlevel && bound < maxWide; i++) bound *= 8u;     // <= 8^level items
+    if (bound > maxWide) bound = maxWide;
+    const uint32_t blocks = (uint32_t)((bound + 63u) / 64u) < 16384u ? (uint32_t)((bound + 63u) / 64u) : 16384u;
+    hipLaunchKernelGGL(wide_level, dim3(blocks), dim3(64), 0, st, wc, bnodes.p, wnodes.p, finalIds.p, outIds.p, wn, ctr.p, prm, maxWide, rootArea);
+    hipLaunchKernelGGL(wide_advance, dim3(1), dim3(1), 0, st, ctr.p);
+    WideItem* t = wc; wc = wn; wn = t; wlevel++;
+  };
+  for (uint32_t i = 0; i < 8u; i++) enqueue_wide_level();
+  for (;;) {
     HIP_TRY(hipGetLastError());
-    uint32_t tmp[2];
-    HIP_TRY(hipMemcpyAsync(tmp, &ctr.p->numWideNext, 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(tmp + 1, &ctr.p->overflow, 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    if (tmp[1]) return set_error(hipErrorOutOfMemory, "wide node pool overflow");
-    numItems = tmp[0];
-    HIP_TRY(hipMemsetAsync(&ctr.p->numWideNext, 0, 4, st));
-    WideItem* t = wc; wc = wn; wn = t; depth++;
+    HIP_TRY(hipMemcpyAsync(&h, ctr.p, sizeof(h), hipMemcpyDeviceToHost, st)); HIP_TRY(hipStreamSynchronize(st));
+    if (h.overflow) return set_error(hipErrorOutOfMemory, "wide node pool overflow");
+    if (h.numWideCur == 0) break;
+    for (uint32_t i = 0; i < 4u; i++) enqueue_wide_level();
   }
-  HIP_TRY(hipMemcpyAsync(&h, ctr.p, sizeof(h), hipMemcpyDeviceToHost, st)); HIP_TRY(hipStreamSynchronize(st));
+  const uint32_t depth = h.wideDepth;
 
   // ---- final arrays (exact size) + triangle records
   const uint32_t numNodes = h.numWide;
