@@ -64,8 +64,8 @@ struct Counters {
   uint32_t numPrims, numBLeaves, numSegsNext, numChunks, numSmall, numWide, numWideNext, numLeaves;
   uint32_t bounds[12];                          // scene geom lo/hi + centroid lo/hi (ordered uint)
   uint32_t overflow, rootRef, numTrisOut, numInvalid;
-  uint32_t numSegs, topLevels, numWideCur, wideDepth;      // level loops are driven from the device: no host readback per level
-  float sahSum;
+  uint32_t numSegs, topLevels, wideDepth, lvlNodeBase, lvlTriBase, wideCount[2];      // level loops are driven from the device: no host readback per level
+  unsigned long long sahFixed;                    // SAH statistics, 2^-24 fixed point (order-independent sum)
 };
 struct Params { uint32_t shift, minLeaf, maxLeaf, small; float travCost, intCost; };
 
@@ -73,6 +73,7 @@ struct Params { uint32_t shift, minLeaf, maxLeaf, small; float travCost, intCost
 __device__ __forceinline__ uint32_t enc(float f) { uint32_t u = __float_as_uint(f); return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u); }
 __device__ __forceinline__ float dec(uint32_t u) { return __uint_as_float(u ^ ((u >> 31) ? 0x80000000u : 0xFFFFFFFFu)); }
 __device__ __forceinline__ float half_area3(float dx, float dy, float dz) { return fmaf(dx, dy + dz, dy * dz); }  // common/math/vec3fa.h:349
+__device__ __forceinline__ float sel3(uint32_t d, float a, float b, float c) { return d == 0u ? a : (d == 1u ? b : c); }   // no dynamically indexed register arrays (scratch)
 __device__ __forceinline__ bool valid_f(float x) { return x > -1.844E18f && x < 1.844E18f; }  // isvalid, FLT_LARGE constants.h:21
 
 __device__ __forceinline__ PrimRef load_prim(const PrimRef* p) {
@@ -219,6 +220,7 @@ __device__ __forceinline__ void bins_add(uint32_t* bins, const Mapping& m, const
 __device__ __forceinline__ void bins_add_wave(uint32_t* bins, const Mapping& m, const PrimRef& r, bool valid, uint32_t lane) {
   uint32_t c[6];
   for (int k = 0; k < 3; k++) { c[k] = enc(r.lo[k]); c[3 + k] = enc(r.hi[k]); }
+#pragma unroll
   for (int d = 0; d < 3; d++) {
     int b = valid ? bin_clamped(r.lo[d] + r.hi[d], m.ofs[d], m.scale[d], m.nb) : -1;
     unsigned long long rem = __ballot(b >= 0);
@@ -250,42 +252,56 @@ __device__ __forceinline__ void bins_add_wave(uint32_t* bins, const Mapping& m, 
 
 struct SplitResult { float sah; int dim, pos; uint32_t nL; float llo[3], lhi[3], rlo[3], rhi[3]; };
 
-// BinInfoT::best (heuristic_binning.h:339-386) evaluated candidate-parallel by ONE wavefront: lane c
-// handles (axis = c/32, pos = c%32); the reference's "first strict minimum per axis, then first better
-// axis" equals the lexicographic minimum of (sah, axis, pos).  Result lands in `res` (LDS).
+// BinInfoT::best (heuristic_binning.h:339-386) by ONE wavefront as two scans: lanes 0-31 hold the 32 bins of one axis, lanes
+// 32-63 those of the next (second pass: the third axis).  An inclusive prefix scan gives "everything left of the plane", a
+// suffix scan "everything right of it"; lane pos then prices the candidate (axis, pos).  The reference's "first strict minimum
+// per axis, then first better axis" is the lexicographic minimum of (sah, axis, pos).  Result lands in `res` (LDS).
+// (The first version let every candidate loop over all bins: 3 x 31 x 32 bin visits, ~1900 instructions per lane.)
 __device__ void sah_best_wave(const uint32_t* bins, const Mapping& m, uint32_t shift, SplitResult* res, uint32_t lane) {
-  float bestSah = __builtin_inff(); uint32_t bestC = NIL; uint32_t bestNL = 0;
-  float bl[3] = {0, 0, 0}, bh[3] = {0, 0, 0}, rl[3] = {0, 0, 0}, rh[3] = {0, 0, 0};
+  const uint32_t b = lane & 31u, half = lane >> 5;
   const uint32_t add = (1u << shift) - 1u;
-  for (uint32_t c = lane; c < 3u * NBINS; c += 64u) {
-    const uint32_t axis = c >> 5, pos = c & 31u;
-    if (pos == 0u || pos >= m.nb || m.scale[axis] == 0.0f) continue;   // mapping.invalid(dim) :375, pos != 0 :379
-    float llo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, lhi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
-    float rlo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, rhi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
-    uint32_t lN = 0, rN = 0;
-    for (uint32_t b = 0; b < m.nb; b++) {
+  unsigned long long bestKey = ~0ull; uint32_t bestNL = 0;
+  float bl[3] = {0, 0, 0}, bh[3] = {0, 0, 0}, rl[3] = {0, 0, 0}, rh[3] = {0, 0, 0};
+#pragma unroll
+  for (uint32_t pass = 0; pass < 2u; pass++) {
+    const uint32_t axis = pass * 2u + half;
+    const bool live = axis < 3u && b < m.nb;
+    float plo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, phi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+    uint32_t pn = 0;
+    if (live) {
       const uint32_t* e = bins + (axis * NBINS + b) * BINW;
-      const uint32_t cnt = e[6];
-      if (cnt == 0u) continue;
-      if (b < pos) { lN += cnt; for (int d = 0; d < 3; d++) { llo[d] = fminf(llo[d], dec(e[d])); lhi[d] = fmaxf(lhi[d], dec(e[3 + d])); } }
-      else         { rN += cnt; for (int d = 0; d < 3; d++) { rlo[d] = fminf(rlo[d], dec(e[d])); rhi[d] = fmaxf(rhi[d], dec(e[3 + d])); } }
+      pn = e[6];
+      if (pn) for (int d = 0; d < 3; d++) { plo[d] = dec(e[d]); phi[d] = dec(e[3 + d]); }
     }
-    if (lN == 0u || rN == 0u) continue;                          // empty side: the reference's sah is NaN there and never selected
-    const float lA = half_area3(lhi[0] - llo[0], lhi[1] - llo[1], lhi[2] - llo[2]);
-    const float rA = half_area3(rhi[0] - rlo[0], rhi[1] - rlo[1], rhi[2] - rlo[2]);
-    const float sah = fmaf(lA, (float)((lN + add) >> shift), rA * (float)((rN + add) >> shift));   // :367
-    if (sah < bestSah) {                                         // c ascending per lane -> keeps the lower candidate on ties
-      bestSah = sah; bestC = c; bestNL = lN;
-      for (int d = 0; d < 3; d++) { bl[d] = llo[d]; bh[d] = lhi[d]; rl[d] = rlo[d]; rh[d] = rhi[d]; }
+    float slo[3] = {plo[0], plo[1], plo[2]}, shi[3] = {phi[0], phi[1], phi[2]}; uint32_t sn = pn;
+    for (int o = 1; o < 32; o <<= 1) {
+      const uint32_t un = (uint32_t)__shfl_up((int)pn, o, 32), dn = (uint32_t)__shfl_down((int)sn, o, 32);
+      float ul[3], uh[3], dl[3], dh[3];
+      for (int d = 0; d < 3; d++) { ul[d] = __shfl_up(plo[d], o, 32); uh[d] = __shfl_up(phi[d], o, 32); dl[d] = __shfl_down(slo[d], o, 32); dh[d] = __shfl_down(shi[d], o, 32); }
+      if (b >= (uint32_t)o) { pn += un; for (int d = 0; d < 3; d++) { plo[d] = fminf(plo[d], ul[d]); phi[d] = fmaxf(phi[d], uh[d]); } }
+      if (b + (uint32_t)o < 32u) { sn += dn; for (int d = 0; d < 3; d++) { slo[d] = fminf(slo[d], dl[d]); shi[d] = fmaxf(shi[d], dh[d]); } }
+    }
+    // candidate pos = b: left = prefix of lane b-1, right = my suffix
+    const uint32_t lN = (uint32_t)__shfl_up((int)pn, 1, 32);
+    float llo[3], lhi[3];
+    for (int d = 0; d < 3; d++) { llo[d] = __shfl_up(plo[d], 1, 32); lhi[d] = __shfl_up(phi[d], 1, 32); }
+    const bool cand = live && b != 0u && sel3(axis, m.scale[0], m.scale[1], m.scale[2]) != 0.0f && lN != 0u && sn != 0u;   // mapping.invalid(dim) :375, pos != 0 :379; an empty side is never selected
+    if (cand) {
+      const float lA = half_area3(lhi[0] - llo[0], lhi[1] - llo[1], lhi[2] - llo[2]);
+      const float rA = half_area3(shi[0] - slo[0], shi[1] - slo[1], shi[2] - slo[2]);
+      const float sah = fmaf(lA, (float)((lN + add) >> shift), rA * (float)((sn + add) >> shift));   // :367
+      const unsigned long long key = ((unsigned long long)__float_as_uint(sah) << 32) | ((axis << 5) | b);   // sah >= 0: its bit pattern is order preserving
+      if (key < bestKey) {
+        bestKey = key; bestNL = lN;
+        for (int d = 0; d < 3; d++) { bl[d] = llo[d]; bh[d] = lhi[d]; rl[d] = slo[d]; rh[d] = shi[d]; }
+      }
     }
   }
-  // wave argmin of (sah, c): sah >= 0 so its bit pattern is order preserving
-  unsigned long long key = (bestC == NIL) ? ~0ull : (((unsigned long long)__float_as_uint(bestSah) << 32) | bestC);
-  unsigned long long k = key;
+  unsigned long long k = bestKey;
   for (int o = 32; o >= 1; o >>= 1) { const unsigned long long other = __shfl_xor(k, o, 64); k = other < k ? other : k; }
   if (lane == 0) { res->sah = __builtin_inff(); res->dim = -1; res->pos = 0; res->nL = 0; }
-  if (k != ~0ull && key == k) {                                  // exactly one lane owns the minimum (c is unique)
-    res->sah = bestSah; res->dim = (int)(bestC >> 5); res->pos = (int)(bestC & 31u); res->nL = bestNL;
+  if (k != ~0ull && bestKey == k) {                              // exactly one lane owns the minimum (the candidate index is unique)
+    res->sah = __uint_as_float((uint32_t)(k >> 32)); res->dim = (int)((k >> 5) & 3u); res->pos = (int)(k & 31u); res->nL = bestNL;
     for (int d = 0; d < 3; d++) { res->llo[d] = bl[d]; res->lhi[d] = bh[d]; res->rlo[d] = rl[d]; res->rhi[d] = rh[d]; }
   }
 }
@@ -383,7 +399,7 @@ __global__ __launch_bounds__(256) void top_partition(Seg* segs, const Chunk* chu
     if (v) pr[r] = load_prim(src + i);
     bool left = false;
     if (v) {
-      const float c2 = pr[r].lo[dim] + pr[r].hi[dim];
+      const float c2 = sel3(dim, pr[r].lo[0] + pr[r].hi[0], pr[r].lo[1] + pr[r].hi[1], pr[r].lo[2] + pr[r].hi[2]);
       left = fallback ? (i < mid) : (bin_unsafe(c2, ofs, scale) < (int)pos);     // isLeft: bin_unsafe(center2) < pos (:161)
       const int side = left ? 0 : 1;
       for (int d = 0; d < 3; d++) {                                              // extend_center2 of the child (:168), thread-private first
@@ -476,7 +492,6 @@ __device__ __forceinline__ uint32_t zlo(float f) { return ~enc(f); }          //
 __device__ __forceinline__ float unzlo(uint32_t u) { return dec(~u); }
 __device__ __forceinline__ uint32_t zhi(float f) { return enc(f); }           // enc(x) > 0 for every float
 __device__ __forceinline__ float unzhi(uint32_t u) { return dec(u); }
-__device__ __forceinline__ float sel3(uint32_t d, float a, float b, float c) { return d == 0u ? a : (d == 1u ? b : c); }
 
 // R: per-wave LDS scratch of 64 * W words (W = 28 words per triangle when min_leaf >= 2, 42 for min_leaf = 1):
 //   bins of the segment starting at lane b live at R + b * W as [axis][bin][7] (3 * nb * 7 <= n * W words for every
@@ -489,7 +504,7 @@ __device__ void micro_subtree(uint32_t* R, uint32_t W, uint32_t (*s_cb)[64][6], 
   if (lane < n0) p = load_prim(src + gbegin + lane);
   uint32_t segB = 0, segE = n0, node = rootNode;
   bool act = lane < n0 && n0 > prm.minLeaf;
-  if (lane < 6u) s_cb[0][0][lane] = lane < 3u ? zlo(cmin0[lane]) : zhi(cmax0[lane - 3u]);
+  if (lane == 0u) for (int d = 0; d < 3; d++) { s_cb[0][0][d] = zlo(cmin0[d]); s_cb[0][0][3 + d] = zhi(cmax0[d]); }
   __syncthreads();
   const uint32_t addBlk = (1u << prm.shift) - 1u;
   uint32_t pp = 0;
@@ -674,7 +689,7 @@ __global__ __launch_bounds__(64) void small_build(const SmallEntry* entries, Pri
       PrimRef p{}; bool left = false;
       if (v) {
         p = load_prim(src + i);
-        left = fallback ? (i < mid) : (bin_unsafe(p.lo[dim] + p.hi[dim], m.ofs[dim], m.scale[dim]) < r.pos);
+        left = fallback ? (i < mid) : (bin_unsafe(sel3(dim, p.lo[0] + p.hi[0], p.lo[1] + p.hi[1], p.lo[2] + p.hi[2]), sel3(dim, m.ofs[0], m.ofs[1], m.ofs[2]), sel3(dim, m.scale[0], m.scale[1], m.scale[2])) < r.pos);
         const int side = left ? 0 : 1;
         for (int d = 0; d < 3; d++) {
           const uint32_t cc = enc(p.lo[d] + p.hi[d]);
@@ -713,10 +728,17 @@ __global__ __launch_bounds__(64) void small_build(const SmallEntry* entries, Pri
     }
     // continue with the smaller child, push the larger: the stack stays <= log2(small_threshold) deep
     const bool leftSmaller = (L.end - L.begin) <= (R.end - R.begin);
+    StackEntry keep, push;                                       // field-wise selects: a struct-valued ?: goes through scratch memory
+    keep.begin = leftSmaller ? L.begin : R.begin; keep.end = leftSmaller ? L.end : R.end; keep.bnode = leftSmaller ? L.bnode : R.bnode; keep.buf = L.buf;
+    push.begin = leftSmaller ? R.begin : L.begin; push.end = leftSmaller ? R.end : L.end; push.bnode = leftSmaller ? R.bnode : L.bnode; push.buf = L.buf;
+    for (int d = 0; d < 3; d++) {
+      keep.cmin[d] = leftSmaller ? L.cmin[d] : R.cmin[d]; keep.cmax[d] = leftSmaller ? L.cmax[d] : R.cmax[d];
+      push.cmin[d] = leftSmaller ? R.cmin[d] : L.cmin[d]; push.cmax[d] = leftSmaller ? R.cmax[d] : L.cmax[d];
+    }
     __syncthreads();
-    if (lane == 0) s_stack[sp] = leftSmaller ? R : L;
+    if (lane == 0) s_stack[sp] = push;
     sp++;
-    cur = leftSmaller ? L : R;
+    cur = keep;
     __syncthreads();
   }
 }
@@ -744,144 +766,220 @@ __device__ void sort_leaf(uint2* ids, uint32_t b, uint32_t e) {
   }
 }
 
+// ---- The collapse runs level by level (children of a node get consecutive indices, so numbering is breadth first), three
+// kernels per level, EIGHT LANES PER NODE (lane = child, later = slot), eight nodes per wavefront:
+//   wide_plan   children of every node of the level: the reference's greedy "split the child with the largest half-area until
+//               8 children" (bvh_builder_sah.h:247-272) on the binary tree + leaf-vs-split SAH test; each child becomes a leaf
+//               slot (<= 3 triangles) or an inner slot and is PLACED in the slot whose octant fits its position (greedy
+//               assignment on dot(child centre - node centre, octant signs)); the plan (child per slot, inner/leaf masks) and
+//               the node's counts (#inner children, #leaf triangles) are stored
+//   wide_scan   exclusive scan of the counts in item order -> first child index / first triangle index of every node.  No
+//               atomic counter decides an index: the layout of the tree is identical on every run and on every GPU.
+//   wide_emit   quantises the child boxes (8 bits, verified conservative in fp32), writes the 80-byte node, the next level's
+//               work items, and the leaf triangles' ids in (primID, geomID) order
+// The first version used one thread per node (206 VGPRs, 2 waves/SIMD, atomics for the numbering: 1.6 ms of a 9.4 ms commit).
+struct WidePlan { uint32_t ch[8]; uint32_t imask, leafMask, nch, pad; };   // by slot; NIL = empty slot
+
 __global__ void wide_root(WideItem* items, Counters* ctr) {
   items[0].bnode = 0; items[0].node = 0;                       // the root is always CNode 0
-  ctr->rootRef = 0; ctr->numWide = 1; ctr->numWideCur = 1; ctr->wideDepth = 0; ctr->numWideNext = 0; ctr->numLeaves = 0; ctr->numTrisOut = 0; ctr->sahSum = 0.0f;
+  ctr->rootRef = 0; ctr->numWide = 1; ctr->wideCount[0] = 1; ctr->wideCount[1] = 0; ctr->wideDepth = 0; ctr->numLeaves = 0; ctr->numTrisOut = 0; ctr->sahFixed = 0ull;
 }
 
-// One thread per 8-wide node.  Children: the reference's greedy "split the child with the largest half-area until 8
-// children" (bvh_builder_sah.h:247-272) on the binary tree; each child becomes a leaf slot (<= 3 triangles, decided by
-// the leaf-vs-split SAH test) or an inner slot.  New for the lane-per-ray traversal: children are PLACED in the slot
-// whose octant fits their position (greedy assignment on dot(child centre - node centre, octant signs)), inner
-// children get consecutive node indices in slot order and the triangles of all leaf slots one consecutive TriRec range.
-__device__ void wide_item(const WideItem it, const BNode* bnodes, CNode* nodes, uint2* finalIds, uint2* outIds, WideItem* next,
-                          Counters* ctr, const Params& prm, uint32_t maxNodes, float rootArea) {
-  const BNode root = bnodes[it.bnode];
-  uint32_t ch[8]; uint32_t nch;
-  if (root.left == NIL || make_leaf(root, prm)) { nch = 1; ch[0] = it.bnode; }     // only the tree root can be a leaf itself
-  else {
-    nch = 2; ch[0] = root.left; ch[1] = root.right;
-    while (nch < 8u) {
-      float bestArea = -__builtin_inff(); int best = -1;
-      for (uint32_t i = 0; i < nch; i++) {
-        const BNode c = bnodes[ch[i]];
-        if (c.end - c.begin <= prm.minLeaf || c.left == NIL) continue;
-        const float ar = bnode_area(c);
-        if (ar > bestArea) { bestArea = ar; best = (int)i; }
-      }
-      if (best < 0) break;
-      const BNode c = bnodes[ch[best]];
-      ch[best] = c.left; ch[nch++] = c.right;
-    }
+template <typename T> __device__ __forceinline__ T grp_get(T v, uint32_t lane, uint32_t idx) { return __shfl(v, (int)((lane & ~7u) | idx), 64); }
+__device__ __forceinline__ float grp_min(float v) { v = fminf(v, __shfl_xor(v, 1, 64)); v = fminf(v, __shfl_xor(v, 2, 64)); return fminf(v, __shfl_xor(v, 4, 64)); }
+__device__ __forceinline__ float grp_max(float v) { v = fmaxf(v, __shfl_xor(v, 1, 64)); v = fmaxf(v, __shfl_xor(v, 2, 64)); return fmaxf(v, __shfl_xor(v, 4, 64)); }
+__device__ __forceinline__ float grp_sum(float v) { v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); return v + __shfl_xor(v, 4, 64); }
+// argmax over the 8 lanes of a group; ties go to the lower index (the serial formulation keeps the first maximum)
+__device__ __forceinline__ void grp_argmax(float& v, uint32_t& idx) {
+  for (int o = 1; o < 8; o <<= 1) {
+    const float ov = __shfl_xor(v, o, 64); const uint32_t oi = (uint32_t)__shfl_xor((int)idx, o, 64);
+    if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
   }
-  float lo[8][3], hi[8][3]; bool leaf[8]; uint32_t cb[8], ce[8];
-  float olo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, ohi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
-  float sah = 0.0f;
-  for (uint32_t i = 0; i < nch; i++) {
-    const BNode c = bnodes[ch[i]];
-    for (int d = 0; d < 3; d++) { lo[i][d] = c.lo[d]; hi[i][d] = c.hi[d]; olo[d] = fminf(olo[d], c.lo[d]); ohi[d] = fmaxf(ohi[d], c.hi[d]); }
-    cb[i] = c.begin; ce[i] = c.end;
-    leaf[i] = make_leaf(c, prm);
-    const float A = bnode_area(c);
-    sah += leaf[i] ? prm.intCost * A * (float)((c.end - c.begin + (1u << prm.shift) - 1u) >> prm.shift) : prm.travCost * A;
-  }
-  if (rootArea > 0.0f) atomicAdd(&ctr->sahSum, sah / rootArea);
+}
+__device__ __forceinline__ BNode load_bnode(const BNode* p) {
+  const float4 a = ((const float4*)p)[0], b = ((const float4*)p)[1]; const uint4 c = ((const uint4*)p)[2];
+  BNode r; r.lo[0] = a.x; r.lo[1] = a.y; r.lo[2] = a.z; r.begin = __float_as_uint(a.w); r.hi[0] = b.x; r.hi[1] = b.y; r.hi[2] = b.z; r.end = __float_as_uint(b.w);
+  r.left = c.x; r.right = c.y; r.splitSah = __uint_as_float(c.z); r.pad = 0; return r;
+}
 
-  // ---- slot assignment: repeatedly take the (child, slot) pair with the largest dot(centre offset, octant signs)
-  uint32_t slotOf[8], childAt[8];
-  for (int s = 0; s < 8; s++) childAt[s] = NIL;
-  {
-    uint32_t freeSlots = 0xFFu, todo = (1u << nch) - 1u;
-    float cx[8][3];
-    for (uint32_t i = 0; i < nch; i++) for (int d = 0; d < 3; d++) cx[i][d] = (lo[i][d] + hi[i][d]) - (olo[d] + ohi[d]);   // 2 x centre offset
-    for (uint32_t k = 0; k < nch; k++) {
-      float best = -__builtin_inff(); uint32_t bi = 0, bs = 0;
-      for (uint32_t i = 0; i < nch; i++) {
-        if (!((todo >> i) & 1u)) continue;
-        for (uint32_t s = 0; s < 8u; s++) {
-          if (!((freeSlots >> s) & 1u)) continue;
-          const float c = ((s & 1u) ? cx[i][0] : -cx[i][0]) + ((s & 2u) ? cx[i][1] : -cx[i][1]) + ((s & 4u) ? cx[i][2] : -cx[i][2]);
-          if (c > best || best == -__builtin_inff()) { best = c; bi = i; bs = s; }
-        }
+__global__ __launch_bounds__(64) void wide_plan(const WideItem* items, const BNode* bnodes, WidePlan* plans, uint2* itemCnt, uint2* groupSum,
+                                                Counters* ctr, Params prm, uint32_t parity, float rootArea) {
+  const uint32_t numItems = ctr->wideCount[parity];
+  const uint32_t lane = threadIdx.x, c = lane & 7u, g = lane >> 3;
+  unsigned long long sahAcc = 0ull; uint32_t leafAcc = 0u;      // per-wave partial sums: one atomic per wave at the end (a same-address atomic costs ~2 ns)
+  for (uint32_t base = blockIdx.x * 8u; base < numItems; base += gridDim.x * 8u) {
+    const uint32_t t = base + g; const bool valid = t < numItems;
+    WideItem it; it.bnode = 0; it.node = 0; if (valid) it = items[t];
+    const BNode root = load_bnode(bnodes + it.bnode);
+    // ---- children: lane c holds child c
+    uint32_t nch, my = NIL; BNode mb = root;
+    if (root.left == NIL || make_leaf(root, prm)) { nch = 1; if (c == 0u) my = it.bnode; }        // only the tree root can be a leaf itself
+    else { nch = 2; if (c < 2u) { my = c == 0u ? root.left : root.right; mb = load_bnode(bnodes + my); } }
+    bool done = !valid || nch == 1u;
+    while (__ballot(!done) != 0ull) {
+      float ar = -__builtin_inff(); uint32_t bi = c;
+      if (!done && c < nch && !(mb.end - mb.begin <= prm.minLeaf || mb.left == NIL)) ar = bnode_area(mb);
+      grp_argmax(ar, bi);
+      if (ar == -__builtin_inff()) done = true;
+      const uint32_t l = grp_get(mb.left, lane, bi), r = grp_get(mb.right, lane, bi);
+      if (!done) {
+        if (c == bi) { my = l; mb = load_bnode(bnodes + l); }
+        else if (c == nch) { my = r; mb = load_bnode(bnodes + r); }
+        nch++;
+        if (nch == 8u) done = true;
       }
-      slotOf[bi] = bs; childAt[bs] = bi; todo &= ~(1u << bi); freeSlots &= ~(1u << bs);
     }
-  }
-  // ---- numbering: inner children consecutive in slot order, leaf triangles consecutive in slot order
-  uint32_t imask = 0, nInner = 0, nTri = 0, triOfs[8];
-  for (uint32_t s = 0; s < 8u; s++) {
-    const uint32_t i = childAt[s]; if (i == NIL) continue;
-    if (leaf[i]) { triOfs[s] = nTri; nTri += ce[i] - cb[i]; } else { imask |= 1u << s; nInner++; }
-  }
-  uint32_t childBase = 0, triBase = 0;
-  if (nInner) {
-    childBase = atomicAdd(&ctr->numWide, nInner);
-    if (childBase + nInner > maxNodes) { ctr->overflow = 2u; return; }
-    const uint32_t k = atomicAdd(&ctr->numWideNext, nInner);
-    uint32_t j = 0;
-    for (uint32_t s = 0; s < 8u; s++) if ((imask >> s) & 1u) { next[k + j].bnode = ch[childAt[s]]; next[k + j].node = childBase + j; j++; }
-  }
-  if (nTri) {
-    triBase = atomicAdd(&ctr->numTrisOut, nTri);
-    atomicAdd(&ctr->numLeaves, nch - nInner);
-    for (uint32_t s = 0; s < 8u; s++) {
-      const uint32_t i = childAt[s]; if (i == NIL || !leaf[i]) continue;
-      sort_leaf(finalIds, cb[i], ce[i]);
-      for (uint32_t j = cb[i]; j < ce[i]; j++) outIds[triBase + triOfs[s] + (j - cb[i])] = finalIds[j];
+    const bool has = valid && c < nch;
+    const bool leaf = has && make_leaf(mb, prm);
+    const uint32_t cnt = has ? mb.end - mb.begin : 0u;
+    float lo[3], hi[3], olo[3], ohi[3];
+    for (int d = 0; d < 3; d++) { lo[d] = has ? mb.lo[d] : __builtin_inff(); hi[d] = has ? mb.hi[d] : -__builtin_inff(); olo[d] = grp_min(lo[d]); ohi[d] = grp_max(hi[d]); }
+    // SAH of the finished tree (statistics only), accumulated in fixed point so that the sum does not depend on the order
+    {
+      const float A = has ? bnode_area(mb) : 0.0f;
+      const float sa = grp_sum(has ? (leaf ? prm.intCost * A * (float)((cnt + (1u << prm.shift) - 1u) >> prm.shift) : prm.travCost * A) : 0.0f);
+      if (valid && c == 0u && rootArea > 0.0f) sahAcc += (unsigned long long)((double)(sa / rootArea) * 16777216.0);
     }
-  }
-  // ---- quantise: plane = org + q * 2^(e-127), lower rounded down, upper rounded up, verified in fp32
-  CNode qn; memset(&qn, 0, sizeof(qn));
-  uint32_t ex[3];
-  for (int d = 0; d < 3; d++) {
-    qn.org[d] = olo[d];
-    const float ext = ohi[d] - olo[d];
-    int e = 1;                                               // biased exponent, scale = 2^(e-127)
-    if (ext > 0.0f) { int fe; frexpf(ext / 255.0f, &fe); e = fe + 127; if (e < 1) e = 1; if (e > 254) e = 254; }
-    for (;;) {                                               // grow the scale until every upper plane fits in 8 bits
-      const float s = __uint_as_float((uint32_t)e << 23);
-      bool fits = true;
-      for (uint32_t i = 0; i < nch; i++) {
-        float q = ceilf((hi[i][d] - olo[d]) / s);
-        while (fmaf(q, s, olo[d]) < hi[i][d]) q += 1.0f;
-        if (q > 255.0f) { fits = false; break; }
+    // ---- slot assignment: repeatedly take the (child, slot) pair with the largest dot(centre offset, octant signs)
+    uint32_t slot = NIL;
+    {
+      float v[8];
+      const float cx = has ? (lo[0] + hi[0]) - (olo[0] + ohi[0]) : 0.0f, cy = has ? (lo[1] + hi[1]) - (olo[1] + ohi[1]) : 0.0f, cz = has ? (lo[2] + hi[2]) - (olo[2] + ohi[2]) : 0.0f;   // 2 x centre offset
+      for (uint32_t q = 0; q < 8u; q++) v[q] = ((q & 1u) ? cx : -cx) + ((q & 2u) ? cy : -cy) + ((q & 4u) ? cz : -cz);
+      uint32_t freeSlots = 0xFFu;
+      for (uint32_t k = 0; k < 8u; k++) {
+        const bool pending = has && slot == NIL;
+        float best = -__builtin_inff(); uint32_t bs = 8u;
+        if (pending) for (uint32_t q = 0; q < 8u; q++) if (((freeSlots >> q) & 1u) && (v[q] > best || bs == 8u)) { best = v[q]; bs = q; }
+        // a pending child always has a finite value; -inf means "nothing pending in this lane"
+        float bv = pending ? fmaxf(best, -3.0e38f) : -__builtin_inff(); uint32_t bi = c;
+        grp_argmax(bv, bi);
+        const uint32_t ws = grp_get(bs, lane, bi);
+        if (bv != -__builtin_inff()) { if (c == bi) slot = ws; freeSlots &= ~(1u << ws); }
       }
-      if (fits || e >= 254) break;
-      e++;
     }
-    ex[d] = (uint32_t)e;
-    qn.exp[d] = (uint8_t)e;
+    // ---- transpose: lane s now speaks for slot s
+    uint32_t childAt = NIL;
+    for (uint32_t i = 0; i < 8u; i++) { const uint32_t so = grp_get(slot, lane, i); if (so == c) childAt = i; }
+    const uint32_t src = childAt == NIL ? c : childAt;
+    const uint32_t sCh = grp_get(my, lane, src), sCnt = grp_get(cnt, lane, src); const bool sLeaf = grp_get((int)leaf, lane, src) != 0;
+    const bool sHas = childAt != NIL;
+    const uint32_t gshift = lane & ~7u;
+    const uint32_t imask = (uint32_t)((__ballot(sHas && !sLeaf) >> gshift) & 0xFFull), leafMask = (uint32_t)((__ballot(sHas && sLeaf) >> gshift) & 0xFFull);
+    uint32_t nTri = (sHas && sLeaf) ? sCnt : 0u;
+    nTri += (uint32_t)__shfl_xor((int)nTri, 1, 64); nTri += (uint32_t)__shfl_xor((int)nTri, 2, 64); nTri += (uint32_t)__shfl_xor((int)nTri, 4, 64);
+    const uint32_t nInner = (uint32_t)__popc(imask);
+    if (valid) {
+      plans[t].ch[c] = sHas ? sCh : NIL;
+      if (c == 0u) { plans[t].imask = imask; plans[t].leafMask = leafMask; plans[t].nch = nch; plans[t].pad = 0u; }
+    }
+    // ---- counts: exclusive prefix over the 8 items of this wave, wave total for the scan
+    const uint32_t ci = valid ? nInner : 0u, ct = valid ? nTri : 0u;          // every lane of a group holds the same pair
+    uint32_t xi = ci, xt = ct;
+    for (int o = 8; o < 64; o <<= 1) { const uint32_t ui = (uint32_t)__shfl_up((int)xi, o, 64), ut = (uint32_t)__shfl_up((int)xt, o, 64); if (lane >= (uint32_t)o) { xi += ui; xt += ut; } }
+    if (valid && c == 0u) itemCnt[t] = make_uint2(xi - ci, xt - ct);
+    const uint32_t ti = (uint32_t)__shfl((int)xi, 63, 64), tt = (uint32_t)__shfl((int)xt, 63, 64);
+    if (lane == 0u) groupSum[base >> 3] = make_uint2(ti, tt);
+    leafAcc += (uint32_t)__popcll(__ballot(valid && sHas && sLeaf));
   }
-  qn.imask = (uint8_t)imask; qn.childBase = childBase; qn.triBase = triBase;
-  for (uint32_t s = 0; s < 8u; s++) {
-    const uint32_t i = childAt[s];
-    if (i == NIL) { for (int d = 0; d < 3; d++) { qn.qlo[d][s] = 255; qn.qhi[d][s] = 0; } qn.meta[s] = 0; continue; }
+  for (int o = 8; o < 64; o <<= 1) sahAcc += (unsigned long long)__shfl_xor((long long)sahAcc, o, 64);   // lanes with c == 0 hold the partial sums
+  if (lane == 0u) { if (sahAcc) atomicAdd(&ctr->sahFixed, sahAcc); if (leafAcc) atomicAdd(&ctr->numLeaves, leafAcc); }
+}
+
+// one block: exclusive scan of the per-wave totals in item order; publishes the level's bases and the next level's item count
+__global__ __launch_bounds__(1024) void wide_scan(uint2* groupSum, Counters* ctr, uint32_t parity, uint32_t maxNodes) {
+  __shared__ uint2 s_part[1024];
+  const uint32_t numItems = ctr->wideCount[parity], numGroups = (numItems + 7u) / 8u;
+  const uint32_t tid = threadIdx.x, per = (numGroups + 1023u) / 1024u, b = min(tid * per, numGroups), e = min(b + per, numGroups);
+  uint2 sum = make_uint2(0, 0);
+  for (uint32_t i = b; i < e; i++) { const uint2 x = groupSum[i]; sum.x += x.x; sum.y += x.y; }
+  s_part[tid] = sum; __syncthreads();
+  for (uint32_t o = 1; o < 1024u; o <<= 1) {                    // Hillis-Steele inclusive scan
+    uint2 x = make_uint2(0, 0); if (tid >= o) x = s_part[tid - o];
+    __syncthreads(); if (tid >= o) { s_part[tid].x += x.x; s_part[tid].y += x.y; } __syncthreads();
+  }
+  const uint2 total = s_part[1023];
+  uint2 run = tid ? s_part[tid - 1] : make_uint2(0, 0);
+  for (uint32_t i = b; i < e; i++) { const uint2 x = groupSum[i]; groupSum[i] = run; run.x += x.x; run.y += x.y; }
+  __syncthreads();
+  if (tid == 0) {
+    ctr->lvlNodeBase = ctr->numWide; ctr->lvlTriBase = ctr->numTrisOut;
+    if (numItems) ctr->wideDepth++;
+    if ((uint64_t)ctr->numWide + total.x > maxNodes) { ctr->overflow = 2u; ctr->wideCount[parity ^ 1u] = 0u; }
+    else { ctr->numWide += total.x; ctr->numTrisOut += total.y; ctr->wideCount[parity ^ 1u] = total.x; }
+  }
+}
+
+__global__ __launch_bounds__(64) void wide_emit(const WideItem* items, const BNode* bnodes, const WidePlan* plans, const uint2* itemCnt, const uint2* groupSum,
+                                                CNode* nodes, uint2* finalIds, uint2* outIds, WideItem* next, const Counters* ctr, uint32_t parity) {
+  __shared__ uint32_t s_node[8][20];
+  const uint32_t numItems = ctr->wideCount[parity];
+  if (ctr->overflow) return;
+  const uint32_t nodeBase = ctr->lvlNodeBase, triLvl = ctr->lvlTriBase;
+  const uint32_t lane = threadIdx.x, s = lane & 7u, g = lane >> 3;
+  for (uint32_t base = blockIdx.x * 8u; base < numItems; base += gridDim.x * 8u) {
+    const uint32_t t = base + g; const bool valid = t < numItems;
+    uint32_t ch = NIL, imask = 0, leafMask = 0, node = 0; uint2 ofs = make_uint2(0, 0);
+    if (valid) {
+      ch = plans[t].ch[s]; imask = plans[t].imask; leafMask = plans[t].leafMask; node = items[t].node;
+      const uint2 a = groupSum[base >> 3], b = itemCnt[t]; ofs = make_uint2(a.x + b.x, a.y + b.y);
+    }
+    const bool has = ch != NIL, inner = ((imask >> s) & 1u) != 0u, leaf = ((leafMask >> s) & 1u) != 0u;
+    BNode cb{}; if (has) cb = load_bnode(bnodes + ch);
+    float lo[3], hi[3], olo[3], ohi[3];
+    for (int d = 0; d < 3; d++) { lo[d] = has ? cb.lo[d] : __builtin_inff(); hi[d] = has ? cb.hi[d] : -__builtin_inff(); olo[d] = grp_min(lo[d]); ohi[d] = grp_max(hi[d]); }
+    const uint32_t cnt = leaf ? cb.end - cb.begin : 0u;
+    // numbering: inner children consecutive in slot order, leaf triangles consecutive in slot order
+    const uint32_t below = (1u << s) - 1u;
+    const uint32_t childBase = nodeBase + ofs.x, nextBase = ofs.x, triBase = triLvl + ofs.y;
+    uint32_t triOfs;                                            // exclusive prefix of the leaf counts over the slots
+    { uint32_t x = cnt; for (int o = 1; o < 8; o <<= 1) { const uint32_t u = (uint32_t)__shfl_up((int)x, o, 64); if (s >= (uint32_t)o) x += u; } triOfs = x - cnt; }
+    if (inner) { const uint32_t j = (uint32_t)__popc(imask & below); next[nextBase + j].bnode = ch; next[nextBase + j].node = childBase + j; }
+    if (leaf) {
+      sort_leaf(finalIds, cb.begin, cb.end);
+      for (uint32_t j = cb.begin; j < cb.end; j++) outIds[triBase + triOfs + (j - cb.begin)] = finalIds[j];
+    }
+    // ---- quantise: plane = org + q * 2^(e-127), lower rounded down, upper rounded up, verified in fp32
+    uint32_t ex[3]; uint32_t qa[3], qb[3];
     for (int d = 0; d < 3; d++) {
-      const float sc = __uint_as_float(ex[d] << 23);
-      float a = floorf((lo[i][d] - olo[d]) / sc); if (a < 0.0f) a = 0.0f; if (a > 255.0f) a = 255.0f;
-      while (a > 0.0f && fmaf(a, sc, olo[d]) > lo[i][d]) a -= 1.0f;
-      float b = ceilf((hi[i][d] - olo[d]) / sc); if (b < 0.0f) b = 0.0f;
-      while (b < 255.0f && fmaf(b, sc, olo[d]) < hi[i][d]) b += 1.0f;
-      if (b > 255.0f) b = 255.0f;
-      qn.qlo[d][s] = (uint8_t)a; qn.qhi[d][s] = (uint8_t)b;
+      const float ext = ohi[d] - olo[d];
+      int e = 1;                                                // biased exponent, scale = 2^(e-127)
+      if (ext > 0.0f) { int fe; frexpf(ext / 255.0f, &fe); e = fe + 127; if (e < 1) e = 1; if (e > 254) e = 254; }
+      for (;;) {                                                // grow the scale until every upper plane of the node fits in 8 bits
+        const float sc = __uint_as_float((uint32_t)e << 23);
+        bool fits = true;
+        if (has) { float q = ceilf((hi[d] - olo[d]) / sc); while (fmaf(q, sc, olo[d]) < hi[d]) q += 1.0f; fits = q <= 255.0f; }
+        const bool grpFits = ((__ballot(!fits) >> (lane & ~7u)) & 0xFFull) == 0ull;
+        const bool stop = grpFits || e >= 254;
+        if (!stop) e++;
+        if (__ballot(!stop) == 0ull) break;
+      }
+      ex[d] = (uint32_t)e;
+      qa[d] = 255u; qb[d] = 0u;                                 // empty slot: inverted box, never hit
+      if (has) {
+        const float sc = __uint_as_float(ex[d] << 23);
+        float a = floorf((lo[d] - olo[d]) / sc); if (a < 0.0f) a = 0.0f; if (a > 255.0f) a = 255.0f;
+        while (a > 0.0f && fmaf(a, sc, olo[d]) > lo[d]) a -= 1.0f;
+        float b = ceilf((hi[d] - olo[d]) / sc); if (b < 0.0f) b = 0.0f;
+        while (b < 255.0f && fmaf(b, sc, olo[d]) < hi[d]) b += 1.0f;
+        if (b > 255.0f) b = 255.0f;
+        qa[d] = (uint32_t)a; qb[d] = (uint32_t)b;
+      }
     }
-    if (leaf[i]) qn.meta[s] = (uint8_t)((((1u << (ce[i] - cb[i])) - 1u) << 5) | triOfs[s]);
-    else qn.meta[s] = (uint8_t)((1u << 5) | (24u + s));
+    const uint32_t meta = !has ? 0u : (leaf ? ((((1u << cnt) - 1u) << 5) | triOfs) : ((1u << 5) | (24u + s)));
+    // ---- assemble the 80-byte node in LDS (the bytes of a word come from 4 lanes), 5 lanes store it
+    __syncthreads();
+    uint8_t* nb = (uint8_t*)&s_node[g][0];
+    nb[24 + s] = (uint8_t)meta;
+    for (int d = 0; d < 3; d++) { nb[32 + d * 8 + s] = (uint8_t)qa[d]; nb[56 + d * 8 + s] = (uint8_t)qb[d]; }
+    if (s == 0u) {
+      s_node[g][0] = __float_as_uint(olo[0]); s_node[g][1] = __float_as_uint(olo[1]); s_node[g][2] = __float_as_uint(olo[2]);
+      s_node[g][3] = ex[0] | (ex[1] << 8) | (ex[2] << 16) | (imask << 24);
+      s_node[g][4] = imask ? childBase : 0u; s_node[g][5] = leafMask ? triBase : 0u;
+    }
+    __syncthreads();
+    if (valid && s < 5u) ((uint4*)(nodes + node))[s] = ((const uint4*)&s_node[g][0])[s];
   }
-  uint4* dst = (uint4*)(nodes + it.node); const uint4* src = (const uint4*)&qn;
-  for (int k = 0; k < 5; k++) dst[k] = src[k];
-}
-
-// grid-stride over the current level's items; the item count lives on the device (no host readback per level)
-__global__ __launch_bounds__(64) void wide_level(const WideItem* items, const BNode* bnodes, CNode* nodes, uint2* finalIds, uint2* outIds,
-                                                 WideItem* next, Counters* ctr, Params prm, uint32_t maxNodes, float rootArea) {
-  const uint32_t numItems = ctr->numWideCur;
-  for (uint32_t t = blockIdx.x * 64u + threadIdx.x; t < numItems; t += gridDim.x * 64u)
-    wide_item(items[t], bnodes, nodes, finalIds, outIds, next, ctr, prm, maxNodes, rootArea);
-}
-__global__ void wide_advance(Counters* ctr) {
-  if (ctr->numWideCur) ctr->wideDepth++;
-  ctr->numWideCur = ctr->numWideNext; ctr->numWideNext = 0;
 }
 
 // --------------------------------------------------------------------------------- K5 tri_records
@@ -971,6 +1069,9 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
   HIP_TRY(segs0.alloc(maxSegs)); HIP_TRY(segs1.alloc(maxSegs)); HIP_TRY(bins.alloc((size_t)maxSegs * BINS_WORDS));
   HIP_TRY(chunks.alloc(maxChunks)); HIP_TRY(small.alloc(maxSmall)); HIP_TRY(ctr.alloc(1));
   HIP_TRY(w0.alloc(maxWide)); HIP_TRY(w1.alloc(maxWide)); HIP_TRY(wnodes.alloc(maxWide)); HIP_TRY(outIds.alloc(N));
+  const uint32_t maxLevelItems = N / 2u + 64u;                 // the nodes of one level are disjoint sub-trees of >= 2 triangles each
+  DevBuf<WidePlan> plans; DevBuf<uint2> itemCnt, groupSum;
+  HIP_TRY(plans.alloc(maxLevelItems)); HIP_TRY(itemCnt.alloc(maxLevelItems)); HIP_TRY(groupSum.alloc(maxLevelItems / 8u + 16u));
 
   hipEvent_t ev0, ev1; HIP_TRY(hipEventCreate(&ev0)); HIP_TRY(hipEventCreate(&ev1));
   struct EvGuard { hipEvent_t a, b; ~EvGuard() { hipEventDestroy(a); hipEventDestroy(b); } } evg{ev0, ev1};
@@ -1060,11 +1161,13 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
   WideItem* wc = w0.p; WideItem* wn = w1.p;
   uint32_t wlevel = 0;
   auto enqueue_wide_level = [&]() {
-    uint64_t bound = 1; for (uint32_t i = 0; i < wlevel && bound < maxWide; i++) bound *= 8u;     // <= 8^level items
-    if (bound > maxWide) bound = maxWide;
-    const uint32_t blocks = (uint32_t)((bound + 63u) / 64u) < 16384u ? (uint32_t)((bound + 63u) / 64u) : 16384u;
-    hipLaunchKernelGGL(wide_level, dim3(blocks), dim3(64), 0, st, wc, bnodes.p, wnodes.p, finalIds.p, outIds.p, wn, ctr.p, prm, maxWide, rootArea);
-    hipLaunchKernelGGL(wide_advance, dim3(1), dim3(1), 0, st, ctr.p);
+    uint64_t bound = 1; for (uint32_t i = 0; i < wlevel && bound < maxLevelItems; i++) bound *= 8u;     // <= 8^level items
+    if (bound > maxLevelItems) bound = maxLevelItems;
+    const uint32_t blocks = (uint32_t)((bound + 7u) / 8u) < 8192u ? (uint32_t)((bound + 7u) / 8u) : 8192u;   // = the waves resident at once
+    const uint32_t parity = wlevel & 1u;
+    hipLaunchKernelGGL(wide_plan, dim3(blocks), dim3(64), 0, st, wc, bnodes.p, plans.p, itemCnt.p, groupSum.p, ctr.p, prm, parity, rootArea);
+    hipLaunchKernelGGL(wide_scan, dim3(1), dim3(1024), 0, st, groupSum.p, ctr.p, parity, maxWide);
+    hipLaunchKernelGGL(wide_emit, dim3(blocks), dim3(64), 0, st, wc, bnodes.p, plans.p, itemCnt.p, groupSum.p, wnodes.p, finalIds.p, outIds.p, wn, ctr.p, parity);
     WideItem* t = wc; wc = wn; wn = t; wlevel++;
   };
   for (uint32_t i = 0; i < 8u; i++) enqueue_wide_level();
@@ -1072,7 +1175,7 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(&h, ctr.p, sizeof(h), hipMemcpyDeviceToHost, st)); HIP_TRY(hipStreamSynchronize(st));
     if (h.overflow) return set_error(hipErrorOutOfMemory, "wide node pool overflow");
-    if (h.numWideCur == 0) break;
+    if (h.wideCount[wlevel & 1u] == 0) break;
     for (uint32_t i = 0; i < 4u; i++) enqueue_wide_level();
   }
   const uint32_t depth = h.wideDepth;
@@ -1091,7 +1194,7 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
   bvh->root = h.rootRef;
   info.root_ref = h.rootRef; info.num_nodes = numNodes; info.num_leaves = h.numLeaves; info.num_binary_nodes = 2ull * h.numBLeaves - 1ull;
   info.bytes_nodes = (uint64_t)numNodes * sizeof(CNode); info.bytes_triangles = (uint64_t)n * sizeof(TriRec);
-  info.sah = h.sahSum + (numNodes ? prm.travCost : 0.0f); info.build_ms = ms; info.depth = depth;
+  info.sah = (float)((double)h.sahFixed / 16777216.0) + (numNodes ? prm.travCost : 0.0f); info.build_ms = ms; info.depth = depth;
   guard.ok = true; *out = bvh;
   return 0;
 }

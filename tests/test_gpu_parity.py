@@ -385,6 +385,19 @@ def test_rebuild_is_deterministic(api, dev):
     assert outs[0] == outs[1] == outs[2] and infos[0] == infos[1] == infos[2]
 
 
+def test_tree_layout_is_bit_identical_across_rebuilds(api, dev):
+    """No atomic counter decides an index (implicit binary numbering, scanned wide numbering): the CNode and TriRec arrays of two
+    commits of the same scene are the same bytes -- what makes 'every rank builds its own replica'  exact."""
+    meshes = W.synthetic_crown(num_phi=40)                    # ~310k triangles: several top-phase levels, thousands of small sub-trees
+    blobs = []
+    for _ in range(3):
+        s = api.make_scene(dev, meshes)
+        nodes, tris = s.download_bvh()
+        blobs.append((nodes.tobytes(), tris.tobytes(), s.info()["sah"]))
+        s.release()
+    assert blobs[0] == blobs[1] == blobs[2]
+
+
 # ---------------------------------------------------------------------- BASELINE.json full sizes: properties
 @pytest.fixture(scope="module")
 def crown_full(api, dev):
