@@ -9,6 +9,11 @@ synthetic stand-in of embree_amd/workloads.py (4,762,764 triangles, 49 geometrie
 cosine-weighted bounce rays of a 1024x1024 camera image, generated with the reference's RandomSampler.
 A "step" = one closest-hit pass over one batch of 2^20 rays through rtcIntersect1MDevice, rays already
 resident in HBM (every step has its own pristine copy of the batch, staged before the timed region).
+Steps are issued round-robin on --streams HIP streams (default 4), the way a wavefront renderer keeps several
+ray batches in flight: the persistent traversal kernel fills the chip, so the next batch's blocks start as the
+blocks of the previous one retire and the tail of a batch (lanes that have run out of rays, 22 % of the
+lane-iterations of a lone 2^20-ray launch) overlaps with useful work.  --streams 1 gives the lone-launch number;
+it is measured in every run as well and reported under roofline.serial.
 
 Multi-GPU (--gpus N, launched by torch.distributed.run, one process per GPU): the BVH is replicated
 (every rank builds it from the same inputs), each rank traces its own 2^20-ray batch (weak scaling);
@@ -16,8 +21,11 @@ the ray path has no exchange step, so there is no data-path collective; the barr
 uses torch.distributed (gloo) on the host.
 
 Printed JSON (rank 0, one line): metric/value/... as the driver contract, plus
-  roofline      achieved = ALGORITHMIC bytes per launch / average kernel time measured with HIP events on the
-                launch stream.  bytes = rays*(48 read + 52 written on hit) + visited nodes*80 + fetched
+  roofline      achieved = ALGORITHMIC bytes per launch / (average kernel time / launches in flight), kernel time
+                measured with HIP events on the stream each launch is issued on (kernel_ms_avg: agrees with rocprofv3
+                --kernel-trace of this command); launches in flight = sum of kernel times / wall time of the timed
+                region (concurrency).  roofline.serial = the same kernel launched alone, back to back on one stream.
+                bytes = rays*(48 read + 52 written on hit) + visited nodes*80 + fetched
                 triangle records*48 (visit counts from the counting build of the same kernel, same rays).
   cpu_baseline  the REAL reference (oracle/_ref, Embree 4.4.1 AVX2) looping rtcIntersect1 over the same
                 rays on all host threads (kind "reference"), or the scalar C restatement on a sample (kind "port").
@@ -33,6 +41,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# HIP multiplexes its streams onto 4 hardware queues by default, one of them the null stream's: streams that share a queue
+# run one after the other.  Ask for 8 so that every batch stream gets its own queue (must be set before the runtime starts).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 from embree_amd import api, workloads as W                    # noqa: E402  (loads the HIP library before anything else)
 from embree_amd.rtypes import RAYHIT_DTYPE, INVALID_ID         # noqa: E402
 
@@ -97,9 +108,10 @@ def cpu_baseline(meshes, rays, budget_s=25.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=12)
     ap.add_argument("--rays", type=int, default=1 << 20)
+    ap.add_argument("--streams", type=int, default=4, help="HIP streams the steps are issued on round-robin (ray batches in flight)")
     ap.add_argument("--phi", type=int, default=158, help="sphere tessellation of the synthetic crown (158 -> 4.76M triangles)")
     ap.add_argument("--config", default="", help="extra rtcNewDevice config, e.g. max_leaf=2,int_cost=0.5")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
@@ -151,9 +163,14 @@ def main():
     dprim.free()
     rays = W.diffuse_bounce_rays(traced, meshes, seed=1 + rank)
 
-    stream = C.c_void_p()
-    L.mi355_stream_create(gpu, C.byref(stream))
-    nbuf = args.steps + args.warmup
+    streams = []
+    for _ in range(max(1, args.streams)):
+        st_ = C.c_void_p()
+        L.mi355_stream_create(gpu, C.byref(st_))
+        streams.append(st_)
+    stream = streams[0]
+    nserial = min(args.steps, 10)                             # lone-launch leg (roofline.serial), after the timed region
+    nbuf = args.steps + args.warmup + nserial
     pristine = api.DeviceArray.from_numpy(rays, gpu)
     bufs = [api.DeviceArray(rays.nbytes, gpu) for _ in range(nbuf)]
     for b in bufs:
@@ -173,8 +190,8 @@ def main():
             dist[0].barrier()
 
     for i in range(args.warmup):
-        scene.intersect1M_device(bufs[i].ptr, M, 96, stream)
-    L.mi355_synchronize(stream)
+        scene.intersect1M_device(bufs[i].ptr, M, 96, streams[i % len(streams)])
+    L.mi355_device_synchronize(gpu)
 
     ev = [C.c_void_p() for _ in range(2 * args.steps)]
     for e in ev:
@@ -185,7 +202,7 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         # rtcIntersect1MDevice's launch (mi355_trace_closest) with a HIP event on either side of the kernel
-        rc = L.mi355_trace_timed(bvh, bufs[args.warmup + k].ptr, M, 96, 0, stream, ev[2 * k], ev[2 * k + 1])
+        rc = L.mi355_trace_timed(bvh, bufs[args.warmup + k].ptr, M, 96, 0, streams[k % len(streams)], ev[2 * k], ev[2 * k + 1])
         assert rc == 0, L.mi355_last_error()
     L.mi355_device_synchronize(gpu)
     barrier()
@@ -199,12 +216,30 @@ def main():
         ms = C.c_float()
         L.mi355_event_elapsed_ms(ev[2 * k], ev[2 * k + 1], C.byref(ms))
         kernel_ms.append(ms.value)
-    # the last timed buffer must hold the same answer as the counting run (same rays, same tree)
-    final = bufs[-1].download(RAYHIT_DTYPE)
-    assert final.tobytes() == result.tobytes(), "timed kernel and counting kernel disagree"
+    # lone launches, back to back on one stream (outside the timed region): the kernel's own duration
+    evs = [C.c_void_p() for _ in range(2 * nserial)]
+    for e in evs:
+        L.mi355_event_create(C.byref(e))
+    t1 = time.perf_counter()
+    for k in range(nserial):
+        rc = L.mi355_trace_timed(bvh, bufs[args.warmup + args.steps + k].ptr, M, 96, 0, stream, evs[2 * k], evs[2 * k + 1])
+        assert rc == 0, L.mi355_last_error()
+    L.mi355_device_synchronize(gpu)
+    serial_elapsed = time.perf_counter() - t1
+    serial_ms = []
+    for k in range(nserial):
+        ms = C.c_float()
+        L.mi355_event_elapsed_ms(evs[2 * k], evs[2 * k + 1], C.byref(ms))
+        serial_ms.append(ms.value)
+    # every timed buffer must hold the same answer as the counting run (same rays, same tree)
+    for b in (bufs[args.warmup], bufs[args.warmup + args.steps - 1], bufs[-1]):
+        assert b.download(RAYHIT_DTYPE).tobytes() == result.tobytes(), "timed kernel and counting kernel disagree"
 
     if rank == 0:
         avg_ms = float(np.mean(kernel_ms))
+        conc = float(np.sum(kernel_ms)) * 1e-3 / elapsed       # launches in flight, averaged over the timed region
+        eff_ms = avg_ms / max(conc, 1.0)                       # a launch that shares the chip with c-1 others gets 1/c of it
+        ser_ms = float(np.mean(serial_ms)) if serial_ms else avg_ms
         value = world * M * args.steps / elapsed / 1e6
         out = {
             "metric": "Mrays/s (incoherent diffuse, closest-hit) on crown", "value": round(value, 2), "unit": "Mrays/s",
@@ -213,11 +248,16 @@ def main():
             "config": {"workload": "configs[2]: synthetic-crown (%d triangles, %d geometries; crown.ecs is not shipped), "
                                    "%d incoherent diffuse-bounce rays per GPU, closest-hit, rays + BVH resident in HBM"
                                    % (ntri, len(meshes), M),
-                       "rays_per_gpu": M, "triangles": ntri, "parallelism": "rays sharded x%d, BVH replicated, no collective" % world,
+                       "rays_per_gpu": M, "triangles": ntri, "batches_in_flight": len(streams),
+                       "parallelism": "rays sharded x%d, BVH replicated, no collective" % world,
                        "device_config": args.config},
-            "roofline": {"bound": "hbm", "achieved": round(alg_bytes / (avg_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(alg_bytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(),
+            "roofline": {"bound": "hbm", "achieved": round(alg_bytes / (eff_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(alg_bytes / (eff_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(),
                          "kernel": "trace_kernel_q<closest>", "kernel_ms_avg": round(avg_ms, 4), "kernel_ms_min": round(float(np.min(kernel_ms)), 4),
+                         "concurrency": round(conc, 3),
+                         "serial": {"kernel_ms_avg": round(ser_ms, 4), "kernel_ms_min": round(float(np.min(serial_ms)), 4) if serial_ms else None,
+                                    "achieved": round(alg_bytes / (ser_ms * 1e-3) / 1e9, 1), "frac": round(alg_bytes / (ser_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                    "mrays_per_s": round(M * nserial / serial_elapsed / 1e6, 1) if nserial else None, "launches": nserial},
                          "algorithmic_bytes_per_launch": int(alg_bytes),
                          "per_ray": {"nodes": round(st["nodes"] / M, 2), "node_step_simd_util": round(st["nodes"] / max(1, 64 * st["node_blocks"]), 3),
                                      "tri_step_simd_util": round(st["tris"] / max(1, 64 * st["tri_blocks"]), 3),

@@ -30,6 +30,7 @@
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <vector>
 #include "bvh_common.h"
@@ -1236,7 +1237,11 @@ int mi355_device_synchronize(int device) { HIP_TRY(hipSetDevice(device)); HIP_TR
 int mi355_memcpy_d2d_async(void* d, const void* s, size_t n, void* stream) { HIP_TRY(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, (hipStream_t)stream)); return 0; }
 int mi355_stream_create(int device, void** stream) { HIP_TRY(hipSetDevice(device)); hipStream_t s; HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking)); *stream = (void*)s; return 0; }
 int mi355_stream_destroy(void* stream) { HIP_TRY(hipStreamDestroy((hipStream_t)stream)); return 0; }
-int mi355_event_create(void** e) { hipEvent_t ev; HIP_TRY(hipEventCreate(&ev)); *e = (void*)ev; return 0; }
+int mi355_event_create(void** e) {
+  // timing events without the system-scope fence: a default event makes the kernel behind it start on flushed caches
+  static const unsigned flags = getenv("MI355_EVENT_FLAGS") ? (unsigned)strtoul(getenv("MI355_EVENT_FLAGS"), nullptr, 0) : (unsigned)hipEventDisableSystemFence;
+  hipEvent_t ev; HIP_TRY(hipEventCreateWithFlags(&ev, flags)); *e = (void*)ev; return 0;
+}
 int mi355_event_record(void* e, void* stream) { HIP_TRY(hipEventRecord((hipEvent_t)e, (hipStream_t)stream)); return 0; }
 int mi355_event_elapsed_ms(void* a, void* b, float* ms) { HIP_TRY(hipEventSynchronize((hipEvent_t)b)); HIP_TRY(hipEventElapsedTime(ms, (hipEvent_t)a, (hipEvent_t)b)); return 0; }
 int mi355_event_destroy(void* e) { HIP_TRY(hipEventDestroy((hipEvent_t)e)); return 0; }
