@@ -89,7 +89,7 @@ def load():
         _build.build()
     # RTLD_NOW (+ -z now at link time): every hip* symbol binds to the ROCm runtime this library was linked
     # against at load time, before any other package could bring a second HIP runtime into the process
-    L = C.CDLL(LIB_PATH, mode=os.RTLD_NOW | os.RTLD_LOCAL)
+    L = C.CDLL(os.environ.get("MI355_LIB", LIB_PATH), mode=os.RTLD_NOW | os.RTLD_LOCAL)   # MI355_LIB: A/B builds of the kernels (tools/build_variant.sh)
     vp, u32, sz = C.c_void_p, C.c_uint32, C.c_size_t
     L.rtcNewDevice.restype = vp
     L.rtcNewDevice.argtypes = [C.c_char_p]

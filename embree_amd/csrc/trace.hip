@@ -46,6 +46,7 @@ __device__ __forceinline__ float rcp_nr(float a) {  // v_rcp_f32 + one Newton st
   return fmaf(r, fmaf(-a, r, 1.0f), r);
 }
 __device__ __forceinline__ float xor_sign(float a, uint32_t s) { return __uint_as_float(__float_as_uint(a) ^ s); }
+#define MI355_UNDEF4(n) asm volatile("" : "=v"(n.x), "=v"(n.y), "=v"(n.z), "=v"(n.w))
 template <int J> __device__ __forceinline__ float ubyte(uint32_t w) { return (float)((w >> (8 * J)) & 0xFFu); }   // v_cvt_f32_ubyteJ
 
 struct TraceArgs {
@@ -66,9 +67,10 @@ struct TraceArgs {
 // The reference's fast node test compares exact fp32 planes (intersectNode<8>, node_intersector1.h:484-531); here the planes
 // are dequantised with two extra roundings, so the comparison gets 4 ulp of slack: a ray through the exact corner of a box
 // (cube corner of tutorials/triangle_geometry) must not lose the box to rounding.  Conservative = never wrong, only slower.
+typedef float f2 __attribute__((ext_vector_type(2)));   // v_pk_fma_f32: two fp32 FMAs per VALU issue on gfx950
+struct SlabCoef { f2 sxy, szx, syz, bxy, bzx, byz; };  // plane distance = q * scale + base, paired (x,y) (z,x) (y,z)
 __device__ __forceinline__ uint32_t test4(uint32_t nx, uint32_t ny, uint32_t nz, uint32_t fx, uint32_t fy, uint32_t fz, uint32_t meta4,
-                                          uint32_t octinv4, float adx, float ady, float adz, float bx, float by, float bz,
-                                          float tmin0, float tmax0) {
+                                          uint32_t octinv4, const SlabCoef& k, float tmin0, float tmax0) {
   // meta byte: inner = 001 11sss (bits 3 and 4 set), leaf = ccc ooooo with offset <= 23, empty = 0
   const uint32_t isInner4 = (meta4 & (meta4 << 1)) & 0x10101010u;
   const uint32_t innerMask4 = (isInner4 >> 4) * 7u;                   // 0x07 in the bytes of inner slots
@@ -77,10 +79,13 @@ __device__ __forceinline__ uint32_t test4(uint32_t nx, uint32_t ny, uint32_t nz,
   uint32_t hits = 0;
 #define MI355_CHILD(J)                                                                                         \
   {                                                                                                            \
-    const float tnx = fmaf(ubyte<J>(nx), adx, bx), tny = fmaf(ubyte<J>(ny), ady, by), tnz = fmaf(ubyte<J>(nz), adz, bz); \
-    const float tfx = fmaf(ubyte<J>(fx), adx, bx), tfy = fmaf(ubyte<J>(fy), ady, by), tfz = fmaf(ubyte<J>(fz), adz, bz); \
-    const float tN = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, tmin0));                                                \
-    const float tF = fminf(fminf(tfx, tfy), fminf(tfz, tmax0));                                                \
+    f2 a, b, c;                                                                                                \
+    a.x = ubyte<J>(nx); a.y = ubyte<J>(ny); b.x = ubyte<J>(nz); b.y = ubyte<J>(fx); c.x = ubyte<J>(fy); c.y = ubyte<J>(fz); \
+    a = __builtin_elementwise_fma(a, k.sxy, k.bxy);   /* tnx, tny */                                           \
+    b = __builtin_elementwise_fma(b, k.szx, k.bzx);   /* tnz, tfx */                                           \
+    c = __builtin_elementwise_fma(c, k.syz, k.byz);   /* tfy, tfz */                                           \
+    const float tN = fmaxf(fmaxf(a.x, a.y), fmaxf(b.x, tmin0));                                                \
+    const float tF = fminf(fminf(b.y, c.x), fminf(c.y, tmax0));                                                \
     const uint32_t cb = (childBits4 >> (8 * J)) & 0xFFu, bi = (bitIndex4 >> (8 * J)) & 0x1Fu;                  \
     hits |= (tN <= tF * 1.00000048f) ? (cb << bi) : 0u;   /* 4 ulp of slack: see note above test4 */             \
   }
@@ -99,14 +104,20 @@ __device__ __forceinline__ uint32_t test4(uint32_t nx, uint32_t ny, uint32_t nz,
 //   owners re-read their best[] entry each iteration (that is their current tfar).  A ray retires once its traversal is
 //   done AND the ring has drained past its last pair; u/v/Ng/IDs are recomputed from the winning triangle at that point.
 //   Closest hit = minimum t over ALL accepted candidates, ties to the lower triangle index: independent of scheduling.
-constexpr int QSTACK_LDS = 12;             // stack entries per lane in LDS
+#ifndef MI355_QSTACK_LDS
+#define MI355_QSTACK_LDS 12
+#endif
+constexpr int QSTACK_LDS = MI355_QSTACK_LDS;   // stack entries per lane in LDS
 constexpr uint32_t QCAP = 128;             // ring capacity (pairs) per wave
 constexpr uint32_t PUSH_ROUNDS_DEFAULT = 5;  // triangle bits a lane may queue per iteration (the rest waits one iteration; env MI355_PUSH_ROUNDS)
 constexpr uint32_t NUM_CURSORS = 8;        // ray cursors per launch (one per XCD)
 constexpr uint32_t CURSOR_STRIDE = 64;     // words between cursors: each one in its own 256-byte block
 
+#ifndef MI355_TRACE_ATTR
+#define MI355_TRACE_ATTR
+#endif
 template <bool ANY, bool STATS>
-__global__ __launch_bounds__(BLOCK) void trace_kernel_q(TraceArgs a) {
+__global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceArgs a) {
   __shared__ uint2 s_stack[BLOCK / 64][QSTACK_LDS][64];
   __shared__ uint2 s_queue[BLOCK / 64][QCAP];
   __shared__ unsigned long long s_best[BLOCK / 64][64];
@@ -252,7 +263,8 @@ __global__ __launch_bounds__(BLOCK) void trace_kernel_q(TraceArgs a) {
 
     // ------------------------------------------------------------------ 3a. node step, first half: pick the child, issue its loads
     const bool doNode = active && !travDone && tgHits == 0u && ngHits > 0x00FFFFFFu;
-    uint4 n0 = make_uint4(0, 0, 0, 0), n1 = n0, n2 = n0, n3 = n0, n4 = n0;
+    uint4 n0, n1, n2, n3, n4;                                   // only read under doNode: tell the compiler they are "defined"
+    MI355_UNDEF4(n0); MI355_UNDEF4(n1); MI355_UNDEF4(n2); MI355_UNDEF4(n3); MI355_UNDEF4(n4);   // (20 v_mov per iteration otherwise)
     if (doNode) {
       const uint32_t bit = 31u - (uint32_t)__clz((int)ngHits);
       ngHits &= ~(1u << bit);
@@ -331,8 +343,11 @@ __global__ __launch_bounds__(BLOCK) void trace_kernel_q(TraceArgs a) {
       const uint32_t ny0 = sy ? n4.x : n2.z, ny1 = sy ? n4.y : n2.w, fy0 = sy ? n2.z : n4.x, fy1 = sy ? n2.w : n4.y;
       const uint32_t nz0 = sz ? n4.z : n3.x, nz1 = sz ? n4.w : n3.y, fz0 = sz ? n3.x : n4.z, fz1 = sz ? n3.y : n4.w;
       const float tmax0 = fmaxf(tfar, 0.0f);
-      const uint32_t hits = test4(nx0, ny0, nz0, fx0, fy0, fz0, n1.z, octinv4, adx, ady, adz, bx, by, bz, tnearTrav, tmax0) |
-                            test4(nx1, ny1, nz1, fx1, fy1, fz1, n1.w, octinv4, adx, ady, adz, bx, by, bz, tnearTrav, tmax0);
+      SlabCoef k;
+      k.sxy.x = adx; k.sxy.y = ady; k.szx.x = adz; k.szx.y = adx; k.syz.x = ady; k.syz.y = adz;
+      k.bxy.x = bx; k.bxy.y = by; k.bzx.x = bz; k.bzx.y = bx; k.byz.x = by; k.byz.y = bz;
+      const uint32_t hits = test4(nx0, ny0, nz0, fx0, fy0, fz0, n1.z, octinv4, k, tnearTrav, tmax0) |
+                            test4(nx1, ny1, nz1, fx1, fy1, fz1, n1.w, octinv4, k, tnearTrav, tmax0);
       ngBase = n1.x; ngHits = (hits & 0xFF000000u) | (n0.w >> 24);
       tgBase = n1.y; tgHits = hits & 0x00FFFFFFu;
       if (STATS && hits == 0u) stEmpty++;

@@ -12,7 +12,7 @@ for f in glob.glob(sys.argv[1] + '/**/*.db', recursive=True):
     for r in rows:
         name = r[0]
         try:
-            name = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt", name], capture_output=True, text=True).stdout.strip() or name
+            name = subprocess.run(["c++filt", name.replace(".kd", "")], capture_output=True, text=True).stdout.strip() or name
         except Exception:
             pass
         name = name.replace("(anonymous namespace)::", "").split("(")[0]
