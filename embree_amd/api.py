@@ -48,7 +48,7 @@ mi355_stream_destroy mi355_event_create mi355_event_record mi355_event_elapsed_m
 class BuildParams(C.Structure):
     _fields_ = [("sah_block_shift", C.c_uint32), ("min_leaf", C.c_uint32), ("max_leaf", C.c_uint32),
                 ("small_threshold", C.c_uint32), ("trav_cost", C.c_float), ("int_cost", C.c_float),
-                ("reserved", C.c_uint32 * 2)]
+                ("robust", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class BvhInfo(C.Structure):
@@ -367,8 +367,8 @@ class Scene:
             self._keep = []
 
 
-def make_scene(device, meshes, masks=None, **kw):
-    s = Scene(device)
+def make_scene(device, meshes, masks=None, flags=0, **kw):
+    s = Scene(device, flags)
     for i, (v, t) in enumerate(meshes):
         s.add_triangle_mesh(v, t, None if masks is None else masks[i], **kw)
     s.commit()

@@ -984,7 +984,7 @@ __global__ __launch_bounds__(64) void wide_emit(const WideItem* items, const BNo
 }
 
 // --------------------------------------------------------------------------------- K5 tri_records
-__global__ __launch_bounds__(256) void tri_records(const uint2* finalIds, uint32_t n, const GeomDesc* geoms, TriRec* out) {
+__global__ __launch_bounds__(256) void tri_records(const uint2* finalIds, uint32_t n, const GeomDesc* geoms, TriRec* out, uint32_t robust) {
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i >= n) return;
   const uint2 id = finalIds[i];
@@ -994,6 +994,12 @@ __global__ __launch_bounds__(256) void tri_records(const uint2* finalIds, uint32
   const float* b = (const float*)(g.verts + (size_t)tri[1] * g.vstride);
   const float* c = (const float*)(g.verts + (size_t)tri[2] * g.vstride);
   float4* o = (float4*)(out + i);
+  if (robust) {   // TriangleMv: the three vertices (kernels/geometry/trianglev.h), same 48-byte record
+    o[0] = make_float4(a[0], a[1], a[2], b[0]);
+    o[1] = make_float4(b[1], b[2], c[0], c[1]);
+    o[2] = make_float4(c[2], __uint_as_float(id.y), __uint_as_float(g.geomID), __uint_as_float(g.mask));
+    return;
+  }
   // TriangleM ctor: e1 = v0 - v1, e2 = v2 - v0 (kernels/geometry/triangle.h:40-41)
   o[0] = make_float4(a[0], a[1], a[2], a[0] - b[0]);
   o[1] = make_float4(a[1] - b[1], a[2] - b[2], c[0] - a[0], c[1] - a[1]);
@@ -1188,7 +1194,8 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
     HIP_TRY(hipMalloc(&bvh->d_nodes, (size_t)numNodes * sizeof(CNode)));
     HIP_TRY(hipMemcpyAsync(bvh->d_nodes, wnodes.p, (size_t)numNodes * sizeof(CNode), hipMemcpyDeviceToDevice, st));
   }
-  hipLaunchKernelGGL(tri_records, dim3((n + 255u) / 256u), dim3(256), 0, st, outIds.p, n, dGeoms.p, (TriRec*)bvh->d_tris);
+  hipLaunchKernelGGL(tri_records, dim3((n + 255u) / 256u), dim3(256), 0, st, outIds.p, n, dGeoms.p, (TriRec*)bvh->d_tris, bp->robust ? 1u : 0u);
+  bvh->robust = bp->robust != 0;
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(ev1, st)); HIP_TRY(hipEventSynchronize(ev1));
   float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));

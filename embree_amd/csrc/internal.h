@@ -28,6 +28,7 @@ struct Bvh {
   void* d_nodes = nullptr;       // CNode[numNodes]
   void* d_tris = nullptr;        // TriRec[numTris]
   uint32_t root = 0xFFFFFFFFu;
+  bool robust = false;           // TriRec holds v0,v1,v2 (instead of v0,e1,e2); traversal = conservative node test + Pluecker
   mi355_bvh_info info{};
   std::mutex mtx;
   std::map<hipStream_t, TraceScratch> scratch;

@@ -198,7 +198,9 @@ struct Scene : RefCounted {
     }
     if (progress && !progress(progressPtr, 0.0)) THROW(RTC_ERROR_CANCELLED, "progress monitor forced termination");
     mi355_bvh_t nb = nullptr;
-    core_check(mi355_bvh_build(device->gpu, meshes.data(), (uint32_t)meshes.size(), &device->build, nullptr, &nb), "BVH build");
+    mi355_build_params bp = device->build;
+    bp.robust = (flags & RTC_SCENE_FLAG_ROBUST) ? 1u : 0u;   // scene.cpp:180-188: robust scenes get Triangle4v leaves + the Pluecker intersector
+    core_check(mi355_bvh_build(device->gpu, meshes.data(), (uint32_t)meshes.size(), &bp, nullptr, &nb), "BVH build");
     if (bvh) mi355_bvh_destroy(bvh);
     bvh = nb;
     mi355_bvh_info info; mi355_bvh_get_info(bvh, &info);

@@ -94,6 +94,102 @@ __device__ __forceinline__ uint32_t test4(uint32_t nx, uint32_t ny, uint32_t nz,
   return hits;
 }
 
+// RTC_SCENE_FLAG_ROBUST: intersectNodeRobust (kernels/bvh/node_intersector1.h:539-554) = (plane - org) * rdir_near|far with
+// rdir_near/far = rdir * (1 -+ 3 ulp) (TravRayBase<N,true>, :98-121).  plane - org is a single correctly rounded operation, so
+// the distance has a RELATIVE error of 1.5 ulp and the 3-ulp factors make the test conservative -- which the fast path's
+// q * (scale * rdir) + (org_node - org) * rdir is not (its error is relative to the node origin's distance, not to t).  The
+// plane itself is decoded with the same fmaf(q, scale, org) the builder used to verify that the quantised box contains the
+// child (wide_emit), so decoded planes never cut into the geometry.
+__device__ __forceinline__ uint32_t test4_robust(uint32_t nx, uint32_t ny, uint32_t nz, uint32_t fx, uint32_t fy, uint32_t fz, uint32_t meta4, uint32_t octinv4,
+                                                 float scx, float scy, float scz, float nox, float noy, float noz, float ox, float oy, float oz,
+                                                 float rnx, float rny, float rnz, float rfx, float rfy, float rfz, float tmin0, float tmax0) {
+  const uint32_t isInner4 = (meta4 & (meta4 << 1)) & 0x10101010u;
+  const uint32_t innerMask4 = (isInner4 >> 4) * 7u;
+  const uint32_t bitIndex4 = meta4 ^ (octinv4 & innerMask4);
+  const uint32_t childBits4 = (meta4 >> 5) & 0x07070707u;
+  uint32_t hits = 0;
+#define MI355_CHILD(J)                                                                                         \
+  {                                                                                                            \
+    const float tnx = (fmaf(ubyte<J>(nx), scx, nox) - ox) * rnx, tny = (fmaf(ubyte<J>(ny), scy, noy) - oy) * rny, tnz = (fmaf(ubyte<J>(nz), scz, noz) - oz) * rnz; \
+    const float tfx = (fmaf(ubyte<J>(fx), scx, nox) - ox) * rfx, tfy = (fmaf(ubyte<J>(fy), scy, noy) - oy) * rfy, tfz = (fmaf(ubyte<J>(fz), scz, noz) - oz) * rfz; \
+    const float tN = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, tmin0));                                                \
+    const float tF = fminf(fminf(tfx, tfy), fminf(tfz, tmax0));                                                \
+    const uint32_t cb = (childBits4 >> (8 * J)) & 0xFFu, bi = (bitIndex4 >> (8 * J)) & 0x1Fu;                  \
+    hits |= (tN <= tF) ? (cb << bi) : 0u;                                                                      \
+  }
+  MI355_CHILD(0) MI355_CHILD(1) MI355_CHILD(2) MI355_CHILD(3)
+#undef MI355_CHILD
+  return hits;
+}
+
+// ---- triangle tests.  Record = three float4: fast scenes (v0, e1 = v0-v1, e2 = v2-v0), robust scenes (v0, v1, v2); then primID, geomID, mask.
+struct TriOut { float t, u, v, Ngx, Ngy, Ngz; };
+// Moeller-Trumbore, same operation order and FMA placement as the reference
+// (triangle_intersector_moeller.h:79-108; cross/dot: common/math/vec3.h:204,209); FINISH also produces t,u,v,Ng (Intersect1EpilogM, intersector_epilog.h:235-300)
+template <bool FINISH>
+__device__ __forceinline__ bool tri_moeller(const float4 q0, const float4 q1, const float4 q2, float ox, float oy, float oz, float dx, float dy, float dz,
+                                            float tnear, float tfar, TriOut& o) {
+  const float v0x = q0.x, v0y = q0.y, v0z = q0.z;
+  const float e1x = q0.w, e1y = q1.x, e1z = q1.y;
+  const float e2x = q1.z, e2y = q1.w, e2z = q2.x;
+  const float Ngx = fmaf(e2y, e1z, -(e2z * e1y));
+  const float Ngy = fmaf(e2z, e1x, -(e2x * e1z));
+  const float Ngz = fmaf(e2x, e1y, -(e2y * e1x));
+  const float Cx = v0x - ox, Cy = v0y - oy, Cz = v0z - oz;
+  const float Rx = fmaf(Cy, dz, -(Cz * dy));
+  const float Ry = fmaf(Cz, dx, -(Cx * dz));
+  const float Rz = fmaf(Cx, dy, -(Cy * dx));
+  const float den = fmaf(Ngx, dx, fmaf(Ngy, dy, Ngz * dz));
+  const float absDen = fabsf(den);
+  const uint32_t sgn = __float_as_uint(den) & 0x80000000u;
+  const float U = xor_sign(fmaf(Rx, e2x, fmaf(Ry, e2y, Rz * e2z)), sgn);
+  const float V = xor_sign(fmaf(Rx, e1x, fmaf(Ry, e1y, Rz * e1z)), sgn);
+  const float T = xor_sign(fmaf(Ngx, Cx, fmaf(Ngy, Cy, Ngz * Cz)), sgn);
+  bool ok = (den != 0.0f) && (U >= 0.0f) && (V >= 0.0f) && (U + V <= absDen);
+  ok = ok && (absDen * tnear < T) && (T <= absDen * tfar);      // strict at tnear, inclusive at tfar
+  if (FINISH || ok) {
+    const float rcpd = rcp_nr(absDen);
+    o.t = T * rcpd;
+    if (FINISH) { o.u = U * rcpd; o.v = V * rcpd; o.Ngx = Ngx; o.Ngy = Ngy; o.Ngz = Ngz; }
+  }
+  return ok;
+}
+// modified Pluecker test (triangle_intersector_pluecker.h:68-118), stable_triangle_normal (common/math/vec3.h:210-222),
+// PlueckerHitM::finalize (:26-33); watertight along shared edges.  Same operation order as the reference.
+template <bool FINISH>
+__device__ __forceinline__ bool tri_pluecker(const float4 q0, const float4 q1, const float4 q2, float ox, float oy, float oz, float dx, float dy, float dz,
+                                             float tnear, float tfar, TriOut& o) {
+  const float v0x = q0.x - ox, v0y = q0.y - oy, v0z = q0.z - oz;
+  const float v1x = q0.w - ox, v1y = q1.x - oy, v1z = q1.y - oz;
+  const float v2x = q1.z - ox, v2y = q1.w - oy, v2z = q2.x - oz;
+  const float e0x = v2x - v0x, e0y = v2y - v0y, e0z = v2z - v0z;
+  const float e1x = v0x - v1x, e1y = v0y - v1y, e1z = v0z - v1z;
+  const float e2x = v1x - v2x, e2y = v1y - v2y, e2z = v1z - v2z;
+#define MI355_EDGE(ex, ey, ez, sx, sy, sz) fmaf(fmaf(ey, sz, -(ez * sy)), dx, fmaf(fmaf(ez, sx, -(ex * sz)), dy, fmaf(ex, sy, -(ey * sx)) * dz))
+  const float U = MI355_EDGE(e0x, e0y, e0z, (v2x + v0x), (v2y + v0y), (v2z + v0z));
+  const float V = MI355_EDGE(e1x, e1y, e1z, (v0x + v1x), (v0y + v1y), (v0z + v1z));
+  const float W = MI355_EDGE(e2x, e2y, e2z, (v1x + v2x), (v1y + v2y), (v1z + v2z));
+#undef MI355_EDGE
+  const float UVW = (U + V) + W;
+  const float eps = 1.1920929e-07f * fabsf(UVW);
+  bool ok = (fminf(fminf(U, V), W) >= -eps) || (fmaxf(fmaxf(U, V), W) <= eps);
+  const float abx = e0z * e1y, aby = e0x * e1z, abz = e0y * e1x;
+  const float bcx = e1z * e2y, bcy = e1x * e2z, bcz = e1y * e2x;
+  const float Ngx = fabsf(abx) < fabsf(bcx) ? fmaf(e0y, e1z, -abx) : fmaf(e1y, e2z, -bcx);
+  const float Ngy = fabsf(aby) < fabsf(bcy) ? fmaf(e0z, e1x, -aby) : fmaf(e1z, e2x, -bcy);
+  const float Ngz = fabsf(abz) < fabsf(bcz) ? fmaf(e0x, e1y, -abz) : fmaf(e1x, e2y, -bcz);
+  const float dn = fmaf(Ngx, dx, fmaf(Ngy, dy, Ngz * dz)), den = dn + dn;
+  const float tt = fmaf(v0x, Ngx, fmaf(v0y, Ngy, v0z * Ngz)), T = tt + tt;
+  const float t = rcp_nr(den) * T;
+  ok = ok && (tnear <= t) && (t <= tfar) && (den != 0.0f);      // inclusive at both ends
+  o.t = t;
+  if (FINISH) {
+    const float rcpUVW = fabsf(UVW) < 1e-18f ? 0.0f : rcp_nr(UVW);
+    o.u = fminf(U * rcpUVW, 1.0f); o.v = fminf(V * rcpUVW, 1.0f); o.Ngx = Ngx; o.Ngy = Ngy; o.Ngz = Ngz;
+  }
+  return ok;
+}
+
 // =============================================================================================
 // Triangle tests leave the lane that found them.
 //   If a lane that hits leaf slots had to run its triangle tests itself before opening the next node, the node block and
@@ -116,7 +212,7 @@ constexpr uint32_t CURSOR_STRIDE = 64;     // words between cursors: each one in
 #ifndef MI355_TRACE_ATTR
 #define MI355_TRACE_ATTR
 #endif
-template <bool ANY, bool STATS>
+template <bool ANY, bool STATS, bool ROBUST>
 __global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceArgs a) {
   __shared__ uint2 s_stack[BLOCK / 64][QSTACK_LDS][64];
   __shared__ uint2 s_queue[BLOCK / 64][QCAP];
@@ -136,6 +232,7 @@ __global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceAr
   uint32_t cursor = blockIdx.x % a.numCursors, dryCursors = 0;            // wave-uniform: which ray cursor this wave pulls from
   uint32_t resV = 0; bool resValid = false;                              // the block reserved ahead (lane 0 holds the atomic's result)
   float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0, rdx = 0, rdy = 0, rdz = 0, tnear = 0, tnearTrav = 0, tfar = 0;
+  float rfx = 0, rfy = 0, rfz = 0;                                       // ROBUST: rdir_far (rdx.. hold rdir_near)
   uint32_t stNodes = 0, stTris = 0, stRays = 0, stSpill = 0, stDepth = 0, stIter = 0, stNodeBlk = 0, stTriBlk = 0;
   uint32_t stIdle = 0, stWaitBatch = 0, stWaitDrain = 0, stBlocked = 0, stEmpty = 0, stCulled = 0;
 
@@ -200,19 +297,12 @@ __global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceAr
                 if (ANY) *(float*)(rp + 32) = -__builtin_inff();        // Occluded1EpilogM: tfar = -inf
                 else {
                   // recompute the winner's t, u, v, Ng (same arithmetic as the test in step 4; Intersect1EpilogM, intersector_epilog.h:235-300)
-                  const float e1x = q0.w, e1y = q1.x, e1z = q1.y, e2x = q1.z, e2y = q1.w, e2z = q2.x;
-                  const float Ngx = fmaf(e2y, e1z, -(e2z * e1y)), Ngy = fmaf(e2z, e1x, -(e2x * e1z)), Ngz = fmaf(e2x, e1y, -(e2y * e1x));
-                  const float Cx = q0.x - ox, Cy = q0.y - oy, Cz = q0.z - oz;
-                  const float Rx = fmaf(Cy, dz, -(Cz * dy)), Ry = fmaf(Cz, dx, -(Cx * dz)), Rz = fmaf(Cx, dy, -(Cy * dx));
-                  const float den = fmaf(Ngx, dx, fmaf(Ngy, dy, Ngz * dz));
-                  const uint32_t sgn = __float_as_uint(den) & 0x80000000u;
-                  const float U = xor_sign(fmaf(Rx, e2x, fmaf(Ry, e2y, Rz * e2z)), sgn);
-                  const float V = xor_sign(fmaf(Rx, e1x, fmaf(Ry, e1y, Rz * e1z)), sgn);
-                  const float T = xor_sign(fmaf(Ngx, Cx, fmaf(Ngy, Cy, Ngz * Cz)), sgn);
-                  const float rcpd = rcp_nr(fabsf(den));
-                  *(float*)(rp + 32) = T * rcpd;
-                  *(float4*)(rp + 48) = make_float4(Ngx, Ngy, Ngz, U * rcpd);
-                  *(uint4*)(rp + 64) = make_uint4(__float_as_uint(V * rcpd), __float_as_uint(q2.y), __float_as_uint(q2.z), MI355_EMPTY_REF);
+                  TriOut w;
+                  if (ROBUST) tri_pluecker<true>(q0, q1, q2, ox, oy, oz, dx, dy, dz, tnear, tfar, w);
+                  else tri_moeller<true>(q0, q1, q2, ox, oy, oz, dx, dy, dz, tnear, tfar, w);
+                  *(float*)(rp + 32) = w.t;
+                  *(float4*)(rp + 48) = make_float4(w.Ngx, w.Ngy, w.Ngz, w.u);
+                  *(uint4*)(rp + 64) = make_uint4(__float_as_uint(w.v), __float_as_uint(q2.y), __float_as_uint(q2.z), MI355_EMPTY_REF);
                   *(uint32_t*)(rp + 80) = MI355_EMPTY_REF;
                 }
               }
@@ -227,9 +317,15 @@ __global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceAr
             tfar = r2.x; rmask = __float_as_uint(r2.y);
             // TravRay: rdir = rcp_safe(dir) (|d| < 1e-18 -> +1e-18), tnear/tfar clamped to >= 0 for traversal
             // kernels/bvh/node_intersector1.h:29-57, common/math/vec3fa.h:167-172, bvh_intersector1.cpp:65
-            rdx = rcp_nr(fabsf(dx) < 1e-18f ? 1e-18f : dx);
-            rdy = rcp_nr(fabsf(dy) < 1e-18f ? 1e-18f : dy);
-            rdz = rcp_nr(fabsf(dz) < 1e-18f ? 1e-18f : dz);
+            if (ROBUST) {                                                // TravRayBase<N,true>: a true division, then 3 ulp down / up
+              const float rx = 1.0f / (fabsf(dx) < 1e-18f ? 1e-18f : dx), ry = 1.0f / (fabsf(dy) < 1e-18f ? 1e-18f : dy), rz = 1.0f / (fabsf(dz) < 1e-18f ? 1e-18f : dz);
+              const float down = 1.0f - 3.0f * 1.1920929e-07f, up = 1.0f + 3.0f * 1.1920929e-07f;
+              rdx = down * rx; rdy = down * ry; rdz = down * rz; rfx = up * rx; rfy = up * ry; rfz = up * rz;
+            } else {
+              rdx = rcp_nr(fabsf(dx) < 1e-18f ? 1e-18f : dx);
+              rdy = rcp_nr(fabsf(dy) < 1e-18f ? 1e-18f : dy);
+              rdz = rcp_nr(fabsf(dz) < 1e-18f ? 1e-18f : dz);
+            }
             tnearTrav = fmaxf(tnear, 0.0f);
             // a ray travelling towards +x meets the children on the -x side first: priority of slot s = s ^ octinv
             octinv4 = ((rdx < 0.0f ? 0u : 1u) | (rdy < 0.0f ? 0u : 2u) | (rdz < 0.0f ? 0u : 4u)) * 0x01010101u;
@@ -301,32 +397,12 @@ __global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceAr
         const float4* tp = a.tris + (size_t)e.x * 3u;
         const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
         if (STATS) stTris++;
-        const float v0x = q0.x, v0y = q0.y, v0z = q0.z;
-        const float e1x = q0.w, e1y = q1.x, e1z = q1.y;
-        const float e2x = q1.z, e2y = q1.w, e2z = q2.x;
         const uint32_t tmask = __float_as_uint(q2.w);
-        // Moeller-Trumbore, same operation order and FMA placement as the reference
-        // (triangle_intersector_moeller.h:79-108; cross/dot: common/math/vec3.h:204,209)
-        const float Ngx = fmaf(e2y, e1z, -(e2z * e1y));
-        const float Ngy = fmaf(e2z, e1x, -(e2x * e1z));
-        const float Ngz = fmaf(e2x, e1y, -(e2y * e1x));
-        const float Cx = v0x - gox, Cy = v0y - goy, Cz = v0z - goz;
-        const float Rx = fmaf(Cy, gdz, -(Cz * gdy));
-        const float Ry = fmaf(Cz, gdx, -(Cx * gdz));
-        const float Rz = fmaf(Cx, gdy, -(Cy * gdx));
-        const float den = fmaf(Ngx, gdx, fmaf(Ngy, gdy, Ngz * gdz));
-        const float absDen = fabsf(den);
-        const uint32_t sgn = __float_as_uint(den) & 0x80000000u;
-        const float U = xor_sign(fmaf(Rx, e2x, fmaf(Ry, e2y, Rz * e2z)), sgn);
-        const float V = xor_sign(fmaf(Rx, e1x, fmaf(Ry, e1y, Rz * e1z)), sgn);
-        const float T = xor_sign(fmaf(Ngx, Cx, fmaf(Ngy, Cy, Ngz * Cz)), sgn);
-        bool ok = (den != 0.0f) && (U >= 0.0f) && (V >= 0.0f) && (U + V <= absDen);
-        ok = ok && (absDen * gtnear < T) && (T <= absDen * gtfar);  // strict at tnear, inclusive at tfar
+        TriOut w;
+        bool ok = ROBUST ? tri_pluecker<false>(q0, q1, q2, gox, goy, goz, gdx, gdy, gdz, gtnear, gtfar, w)
+                         : tri_moeller<false>(q0, q1, q2, gox, goy, goz, gdx, gdy, gdz, gtnear, gtfar, w);
         ok = ok && ((tmask & grmask) != 0u);                           // EMBREE_RAY_MASK, intersector_epilog.h:256-262
-        if (ok) {
-          const float t = T * rcp_nr(absDen);
-          atomicMin(&best[owner], ((unsigned long long)__float_as_uint(t) << 32) | e.x);
-        }
+        if (ok) atomicMin(&best[owner], ((unsigned long long)__float_as_uint(w.t + 0.0f) << 32) | e.x);   // + 0: a hit at -0 must not sort as a huge key
       }
       qHead += n;
     }
@@ -343,11 +419,19 @@ __global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceAr
       const uint32_t ny0 = sy ? n4.x : n2.z, ny1 = sy ? n4.y : n2.w, fy0 = sy ? n2.z : n4.x, fy1 = sy ? n2.w : n4.y;
       const uint32_t nz0 = sz ? n4.z : n3.x, nz1 = sz ? n4.w : n3.y, fz0 = sz ? n3.x : n4.z, fz1 = sz ? n3.y : n4.w;
       const float tmax0 = fmaxf(tfar, 0.0f);
+      uint32_t hits;
+      if (ROBUST) {
+        const float scx = __uint_as_float((n0.w & 0xFFu) << 23), scy = __uint_as_float(((n0.w >> 8) & 0xFFu) << 23), scz = __uint_as_float(((n0.w >> 16) & 0xFFu) << 23);
+        const float nox = __uint_as_float(n0.x), noy = __uint_as_float(n0.y), noz = __uint_as_float(n0.z);
+        hits = test4_robust(nx0, ny0, nz0, fx0, fy0, fz0, n1.z, octinv4, scx, scy, scz, nox, noy, noz, ox, oy, oz, rdx, rdy, rdz, rfx, rfy, rfz, tnearTrav, tmax0) |
+               test4_robust(nx1, ny1, nz1, fx1, fy1, fz1, n1.w, octinv4, scx, scy, scz, nox, noy, noz, ox, oy, oz, rdx, rdy, rdz, rfx, rfy, rfz, tnearTrav, tmax0);
+      } else {
       SlabCoef k;
       k.sxy.x = adx; k.sxy.y = ady; k.szx.x = adz; k.szx.y = adx; k.syz.x = ady; k.syz.y = adz;
       k.bxy.x = bx; k.bxy.y = by; k.bzx.x = bz; k.bzx.y = bx; k.byz.x = by; k.byz.y = bz;
-      const uint32_t hits = test4(nx0, ny0, nz0, fx0, fy0, fz0, n1.z, octinv4, k, tnearTrav, tmax0) |
-                            test4(nx1, ny1, nz1, fx1, fy1, fz1, n1.w, octinv4, k, tnearTrav, tmax0);
+      hits = test4(nx0, ny0, nz0, fx0, fy0, fz0, n1.z, octinv4, k, tnearTrav, tmax0) |
+             test4(nx1, ny1, nz1, fx1, fy1, fz1, n1.w, octinv4, k, tnearTrav, tmax0);
+      }
       ngBase = n1.x; ngHits = (hits & 0xFF000000u) | (n0.w >> 24);
       tgBase = n1.y; tgHits = hits & 0x00FFFFFFu;
       if (STATS && hits == 0u) stEmpty++;
@@ -433,8 +517,9 @@ static uint32_t env_u32(const char* name, uint32_t def, uint32_t lo, uint32_t hi
   const char* e = getenv(name); if (!e) return def;
   const long v = atol(e); return v < (long)lo || v > (long)hi ? def : (uint32_t)v;
 }
-static TraceFn pick_kernel(bool any, bool stats) {
-  return any ? (stats ? trace_kernel_q<true, true> : trace_kernel_q<true, false>) : (stats ? trace_kernel_q<false, true> : trace_kernel_q<false, false>);
+static TraceFn pick_kernel(bool any, bool stats, bool robust) {
+  if (robust) return any ? (stats ? trace_kernel_q<true, true, true> : trace_kernel_q<true, false, true>) : (stats ? trace_kernel_q<false, true, true> : trace_kernel_q<false, false, true>);
+  return any ? (stats ? trace_kernel_q<true, true, false> : trace_kernel_q<true, false, false>) : (stats ? trace_kernel_q<false, true, false> : trace_kernel_q<false, false, false>);
 }
 // persistent grid = exactly the blocks that are resident at once (a larger grid would run a second, ragged round)
 static uint32_t resident_blocks(Bvh* b, TraceFn fn) {
@@ -461,7 +546,7 @@ static int launch_trace(Bvh* b, void* d_rays, uint32_t count, size_t stride, boo
   if (count == 0) return 0;
   if (stride < (any ? 48u : 96u) || (stride & 15u) || ((uintptr_t)d_rays & 15u)) return set_error(hipErrorInvalidValue, "ray array must be 16-byte aligned with a 16-byte-multiple stride");
   HIP_TRY(hipSetDevice(b->device));
-  const TraceFn fn = pick_kernel(any, statsOut != nullptr);
+  const TraceFn fn = pick_kernel(any, statsOut != nullptr, b->robust);
   const uint32_t maxBlocks = resident_blocks(b, fn);
   uint32_t blocks = (count + BLOCK - 1) / BLOCK;
   if (blocks > maxBlocks) blocks = maxBlocks;

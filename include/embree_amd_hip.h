@@ -46,7 +46,10 @@ typedef struct mi355_build_params {
   uint32_t small_threshold;  /* sub-trees of <= this many triangles are finished by one wavefront in LDS.   default 1024 */
   float    trav_cost;        /* reference travCost = 1 */
   float    int_cost;         /* reference intCost  = 1 */
-  uint32_t reserved[2];
+  uint32_t robust;           /* RTC_SCENE_FLAG_ROBUST (kernels/common/scene.cpp:180-188): leaves keep v0,v1,v2; traversal uses the
+                                conservative node test (node_intersector1.h:539-554) and the Pluecker triangle test
+                                (triangle_intersector_pluecker.h:68-118).  default 0 */
+  uint32_t reserved;
 } mi355_build_params;
 
 typedef struct mi355_bvh_info {

@@ -17,6 +17,7 @@
  * tutorials/minimal/minimal.cpp) and against outputs of the real reference
  * (oracle/_ref, built by oracle/ref.mk) on the same scenes and rays.
  */
+#include <float.h>
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -52,6 +53,7 @@ typedef struct {
   Box bounds;
   double sah;              /* sum(area(node))/area(root) style statistic, see ora_stats */
   uint64_t stat_nodes, stat_leaves, stat_blocks; /* traversal visit counters (STAT3, kernels/common/stat.h:9-19) */
+  int robust;              /* RTC_SCENE_FLAG_ROBUST: Triangle4v leaves (v0,v1,v2) + Pluecker test + conservative node test (scene.cpp:180-188) */
 } Scene;
 
 #define EMPTY_REF INT32_MIN
@@ -79,6 +81,7 @@ static float xorf(float a, uint32_t s) { uint32_t u; memcpy(&u, &a, 4); u ^= s; 
 static uint32_t fbits(float a) { uint32_t u; memcpy(&u, &a, 4); return u; }
 
 /* ------------------------------------------------------------------ scene */
+API void ora_set_robust(Scene* s, int robust) { s->robust = robust; }   /* rtcSetSceneFlags(RTC_SCENE_FLAG_ROBUST), before ora_commit */
 API Scene* ora_new(void) { Scene* s = (Scene*)calloc(1, sizeof(Scene)); s->root = EMPTY_REF; return s; }
 
 static void free_build(Scene* s) {
@@ -250,7 +253,8 @@ static int32_t create_leaf(Scene* s, const Set* set) {
       const Mesh* m = &s->mesh[p->geomID];
       const uint32_t* tri = m->t + 3 * (size_t)p->primID;
       const float *v0 = m->v + 3 * (size_t)tri[0], *v1 = m->v + 3 * (size_t)tri[1], *v2 = m->v + 3 * (size_t)tri[2];
-      for (int d = 0; d < 3; d++) { t->v0[d][i] = v0[d]; t->e1[d][i] = v0[d] - v1[d]; t->e2[d][i] = v2[d] - v0[d]; }
+      if (s->robust) for (int d = 0; d < 3; d++) { t->v0[d][i] = v0[d]; t->e1[d][i] = v1[d]; t->e2[d][i] = v2[d]; }   /* TriangleMv: the vertices themselves, kernels/geometry/trianglev.h */
+      else for (int d = 0; d < 3; d++) { t->v0[d][i] = v0[d]; t->e1[d][i] = v0[d] - v1[d]; t->e2[d][i] = v2[d] - v0[d]; }
       t->geomID[i] = p->geomID; t->primID[i] = p->primID;
     }
   }
@@ -337,7 +341,7 @@ API void ora_visit_stats(Scene* s, uint64_t* out3, int reset) {
 }
 
 /* --------------------------------------------------------------- traversal */
-typedef struct { float org[3], dir[3], rdir[3], org_rdir[3]; int nearIsUpper[3]; float tnear, tfar; } TravRay;
+typedef struct { float org[3], dir[3], rdir[3], org_rdir[3], rdir_near[3], rdir_far[3]; int nearIsUpper[3]; float tnear, tfar; } TravRay;
 /* TravRayBase<N,false>  kernels/bvh/node_intersector1.h:29-57; rcp_safe  common/math/vec3fa.h:167-172 */
 static void travray_init(TravRay* t, const Ray* r) {
   const float o[3] = { r->org_x, r->org_y, r->org_z }, d[3] = { r->dir_x, r->dir_y, r->dir_z };
@@ -349,6 +353,37 @@ static void travray_init(TravRay* t, const Ray* r) {
     t->nearIsUpper[k] = !(t->rdir[k] >= 0.0f);
   }
   t->tnear = fmaxf_(r->tnear, 0.0f); t->tfar = fmaxf_(r->tfar, 0.0f); /* bvh_intersector1.cpp:65 */
+}
+/* TravRayBase<N,true>  node_intersector1.h:98-121: rdir = 1/zero_fix(dir) (a true division), rdir_near/far = rdir * (1 -+ 3 ulp) */
+static void travray_init_robust(TravRay* t, const Ray* r) {
+  const float o[3] = { r->org_x, r->org_y, r->org_z }, d[3] = { r->dir_x, r->dir_y, r->dir_z };
+  const float round_down = 1.0f - 3.0f * FLT_EPSILON, round_up = 1.0f + 3.0f * FLT_EPSILON;
+  for (int k = 0; k < 3; k++) {
+    t->org[k] = o[k]; t->dir[k] = d[k];
+    float z = fabsf(d[k]) < 1E-18f ? 1E-18f : d[k];
+    float rd = 1.0f / z;
+    t->rdir[k] = rd; t->rdir_near[k] = round_down * rd; t->rdir_far[k] = round_up * rd;
+    t->nearIsUpper[k] = !(t->rdir_near[k] >= 0.0f);
+  }
+  t->tnear = fmaxf_(r->tnear, 0.0f); t->tfar = fmaxf_(r->tfar, 0.0f);
+}
+/* intersectNodeRobust  node_intersector1.h:539-554: (plane - org) * rdir_near|far */
+static unsigned node_test_robust(const Node8* n, const TravRay* t, float dist[8]) {
+  unsigned mask = 0;
+  for (int i = 0; i < 8; i++) {
+    float tn[3], tf[3];
+    for (int k = 0; k < 3; k++) {
+      float pn = t->nearIsUpper[k] ? n->upper[k][i] : n->lower[k][i];
+      float pf = t->nearIsUpper[k] ? n->lower[k][i] : n->upper[k][i];
+      tn[k] = (pn - t->org[k]) * t->rdir_near[k];
+      tf[k] = (pf - t->org[k]) * t->rdir_far[k];
+    }
+    float tNear = fmaxf_(fmaxf_(tn[0], tn[1]), fmaxf_(tn[2], t->tnear));
+    float tFar = fminf_(fminf_(tf[0], tf[1]), fminf_(tf[2], t->tfar));
+    dist[i] = tNear;
+    if (tNear <= tFar) mask |= 1u << i;
+  }
+  return mask;
 }
 /* intersectNode<8> AVX2 branch  node_intersector1.h:484-531: t = msub(plane, rdir, org_rdir) */
 static unsigned node_test(const Node8* n, const TravRay* t, float dist[8]) {
@@ -392,6 +427,38 @@ static void mt_lane(const Tri4* b, int i, const Ray* ray, MTHit* h) {
   h->T = T; h->U = U; h->V = V; h->absDen = absDen; h->Ng[0] = Ng[0]; h->Ng[1] = Ng[1]; h->Ng[2] = Ng[2];
 }
 
+/* PlueckerIntersector1<4>::intersect  kernels/geometry/triangle_intersector_pluecker.h:68-118 on one lane of a TriangleMv block
+   (fields e1/e2 of Tri4 hold v1/v2 in robust scenes); PlueckerHitM::finalize :26-33.  h->T carries t itself, h->absDen = 1. */
+typedef struct { int valid; float t, u, v, Ng[3]; } PLHit;
+static void cross3(const float* a, const float* b, float* o) { o[0] = fmaf(a[1], b[2], -(a[2] * b[1])); o[1] = fmaf(a[2], b[0], -(a[0] * b[2])); o[2] = fmaf(a[0], b[1], -(a[1] * b[0])); }
+static float dot3(const float* a, const float* b) { return fmaf(a[0], b[0], fmaf(a[1], b[1], a[2] * b[2])); }
+static void pl_lane(const Tri4* b, int i, const Ray* ray, PLHit* h) {
+  const float O[3] = { ray->org_x, ray->org_y, ray->org_z }, D[3] = { ray->dir_x, ray->dir_y, ray->dir_z };
+  float v0[3], v1[3], v2[3], e0[3], e1[3], e2[3], s0[3], s1[3], s2[3], c[3];
+  for (int d = 0; d < 3; d++) { v0[d] = b->v0[d][i] - O[d]; v1[d] = b->e1[d][i] - O[d]; v2[d] = b->e2[d][i] - O[d]; }
+  for (int d = 0; d < 3; d++) { e0[d] = v2[d] - v0[d]; e1[d] = v0[d] - v1[d]; e2[d] = v1[d] - v2[d]; s0[d] = v2[d] + v0[d]; s1[d] = v0[d] + v1[d]; s2[d] = v1[d] + v2[d]; }
+  cross3(e0, s0, c); const float U = dot3(c, D);
+  cross3(e1, s1, c); const float V = dot3(c, D);
+  cross3(e2, s2, c); const float W = dot3(c, D);
+  const float UVW = (U + V) + W;
+  const float eps = FLT_EPSILON * fabsf(UVW);
+  const float mn = fminf_(fminf_(U, V), W), mx = fmaxf_(fmaxf_(U, V), W);
+  int valid = (mn >= -eps) || (mx <= eps);
+  /* stable_triangle_normal(e0,e1,e2)  common/math/vec3.h:210-222 */
+  const float ab_x = e0[2] * e1[1], ab_y = e0[0] * e1[2], ab_z = e0[1] * e1[0];
+  const float bc_x = e1[2] * e2[1], bc_y = e1[0] * e2[2], bc_z = e1[1] * e2[0];
+  const float cab[3] = { fmaf(e0[1], e1[2], -ab_x), fmaf(e0[2], e1[0], -ab_y), fmaf(e0[0], e1[1], -ab_z) };
+  const float cbc[3] = { fmaf(e1[1], e2[2], -bc_x), fmaf(e1[2], e2[0], -bc_y), fmaf(e1[0], e2[1], -bc_z) };
+  const float Ng[3] = { fabsf(ab_x) < fabsf(bc_x) ? cab[0] : cbc[0], fabsf(ab_y) < fabsf(bc_y) ? cab[1] : cbc[1], fabsf(ab_z) < fabsf(bc_z) ? cab[2] : cbc[2] };
+  const float dn = dot3(Ng, D), den = dn + dn;
+  const float tt = dot3(v0, Ng), T = tt + tt;
+  const float t = rcp_nr(den) * T;
+  valid = valid && (ray->tnear <= t) && (t <= ray->tfar) && (den != 0.0f);
+  const float rcpUVW = fabsf(UVW) < 1E-18f ? 0.0f : rcp_nr(UVW);
+  h->valid = valid; h->t = t; h->u = fminf_(U * rcpUVW, 1.0f); h->v = fminf_(V * rcpUVW, 1.0f);
+  h->Ng[0] = Ng[0]; h->Ng[1] = Ng[1]; h->Ng[2] = Ng[2];
+}
+
 /* ArrayIntersector1::intersect (kernels/geometry/intersector_iterators.h:23-28) over the leaf's blocks,
    each block = MoellerTrumbore x4 + Intersect1EpilogM<4,true> (kernels/geometry/intersector_epilog.h:235-300) */
 static void leaf_intersect(Scene* s, RayHit* rh, size_t start, size_t num) {
@@ -399,11 +466,20 @@ static void leaf_intersect(Scene* s, RayHit* rh, size_t start, size_t num) {
     const Tri4* b = &s->blocks[start + k];
     s->stat_blocks++;
     MTHit h[4]; float t[4], u[4], v[4]; int valid[4], any = 0;
+    if (s->robust) {
+      for (int i = 0; i < 4; i++) {
+        PLHit p; pl_lane(b, i, &rh->ray, &p);
+        valid[i] = p.valid; any |= valid[i]; t[i] = p.t; u[i] = p.u; v[i] = p.v;
+        h[i].Ng[0] = p.Ng[0]; h[i].Ng[1] = p.Ng[1]; h[i].Ng[2] = p.Ng[2];
+      }
+      if (!any) continue;
+    } else {
     for (int i = 0; i < 4; i++) { mt_lane(b, i, &rh->ray, &h[i]); valid[i] = h[i].valid; any |= valid[i]; }
     if (!any) continue;
     for (int i = 0; i < 4; i++) { /* finalize(): t,u,v = T,U,V * rcp(absDen)  triangle_intersector_moeller.h:29-36 */
       float r = rcp_nr(h[i].absDen);
       t[i] = h[i].T * r; u[i] = h[i].U * r; v[i] = h[i].V * r;
+    }
     }
     for (;;) {
       /* select_min(valid, vt): lowest lane among the minimum  common/simd/vfloat4_sse2.h:759 */
@@ -429,8 +505,10 @@ static int leaf_occluded(Scene* s, const Ray* ray, size_t start, size_t num) {
     const Tri4* b = &s->blocks[start + k];
     s->stat_blocks++;
     for (int i = 0; i < 4; i++) {
-      MTHit h; mt_lane(b, i, ray, &h);
-      if (h.valid && (s->mesh[b->geomID[i]].mask & ray->mask) != 0) return 1;
+      int valid;
+      if (s->robust) { PLHit p; pl_lane(b, i, ray, &p); valid = p.valid && b->geomID[i] != INVALID_ID; }
+      else { MTHit h; mt_lane(b, i, ray, &h); valid = h.valid; }
+      if (valid && (s->mesh[b->geomID[i]].mask & ray->mask) != 0) return 1;
     }
   }
   return 0;
@@ -442,7 +520,7 @@ typedef struct { int32_t ref; uint32_t dist; } StackItem; /* StackItemT  kernels
 /* BVHNIntersector1::intersect  kernels/bvh/bvh_intersector1.cpp:32-114 */
 static void intersect1(Scene* s, RayHit* rh) {
   if (s->root == EMPTY_REF) return;
-  TravRay tr; travray_init(&tr, &rh->ray);
+  TravRay tr; if (s->robust) travray_init_robust(&tr, &rh->ray); else travray_init(&tr, &rh->ray);
   StackItem stack[STACK]; int sp = 1;
   stack[0].ref = s->root; stack[0].dist = fbits(-INFINITY);
   while (sp > 0) {
@@ -455,7 +533,7 @@ static void intersect1(Scene* s, RayHit* rh) {
       const Node8* n = &s->nodes[cur];
       float dist[8];
       s->stat_nodes++;
-      unsigned mask = node_test(n, &tr, dist);
+      unsigned mask = s->robust ? node_test_robust(n, &tr, dist) : node_test(n, &tr, dist);
       if (mask == 0) { popped = 1; break; }
       /* traverseClosestHit  kernels/bvh/bvh_traverser1.h:311-433: nearest child next, rest pushed far -> near */
       StackItem hit[8]; int nh = 0;
@@ -483,7 +561,7 @@ static void intersect1(Scene* s, RayHit* rh) {
 static void occluded1(Scene* s, Ray* ray) {
   if (s->root == EMPTY_REF) return;
   if (ray->tfar < 0.0f) return;
-  TravRay tr; travray_init(&tr, ray);
+  TravRay tr; if (s->robust) travray_init_robust(&tr, ray); else travray_init(&tr, ray);
   int32_t stack[STACK]; int sp = 1; stack[0] = s->root;
   while (sp > 0) {
     int32_t cur = stack[--sp];
@@ -492,7 +570,7 @@ static void occluded1(Scene* s, Ray* ray) {
       const Node8* n = &s->nodes[cur];
       float dist[8];
       s->stat_nodes++;
-      unsigned mask = node_test(n, &tr, dist);
+      unsigned mask = s->robust ? node_test_robust(n, &tr, dist) : node_test(n, &tr, dist);
       if (mask == 0) { popped = 1; break; }
       int last = -1;
       for (int i = 0; i < 8; i++) if (mask & (1u << i)) { if (last >= 0) stack[sp++] = n->child[last]; last = i; }
@@ -521,6 +599,12 @@ API void ora_triangle_t(Scene* s, const RayHit* rh, const uint32_t* geomID, cons
     if (tri[0] >= m->nv || tri[1] >= m->nv || tri[2] >= m->nv) continue;
     Tri4 b; memset(&b, 0, sizeof(b));
     const float *v0 = m->v + 3 * (size_t)tri[0], *v1 = m->v + 3 * (size_t)tri[1], *v2 = m->v + 3 * (size_t)tri[2];
+    if (s->robust) {
+      for (int d = 0; d < 3; d++) { b.v0[d][0] = v0[d]; b.e1[d][0] = v1[d]; b.e2[d][0] = v2[d]; }
+      PLHit ph; pl_lane(&b, 0, &rh[i].ray, &ph);
+      if (ph.valid) t_out[i] = ph.t;
+      continue;
+    }
     for (int d = 0; d < 3; d++) { b.v0[d][0] = v0[d]; b.e1[d][0] = v0[d] - v1[d]; b.e2[d][0] = v2[d] - v0[d]; }
     MTHit h; mt_lane(&b, 0, &rh[i].ray, &h);
     if (h.valid) t_out[i] = h.T * rcp_nr(h.absDen);

@@ -26,6 +26,7 @@ def _load():
         L.ora_add_mesh.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint, ctypes.c_void_p,
                                    ctypes.c_uint, ctypes.c_uint]
         L.ora_commit.argtypes = [ctypes.c_void_p]
+        L.ora_set_robust.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.ora_bounds.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         L.ora_counts.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         L.ora_visit_stats.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
@@ -38,8 +39,11 @@ def _load():
 
 
 class OracleScene:
-    def __init__(self):
+    def __init__(self, robust=False):
+        """robust=True restates RTC_SCENE_FLAG_ROBUST: Triangle4v leaves, Pluecker test, conservative node test."""
         self._h = _load().ora_new()
+        if robust:
+            _load().ora_set_robust(self._h, 1)
 
     def add_mesh(self, verts, tris, mask=1):
         v = np.ascontiguousarray(verts, np.float32).reshape(-1, 3)

@@ -14,6 +14,9 @@ Outputs
   ref_soup_8k.npz        8192 incoherent rays on a seeded 3,000-triangle soup (two geometries,
                          masks 1 and 2, ray masks alternating) incl. occluded results
   ref_trianglehit.npz    TriangleHitTest (tutorials/verify/verify.cpp:2462-2547) inputs + real-reference outputs
+  ref_watertight_robust.npz  WatertightTest (verify.cpp:3611-3688) at its position (148376, 1234, -223423): triangle sphere of
+                         radius 2 (numPhi 50), 8192 rays from inside, real reference with RTC_SCENE_FLAG_ROBUST
+                         (BVH8Triangle4v + Pluecker + conservative node test); rtcIntersect1 and rtcOccluded1 results
 """
 import os
 import sys
@@ -47,8 +50,8 @@ def parse_obj(path):
     return np.array(verts, np.float32), np.array(tris, np.uint32)
 
 
-def trace_ref(meshes, rayhits, masks=None, occl=True):
-    s = refembree.RefScene("threads=1")
+def trace_ref(meshes, rayhits, masks=None, occl=True, flags=0):
+    s = refembree.RefScene("threads=1", flags=flags)
     for i, (v, t) in enumerate(meshes):
         s.add_mesh(v, t, 1 if masks is None else masks[i])
     s.commit()
@@ -99,6 +102,15 @@ def main():
     d = trace_ref([(tv, tt)], make_rayhits(org, tgt - org))
     d.update(u0=u, v0=w)
     np.savez_compressed(os.path.join(OUT, "ref_trianglehit.npz"), **d)
+    # WatertightTest: rays from inside a sphere far away from the origin; every ray must hit (robust scenes only)
+    pos = np.array([148376.0, 1234.0, -223423.0], np.float32)
+    sph = W.triangle_sphere(pos, 2.0, 50)
+    rng = np.random.default_rng(77)
+    org = (pos[None, :] + (2.0 * rng.random((8192, 3), dtype=np.float32) - 1.0)).astype(np.float32)
+    dirs = (2.0 * rng.random((8192, 3), dtype=np.float32) - 1.0).astype(np.float32)
+    d = trace_ref([sph], make_rayhits(org, dirs), flags=4)          # RTC_SCENE_FLAG_ROBUST
+    assert (d["hits"]["geomID"] == 0).all() and np.isneginf(d["occluded_tfar"]).all(), "the reference itself is not watertight here"
+    np.savez_compressed(os.path.join(OUT, "ref_watertight_robust.npz"), **d)
     print("golden fixtures written to", OUT)
 
 

@@ -398,6 +398,97 @@ def test_tree_layout_is_bit_identical_across_rebuilds(api, dev):
     assert blobs[0] == blobs[1] == blobs[2]
 
 
+# ---------------------------------------------------------------------- RTC_SCENE_FLAG_ROBUST
+WATERTIGHT_POS = np.array([148376.0, 1234.0, -223423.0], np.float32)     # verify.cpp:6575-6621
+
+
+def test_robust_golden_watertight(api, dev, restate, golden_dir):
+    """Robust scenes against the REAL reference's robust outputs (tests/golden/ref_watertight_robust.npz): WatertightTest's sphere
+    200 km from the origin, rays from inside.  IDs bit-exact (tie rule), t/u/v/Ng within tolerance, every ray hits."""
+    g = np.load(os.path.join(golden_dir, "ref_watertight_robust.npz"))
+    sph = W.triangle_sphere(WATERTIGHT_POS, 2.0, 50)
+    s = api.make_scene(dev, [sph], flags=api.RTC_SCENE_FLAG_ROBUST)
+    o = restate.OracleScene(robust=True)
+    o.add_mesh(*sph)
+    o.commit()
+    got = g["rays"].copy()
+    s.intersect1M(got)
+    assert (got["geomID"] == 0).all(), "a ray leaked through the closed sphere in robust mode"
+    compare_closest(got, g["hits"], g["rays"], o.triangle_t, label="robust golden")
+    r = rays_of(g["rays"])
+    s.occluded1M(r)
+    compare_occluded(r["tfar"], g["occluded_tfar"], rays_of(g["rays"])["tfar"], label="robust golden occluded")
+    nodes, tris = s.download_bvh()
+    # robust leaves keep the vertices themselves (TriangleMv), not v0/e1/e2
+    v, t = sph
+    key = {int(p): i for i, p in enumerate(tris["primID"])}
+    for p in (0, 17, t.shape[0] - 1):
+        rec = tris[key[p]]
+        assert (rec["v0"] == v[t[p, 0]]).all() and (rec["e1"] == v[t[p, 1]]).all() and (rec["e2"] == v[t[p, 2]]).all()
+    s.release()
+
+
+@pytest.mark.parametrize("model", ["sphere", "plane"])
+def test_robust_watertight_fail_rate(api, dev, model):
+    """WatertightTest (verify.cpp:3611-3688) at full intensity: numPhi / grid 200, rays as the test builds them; the reference accepts a
+    failure rate of 2e-5, closest hit and occlusion."""
+    rng = np.random.default_rng(5)
+    n = 400000
+    if model == "sphere":
+        mesh = W.triangle_sphere(WATERTIGHT_POS, 2.0, 200)
+        org = (WATERTIGHT_POS[None, :] + (2.0 * rng.random((n, 3), dtype=np.float32) - 1.0)).astype(np.float32)
+        dirs = (2.0 * rng.random((n, 3), dtype=np.float32) - 1.0).astype(np.float32)
+    else:   # createTrianglePlane(p0 = (pos.x,-6,-6), dx = (0,0,12), dy = (0,12,0), 200 x 200)
+        k = 200
+        gy, gx = np.meshgrid(np.arange(k + 1, dtype=np.float32), np.arange(k + 1, dtype=np.float32), indexing="ij")
+        verts = np.stack([np.full_like(gx, WATERTIGHT_POS[0]), -6.0 + 12.0 * gy / k, -6.0 + 12.0 * gx / k], -1).reshape(-1, 3).astype(np.float32)
+        i = (np.arange(k)[:, None] * (k + 1) + np.arange(k)[None, :]).ravel()
+        tris = np.concatenate([np.stack([i, i + 1, i + k + 1], -1), np.stack([i + 1, i + k + 2, i + k + 1], -1)]).astype(np.uint32)
+        mesh = (verts, tris)
+        org = np.tile(np.array([[WATERTIGHT_POS[0] - 3.0, 0.0, 0.0]], np.float32), (n, 1))
+        dirs = (2.0 * rng.random((n, 3), dtype=np.float32) - 1.0).astype(np.float32)
+        dirs[:, 0] = 1.0
+    s = api.make_scene(dev, [mesh], flags=api.RTC_SCENE_FLAG_ROBUST)
+    rh = make_rayhits(org, dirs)
+    s.intersect1M(rh)
+    fail = float((rh["geomID"] == INVALID_ID).mean())
+    r = rays_of(make_rayhits(org, dirs))
+    s.occluded1M(r)
+    fail_o = float((~np.isneginf(r["tfar"])).mean())
+    s.release()
+    assert fail <= 2e-5 and fail_o <= 2e-5, (model, fail, fail_o)
+
+
+def test_robust_parity_crown_vs_oracle(api, dev, restate):
+    """Robust traversal on a multi-geometry scene against the robust restatement: incoherent closest hit + occlusion + packets."""
+    meshes = W.synthetic_crown(num_phi=24)
+    rays = W.incoherent_rays(60000, [2, 2, 1.5], seed=9)
+    s = api.make_scene(dev, meshes, flags=api.RTC_SCENE_FLAG_ROBUST)
+    o = restate.OracleScene(robust=True)
+    for v, t in meshes:
+        o.add_mesh(v, t)
+    o.commit()
+    want = rays.copy()
+    o.intersect1(want)
+    got = rays.copy()
+    s.intersect1M(got)
+    st = compare_closest(got, want, rays, o.triangle_t, label="robust crown")
+    assert st["hits"] > 0.9 * rays.shape[0]
+    wr, gr = rays_of(rays), rays_of(rays)
+    o.occluded1(wr)
+    s.occluded1M(gr)
+    compare_occluded(gr["tfar"], wr["tfar"], rays_of(rays)["tfar"], label="robust crown occluded")
+    # the fast scene of the same geometry must still give the fast answers (flag is per scene)
+    f = api.make_scene(dev, meshes)
+    of = oracle_scene(restate, meshes)
+    wf, gf = rays.copy(), rays.copy()
+    of.intersect1(wf)
+    f.intersect1M(gf)
+    compare_closest(gf, wf, rays, of.triangle_t, label="fast scene next to a robust one")
+    f.release()
+    s.release()
+
+
 # ---------------------------------------------------------------------- BASELINE.json full sizes: properties
 @pytest.fixture(scope="module")
 def crown_full(api, dev):
