@@ -20,6 +20,7 @@ ap.add_argument("--config", default="")
 ap.add_argument("--phi", type=int, default=158)
 ap.add_argument("--reps", type=int, default=10)
 ap.add_argument("--any", action="store_true")
+ap.add_argument("--robust", action="store_true", help="RTC_SCENE_FLAG_ROBUST scene")
 ap.add_argument("--primary", action="store_true")
 ap.add_argument("--tag", default="")
 ap.add_argument("--retrace", action="store_true", help="trace once, then time the same rays with tfar preset to the hit distance (perfect-culling bound)")
@@ -27,7 +28,7 @@ a = ap.parse_args()
 L = api.load()
 dev = api.Device(a.config)
 meshes = W.synthetic_crown(num_phi=a.phi)
-s = api.Scene(dev)
+s = api.Scene(dev, api.RTC_SCENE_FLAG_ROBUST if a.robust else 0)
 for v, t in meshes:
     s.add_triangle_mesh(v, t, device_resident=True)
 s.commit()
