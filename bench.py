@@ -44,7 +44,7 @@ sys.path.insert(0, ROOT)
 # HIP multiplexes its streams onto 4 hardware queues by default, one of them the null stream's: streams that share a queue
 # run one after the other.  Ask for 8 so that every batch stream gets its own queue (must be set before the runtime starts).
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-from embree_amd import api, workloads as W                    # noqa: E402  (loads the HIP library before anything else)
+from embree_amd import api, loaders, workloads as W           # noqa: E402  (loads the HIP library before anything else)
 from embree_amd.rtypes import RAYHIT_DTYPE, INVALID_ID         # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md (6.29 TB/s measured copy rate)
@@ -115,6 +115,8 @@ def main():
     ap.add_argument("--phi", type=int, default=158, help="sphere tessellation of the synthetic crown (158 -> 4.76M triangles)")
     ap.add_argument("--config", default="", help="extra rtcNewDevice config, e.g. max_leaf=2,int_cost=0.5")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--scene", default="", help=".ecs / .xml / .obj scene file; default: $EMBREE_MODEL_DIR/crown/crown.ecs if it exists, "
+                                                 "else the synthetic crown stand-in")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -138,7 +140,14 @@ def main():
 
     # ---- scene: replicated BVH, geometry resident on the device
     t0 = time.time()
-    meshes = W.synthetic_crown(num_phi=args.phi)
+    scene_path = args.scene or loaders.find_model("crown")
+    if scene_path:                                         # the real asset when the box has it (the reference does not ship it)
+        loaded = loaders.load_scene(scene_path)
+        meshes, camera = loaded.meshes, loaded.camera
+        scene_name = "%s (%s)" % (os.path.basename(scene_path), "loaded with embree_amd/loaders.py")
+    else:
+        meshes, camera = W.synthetic_crown(num_phi=args.phi), None
+        scene_name = "synthetic-crown (crown.ecs is not shipped)"
     ntri = W.num_triangles(meshes)
     gen_s = time.time() - t0
     scene = api.Scene(dev)
@@ -154,7 +163,8 @@ def main():
 
     # ---- rays: primary image traced on the GPU -> diffuse bounce rays (this rank's own seed)
     side = int(round(args.rays ** 0.5))
-    prim = W.crown_camera_rays(meshes, side, side)
+    prim = (W.camera_rays(camera["vp"], camera["vi"], camera["vu"], camera["fov"], side, side) if camera
+            else W.crown_camera_rays(meshes, side, side))
     M = prim.shape[0]
     dprim = api.DeviceArray.from_numpy(prim, gpu)
     scene.intersect1M_device(dprim.ptr, M)
@@ -244,10 +254,10 @@ def main():
         out = {
             "metric": "Mrays/s (incoherent diffuse, closest-hit) on crown", "value": round(value, 2), "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[2]: synthetic-crown (%d triangles, %d geometries; crown.ecs is not shipped), "
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic" if not scene_path else "file",
+            "config": {"workload": "configs[2]: %s, %d triangles, %d geometries, "
                                    "%d incoherent diffuse-bounce rays per GPU, closest-hit, rays + BVH resident in HBM"
-                                   % (ntri, len(meshes), M),
+                                   % (scene_name, ntri, len(meshes), M),
                        "rays_per_gpu": M, "triangles": ntri, "batches_in_flight": len(streams),
                        "parallelism": "rays sharded x%d, BVH replicated, no collective" % world,
                        "device_config": args.config},
