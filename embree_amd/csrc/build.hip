@@ -205,48 +205,71 @@ __device__ __forceinline__ int bin_clamped(float c2, float ofs, float scale, uin
 __device__ __forceinline__ void bins_clear(uint32_t* bins, uint32_t tid, uint32_t nthreads) {
   for (uint32_t w = tid; w < (uint32_t)BINS_WORDS; w += nthreads) { const uint32_t k = w % BINW; bins[w] = k < 3 ? ENC_POS_INF : (k < 6 ? ENC_NEG_INF : 0u); }
 }
-__device__ __forceinline__ void bins_add(uint32_t* bins, const Mapping& m, const PrimRef& r) {   // BinInfoT::bin, heuristic_binning.h:210-257
-  for (int d = 0; d < 3; d++) {
-    const int b = bin_clamped(r.lo[d] + r.hi[d], m.ofs[d], m.scale[d], m.nb);
-    uint32_t* e = bins + (d * NBINS + b) * BINW;
-    atomicMin(&e[0], enc(r.lo[0])); atomicMin(&e[1], enc(r.lo[1])); atomicMin(&e[2], enc(r.lo[2]));
-    atomicMax(&e[3], enc(r.hi[0])); atomicMax(&e[4], enc(r.hi[1])); atomicMax(&e[5], enc(r.hi[2]));
-    atomicAdd(&e[6], 1u);
-  }
+
+__device__ __forceinline__ uint32_t wave_uadd63(uint32_t v) {
+  v += dpp_u<0xB1, 0xF>(0u, v); v += dpp_u<0x4E, 0xF>(0u, v); v += dpp_u<0x114, 0xF>(0u, v);
+  v += dpp_u<0x118, 0xF>(0u, v); v += dpp_u<0x142, 0xA>(0u, v); v += dpp_u<0x143, 0xC>(0u, v);
+  return v;
 }
 
-// wave-cooperative version: every lane of the wave calls it (valid = this lane holds a triangle).  Per axis, the lanes that
-// share the bin of the first pending lane are reduced in registers and lane 63 issues their 7 atomics; this is repeated once
-// for what is left, the rest goes lane by lane.
-__device__ __forceinline__ void bins_add_wave(uint32_t* bins, const Mapping& m, const PrimRef& r, bool valid, uint32_t lane) {
+// BinInfoT::bin (heuristic_binning.h:210-257) with run merging in front of the bins.  A lane sees triangles i, i + 64, i + 128, ... of a contiguous span; in mesh order those fall
+// into the same bin again and again, so every lane keeps, per axis, the bin it is currently in with the merged bounds and the
+// count of that run (24 registers) and only touches the LDS bins when the bin changes.  What is left at the end of the span is
+// folded across the wave (DPP reductions of the lanes that share a bin) before the last atomics.  The earlier version reduced
+// every batch of 64 triangles across the wave: ~600 VALU instructions per batch; this one needs ~100.
+struct BinRuns { int b[3]; uint32_t lo[3][3], hi[3][3], n[3]; };
+__device__ __forceinline__ void runs_init(BinRuns& r) { for (int d = 0; d < 3; d++) { r.b[d] = -1; r.n[d] = 0u; for (int k = 0; k < 3; k++) { r.lo[d][k] = 0xFFFFFFFFu; r.hi[d][k] = 0u; } } }
+__device__ __forceinline__ void runs_add(BinRuns& r, uint32_t* bins, const Mapping& m, const PrimRef& p, bool valid) {
+  if (!valid) return;
   uint32_t c[6];
-  for (int k = 0; k < 3; k++) { c[k] = enc(r.lo[k]); c[3 + k] = enc(r.hi[k]); }
+  for (int k = 0; k < 3; k++) { c[k] = enc(p.lo[k]); c[3 + k] = enc(p.hi[k]); }
 #pragma unroll
   for (int d = 0; d < 3; d++) {
-    int b = valid ? bin_clamped(r.lo[d] + r.hi[d], m.ofs[d], m.scale[d], m.nb) : -1;
+    const int b = bin_clamped(p.lo[d] + p.hi[d], m.ofs[d], m.scale[d], m.nb);
+    if (b != r.b[d]) {
+      if (r.n[d]) {                                             // the run ends: its 7 atomics
+        uint32_t* e = bins + (d * NBINS + r.b[d]) * BINW;
+        atomicMin(&e[0], r.lo[d][0]); atomicMin(&e[1], r.lo[d][1]); atomicMin(&e[2], r.lo[d][2]);
+        atomicMax(&e[3], r.hi[d][0]); atomicMax(&e[4], r.hi[d][1]); atomicMax(&e[5], r.hi[d][2]);
+        atomicAdd(&e[6], r.n[d]);
+      }
+      r.b[d] = b; r.n[d] = 1u;
+      for (int k = 0; k < 3; k++) { r.lo[d][k] = c[k]; r.hi[d][k] = c[3 + k]; }
+    } else {
+      r.n[d]++;
+      for (int k = 0; k < 3; k++) { r.lo[d][k] = min(r.lo[d][k], c[k]); r.hi[d][k] = max(r.hi[d][k], c[3 + k]); }
+    }
+  }
+}
+// every lane of the wave calls it: the pending runs of the lanes that share a bin are reduced in registers, lane 63 issues the atomics
+__device__ __forceinline__ void runs_flush_wave(BinRuns& r, uint32_t* bins, uint32_t lane) {
+#pragma unroll
+  for (int d = 0; d < 3; d++) {
+    int b = r.n[d] ? r.b[d] : -1;
     unsigned long long rem = __ballot(b >= 0);
-    for (int round = 0; round < 2; round++) {
-      if (__popcll(rem) < 12) break;
+    for (int round = 0; round < 3; round++) {
+      if (__popcll(rem) < 8) break;
       const int b0 = __builtin_amdgcn_readlane(b, __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(rem)));
       const bool mt = b == b0;
       const unsigned long long mm = __ballot(mt);
-      if (__popcll(mm) < 6) break;
+      if (__popcll(mm) < 4) break;
       uint32_t v[6];
-      for (int k = 0; k < 3; k++) { v[k] = wave_umin63(mt ? c[k] : 0xFFFFFFFFu); v[3 + k] = wave_umax63(mt ? c[3 + k] : 0u); }
+      for (int k = 0; k < 3; k++) { v[k] = wave_umin63(mt ? r.lo[d][k] : 0xFFFFFFFFu); v[3 + k] = wave_umax63(mt ? r.hi[d][k] : 0u); }
+      const uint32_t cnt = wave_uadd63(mt ? r.n[d] : 0u);
       if (lane == 63u) {
         uint32_t* e = bins + (d * NBINS + b0) * BINW;
         atomicMin(&e[0], v[0]); atomicMin(&e[1], v[1]); atomicMin(&e[2], v[2]);
         atomicMax(&e[3], v[3]); atomicMax(&e[4], v[4]); atomicMax(&e[5], v[5]);
-        atomicAdd(&e[6], (uint32_t)__popcll(mm));
+        atomicAdd(&e[6], cnt);
       }
       if (mt) b = -1;
       rem &= ~mm;
     }
     if (b >= 0) {
       uint32_t* e = bins + (d * NBINS + b) * BINW;
-      atomicMin(&e[0], c[0]); atomicMin(&e[1], c[1]); atomicMin(&e[2], c[2]);
-      atomicMax(&e[3], c[3]); atomicMax(&e[4], c[4]); atomicMax(&e[5], c[5]);
-      atomicAdd(&e[6], 1u);
+      atomicMin(&e[0], r.lo[d][0]); atomicMin(&e[1], r.lo[d][1]); atomicMin(&e[2], r.lo[d][2]);
+      atomicMax(&e[3], r.hi[d][0]); atomicMax(&e[4], r.hi[d][1]); atomicMax(&e[5], r.hi[d][2]);
+      atomicAdd(&e[6], r.n[d]);
     }
   }
 }
@@ -338,10 +361,15 @@ __global__ __launch_bounds__(256) void top_bin(const Seg* segs, const Chunk* chu
   Mapping m; for (int d = 0; d < 3; d++) { m.ofs[d] = sg->ofs[d]; m.scale[d] = sg->scale[d]; } m.nb = sg->nb;
   bins_clear(s_bins, tid, 256u);
   __syncthreads();
-  for (uint32_t i0 = ck.begin; i0 < ck.end; i0 += 256u) {       // block-uniform trip count
-    const uint32_t i = i0 + tid; const bool v = i < ck.end;
-    PrimRef r{}; if (v) r = load_prim(src + i);
-    bins_add_wave(s_bins, m, r, v, tid & 63u);
+  {                                                             // each wave owns a contiguous quarter of the chunk (see BinRuns)
+    const uint32_t lane = tid & 63u, span = ck.begin + (tid >> 6) * (CHUNK / 4u), spanEnd = min(span + CHUNK / 4u, ck.end);
+    BinRuns runs; runs_init(runs);
+    for (uint32_t i0 = span; i0 < spanEnd; i0 += 64u) {         // wave-uniform trip count
+      const uint32_t i = i0 + lane; const bool v = i < spanEnd;
+      PrimRef r{}; if (v) r = load_prim(src + i);
+      runs_add(runs, s_bins, m, r, v);
+    }
+    runs_flush_wave(runs, s_bins, lane);
   }
   __syncthreads();
   uint32_t* g = bins + (size_t)ck.seg * BINS_WORDS;
@@ -494,8 +522,8 @@ __device__ __forceinline__ float unzlo(uint32_t u) { return dec(~u); }
 __device__ __forceinline__ uint32_t zhi(float f) { return enc(f); }           // enc(x) > 0 for every float
 __device__ __forceinline__ float unzhi(uint32_t u) { return dec(u); }
 
-// R: per-wave LDS scratch of 64 * W words (W = 28 words per triangle when min_leaf >= 2, 42 for min_leaf = 1):
-//   bins of the segment starting at lane b live at R + b * W as [axis][bin][7] (3 * nb * 7 <= n * W words for every
+// R: per-wave LDS scratch of 64 * W words (W = 32 words per triangle when min_leaf >= 2, 48 for min_leaf = 1):
+//   bins of the segment starting at lane b live at R + b * W as [axis][bin][8] (3 * nb * 8 <= n * W words for every
 //   splittable n); once the candidates are evaluated the same memory holds the split records (16 words per segment at
 //   R + b * 16) and the exchange buffer the partition moves the triangles through (10 x 64 words at R + 1024).
 __device__ void micro_subtree(uint32_t* R, uint32_t W, uint32_t (*s_cb)[64][6], unsigned long long* s_key, const PrimRef* src,
@@ -522,7 +550,7 @@ __device__ void micro_subtree(uint32_t* R, uint32_t W, uint32_t (*s_cb)[64][6], 
       nb = m.nb;
     }
     __syncthreads();                                             // everybody has read s_cb[pp] and is done with the exchange buffer
-    for (uint32_t i = 0; i < W; i++) R[i * 64u + lane] = 0u;
+    for (uint32_t i = 0; i < W / 4u; i++) ((uint4*)R)[i * 64u + lane] = make_uint4(0u, 0u, 0u, 0u);
     s_key[lane] = ~0ull;
     for (int k = 0; k < 6; k++) s_cb[pp ^ 1u][lane][k] = 0u;
     __syncthreads();
@@ -531,7 +559,7 @@ __device__ void micro_subtree(uint32_t* R, uint32_t W, uint32_t (*s_cb)[64][6], 
     if (act) {
       for (int d = 0; d < 3; d++) {
         const int b = bin_clamped(p.lo[d] + p.hi[d], ofs[d], scale[d], nb);
-        uint32_t* e = sb + ((uint32_t)d * nb + (uint32_t)b) * 7u;
+        uint32_t* e = sb + ((uint32_t)d * nb + (uint32_t)b) * 8u;     // 8-word entries: lo.xyz hi.xyz count pad (two 16-byte reads)
         atomicMax(&e[0], zlo(p.lo[0])); atomicMax(&e[1], zlo(p.lo[1])); atomicMax(&e[2], zlo(p.lo[2]));
         atomicMax(&e[3], zhi(p.hi[0])); atomicMax(&e[4], zhi(p.hi[1])); atomicMax(&e[5], zhi(p.hi[2]));
         atomicAdd(&e[6], 1u);
@@ -542,7 +570,42 @@ __device__ void micro_subtree(uint32_t* R, uint32_t W, uint32_t (*s_cb)[64][6], 
     //      candidate c = axis * (nb - 1) + (pos - 1), so the minimum of (sah, c) is the reference's choice
     float bestSah = __builtin_inff(); uint32_t bestC = NIL, bestNL = 0;
     float bl[3] = {0, 0, 0}, bh[3] = {0, 0, 0}, rl[3] = {0, 0, 0}, rh[3] = {0, 0, 0};
-    if (act) {
+    if (act && nb == 4u) {
+      // the common case (n < 20): lane j of the segment sweeps axis j once -- suffix bounds S1..S3, then a running prefix; 4 bins are read
+      // once (8 x 16 bytes) instead of once per candidate
+      for (uint32_t axis = lane - segB; axis < 3u; axis += n) {
+        if (sel3(axis, scale[0], scale[1], scale[2]) == 0.0f) continue;          // mapping.invalid(dim) :375
+        const uint4* e = (const uint4*)(sb + axis * 32u);
+        float lo[4][3], hi[4][3]; uint32_t cn[4];
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+          const uint4 x = e[2 * b], y = e[2 * b + 1];
+          cn[b] = y.z;
+          const bool any = cn[b] != 0u;
+          lo[b][0] = any ? unzlo(x.x) : __builtin_inff(); lo[b][1] = any ? unzlo(x.y) : __builtin_inff(); lo[b][2] = any ? unzlo(x.z) : __builtin_inff();
+          hi[b][0] = any ? unzhi(x.w) : -__builtin_inff(); hi[b][1] = any ? unzhi(y.x) : -__builtin_inff(); hi[b][2] = any ? unzhi(y.y) : -__builtin_inff();
+        }
+        float slo[4][3], shi[4][3]; uint32_t sn[4];                            // suffix: bins pos..3
+        for (int d = 0; d < 3; d++) { slo[3][d] = lo[3][d]; shi[3][d] = hi[3][d]; } sn[3] = cn[3];
+#pragma unroll
+        for (int b = 2; b >= 1; b--) { for (int d = 0; d < 3; d++) { slo[b][d] = fminf(lo[b][d], slo[b + 1][d]); shi[b][d] = fmaxf(hi[b][d], shi[b + 1][d]); } sn[b] = cn[b] + sn[b + 1]; }
+        float llo[3] = {lo[0][0], lo[0][1], lo[0][2]}, lhi[3] = {hi[0][0], hi[0][1], hi[0][2]}; uint32_t lN = cn[0];
+#pragma unroll
+        for (int pos = 1; pos < 4; pos++) {
+          if (lN != 0u && sn[pos] != 0u) {
+            const float lA = half_area3(lhi[0] - llo[0], lhi[1] - llo[1], lhi[2] - llo[2]);
+            const float rA = half_area3(shi[pos][0] - slo[pos][0], shi[pos][1] - slo[pos][1], shi[pos][2] - slo[pos][2]);
+            const float sah = fmaf(lA, (float)((lN + addBlk) >> prm.shift), rA * (float)((sn[pos] + addBlk) >> prm.shift));
+            if (sah < bestSah) {
+              bestSah = sah; bestC = axis * 3u + (uint32_t)(pos - 1); bestNL = lN;
+              for (int d = 0; d < 3; d++) { bl[d] = llo[d]; bh[d] = lhi[d]; rl[d] = slo[pos][d]; rh[d] = shi[pos][d]; }
+            }
+          }
+          for (int d = 0; d < 3; d++) { llo[d] = fminf(llo[d], lo[pos][d]); lhi[d] = fmaxf(lhi[d], hi[pos][d]); }
+          lN += cn[pos];
+        }
+      }
+    } else if (act) {
       const uint32_t nb1 = nb - 1u, ncand = 3u * nb1;
       for (uint32_t c = lane - segB; c < ncand; c += n) {
         const uint32_t axis = (c >= nb1 ? 1u : 0u) + (c >= 2u * nb1 ? 1u : 0u), pos = c - axis * nb1 + 1u;
@@ -551,7 +614,7 @@ __device__ void micro_subtree(uint32_t* R, uint32_t W, uint32_t (*s_cb)[64][6], 
         float rlo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, rhi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
         uint32_t lN = 0, rN = 0;
         for (uint32_t b = 0; b < nb; b++) {
-          const uint32_t* e = sb + (axis * nb + b) * 7u;
+          const uint32_t* e = sb + (axis * nb + b) * 8u;
           const uint32_t cnt = e[6];
           if (cnt == 0u) continue;
           if (b < pos) { lN += cnt; for (int d = 0; d < 3; d++) { llo[d] = fminf(llo[d], unzlo(e[d])); lhi[d] = fmaxf(lhi[d], unzhi(e[3 + d])); } }
@@ -642,7 +705,7 @@ __device__ void micro_subtree(uint32_t* R, uint32_t W, uint32_t (*s_cb)[64][6], 
 
 __global__ __launch_bounds__(64) void small_build(const SmallEntry* entries, PrimRef* bufA, PrimRef* bufB, BNode* bnodes,
                                                   uint2* finalIds, Counters* ctr, Params prm, uint32_t W) {
-  extern __shared__ uint32_t s_R[];                            // max(BINS_WORDS, 64 * W) words: bins / micro scratch
+  extern __shared__ __attribute__((aligned(16))) uint32_t s_R[];   // max(BINS_WORDS, 64 * W) words: bins / micro scratch
   __shared__ SplitResult s_res;
   __shared__ uint32_t s_acc[2][12];
   __shared__ StackEntry s_stack[24];
@@ -669,10 +732,14 @@ __global__ __launch_bounds__(64) void small_build(const SmallEntry* entries, Pri
     bins_clear(s_bins, lane, 64u);
     if (lane < 24) s_acc[lane / 12][lane % 12] = (lane % 6 < 3) ? ENC_POS_INF : ENC_NEG_INF;
     __syncthreads();
-    for (uint32_t i0 = 0; i0 < n; i0 += 64u) {
-      const bool v = i0 + lane < n;
-      PrimRef r{}; if (v) r = load_prim(src + cur.begin + i0 + lane);
-      bins_add_wave(s_bins, m, r, v, lane);
+    {
+      BinRuns runs; runs_init(runs);
+      for (uint32_t i0 = 0; i0 < n; i0 += 64u) {
+        const bool v = i0 + lane < n;
+        PrimRef r{}; if (v) r = load_prim(src + cur.begin + i0 + lane);
+        runs_add(runs, s_bins, m, r, v);
+      }
+      runs_flush_wave(runs, s_bins, lane);
     }
     __syncthreads();
     sah_best_wave(s_bins, m, prm.shift, &s_res, lane);
@@ -1157,7 +1224,7 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
   if (numSmall > maxSmall) return set_error(hipErrorOutOfMemory, "small list overflow");
 
   // ---- small phase
-  const uint32_t microW = prm.minLeaf >= 2u ? 28u : 42u;       // LDS words per triangle of the micro mode (see micro_subtree)
+  const uint32_t microW = prm.minLeaf >= 2u ? 32u : 48u;       // LDS words per triangle of the micro mode (see micro_subtree)
   const size_t smallLds = sizeof(uint32_t) * (64u * microW > (uint32_t)BINS_WORDS ? 64u * microW : (uint32_t)BINS_WORDS);
   if (numSmall) hipLaunchKernelGGL(small_build, dim3(numSmall), dim3(64), smallLds, st, small.p, bufA.p, bufB.p, bnodes.p, finalIds.p, ctr.p, prm, microW);
   HIP_TRY(hipGetLastError());
