@@ -42,7 +42,11 @@ constexpr uint32_t NIL = 0xFFFFFFFFu;
 constexpr int NBINS = 32;                       // NUM_OBJECT_BINS, kernels/builders/bvh_builder_sah.h:10
 constexpr int BINW = 7;                         // lo.xyz, hi.xyz (ordered uint), count
 constexpr int BINS_WORDS = 3 * NBINS * BINW;    // 672 words = 2688 B per segment
-constexpr uint32_t CHUNK = 2048;                // triangles per top-phase workgroup
+#ifndef MI355_CHUNK
+#define MI355_CHUNK 2048
+#endif
+constexpr uint32_t CHUNK = MI355_CHUNK;         // triangles per top-phase workgroup
+constexpr int CHUNK_ROUNDS = CHUNK / 256;       // triangles per thread of top_partition
 constexpr uint32_t ENC_POS_INF = 0xFF800000u;   // enc(+inf)
 constexpr uint32_t ENC_NEG_INF = 0x007FFFFFu;   // enc(-inf)
 
@@ -409,7 +413,7 @@ __global__ __launch_bounds__(64) void top_split(Seg* segs, const uint32_t* bins,
 }
 
 __global__ __launch_bounds__(256) void top_partition(Seg* segs, const Chunk* chunks, const PrimRef* src, PrimRef* dst, const Counters* ctr) {
-  __shared__ uint32_t s_cnt[8][4][2], s_off[8][4][2], s_acc[2][12], s_baseL, s_baseR;
+  __shared__ uint32_t s_cnt[CHUNK_ROUNDS][4][2], s_off[CHUNK_ROUNDS][4][2], s_acc[2][12], s_baseL, s_baseR;
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   if (blockIdx.x >= ctr->numChunks) return;
   const Chunk ck = chunks[blockIdx.x];
@@ -419,10 +423,10 @@ __global__ __launch_bounds__(256) void top_partition(Seg* segs, const Chunk* chu
   const float ofs = sg->ofs[dim], scale = sg->scale[dim];
   if (tid < 24) s_acc[tid / 12][tid % 12] = (tid % 6 < 3) ? ENC_POS_INF : ENC_NEG_INF;
   __syncthreads();
-  PrimRef pr[8]; uint32_t sideBits = 0, validBits = 0; unsigned long long lm[8], rm[8];
+  PrimRef pr[CHUNK_ROUNDS]; uint32_t sideBits = 0, validBits = 0; unsigned long long lm[CHUNK_ROUNDS], rm[CHUNK_ROUNDS];
   uint32_t aL[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u}, aR[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
 #pragma unroll
-  for (int r = 0; r < 8; r++) {
+  for (int r = 0; r < CHUNK_ROUNDS; r++) {
     const uint32_t i = ck.begin + (uint32_t)r * 256u + tid;
     const bool v = i < ck.end;
     if (v) pr[r] = load_prim(src + i);
@@ -449,13 +453,13 @@ __global__ __launch_bounds__(256) void top_partition(Seg* segs, const Chunk* chu
   __syncthreads();
   if (tid == 0) {
     uint32_t l = 0, rr = 0;
-    for (int r = 0; r < 8; r++) for (int w = 0; w < 4; w++) { s_off[r][w][0] = l; s_off[r][w][1] = rr; l += s_cnt[r][w][0]; rr += s_cnt[r][w][1]; }
+    for (int r = 0; r < CHUNK_ROUNDS; r++) for (int w = 0; w < 4; w++) { s_off[r][w][0] = l; s_off[r][w][1] = rr; l += s_cnt[r][w][0]; rr += s_cnt[r][w][1]; }
     s_baseL = l ? atomicAdd(&sg->curL, l) : 0u; s_baseR = rr ? atomicAdd(&sg->curR, rr) : 0u;
   }
   __syncthreads();
   const unsigned long long lt = (1ull << lane) - 1ull;
 #pragma unroll
-  for (int r = 0; r < 8; r++) {
+  for (int r = 0; r < CHUNK_ROUNDS; r++) {
     if (!(validBits & (1u << r))) continue;
     const bool left = (sideBits >> r) & 1u;
     const uint32_t o = left ? s_baseL + s_off[r][wave][0] + (uint32_t)__popcll(lm[r] & lt)
