@@ -216,14 +216,66 @@ __device__ __forceinline__ uint32_t wave_uadd63(uint32_t v) {
   return v;
 }
 
-// BinInfoT::bin (heuristic_binning.h:210-257) with run merging in front of the bins.  A lane sees triangles i, i + 64, i + 128, ... of a contiguous span; in mesh order those fall
-// into the same bin again and again, so every lane keeps, per axis, the bin it is currently in with the merged bounds and the
-// count of that run (24 registers) and only touches the LDS bins when the bin changes.  What is left at the end of the span is
-// folded across the wave (DPP reductions of the lanes that share a bin) before the last atomics.  The earlier version reduced
-// every batch of 64 triangles across the wave: ~600 VALU instructions per batch; this one needs ~100.
-struct BinRuns { int b[3]; uint32_t lo[3][3], hi[3][3], n[3]; };
+// BinInfoT::bin (heuristic_binning.h:210-257) with run merging in front of the bins.  Same-word LDS atomics are what the binning
+// kernels wait for (PMC: SQ_WAIT_INST_LDS = 73 % of top_bin's wave cycles with one atomic per triangle, profiles/r01_build_history.md).
+// A batch of 64 consecutive triangles of a mesh almost always falls into ONE bin per axis, so the wave keeps a current bin per axis
+// (uniform) and every lane a private partial (bounds + count) of it in registers; only when the wave's bin changes, or at the end
+// of the span, the partials are folded across the wave with DPP and lane 63 issues the run's 7 atomics.  Lanes of a batch that
+// straddles bins and are not in the wave's bin go to the LDS bins directly.
+struct BinRuns { int b[3]; uint32_t lo[3][3], hi[3][3], n[3]; };   // b: the WAVE's current bin per axis (uniform); the rest: this lane's partial of that bin
 __device__ __forceinline__ void runs_init(BinRuns& r) { for (int d = 0; d < 3; d++) { r.b[d] = -1; r.n[d] = 0u; for (int k = 0; k < 3; k++) { r.lo[d][k] = 0xFFFFFFFFu; r.hi[d][k] = 0u; } } }
-__device__ __forceinline__ void runs_add(BinRuns& r, uint32_t* bins, const Mapping& m, const PrimRef& p, bool valid) {
+// fold the lanes' partials of axis d across the wave (DPP), lane 63 issues the 7 atomics of the run
+__device__ __forceinline__ void runs_flush_axis(BinRuns& r, int d, uint32_t* bins, uint32_t lane) {
+  if (r.b[d] >= 0) {                                            // wave-uniform
+    uint32_t v[6];
+    for (int k = 0; k < 3; k++) { v[k] = wave_umin63(r.lo[d][k]); v[3 + k] = wave_umax63(r.hi[d][k]); }
+    const uint32_t cnt = wave_uadd63(r.n[d]);
+    if (lane == 63u && cnt) {
+      uint32_t* e = bins + (d * NBINS + r.b[d]) * BINW;
+      atomicMin(&e[0], v[0]); atomicMin(&e[1], v[1]); atomicMin(&e[2], v[2]);
+      atomicMax(&e[3], v[3]); atomicMax(&e[4], v[4]); atomicMax(&e[5], v[5]);
+      atomicAdd(&e[6], cnt);
+    }
+  }
+  r.n[d] = 0u; for (int k = 0; k < 3; k++) { r.lo[d][k] = 0xFFFFFFFFu; r.hi[d][k] = 0u; }
+}
+// every lane of the wave calls it with its triangle of the batch (valid = holds one)
+__device__ __forceinline__ void runs_add(BinRuns& r, uint32_t* bins, const Mapping& m, const PrimRef& p, bool valid, uint32_t lane) {
+  const unsigned long long vm = __ballot(valid);
+  if (vm == 0ull) return;
+  const int first = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(vm));
+  uint32_t c[6];
+  for (int k = 0; k < 3; k++) { c[k] = enc(p.lo[k]); c[3 + k] = enc(p.hi[k]); }
+#pragma unroll
+  for (int d = 0; d < 3; d++) {
+    const int b = valid ? bin_clamped(p.lo[d] + p.hi[d], m.ofs[d], m.scale[d], m.nb) : -1;
+    const int b0 = __builtin_amdgcn_readlane(b, first);
+    const bool uniform = __ballot(valid && b == b0) == vm;      // the usual case: 64 consecutive triangles, one bin
+    if (uniform && b0 != r.b[d]) { runs_flush_axis(r, d, bins, lane); r.b[d] = b0; }
+    if (valid) {
+      if (b == r.b[d]) {                                        // into my partial of the wave's bin: registers only
+        r.n[d]++;
+        for (int k = 0; k < 3; k++) { r.lo[d][k] = min(r.lo[d][k], c[k]); r.hi[d][k] = max(r.hi[d][k], c[3 + k]); }
+      } else {                                                  // the batch straddles bins: this lane goes to the LDS bins directly
+        uint32_t* e = bins + (d * NBINS + b) * BINW;
+        atomicMin(&e[0], c[0]); atomicMin(&e[1], c[1]); atomicMin(&e[2], c[2]);
+        atomicMax(&e[3], c[3]); atomicMax(&e[4], c[4]); atomicMax(&e[5], c[5]);
+        atomicAdd(&e[6], 1u);
+      }
+    }
+  }
+}
+__device__ __forceinline__ void runs_flush_wave(BinRuns& r, uint32_t* bins, uint32_t lane) {
+  for (int d = 0; d < 3; d++) runs_flush_axis(r, d, bins, lane);
+}
+
+// Lane-private variant for top_bin: a lane sees triangles i, i + 64, ... of its wave's span and keeps its OWN current bin per axis; a run
+// ends with 7 LDS atomics of that lane, what is pending at the end of the span is folded across the wave.  Measured on the full-size
+// passes of top_bin: 110 us against 129 us for the wave-uniform runs above (batches straddling a bin boundary send most lanes to the LDS
+// bins there), while the wave-uniform runs are the faster ones inside small_build (2.65 against 2.85 ms).
+struct LaneRuns { int b[3]; uint32_t lo[3][3], hi[3][3], n[3]; };
+__device__ __forceinline__ void lane_runs_init(LaneRuns& r) { for (int d = 0; d < 3; d++) { r.b[d] = -1; r.n[d] = 0u; for (int k = 0; k < 3; k++) { r.lo[d][k] = 0xFFFFFFFFu; r.hi[d][k] = 0u; } } }
+__device__ __forceinline__ void lane_runs_add(LaneRuns& r, uint32_t* bins, const Mapping& m, const PrimRef& p, bool valid) {
   if (!valid) return;
   uint32_t c[6];
   for (int k = 0; k < 3; k++) { c[k] = enc(p.lo[k]); c[3 + k] = enc(p.hi[k]); }
@@ -246,7 +298,7 @@ __device__ __forceinline__ void runs_add(BinRuns& r, uint32_t* bins, const Mappi
   }
 }
 // every lane of the wave calls it: the pending runs of the lanes that share a bin are reduced in registers, lane 63 issues the atomics
-__device__ __forceinline__ void runs_flush_wave(BinRuns& r, uint32_t* bins, uint32_t lane) {
+__device__ __forceinline__ void lane_runs_flush_wave(LaneRuns& r, uint32_t* bins, uint32_t lane) {
 #pragma unroll
   for (int d = 0; d < 3; d++) {
     int b = r.n[d] ? r.b[d] : -1;
@@ -367,13 +419,13 @@ __global__ __launch_bounds__(256) void top_bin(const Seg* segs, const Chunk* chu
   __syncthreads();
   {                                                             // each wave owns a contiguous quarter of the chunk (see BinRuns)
     const uint32_t lane = tid & 63u, span = ck.begin + (tid >> 6) * (CHUNK / 4u), spanEnd = min(span + CHUNK / 4u, ck.end);
-    BinRuns runs; runs_init(runs);
+    LaneRuns runs; lane_runs_init(runs);
     for (uint32_t i0 = span; i0 < spanEnd; i0 += 64u) {         // wave-uniform trip count
       const uint32_t i = i0 + lane; const bool v = i < spanEnd;
       PrimRef r{}; if (v) r = load_prim(src + i);
-      runs_add(runs, s_bins, m, r, v);
+      lane_runs_add(runs, s_bins, m, r, v);
     }
-    runs_flush_wave(runs, s_bins, lane);
+    lane_runs_flush_wave(runs, s_bins, lane);
   }
   __syncthreads();
   uint32_t* g = bins + (size_t)ck.seg * BINS_WORDS;
@@ -741,7 +793,7 @@ __global__ __launch_bounds__(64) void small_build(const SmallEntry* entries, Pri
       for (uint32_t i0 = 0; i0 < n; i0 += 64u) {
         const bool v = i0 + lane < n;
         PrimRef r{}; if (v) r = load_prim(src + cur.begin + i0 + lane);
-        runs_add(runs, s_bins, m, r, v);
+        runs_add(runs, s_bins, m, r, v, lane);
       }
       runs_flush_wave(runs, s_bins, lane);
     }
