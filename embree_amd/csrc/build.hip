@@ -32,6 +32,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <map>
+#include <mutex>
 #include <vector>
 #include "bvh_common.h"
 #include "internal.h"
@@ -1129,10 +1131,38 @@ __global__ __launch_bounds__(256) void tri_records(const uint2* finalIds, uint32
   o[2] = make_float4(c[2] - a[2], __uint_as_float(id.y), __uint_as_float(g.geomID), __uint_as_float(g.mask));
 }
 
+// Build scratch comes from a per-device arena that survives the commit: rtcCommitScene is timed on the wall clock
+// (tutorials/buildbench/buildbench_device.cpp:385-387) and ~20 hipMalloc/hipFree pairs cost 3 ms of a 10.7 ms commit of 4.76 M
+// triangles.  Blocks are kept until mi355_release_build_scratch(); commits on one device are serialised by the arena's mutex
+// (the reference's rtcCommitScene is blocking as well and runs on its own worker pool).
+struct Arena {
+  struct Block { char* p; size_t cap, used; };
+  std::mutex mtx;
+  std::vector<Block> blocks;
+  void reset() { for (auto& b : blocks) b.used = 0; }
+  hipError_t take(size_t bytes, void** out) {
+    bytes = (bytes + 255) & ~(size_t)255;
+    for (auto& b : blocks) if (b.cap - b.used >= bytes) { *out = b.p + b.used; b.used += bytes; return hipSuccess; }
+    Block nb; nb.cap = bytes > ((size_t)64 << 20) ? bytes : ((size_t)64 << 20); nb.used = bytes; nb.p = nullptr;
+    const hipError_t e = hipMalloc((void**)&nb.p, nb.cap);
+    if (e != hipSuccess) return e;
+    blocks.push_back(nb); *out = nb.p; return hipSuccess;
+  }
+  void release() { for (auto& b : blocks) hipFree(b.p); blocks.clear(); }
+};
+static std::mutex g_arenaMtx;
+static std::map<int, Arena*> g_arenas;
+static Arena* arena_of(int device) {
+  std::lock_guard<std::mutex> lk(g_arenaMtx);
+  Arena*& a = g_arenas[device];
+  if (!a) a = new Arena;
+  return a;
+}
+static thread_local Arena* t_arena = nullptr;
+
 template <typename T> struct DevBuf {
   T* p = nullptr;
-  ~DevBuf() { if (p) hipFree(p); }
-  hipError_t alloc(size_t n) { return hipMalloc((void**)&p, (n ? n : 1) * sizeof(T)); }
+  hipError_t alloc(size_t n) { return t_arena->take((n ? n : 1) * sizeof(T), (void**)&p); }
 };
 
 }  // namespace
@@ -1164,8 +1194,15 @@ Bvh::~Bvh() {
 
 static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, const mi355_build_params* bp, hipStream_t st, Bvh** out) {
   HIP_TRY(hipSetDevice(device));
-  hipDeviceProp_t prop; HIP_TRY(hipGetDeviceProperties(&prop, device));
-  Bvh* bvh = new Bvh; bvh->device = device; bvh->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  Arena* arena = arena_of(device);
+  std::lock_guard<std::mutex> arenaLock(arena->mtx);
+  arena->reset(); t_arena = arena;
+  static std::mutex propMtx; static std::map<int, int> cuCount;
+  int numCUs;
+  { std::lock_guard<std::mutex> lk(propMtx); auto it = cuCount.find(device);
+    if (it == cuCount.end()) { hipDeviceProp_t prop; HIP_TRY(hipGetDeviceProperties(&prop, device)); it = cuCount.emplace(device, prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256).first; }
+    numCUs = it->second; }
+  Bvh* bvh = new Bvh; bvh->device = device; bvh->numCUs = numCUs;
   struct Guard { Bvh*& b; bool ok = false; ~Guard() { if (!ok) { delete b; b = nullptr; } } } guard{bvh};
 
   Params prm; prm.shift = bp->sah_block_shift; prm.minLeaf = bp->min_leaf ? bp->min_leaf : 1u;
@@ -1351,6 +1388,11 @@ int mi355_bvh_build(int device, const mi355_mesh* meshes, uint32_t num_meshes, c
   *out = (mi355_bvh_t)b; return rc;
 }
 void mi355_bvh_destroy(mi355_bvh_t bvh) { delete (mi355::Bvh*)bvh; }
+void mi355_release_build_scratch(int device) {
+  Arena* a = arena_of(device);
+  std::lock_guard<std::mutex> lk(a->mtx);
+  hipSetDevice(device); a->release();
+}
 int mi355_bvh_get_info(mi355_bvh_t bvh, mi355_bvh_info* info) { *info = ((mi355::Bvh*)bvh)->info; return 0; }
 int mi355_bvh_download(mi355_bvh_t bvh, void* nodes, size_t nb, void* tris, size_t tb) {
   mi355::Bvh* b = (mi355::Bvh*)bvh; HIP_TRY(hipSetDevice(b->device));

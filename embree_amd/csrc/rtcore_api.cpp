@@ -53,6 +53,7 @@ struct Device : RefCounted {
   std::string name;
   static size_t threadToken() { static thread_local char t; return (size_t)&t; }
   ErrState& err() { std::lock_guard<std::mutex> lk(errMutex); return errors[threadToken()]; }
+  ~Device() override { mi355_release_build_scratch(gpu); }   // the build arena of this GPU goes back to the driver with the last user
 };
 
 void process_error(Device* dev, RTCError code, const char* str) {     // Device::process_error, device.cpp:312-330

@@ -12,7 +12,7 @@ powerplant.ecs drop into bench.py and the tests when they are available ($EMBREE
                         (tutorials/common/scenegraph/obj_loader.cpp); one mesh, or one per 'usemtl'/'g'/'o' group with split_groups=True
   save_xml(path, meshes, camera)   writer for the XML + .bin pair (tests, and to hand a generated scene to the reference's viewer)
 
-meshes = [(verts float32 [nv,3], tris uint32 [nt,3]), ...] -- what embree_amd.api.make_scene and the oracle take.
+meshes = [(verts float32 [nv,3], tris uint32 [nt,3]), ...] -- what embree_amd.api.make_scene takes.
 """
 import os
 import xml.etree.ElementTree as ET

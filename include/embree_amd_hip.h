@@ -73,6 +73,8 @@ MI355_API int mi355_device_name(int device, char* out, size_t n);
 MI355_API int mi355_bvh_build(int device, const mi355_mesh* meshes, uint32_t num_meshes,
                               const mi355_build_params* params, void* stream, mi355_bvh_t* out);
 MI355_API void mi355_bvh_destroy(mi355_bvh_t bvh);
+/* Build scratch (prim refs, binary tree, work lists) is kept per device between commits; this returns it to the driver. */
+MI355_API void mi355_release_build_scratch(int device);
 MI355_API int mi355_bvh_get_info(mi355_bvh_t bvh, mi355_bvh_info* info);
 /* Copies the tree to host memory for validation (tests): nodes = num_nodes*80 B, tris = num_triangles*48 B. */
 MI355_API int mi355_bvh_download(mi355_bvh_t bvh, void* nodes, size_t nodes_bytes, void* tris, size_t tris_bytes);

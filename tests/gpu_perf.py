@@ -21,13 +21,14 @@ ap.add_argument("--phi", type=int, default=158)
 ap.add_argument("--reps", type=int, default=10)
 ap.add_argument("--any", action="store_true")
 ap.add_argument("--robust", action="store_true", help="RTC_SCENE_FLAG_ROBUST scene")
+ap.add_argument("--powerplant", action="store_true", help="configs[4]: the 12.7 M triangle powerplant stand-in instead of the crown stand-in")
 ap.add_argument("--primary", action="store_true")
 ap.add_argument("--tag", default="")
 ap.add_argument("--retrace", action="store_true", help="trace once, then time the same rays with tfar preset to the hit distance (perfect-culling bound)")
 a = ap.parse_args()
 L = api.load()
 dev = api.Device(a.config)
-meshes = W.synthetic_crown(num_phi=a.phi)
+meshes = W.synthetic_powerplant() if a.powerplant else W.synthetic_crown(num_phi=a.phi)
 s = api.Scene(dev, api.RTC_SCENE_FLAG_ROBUST if a.robust else 0)
 for v, t in meshes:
     s.add_triangle_mesh(v, t, device_resident=True)
