@@ -21,6 +21,7 @@ RTC_GEOMETRY_TYPE_TRIANGLE, RTC_GEOMETRY_TYPE_QUAD = 0, 1
 RTC_BUFFER_TYPE_INDEX, RTC_BUFFER_TYPE_VERTEX, RTC_BUFFER_TYPE_VERTEX_ATTRIBUTE = 0, 1, 2
 RTC_FORMAT_UINT3, RTC_FORMAT_FLOAT3 = 0x5003, 0x9003
 RTC_SCENE_FLAG_ROBUST = 4
+RTC_BUILD_QUALITY_LOW, RTC_BUILD_QUALITY_MEDIUM, RTC_BUILD_QUALITY_HIGH = 0, 1, 2
 
 # every symbol include/embree4/rtcore.h and include/embree_amd_hip.h declare (checked by tests/test_abi.py)
 RTC_SYMBOLS = """rtcNewDevice rtcRetainDevice rtcReleaseDevice rtcGetDeviceProperty rtcSetDeviceProperty rtcGetErrorString
@@ -48,7 +49,7 @@ mi355_stream_destroy mi355_event_create mi355_event_record mi355_event_elapsed_m
 class BuildParams(C.Structure):
     _fields_ = [("sah_block_shift", C.c_uint32), ("min_leaf", C.c_uint32), ("max_leaf", C.c_uint32),
                 ("small_threshold", C.c_uint32), ("trav_cost", C.c_float), ("int_cost", C.c_float),
-                ("robust", C.c_uint32), ("reserved", C.c_uint32)]
+                ("robust", C.c_uint32), ("quality", C.c_uint32)]
 
 
 class BvhInfo(C.Structure):
@@ -251,12 +252,14 @@ class DeviceArray:
 class Scene:
     """rtcNewScene + helpers that follow the tutorials' idiom (attach, release, commit)."""
 
-    def __init__(self, device, flags=0):
+    def __init__(self, device, flags=0, quality=None):
         self.dev, self.L = device, device.L
         self.h = self.L.rtcNewScene(device.h)
         device.check()
         if flags:
             self.L.rtcSetSceneFlags(self.h, flags)
+        if quality is not None:
+            self.L.rtcSetSceneBuildQuality(self.h, quality)
         self._keep = []
 
     def add_triangle_mesh(self, verts, tris, mask=None, shared=True, device_resident=False):
@@ -367,8 +370,8 @@ class Scene:
             self._keep = []
 
 
-def make_scene(device, meshes, masks=None, flags=0, **kw):
-    s = Scene(device, flags)
+def make_scene(device, meshes, masks=None, flags=0, quality=None, **kw):
+    s = Scene(device, flags, quality)
     for i, (v, t) in enumerate(meshes):
         s.add_triangle_mesh(v, t, None if masks is None else masks[i], **kw)
     s.commit()

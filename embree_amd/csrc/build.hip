@@ -27,6 +27,7 @@
 // (heuristic_binning_array_aligned.h:178-182).  The tree need not equal the reference's tree:
 // t/u/v/Ng/IDs of a closest hit do not depend on tree shape.
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>     // DeviceRadixSort for the Morton build (a plain library sort; everything else here is hand-written)
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -74,7 +75,7 @@ struct Counters {
   uint32_t numSegs, topLevels, wideDepth, lvlNodeBase, lvlTriBase, wideCount[2];      // level loops are driven from the device: no host readback per level
   unsigned long long sahFixed;                    // SAH statistics, 2^-24 fixed point (order-independent sum)
 };
-struct Params { uint32_t shift, minLeaf, maxLeaf, small; float travCost, intCost; };
+struct Params { uint32_t shift, minLeaf, maxLeaf, small; float travCost, intCost; uint32_t quality; };
 
 // order-preserving float <-> uint so that integer atomicMin/Max reduce floats exactly
 __device__ __forceinline__ uint32_t enc(float f) { uint32_t u = __float_as_uint(f); return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u); }
@@ -869,6 +870,102 @@ __global__ __launch_bounds__(64) void small_build(const SmallEntry* entries, Pri
   }
 }
 
+// ---------------------------------------------------------------------------- fast build (RTC_BUILD_QUALITY_LOW)
+// The reference answers RTC_BUILD_QUALITY_LOW with its Morton builder (kernels/builders/bvh_builder_morton.h:  63-bit codes of the
+// centroids, radix sort, recursive splits at the highest differing bit; selected per mesh by the two-level builder, kernels/bvh/
+// bvh_builder_twolevel.cpp, kernels/common/scene.cpp:195-206).  The GPU formulation of the same tree: sort the 63-bit codes, then
+// every internal node finds its own range and split from the codes alone (Karras 2012: the split of a range is where the common
+// prefix of the codes is shortest; ties between equal codes are broken by the index), and the boxes are propagated from the leaves
+// with one atomic flag per node.  The result is a binary tree in the BNode format, so the wide collapse, quantisation and leaf
+// layout are the ones of the SAH build; only the decisions differ.  Leaf j is BNode (n-1)+j, internal node i is BNode i, root = 0.
+__device__ __forceinline__ unsigned long long spread21(uint32_t v) {   // 21 bits -> every third bit
+  unsigned long long x = v & 0x1FFFFFull;
+  x = (x | x << 32) & 0x1F00000000FFFFull; x = (x | x << 16) & 0x1F0000FF0000FFull; x = (x | x << 8) & 0x100F00F00F00F00Full;
+  x = (x | x << 4) & 0x10C30C30C30C30C3ull; x = (x | x << 2) & 0x1249249249249249ull;
+  return x;
+}
+__global__ __launch_bounds__(256) void morton_keys(const PrimRef* prims, uint32_t n, float3 cmin, float3 cscale, unsigned long long* keys, uint32_t* vals) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  const PrimRef p = load_prim(prims + i);
+  const float fx = ((p.lo[0] + p.hi[0]) - cmin.x) * cscale.x, fy = ((p.lo[1] + p.hi[1]) - cmin.y) * cscale.y, fz = ((p.lo[2] + p.hi[2]) - cmin.z) * cscale.z;
+  const uint32_t ix = (uint32_t)fminf(fmaxf(fx, 0.0f), 2097151.0f), iy = (uint32_t)fminf(fmaxf(fy, 0.0f), 2097151.0f), iz = (uint32_t)fminf(fmaxf(fz, 0.0f), 2097151.0f);
+  keys[i] = spread21(ix) | (spread21(iy) << 1) | (spread21(iz) << 2);
+  vals[i] = i;
+}
+__global__ __launch_bounds__(256) void morton_gather(const PrimRef* src, const uint32_t* order, uint32_t n, PrimRef* dst, uint2* finalIds) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  const PrimRef p = load_prim(src + order[i]);
+  store_prim(dst + i, p);
+  finalIds[i] = make_uint2(p.geom, p.prim);
+}
+// length of the common prefix of the (code, index) pairs i and j; -1 outside the array
+__device__ __forceinline__ int lbvh_delta(const unsigned long long* keys, int n, int i, int j) {
+  if (j < 0 || j >= n) return -1;
+  const unsigned long long a = keys[i], b = keys[j];
+  return a != b ? __clzll((long long)(a ^ b)) : 64 + __clz(i ^ j);
+}
+__global__ __launch_bounds__(256) void lbvh_hierarchy(const unsigned long long* keys, uint32_t n, BNode* bnodes, uint32_t* parent) {
+  const int i = (int)(blockIdx.x * 256u + threadIdx.x), N = (int)n;
+  if (i >= N - 1) return;
+  const int d = lbvh_delta(keys, N, i, i + 1) - lbvh_delta(keys, N, i, i - 1) >= 0 ? 1 : -1;
+  const int dmin = lbvh_delta(keys, N, i, i - d);
+  int lmax = 2;
+  while (lbvh_delta(keys, N, i, i + lmax * d) > dmin) lmax <<= 1;
+  int l = 0;
+  for (int t = lmax >> 1; t >= 1; t >>= 1) if (lbvh_delta(keys, N, i, i + (l + t) * d) > dmin) l += t;
+  const int j = i + l * d;
+  const int dnode = lbvh_delta(keys, N, i, j);
+  int sft = 0;
+  for (int t = (l + 1) >> 1; ; t = (t + 1) >> 1) { if (lbvh_delta(keys, N, i, i + (sft + t) * d) > dnode) sft += t; if (t == 1) break; }
+  const int gamma = i + sft * d + min(d, 0);
+  const int first = min(i, j), last = max(i, j);
+  const uint32_t left = gamma == first ? (uint32_t)(N - 1 + gamma) : (uint32_t)gamma;
+  const uint32_t right = gamma + 1 == last ? (uint32_t)(N - 1 + gamma + 1) : (uint32_t)(gamma + 1);
+  ((uint4*)(bnodes + i))[2] = make_uint4(left, right, __float_as_uint(__builtin_inff()), 0u);   // splitSah = inf: <= max_leaf triangles always form a leaf slot
+  ((uint32_t*)(bnodes + i))[3] = (uint32_t)first; ((uint32_t*)(bnodes + i))[7] = (uint32_t)last + 1u;
+  parent[left] = (uint32_t)i; parent[right] = (uint32_t)i;
+}
+// Boxes from the leaves up: the second child to arrive at a node (atomic flag) merges the two child boxes and goes on.  The
+// two children are usually processed by different CUs, often on different XCDs, whose L2s are not coherent with each other: the
+// boxes are therefore written and read with system-scope (sc0 sc1) 16-byte accesses, which go through to memory, and a store is made to
+// complete (s_waitcnt vmcnt(0)) before the flag is touched -- the "sc0 sc1 on both sides" hand-off of MI355X_MICROARCH.md; a
+// __threadfence() per step would write back the whole L2 each time (microseconds) and a plain load may return a stale line.
+typedef float v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st16_sys(void* p, v4f v) { asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory"); }
+// the two 16-byte halves (lo|begin, hi|end) of two BNodes, system scope, one wait for the four loads
+__device__ __forceinline__ void ld_boxes_sys(const BNode* x, const BNode* y, v4f& xl, v4f& xh, v4f& yl, v4f& yh) {
+  asm volatile("global_load_dwordx4 %0, %4, off sc0 sc1\n\tglobal_load_dwordx4 %1, %4, off offset:16 sc0 sc1\n\t"
+               "global_load_dwordx4 %2, %5, off sc0 sc1\n\tglobal_load_dwordx4 %3, %5, off offset:16 sc0 sc1\n\ts_waitcnt vmcnt(0)"
+               : "=&v"(xl), "=&v"(xh), "=&v"(yl), "=&v"(yh) : "v"(x), "v"(y) : "memory");
+}
+__global__ __launch_bounds__(256) void lbvh_bounds(const PrimRef* prims, uint32_t n, BNode* bnodes, const uint32_t* parent, uint32_t* flags, Counters* ctr) {
+  const uint32_t j = blockIdx.x * 256u + threadIdx.x;
+  if (j >= n) return;
+  const PrimRef p = load_prim(prims + j);
+  uint32_t id = n - 1u + j;
+  {
+    v4f l = {p.lo[0], p.lo[1], p.lo[2], __uint_as_float(j)}, h = {p.hi[0], p.hi[1], p.hi[2], __uint_as_float(j + 1u)};
+    st16_sys(bnodes + id, l); st16_sys((char*)(bnodes + id) + 16, h);
+    ((uint4*)(bnodes + id))[2] = make_uint4(NIL, NIL, __float_as_uint(__builtin_inff()), 0u);   // links: only read by later kernels
+  }
+  if (j == 0u) ctr->numBLeaves = n;
+  while (id != 0u) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // my box is in memory before my arrival is announced
+    const uint32_t par = parent[id];
+    if (atomicAdd(&flags[par], 1u) == 0u) return;               // first to arrive: the sibling's thread takes over
+    const uint32_t* pw = (const uint32_t*)(bnodes + par);       // links and range: written by lbvh_hierarchy, never changed here
+    const uint32_t l = pw[8], r = pw[9], first = pw[3], end = pw[7];
+    v4f al, ah, bl, bh;
+    ld_boxes_sys(bnodes + l, bnodes + r, al, ah, bl, bh);
+    v4f lo = {fminf(al.x, bl.x), fminf(al.y, bl.y), fminf(al.z, bl.z), __uint_as_float(first)};
+    v4f hi = {fmaxf(ah.x, bh.x), fmaxf(ah.y, bh.y), fmaxf(ah.z, bh.z), __uint_as_float(end)};
+    st16_sys(bnodes + par, lo); st16_sys((char*)(bnodes + par) + 16, hi);
+    id = par;
+  }
+}
+
 // -------------------------------------------------------------------------------- K4 wide collapse
 __device__ __forceinline__ float bnode_area(const BNode& b) { return half_area3(b.hi[0] - b.lo[0], b.hi[1] - b.lo[1], b.hi[2] - b.lo[2]); }
 
@@ -1208,7 +1305,7 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
   Params prm; prm.shift = bp->sah_block_shift; prm.minLeaf = bp->min_leaf ? bp->min_leaf : 1u;
   prm.maxLeaf = bp->max_leaf > MI355_MAX_LEAF ? MI355_MAX_LEAF : bp->max_leaf; if (prm.maxLeaf < prm.minLeaf) prm.maxLeaf = prm.minLeaf;
   if (prm.minLeaf > MI355_MAX_LEAF) prm.minLeaf = prm.maxLeaf = MI355_MAX_LEAF;
-  prm.small = bp->small_threshold < 64u ? 64u : (bp->small_threshold > 65536u ? 65536u : bp->small_threshold); prm.travCost = bp->trav_cost; prm.intCost = bp->int_cost;
+  prm.small = bp->small_threshold < 64u ? 64u : (bp->small_threshold > 65536u ? 65536u : bp->small_threshold); prm.travCost = bp->trav_cost; prm.intCost = bp->int_cost; prm.quality = bp->quality;
 
   std::vector<GeomDesc> gd; uint64_t total = 0;
   for (uint32_t i = 0; i < numMeshes; i++) {
@@ -1283,6 +1380,25 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
   }
   HIP_TRY(hipMemcpyAsync(ctr.p, &h, sizeof(h), hipMemcpyHostToDevice, st));
 
+  if (prm.quality == 1u) {                                     // RTC_BUILD_QUALITY_LOW: Morton codes -> sort -> hierarchy -> boxes
+    DevBuf<unsigned long long> keys, keysSorted; DevBuf<uint32_t> vals, valsSorted, parent, flags; DevBuf<char> tmp;
+    HIP_TRY(keys.alloc(n)); HIP_TRY(keysSorted.alloc(n)); HIP_TRY(vals.alloc(n)); HIP_TRY(valsSorted.alloc(n)); HIP_TRY(parent.alloc(2ull * n)); HIP_TRY(flags.alloc(n));
+    size_t tmpBytes = 0;
+    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmpBytes, keys.p, keysSorted.p, vals.p, valsSorted.p, (int)n, 0, 63, st));
+    HIP_TRY(tmp.alloc(tmpBytes));
+    float3 cmin = make_float3(clo[0], clo[1], clo[2]), cscale;
+    { const float e[3] = {chi[0] - clo[0], chi[1] - clo[1], chi[2] - clo[2]}; float s3[3]; for (int d = 0; d < 3; d++) s3[d] = e[d] > 0.0f ? 2097152.0f / e[d] : 0.0f; cscale = make_float3(s3[0], s3[1], s3[2]); }
+    const uint32_t g = (n + 255u) / 256u;
+    hipLaunchKernelGGL(morton_keys, dim3(g), dim3(256), 0, st, bufA.p, n, cmin, cscale, keys.p, vals.p);
+    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.p, tmpBytes, keys.p, keysSorted.p, vals.p, valsSorted.p, (int)n, 0, 63, st));
+    hipLaunchKernelGGL(morton_gather, dim3(g), dim3(256), 0, st, bufA.p, valsSorted.p, n, bufB.p, finalIds.p);
+    HIP_TRY(hipMemsetAsync(flags.p, 0, (size_t)n * 4, st));
+    if (n > 1u) hipLaunchKernelGGL(lbvh_hierarchy, dim3((n + 254u) / 256u), dim3(256), 0, st, keysSorted.p, n, bnodes.p, parent.p);
+    hipLaunchKernelGGL(lbvh_bounds, dim3(g), dim3(256), 0, st, bufB.p, n, bnodes.p, parent.p, flags.p, ctr.p);
+    HIP_TRY(hipGetLastError());
+    numSegs = 0; numSmall = 0;
+  }
+  const bool sahBuild = prm.quality != 1u;
   // ---- top phase: one pass over the data per binary level.  Work-list sizes stay on the device: every kernel is launched with
   //      an upper bound of its grid (<= 2^level segments, <= N/CHUNK + #segments chunks) and surplus blocks exit at once, so
   //      the levels are enqueued back to back; the host looks at the counters only where the level count is not implied by N.
@@ -1301,7 +1417,7 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
     hipLaunchKernelGGL(top_advance, dim3(1), dim3(1), 0, st, ctr.p, maxSegs);
     Seg* t = cur; cur = nxt; nxt = t; level++;
   };
-  if (numSegs) {
+  if (numSegs && sahBuild) {
     uint32_t sure = 1; while (sure < 40u && ((uint64_t)prm.small << sure) < n) sure++;   // the largest segment halves at best: that many levels exist
     for (uint32_t i = 0; i < sure; i++) enqueue_top_level();
     for (;;) {
@@ -1313,7 +1429,7 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
     }
   } else { HIP_TRY(hipMemcpyAsync(&h, ctr.p, sizeof(h), hipMemcpyDeviceToHost, st)); HIP_TRY(hipStreamSynchronize(st)); }
   info.top_levels = h.topLevels;
-  numSmall = h.numSmall;
+  numSmall = sahBuild ? h.numSmall : 0u;
   if (numSmall > maxSmall) return set_error(hipErrorOutOfMemory, "small list overflow");
 
   // ---- small phase

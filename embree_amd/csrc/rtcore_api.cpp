@@ -200,7 +200,8 @@ struct Scene : RefCounted {
     if (progress && !progress(progressPtr, 0.0)) THROW(RTC_ERROR_CANCELLED, "progress monitor forced termination");
     mi355_bvh_t nb = nullptr;
     mi355_build_params bp = device->build;
-    bp.robust = (flags & RTC_SCENE_FLAG_ROBUST) ? 1u : 0u;   // scene.cpp:180-188: robust scenes get Triangle4v leaves + the Pluecker intersector
+    bp.robust = (flags & RTC_SCENE_FLAG_ROBUST) ? 1u : 0u;
+    if (quality == RTC_BUILD_QUALITY_LOW) bp.quality = 1u;    // scene.cpp:195-206: low quality = the Morton builder   // scene.cpp:180-188: robust scenes get Triangle4v leaves + the Pluecker intersector
     core_check(mi355_bvh_build(device->gpu, meshes.data(), (uint32_t)meshes.size(), &bp, nullptr, &nb), "BVH build");
     if (bvh) mi355_bvh_destroy(bvh);
     bvh = nb;
@@ -239,6 +240,7 @@ void parse_config(Device* d, const char* cfg) {
     else if (k == "min_leaf") d->build.min_leaf = (uint32_t)atoi(v.c_str());
     else if (k == "leaf_block_shift") d->build.sah_block_shift = (uint32_t)atoi(v.c_str());
     else if (k == "small_threshold") d->build.small_threshold = (uint32_t)atoi(v.c_str());
+    else if (k == "quality") d->build.quality = (v == "low" || v == "1") ? 1u : 0u;
     else if (k == "int_cost") d->build.int_cost = (float)atof(v.c_str());
     else if (k == "trav_cost") d->build.trav_cost = (float)atof(v.c_str());
     // CPU-only keys of the reference (threads, isa, tri_accel, hugepages, ...) are accepted and ignored

@@ -49,7 +49,8 @@ typedef struct mi355_build_params {
   uint32_t robust;           /* RTC_SCENE_FLAG_ROBUST (kernels/common/scene.cpp:180-188): leaves keep v0,v1,v2; traversal uses the
                                 conservative node test (node_intersector1.h:539-554) and the Pluecker triangle test
                                 (triangle_intersector_pluecker.h:68-118).  default 0 */
-  uint32_t reserved;
+  uint32_t quality;          /* 0 = RTC_BUILD_QUALITY_MEDIUM (binned SAH, the default); 1 = RTC_BUILD_QUALITY_LOW: Morton-code build like the
+                                reference's fast builder (kernels/builders/bvh_builder_morton.h), same node and leaf layout */
 } mi355_build_params;
 
 typedef struct mi355_bvh_info {

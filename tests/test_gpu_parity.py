@@ -398,6 +398,64 @@ def test_tree_layout_is_bit_identical_across_rebuilds(api, dev):
     assert blobs[0] == blobs[1] == blobs[2]
 
 
+# ---------------------------------------------------------------------- RTC_BUILD_QUALITY_LOW: Morton build
+@pytest.mark.parametrize("n,seed", [(1, 1), (2, 7), (5, 2), (64, 3), (1000, 4), (30000, 6)])
+def test_low_quality_build_tree_and_parity(api, dev, restate, n, seed):
+    """rtcSetSceneBuildQuality(LOW) = Morton-code build: the tree must satisfy every structural invariant of the SAH tree (same node / leaf
+    layout) and the hits must be the reference's (they do not depend on the tree)."""
+    m = [soup(n, seed)]
+    s = api.make_scene(dev, m, quality=api.RTC_BUILD_QUALITY_LOW)
+    info = s.info()
+    nodes, tris = s.download_bvh()
+    bvh_check.validate(nodes, tris, info["root_ref"], m, max_leaf=info["max_leaf"])
+    o = oracle_scene(restate, m)
+    rays = W.incoherent_rays(4096, [0.5, 0.5, 0.5], seed=seed)
+    want, got = rays.copy(), rays.copy()
+    o.intersect1(want)
+    s.intersect1M(got)
+    compare_closest(got, want, rays, o.triangle_t, label="morton soup %d" % n)
+    s.release()
+
+
+def test_low_quality_crown_duplicates_and_determinism(api, dev, restate):
+    """Morton build on a multi-geometry scene with thousands of coincident centroids (equal codes: ties broken by index), bit-identical
+    across rebuilds, robust flag combined with it, and a sane SAH (the quality knob trades build time for SAH, not correctness)."""
+    meshes = W.synthetic_crown(num_phi=24)
+    base = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32) * 0.01 + np.float32(1.0)
+    dup = (np.tile(base, (2000, 1)), np.arange(6000, dtype=np.uint32).reshape(-1, 3))       # 2000 identical triangles = 2000 equal Morton codes
+    meshes = meshes + [dup]
+    blobs = []
+    for _ in range(2):
+        s = api.make_scene(dev, meshes, quality=api.RTC_BUILD_QUALITY_LOW)
+        nodes, tris = s.download_bvh()
+        blobs.append((nodes.tobytes(), tris.tobytes()))
+        info_low = s.info()
+        if _ == 0:
+            bvh_check.validate(nodes, tris, info_low["root_ref"], meshes, max_leaf=info_low["max_leaf"])
+            o = oracle_scene(restate, meshes)
+            rays = W.incoherent_rays(40000, [2, 2, 1.5], seed=11)
+            want, got = rays.copy(), rays.copy()
+            o.intersect1(want)
+            s.intersect1M(got)
+            compare_closest(got, want, rays, o.triangle_t, max_tie_frac=0.05, label="morton crown")
+        s.release()
+    assert blobs[0] == blobs[1]
+    med = api.make_scene(dev, meshes)
+    assert info_low["sah"] < 2.5 * med.info()["sah"], (info_low["sah"], med.info()["sah"])
+    med.release()
+    r = api.make_scene(dev, meshes, flags=api.RTC_SCENE_FLAG_ROBUST, quality=api.RTC_BUILD_QUALITY_LOW)
+    orb = restate.OracleScene(robust=True)
+    for v, t in meshes:
+        orb.add_mesh(v, t)
+    orb.commit()
+    rays = W.incoherent_rays(20000, [2, 2, 1.5], seed=12)
+    want, got = rays.copy(), rays.copy()
+    orb.intersect1(want)
+    r.intersect1M(got)
+    compare_closest(got, want, rays, orb.triangle_t, max_tie_frac=0.05, label="morton + robust")
+    r.release()
+
+
 # ---------------------------------------------------------------------- RTC_SCENE_FLAG_ROBUST (SURVEY 8f-1)
 WATERTIGHT_POS = np.array([148376.0, 1234.0, -223423.0], np.float32)     # verify.cpp:6575-6621
 
