@@ -160,6 +160,16 @@ def main():
         commit_wall.append(time.time() - t0)
         build_ms.append(scene.info()["build_ms"])
     info = scene.info()
+    # the same scene with RTC_BUILD_QUALITY_LOW (Morton build), reported next to the SAH build; the timed rays use the SAH tree
+    low_ms = []
+    L.rtcSetSceneBuildQuality(scene.h, api.RTC_BUILD_QUALITY_LOW)
+    for rep in range(3):
+        scene.commit()
+        low_ms.append(scene.info()["build_ms"])
+    low_info = scene.info()
+    L.rtcSetSceneBuildQuality(scene.h, api.RTC_BUILD_QUALITY_MEDIUM)
+    scene.commit()
+    assert scene.info()["num_nodes"] == info["num_nodes"]
 
     # ---- rays: primary image traced on the GPU -> diffuse bounce rays (this rank's own seed)
     side = int(round(args.rays ** 0.5))
@@ -277,7 +287,9 @@ def main():
                       "commit_wall_ms": round(1e3 * float(np.min(commit_wall)), 3),
                       "mprims_per_s_commit": round(ntri / float(np.min(commit_wall)) / 1e6, 1),
                       "nodes": info["num_nodes"], "leaves": info["num_leaves"], "sah": round(info["sah"], 3),
-                      "bvh_bytes": info["bytes_nodes"] + info["bytes_triangles"]},
+                      "bvh_bytes": info["bytes_nodes"] + info["bytes_triangles"],
+                      "low_quality": {"what": "RTC_BUILD_QUALITY_LOW: Morton-code build, same node/leaf layout", "gpu_build_ms": round(float(np.min(low_ms)), 3),
+                                      "mprims_per_s_gpu": round(ntri / (float(np.min(low_ms)) * 1e-3) / 1e6, 1), "sah": round(low_info["sah"], 3)}},
             "hit_fraction": round(nhit / M, 4),
         }
         if world == 1 and not args.no_cpu:

@@ -200,8 +200,8 @@ struct Scene : RefCounted {
     if (progress && !progress(progressPtr, 0.0)) THROW(RTC_ERROR_CANCELLED, "progress monitor forced termination");
     mi355_bvh_t nb = nullptr;
     mi355_build_params bp = device->build;
-    bp.robust = (flags & RTC_SCENE_FLAG_ROBUST) ? 1u : 0u;
-    if (quality == RTC_BUILD_QUALITY_LOW) bp.quality = 1u;    // scene.cpp:195-206: low quality = the Morton builder   // scene.cpp:180-188: robust scenes get Triangle4v leaves + the Pluecker intersector
+    bp.robust = (flags & RTC_SCENE_FLAG_ROBUST) ? 1u : 0u;   // scene.cpp:180-188: robust scenes get Triangle4v leaves + the Pluecker intersector
+    if (quality == RTC_BUILD_QUALITY_LOW) bp.quality = 1u;    // scene.cpp:195-206: low quality = the Morton builder
     core_check(mi355_bvh_build(device->gpu, meshes.data(), (uint32_t)meshes.size(), &bp, nullptr, &nb), "BVH build");
     if (bvh) mi355_bvh_destroy(bvh);
     bvh = nb;
