@@ -19,7 +19,7 @@ RTC_ERROR_NONE, RTC_ERROR_UNKNOWN, RTC_ERROR_INVALID_ARGUMENT, RTC_ERROR_INVALID
 RTC_ERROR_OUT_OF_MEMORY, RTC_ERROR_UNSUPPORTED_CPU, RTC_ERROR_CANCELLED = 4, 5, 6
 RTC_GEOMETRY_TYPE_TRIANGLE, RTC_GEOMETRY_TYPE_QUAD = 0, 1
 RTC_BUFFER_TYPE_INDEX, RTC_BUFFER_TYPE_VERTEX, RTC_BUFFER_TYPE_VERTEX_ATTRIBUTE = 0, 1, 2
-RTC_FORMAT_UINT3, RTC_FORMAT_FLOAT3 = 0x5003, 0x9003
+RTC_FORMAT_UINT3, RTC_FORMAT_UINT4, RTC_FORMAT_FLOAT3 = 0x5003, 0x5004, 0x9003
 RTC_SCENE_FLAG_ROBUST = 4
 RTC_BUILD_QUALITY_LOW, RTC_BUILD_QUALITY_MEDIUM, RTC_BUILD_QUALITY_HIGH = 0, 1, 2
 
@@ -288,6 +288,25 @@ class Scene:
                 C.memmove(pv, v.ctypes.data, v.nbytes)
             if t.size:
                 C.memmove(pt, t.ctypes.data, t.nbytes)
+        if mask is not None:
+            L.rtcSetGeometryMask(g, mask)
+        L.rtcCommitGeometry(g)
+        gid = L.rtcAttachGeometry(self.h, g)
+        L.rtcReleaseGeometry(g)
+        self.dev.check()
+        return gid
+
+    def add_quad_mesh(self, verts, quads, mask=None):
+        """rtcNewGeometry(QUAD): float3 vertices, uint4 indices (shared host buffers)."""
+        L = self.L
+        v = np.ascontiguousarray(verts, np.float32).reshape(-1, 3)
+        q = np.ascontiguousarray(quads, np.uint32).reshape(-1, 4)
+        g = L.rtcNewGeometry(self.dev.h, RTC_GEOMETRY_TYPE_QUAD)
+        self.dev.check()
+        vp = np.concatenate([v.ravel(), np.zeros(4, np.float32)])
+        self._keep += [vp, q]
+        L.rtcSetSharedGeometryBuffer(g, RTC_BUFFER_TYPE_VERTEX, 0, RTC_FORMAT_FLOAT3, vp.ctypes.data, 0, 12, v.shape[0])
+        L.rtcSetSharedGeometryBuffer(g, RTC_BUFFER_TYPE_INDEX, 0, RTC_FORMAT_UINT4, q.ctypes.data, 0, 16, q.shape[0])
         if mask is not None:
             L.rtcSetGeometryMask(g, mask)
         L.rtcCommitGeometry(g)

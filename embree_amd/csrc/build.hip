@@ -54,7 +54,18 @@ constexpr uint32_t ENC_POS_INF = 0xFF800000u;   // enc(+inf)
 constexpr uint32_t ENC_NEG_INF = 0x007FFFFFu;   // enc(-inf)
 
 struct PrimRef { float lo[3]; uint32_t geom; float hi[3]; uint32_t prim; };   // kernels/builders/primref.h:11-107 (geom = table index)
-struct GeomDesc { const char* verts; const char* idx; uint32_t vstride, istride, nv, nt, geomID, mask, primOffset, pad; };
+struct GeomDesc { const char* verts; const char* idx; uint32_t vstride, istride, nv, nt, geomID, mask, primOffset, quad; };   // nt = internal triangles (2 per quad)
+// internal triangle j of a geometry -> its three vertex indices; quads: j>>1 = quad, odd j = second half (v2,v1,v3), even = (v0,v1,v3)
+__device__ __forceinline__ void prim_indices(const GeomDesc& g, uint32_t j, uint32_t& i0, uint32_t& i1, uint32_t& i2, uint32_t& id) {
+  if (g.quad) {
+    const uint32_t* q = (const uint32_t*)(g.idx + (size_t)(j >> 1) * g.istride);
+    i0 = (j & 1u) ? q[2] : q[0]; i1 = q[1]; i2 = q[3]; id = (j >> 1) | ((j & 1u) << 31);
+    if (q[0] >= g.nv || q[2] >= g.nv) i0 = 0xFFFFFFFFu;           // a quad with ANY invalid index is skipped as a whole (QuadMesh::buildBounds)
+  } else {
+    const uint32_t* t = (const uint32_t*)(g.idx + (size_t)j * g.istride);
+    i0 = t[0]; i1 = t[1]; i2 = t[2]; id = j;
+  }
+}
 struct BNode { float lo[3]; uint32_t begin; float hi[3]; uint32_t end; uint32_t left, right; float splitSah; uint32_t pad; };
 struct Seg {
   uint32_t begin, end, bnode, flags;            // flags bit0: fallback (median) split
@@ -132,8 +143,8 @@ __global__ __launch_bounds__(256) void primref_gen(const GeomDesc* geoms, uint32
       gi = lo; g = geoms[lo];
     }
     const uint32_t j = p - g.primOffset;
-    const uint32_t* tri = (const uint32_t*)(g.idx + (size_t)j * g.istride);
-    const uint32_t i0 = tri[0], i1 = tri[1], i2 = tri[2];
+    uint32_t i0, i1, i2, pid;
+    prim_indices(g, j, i0, i1, i2, pid);
     bool ok = false; PrimRef r{};
     if (i0 < g.nv && i1 < g.nv && i2 < g.nv) {
       const float* a = (const float*)(g.verts + (size_t)i0 * g.vstride);
@@ -145,6 +156,11 @@ __global__ __launch_bounds__(256) void primref_gen(const GeomDesc* geoms, uint32
         ok = ok && valid_f(x) && valid_f(y) && valid_f(z);
         r.lo[d] = fminf(fminf(x, y), z); r.hi[d] = fmaxf(fmaxf(x, y), z);
       }
+    }
+    if (ok && g.quad) {                                       // non-finite fourth vertex: the reference drops the whole quad
+      const uint32_t* q = (const uint32_t*)(g.idx + (size_t)(j >> 1) * g.istride);
+      const float* o4 = (const float*)(g.verts + (size_t)((j & 1u) ? q[0] : q[2]) * g.vstride);
+      ok = valid_f(o4[0]) && valid_f(o4[1]) && valid_f(o4[2]);
     }
     r.geom = ok ? gi : NIL; r.prim = j;
     store_prim(out + p, r);
@@ -1209,12 +1225,14 @@ __global__ __launch_bounds__(64) void wide_emit(const WideItem* items, const BNo
 __global__ __launch_bounds__(256) void tri_records(const uint2* finalIds, uint32_t n, const GeomDesc* geoms, TriRec* out, uint32_t robust) {
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i >= n) return;
-  const uint2 id = finalIds[i];
+  uint2 id = finalIds[i];
   const GeomDesc g = geoms[id.x];
-  const uint32_t* tri = (const uint32_t*)(g.idx + (size_t)id.y * g.istride);
-  const float* a = (const float*)(g.verts + (size_t)tri[0] * g.vstride);
-  const float* b = (const float*)(g.verts + (size_t)tri[1] * g.vstride);
-  const float* c = (const float*)(g.verts + (size_t)tri[2] * g.vstride);
+  uint32_t i0, i1, i2, pid;
+  prim_indices(g, id.y, i0, i1, i2, pid);
+  id.y = pid;                                                   // quads: quad index, bit 31 = second half (cleared again when a hit is written)
+  const float* a = (const float*)(g.verts + (size_t)i0 * g.vstride);
+  const float* b = (const float*)(g.verts + (size_t)i1 * g.vstride);
+  const float* c = (const float*)(g.verts + (size_t)i2 * g.vstride);
   float4* o = (float4*)(out + i);
   if (robust) {   // TriangleMv: the three vertices (kernels/geometry/trianglev.h), same 48-byte record
     o[0] = make_float4(a[0], a[1], a[2], b[0]);
@@ -1311,10 +1329,10 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
   for (uint32_t i = 0; i < numMeshes; i++) {
     const mi355_mesh& m = meshes[i];
     if (m.num_triangles == 0) continue;
-    if (m.vertex_stride < 12 || (m.vertex_stride & 3) || m.index_stride < 12 || (m.index_stride & 3)) return set_error(hipErrorInvalidValue, "buffer stride");
+    if (m.vertex_stride < 12 || (m.vertex_stride & 3) || m.index_stride < (m.quads ? 16u : 12u) || (m.index_stride & 3)) return set_error(hipErrorInvalidValue, "buffer stride");
     GeomDesc g{}; g.verts = (const char*)m.d_vertices; g.idx = (const char*)m.d_indices; g.vstride = (uint32_t)m.vertex_stride; g.istride = (uint32_t)m.index_stride;
-    g.nv = m.num_vertices; g.nt = m.num_triangles; g.geomID = m.geom_id; g.mask = m.mask; g.primOffset = (uint32_t)total;
-    total += m.num_triangles; gd.push_back(g);
+    g.nv = m.num_vertices; g.quad = m.quads ? 1u : 0u; g.nt = m.num_triangles * (g.quad ? 2u : 1u); g.geomID = m.geom_id; g.mask = m.mask; g.primOffset = (uint32_t)total;
+    total += g.nt; gd.push_back(g);
   }
   if (total >= (1ull << 31)) return set_error(hipErrorInvalidValue, "more than 2^31 triangles are not supported by the 32-bit triangle index");
   mi355_bvh_info& info = bvh->info; memset(&info, 0, sizeof(info));

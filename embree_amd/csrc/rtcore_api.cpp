@@ -130,7 +130,7 @@ struct Geometry : RefCounted {
       v = &vertices;
     } else if (t == RTC_BUFFER_TYPE_INDEX) {
       if (slot != 0) THROW(RTC_ERROR_INVALID_ARGUMENT, "invalid buffer slot");
-      if (fmt != RTC_FORMAT_UINT3) THROW(RTC_ERROR_INVALID_OPERATION, "invalid index buffer format");
+      if (fmt != (type == RTC_GEOMETRY_TYPE_QUAD ? RTC_FORMAT_UINT4 : RTC_FORMAT_UINT3)) THROW(RTC_ERROR_INVALID_OPERATION, "invalid index buffer format");
       v = &indices;
     } else if (t == RTC_BUFFER_TYPE_VERTEX_ATTRIBUTE) {
       if (fmt < RTC_FORMAT_FLOAT || fmt > RTC_FORMAT_FLOAT16) THROW(RTC_ERROR_INVALID_OPERATION, "invalid vertex attribute buffer format");
@@ -139,8 +139,9 @@ struct Geometry : RefCounted {
       attribs[slot] = b;
       return;
     } else THROW(RTC_ERROR_INVALID_ARGUMENT, "unknown buffer type");
-    if (stride < 12) THROW(RTC_ERROR_INVALID_OPERATION, "stride smaller than the element");
-    if (num && off + stride * (num - 1) + 12 > b->bytes) THROW(RTC_ERROR_INVALID_ARGUMENT, "buffer too small for view");
+    const size_t elem = (t == RTC_BUFFER_TYPE_INDEX && type == RTC_GEOMETRY_TYPE_QUAD) ? 16 : 12;
+    if (stride < elem) THROW(RTC_ERROR_INVALID_OPERATION, "stride smaller than the element");
+    if (num && off + stride * (num - 1) + elem > b->bytes) THROW(RTC_ERROR_INVALID_ARGUMENT, "buffer too small for view");
     b->retain();
     if (v->buf) v->buf->release();
     v->buf = b; v->offset = off; v->stride = stride; v->num = (unsigned)num;
@@ -194,7 +195,7 @@ struct Scene : RefCounted {
       mi355_mesh m;
       m.d_vertices = g->vertices.buf->dev + g->vertices.offset; m.vertex_stride = g->vertices.stride; m.num_vertices = g->vertices.num;
       m.d_indices = g->indices.buf->dev + g->indices.offset; m.index_stride = g->indices.stride; m.num_triangles = g->indices.num;
-      m.geom_id = kv.first; m.mask = g->mask;
+      m.geom_id = kv.first; m.mask = g->mask; m.quads = g->type == RTC_GEOMETRY_TYPE_QUAD ? 1u : 0u; m.reserved = 0;
       meshes.push_back(m);
     }
     if (progress && !progress(progressPtr, 0.0)) THROW(RTC_ERROR_CANCELLED, "progress monitor forced termination");
@@ -371,7 +372,8 @@ RTC_API void rtcReleaseBuffer(RTCBuffer b) { if (b) ((Buffer*)b)->release(); }
 RTC_API RTCGeometry rtcNewGeometry(RTCDevice h, enum RTCGeometryType type) {
   CATCH_BEGIN
   Device* d = dev_of(h);
-  if (type != RTC_GEOMETRY_TYPE_TRIANGLE) THROW(RTC_ERROR_INVALID_OPERATION, "only RTC_GEOMETRY_TYPE_TRIANGLE is supported by the MI355X core");
+  if (type != RTC_GEOMETRY_TYPE_TRIANGLE && type != RTC_GEOMETRY_TYPE_QUAD)
+    THROW(RTC_ERROR_INVALID_OPERATION, "only RTC_GEOMETRY_TYPE_TRIANGLE and RTC_GEOMETRY_TYPE_QUAD are supported by the MI355X core");
   return (RTCGeometry) new Geometry(d, type);
   CATCH_END((Device*)h)
   return nullptr;

@@ -128,7 +128,7 @@ struct TriOut { float t, u, v, Ngx, Ngy, Ngz; };
 // (triangle_intersector_moeller.h:79-108; cross/dot: common/math/vec3.h:204,209); FINISH also produces t,u,v,Ng (Intersect1EpilogM, intersector_epilog.h:235-300)
 template <bool FINISH>
 __device__ __forceinline__ bool tri_moeller(const float4 q0, const float4 q1, const float4 q2, float ox, float oy, float oz, float dx, float dy, float dz,
-                                            float tnear, float tfar, TriOut& o) {
+                                            float tnear, float tfar, TriOut& o, bool quad2 = false) {
   const float v0x = q0.x, v0y = q0.y, v0z = q0.z;
   const float e1x = q0.w, e1y = q1.x, e1z = q1.y;
   const float e2x = q1.z, e2y = q1.w, e2z = q2.x;
@@ -150,7 +150,11 @@ __device__ __forceinline__ bool tri_moeller(const float4 q0, const float4 q1, co
   if (FINISH || ok) {
     const float rcpd = rcp_nr(absDen);
     o.t = T * rcpd;
-    if (FINISH) { o.u = U * rcpd; o.v = V * rcpd; o.Ngx = Ngx; o.Ngy = Ngy; o.Ngz = Ngz; }
+    if (FINISH) {
+      // second half (v2,v1,v3) of a quad: U,V <- absDen-V, absDen-U and Ng <- -Ng (quad_intersector_moeller.h:205-207, AVX path)
+      const float Uq = quad2 ? absDen - V : U, Vq = quad2 ? absDen - U : V, sg = quad2 ? -1.0f : 1.0f;
+      o.u = Uq * rcpd; o.v = Vq * rcpd; o.Ngx = Ngx * sg; o.Ngy = Ngy * sg; o.Ngz = Ngz * sg;
+    }
   }
   return ok;
 }
@@ -158,7 +162,7 @@ __device__ __forceinline__ bool tri_moeller(const float4 q0, const float4 q1, co
 // PlueckerHitM::finalize (:26-33); watertight along shared edges.  Same operation order as the reference.
 template <bool FINISH>
 __device__ __forceinline__ bool tri_pluecker(const float4 q0, const float4 q1, const float4 q2, float ox, float oy, float oz, float dx, float dy, float dz,
-                                             float tnear, float tfar, TriOut& o) {
+                                             float tnear, float tfar, TriOut& o, bool quad2 = false) {
   const float v0x = q0.x - ox, v0y = q0.y - oy, v0z = q0.z - oz;
   const float v1x = q0.w - ox, v1y = q1.x - oy, v1z = q1.y - oz;
   const float v2x = q1.z - ox, v2y = q1.w - oy, v2z = q2.x - oz;
@@ -185,7 +189,9 @@ __device__ __forceinline__ bool tri_pluecker(const float4 q0, const float4 q1, c
   o.t = t;
   if (FINISH) {
     const float rcpUVW = fabsf(UVW) < 1e-18f ? 0.0f : rcp_nr(UVW);
-    o.u = fminf(U * rcpUVW, 1.0f); o.v = fminf(V * rcpUVW, 1.0f); o.Ngx = Ngx; o.Ngy = Ngy; o.Ngz = Ngz;
+    const float u = fminf(U * rcpUVW, 1.0f), v = fminf(V * rcpUVW, 1.0f), sg = quad2 ? -1.0f : 1.0f;
+    // second half of a quad: u,v <- 1-v, 1-u and Ng <- -Ng (QuadHitPlueckerM::finalize, quad_intersector_pluecker.h:33-50, AVX path)
+    o.u = quad2 ? 1.0f - v : u; o.v = quad2 ? 1.0f - u : v; o.Ngx = sg * Ngx; o.Ngy = sg * Ngy; o.Ngz = sg * Ngz;
   }
   return ok;
 }
@@ -298,11 +304,12 @@ __global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceAr
                 else {
                   // recompute the winner's t, u, v, Ng (same arithmetic as the test in step 4; Intersect1EpilogM, intersector_epilog.h:235-300)
                   TriOut w;
-                  if (ROBUST) tri_pluecker<true>(q0, q1, q2, ox, oy, oz, dx, dy, dz, tnear, tfar, w);
-                  else tri_moeller<true>(q0, q1, q2, ox, oy, oz, dx, dy, dz, tnear, tfar, w);
+                  const uint32_t pid = __float_as_uint(q2.y);            // bit 31: second triangle of a quad (tri_records, build.hip)
+                  if (ROBUST) tri_pluecker<true>(q0, q1, q2, ox, oy, oz, dx, dy, dz, tnear, tfar, w, (pid >> 31) != 0u);
+                  else tri_moeller<true>(q0, q1, q2, ox, oy, oz, dx, dy, dz, tnear, tfar, w, (pid >> 31) != 0u);
                   *(float*)(rp + 32) = w.t;
                   *(float4*)(rp + 48) = make_float4(w.Ngx, w.Ngy, w.Ngz, w.u);
-                  *(uint4*)(rp + 64) = make_uint4(__float_as_uint(w.v), __float_as_uint(q2.y), __float_as_uint(q2.z), MI355_EMPTY_REF);
+                  *(uint4*)(rp + 64) = make_uint4(__float_as_uint(w.v), pid & 0x7FFFFFFFu, __float_as_uint(q2.z), MI355_EMPTY_REF);
                   *(uint32_t*)(rp + 80) = MI355_EMPTY_REF;
                 }
               }

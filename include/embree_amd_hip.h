@@ -37,6 +37,10 @@ typedef struct mi355_mesh {
   const void* d_indices;  size_t index_stride;  uint32_t num_triangles;
   uint32_t geom_id;       /* value reported in RTCHit.geomID */
   uint32_t mask;          /* geometry mask, tested against RTCRay.mask (default 1, kernels/common/geometry.cpp:48) */
+  uint32_t quads;         /* 1: RTC_GEOMETRY_TYPE_QUAD -- indices are uint4 (stride >= 16), num_triangles counts QUADS.  A quad (v0,v1,v2,v3) is the
+                             triangle pair (v0,v1,v3), (v2,v1,v3) of the reference's AVX quad intersectors (kernels/geometry/
+                             quad_intersector_moeller.h:179-216); hits report the quad's index as primID and the quad's u,v */
+  uint32_t reserved;
 } mi355_mesh;
 
 typedef struct mi355_build_params {

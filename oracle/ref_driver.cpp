@@ -86,6 +86,22 @@ __attribute__((visibility("default"))) unsigned refd_add_mesh(void* h, const flo
   return id;
 }
 
+// RTC_GEOMETRY_TYPE_QUAD: index buffer of uint4 (rtcore_geometry.h), same vertex buffer layout
+__attribute__((visibility("default"))) unsigned refd_add_quads(void* h, const float* verts, unsigned nv,
+                                                               const unsigned* idx, unsigned nq, unsigned mask) {
+  RefScene* s = (RefScene*)h;
+  RTCGeometry g = rtcNewGeometry(s->device, RTC_GEOMETRY_TYPE_QUAD);
+  float* v = (float*)rtcSetNewGeometryBuffer(g, RTC_BUFFER_TYPE_VERTEX, 0, RTC_FORMAT_FLOAT3, 12, nv);
+  unsigned* t = (unsigned*)rtcSetNewGeometryBuffer(g, RTC_BUFFER_TYPE_INDEX, 0, RTC_FORMAT_UINT4, 16, nq);
+  if (v && nv) memcpy(v, verts, (size_t)nv * 12);
+  if (t && nq) memcpy(t, idx, (size_t)nq * 16);
+  rtcSetGeometryMask(g, mask);
+  rtcCommitGeometry(g);
+  unsigned id = rtcAttachGeometry(s->scene, g);
+  rtcReleaseGeometry(g);
+  return id;
+}
+
 __attribute__((visibility("default"))) double refd_commit(void* h) {
   RefScene* s = (RefScene*)h;
   double t0 = now();

@@ -29,6 +29,8 @@ def _load():
         L.refd_add_mesh.restype = ctypes.c_uint
         L.refd_add_mesh.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint,
                                     ctypes.c_void_p, ctypes.c_uint, ctypes.c_uint]
+        L.refd_add_quads.restype = ctypes.c_uint
+        L.refd_add_quads.argtypes = L.refd_add_mesh.argtypes
         L.refd_commit.restype = ctypes.c_double
         L.refd_commit.argtypes = [ctypes.c_void_p]
         L.refd_error.restype = ctypes.c_int
@@ -64,6 +66,11 @@ class RefScene:
         v = np.ascontiguousarray(verts, np.float32).reshape(-1, 3)
         t = np.ascontiguousarray(tris, np.uint32).reshape(-1, 3)
         return _load().refd_add_mesh(self._h, v.ctypes.data, v.shape[0], t.ctypes.data, t.shape[0], mask)
+
+    def add_quads(self, verts, quads, mask=1):
+        v = np.ascontiguousarray(verts, np.float32).reshape(-1, 3)
+        q = np.ascontiguousarray(quads, np.uint32).reshape(-1, 4)
+        return _load().refd_add_quads(self._h, v.ctypes.data, v.shape[0], q.ctypes.data, q.shape[0], mask)
 
     def commit(self):
         self.commit_seconds = _load().refd_commit(self._h)

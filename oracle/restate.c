@@ -40,9 +40,9 @@ typedef struct { Box geom, cent; size_t begin, end; } Set; /* PrimInfoRange, ker
 /* BVH8 inner node: kernels/bvh/bvh_node_aabb.h:12-222 (SoA planes + 8 refs) */
 typedef struct { float lower[3][8], upper[3][8]; int32_t child[8]; } Node8;
 /* Triangle4 leaf block: kernels/geometry/triangle.h:13-156 (v0, e1=v0-v1, e2=v2-v0) */
-typedef struct { float v0[3][4], e1[3][4], e2[3][4]; uint32_t geomID[4], primID[4]; } Tri4;
+typedef struct { float v0[3][4], e1[3][4], e2[3][4], v3[3][4]; uint32_t geomID[4], primID[4]; } Tri4;   /* quad scenes: QuadMv<4> = v0,v1,v2,v3 (kernels/geometry/quadv.h) */
 
-typedef struct { const float* v; uint32_t nv; const uint32_t* t; uint32_t nt; uint32_t mask; float* vown; uint32_t* town; } Mesh;
+typedef struct { const float* v; uint32_t nv; const uint32_t* t; uint32_t nt; uint32_t mask; float* vown; uint32_t* town; int quad; } Mesh;   /* quad: 4 indices per primitive */
 
 typedef struct {
   Mesh* mesh; uint32_t nmesh, cmesh;
@@ -53,6 +53,8 @@ typedef struct {
   Box bounds;
   double sah;              /* sum(area(node))/area(root) style statistic, see ora_stats */
   uint64_t stat_nodes, stat_leaves, stat_blocks; /* traversal visit counters (STAT3, kernels/common/stat.h:9-19) */
+  int quads;               /* this tree is the scene's QUAD accel (BVH8Quad4v, scene.cpp:276-320): the reference builds one BVH per geometry type and
+                              queries them in turn (AccelN, kernels/common/acceln.cpp:44-50); oracle/restate.py keeps one Scene per type */
   int robust;              /* RTC_SCENE_FLAG_ROBUST: Triangle4v leaves (v0,v1,v2) + Pluecker test + conservative node test (scene.cpp:180-188) */
 } Scene;
 
@@ -102,7 +104,17 @@ API uint32_t ora_add_mesh(Scene* s, const float* v, uint32_t nv, const uint32_t*
   m->vown = (float*)malloc((size_t)nv * 12 + 16); m->town = (uint32_t*)malloc((size_t)nt * 12 + 16);
   if (nv) memcpy(m->vown, v, (size_t)nv * 12);
   if (nt) memcpy(m->town, t, (size_t)nt * 12);
-  m->v = m->vown; m->nv = nv; m->t = m->town; m->nt = nt; m->mask = mask;
+  m->v = m->vown; m->nv = nv; m->t = m->town; m->nt = nt; m->mask = mask; m->quad = 0;
+  return s->nmesh++;
+}
+/* RTC_GEOMETRY_TYPE_QUAD: uint4 indices (kernels/common/scene_quad_mesh.h) */
+API uint32_t ora_add_quads(Scene* s, const float* v, uint32_t nv, const uint32_t* q, uint32_t nq, uint32_t mask) {
+  if (s->nmesh == s->cmesh) { s->cmesh = s->cmesh ? 2 * s->cmesh : 8; s->mesh = (Mesh*)realloc(s->mesh, s->cmesh * sizeof(Mesh)); }
+  Mesh* m = &s->mesh[s->nmesh];
+  m->vown = (float*)malloc((size_t)nv * 12 + 16); m->town = (uint32_t*)malloc((size_t)nq * 16 + 16);
+  if (nv) memcpy(m->vown, v, (size_t)nv * 12);
+  if (nq) memcpy(m->town, q, (size_t)nq * 16);
+  m->v = m->vown; m->nv = nv; m->t = m->town; m->nt = nq; m->mask = mask; m->quad = 1; s->quads = 1;
   return s->nmesh++;
 }
 
@@ -118,7 +130,20 @@ static void gen_primrefs(Scene* s, Set* all) {
   size_t k = 0;
   for (uint32_t g = 0; g < s->nmesh; g++) {
     const Mesh* m = &s->mesh[g];
-    for (uint32_t j = 0; j < m->nt; j++) {
+    for (uint32_t j = 0; j < m->nt && m->quad; j++) {   /* QuadMesh::buildBounds kernels/common/scene_quad_mesh.h:170-195: box of the four vertices */
+      const uint32_t* q = m->t + 4 * (size_t)j;
+      if (q[0] >= m->nv || q[1] >= m->nv || q[2] >= m->nv || q[3] >= m->nv) continue;
+      const float* vv[4] = { m->v + 3 * (size_t)q[0], m->v + 3 * (size_t)q[1], m->v + 3 * (size_t)q[2], m->v + 3 * (size_t)q[3] };
+      int ok = 1;
+      for (int c = 0; c < 4; c++) for (int d = 0; d < 3; d++) ok &= valid_f(vv[c][d]);
+      if (!ok) continue;
+      PrimRef* p = &s->prims[k++];
+      for (int d = 0; d < 3; d++) { p->lo[d] = fminf_(fminf_(vv[0][d], vv[1][d]), fminf_(vv[2][d], vv[3][d])); p->hi[d] = fmaxf_(fmaxf_(vv[0][d], vv[1][d]), fmaxf_(vv[2][d], vv[3][d])); }
+      p->geomID = g; p->primID = j;
+      float c2[3] = { p->lo[0] + p->hi[0], p->lo[1] + p->hi[1], p->lo[2] + p->hi[2] };
+      box_extend(&all->geom, p->lo, p->hi); box_extend_pt(&all->cent, c2);
+    }
+    for (uint32_t j = 0; j < m->nt && !m->quad; j++) {
       const uint32_t* tri = m->t + 3 * (size_t)j;
       if (tri[0] >= m->nv || tri[1] >= m->nv || tri[2] >= m->nv) continue;
       const float *a = m->v + 3 * (size_t)tri[0], *b = m->v + 3 * (size_t)tri[1], *c = m->v + 3 * (size_t)tri[2];
@@ -251,6 +276,12 @@ static int32_t create_leaf(Scene* s, const Set* set) {
     for (int i = 0; i < 4 && b < set->end; i++, b++) {
       const PrimRef* p = &s->prims[b];
       const Mesh* m = &s->mesh[p->geomID];
+      if (m->quad) {                                            /* Quad4v::fill kernels/geometry/quadv.h */
+        const uint32_t* q = m->t + 4 * (size_t)p->primID;
+        for (int d = 0; d < 3; d++) { t->v0[d][i] = m->v[3 * (size_t)q[0] + d]; t->e1[d][i] = m->v[3 * (size_t)q[1] + d]; t->e2[d][i] = m->v[3 * (size_t)q[2] + d]; t->v3[d][i] = m->v[3 * (size_t)q[3] + d]; }
+        t->geomID[i] = p->geomID; t->primID[i] = p->primID;
+        continue;
+      }
       const uint32_t* tri = m->t + 3 * (size_t)p->primID;
       const float *v0 = m->v + 3 * (size_t)tri[0], *v1 = m->v + 3 * (size_t)tri[1], *v2 = m->v + 3 * (size_t)tri[2];
       if (s->robust) for (int d = 0; d < 3; d++) { t->v0[d][i] = v0[d]; t->e1[d][i] = v1[d]; t->e2[d][i] = v2[d]; }   /* TriangleMv: the vertices themselves, kernels/geometry/trianglev.h */
@@ -459,6 +490,67 @@ static void pl_lane(const Tri4* b, int i, const Ray* ray, PLHit* h) {
   h->Ng[0] = Ng[0]; h->Ng[1] = Ng[1]; h->Ng[2] = Ng[2];
 }
 
+/* QuadMIntersector1MoellerTrumbore<4> / QuadMIntersector1Pluecker<4>, AVX specialisations (kernels/geometry/quad_intersector_moeller.h:179-216,
+   quad_intersector_pluecker.h:198-217): eight lanes = triangles (v0,v1,v3) of the four quads, then triangles (v2,v1,v3) with flag set;
+   flagged lanes: U,V <- absDen-V, absDen-U and Ng <- -Ng (fast), u,v <- 1-v, 1-u and Ng <- -Ng (robust, QuadHitPlueckerM::finalize :33-50).
+   Fills t/u/v/Ng/valid for lane l (0..7) of block b. */
+typedef struct { int valid; float t, u, v, Ng[3]; } QLane;
+static void quad_lane(const Scene* s, const Tri4* b, int l, const Ray* ray, QLane* o) {
+  const int i = l & 3, flag = l >> 2;
+  Tri4 tmp; memset(&tmp, 0, sizeof(tmp));
+  const float (*A)[4] = flag ? b->e2 : b->v0;                   /* first vertex: v0 or v2 */
+  if (s->robust) {
+    for (int d = 0; d < 3; d++) { tmp.v0[d][0] = A[d][i]; tmp.e1[d][0] = b->e1[d][i]; tmp.e2[d][0] = b->v3[d][i]; }
+    PLHit p; pl_lane(&tmp, 0, ray, &p);
+    o->valid = p.valid; o->t = p.t;
+    o->u = flag ? 1.0f - p.v : p.u; o->v = flag ? 1.0f - p.u : p.v;
+    for (int d = 0; d < 3; d++) o->Ng[d] = flag ? -1.0f * p.Ng[d] : 1.0f * p.Ng[d];
+  } else {
+    for (int d = 0; d < 3; d++) { tmp.v0[d][0] = A[d][i]; tmp.e1[d][0] = A[d][i] - b->e1[d][i]; tmp.e2[d][0] = b->v3[d][i] - A[d][i]; }   /* e1 = v0-v1, e2 = v2-v0 */
+    MTHit h; mt_lane(&tmp, 0, ray, &h);
+    const float U = flag ? h.absDen - h.V : h.U, V = flag ? h.absDen - h.U : h.V;
+    const float r = rcp_nr(h.absDen);
+    o->valid = h.valid; o->t = h.T * r; o->u = U * r; o->v = V * r;
+    for (int d = 0; d < 3; d++) o->Ng[d] = flag ? h.Ng[d] * -1.0f : h.Ng[d] * 1.0f;
+  }
+  if (b->geomID[i] == INVALID_ID) o->valid = 0;
+}
+static void quad_leaf_intersect(Scene* s, RayHit* rh, size_t start, size_t num) {
+  for (size_t k = 0; k < num; k++) {
+    const Tri4* b = &s->blocks[start + k];
+    s->stat_blocks++;
+    QLane q[8]; int valid[8], any = 0;
+    for (int l = 0; l < 8; l++) { quad_lane(s, b, l, &rh->ray, &q[l]); valid[l] = q[l].valid; any |= valid[l]; }
+    if (!any) continue;
+    for (;;) {                                                  /* Intersect1EpilogM<8,true>: select_min over the 8 lanes, lowest lane on equal t */
+      int best = -1; float bt = INFINITY;
+      for (int l = 0; l < 8; l++) if (valid[l] && q[l].t < bt) bt = q[l].t;
+      for (int l = 0; l < 8; l++) if (valid[l] && q[l].t == bt) { best = l; break; }
+      if (best < 0) for (int l = 0; l < 8; l++) if (valid[l]) { best = l; break; }
+      if (best < 0) break;
+      const uint32_t g = b->geomID[best & 3];
+      if ((s->mesh[g].mask & rh->ray.mask) == 0) { valid[best] = 0; continue; }
+      rh->ray.tfar = q[best].t;
+      rh->hit.Ng_x = q[best].Ng[0]; rh->hit.Ng_y = q[best].Ng[1]; rh->hit.Ng_z = q[best].Ng[2];
+      rh->hit.u = q[best].u; rh->hit.v = q[best].v;
+      rh->hit.primID = b->primID[best & 3]; rh->hit.geomID = g;
+      rh->hit.instID = INVALID_ID; rh->hit.instPrimID = INVALID_ID;
+      break;
+    }
+  }
+}
+static int quad_leaf_occluded(Scene* s, const Ray* ray, size_t start, size_t num) {
+  for (size_t k = 0; k < num; k++) {
+    const Tri4* b = &s->blocks[start + k];
+    s->stat_blocks++;
+    for (int l = 0; l < 8; l++) {
+      QLane q; quad_lane(s, b, l, ray, &q);
+      if (q.valid && (s->mesh[b->geomID[l & 3]].mask & ray->mask) != 0) return 1;
+    }
+  }
+  return 0;
+}
+
 /* ArrayIntersector1::intersect (kernels/geometry/intersector_iterators.h:23-28) over the leaf's blocks,
    each block = MoellerTrumbore x4 + Intersect1EpilogM<4,true> (kernels/geometry/intersector_epilog.h:235-300) */
 static void leaf_intersect(Scene* s, RayHit* rh, size_t start, size_t num) {
@@ -553,7 +645,7 @@ static void intersect1(Scene* s, RayHit* rh) {
     if (cur == EMPTY_REF) continue;
     size_t start, num; dec_leaf(cur, &start, &num);
     s->stat_leaves++;
-    leaf_intersect(s, rh, start, num);
+    if (s->quads) quad_leaf_intersect(s, rh, start, num); else leaf_intersect(s, rh, start, num);
     tr.tfar = rh->ray.tfar; /* :105 */
   }
 }
@@ -580,7 +672,7 @@ static void occluded1(Scene* s, Ray* ray) {
     if (cur == EMPTY_REF) continue;
     size_t start, num; dec_leaf(cur, &start, &num);
     s->stat_leaves++;
-    if (leaf_occluded(s, ray, start, num)) { ray->tfar = -INFINITY; break; }
+    if (s->quads ? quad_leaf_occluded(s, ray, start, num) : leaf_occluded(s, ray, start, num)) { ray->tfar = -INFINITY; break; }
   }
 }
 
@@ -595,7 +687,17 @@ API void ora_triangle_t(Scene* s, const RayHit* rh, const uint32_t* geomID, cons
     t_out[i] = NAN;
     uint32_t g = geomID[i], p = primID[i];
     if (g >= s->nmesh || p >= s->mesh[g].nt) continue;
-    const Mesh* m = &s->mesh[g]; const uint32_t* tri = m->t + 3 * (size_t)p;
+    const Mesh* m = &s->mesh[g];
+    if (m->quad) {                                              /* a quad: the nearer of its two triangles */
+      const uint32_t* q = m->t + 4 * (size_t)p;
+      if (q[0] >= m->nv || q[1] >= m->nv || q[2] >= m->nv || q[3] >= m->nv) continue;
+      Tri4 b; memset(&b, 0, sizeof(b));
+      for (int d = 0; d < 3; d++) { b.v0[d][0] = m->v[3 * (size_t)q[0] + d]; b.e1[d][0] = m->v[3 * (size_t)q[1] + d]; b.e2[d][0] = m->v[3 * (size_t)q[2] + d]; b.v3[d][0] = m->v[3 * (size_t)q[3] + d]; }
+      b.geomID[0] = g; b.primID[0] = p;
+      for (int l = 0; l < 8; l += 4) { QLane ql; quad_lane(s, &b, l, &rh[i].ray, &ql); if (ql.valid && !(ql.t >= t_out[i])) t_out[i] = ql.t; }
+      continue;
+    }
+    const uint32_t* tri = m->t + 3 * (size_t)p;
     if (tri[0] >= m->nv || tri[1] >= m->nv || tri[2] >= m->nv) continue;
     Tri4 b; memset(&b, 0, sizeof(b));
     const float *v0 = m->v + 3 * (size_t)tri[0], *v1 = m->v + 3 * (size_t)tri[1], *v2 = m->v + 3 * (size_t)tri[2];

@@ -25,6 +25,8 @@ def _load():
         L.ora_add_mesh.restype = ctypes.c_uint
         L.ora_add_mesh.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint, ctypes.c_void_p,
                                    ctypes.c_uint, ctypes.c_uint]
+        L.ora_add_quads.restype = ctypes.c_uint
+        L.ora_add_quads.argtypes = L.ora_add_mesh.argtypes
         L.ora_commit.argtypes = [ctypes.c_void_p]
         L.ora_set_robust.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.ora_bounds.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
@@ -39,24 +41,42 @@ def _load():
 
 
 class OracleScene:
+    """One scene of the reference = one BVH per geometry type, queried in turn (Scene::commit kernels/common/scene.cpp:777-779: triangle accel, then
+    quad accel; AccelN::intersect kernels/common/acceln.cpp:44-50).  geomIDs are shared: a mesh occupies its id in both trees, empty in the other."""
+
     def __init__(self, robust=False):
-        """robust=True restates RTC_SCENE_FLAG_ROBUST: Triangle4v leaves, Pluecker test, conservative node test."""
-        self._h = _load().ora_new()
+        """robust=True restates RTC_SCENE_FLAG_ROBUST: Triangle4v / Quad4v leaves, Pluecker test, conservative node test."""
+        L = _load()
+        self._h, self._hq = L.ora_new(), L.ora_new()
+        self._has_quads = False
         if robust:
-            _load().ora_set_robust(self._h, 1)
+            L.ora_set_robust(self._h, 1)
+            L.ora_set_robust(self._hq, 1)
 
     def add_mesh(self, verts, tris, mask=1):
         v = np.ascontiguousarray(verts, np.float32).reshape(-1, 3)
         t = np.ascontiguousarray(tris, np.uint32).reshape(-1, 3)
-        return _load().ora_add_mesh(self._h, v.ctypes.data, v.shape[0], t.ctypes.data, t.shape[0], mask)
+        L = _load()
+        L.ora_add_quads(self._hq, None, 0, None, 0, mask)
+        return L.ora_add_mesh(self._h, v.ctypes.data, v.shape[0], t.ctypes.data, t.shape[0], mask)
+
+    def add_quads(self, verts, quads, mask=1):
+        v = np.ascontiguousarray(verts, np.float32).reshape(-1, 3)
+        q = np.ascontiguousarray(quads, np.uint32).reshape(-1, 4)
+        L = _load()
+        self._has_quads = True
+        L.ora_add_mesh(self._h, None, 0, None, 0, mask)
+        return L.ora_add_quads(self._hq, v.ctypes.data, v.shape[0], q.ctypes.data, q.shape[0], mask)
 
     def commit(self):
         _load().ora_commit(self._h)
+        _load().ora_commit(self._hq)
 
     def bounds(self):
-        b = np.zeros(6, np.float32)
+        b, c = np.zeros(6, np.float32), np.zeros(6, np.float32)
         _load().ora_bounds(self._h, b.ctypes.data)
-        return b[:3].copy(), b[3:].copy()
+        _load().ora_bounds(self._hq, c.ctypes.data)
+        return np.minimum(b[:3], c[:3]), np.maximum(b[3:], c[3:])
 
     def counts(self):
         c = np.zeros(4, np.uint64)
@@ -71,25 +91,33 @@ class OracleScene:
     def intersect1(self, rayhits):
         assert rayhits.flags["C_CONTIGUOUS"] and rayhits.dtype.itemsize == 96
         _load().ora_intersect1(self._h, rayhits.ctypes.data, rayhits.shape[0])
+        if self._has_quads:
+            _load().ora_intersect1(self._hq, rayhits.ctypes.data, rayhits.shape[0])
 
     def occluded1(self, rays):
         assert rays.flags["C_CONTIGUOUS"] and rays.dtype.itemsize == 48
         _load().ora_occluded1(self._h, rays.ctypes.data, rays.shape[0])
+        if self._has_quads:
+            _load().ora_occluded1(self._hq, rays.ctypes.data, rays.shape[0])
 
     def triangle_t(self, rayhits_in, geomID, primID):
-        """t of ray i against the single triangle (geomID[i], primID[i]); NaN if not hit.
+        """t of ray i against the single primitive (geomID[i], primID[i]) (a quad: the nearer of its two triangles); NaN if not hit.
         `rayhits_in` must carry the ORIGINAL tnear/tfar (not a traced result)."""
         g = np.ascontiguousarray(geomID, np.uint32)
         p = np.ascontiguousarray(primID, np.uint32)
         out = np.zeros(rayhits_in.shape[0], np.float32)
-        _load().ora_triangle_t(self._h, rayhits_in.ctypes.data, g.ctypes.data, p.ctypes.data, out.ctypes.data,
-                               rayhits_in.shape[0])
+        _load().ora_triangle_t(self._h, rayhits_in.ctypes.data, g.ctypes.data, p.ctypes.data, out.ctypes.data, rayhits_in.shape[0])
+        if self._has_quads:
+            out2 = np.zeros_like(out)
+            _load().ora_triangle_t(self._hq, rayhits_in.ctypes.data, g.ctypes.data, p.ctypes.data, out2.ctypes.data, rayhits_in.shape[0])
+            out = np.where(np.isnan(out), out2, out)
         return out
 
     def close(self):
-        if self._h:
-            _load().ora_free(self._h)
-            self._h = None
+        for h in (getattr(self, "_h", None), getattr(self, "_hq", None)):
+            if h:
+                _load().ora_free(h)
+        self._h = self._hq = None
 
     def __del__(self):
         try:

@@ -14,6 +14,7 @@ Outputs
   ref_soup_8k.npz        8192 incoherent rays on a seeded 3,000-triangle soup (two geometries,
                          masks 1 and 2, ray masks alternating) incl. occluded results
   ref_trianglehit.npz    TriangleHitTest (tutorials/verify/verify.cpp:2462-2547) inputs + real-reference outputs
+  ref_quads.npz          a noisy 40x40 quad grid (RTC_GEOMETRY_TYPE_QUAD, mask 3) + a triangle sphere, 26,000 rays, fast and robust scenes
   ref_watertight_robust.npz  WatertightTest (verify.cpp:3611-3688) at its position (148376, 1234, -223423): triangle sphere of
                          radius 2 (numPhi 50), 8192 rays from inside, real reference with RTC_SCENE_FLAG_ROBUST
                          (BVH8Triangle4v + Pluecker + conservative node test); rtcIntersect1 and rtcOccluded1 results
@@ -111,6 +112,29 @@ def main():
     d = trace_ref([sph], make_rayhits(org, dirs), flags=4)          # RTC_SCENE_FLAG_ROBUST
     assert (d["hits"]["geomID"] == 0).all() and np.isneginf(d["occluded_tfar"]).all(), "the reference itself is not watertight here"
     np.savez_compressed(os.path.join(OUT, "ref_watertight_robust.npz"), **d)
+    # quads next to triangles (RTC_GEOMETRY_TYPE_QUAD, non-planar quads, geometry mask 3), fast and robust
+    k = 40
+    gy, gx = np.meshgrid(np.arange(k + 1, dtype=np.float32), np.arange(k + 1, dtype=np.float32), indexing="ij")
+    rq = np.random.default_rng(1)
+    qv = np.stack([gx / k, gy / k, 0.5 + 0.05 * rq.standard_normal(gx.shape).astype(np.float32)], -1).reshape(-1, 3).astype(np.float32)
+    ii = (np.arange(k)[:, None] * (k + 1) + np.arange(k)[None, :]).ravel()
+    qq = np.stack([ii, ii + 1, ii + k + 2, ii + k + 1], -1).astype(np.uint32)
+    tv, tt = W.triangle_sphere([0.5, 0.5, 0.2], 0.3, 12)
+    rays = np.concatenate([W.incoherent_rays(20000, [0.5, 0.5, 1.2], seed=1), W.incoherent_rays(6000, [0.5, 0.5, 0.25], seed=2)])
+    out = dict(tv=tv, tt=tt, qv=qv, qq=qq, rays=rays)
+    for fl, suffix in ((0, ""), (4, "_robust")):
+        sc = refembree.RefScene("threads=1", flags=fl)
+        sc.add_mesh(tv, tt)
+        sc.add_quads(qv, qq, 3)
+        sc.commit()
+        rh = rays.copy()
+        sc.intersect1(rh)
+        rr = rays_of(rays)
+        sc.occluded1(rr)
+        out["hits" + suffix], out["occl" + suffix] = rh, rr["tfar"].copy()
+        out["bounds_lo"], out["bounds_hi"] = sc.bounds()
+        sc.close()
+    np.savez_compressed(os.path.join(OUT, "ref_quads.npz"), **out)
     print("golden fixtures written to", OUT)
 
 

@@ -22,6 +22,7 @@ ap.add_argument("--reps", type=int, default=10)
 ap.add_argument("--any", action="store_true")
 ap.add_argument("--robust", action="store_true", help="RTC_SCENE_FLAG_ROBUST scene")
 ap.add_argument("--low", action="store_true", help="RTC_BUILD_QUALITY_LOW (Morton build)")
+ap.add_argument("--sort", default="", help="experiment: reorder the rays on the host before the upload: origin | origin+octant | octant")
 ap.add_argument("--powerplant", action="store_true", help="configs[4]: the 12.7 M triangle powerplant stand-in instead of the crown stand-in")
 ap.add_argument("--primary", action="store_true")
 ap.add_argument("--tag", default="")
@@ -50,6 +51,19 @@ if a.retrace:
     rays = rays.copy()
     rays["tfar"] = np.where(t2["geomID"] != 0xFFFFFFFF, t2["tfar"] * np.float32(1.000001), rays["tfar"])
     d2.free()
+if a.sort:
+    lo, hi = W.scene_bounds(meshes)
+    org = np.stack([rays["org_x"], rays["org_y"], rays["org_z"]], -1)
+    q = np.clip(((org - lo) / np.maximum(hi - lo, 1e-20) * 32).astype(np.int64), 0, 31)
+    def spread(v):
+        out = np.zeros_like(v)
+        for b in range(5):
+            out |= ((v >> b) & 1) << (3 * b)
+        return out
+    cell = spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2)
+    octant = (rays["dir_x"] < 0).astype(np.int64) | ((rays["dir_y"] < 0).astype(np.int64) << 1) | ((rays["dir_z"] < 0).astype(np.int64) << 2)
+    key = {"origin": cell, "origin+octant": (cell << 3) | octant, "octant": octant, "octant+origin": (octant << 15) | cell}[a.sort]
+    rays = rays[np.argsort(key, kind="stable")].copy()
 if a.any:
     rays = rays_of(rays)
 M, rec = rays.shape[0], rays.dtype.itemsize

@@ -263,7 +263,7 @@ def test_errors_and_state_machine(api, dev):
     L.rtcIntersect1(s.h, rh.ctypes.data, None)               # not committed: missing_rtcCommit -> INVALID_OPERATION
     assert dev.get_error() == api.RTC_ERROR_INVALID_OPERATION
     assert dev.get_error() == api.RTC_ERROR_NONE             # cleared on read
-    g = L.rtcNewGeometry(dev.h, api.RTC_GEOMETRY_TYPE_QUAD)   # feature outside the triangle path
+    g = L.rtcNewGeometry(dev.h, 2)                            # RTC_GEOMETRY_TYPE_GRID: a feature outside the triangle / quad path
     assert not g and dev.get_error() == api.RTC_ERROR_INVALID_OPERATION
     g = L.rtcNewGeometry(dev.h, api.RTC_GEOMETRY_TYPE_TRIANGLE)
     v = np.zeros(16, np.float32)
@@ -277,7 +277,7 @@ def test_errors_and_state_machine(api, dev):
     assert dev.get_error() == api.RTC_ERROR_INVALID_OPERATION
     L.rtcReleaseGeometry(g)
     # two errors: the first one is kept
-    L.rtcNewGeometry(dev.h, api.RTC_GEOMETRY_TYPE_QUAD)
+    L.rtcNewGeometry(dev.h, 2)
     L.rtcSetSharedGeometryBuffer(None, 0, 0, 0, None, 0, 0, 0)
     assert dev.get_error() == api.RTC_ERROR_INVALID_OPERATION
     s.release()
@@ -396,6 +396,52 @@ def test_tree_layout_is_bit_identical_across_rebuilds(api, dev):
         blobs.append((nodes.tobytes(), tris.tobytes(), s.info()["sah"]))
         s.release()
     assert blobs[0] == blobs[1] == blobs[2]
+
+
+# ---------------------------------------------------------------------- RTC_GEOMETRY_TYPE_QUAD (first half)
+def noisy_quad_grid(k, seed, z=0.5, amp=0.05):
+    gy, gx = np.meshgrid(np.arange(k + 1, dtype=np.float32), np.arange(k + 1, dtype=np.float32), indexing="ij")
+    rng = np.random.default_rng(seed)
+    v = np.stack([gx / k, gy / k, z + amp * rng.standard_normal(gx.shape).astype(np.float32)], -1).reshape(-1, 3).astype(np.float32)
+    i = (np.arange(k)[:, None] * (k + 1) + np.arange(k)[None, :]).ravel()
+    return v, np.stack([i, i + 1, i + k + 2, i + k + 1], -1).astype(np.uint32)      # non-planar quads
+
+
+@pytest.mark.parametrize("robust", [False, True])
+def test_quads_mixed_scene_vs_golden_and_oracle(api, dev, restate, golden_dir, robust):
+    """Quad meshes next to triangle meshes: primID = quad index, u/v/Ng of the quad (second half flipped like the reference's AVX quad
+    intersectors), against the REAL reference's outputs (tests/golden/ref_quads.npz) and the restatement; invalid quads are dropped whole."""
+    g = np.load(os.path.join(golden_dir, "ref_quads.npz"))
+    tv, tt, qv, qq = g["tv"], g["tt"], g["qv"], g["qq"]
+    flags = api.RTC_SCENE_FLAG_ROBUST if robust else 0
+    s = api.Scene(dev, flags)
+    o = restate.OracleScene(robust=robust)
+    assert s.add_triangle_mesh(tv, tt) == 0 and o.add_mesh(tv, tt) == 0
+    assert s.add_quad_mesh(qv, qq, mask=3) == 1 and o.add_quads(qv, qq, 3) == 1
+    s.commit()
+    o.commit()
+    rays = g["rays"]
+    want = g["hits_robust" if robust else "hits"]
+    got = rays.copy()
+    s.intersect1M(got)
+    st = compare_closest(got, want, rays, o.triangle_t, label="quads golden robust=%s" % robust)
+    assert (want["geomID"] == 1).sum() > 1000 and st["ties"] < 50
+    r = rays_of(rays)
+    s.occluded1M(r)
+    compare_occluded(r["tfar"], g["occl_robust" if robust else "occl"], rays_of(rays)["tfar"], label="quads occluded")
+    lo, hi = s.bounds()
+    assert (lo == g["bounds_lo"]).all() and (hi == g["bounds_hi"]).all()
+    info = s.info()
+    assert info["num_triangles"] == tt.shape[0] + 2 * qq.shape[0]
+    s.release()
+    # a quad with an out-of-range index or a non-finite vertex disappears as a whole (QuadMesh::buildBounds)
+    bad_v = np.concatenate([qv, np.array([[np.nan, 0, 0]], np.float32)])
+    bad_q = np.concatenate([qq[:50], np.array([[0, 1, 2, 9999999], [0, 1, qv.shape[0], 3]], np.uint32)])
+    s2 = api.Scene(dev, flags)
+    s2.add_quad_mesh(bad_v, bad_q)
+    s2.commit()
+    assert s2.info()["num_triangles"] == 100
+    s2.release()
 
 
 # ---------------------------------------------------------------------- RTC_BUILD_QUALITY_LOW (SURVEY 8f-3): Morton build

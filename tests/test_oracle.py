@@ -96,6 +96,27 @@ def test_oracle_robust_matches_golden_bit_exact(restate, golden_dir):
     assert (fh["tfar"].view(np.uint32) != rh["tfar"].view(np.uint32)).any()
 
 
+@pytest.mark.parametrize("robust", [False, True])
+def test_oracle_quads_match_golden_bit_exact(restate, golden_dir, robust):
+    """Quad restatement (one BVH per geometry type, 8-lane quad leaves, fast and robust) against the real reference's outputs."""
+    g = np.load(os.path.join(golden_dir, "ref_quads.npz"))
+    o = restate.OracleScene(robust=robust)
+    o.add_mesh(g["tv"], g["tt"])
+    o.add_quads(g["qv"], g["qq"], 3)
+    o.commit()
+    rh = g["rays"].copy()
+    o.intersect1(rh)
+    want = g["hits_robust" if robust else "hits"]
+    for f in ("tfar", "u", "v", "Ng_x", "Ng_y", "Ng_z", "primID", "geomID"):
+        assert (_bits(rh[f]) == _bits(want[f])).all(), f
+    r = rays_of(g["rays"])
+    o.occluded1(r)
+    assert (_bits(r["tfar"]) == _bits(g["occl_robust" if robust else "occl"])).all()
+    lo, hi = o.bounds()
+    assert (lo == g["bounds_lo"]).all() and (hi == g["bounds_hi"]).all()
+    assert ((want["geomID"] == 1).sum() > 1000)
+
+
 def test_triangle_hit_known_answer(restate, golden_dir):
     """TriangleHitTest: geomID 0, primID 0, |u-u0|,|v-v0|,|t-1| <= 16 ulp, Ng == (0,0,1) +- 16 ulp."""
     g = np.load(os.path.join(golden_dir, "ref_trianglehit.npz"))
