@@ -349,6 +349,60 @@ __device__ __forceinline__ void lane_runs_flush_wave(LaneRuns& r, uint32_t* bins
   }
 }
 
+// Row aggregation for top_bin: the 16 lanes of a DPP row hold 16 consecutive triangles, which sit in one bin per axis or straddle ONE bin
+// boundary (measured with cycle counters on the crown stand-in: consecutive triangles march along a ring of a sphere, 16 of them cover
+// about one bin width, so "everything in one bin" is the exception there).  A row therefore forms two groups, the lanes in its lowest and
+// in its highest bin, reduces each with four row_shr steps (result in lane 15 of the row) and that lane issues 7 atomics per group;
+// a lane strictly between the two, and rows holding the end of the chunk, go lane by lane.  At most 4 x 14 instead of 64 x 7 same-word
+// LDS atomics per axis and batch -- the atomics are what top_bin waits for (PMC: SQ_WAIT_INST_LDS 73 % of the wave cycles).
+__device__ __forceinline__ uint32_t row_umin15(uint32_t v) {
+  v = min(v, dpp_u<0x111, 0xF>(v, v)); v = min(v, dpp_u<0x112, 0xF>(v, v)); v = min(v, dpp_u<0x114, 0xF>(v, v)); v = min(v, dpp_u<0x118, 0xF>(v, v));
+  return v;
+}
+__device__ __forceinline__ uint32_t row_umax15(uint32_t v) {
+  v = max(v, dpp_u<0x111, 0xF>(v, v)); v = max(v, dpp_u<0x112, 0xF>(v, v)); v = max(v, dpp_u<0x114, 0xF>(v, v)); v = max(v, dpp_u<0x118, 0xF>(v, v));
+  return v;
+}
+__device__ __forceinline__ void bins_add_rows(uint32_t* bins, const Mapping& m, const PrimRef& p, bool valid, uint32_t lane) {
+  uint32_t c[6];
+  for (int k = 0; k < 3; k++) { c[k] = enc(p.lo[k]); c[3 + k] = enc(p.hi[k]); }
+  const unsigned long long vm = __ballot(valid);
+  const uint32_t rowBase = lane & 48u;
+  const bool rowFull = ((vm >> rowBase) & 0xFFFFull) == 0xFFFFull;          // all 16 lanes of my row hold a triangle
+#pragma unroll
+  for (int d = 0; d < 3; d++) {
+    const uint32_t b = valid ? (uint32_t)bin_clamped(p.lo[d] + p.hi[d], m.ofs[d], m.scale[d], m.nb) : 0u;
+    // the row's lowest and highest bin (lane 15 holds the reduction; everybody reads it from there)
+    const uint32_t bmin = (uint32_t)__shfl((int)row_umin15(b), (int)(lane | 15u), 64), bmax = (uint32_t)__shfl((int)row_umax15(b), (int)(lane | 15u), 64);
+    const bool inLo = rowFull && b == bmin, inHi = rowFull && b == bmax && bmax != bmin;
+    // 16 consecutive triangles sit in one bin or straddle one boundary: two groups cover the row; a lane strictly between goes alone
+    uint32_t lo[6], hi[6];
+    for (int k = 0; k < 3; k++) {
+      lo[k] = row_umin15(inLo ? c[k] : 0xFFFFFFFFu); lo[3 + k] = row_umax15(inLo ? c[3 + k] : 0u);
+      hi[k] = row_umin15(inHi ? c[k] : 0xFFFFFFFFu); hi[3 + k] = row_umax15(inHi ? c[3 + k] : 0u);
+    }
+    const uint32_t nLo = (uint32_t)__popcll((__ballot(inLo) >> rowBase) & 0xFFFFull), nHi = (uint32_t)__popcll((__ballot(inHi) >> rowBase) & 0xFFFFull);
+    if ((lane & 15u) == 15u && rowFull) {
+      uint32_t* e = bins + (d * NBINS + bmin) * BINW;
+      atomicMin(&e[0], lo[0]); atomicMin(&e[1], lo[1]); atomicMin(&e[2], lo[2]);
+      atomicMax(&e[3], lo[3]); atomicMax(&e[4], lo[4]); atomicMax(&e[5], lo[5]);
+      atomicAdd(&e[6], nLo);
+      if (nHi) {
+        uint32_t* f = bins + (d * NBINS + bmax) * BINW;
+        atomicMin(&f[0], hi[0]); atomicMin(&f[1], hi[1]); atomicMin(&f[2], hi[2]);
+        atomicMax(&f[3], hi[3]); atomicMax(&f[4], hi[4]); atomicMax(&f[5], hi[5]);
+        atomicAdd(&f[6], nHi);
+      }
+    }
+    if (valid && !inLo && !inHi) {
+      uint32_t* e = bins + (d * NBINS + b) * BINW;
+      atomicMin(&e[0], c[0]); atomicMin(&e[1], c[1]); atomicMin(&e[2], c[2]);
+      atomicMax(&e[3], c[3]); atomicMax(&e[4], c[4]); atomicMax(&e[5], c[5]);
+      atomicAdd(&e[6], 1u);
+    }
+  }
+}
+
 struct SplitResult { float sah; int dim, pos; uint32_t nL; float llo[3], lhi[3], rlo[3], rhi[3]; };
 
 // BinInfoT::best (heuristic_binning.h:339-386) by ONE wavefront as two scans: lanes 0-31 hold the 32 bins of one axis, lanes
@@ -438,13 +492,11 @@ __global__ __launch_bounds__(256) void top_bin(const Seg* segs, const Chunk* chu
   __syncthreads();
   {                                                             // each wave owns a contiguous quarter of the chunk (see BinRuns)
     const uint32_t lane = tid & 63u, span = ck.begin + (tid >> 6) * (CHUNK / 4u), spanEnd = min(span + CHUNK / 4u, ck.end);
-    LaneRuns runs; lane_runs_init(runs);
     for (uint32_t i0 = span; i0 < spanEnd; i0 += 64u) {         // wave-uniform trip count
       const uint32_t i = i0 + lane; const bool v = i < spanEnd;
       PrimRef r{}; if (v) r = load_prim(src + i);
-      lane_runs_add(runs, s_bins, m, r, v);
+      bins_add_rows(s_bins, m, r, v, lane);
     }
-    lane_runs_flush_wave(runs, s_bins, lane);
   }
   __syncthreads();
   uint32_t* g = bins + (size_t)ck.seg * BINS_WORDS;
