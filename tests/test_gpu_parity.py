@@ -398,6 +398,31 @@ def test_tree_layout_is_bit_identical_across_rebuilds(api, dev):
     assert blobs[0] == blobs[1] == blobs[2]
 
 
+@pytest.mark.parametrize("quality", [None, 0])
+def test_degenerate_inputs_at_scale(api, dev, quality):
+    """Inputs that defeat the heuristics must neither hang nor lose triangles: 300,000 coincident triangles (every SAH split invalid -> median
+    splits all the way down; equal Morton codes), plus two far outliers that stretch the scene bounds by 10^6, plus zero-area triangles."""
+    base = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32)
+    n = 300000
+    v = np.tile(base, (n, 1))
+    t = np.arange(3 * n, dtype=np.uint32).reshape(-1, 3)
+    far = np.array([[1e6, 1e6, 1e6], [1e6 + 1, 1e6, 1e6], [1e6, 1e6 + 1, 1e6], [-1e6, 0, 0], [-1e6, 1, 0], [-1e6, 0, 1], [5, 5, 5], [5, 5, 5], [5, 5, 5]], np.float32)
+    m = [(v, t), (far, np.arange(9, dtype=np.uint32).reshape(-1, 3))]
+    s = api.make_scene(dev, m, quality=quality)
+    info = s.info()
+    assert info["num_triangles"] == n + 3 and info["depth"] < 64
+    rays = make_rayhits(np.array([[0.25, 0.25, -1], [1e6 + 0.25, 1e6 + 0.25, 1e6 - 1], [-1e6, 0.25, 0.25 - 1 + 1], [9, 9, 9]], np.float32),
+                        np.array([[0, 0, 1], [0, 0, 1], [0, 0, 1], [0, 0, 1]], np.float32))
+    rays["org_x"][2], rays["org_y"][2], rays["org_z"][2] = -1e6 - 1, 0.25, 0.25
+    rays["dir_x"][2], rays["dir_y"][2], rays["dir_z"][2] = 1, 0, 0
+    s.intersect1M(rays)
+    assert rays["geomID"][0] == 0 and rays["tfar"][0] == 1.0          # one of the 300,000 (which one is an exact tie)
+    assert rays["geomID"][1] == 1 and rays["primID"][1] == 0
+    assert rays["geomID"][2] == 1 and rays["primID"][2] == 1
+    assert rays["geomID"][3] == INVALID_ID
+    s.release()
+
+
 # ---------------------------------------------------------------------- RTC_GEOMETRY_TYPE_QUAD (SURVEY 8f-4, first half)
 def noisy_quad_grid(k, seed, z=0.5, amp=0.05):
     gy, gx = np.meshgrid(np.arange(k + 1, dtype=np.float32), np.arange(k + 1, dtype=np.float32), indexing="ij")
