@@ -1350,11 +1350,12 @@ TraceScratch* Bvh::scratch_for(hipStream_t s) {
   if (hipMalloc((void**)&sc.counter, 4096) != hipSuccess) return nullptr;
   if (hipMalloc(&sc.spill, trace_spill_bytes(numCUs, info.depth)) != hipSuccess) return nullptr;
   if (hipMalloc((void**)&sc.stats, 128) != hipSuccess) return nullptr;
+  sc.enqueue = new std::mutex;
   return &(scratch[s] = sc);
 }
 Bvh::~Bvh() {
   hipSetDevice(device);
-  for (auto& kv : scratch) { hipFree(kv.second.counter); hipFree(kv.second.spill); hipFree(kv.second.stats); }
+  for (auto& kv : scratch) { hipFree(kv.second.counter); hipFree(kv.second.spill); hipFree(kv.second.stats); delete kv.second.enqueue; }
   if (d_nodes) hipFree(d_nodes);
   if (d_tris) hipFree(d_tris);
 }

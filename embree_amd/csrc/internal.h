@@ -17,6 +17,7 @@ int set_error(hipError_t e, const char* what);          // records text for mi35
   } while (0)
 
 struct TraceScratch {
+  std::mutex* enqueue = nullptr; // a launch = cursor reset + kernel: the two must reach the stream back to back (several host threads may query one scene)
   uint32_t* counter = nullptr;   // ray cursor of the persistent kernel
   void* spill = nullptr;         // stack spill area
   uint64_t* stats = nullptr;     // 8 counters for the counting build

@@ -559,6 +559,7 @@ static int launch_trace(Bvh* b, void* d_rays, uint32_t count, size_t stride, boo
   if (blocks > maxBlocks) blocks = maxBlocks;
   TraceScratch* sc = b->scratch_for(s);
   if (!sc) return set_error(hipErrorOutOfMemory, "trace scratch allocation failed");
+  std::lock_guard<std::mutex> enqueueLock(*sc->enqueue);       // rtcIntersect* are thread safe: another thread's reset must not slip between my reset and my kernel
   HIP_TRY(hipMemsetAsync(sc->counter, 0, NUM_CURSORS * CURSOR_STRIDE * sizeof(uint32_t), s));
   TraceArgs a;
   a.nodes = (const uint4*)b->d_nodes; a.tris = (const float4*)b->d_tris; a.hasRoot = b->root != MI355_EMPTY_REF ? 1u : 0u;

@@ -398,6 +398,58 @@ def test_tree_layout_is_bit_identical_across_rebuilds(api, dev):
     assert blobs[0] == blobs[1] == blobs[2]
 
 
+def test_queries_are_thread_safe_and_streams_independent(api, dev, restate):
+    """rtcIntersect1M / rtcOccluded1M from several host threads on one committed scene (doc/src/api/rtcIntersect1.md: thread safe), and
+    rtcIntersect1MDevice on four streams at once (each stream has its own traversal scratch): every call returns the single-threaded answer."""
+    import threading
+    meshes = W.synthetic_crown(num_phi=20)
+    s = api.make_scene(dev, meshes)
+    L = api.load()
+    rays = [W.incoherent_rays(30000, [2, 2, 1.5], seed=20 + k) for k in range(6)]
+    want = []
+    for r in rays:
+        w = r.copy()
+        s.intersect1M(w)
+        want.append(w)
+    got = [r.copy() for r in rays]
+    occ = [rays_of(r) for r in rays]
+    errs = []
+
+    def work(k):
+        try:
+            for _ in range(3):
+                g = rays[k].copy()
+                s.intersect1M(g)
+                assert g.tobytes() == want[k].tobytes()
+            s.intersect1M(got[k])
+            s.occluded1M(occ[k])
+        except Exception as e:            # noqa: BLE001
+            errs.append(repr(e))
+    th = [threading.Thread(target=work, args=(k,)) for k in range(6)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+    for k in range(6):
+        assert got[k].tobytes() == want[k].tobytes()
+        assert (np.isneginf(occ[k]["tfar"]) == (want[k]["geomID"] != INVALID_ID)).all()
+    # device-pointer entry point on four streams, launches interleaved
+    streams, bufs = [], []
+    for k in range(4):
+        st = C.c_void_p()
+        L.mi355_stream_create(0, C.byref(st))
+        streams.append(st)
+        bufs.append(api.DeviceArray.from_numpy(rays[k]))
+    for rep in range(3):
+        for k in range(4):
+            s.intersect1M_device(bufs[k].ptr, rays[k].shape[0], 96, streams[k])
+    L.mi355_device_synchronize(0)
+    for k in range(4):      # tracing a traced buffer again must not change it (tfar already holds the hit distance: same hit, inclusive at tfar)
+        assert bufs[k].download(RAYHIT_DTYPE).tobytes() == want[k].tobytes()
+        bufs[k].free()
+        L.mi355_stream_destroy(streams[k])
+    s.release()
+
+
 @pytest.mark.parametrize("quality", [None, 0])
 def test_degenerate_inputs_at_scale(api, dev, quality):
     """Inputs that defeat the heuristics must neither hang nor lose triangles: 300,000 coincident triangles (every SAH split invalid -> median
