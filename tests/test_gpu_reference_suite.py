@@ -1,0 +1,212 @@
+"""More of the reference's own test programme (tutorials/verify/verify.cpp), through the C ABI on the GPU (pytest -m gpu):
+QuadHitTest :2549, UpdateTest :1835, GarbageGeometryTest :1915, UserGeometryIDTest :1591, NewDeleteGeometryTest :1523 / IntensiveRegressionTest :5298
+(reduced), MultipleDevicesTest :764, GetUserDataTest :865, EmptyGeometryTest :1086, OverlappingGeometryTest :1209, DisableAndDetachGeometryTest :1700.
+Expected values are the reference's (16 ulp on t/u/v/Ng where it states them); everything else is "no error, no hang, right geometry hit"."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from embree_amd import workloads as W
+from embree_amd.rtypes import make_rayhits, rays_of, INVALID_ID
+
+pytestmark = pytest.mark.gpu
+ULP = np.float32(1.1920929e-07)
+
+
+@pytest.fixture(scope="module")
+def api():
+    from embree_amd import api as A
+    A.load()
+    assert A.load().mi355_device_count() > 0, "no HIP device: the product has no CPU fallback"
+    return A
+
+
+@pytest.fixture(scope="module")
+def dev(api):
+    d = api.Device("gpu=0")
+    yield d
+    d.release()
+
+
+@pytest.mark.parametrize("flags", [0, 4])
+def test_quad_hit(api, dev, flags):
+    """QuadHitTest: unit quad, 256 rays from (0,0,-1) to v0 + u (v1-v0) + v (v3-v0): primID 0, u, v, t = 1, Ng = (0,0,1) within 16 ulp."""
+    rng = np.random.default_rng(3)
+    u, v = rng.random(256, dtype=np.float32), rng.random(256, dtype=np.float32)
+    edge = (u < 0.001) | (v < 0.001) | (u > 0.999) | (v > 0.999)
+    u[edge], v[edge] = 0.333, 0.333
+    s = api.Scene(dev, flags)
+    s.add_quad_mesh(np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0]], np.float32), np.array([[0, 1, 2, 3]], np.uint32))
+    s.commit()
+    org = np.tile(np.array([[0, 0, -1]], np.float32), (256, 1))
+    to = np.stack([u, v, np.zeros_like(u)], -1)
+    rh = make_rayhits(org, to - org)
+    s.intersect1M(rh)
+    assert (rh["primID"] == 0).all() and (rh["geomID"] == 0).all()
+    assert np.abs(rh["u"] - u).max() <= 16 * ULP and np.abs(rh["v"] - v).max() <= 16 * ULP and np.abs(rh["tfar"] - 1).max() <= 16 * ULP
+    assert np.abs(rh["Ng_x"]).max() <= 16 * ULP and np.abs(rh["Ng_y"]).max() <= 16 * ULP and np.abs(rh["Ng_z"] - 1).max() <= 16 * ULP
+    r = rays_of(make_rayhits(org, to - org))
+    s.occluded1M(r)
+    assert np.isneginf(r["tfar"]).all()
+    s.release()
+
+
+def test_update_geometry_buffers(api, dev):
+    """UpdateTest: a triangle sphere and a quad sphere whose vertex buffers are moved in place (rtcGetGeometryBufferData, rtcUpdateGeometryBuffer,
+    rtcCommitGeometry, rtcCommitScene); after every step a ray from above must hit the geometry it is aimed at, closest hit and occlusion."""
+    L = api.load()
+    s = api.Scene(dev)
+    num_phi = 10
+    tv, tt = W.triangle_sphere([-10, 0, -10], 1.0, num_phi)
+    # quad sphere: the same rings as quads (poles stay triangles in the reference; a quad with a repeated vertex is legal)
+    nt = 2 * num_phi
+    q = []
+    for ph in range(num_phi):
+        for th in range(nt):
+            a, b = ph * nt + th, ph * nt + (th + 1) % nt
+            q.append([a, b, b + nt, a + nt])
+    qv, _ = W.triangle_sphere([-10, 0, 10], 1.0, num_phi)
+    geoms, pos = [], [np.array([-10, 0, -10], np.float32), np.array([-10, 0, 10], np.float32)]
+    for kind, (v, idx) in (("tri", (tv, tt)), ("quad", (qv, np.array(q, np.uint32)))):
+        g = L.rtcNewGeometry(dev.h, api.RTC_GEOMETRY_TYPE_TRIANGLE if kind == "tri" else api.RTC_GEOMETRY_TYPE_QUAD)
+        pv = L.rtcSetNewGeometryBuffer(g, api.RTC_BUFFER_TYPE_VERTEX, 0, api.RTC_FORMAT_FLOAT3, 12, v.shape[0])
+        pi = L.rtcSetNewGeometryBuffer(g, api.RTC_BUFFER_TYPE_INDEX, 0, api.RTC_FORMAT_UINT3 if kind == "tri" else api.RTC_FORMAT_UINT4,
+                                       12 if kind == "tri" else 16, idx.shape[0])
+        dev.check()
+        C.memmove(pv, np.ascontiguousarray(v).ctypes.data, v.nbytes)
+        C.memmove(pi, np.ascontiguousarray(idx).ctypes.data, idx.nbytes)
+        L.rtcCommitGeometry(g)
+        gid = L.rtcAttachGeometry(s.h, g)
+        L.rtcReleaseGeometry(g)
+        geoms.append((gid, v.shape[0]))
+    for step in range(8):
+        for k, (gid, nv) in enumerate(geoms):
+            if step & (1 << k):
+                h = L.rtcGetGeometry(s.h, gid)
+                p = L.rtcGetGeometryBufferData(h, api.RTC_BUFFER_TYPE_VERTEX, 0)
+                arr = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_float)), shape=(nv, 3))
+                arr += np.array([2, 0.1, 2], np.float32)
+                L.rtcUpdateGeometryBuffer(h, api.RTC_BUFFER_TYPE_VERTEX, 0)
+                L.rtcCommitGeometry(h)
+                pos[k] = pos[k] + np.array([2, 0.1, 2], np.float32)
+        s.commit()
+        org = np.stack([p + np.array([0.1, 10, 0.1], np.float32) for p in pos] * 25)
+        rh = make_rayhits(org, np.tile(np.array([[0, -1, 0]], np.float32), (org.shape[0], 1)))
+        s.intersect1M(rh)
+        assert (rh["geomID"] == np.array([g for g, _ in geoms] * 25, np.uint32)).all(), step
+        r = rays_of(make_rayhits(org, np.tile(np.array([[0, -1, 0]], np.float32), (org.shape[0], 1))))
+        s.occluded1M(r)
+        assert np.isneginf(r["tfar"]).all()
+    s.release()
+
+
+def test_garbage_geometry(api, dev):
+    """GarbageGeometryTest: meshes filled with random BITS (NaNs, infinities, denormals, huge values, out-of-range indices), triangles and quads,
+    fast / robust / low-quality scenes: commit and queries must come back without an error and without hanging."""
+    rng = np.random.default_rng(23565)
+    for i in range(24):
+        s = api.Scene(dev, api.RTC_SCENE_FLAG_ROBUST if i % 3 == 1 else 0, api.RTC_BUILD_QUALITY_LOW if i % 4 == 3 else None)
+        total = 0
+        for j in range(8):
+            n = int(rng.integers(0, 256))
+            nv = max(3 * n, 4)
+            v = rng.integers(0, 2 ** 32, size=(nv, 3), dtype=np.uint64).astype(np.uint32).view(np.float32)
+            if j % 2:
+                idx = rng.integers(0, 2 ** 32, size=(n, 4 if j % 4 == 1 else 3), dtype=np.uint64).astype(np.uint32)      # garbage topology too
+            else:
+                idx = rng.integers(0, nv, size=(n, 4 if j % 4 == 0 else 3), dtype=np.uint64).astype(np.uint32)
+            (s.add_quad_mesh if idx.shape[1] == 4 else s.add_triangle_mesh)(v, idx)
+            total += n
+        s.commit()
+        rays = W.incoherent_rays(2000, [0, 0, 0], seed=i)
+        s.intersect1M(rays)
+        r = rays_of(W.incoherent_rays(2000, [0, 0, 0], seed=i))
+        s.occluded1M(r)
+        assert s.info()["num_triangles"] <= 2 * total
+        s.release()
+    dev.check()
+
+
+def test_attach_by_id_user_data_and_detach(api, dev):
+    """UserGeometryIDTest (rtcAttachGeometryByID), GetUserDataTest, DisableAndDetachGeometryTest: IDs chosen by the caller come back in the hits,
+    user data round-trips, a detached / disabled geometry is not hit after the next commit and its ID can be reused."""
+    L = api.load()
+    L.rtcSetGeometryUserData.argtypes = [C.c_void_p, C.c_void_p]
+    L.rtcGetGeometryUserData.restype = C.c_void_p
+    L.rtcGetGeometryUserData.argtypes = [C.c_void_p]
+    s = api.Scene(dev)
+    keep, ids = [], [7, 3, 1000, 42]
+    for k, gid in enumerate(ids):
+        v = np.array([[0, 0, k], [1, 0, k], [0, 1, k], [0, 0, 0]], np.float32)
+        t = np.array([[0, 1, 2]], np.uint32)
+        keep += [v, t]
+        g = L.rtcNewGeometry(dev.h, api.RTC_GEOMETRY_TYPE_TRIANGLE)
+        L.rtcSetSharedGeometryBuffer(g, api.RTC_BUFFER_TYPE_VERTEX, 0, api.RTC_FORMAT_FLOAT3, v.ctypes.data, 0, 12, 3)
+        L.rtcSetSharedGeometryBuffer(g, api.RTC_BUFFER_TYPE_INDEX, 0, api.RTC_FORMAT_UINT3, t.ctypes.data, 0, 12, 1)
+        L.rtcSetGeometryUserData(g, C.c_void_p(0x1000 + gid))
+        L.rtcCommitGeometry(g)
+        L.rtcAttachGeometryByID(s.h, g, gid)
+        L.rtcReleaseGeometry(g)
+    dev.check()
+    s.commit()
+    for gid in ids:
+        assert L.rtcGetGeometryUserData(L.rtcGetGeometry(s.h, gid)) == 0x1000 + gid
+    org = np.array([[0.2, 0.2, k - 0.5] for k in range(4)], np.float32)
+    rh = make_rayhits(org, np.tile(np.array([[0, 0, 1]], np.float32), (4, 1)))
+    s.intersect1M(rh)
+    assert (rh["geomID"] == np.array(ids, np.uint32)).all() and np.allclose(rh["tfar"], 0.5)
+    L.rtcDetachGeometry(s.h, 3)                                   # the triangle at z = 1 goes away ...
+    L.rtcDisableGeometry(L.rtcGetGeometry(s.h, 1000))             # ... and the one at z = 2 is switched off
+    s.commit()
+    rh = make_rayhits(org, np.tile(np.array([[0, 0, 1]], np.float32), (4, 1)))
+    s.intersect1M(rh)
+    assert list(rh["geomID"]) == [7, 42, 42, 42] and np.allclose(rh["tfar"], [0.5, 2.5, 1.5, 0.5])
+    assert s.add_triangle_mesh(keep[0], keep[1]) in (0, 3)         # a free ID is handed out again (lowest free one)
+    dev.check()
+    s.release()
+
+
+def test_many_scenes_devices_and_empty_geometry(api, dev):
+    """MultipleDevicesTest + NewDeleteGeometryTest / IntensiveRegressionTest (reduced) + EmptyGeometryTest + OverlappingGeometryTest: several devices
+    and scenes alive at once, geometries created, committed, detached and re-created in a loop, empty geometries, 20,000 overlapping copies."""
+    L = api.load()
+    devs = [api.Device("gpu=0") for _ in range(3)]
+    scenes = []
+    rng = np.random.default_rng(9)
+    for d in devs:
+        s = api.Scene(d)
+        g = L.rtcNewGeometry(d.h, api.RTC_GEOMETRY_TYPE_TRIANGLE)          # EmptyGeometryTest: no buffers at all
+        L.rtcCommitGeometry(g)
+        L.rtcAttachGeometry(s.h, g)
+        L.rtcReleaseGeometry(g)
+        s.add_triangle_mesh(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.uint32))   # zero-sized buffers
+        s.commit()
+        d.check()
+        assert s.info()["num_triangles"] == 0
+        scenes.append(s)
+    for it in range(12):                                             # geometry churn on every device
+        for d, s in zip(devs, scenes):
+            n = int(rng.integers(1, 400))
+            c = rng.random((n, 1, 3), dtype=np.float32)
+            v = (c + 0.05 * rng.random((n, 3, 3), dtype=np.float32)).reshape(-1, 3).astype(np.float32)
+            gid = s.add_triangle_mesh(v, np.arange(3 * n, dtype=np.uint32).reshape(-1, 3))
+            if it % 3 == 2:
+                L.rtcDetachGeometry(s.h, gid)
+            s.commit()
+            r = W.incoherent_rays(512, [0.5, 0.5, 0.5], seed=it)
+            s.intersect1M(r)
+            d.check()
+    base = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32)   # OverlappingGeometryTest
+    s = api.Scene(devs[0])
+    for _ in range(4):
+        s.add_triangle_mesh(np.tile(base, (5000, 1)), np.arange(15000, dtype=np.uint32).reshape(-1, 3))
+    s.commit()
+    rh = make_rayhits(np.array([[0.2, 0.2, -1]], np.float32), np.array([[0, 0, 1]], np.float32))
+    s.intersect1M(rh)
+    assert rh["geomID"][0] != INVALID_ID and rh["tfar"][0] == 1.0
+    s.release()
+    for s in scenes:
+        s.release()
+    for d in devs:
+        d.release()
