@@ -53,7 +53,13 @@ struct Device : RefCounted {
   std::string name;
   static size_t threadToken() { static thread_local char t; return (size_t)&t; }
   ErrState& err() { std::lock_guard<std::mutex> lk(errMutex); return errors[threadToken()]; }
-  ~Device() override { mi355_release_build_scratch(gpu); }   // the build arena of this GPU goes back to the driver with the last user
+  ~Device() override { mi355_release_build_scratch(gpu); }
+  // Device::memoryMonitor (kernels/common/device.cpp:332-345): every allocation the library keeps on the caller's behalf (buffers it owns, their
+  // device copies, the committed BVH) is announced with +bytes before and -bytes after; a callback answering false fails the request with
+  // RTC_ERROR_OUT_OF_MEMORY.  Build scratch is transient and not announced.
+  void memoryMonitor(ssize_t bytes, bool post) {
+    if (memFn && bytes != 0 && !memFn(memFnPtr, bytes, post) && bytes > 0) THROW(RTC_ERROR_OUT_OF_MEMORY, "memory monitor forced termination");
+  }   // the build arena of this GPU goes back to the driver with the last user
 };
 
 void process_error(Device* dev, RTCError code, const char* str) {     // Device::process_error, device.cpp:312-330
@@ -88,14 +94,25 @@ struct Buffer : RefCounted {
   Buffer(Device* d, size_t n, void* shared, void* sharedDev = nullptr) : device(d), bytes(n) {
     d->retain();
     if (shared) host = (char*)shared;
-    else { host = (char*)aligned_alloc(64, ((n + 16 + 63) / 64) * 64); if (!host) throw std::bad_alloc(); ownsHost = true; memset(host, 0, n); }
+    else {
+      try { d->memoryMonitor((ssize_t)n, false); } catch (...) { d->release(); throw; }
+      host = (char*)aligned_alloc(64, ((n + 16 + 63) / 64) * 64); if (!host) { d->memoryMonitor(-(ssize_t)n, true); d->release(); throw std::bad_alloc(); } ownsHost = true; memset(host, 0, n);
+    }
     if (sharedDev) { dev = (char*)sharedDev; devDirty = false; }
   }
-  ~Buffer() override { if (ownsHost) free(host); if (ownsDev && dev) { hipSetDevice(device->gpu); hipFree(dev); } device->release(); }
+  ~Buffer() override {
+    if (ownsHost) { free(host); device->memoryMonitor(-(ssize_t)bytes, true); }
+    if (ownsDev && dev) { hipSetDevice(device->gpu); hipFree(dev); device->memoryMonitor(-(ssize_t)bytes, true); }
+    device->release();
+  }
   void upload() {                                           // the reference's SYCL path copies in rtcCommitBuffer/rtcCommitGeometry too
     if (!devDirty && dev) return;
     hip_check(hipSetDevice(device->gpu), "hipSetDevice");
-    if (!dev) { hip_check(hipMalloc((void**)&dev, bytes + 16), "hipMalloc(geometry buffer)"); ownsDev = true; }
+    if (!dev) {
+      device->memoryMonitor((ssize_t)bytes, false);
+      if (hipMalloc((void**)&dev, bytes + 16) != hipSuccess) { dev = nullptr; device->memoryMonitor(-(ssize_t)bytes, true); THROW(RTC_ERROR_OUT_OF_MEMORY, "hipMalloc(geometry buffer)"); }
+      ownsDev = true;
+    }
     if (bytes) hip_check(hipMemcpy(dev, host, bytes, hipMemcpyHostToDevice), "hipMemcpy(geometry buffer)");
     devDirty = false;
   }
@@ -154,7 +171,7 @@ struct Scene : RefCounted {
   std::mutex mtx;
   std::map<unsigned, Geometry*> geoms;
   RTCSceneFlags flags = RTC_SCENE_FLAG_NONE; RTCBuildQuality quality = RTC_BUILD_QUALITY_MEDIUM;
-  mi355_bvh_t bvh = nullptr; bool committed = false, modified = true;
+  mi355_bvh_t bvh = nullptr; ssize_t bvhBytes = 0; bool committed = false, modified = true;
   RTCBounds bounds;
   RTCProgressMonitorFunction progress = nullptr; void* progressPtr = nullptr;
   // host-pointer query staging (device memory), one per calling thread
@@ -168,7 +185,7 @@ struct Scene : RefCounted {
   ~Scene() override {
     for (auto& kv : geoms) { kv.second->attached--; kv.second->release(); }
     hipSetDevice(device->gpu);
-    if (bvh) mi355_bvh_destroy(bvh);
+    if (bvh) { mi355_bvh_destroy(bvh); device->memoryMonitor(-bvhBytes, true); }
     for (auto& kv : staging) if (kv.second.d) hipFree(kv.second.d);
     device->release();
   }
@@ -204,9 +221,11 @@ struct Scene : RefCounted {
     bp.robust = (flags & RTC_SCENE_FLAG_ROBUST) ? 1u : 0u;   // scene.cpp:180-188: robust scenes get Triangle4v leaves + the Pluecker intersector
     if (quality == RTC_BUILD_QUALITY_LOW) bp.quality = 1u;    // scene.cpp:195-206: low quality = the Morton builder
     core_check(mi355_bvh_build(device->gpu, meshes.data(), (uint32_t)meshes.size(), &bp, nullptr, &nb), "BVH build");
-    if (bvh) mi355_bvh_destroy(bvh);
-    bvh = nb;
-    mi355_bvh_info info; mi355_bvh_get_info(bvh, &info);
+    mi355_bvh_info info; mi355_bvh_get_info(nb, &info);
+    const ssize_t newBytes = (ssize_t)(info.bytes_nodes + info.bytes_triangles);
+    try { device->memoryMonitor(newBytes, false); } catch (...) { mi355_bvh_destroy(nb); throw; }   // the old tree stays in place
+    if (bvh) { mi355_bvh_destroy(bvh); device->memoryMonitor(-bvhBytes, true); }
+    bvh = nb; bvhBytes = newBytes;
     setEmptyBounds();
     if (info.num_triangles) {
       bounds.lower_x = info.bounds_lower[0]; bounds.lower_y = info.bounds_lower[1]; bounds.lower_z = info.bounds_lower[2];

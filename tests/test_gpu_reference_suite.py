@@ -210,3 +210,56 @@ def test_many_scenes_devices_and_empty_geometry(api, dev):
         s.release()
     for d in devs:
         d.release()
+
+
+def test_memory_monitor(api):
+    """MemoryMonitorTest (verify.cpp:5378): rtcSetDeviceMemoryMonitorFunction sees every allocation the library keeps (+bytes) and every release
+    (-bytes): the sum is zero once everything is released; a callback answering false makes the request fail with RTC_ERROR_OUT_OF_MEMORY, leaves
+    the accounting balanced and the previously committed tree usable."""
+    L = api.load()
+    MON = C.CFUNCTYPE(C.c_bool, C.c_void_p, C.c_ssize_t, C.c_bool)
+    L.rtcSetDeviceMemoryMonitorFunction.argtypes = [C.c_void_p, MON, C.c_void_p]
+    state = dict(used=0, calls=0, break_at=None, broke=0)
+
+    def monitor(ptr, nbytes, post):
+        state["calls"] += 1
+        if nbytes > 0 and state["break_at"] is not None and state["calls"] >= state["break_at"]:
+            state["broke"] += 1
+            return False
+        state["used"] += nbytes
+        return True
+    cb = MON(monitor)
+    d = api.Device("gpu=0")
+    L.rtcSetDeviceMemoryMonitorFunction(d.h, cb, None)
+    meshes = W.synthetic_crown(num_phi=12)
+    s = api.Scene(d)
+    for v, t in meshes[:6]:
+        s.add_triangle_mesh(v, t, shared=False)                  # library-owned buffers (rtcSetNewGeometryBuffer)
+    s.commit()
+    d.check()
+    info = s.info()
+    assert state["used"] >= info["bytes_nodes"] + info["bytes_triangles"] > 0
+    calls_ok = state["calls"]
+    rays = W.incoherent_rays(2000, [2, 2, 1.5], seed=1)
+    want = rays.copy()
+    s.intersect1M(want)
+    # now refuse the next allocation: the commit fails, the old tree keeps answering
+    state["break_at"] = state["calls"] + 1
+    L.rtcCommitScene(s.h)
+    assert d.get_error() == api.RTC_ERROR_OUT_OF_MEMORY and state["broke"] == 1
+    state["break_at"] = None
+    got = rays.copy()
+    s.intersect1M(got)
+    assert got.tobytes() == want.tobytes()
+    s.release()
+    assert state["used"] == 0 and state["calls"] > calls_ok
+    # a refused buffer allocation
+    state["break_at"] = state["calls"] + 1
+    g = L.rtcNewGeometry(d.h, api.RTC_GEOMETRY_TYPE_TRIANGLE)
+    p = L.rtcSetNewGeometryBuffer(g, api.RTC_BUFFER_TYPE_VERTEX, 0, api.RTC_FORMAT_FLOAT3, 12, 1000)
+    assert not p and d.get_error() == api.RTC_ERROR_OUT_OF_MEMORY
+    state["break_at"] = None
+    L.rtcReleaseGeometry(g)
+    assert state["used"] == 0
+    L.rtcSetDeviceMemoryMonitorFunction(d.h, C.cast(None, MON), None)
+    d.release()
