@@ -209,6 +209,8 @@ def main():
         if dist:
             dist[0].barrier()
 
+    for st_ in streams:                                     # per-stream traversal scratch exists before anything is timed (also when --warmup 0)
+        assert L.mi355_trace_prepare(scene.bvh(), st_) == 0, L.mi355_last_error()
     for i in range(args.warmup):
         scene.intersect1M_device(bufs[i].ptr, M, 96, streams[i % len(streams)])
     L.mi355_device_synchronize(gpu)

@@ -40,7 +40,7 @@ rtcTraversableIntersect1 rtcTraversableIntersect4 rtcTraversableIntersect8 rtcTr
 rtcTraversableOccluded1 rtcTraversableOccluded4 rtcTraversableOccluded8 rtcTraversableOccluded16
 rtcIntersect1M rtcOccluded1M rtcIntersect1MDevice rtcOccluded1MDevice""".split()
 MI355_SYMBOLS = """mi355_default_build_params mi355_last_error mi355_device_count mi355_device_name mi355_bvh_build
-mi355_bvh_destroy mi355_release_build_scratch mi355_bvh_get_info mi355_bvh_download mi355_trace_closest mi355_trace_any
+mi355_bvh_destroy mi355_release_build_scratch mi355_bvh_get_info mi355_bvh_download mi355_trace_prepare mi355_trace_closest mi355_trace_any
 mi355_trace_closest_packet mi355_trace_any_packet mi355_trace_stats mi355_trace_timed mi355_malloc mi355_free mi355_memcpy_h2d
 mi355_memcpy_d2h mi355_synchronize mi355_device_synchronize mi355_memcpy_d2d_async mi355_stream_create
 mi355_stream_destroy mi355_event_create mi355_event_record mi355_event_elapsed_ms mi355_event_destroy""".split()
@@ -148,6 +148,7 @@ def load():
     L.mi355_device_name.argtypes = [C.c_int, C.c_char_p, sz]
     L.mi355_bvh_get_info.argtypes = [vp, C.POINTER(BvhInfo)]
     L.mi355_bvh_download.argtypes = [vp, vp, sz, vp, sz]
+    L.mi355_trace_prepare.argtypes = [vp, vp]
     L.mi355_trace_closest.argtypes = [vp, vp, u32, sz, vp]
     L.mi355_trace_any.argtypes = [vp, vp, u32, sz, vp]
     L.mi355_trace_timed.argtypes = [vp, vp, u32, sz, C.c_int, vp, vp, vp]

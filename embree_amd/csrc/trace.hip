@@ -614,6 +614,10 @@ static int launch_packets(Bvh* b, const int* d_valid, void* d_pk, uint32_t K, ui
 }  // namespace mi355
 
 extern "C" {
+int mi355_trace_prepare(mi355_bvh_t bvh, void* stream) {      // allocates the per-stream traversal scratch now instead of inside the first launch on that stream
+  mi355::Bvh* b = (mi355::Bvh*)bvh; HIP_TRY(hipSetDevice(b->device));
+  return b->scratch_for((hipStream_t)stream) ? 0 : mi355::set_error(hipErrorOutOfMemory, "trace scratch allocation failed");
+}
 int mi355_trace_closest(mi355_bvh_t bvh, void* d, uint32_t n, size_t stride, void* stream) {
   return mi355::launch_trace((mi355::Bvh*)bvh, d, n, stride, false, (hipStream_t)stream, nullptr);
 }

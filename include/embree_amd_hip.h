@@ -86,6 +86,8 @@ MI355_API int mi355_bvh_download(mi355_bvh_t bvh, void* nodes, size_t nodes_byte
 
 /* Ray queries on DEVICE-resident AoS arrays (RTCRayHit = 96 B / RTCRay = 48 B records, byte_stride apart).
    Asynchronous on `stream`.  Per-ray contract = rtcIntersect1 / rtcOccluded1. */
+/* Optional: create the traversal scratch of `stream` (ray cursors, stack spill area) ahead of the first launch on it (which would otherwise allocate it). */
+MI355_API int mi355_trace_prepare(mi355_bvh_t bvh, void* stream);
 MI355_API int mi355_trace_closest(mi355_bvh_t bvh, void* d_rayhit, uint32_t count, size_t byte_stride, void* stream);
 MI355_API int mi355_trace_any(mi355_bvh_t bvh, void* d_ray, uint32_t count, size_t byte_stride, void* stream);
 /* Same launch with a HIP event recorded on `stream` immediately before and after the traversal kernel
