@@ -211,7 +211,7 @@ __device__ __forceinline__ bool tri_pluecker(const float4 q0, const float4 q1, c
 //   done AND the ring has drained past its last pair; u/v/Ng/IDs are recomputed from the winning triangle at that point.
 //   Closest hit = minimum t over ALL accepted candidates, ties to the lower triangle index: independent of scheduling.
 #ifndef MI355_QSTACK_LDS
-#define MI355_QSTACK_LDS 12
+#define MI355_QSTACK_LDS 11
 #endif
 constexpr int QSTACK_LDS = MI355_QSTACK_LDS;   // stack entries per lane in LDS
 constexpr uint32_t QCAP = 128;             // ring capacity (pairs) per wave
@@ -227,15 +227,19 @@ __global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceAr
   __shared__ uint2 s_stack[BLOCK / 64][QSTACK_LDS][64];
   __shared__ uint2 s_queue[BLOCK / 64][QCAP];
   __shared__ unsigned long long s_best[BLOCK / 64][64];
+  __shared__ uint32_t s_pend[BLOCK / 64][64], s_lastT[BLOCK / 64][64];   // per ray slot: helper sub-trees in flight, last ring ticket pushed by helpers
 
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = tid & 63u;
   uint2* const stk = &s_stack[tid >> 6][0][lane];
   uint2* const queue = &s_queue[tid >> 6][0];
   unsigned long long* const best = &s_best[tid >> 6][0];
+  uint32_t* const pend = &s_pend[tid >> 6][0];
+  uint32_t* const lastT = &s_lastT[tid >> 6][0];
   uint2* const spill = a.spill + (size_t)(blockIdx.x * BLOCK + tid) * a.spillPerLane;
 
   bool active = false, travDone = false, exhausted = false;
+  uint32_t owner = lane; bool helper = false, helpersUsed = false;     // tail: a lane without a ray traverses a sub-tree of another lane's ray (see 1b)
   uint32_t rayIdx = 0, rmask = 0, octinv4 = 0, sp = 0, lastTicket = 0;
   uint32_t ngBase = 0, ngHits = 0, tgBase = 0, tgHits = 0;
   uint32_t qHead = 0, qTail = 0;                                         // wave-uniform ring cursors (monotonic)
@@ -257,7 +261,8 @@ __global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceAr
     // new rays, so a refill costs one memory round trip, not three.  A wave whose cursor runs dry moves on to the next
     // cursor; every ray is handed out exactly once; a wave never exits while it holds a block that exists.
     {
-      const bool retirable = active && travDone && (int)(qHead - lastTicket) >= 0;
+      bool retirable = active && !helper && travDone && (int)(qHead - lastTicket) >= 0;
+      if (helpersUsed && retirable) retirable = pend[lane] == 0u && (int)(qHead - lastT[lane]) >= 0;   // helpers done and their pairs tested
       const unsigned long long freeMask = __ballot(retirable || !active);
       const bool anyBusy = __ballot(active && !retirable) != 0ull;
       if ((uint32_t)__popcll(freeMask) >= a.refillMin || !anyBusy) {
@@ -343,6 +348,7 @@ __global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceAr
             sp = 0; ngBase = 0; ngHits = 0x80000000u; tgBase = 0; tgHits = 0;   // "the root is the one hit child of a virtual node"
             lastTicket = qHead; travDone = false;
             best[lane] = ((unsigned long long)__float_as_uint(tfar) << 32) | 0xFFFFFFFFull;
+            pend[lane] = 0u; lastT[lane] = qHead;
             active = a.hasRoot != 0u && !(ANY && tfar < 0.0f);            // empty scene / already occluded (bvh_intersector1.cpp:128)
             if (STATS) stRays++;
           }
@@ -351,20 +357,72 @@ __global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceAr
       }
       if (__ballot(active) == 0ull) { if (exhausted) break; else continue; }
     }
+    // ------------------------------------------------------------------ 1b. tail: lanes without a ray help the rays that are left
+    // Once the cursors are dry a wave keeps paying full instruction cost for its last, longest rays (22 % of the lane-iterations of a
+    // lone 2^20-ray launch belong to lanes without a ray) and the launch cannot end before its longest ray has walked its nodes one
+    // after the other.  So a free lane takes the top stack entry (= the nearest pending sub-trees) of a lane that still traverses,
+    // copies that lane's ray and traverses the entry on its behalf: hits go to best[owner] through the ring exactly like the
+    // owner's own (ring pairs carry the owner, the testers fetch the ray from the owner's registers), the owner retires when its own
+    // traversal is done, pend[owner] == 0 and the ring has passed the last ticket any of its helpers drew.  The result is the same
+    // minimum over all accepted candidates; only the order in which sub-trees are visited changes.
+    if (exhausted) {
+      const unsigned long long freeM = __ballot(!active);
+      const bool canGive = active && !travDone && sp > 0u && sp <= (uint32_t)QSTACK_LDS && !(ANY && (uint32_t)best[owner] != MI355_EMPTY_REF);
+      const unsigned long long giveM = __ballot(canGive);
+      if (freeM != 0ull && giveM != 0ull) {
+        helpersUsed = true;
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        const uint32_t k = min((uint32_t)__popcll(freeM), (uint32_t)__popcll(giveM));
+        const bool gives = canGive && (uint32_t)__popcll(giveM & lt) < k;
+        uint2 e = make_uint2(0u, 0u);
+        if (gives) { sp--; e = stk[sp * 64u]; }
+        const uint32_t rf = (uint32_t)__popcll(freeM & lt);
+        const bool takes = !active && rf < k;
+        // lane of the rf-th giver: rf-th set bit of giveM
+        uint32_t n = takes ? rf : 0u, pos = 0u, w = (uint32_t)giveM, c = (uint32_t)__popc(w);
+        if (n >= c) { n -= c; pos = 32u; w = (uint32_t)(giveM >> 32); }
+        c = (uint32_t)__popc(w & 0xFFFFu); if (n >= c) { n -= c; pos += 16u; w >>= 16; }
+        c = (uint32_t)__popc(w & 0xFFu);   if (n >= c) { n -= c; pos += 8u;  w >>= 8; }
+        c = (uint32_t)__popc(w & 0xFu);    if (n >= c) { n -= c; pos += 4u;  w >>= 4; }
+        c = (uint32_t)__popc(w & 0x3u);    if (n >= c) { n -= c; pos += 2u;  w >>= 2; }
+        if (n >= (w & 1u)) pos += 1u;
+        const int src = (int)(pos & 63u);
+        const uint32_t gx = (uint32_t)__shfl((int)e.x, src, 64), gy = (uint32_t)__shfl((int)e.y, src, 64), gown = (uint32_t)__shfl((int)owner, src, 64);
+        const float h0 = __shfl(ox, src, 64), h1 = __shfl(oy, src, 64), h2 = __shfl(oz, src, 64), h3 = __shfl(dx, src, 64), h4 = __shfl(dy, src, 64), h5 = __shfl(dz, src, 64);
+        const float h6 = __shfl(rdx, src, 64), h7 = __shfl(rdy, src, 64), h8 = __shfl(rdz, src, 64), h9 = __shfl(tnear, src, 64), h10 = __shfl(tnearTrav, src, 64);
+        const uint32_t hm = (uint32_t)__shfl((int)rmask, src, 64), ho = (uint32_t)__shfl((int)octinv4, src, 64);
+        float h11 = 0, h12 = 0, h13 = 0;
+        if (ROBUST) { h11 = __shfl(rfx, src, 64); h12 = __shfl(rfy, src, 64); h13 = __shfl(rfz, src, 64); }
+        if (takes) {
+          ox = h0; oy = h1; oz = h2; dx = h3; dy = h4; dz = h5; rdx = h6; rdy = h7; rdz = h8; tnear = h9; tnearTrav = h10; rmask = hm; octinv4 = ho;
+          if (ROBUST) { rfx = h11; rfy = h12; rfz = h13; }
+          owner = gown; helper = true; active = true; travDone = false;
+          sp = 0; ngBase = gx; ngHits = gy; tgBase = 0; tgHits = 0; lastTicket = qHead;
+          atomicAdd(&pend[owner], 1u);
+        }
+      }
+    }
     if (STATS && lane == 0u) stIter++;
 
     // ------------------------------------------------------------------ 2. current tfar = what the testers published; pop / finish traversal
     if (active && !travDone) {
-      const unsigned long long b = best[lane];
+      const unsigned long long b = best[owner];
       tfar = __uint_as_float((uint32_t)(b >> 32));
-      if (ANY && (uint32_t)b != MI355_EMPTY_REF) { travDone = true; lastTicket = qHead; tgHits = 0; ngHits = 0; sp = 0; }   // occluded: nothing left to wait for
+      bool finished = false;
+      if (ANY && (uint32_t)b != MI355_EMPTY_REF) { finished = true; tgHits = 0; ngHits = 0; sp = 0; lastTicket = qHead; }   // occluded: nothing left to wait for
       else if (tgHits == 0u && ngHits <= 0x00FFFFFFu) {
         if (sp != 0u) {
           sp--;
           uint2 e = stk[min(sp, (uint32_t)(QSTACK_LDS - 1)) * 64u];
           if (__builtin_expect(sp >= (uint32_t)QSTACK_LDS, 0)) e = spill[sp - QSTACK_LDS];
           ngBase = e.x; ngHits = e.y;
-        } else travDone = true;                                     // lastTicket already names this ray's last queued pair
+        } else finished = true;
+      }
+      if (finished) {
+        if (helper) {                                             // hand the sub-tree back: my tickets first, then my share of pend
+          atomicMax(&lastT[owner], lastTicket); atomicSub(&pend[owner], 1u);
+          active = false; helper = false; owner = lane;
+        } else travDone = true;                                    // lastTicket already names this ray's last queued pair
       }
     }
 
@@ -465,7 +523,7 @@ __global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceAr
         const uint32_t k = (uint32_t)__builtin_ctz(tgHits);
         tgHits &= tgHits - 1u;
         const uint32_t pos = qTail + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-        queue[pos & (QCAP - 1u)] = make_uint2(tgBase + k, lane);
+        queue[pos & (QCAP - 1u)] = make_uint2(tgBase + k, owner);
         lastTicket = pos + 1u;
       }
       qTail += n;
