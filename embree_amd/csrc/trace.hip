@@ -211,10 +211,13 @@ __device__ __forceinline__ bool tri_pluecker(const float4 q0, const float4 q1, c
 //   done AND the ring has drained past its last pair; u/v/Ng/IDs are recomputed from the winning triangle at that point.
 //   Closest hit = minimum t over ALL accepted candidates, ties to the lower triangle index: independent of scheduling.
 #ifndef MI355_QSTACK_LDS
-#define MI355_QSTACK_LDS 11
+#define MI355_QSTACK_LDS 9
 #endif
 constexpr int QSTACK_LDS = MI355_QSTACK_LDS;   // stack entries per lane in LDS
-constexpr uint32_t QCAP = 128;             // ring capacity (pairs) per wave
+#ifndef MI355_QCAP
+#define MI355_QCAP 256
+#endif
+constexpr uint32_t QCAP = MI355_QCAP;      // ring capacity (pairs) per wave
 constexpr uint32_t PUSH_ROUNDS_DEFAULT = 5;  // triangle bits a lane may queue per iteration (the rest waits one iteration; env MI355_PUSH_ROUNDS)
 constexpr uint32_t NUM_CURSORS = 8;        // ray cursors per launch (one per XCD)
 constexpr uint32_t CURSOR_STRIDE = 64;     // words between cursors: each one in its own 256-byte block
