@@ -17,7 +17,7 @@
 //   * traversal order needs no sort: children are stored in the slot matching their octant, so the hit bits of
 //     a node, XOR-ed with the ray's octant, are already front to back.  The hits of one node are a 32-bit word
 //     (8 inner-node bits, 24 triangle bits); the per-lane stack holds {child base, hit word} pairs = one entry
-//     per tree level at most, 12 entries per lane in LDS ([entry][lane] so that lanes never bank-conflict),
+//     per tree level at most, 9 entries per lane in LDS ([entry][lane] so that lanes never bank-conflict),
 //     deeper levels spill to HBM (sized from the depth the builder reports, so it can never overflow).
 //   * the kernel is VALU-issue bound (profiles/r01_pmc_trace.md), so what matters is how many lanes each wave
 //     instruction serves.  Triangle tests therefore do not run in the lane that found them: triangle bits go
