@@ -11,8 +11,8 @@
 //
 // MI355X mapping -- one ray per lane, persistent waves, triangle tests pooled per wave:
 //   * a wave owns 64 rays; every lane walks its own ray through the 8-wide compressed tree of bvh_common.h.
-//     A node visit is five 16-byte loads per lane (80-byte node) and ~250 VALU instructions for the wave
-//     (8 slab tests on dequantised planes: v_cvt_f32_ubyte + v_fma per plane, v_max3/v_min3 per child);
+//     A node visit is five 16-byte loads per lane (80-byte node) and ~200 VALU instructions for the wave
+//     (8 slab tests on dequantised planes: v_cvt_f32_ubyte per plane, v_pk_fma_f32 per plane pair, v_max3/v_min3 per child);
 //     a triangle visit is three 16-byte loads and the reference's Moeller-Trumbore arithmetic.
 //   * traversal order needs no sort: children are stored in the slot matching their octant, so the hit bits of
 //     a node, XOR-ed with the ray's octant, are already front to back.  The hits of one node are a 32-bit word
@@ -22,7 +22,9 @@
 //   * the kernel is VALU-issue bound (profiles/r01_pmc_trace.md), so what matters is how many lanes each wave
 //     instruction serves.  Triangle tests therefore do not run in the lane that found them: triangle bits go
 //     to a per-wave LDS ring and are tested 64 at a time by all lanes (see trace_kernel_q below).
-//   * persistent threads: rays are handed out in blocks of REFILL_MIN through 8 cache-line-separated cursors.
+//   * persistent threads: rays are handed out in blocks of REFILL_MIN through 8 cache-line-separated cursors; one wave per
+//     workgroup (waves never synchronise), so a CU slot frees as soon as one wave is done.
+//   * tail: once the cursors are dry, lanes without a ray take pending sub-trees of the rays that are left (step 1b).
 //   All arithmetic is fp32; the triangle test keeps the reference's operation order and FMA placement (compiled
 //   with -ffp-contract=off so only the explicit fmaf()s fuse).  MFMA is not used: no dense contraction here.
 #include <hip/hip_runtime.h>
