@@ -277,6 +277,8 @@ def main():
                          "frac": round(alg_bytes / (eff_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(),
                          "kernel": "trace_kernel_q<closest>", "kernel_ms_avg": round(avg_ms, 4), "kernel_ms_min": round(float(np.min(kernel_ms)), 4),
                          "concurrency": round(conc, 3),
+                         "note": "achieved = algorithmic bytes (SURVEY 8d) per launch / (kernel time / launches in flight); most of these bytes are served by L1/L2/Infinity "
+                                 "Cache (traffic = HBM bytes per launch from the PMC passes), so the fraction of the HBM peak can exceed 1; the kernel is VALU-issue bound",
                          "serial": {"kernel_ms_avg": round(ser_ms, 4), "kernel_ms_min": round(float(np.min(serial_ms)), 4) if serial_ms else None,
                                     "achieved": round(alg_bytes / (ser_ms * 1e-3) / 1e9, 1), "frac": round(alg_bytes / (ser_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                     "mrays_per_s": round(M * nserial / serial_elapsed / 1e6, 1) if nserial else None, "launches": nserial},
