@@ -21,7 +21,8 @@ RTC_GEOMETRY_TYPE_TRIANGLE, RTC_GEOMETRY_TYPE_QUAD = 0, 1
 RTC_BUFFER_TYPE_INDEX, RTC_BUFFER_TYPE_VERTEX, RTC_BUFFER_TYPE_VERTEX_ATTRIBUTE = 0, 1, 2
 RTC_FORMAT_UINT3, RTC_FORMAT_UINT4, RTC_FORMAT_FLOAT3 = 0x5003, 0x5004, 0x9003
 RTC_SCENE_FLAG_ROBUST = 4
-RTC_BUILD_QUALITY_LOW, RTC_BUILD_QUALITY_MEDIUM, RTC_BUILD_QUALITY_HIGH = 0, 1, 2
+RTC_BUILD_QUALITY_LOW, RTC_BUILD_QUALITY_MEDIUM, RTC_BUILD_QUALITY_HIGH, RTC_BUILD_QUALITY_REFIT = 0, 1, 2, 3
+RTC_SCENE_FLAG_DYNAMIC = 1
 
 # every symbol include/embree4/rtcore.h and include/embree_amd_hip.h declare (checked by tests/test_abi.py)
 RTC_SYMBOLS = """rtcNewDevice rtcRetainDevice rtcReleaseDevice rtcGetDeviceProperty rtcSetDeviceProperty rtcGetErrorString
@@ -40,7 +41,7 @@ rtcTraversableIntersect1 rtcTraversableIntersect4 rtcTraversableIntersect8 rtcTr
 rtcTraversableOccluded1 rtcTraversableOccluded4 rtcTraversableOccluded8 rtcTraversableOccluded16
 rtcIntersect1M rtcOccluded1M rtcIntersect1MDevice rtcOccluded1MDevice""".split()
 MI355_SYMBOLS = """mi355_default_build_params mi355_last_error mi355_device_count mi355_device_name mi355_bvh_build
-mi355_bvh_destroy mi355_release_build_scratch mi355_bvh_get_info mi355_bvh_download mi355_trace_prepare mi355_trace_closest mi355_trace_any
+mi355_bvh_destroy mi355_bvh_refit mi355_release_build_scratch mi355_bvh_get_info mi355_bvh_download mi355_trace_prepare mi355_trace_closest mi355_trace_any
 mi355_trace_closest_packet mi355_trace_any_packet mi355_trace_stats mi355_trace_timed mi355_malloc mi355_free mi355_memcpy_h2d
 mi355_memcpy_d2h mi355_synchronize mi355_device_synchronize mi355_memcpy_d2d_async mi355_stream_create
 mi355_stream_destroy mi355_event_create mi355_event_record mi355_event_elapsed_ms mi355_event_destroy""".split()
@@ -49,7 +50,7 @@ mi355_stream_destroy mi355_event_create mi355_event_record mi355_event_elapsed_m
 class BuildParams(C.Structure):
     _fields_ = [("sah_block_shift", C.c_uint32), ("min_leaf", C.c_uint32), ("max_leaf", C.c_uint32),
                 ("small_threshold", C.c_uint32), ("trav_cost", C.c_float), ("int_cost", C.c_float),
-                ("robust", C.c_uint32), ("quality", C.c_uint32)]
+                ("robust", C.c_uint32), ("quality", C.c_uint32), ("refit", C.c_uint32)]
 
 
 class BvhInfo(C.Structure):
@@ -57,7 +58,8 @@ class BvhInfo(C.Structure):
                 ("num_binary_nodes", C.c_uint64), ("bytes_nodes", C.c_uint64), ("bytes_triangles", C.c_uint64),
                 ("bounds_lower", C.c_float * 3), ("bounds_upper", C.c_float * 3), ("sah", C.c_float),
                 ("build_ms", C.c_float), ("root_ref", C.c_uint32), ("top_levels", C.c_uint32),
-                ("max_leaf", C.c_uint32), ("depth", C.c_uint32)]
+                ("max_leaf", C.c_uint32), ("depth", C.c_uint32),
+                ("bytes_refit", C.c_uint64), ("num_refits", C.c_uint32), ("reserved", C.c_uint32)]
 
     def as_dict(self):
         d = {k: getattr(self, k) for k, _ in self._fields_ if not k.startswith("bounds")}
@@ -108,6 +110,7 @@ def load():
     for f in ("rtcReleaseGeometry", "rtcCommitGeometry", "rtcEnableGeometry", "rtcDisableGeometry", "rtcRetainGeometry"):
         getattr(L, f).argtypes = [vp]
     L.rtcSetGeometryMask.argtypes = [vp, u32]
+    L.rtcSetGeometryBuildQuality.argtypes = [vp, C.c_int]
     L.rtcSetGeometryVertexAttributeCount.argtypes = [vp, u32]
     L.rtcSetSharedGeometryBuffer.argtypes = [vp, C.c_int, u32, C.c_int, vp, sz, sz, sz]
     L.rtcSetSharedGeometryBufferHostDevice.argtypes = [vp, C.c_int, u32, C.c_int, vp, vp, sz, sz, sz]
@@ -148,6 +151,7 @@ def load():
     L.mi355_device_name.argtypes = [C.c_int, C.c_char_p, sz]
     L.mi355_bvh_get_info.argtypes = [vp, C.POINTER(BvhInfo)]
     L.mi355_bvh_download.argtypes = [vp, vp, sz, vp, sz]
+    L.mi355_bvh_refit.argtypes = [vp, vp, u32, vp]
     L.mi355_trace_prepare.argtypes = [vp, vp]
     L.mi355_trace_closest.argtypes = [vp, vp, u32, sz, vp]
     L.mi355_trace_any.argtypes = [vp, vp, u32, sz, vp]
@@ -315,6 +319,24 @@ class Scene:
         L.rtcReleaseGeometry(g)
         self.dev.check()
         return gid
+
+    def set_geometry_build_quality(self, gid, quality):
+        """rtcSetGeometryBuildQuality; RTC_BUILD_QUALITY_REFIT makes the next commit after a vertex update refit the tree."""
+        self.L.rtcSetGeometryBuildQuality(self.L.rtcGetGeometry(self.h, gid), quality)
+        self.dev.check()
+
+    def update_vertices(self, gid, verts):
+        """The dynamic-scene idiom of the tutorials: write the vertex buffer in place, rtcUpdateGeometryBuffer, rtcCommitGeometry
+        (the caller commits the scene).  For meshes added with host buffers (shared or library-owned)."""
+        L = self.L
+        g = L.rtcGetGeometry(self.h, gid)
+        v = np.ascontiguousarray(verts, np.float32).reshape(-1, 3)
+        p = L.rtcGetGeometryBufferData(g, RTC_BUFFER_TYPE_VERTEX, 0)
+        self.dev.check()
+        C.memmove(p, v.ctypes.data, v.nbytes)
+        L.rtcUpdateGeometryBuffer(g, RTC_BUFFER_TYPE_VERTEX, 0)
+        L.rtcCommitGeometry(g)
+        self.dev.check()
 
     def commit(self):
         self.L.rtcCommitScene(self.h)

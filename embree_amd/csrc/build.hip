@@ -85,6 +85,7 @@ struct Counters {
   uint32_t overflow, rootRef, numTrisOut, numInvalid;
   uint32_t numSegs, topLevels, wideDepth, lvlNodeBase, lvlTriBase, wideCount[2];      // level loops are driven from the device: no host readback per level
   unsigned long long sahFixed;                    // SAH statistics, 2^-24 fixed point (order-independent sum)
+  uint32_t lvlStart[64];                          // first node of every level of the wide tree (numbering is breadth first): what a refit walks bottom-up
 };
 struct Params { uint32_t shift, minLeaf, maxLeaf, small; float travCost, intCost; uint32_t quality; };
 
@@ -1073,7 +1074,7 @@ struct WidePlan { uint32_t ch[8]; uint32_t imask, leafMask, nch, pad; };   // by
 
 __global__ void wide_root(WideItem* items, Counters* ctr) {
   items[0].bnode = 0; items[0].node = 0;                       // the root is always CNode 0
-  ctr->rootRef = 0; ctr->numWide = 1; ctr->wideCount[0] = 1; ctr->wideCount[1] = 0; ctr->wideDepth = 0; ctr->numLeaves = 0; ctr->numTrisOut = 0; ctr->sahFixed = 0ull;
+  ctr->rootRef = 0; ctr->numWide = 1; ctr->wideCount[0] = 1; ctr->wideCount[1] = 0; ctr->wideDepth = 0; ctr->lvlStart[0] = 0; ctr->numLeaves = 0; ctr->numTrisOut = 0; ctr->sahFixed = 0ull;
 }
 
 template <typename T> __device__ __forceinline__ T grp_get(T v, uint32_t lane, uint32_t idx) { return __shfl(v, (int)((lane & ~7u) | idx), 64); }
@@ -1195,9 +1196,41 @@ __global__ __launch_bounds__(1024) void wide_scan(uint2* groupSum, Counters* ctr
   __syncthreads();
   if (tid == 0) {
     ctr->lvlNodeBase = ctr->numWide; ctr->lvlTriBase = ctr->numTrisOut;
-    if (numItems) ctr->wideDepth++;
+    if (numItems) { ctr->wideDepth++; if (ctr->wideDepth < 64u) ctr->lvlStart[ctr->wideDepth] = ctr->numWide; }
     if ((uint64_t)ctr->numWide + total.x > maxNodes) { ctr->overflow = 2u; ctr->wideCount[parity ^ 1u] = 0u; }
     else { ctr->numWide += total.x; ctr->numTrisOut += total.y; ctr->wideCount[parity ^ 1u] = total.x; }
+  }
+}
+
+// Quantises the child boxes of 8 nodes at once (lane = 8 * node + slot): plane = org + q * 2^(e-127), lower planes rounded down, upper planes
+// rounded up, verified in fp32.  Shared by wide_emit and refit_level so that a refitted node is what a build would have written for the same boxes.
+__device__ __forceinline__ void quantise_slots(bool has, uint32_t lane, const float (&lo)[3], const float (&hi)[3], const float (&olo)[3], const float (&ohi)[3],
+                                               uint32_t (&ex)[3], uint32_t (&qa)[3], uint32_t (&qb)[3]) {
+  // ---- quantise: plane = org + q * 2^(e-127), lower rounded down, upper rounded up, verified in fp32
+  for (int d = 0; d < 3; d++) {
+    const float ext = ohi[d] - olo[d];
+    int e = 1;                                                // biased exponent, scale = 2^(e-127)
+    if (ext > 0.0f) { int fe; frexpf(ext / 255.0f, &fe); e = fe + 127; if (e < 1) e = 1; if (e > 254) e = 254; }
+    for (;;) {                                                // grow the scale until every upper plane of the node fits in 8 bits
+      const float sc = __uint_as_float((uint32_t)e << 23);
+      bool fits = true;
+      if (has) { float q = ceilf((hi[d] - olo[d]) / sc); while (fmaf(q, sc, olo[d]) < hi[d]) q += 1.0f; fits = q <= 255.0f; }
+      const bool grpFits = ((__ballot(!fits) >> (lane & ~7u)) & 0xFFull) == 0ull;
+      const bool stop = grpFits || e >= 254;
+      if (!stop) e++;
+      if (__ballot(!stop) == 0ull) break;
+    }
+    ex[d] = (uint32_t)e;
+    qa[d] = 255u; qb[d] = 0u;                                 // empty slot: inverted box, never hit
+    if (has) {
+      const float sc = __uint_as_float(ex[d] << 23);
+      float a = floorf((lo[d] - olo[d]) / sc); if (a < 0.0f) a = 0.0f; if (a > 255.0f) a = 255.0f;
+      while (a > 0.0f && fmaf(a, sc, olo[d]) > lo[d]) a -= 1.0f;
+      float b = ceilf((hi[d] - olo[d]) / sc); if (b < 0.0f) b = 0.0f;
+      while (b < 255.0f && fmaf(b, sc, olo[d]) < hi[d]) b += 1.0f;
+      if (b > 255.0f) b = 255.0f;
+      qa[d] = (uint32_t)a; qb[d] = (uint32_t)b;
+    }
   }
 }
 
@@ -1230,33 +1263,8 @@ __global__ __launch_bounds__(64) void wide_emit(const WideItem* items, const BNo
       sort_leaf(finalIds, cb.begin, cb.end);
       for (uint32_t j = cb.begin; j < cb.end; j++) outIds[triBase + triOfs + (j - cb.begin)] = finalIds[j];
     }
-    // ---- quantise: plane = org + q * 2^(e-127), lower rounded down, upper rounded up, verified in fp32
-    uint32_t ex[3]; uint32_t qa[3], qb[3];
-    for (int d = 0; d < 3; d++) {
-      const float ext = ohi[d] - olo[d];
-      int e = 1;                                                // biased exponent, scale = 2^(e-127)
-      if (ext > 0.0f) { int fe; frexpf(ext / 255.0f, &fe); e = fe + 127; if (e < 1) e = 1; if (e > 254) e = 254; }
-      for (;;) {                                                // grow the scale until every upper plane of the node fits in 8 bits
-        const float sc = __uint_as_float((uint32_t)e << 23);
-        bool fits = true;
-        if (has) { float q = ceilf((hi[d] - olo[d]) / sc); while (fmaf(q, sc, olo[d]) < hi[d]) q += 1.0f; fits = q <= 255.0f; }
-        const bool grpFits = ((__ballot(!fits) >> (lane & ~7u)) & 0xFFull) == 0ull;
-        const bool stop = grpFits || e >= 254;
-        if (!stop) e++;
-        if (__ballot(!stop) == 0ull) break;
-      }
-      ex[d] = (uint32_t)e;
-      qa[d] = 255u; qb[d] = 0u;                                 // empty slot: inverted box, never hit
-      if (has) {
-        const float sc = __uint_as_float(ex[d] << 23);
-        float a = floorf((lo[d] - olo[d]) / sc); if (a < 0.0f) a = 0.0f; if (a > 255.0f) a = 255.0f;
-        while (a > 0.0f && fmaf(a, sc, olo[d]) > lo[d]) a -= 1.0f;
-        float b = ceilf((hi[d] - olo[d]) / sc); if (b < 0.0f) b = 0.0f;
-        while (b < 255.0f && fmaf(b, sc, olo[d]) < hi[d]) b += 1.0f;
-        if (b > 255.0f) b = 255.0f;
-        qa[d] = (uint32_t)a; qb[d] = (uint32_t)b;
-      }
-    }
+    uint32_t ex[3], qa[3], qb[3];
+    quantise_slots(has, lane, lo, hi, olo, ohi, ex, qa, qb);
     const uint32_t meta = !has ? 0u : (leaf ? ((((1u << cnt) - 1u) << 5) | triOfs) : ((1u << 5) | (24u + s)));
     // ---- assemble the 80-byte node in LDS (the bytes of a word come from 4 lanes), 5 lanes store it
     __syncthreads();
@@ -1296,6 +1304,70 @@ __global__ __launch_bounds__(256) void tri_records(const uint2* finalIds, uint32
   o[0] = make_float4(a[0], a[1], a[2], a[0] - b[0]);
   o[1] = make_float4(a[1] - b[1], a[2] - b[2], c[0] - a[0], c[1] - a[1]);
   o[2] = make_float4(c[2] - a[2], __uint_as_float(id.y), __uint_as_float(g.geomID), __uint_as_float(g.mask));
+}
+
+// --------------------------------------------------------------------------------- refit (RTC_BUILD_QUALITY_REFIT, kernels/bvh/bvh_refit.cpp)
+// The topology of the tree stays; the triangle records are rewritten from the moved vertices (tri_records) and the boxes are
+// recomputed bottom-up, one launch per level of the wide tree (nodes are numbered breadth first, so a level is a contiguous range).
+// Eight lanes per node as in wide_emit: lane = child slot; a leaf slot bounds its <= 3 triangles from the vertex buffers (the same
+// min/max as primref_gen), an inner slot takes the exact box its child wrote one launch earlier; the node is re-quantised with the
+// builder's own routine.  A triangle that has become invalid (non-finite / huge coordinate) raises *flag: the caller rebuilds.
+__global__ __launch_bounds__(64) void refit_level(CNode* nodes, float4* boxes, const uint2* ids, const GeomDesc* geoms, uint32_t first, uint32_t count, uint32_t* flag) {
+  __shared__ uint32_t s_node[8][20];
+  const uint32_t lane = threadIdx.x, s = lane & 7u, g = lane >> 3;
+  for (uint32_t base = blockIdx.x * 8u; base < count; base += gridDim.x * 8u) {
+    const uint32_t t = base + g; const bool valid = t < count;
+    const uint32_t node = first + (valid ? t : 0u);
+    __syncthreads();
+    if (valid && s < 5u) ((uint4*)&s_node[g][0])[s] = ((const uint4*)(nodes + node))[s];
+    __syncthreads();
+    const uint8_t* nbr = (const uint8_t*)&s_node[g][0];
+    const uint32_t meta = valid ? nbr[24 + s] : 0u, imask = s_node[g][3] >> 24, childBase = s_node[g][4], triBase = s_node[g][5];
+    const bool has = meta != 0u, inner = has && ((imask >> s) & 1u) != 0u;
+    float lo[3], hi[3], olo[3], ohi[3];
+    for (int d = 0; d < 3; d++) { lo[d] = __builtin_inff(); hi[d] = -__builtin_inff(); }
+    if (inner) {
+      const uint32_t c = childBase + (uint32_t)__popc(imask & ((1u << s) - 1u));
+      const float4 a = boxes[2u * c], b = boxes[2u * c + 1u];
+      lo[0] = a.x; lo[1] = a.y; lo[2] = a.z; hi[0] = b.x; hi[1] = b.y; hi[2] = b.z;
+    } else if (has) {
+      const uint32_t cnt = (uint32_t)__popc(meta >> 5), t0 = triBase + (meta & 31u);
+      bool ok = true;
+      for (uint32_t k = 0; k < cnt; k++) {
+        const uint2 id = ids[t0 + k];
+        const GeomDesc gd = geoms[id.x];
+        uint32_t i0, i1, i2, pid;
+        prim_indices(gd, id.y, i0, i1, i2, pid);
+        const float* a = (const float*)(gd.verts + (size_t)i0 * gd.vstride);
+        const float* b = (const float*)(gd.verts + (size_t)i1 * gd.vstride);
+        const float* c = (const float*)(gd.verts + (size_t)i2 * gd.vstride);
+        for (int d = 0; d < 3; d++) {
+          const float x = a[d], y = b[d], z = c[d];
+          ok = ok && valid_f(x) && valid_f(y) && valid_f(z);
+          lo[d] = fminf(lo[d], fminf(fminf(x, y), z)); hi[d] = fmaxf(hi[d], fmaxf(fmaxf(x, y), z));
+        }
+        if (gd.quad) {
+          const uint32_t* q = (const uint32_t*)(gd.idx + (size_t)(id.y >> 1) * gd.istride);
+          const float* o4 = (const float*)(gd.verts + (size_t)((id.y & 1u) ? q[0] : q[2]) * gd.vstride);
+          ok = ok && valid_f(o4[0]) && valid_f(o4[1]) && valid_f(o4[2]);
+        }
+      }
+      if (!ok) { atomicOr(flag, 1u); for (int d = 0; d < 3; d++) { lo[d] = 0.0f; hi[d] = 0.0f; } }
+    }
+    for (int d = 0; d < 3; d++) { olo[d] = grp_min(lo[d]); ohi[d] = grp_max(hi[d]); }
+    uint32_t ex[3], qa[3], qb[3];
+    quantise_slots(has, lane, lo, hi, olo, ohi, ex, qa, qb);
+    __syncthreads();
+    uint8_t* nb = (uint8_t*)&s_node[g][0];
+    for (int d = 0; d < 3; d++) { nb[32 + d * 8 + s] = (uint8_t)qa[d]; nb[56 + d * 8 + s] = (uint8_t)qb[d]; }
+    if (s == 0u) {
+      s_node[g][0] = __float_as_uint(olo[0]); s_node[g][1] = __float_as_uint(olo[1]); s_node[g][2] = __float_as_uint(olo[2]);
+      s_node[g][3] = ex[0] | (ex[1] << 8) | (ex[2] << 16) | (imask << 24);
+      if (valid) { boxes[2u * node] = make_float4(olo[0], olo[1], olo[2], 0.0f); boxes[2u * node + 1u] = make_float4(ohi[0], ohi[1], ohi[2], 0.0f); }
+    }
+    __syncthreads();
+    if (valid && s < 5u) ((uint4*)(nodes + node))[s] = ((const uint4*)&s_node[g][0])[s];
+  }
 }
 
 // Build scratch comes from a per-device arena that survives the commit: rtcCommitScene is timed on the wall clock
@@ -1358,6 +1430,7 @@ Bvh::~Bvh() {
   for (auto& kv : scratch) { hipFree(kv.second.counter); hipFree(kv.second.spill); hipFree(kv.second.stats); delete kv.second.enqueue; }
   if (d_nodes) hipFree(d_nodes);
   if (d_tris) hipFree(d_tris);
+  if (d_ids) hipFree(d_ids);
 }
 
 static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, const mi355_build_params* bp, hipStream_t st, Bvh** out) {
@@ -1543,6 +1616,13 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
   }
   hipLaunchKernelGGL(tri_records, dim3((n + 255u) / 256u), dim3(256), 0, st, outIds.p, n, dGeoms.p, (TriRec*)bvh->d_tris, bp->robust ? 1u : 0u);
   bvh->robust = bp->robust != 0;
+  if (bp->refit && h.numInvalid == 0u && depth < 64u) {        // keep the leaf order and the level table for mi355_bvh_refit
+    HIP_TRY(hipMalloc(&bvh->d_ids, (size_t)n * sizeof(uint2)));
+    HIP_TRY(hipMemcpyAsync(bvh->d_ids, outIds.p, (size_t)n * sizeof(uint2), hipMemcpyDeviceToDevice, st));
+    bvh->lvlStart.assign(h.lvlStart, h.lvlStart + depth); bvh->lvlStart.push_back(numNodes);
+    for (const GeomDesc& g : gd) bvh->sig.push_back({g.geomID, g.nt, g.nv, g.quad});
+    info.bytes_refit = (uint64_t)n * sizeof(uint2);
+  }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(ev1, st)); HIP_TRY(hipEventSynchronize(ev1));
   float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
@@ -1551,6 +1631,56 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
   info.bytes_nodes = (uint64_t)numNodes * sizeof(CNode); info.bytes_triangles = (uint64_t)n * sizeof(TriRec);
   info.sah = (float)((double)h.sahFixed / 16777216.0) + (numNodes ? prm.travCost : 0.0f); info.build_ms = ms; info.depth = depth;
   guard.ok = true; *out = bvh;
+  return 0;
+}
+
+static int refit_impl(Bvh* bvh, const mi355_mesh* meshes, uint32_t numMeshes, hipStream_t st) {
+  HIP_TRY(hipSetDevice(bvh->device));
+  const uint32_t n = (uint32_t)bvh->info.num_triangles, numNodes = (uint32_t)bvh->info.num_nodes;
+  if (!bvh->d_ids || n == 0u || numNodes == 0u) return MI355_REFIT_IMPOSSIBLE;
+  std::vector<GeomDesc> gd; uint64_t total = 0;
+  for (uint32_t i = 0; i < numMeshes; i++) {
+    const mi355_mesh& m = meshes[i];
+    if (m.num_triangles == 0) continue;
+    if (m.vertex_stride < 12 || (m.vertex_stride & 3) || m.index_stride < (m.quads ? 16u : 12u) || (m.index_stride & 3)) return set_error(hipErrorInvalidValue, "buffer stride");
+    GeomDesc g{}; g.verts = (const char*)m.d_vertices; g.idx = (const char*)m.d_indices; g.vstride = (uint32_t)m.vertex_stride; g.istride = (uint32_t)m.index_stride;
+    g.nv = m.num_vertices; g.quad = m.quads ? 1u : 0u; g.nt = m.num_triangles * (g.quad ? 2u : 1u); g.geomID = m.geom_id; g.mask = m.mask; g.primOffset = (uint32_t)total;
+    total += g.nt; gd.push_back(g);
+  }
+  if (gd.size() != bvh->sig.size()) return MI355_REFIT_IMPOSSIBLE;
+  for (size_t i = 0; i < gd.size(); i++) {
+    const Bvh::MeshSig& s = bvh->sig[i];
+    if (s.geomID != gd[i].geomID || s.numPrims != gd[i].nt || s.numVerts != gd[i].nv || s.quads != gd[i].quad) return MI355_REFIT_IMPOSSIBLE;
+  }
+  Arena* arena = arena_of(bvh->device);
+  std::lock_guard<std::mutex> arenaLock(arena->mtx);
+  arena->reset(); t_arena = arena;
+  DevBuf<GeomDesc> dGeoms; DevBuf<float4> boxes; DevBuf<uint32_t> flag;
+  HIP_TRY(dGeoms.alloc(gd.size())); HIP_TRY(boxes.alloc(2ull * numNodes)); HIP_TRY(flag.alloc(1));
+  hipEvent_t ev0, ev1; HIP_TRY(hipEventCreate(&ev0)); HIP_TRY(hipEventCreate(&ev1));
+  struct EvGuard { hipEvent_t a, b; ~EvGuard() { hipEventDestroy(a); hipEventDestroy(b); } } evg{ev0, ev1};
+  HIP_TRY(hipEventRecord(ev0, st));
+  HIP_TRY(hipMemcpyAsync(dGeoms.p, gd.data(), gd.size() * sizeof(GeomDesc), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemsetAsync(flag.p, 0, 4, st));
+  hipLaunchKernelGGL(tri_records, dim3((n + 255u) / 256u), dim3(256), 0, st, (const uint2*)bvh->d_ids, n, dGeoms.p, (TriRec*)bvh->d_tris, bvh->robust ? 1u : 0u);
+  for (size_t l = bvh->lvlStart.size() - 1; l-- > 0;) {        // deepest level first
+    const uint32_t first = bvh->lvlStart[l], count = bvh->lvlStart[l + 1] - first;
+    if (!count) continue;
+    const uint32_t blocks = (count + 7u) / 8u < 8192u ? (count + 7u) / 8u : 8192u;
+    hipLaunchKernelGGL(refit_level, dim3(blocks), dim3(64), 0, st, (CNode*)bvh->d_nodes, boxes.p, (const uint2*)bvh->d_ids, dGeoms.p, first, count, flag.p);
+  }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(ev1, st));
+  uint32_t hflag = 0; float4 rb[2];
+  HIP_TRY(hipMemcpyAsync(&hflag, flag.p, 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(rb, boxes.p, sizeof(rb), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
+  if (hflag) return MI355_REFIT_IMPOSSIBLE;
+  mi355_bvh_info& info = bvh->info;
+  info.bounds_lower[0] = rb[0].x; info.bounds_lower[1] = rb[0].y; info.bounds_lower[2] = rb[0].z;
+  info.bounds_upper[0] = rb[1].x; info.bounds_upper[1] = rb[1].y; info.bounds_upper[2] = rb[1].z;
+  info.build_ms = ms; info.num_refits++;
   return 0;
 }
 
@@ -1575,6 +1705,10 @@ int mi355_bvh_build(int device, const mi355_mesh* meshes, uint32_t num_meshes, c
   *out = (mi355_bvh_t)b; return rc;
 }
 void mi355_bvh_destroy(mi355_bvh_t bvh) { delete (mi355::Bvh*)bvh; }
+int mi355_bvh_refit(mi355_bvh_t bvh, const mi355_mesh* meshes, uint32_t num_meshes, void* stream) {
+  if (!bvh) return MI355_REFIT_IMPOSSIBLE;
+  return mi355::refit_impl((mi355::Bvh*)bvh, meshes, num_meshes, (hipStream_t)stream);
+}
 void mi355_release_build_scratch(int device) {
   Arena* a = arena_of(device);
   std::lock_guard<std::mutex> lk(a->mtx);

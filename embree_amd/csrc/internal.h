@@ -5,6 +5,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <vector>
 #include "../../include/embree_amd_hip.h"
 
 namespace mi355 {
@@ -31,6 +32,11 @@ struct Bvh {
   uint32_t root = 0xFFFFFFFFu;
   bool robust = false;           // TriRec holds v0,v1,v2 (instead of v0,e1,e2); traversal = conservative node test + Pluecker
   mi355_bvh_info info{};
+  // refit data (params.refit): leaf order (geometry table index, internal triangle) per TriRec, first node of every level, the mesh list it was built from
+  void* d_ids = nullptr;
+  std::vector<uint32_t> lvlStart;
+  struct MeshSig { uint32_t geomID, numPrims, numVerts, quads; };
+  std::vector<MeshSig> sig;
   std::mutex mtx;
   std::map<hipStream_t, TraceScratch> scratch;
   TraceScratch* scratch_for(hipStream_t s);

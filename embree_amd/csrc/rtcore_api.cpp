@@ -126,6 +126,8 @@ struct Geometry : RefCounted {
   std::map<unsigned, Buffer*> attribs;                     // vertex attributes: kept alive for the caller, unused by the kernels
   unsigned mask = 1;                                        // Geometry ctor, geometry.cpp:48
   bool enabled = true, modified = true, committed = false;
+  RTCBuildQuality quality = RTC_BUILD_QUALITY_MEDIUM;
+  unsigned topoCounter = 0, dataCounter = 0;                // bumped when buffers are (re)bound / the index data changes; when vertex data or the mask changes
   void* userPtr = nullptr;
   std::atomic<int> attached{0};
   Geometry(Device* d, RTCGeometryType t) : device(d), type(t) { d->retain(); }
@@ -162,7 +164,7 @@ struct Geometry : RefCounted {
     b->retain();
     if (v->buf) v->buf->release();
     v->buf = b; v->offset = off; v->stride = stride; v->num = (unsigned)num;
-    modified = true; committed = false;
+    modified = true; committed = false; topoCounter++;
   }
 };
 
@@ -172,6 +174,8 @@ struct Scene : RefCounted {
   std::map<unsigned, Geometry*> geoms;
   RTCSceneFlags flags = RTC_SCENE_FLAG_NONE; RTCBuildQuality quality = RTC_BUILD_QUALITY_MEDIUM;
   mi355_bvh_t bvh = nullptr; ssize_t bvhBytes = 0; bool committed = false, modified = true;
+  struct BuiltFrom { unsigned id; Geometry* g; unsigned topo, data; };   // what the current tree was built from: decides rebuild vs refit
+  std::vector<BuiltFrom> builtFrom; unsigned builtFlags = 0;
   RTCBounds bounds;
   RTCProgressMonitorFunction progress = nullptr; void* progressPtr = nullptr;
   // host-pointer query staging (device memory), one per calling thread
@@ -216,23 +220,50 @@ struct Scene : RefCounted {
       meshes.push_back(m);
     }
     if (progress && !progress(progressPtr, 0.0)) THROW(RTC_ERROR_CANCELLED, "progress monitor forced termination");
-    mi355_bvh_t nb = nullptr;
     mi355_build_params bp = device->build;
     bp.robust = (flags & RTC_SCENE_FLAG_ROBUST) ? 1u : 0u;   // scene.cpp:180-188: robust scenes get Triangle4v leaves + the Pluecker intersector
     if (quality == RTC_BUILD_QUALITY_LOW) bp.quality = 1u;    // scene.cpp:195-206: low quality = the Morton builder
-    core_check(mi355_bvh_build(device->gpu, meshes.data(), (uint32_t)meshes.size(), &bp, nullptr, &nb), "BVH build");
-    mi355_bvh_info info; mi355_bvh_get_info(nb, &info);
-    const ssize_t newBytes = (ssize_t)(info.bytes_nodes + info.bytes_triangles);
-    try { device->memoryMonitor(newBytes, false); } catch (...) { mi355_bvh_destroy(nb); throw; }   // the old tree stays in place
-    if (bvh) { mi355_bvh_destroy(bvh); device->memoryMonitor(-bvhBytes, true); }
-    bvh = nb; bvhBytes = newBytes;
+    std::vector<BuiltFrom> from; bool wantRefit = (flags & RTC_SCENE_FLAG_DYNAMIC) != 0;
+    for (auto& kv : geoms) {
+      Geometry* g = kv.second;
+      if (!g->enabled || !g->vertices.buf || !g->indices.buf) continue;
+      from.push_back({kv.first, g, g->topoCounter, g->dataCounter});
+      wantRefit = wantRefit || g->quality == RTC_BUILD_QUALITY_REFIT;
+    }
+    bp.refit = wantRefit ? 1u : 0u;
+    const unsigned nowFlags = (bp.robust ? 1u : 0u) | (bp.quality << 1);
+    // Refit instead of rebuild (the reference: BVHNRefitT for RTC_BUILD_QUALITY_REFIT meshes of a dynamic scene, kernels/bvh/bvh_refit.cpp):
+    // same geometries with the same buffer bindings and index data, and every geometry whose vertices / mask changed asks for REFIT.
+    bool refit = bvh && committed && from.size() == builtFrom.size() && nowFlags == builtFlags && !from.empty();
+    for (size_t i = 0; refit && i < from.size(); i++) {
+      const BuiltFrom &a = from[i], &b = builtFrom[i];
+      refit = a.id == b.id && a.g == b.g && a.topo == b.topo && (a.data == b.data || a.g->quality == RTC_BUILD_QUALITY_REFIT);
+    }
+    mi355_bvh_info info;
+    bool done = false;
+    if (refit) {
+      const int rc = mi355_bvh_refit(bvh, meshes.data(), (uint32_t)meshes.size(), nullptr);
+      if (rc == 0) done = true;
+      else { committed = false; if (rc != MI355_REFIT_IMPOSSIBLE) core_check(rc, "BVH refit"); }   // a refit that stopped half way leaves no usable tree
+    }
+    if (!done) {
+      mi355_bvh_t nb = nullptr;
+      core_check(mi355_bvh_build(device->gpu, meshes.data(), (uint32_t)meshes.size(), &bp, nullptr, &nb), "BVH build");
+      mi355_bvh_get_info(nb, &info);
+      const ssize_t newBytes = (ssize_t)(info.bytes_nodes + info.bytes_triangles + info.bytes_refit);
+      try { device->memoryMonitor(newBytes, false); } catch (...) { mi355_bvh_destroy(nb); throw; }   // the old tree stays in place
+      if (bvh) { mi355_bvh_destroy(bvh); device->memoryMonitor(-bvhBytes, true); }
+      bvh = nb; bvhBytes = newBytes;
+    }
+    mi355_bvh_get_info(bvh, &info);
+    builtFrom = from; builtFlags = nowFlags;
     setEmptyBounds();
     if (info.num_triangles) {
       bounds.lower_x = info.bounds_lower[0]; bounds.lower_y = info.bounds_lower[1]; bounds.lower_z = info.bounds_lower[2];
       bounds.upper_x = info.bounds_upper[0]; bounds.upper_y = info.bounds_upper[1]; bounds.upper_z = info.bounds_upper[2];
     }
     if (device->verbose >= 2 || device->benchmark)           // BVHN::postBuild prints BENCHMARK_BUILD, bvh.cpp:175-179
-      printf("BENCHMARK_BUILD %.3f ms %.3f Mprims/s sah %.4f nodes %llu tris %llu bytes %llu\n", info.build_ms,
+      printf("%s %.3f ms %.3f Mprims/s sah %.4f nodes %llu tris %llu bytes %llu\n", done ? "BENCHMARK_REFIT" : "BENCHMARK_BUILD", info.build_ms,
              info.build_ms > 0 ? info.num_triangles / (info.build_ms * 1e3) : 0.0, info.sah, (unsigned long long)info.num_nodes,
              (unsigned long long)info.num_triangles, (unsigned long long)(info.bytes_nodes + info.bytes_triangles));
     if (progress) progress(progressPtr, 1.0);
@@ -414,10 +445,11 @@ RTC_API void rtcSetGeometryTimeStepCount(RTCGeometry h, unsigned n) {
   CATCH_BEGIN geom_of(h); if (n != 1) THROW(RTC_ERROR_INVALID_OPERATION, "motion blur is not supported by the MI355X core"); CATCH_END(GEOM_DEV(h))
 }
 RTC_API void rtcSetGeometryVertexAttributeCount(RTCGeometry h, unsigned) { CATCH_BEGIN geom_of(h); CATCH_END(GEOM_DEV(h)) }
-RTC_API void rtcSetGeometryMask(RTCGeometry h, unsigned mask) { CATCH_BEGIN Geometry* g = geom_of(h); g->mask = mask; g->committed = false; CATCH_END(GEOM_DEV(h)) }
+RTC_API void rtcSetGeometryMask(RTCGeometry h, unsigned mask) { CATCH_BEGIN Geometry* g = geom_of(h); g->mask = mask; g->committed = false; g->dataCounter++; CATCH_END(GEOM_DEV(h)) }
 RTC_API void rtcSetGeometryBuildQuality(RTCGeometry h, enum RTCBuildQuality q) {
-  CATCH_BEGIN geom_of(h);
+  CATCH_BEGIN Geometry* g = geom_of(h);
   if (q != RTC_BUILD_QUALITY_LOW && q != RTC_BUILD_QUALITY_MEDIUM && q != RTC_BUILD_QUALITY_HIGH && q != RTC_BUILD_QUALITY_REFIT) THROW(RTC_ERROR_INVALID_OPERATION, "invalid build quality");
+  g->quality = q;                                           // REFIT: a commit after a vertex update refits the tree instead of rebuilding it (Scene::commit)
   CATCH_END(GEOM_DEV(h))
 }
 RTC_API void rtcSetGeometryBuffer(RTCGeometry h, enum RTCBufferType type, unsigned slot, enum RTCFormat fmt, RTCBuffer buffer,
@@ -479,6 +511,7 @@ RTC_API void rtcUpdateGeometryBuffer(RTCGeometry h, enum RTCBufferType type, uns
   if (v->buf && v->buf->ownsDev) v->buf->devDirty = true;
   if (v->buf && !v->buf->dev) v->buf->devDirty = true;
   g->modified = true; g->committed = false;
+  if (type == RTC_BUFFER_TYPE_VERTEX) g->dataCounter++; else g->topoCounter++;
   CATCH_END(GEOM_DEV(h))
 }
 RTC_API void rtcSetGeometryUserData(RTCGeometry h, void* p) { CATCH_BEGIN geom_of(h)->userPtr = p; CATCH_END(GEOM_DEV(h)) }

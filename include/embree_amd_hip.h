@@ -55,6 +55,7 @@ typedef struct mi355_build_params {
                                 (triangle_intersector_pluecker.h:68-118).  default 0 */
   uint32_t quality;          /* 0 = RTC_BUILD_QUALITY_MEDIUM (binned SAH, the default); 1 = RTC_BUILD_QUALITY_LOW: Morton-code build like the
                                 reference's fast builder (kernels/builders/bvh_builder_morton.h), same node and leaf layout */
+  uint32_t refit;            /* 1: keep what mi355_bvh_refit needs (8 B per triangle: the leaf order, and the level table).  default 0 */
 } mi355_build_params;
 
 typedef struct mi355_bvh_info {
@@ -67,6 +68,9 @@ typedef struct mi355_bvh_info {
   float    sah;              /* (sum inner area*travCost + sum leaf area*blocks*intCost) / root area */
   float    build_ms;         /* GPU time of the last build (hipEvent), excluding host->device uploads */
   uint32_t root_ref, top_levels, max_leaf, depth;
+  uint64_t bytes_refit;      /* extra device memory kept for mi355_bvh_refit (0 unless built with params.refit) */
+  uint32_t num_refits;       /* refits since the build; build_ms is the GPU time of the last build OR refit */
+  uint32_t reserved;
 } mi355_bvh_info;
 
 MI355_API void mi355_default_build_params(mi355_build_params* p);
@@ -78,6 +82,13 @@ MI355_API int mi355_device_name(int device, char* out, size_t n);
 MI355_API int mi355_bvh_build(int device, const mi355_mesh* meshes, uint32_t num_meshes,
                               const mi355_build_params* params, void* stream, mi355_bvh_t* out);
 MI355_API void mi355_bvh_destroy(mi355_bvh_t bvh);
+/* Refit (RTC_BUILD_QUALITY_REFIT; the reference: kernels/bvh/bvh_refit.cpp, BVHNRefitT): the vertices moved, the topology did not.
+   `meshes` must list the same geometries (ids, primitive counts, types) in the same order as at the build; vertex pointers, strides and
+   masks are taken anew.  Triangle records are rewritten and the node boxes recomputed bottom-up, in place; blocking.
+   Returns 0 on success; MI355_REFIT_IMPOSSIBLE when the tree was built without params.refit, the mesh list differs, the build had skipped
+   invalid triangles, or a triangle has become invalid -- the tree is then UNUSABLE and the caller must build again; other values: HIP errors. */
+#define MI355_REFIT_IMPOSSIBLE (-2)
+MI355_API int mi355_bvh_refit(mi355_bvh_t bvh, const mi355_mesh* meshes, uint32_t num_meshes, void* stream);
 /* Build scratch (prim refs, binary tree, work lists) is kept per device between commits; this returns it to the driver. */
 MI355_API void mi355_release_build_scratch(int device);
 MI355_API int mi355_bvh_get_info(mi355_bvh_t bvh, mi355_bvh_info* info);

@@ -263,3 +263,82 @@ def test_memory_monitor(api):
     assert state["used"] == 0
     L.rtcSetDeviceMemoryMonitorFunction(d.h, C.cast(None, MON), None)
     d.release()
+
+
+def _wobble(meshes, step):
+    """the same topology, moved vertices: every sphere breathes and drifts (a deforming-mesh frame)"""
+    out = []
+    for k, (v, t) in enumerate(meshes):
+        c = v.mean(0)
+        s = np.float32(1.0 + 0.25 * np.sin(0.9 * step + k))
+        d = np.array([np.sin(step + k), np.cos(1.3 * step + 2 * k), np.sin(0.7 * step - k)], np.float32) * np.float32(0.35)
+        out.append((((v - c) * s + c + d).astype(np.float32), t))
+    return out
+
+
+def _same_hits(a, b):
+    """two trees over the same triangles: identical records except where two triangles tie on t (which one is reported depends on the leaf order)"""
+    same = (a["geomID"] == b["geomID"]) & (a["primID"] == b["primID"])
+    assert (a["tfar"][~same] == b["tfar"][~same]).all(), "different triangle without a tie on t"
+    assert (~same).sum() <= max(4, a.shape[0] // 2000)
+    for f in ("tfar", "u", "v", "Ng_x", "Ng_y", "Ng_z"):
+        assert (a[f][same] == b[f][same]).all(), f
+
+
+@pytest.mark.parametrize("flags", [0, 4])
+def test_refit_equals_rebuild(api, dev, flags):
+    """RTC_BUILD_QUALITY_REFIT (rtcSetGeometryBuildQuality.md; BVHNRefitT, kernels/bvh/bvh_refit.cpp): after rtcUpdateGeometryBuffer(VERTEX) the
+    commit keeps the topology of the tree and refits it.  The refitted scene must answer like a scene built from scratch on the moved vertices --
+    bit for bit, closest hit and any hit -- the scene bounds must follow, and what cannot be refitted (new index data, a triangle gone invalid)
+    must fall back to a rebuild."""
+    L = api.load()
+    base = [W.triangle_sphere(np.array([x * 2.2, 0.4 * x, 0.3 * (x % 2)], np.float32), 1.0, 40, noise=0.1, seed=7 + x) for x in range(5)]
+    s = api.Scene(dev, flags)
+    gids = [s.add_triangle_mesh(v, t, shared=False) for v, t in base]
+    for g in gids[:4]:
+        s.set_geometry_build_quality(g, api.RTC_BUILD_QUALITY_REFIT)
+    s.commit()
+    i0 = s.info()
+    assert i0["num_refits"] == 0 and i0["bytes_refit"] == 8 * i0["num_triangles"]
+    rng = np.random.default_rng(11)
+    org = (rng.random((60000, 3), dtype=np.float32) - 0.5) * np.array([16, 8, 8], np.float32) + np.array([4.4, 0.8, 0], np.float32)
+    tgt = (rng.random((60000, 3), dtype=np.float32) - 0.5) * np.array([10, 2, 2], np.float32) + np.array([4.4, 0.8, 0], np.float32)
+    refits = 0
+    for step in range(1, 4):
+        moved = _wobble(base, step)
+        moved[4] = base[4]                                      # the MEDIUM-quality mesh stays: only REFIT meshes changed
+        for g in gids[:4]:
+            s.update_vertices(g, moved[g][0])
+        s.commit()
+        i1 = s.info()
+        refits += 1
+        assert i1["num_refits"] == refits and i1["num_nodes"] == i0["num_nodes"], "the commit rebuilt instead of refitting"
+        fresh = api.make_scene(dev, moved, flags=flags)
+        lo, hi = s.bounds(); flo, fhi = fresh.bounds()
+        assert (lo == flo).all() and (hi == fhi).all()
+        a, b = make_rayhits(org, tgt - org), make_rayhits(org, tgt - org)
+        s.intersect1M(a); fresh.intersect1M(b)
+        assert (a["geomID"] != INVALID_ID).sum() > 20000
+        _same_hits(a, b)
+        ra, rb = rays_of(make_rayhits(org, tgt - org)), rays_of(make_rayhits(org, tgt - org))
+        s.occluded1M(ra); fresh.occluded1M(rb)
+        assert (np.isneginf(ra["tfar"]) == np.isneginf(rb["tfar"])).all()
+        fresh.release()
+    # a mesh of MEDIUM quality moved: full rebuild (num_refits restarts with the new tree)
+    moved = _wobble(base, 5)
+    s.update_vertices(gids[4], moved[4][0])
+    s.commit()
+    assert s.info()["num_refits"] == 0
+    # a triangle that becomes invalid cannot be refitted: the commit falls back to the builder, which skips it (scene_triangle_mesh.h:195-215)
+    bad = moved[0][0].copy(); bad[base[0][1][17, 0]] = np.nan
+    s.update_vertices(gids[0], bad)
+    s.commit()
+    i2 = s.info()
+    assert i2["num_refits"] == 0 and i2["num_triangles"] < i0["num_triangles"]
+    ref = [(bad, base[0][1])] + [(moved[k][0] if k == 4 else _wobble(base, 3)[k][0], base[k][1]) for k in range(1, 5)]
+    fresh = api.make_scene(dev, ref, flags=flags)
+    a, b = make_rayhits(org, tgt - org), make_rayhits(org, tgt - org)
+    s.intersect1M(a); fresh.intersect1M(b)
+    _same_hits(a, b)
+    fresh.release()
+    s.release()
