@@ -102,6 +102,30 @@ __attribute__((visibility("default"))) unsigned refd_add_quads(void* h, const fl
   return id;
 }
 
+// a second scene on the SAME device (rtcRetainDevice), to be instanced by the first: RTC_GEOMETRY_TYPE_INSTANCE needs both on one device
+__attribute__((visibility("default"))) void* refd_new_object(void* parent) {
+  RefScene* p = (RefScene*)parent;
+  RefScene* s = new RefScene;
+  s->device = p->device; rtcRetainDevice(s->device);
+  s->scene = rtcNewScene(s->device);
+  return s;
+}
+
+// rtcNewGeometry(INSTANCE) + rtcSetGeometryInstancedScene + rtcSetGeometryTransform(FLOAT3X4_COLUMN_MAJOR: vx, vy, vz, p)
+// (tutorials/instanced_geometry/instanced_geometry_device.cpp:145-160 is the idiom); the object scene must be committed by the caller
+__attribute__((visibility("default"))) unsigned refd_add_instance(void* h, void* object, const float* xfm12, unsigned mask) {
+  RefScene* s = (RefScene*)h;
+  RTCGeometry g = rtcNewGeometry(s->device, RTC_GEOMETRY_TYPE_INSTANCE);
+  rtcSetGeometryInstancedScene(g, ((RefScene*)object)->scene);
+  rtcSetGeometryTimeStepCount(g, 1);
+  rtcSetGeometryTransform(g, 0, RTC_FORMAT_FLOAT3X4_COLUMN_MAJOR, xfm12);
+  rtcSetGeometryMask(g, mask);
+  rtcCommitGeometry(g);
+  unsigned id = rtcAttachGeometry(s->scene, g);
+  rtcReleaseGeometry(g);
+  return id;
+}
+
 __attribute__((visibility("default"))) double refd_commit(void* h) {
   RefScene* s = (RefScene*)h;
   double t0 = now();

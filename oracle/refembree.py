@@ -31,6 +31,10 @@ def _load():
                                     ctypes.c_void_p, ctypes.c_uint, ctypes.c_uint]
         L.refd_add_quads.restype = ctypes.c_uint
         L.refd_add_quads.argtypes = L.refd_add_mesh.argtypes
+        L.refd_new_object.restype = ctypes.c_void_p
+        L.refd_new_object.argtypes = [ctypes.c_void_p]
+        L.refd_add_instance.restype = ctypes.c_uint
+        L.refd_add_instance.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint]
         L.refd_commit.restype = ctypes.c_double
         L.refd_commit.argtypes = [ctypes.c_void_p]
         L.refd_error.restype = ctypes.c_int
@@ -53,9 +57,9 @@ def hw_threads():
 class RefScene:
     """One device + one scene of the real reference."""
 
-    def __init__(self, cfg="", flags=0, quality=1):
+    def __init__(self, cfg="", flags=0, quality=1, parent=None):
         L = _load()
-        self._h = L.refd_new(cfg.encode())
+        self._h = L.refd_new_object(parent._h) if parent is not None else L.refd_new(cfg.encode())
         if not self._h:
             raise RuntimeError("reference rtcNewDevice failed")
         if flags or quality != 1:
@@ -71,6 +75,15 @@ class RefScene:
         v = np.ascontiguousarray(verts, np.float32).reshape(-1, 3)
         q = np.ascontiguousarray(quads, np.uint32).reshape(-1, 4)
         return _load().refd_add_quads(self._h, v.ctypes.data, v.shape[0], q.ctypes.data, q.shape[0], mask)
+
+    def new_object(self, flags=0):
+        """a second scene on this scene's device, to be instanced with add_instance (commit it first)"""
+        return RefScene(flags=flags, parent=self)
+
+    def add_instance(self, obj, local2world, mask=1):
+        """RTC_GEOMETRY_TYPE_INSTANCE of `obj`; local2world = 12 floats, column major (vx, vy, vz, p)"""
+        x = np.ascontiguousarray(local2world, np.float32).reshape(12)
+        return _load().refd_add_instance(self._h, obj._h, x.ctypes.data, mask)
 
     def commit(self):
         self.commit_seconds = _load().refd_commit(self._h)

@@ -55,6 +55,7 @@ typedef struct {
   uint64_t stat_nodes, stat_leaves, stat_blocks; /* traversal visit counters (STAT3, kernels/common/stat.h:9-19) */
   int quads;               /* this tree is the scene's QUAD accel (BVH8Quad4v, scene.cpp:276-320): the reference builds one BVH per geometry type and
                               queries them in turn (AccelN, kernels/common/acceln.cpp:44-50); oracle/restate.py keeps one Scene per type */
+  uint32_t ctxInstID, ctxInstPrimID; /* RTCRayQueryContext::instID[0] / instPrimID[0] while this scene is queried through an instance (instance_stack.h:19-50); INVALID otherwise */
   int robust;              /* RTC_SCENE_FLAG_ROBUST: Triangle4v leaves (v0,v1,v2) + Pluecker test + conservative node test (scene.cpp:180-188) */
 } Scene;
 
@@ -84,7 +85,7 @@ static uint32_t fbits(float a) { uint32_t u; memcpy(&u, &a, 4); return u; }
 
 /* ------------------------------------------------------------------ scene */
 API void ora_set_robust(Scene* s, int robust) { s->robust = robust; }   /* rtcSetSceneFlags(RTC_SCENE_FLAG_ROBUST), before ora_commit */
-API Scene* ora_new(void) { Scene* s = (Scene*)calloc(1, sizeof(Scene)); s->root = EMPTY_REF; return s; }
+API Scene* ora_new(void) { Scene* s = (Scene*)calloc(1, sizeof(Scene)); s->root = EMPTY_REF; s->ctxInstID = s->ctxInstPrimID = INVALID_ID; return s; }
 
 static void free_build(Scene* s) {
   free(s->prims); free(s->nodes); free(s->blocks);
@@ -534,7 +535,7 @@ static void quad_leaf_intersect(Scene* s, RayHit* rh, size_t start, size_t num) 
       rh->hit.Ng_x = q[best].Ng[0]; rh->hit.Ng_y = q[best].Ng[1]; rh->hit.Ng_z = q[best].Ng[2];
       rh->hit.u = q[best].u; rh->hit.v = q[best].v;
       rh->hit.primID = b->primID[best & 3]; rh->hit.geomID = g;
-      rh->hit.instID = INVALID_ID; rh->hit.instPrimID = INVALID_ID;
+      rh->hit.instID = s->ctxInstID; rh->hit.instPrimID = s->ctxInstPrimID;
       break;
     }
   }
@@ -586,7 +587,7 @@ static void leaf_intersect(Scene* s, RayHit* rh, size_t start, size_t num) {
       rh->hit.Ng_x = h[best].Ng[0]; rh->hit.Ng_y = h[best].Ng[1]; rh->hit.Ng_z = h[best].Ng[2];
       rh->hit.u = u[best]; rh->hit.v = v[best];
       rh->hit.primID = b->primID[best]; rh->hit.geomID = g;
-      rh->hit.instID = INVALID_ID; rh->hit.instPrimID = INVALID_ID; /* copy of the default context, :295-298 */
+      rh->hit.instID = s->ctxInstID; rh->hit.instPrimID = s->ctxInstPrimID; /* copy of the default context, :295-298 */
       break;
     }
   }
@@ -679,6 +680,103 @@ static void occluded1(Scene* s, Ray* ray) {
 /* API wrappers: rtcIntersect1 / rtcOccluded1 looped over an AoS array (kernels/common/rtcore.cpp:599,918) */
 API void ora_intersect1(Scene* s, RayHit* rh, uint32_t M) { for (uint32_t i = 0; i < M; i++) intersect1(s, &rh[i]); }
 API void ora_occluded1(Scene* s, Ray* r, uint32_t M) { for (uint32_t i = 0; i < M; i++) occluded1(s, &r[i]); }
+
+/* ------------------------------------------------------------------ instances (RTC_GEOMETRY_TYPE_INSTANCE, one level)
+ * Instance::setTransform / commit (kernels/common/scene_instance.cpp:105,150-153): world2local0 = rcp(local2world[0]);
+ * rcp(AffineSpace) = (il = rcp(l), -(il * p)) (common/math/affinespace.h:83); LinearSpace3::inverse = adjoint() / det()
+ * (linearspace3.h:44-51), cross = msub(a0,b0,a1*b1) shuffled (vec3fa.h:334-341), dot = DPPS 0x7F (:325-327).
+ * InstanceIntersector1::intersect / occluded (kernels/geometry/instance_intersector.cpp:15-68): ray mask test, push the instance id
+ * (fails when a level is already open: RTC_MAX_INSTANCE_LEVEL_COUNT = 1), org' = xfmPoint(w2l, org), dir' = xfmVector(w2l, dir)
+ * (affinespace.h:102-103, linearspace3.h:159: nested madd), the object's accels are queried with the transformed ray (tnear, tfar and
+ * therefore every t are unchanged), org/dir restored.  The hit keeps the object-space Ng and gets instID[0] / instPrimID[0] = id / 0.
+ * The reference finds the instances whose bounds a ray enters with a BVH4 over xfmBounds(local2world, object bounds)
+ * (Instance::bounds, scene_instance.h:64-69); here they are visited in id order with the same box test as a cull -- the set of
+ * candidate hits is the same, only the order (= which of two hits at the identical t is kept) can differ. */
+typedef struct { Scene* tri; Scene* quad; float l2w[12], w2l[12]; uint32_t mask, id; Box bounds; int valid; } Inst;
+typedef struct { Inst* inst; uint32_t n, cap; Box bounds; } InstSet;
+
+static void cross3f(const float* a, const float* b, float* o) {     /* vec3fa.h:334-341 */
+  o[0] = fmaf(a[1], b[2], -(a[2] * b[1])); o[1] = fmaf(a[2], b[0], -(a[0] * b[2])); o[2] = fmaf(a[0], b[1], -(a[1] * b[0]));
+}
+static float dpps3(const float* a, const float* b) { return (a[0] * b[0] + a[1] * b[1]) + (a[2] * b[2] + 0.0f); }   /* _mm_dp_ps(a,b,0x7F) */
+static void affine_rcp(const float* m, float* o) {
+  const float *vx = m, *vy = m + 3, *vz = m + 6, *p = m + 9;
+  float c0[3], c1[3], c2[3];
+  cross3f(vy, vz, c0); cross3f(vz, vx, c1); cross3f(vx, vy, c2);   /* adjoint = (c0, c1, c2) transposed */
+  const float det = dpps3(vx, c0);
+  float il[9];                                                     /* columns of the inverse */
+  for (int r = 0; r < 3; r++) { il[0 + r] = (r == 0 ? c0[0] : r == 1 ? c1[0] : c2[0]) / det; il[3 + r] = (r == 0 ? c0[1] : r == 1 ? c1[1] : c2[1]) / det; il[6 + r] = (r == 0 ? c0[2] : r == 1 ? c1[2] : c2[2]) / det; }
+  memcpy(o, il, 36);
+  for (int r = 0; r < 3; r++) o[9 + r] = -fmaf(p[0], il[0 + r], fmaf(p[1], il[3 + r], p[2] * il[6 + r]));   /* -(il * p), linearspace3.h:150 */
+}
+static void xfm_point(const float* m, const float* p, float* o) { for (int r = 0; r < 3; r++) o[r] = fmaf(p[0], m[0 + r], fmaf(p[1], m[3 + r], fmaf(p[2], m[6 + r], m[9 + r]))); }
+static void xfm_vector(const float* m, const float* v, float* o) { for (int r = 0; r < 3; r++) o[r] = fmaf(v[0], m[0 + r], fmaf(v[1], m[3 + r], v[2] * m[6 + r])); }
+
+API InstSet* ora_inst_new(void) { InstSet* s = (InstSet*)calloc(1, sizeof(InstSet)); box_empty(&s->bounds); return s; }
+API void ora_inst_free(InstSet* s) { if (s) { free(s->inst); free(s); } }
+/* tri / quad: the object scene's two accels (either may be NULL), already committed; l2w: vx, vy, vz, p */
+API void ora_inst_add(InstSet* s, Scene* tri, Scene* quad, const float* l2w, uint32_t mask, uint32_t id) {
+  if (s->n == s->cap) { s->cap = s->cap ? 2 * s->cap : 16; s->inst = (Inst*)realloc(s->inst, s->cap * sizeof(Inst)); }
+  Inst* I = &s->inst[s->n++];
+  I->tri = tri; I->quad = quad; I->mask = mask; I->id = id;
+  memcpy(I->l2w, l2w, 48); affine_rcp(l2w, I->w2l);
+  Box ob; box_empty(&ob);
+  if (tri && tri->nprims) box_extend(&ob, tri->bounds.lo, tri->bounds.hi);
+  if (quad && quad->nprims) box_extend(&ob, quad->bounds.lo, quad->bounds.hi);
+  box_empty(&I->bounds);
+  for (int c = 0; c < 8; c++) {                                   /* xfmBounds, affinespace.h:106-118 */
+    const float p[3] = { (c & 4) ? ob.hi[0] : ob.lo[0], (c & 2) ? ob.hi[1] : ob.lo[1], (c & 1) ? ob.hi[2] : ob.lo[2] };
+    float q[3]; xfm_point(I->l2w, p, q); box_extend_pt(&I->bounds, q);
+  }
+  I->valid = 1;
+  for (int k = 0; k < 3; k++) if (!(valid_f(I->bounds.lo[k]) && valid_f(I->bounds.hi[k]) && I->bounds.lo[k] <= I->bounds.hi[k])) I->valid = 0;   /* Instance::buildBounds: isvalid(b) */
+  if (I->valid) box_extend(&s->bounds, I->bounds.lo, I->bounds.hi);
+}
+API void ora_inst_bounds(const InstSet* s, float* lo3hi3) { memcpy(lo3hi3, &s->bounds, 24); }
+
+static int inst_box_hit(const Inst* I, const Ray* r, float tfar) {    /* the cull only: slab test against the instance's world box */
+  const float o[3] = { r->org_x, r->org_y, r->org_z }, d[3] = { r->dir_x, r->dir_y, r->dir_z };
+  float t0 = fmaxf_(r->tnear, 0.0f), t1 = tfar;
+  for (int k = 0; k < 3; k++) {
+    const float rd = 1.0f / (fabsf(d[k]) < 1E-18f ? 1E-18f : d[k]);
+    float a = (I->bounds.lo[k] - o[k]) * rd, b = (I->bounds.hi[k] - o[k]) * rd;
+    if (a > b) { float t = a; a = b; b = t; }
+    a *= a > 0 ? 1.0f - 4.0f * FLT_EPSILON : 1.0f + 4.0f * FLT_EPSILON; b *= b > 0 ? 1.0f + 4.0f * FLT_EPSILON : 1.0f - 4.0f * FLT_EPSILON;
+    if (a > t0) t0 = a;
+    if (b < t1) t1 = b;
+  }
+  return t0 <= t1;
+}
+static void inst_enter(const Inst* I, Ray* r, float* save) {
+  save[0] = r->org_x; save[1] = r->org_y; save[2] = r->org_z; save[3] = r->dir_x; save[4] = r->dir_y; save[5] = r->dir_z;
+  float o[3], d[3]; xfm_point(I->w2l, save, o); xfm_vector(I->w2l, save + 3, d);
+  r->org_x = o[0]; r->org_y = o[1]; r->org_z = o[2]; r->dir_x = d[0]; r->dir_y = d[1]; r->dir_z = d[2];
+}
+static void inst_leave(Ray* r, const float* save) { r->org_x = save[0]; r->org_y = save[1]; r->org_z = save[2]; r->dir_x = save[3]; r->dir_y = save[4]; r->dir_z = save[5]; }
+static void inst_ctx(const Inst* I, uint32_t id, uint32_t prim) { if (I->tri) { I->tri->ctxInstID = id; I->tri->ctxInstPrimID = prim; } if (I->quad) { I->quad->ctxInstID = id; I->quad->ctxInstPrimID = prim; } }
+
+API void ora_inst_intersect1(InstSet* s, RayHit* rh, uint32_t M) {
+  for (uint32_t i = 0; i < M; i++) for (uint32_t k = 0; k < s->n; k++) {
+    const Inst* I = &s->inst[k];
+    if (!I->valid || (rh[i].ray.mask & I->mask) == 0) continue;
+    if (!inst_box_hit(I, &rh[i].ray, rh[i].ray.tfar)) continue;
+    float save[6]; inst_enter(I, &rh[i].ray, save); inst_ctx(I, I->id, 0);
+    if (I->tri) intersect1(I->tri, &rh[i]);
+    if (I->quad) intersect1(I->quad, &rh[i]);
+    inst_ctx(I, INVALID_ID, INVALID_ID); inst_leave(&rh[i].ray, save);
+  }
+}
+API void ora_inst_occluded1(InstSet* s, Ray* r, uint32_t M) {
+  for (uint32_t i = 0; i < M; i++) for (uint32_t k = 0; k < s->n && !(r[i].tfar < 0.0f); k++) {
+    const Inst* I = &s->inst[k];
+    if (!I->valid || (r[i].mask & I->mask) == 0) continue;
+    if (!inst_box_hit(I, &r[i], r[i].tfar)) continue;
+    float save[6]; inst_enter(I, &r[i], save);
+    if (I->tri) occluded1(I->tri, &r[i]);
+    if (I->quad && !(r[i].tfar < 0.0f)) occluded1(I->quad, &r[i]);
+    inst_leave(&r[i], save);
+  }
+}
 
 /* Tie classification helper: t of ray i against ONE named triangle,
    computed with the same Moeller-Trumbore arithmetic; NaN if that triangle is not hit in (tnear, tfar_in]. */

@@ -36,6 +36,12 @@ def _load():
         L.ora_occluded1.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint]
         L.ora_triangle_t.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                      ctypes.c_void_p, ctypes.c_uint]
+        L.ora_inst_new.restype = ctypes.c_void_p
+        L.ora_inst_free.argtypes = [ctypes.c_void_p]
+        L.ora_inst_add.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint, ctypes.c_uint]
+        L.ora_inst_bounds.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        L.ora_inst_intersect1.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint]
+        L.ora_inst_occluded1.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint]
         _lib = L
     return _lib
 
@@ -49,6 +55,7 @@ class OracleScene:
         L = _load()
         self._h, self._hq = L.ora_new(), L.ora_new()
         self._has_quads = False
+        self._hi, self._objs, self._next_id = None, [], 0          # instance accel (created with the first instance), instanced scenes kept alive
         if robust:
             L.ora_set_robust(self._h, 1)
             L.ora_set_robust(self._hq, 1)
@@ -58,6 +65,7 @@ class OracleScene:
         t = np.ascontiguousarray(tris, np.uint32).reshape(-1, 3)
         L = _load()
         L.ora_add_quads(self._hq, None, 0, None, 0, mask)
+        self._next_id += 1
         return L.ora_add_mesh(self._h, v.ctypes.data, v.shape[0], t.ctypes.data, t.shape[0], mask)
 
     def add_quads(self, verts, quads, mask=1):
@@ -66,7 +74,23 @@ class OracleScene:
         L = _load()
         self._has_quads = True
         L.ora_add_mesh(self._h, None, 0, None, 0, mask)
+        self._next_id += 1
         return L.ora_add_quads(self._hq, v.ctypes.data, v.shape[0], q.ctypes.data, q.shape[0], mask)
+
+    def add_instance(self, obj, local2world, mask=1):
+        """RTC_GEOMETRY_TYPE_INSTANCE of the committed OracleScene `obj` (its triangle and quad accels; instances inside `obj` are dropped like the
+        reference drops a second level, instance_stack.h:36-47); local2world = 12 floats column major (vx, vy, vz, p).  Takes the next geometry id."""
+        L = _load()
+        if self._hi is None:
+            self._hi = L.ora_inst_new()
+        x = np.ascontiguousarray(local2world, np.float32).reshape(12)
+        gid = self._next_id
+        self._next_id += 1
+        L.ora_add_mesh(self._h, None, 0, None, 0, mask)           # the id stays empty in the other accels
+        L.ora_add_quads(self._hq, None, 0, None, 0, mask)
+        L.ora_inst_add(self._hi, obj._h, obj._hq if obj._has_quads else None, x.ctypes.data, mask, gid)
+        self._objs.append(obj)
+        return gid
 
     def commit(self):
         _load().ora_commit(self._h)
@@ -76,7 +100,11 @@ class OracleScene:
         b, c = np.zeros(6, np.float32), np.zeros(6, np.float32)
         _load().ora_bounds(self._h, b.ctypes.data)
         _load().ora_bounds(self._hq, c.ctypes.data)
-        return np.minimum(b[:3], c[:3]), np.maximum(b[3:], c[3:])
+        lo, hi = np.minimum(b[:3], c[:3]), np.maximum(b[3:], c[3:])
+        if self._hi is not None:
+            _load().ora_inst_bounds(self._hi, c.ctypes.data)
+            lo, hi = np.minimum(lo, c[:3]), np.maximum(hi, c[3:])
+        return lo, hi
 
     def counts(self):
         c = np.zeros(4, np.uint64)
@@ -93,12 +121,16 @@ class OracleScene:
         _load().ora_intersect1(self._h, rayhits.ctypes.data, rayhits.shape[0])
         if self._has_quads:
             _load().ora_intersect1(self._hq, rayhits.ctypes.data, rayhits.shape[0])
+        if self._hi is not None:                                   # the instance accel comes last (Scene::commit, kernels/common/scene.cpp:777-790)
+            _load().ora_inst_intersect1(self._hi, rayhits.ctypes.data, rayhits.shape[0])
 
     def occluded1(self, rays):
         assert rays.flags["C_CONTIGUOUS"] and rays.dtype.itemsize == 48
         _load().ora_occluded1(self._h, rays.ctypes.data, rays.shape[0])
         if self._has_quads:
             _load().ora_occluded1(self._hq, rays.ctypes.data, rays.shape[0])
+        if self._hi is not None:
+            _load().ora_inst_occluded1(self._hi, rays.ctypes.data, rays.shape[0])
 
     def triangle_t(self, rayhits_in, geomID, primID):
         """t of ray i against the single primitive (geomID[i], primID[i]) (a quad: the nearer of its two triangles); NaN if not hit.
@@ -118,6 +150,9 @@ class OracleScene:
             if h:
                 _load().ora_free(h)
         self._h = self._hq = None
+        if getattr(self, "_hi", None):
+            _load().ora_inst_free(self._hi)
+            self._hi = None
 
     def __del__(self):
         try:

@@ -15,6 +15,9 @@ Outputs
                          masks 1 and 2, ray masks alternating) incl. occluded results
   ref_trianglehit.npz    TriangleHitTest (tutorials/verify/verify.cpp:2462-2547) inputs + real-reference outputs
   ref_quads.npz          a noisy 40x40 quad grid (RTC_GEOMETRY_TYPE_QUAD, mask 3) + a triangle sphere, 26,000 rays, fast and robust scenes
+  ref_instances.npz      RTC_GEOMETRY_TYPE_INSTANCE: a ground plane and a sphere as the scene's own geometry + 24 instances (random rotation, non-uniform
+                         scale, shear, translation; geometry masks 1/2/3) of two object scenes (a noisy sphere; a cube + a 4x4 quad patch), 40,000 rays
+                         with masks, fast and robust scenes: rtcIntersect1 (incl. instID / instPrimID) and rtcOccluded1 results
   ref_watertight_robust.npz  WatertightTest (verify.cpp:3611-3688) at its position (148376, 1234, -223423): triangle sphere of
                          radius 2 (numPhi 50), 8192 rays from inside, real reference with RTC_SCENE_FLAG_ROBUST
                          (BVH8Triangle4v + Pluecker + conservative node test); rtcIntersect1 and rtcOccluded1 results
@@ -77,6 +80,59 @@ def soup(n, seed):
     return v.astype(np.float32), t
 
 
+def instances_fixture():
+    rng = np.random.default_rng(2024)
+    ground = (np.array([[-8, -3, -8], [8, -3, -8], [8, -3, 8], [-8, -3, 8]], np.float32), np.array([[0, 1, 2], [0, 2, 3]], np.uint32))
+    own_sphere = W.triangle_sphere([0.0, 0.0, 0.0], 0.8, 10)
+    obj_a = W.triangle_sphere([0.1, -0.2, 0.05], 1.0, 16, noise=0.2, seed=9)
+    cube = W.cube_and_plane()[0]
+    k = 4
+    gy, gx = np.meshgrid(np.arange(k + 1, dtype=np.float32), np.arange(k + 1, dtype=np.float32), indexing="ij")
+    qv = np.stack([gx / k * 2 - 1, 1.3 + 0.1 * rng.standard_normal(gx.shape).astype(np.float32), gy / k * 2 - 1], -1).reshape(-1, 3).astype(np.float32)
+    ii = (np.arange(k)[:, None] * (k + 1) + np.arange(k)[None, :]).ravel()
+    qq = np.stack([ii, ii + 1, ii + k + 2, ii + k + 1], -1).astype(np.uint32)
+    n_inst = 24
+    xf = np.zeros((n_inst, 12), np.float32)
+    for i in range(n_inst):
+        q, _ = np.linalg.qr(rng.standard_normal((3, 3)))
+        sc = np.diag(rng.uniform(0.3, 1.2, 3))
+        sh = np.eye(3); sh[0, 1] = rng.uniform(-0.3, 0.3)
+        m = q @ sh @ sc
+        xf[i, :9] = m.T.reshape(9).astype(np.float32)             # column major: vx, vy, vz
+        xf[i, 9:] = rng.uniform(-4.5, 4.5, 3).astype(np.float32) * np.array([1, 0.5, 1], np.float32)
+    imask = np.array([1 + (i % 3) for i in range(n_inst)], np.uint32)
+    which = np.array([i % 2 for i in range(n_inst)], np.uint32)        # 0: object A, 1: object B
+    rays = np.concatenate([W.incoherent_rays(24000, [0.0, 0.5, 0.0], seed=21), W.incoherent_rays(8000, [3.0, 1.0, -2.0], seed=22)])
+    org = rng.uniform(-9, 9, (8000, 3)).astype(np.float32); org[:, 1] = np.abs(org[:, 1]) * 0.5 + 2.0
+    tgt = (xf[rng.integers(0, n_inst, 8000), 9:] + rng.uniform(-0.6, 0.6, (8000, 3))).astype(np.float32)       # aimed at the instances
+    rays = np.concatenate([rays, make_rayhits(org, tgt - org)])
+    rays["id"] = np.arange(rays.shape[0], dtype=np.uint32)
+    rays["mask"] = np.where(np.arange(rays.shape[0]) % 4 == 0, 1, np.where(np.arange(rays.shape[0]) % 4 == 1, 2, 0xFFFFFFFF)).astype(np.uint32)
+    out = dict(ground_v=ground[0], ground_t=ground[1], sphere_v=own_sphere[0], sphere_t=own_sphere[1], a_v=obj_a[0], a_t=obj_a[1],
+               cube_v=cube[0], cube_t=cube[1], qv=qv, qq=qq, xfm=xf, inst_mask=imask, inst_obj=which, rays=rays)
+    for fl, suffix in ((0, ""), (4, "_robust")):
+        top = refembree.RefScene("threads=1", flags=fl)
+        oa, ob = top.new_object(fl), top.new_object(fl)
+        if fl:
+            refembree._load().refd_set_flags(oa._h, fl, 1); refembree._load().refd_set_flags(ob._h, fl, 1)
+        oa.add_mesh(*obj_a); oa.commit()
+        ob.add_mesh(*cube); ob.add_quads(qv, qq); ob.commit()
+        assert top.add_mesh(*ground) == 0 and top.add_mesh(*own_sphere) == 1
+        for i in range(n_inst):
+            assert top.add_instance(ob if which[i] else oa, xf[i], int(imask[i])) == 2 + i
+        top.commit()
+        rh = rays.copy(); top.intersect1(rh)
+        rr = rays_of(rays); top.occluded1(rr)
+        out["hits" + suffix], out["occl" + suffix] = rh, rr["tfar"].copy()
+        out["bounds_lo"], out["bounds_hi"] = top.bounds()
+        assert top.error() == 0
+        inst_hits = (rh["instID"] != 0xFFFFFFFF).sum()
+        print("instances%s: %d hits, %d through instances, %d occluded" % (suffix, (rh["geomID"] != 0xFFFFFFFF).sum(), inst_hits, np.isneginf(rr["tfar"]).sum()))
+        assert inst_hits > 6000, inst_hits
+        top.close(); oa.close(); ob.close()
+    return out
+
+
 def main():
     v, t = parse_obj(os.path.join(REF, "tutorials/models/cornell_box.obj"))
     assert t.shape[0] == 34, t.shape
@@ -135,6 +191,7 @@ def main():
         out["bounds_lo"], out["bounds_hi"] = sc.bounds()
         sc.close()
     np.savez_compressed(os.path.join(OUT, "ref_quads.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, "ref_instances.npz"), **instances_fixture())
     print("golden fixtures written to", OUT)
 
 

@@ -117,6 +117,37 @@ def test_oracle_quads_match_golden_bit_exact(restate, golden_dir, robust):
     assert ((want["geomID"] == 1).sum() > 1000)
 
 
+def instanced_oracle(restate, g, robust):
+    """the scene of tests/golden/ref_instances.npz on the restatement: (top, objects kept alive)"""
+    oa, ob, top = restate.OracleScene(robust), restate.OracleScene(robust), restate.OracleScene(robust)
+    oa.add_mesh(g["a_v"], g["a_t"]); oa.commit()
+    ob.add_mesh(g["cube_v"], g["cube_t"]); ob.add_quads(g["qv"], g["qq"]); ob.commit()
+    assert top.add_mesh(g["ground_v"], g["ground_t"]) == 0 and top.add_mesh(g["sphere_v"], g["sphere_t"]) == 1
+    for i in range(g["xfm"].shape[0]):
+        assert top.add_instance(ob if g["inst_obj"][i] else oa, g["xfm"][i], int(g["inst_mask"][i])) == 2 + i
+    top.commit()
+    return top, (oa, ob)
+
+
+@pytest.mark.parametrize("robust", [False, True])
+def test_oracle_instances_match_golden_bit_exact(restate, golden_dir, robust):
+    """RTC_GEOMETRY_TYPE_INSTANCE restated (world2local = rcp(local2world) with the reference's cross/dot/division order, xfmPoint / xfmVector as nested
+    FMAs, ray mask test, instID[0] / instPrimID[0] = id / 0, object-space Ng, xfmBounds) against the real reference: every hit field bit for bit."""
+    g = np.load(os.path.join(golden_dir, "ref_instances.npz"))
+    top, keep = instanced_oracle(restate, g, robust)
+    rh = g["rays"].copy()
+    top.intersect1(rh)
+    want = g["hits_robust" if robust else "hits"]
+    for f in ("tfar", "u", "v", "Ng_x", "Ng_y", "Ng_z", "primID", "geomID", "instID", "instPrimID"):
+        assert (_bits(rh[f]) == _bits(want[f])).all(), f
+    r = rays_of(g["rays"])
+    top.occluded1(r)
+    assert (_bits(r["tfar"]) == _bits(g["occl_robust" if robust else "occl"])).all()
+    lo, hi = top.bounds()
+    assert (lo == g["bounds_lo"]).all() and (hi == g["bounds_hi"]).all()
+    assert (want["instID"] != 0xFFFFFFFF).sum() > 6000 and ((want["instID"] == 0xFFFFFFFF) & (want["geomID"] != 0xFFFFFFFF)).sum() > 6000
+
+
 def test_triangle_hit_known_answer(restate, golden_dir):
     """TriangleHitTest: geomID 0, primID 0, |u-u0|,|v-v0|,|t-1| <= 16 ulp, Ng == (0,0,1) +- 16 ulp."""
     g = np.load(os.path.join(golden_dir, "ref_trianglehit.npz"))
