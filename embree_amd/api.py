@@ -23,6 +23,8 @@ RTC_FORMAT_UINT3, RTC_FORMAT_UINT4, RTC_FORMAT_FLOAT3 = 0x5003, 0x5004, 0x9003
 RTC_SCENE_FLAG_ROBUST = 4
 RTC_BUILD_QUALITY_LOW, RTC_BUILD_QUALITY_MEDIUM, RTC_BUILD_QUALITY_HIGH, RTC_BUILD_QUALITY_REFIT = 0, 1, 2, 3
 RTC_SCENE_FLAG_DYNAMIC = 1
+RTC_GEOMETRY_TYPE_INSTANCE = 121
+RTC_FORMAT_FLOAT3X4_ROW_MAJOR, RTC_FORMAT_FLOAT3X4_COLUMN_MAJOR, RTC_FORMAT_FLOAT4X4_COLUMN_MAJOR = 0x9134, 0x9234, 0x9244
 
 # every symbol include/embree4/rtcore.h and include/embree_amd_hip.h declare (checked by tests/test_abi.py)
 RTC_SYMBOLS = """rtcNewDevice rtcRetainDevice rtcReleaseDevice rtcGetDeviceProperty rtcSetDeviceProperty rtcGetErrorString
@@ -30,6 +32,7 @@ rtcGetDeviceError rtcGetDeviceLastErrorMessage rtcSetDeviceErrorFunction rtcSetD
 rtcNewBuffer rtcNewSharedBuffer rtcGetBufferData rtcRetainBuffer rtcReleaseBuffer
 rtcNewGeometry rtcRetainGeometry rtcReleaseGeometry rtcCommitGeometry rtcEnableGeometry rtcDisableGeometry
 rtcSetGeometryTimeStepCount rtcSetGeometryVertexAttributeCount rtcSetGeometryMask rtcSetGeometryBuildQuality
+rtcSetGeometryInstancedScene rtcSetGeometryTransform rtcGetGeometryTransform
 rtcSetGeometryBuffer rtcSetSharedGeometryBuffer rtcSetSharedGeometryBufferHostDevice rtcSetNewGeometryBuffer
 rtcGetGeometryBufferData rtcUpdateGeometryBuffer rtcSetGeometryUserData rtcGetGeometryUserData
 rtcSetGeometryIntersectFilterFunction rtcSetGeometryOccludedFilterFunction
@@ -41,7 +44,7 @@ rtcTraversableIntersect1 rtcTraversableIntersect4 rtcTraversableIntersect8 rtcTr
 rtcTraversableOccluded1 rtcTraversableOccluded4 rtcTraversableOccluded8 rtcTraversableOccluded16
 rtcIntersect1M rtcOccluded1M rtcIntersect1MDevice rtcOccluded1MDevice""".split()
 MI355_SYMBOLS = """mi355_default_build_params mi355_last_error mi355_device_count mi355_device_name mi355_bvh_build
-mi355_bvh_destroy mi355_bvh_refit mi355_release_build_scratch mi355_bvh_get_info mi355_bvh_download mi355_trace_prepare mi355_trace_closest mi355_trace_any
+mi355_bvh_destroy mi355_bvh_build_instanced mi355_bvh_refit mi355_release_build_scratch mi355_bvh_get_info mi355_bvh_download mi355_trace_prepare mi355_trace_closest mi355_trace_any
 mi355_trace_closest_packet mi355_trace_any_packet mi355_trace_stats mi355_trace_timed mi355_malloc mi355_free mi355_memcpy_h2d
 mi355_memcpy_d2h mi355_synchronize mi355_device_synchronize mi355_memcpy_d2d_async mi355_stream_create
 mi355_stream_destroy mi355_event_create mi355_event_record mi355_event_elapsed_ms mi355_event_destroy""".split()
@@ -111,6 +114,10 @@ def load():
         getattr(L, f).argtypes = [vp]
     L.rtcSetGeometryMask.argtypes = [vp, u32]
     L.rtcSetGeometryBuildQuality.argtypes = [vp, C.c_int]
+    L.rtcSetGeometryInstancedScene.argtypes = [vp, vp]
+    L.rtcSetGeometryTransform.argtypes = [vp, u32, C.c_int, vp]
+    L.rtcGetGeometryTransform.argtypes = [vp, C.c_float, C.c_int, vp]
+    L.rtcSetGeometryTimeStepCount.argtypes = [vp, u32]
     L.rtcSetGeometryVertexAttributeCount.argtypes = [vp, u32]
     L.rtcSetSharedGeometryBuffer.argtypes = [vp, C.c_int, u32, C.c_int, vp, sz, sz, sz]
     L.rtcSetSharedGeometryBufferHostDevice.argtypes = [vp, C.c_int, u32, C.c_int, vp, vp, sz, sz, sz]
@@ -312,6 +319,25 @@ class Scene:
         self._keep += [vp, q]
         L.rtcSetSharedGeometryBuffer(g, RTC_BUFFER_TYPE_VERTEX, 0, RTC_FORMAT_FLOAT3, vp.ctypes.data, 0, 12, v.shape[0])
         L.rtcSetSharedGeometryBuffer(g, RTC_BUFFER_TYPE_INDEX, 0, RTC_FORMAT_UINT4, q.ctypes.data, 0, 16, q.shape[0])
+        if mask is not None:
+            L.rtcSetGeometryMask(g, mask)
+        L.rtcCommitGeometry(g)
+        gid = L.rtcAttachGeometry(self.h, g)
+        L.rtcReleaseGeometry(g)
+        self.dev.check()
+        return gid
+
+    def add_instance(self, obj, local2world, mask=None, fmt=RTC_FORMAT_FLOAT3X4_COLUMN_MAJOR):
+        """rtcNewGeometry(INSTANCE) + rtcSetGeometryInstancedScene + rtcSetGeometryTransform + commit + attach + release -> geomID
+        (tutorials/instanced_geometry/instanced_geometry_device.cpp:145-160).  `obj` = a committed Scene of the same device;
+        local2world in `fmt` (default: 12 floats column major = vx, vy, vz, p)."""
+        L = self.L
+        g = L.rtcNewGeometry(self.dev.h, RTC_GEOMETRY_TYPE_INSTANCE)
+        self.dev.check()
+        x = np.ascontiguousarray(local2world, np.float32).ravel()
+        L.rtcSetGeometryInstancedScene(g, obj.h)
+        L.rtcSetGeometryTimeStepCount(g, 1)
+        L.rtcSetGeometryTransform(g, 0, fmt, x.ctypes.data)
         if mask is not None:
             L.rtcSetGeometryMask(g, mask)
         L.rtcCommitGeometry(g)

@@ -1370,6 +1370,16 @@ __global__ __launch_bounds__(64) void refit_level(CNode* nodes, float4* boxes, c
   }
 }
 
+// --------------------------------------------------------------------------------- instanced scenes: object trees copied behind the top tree
+// One thread per node: the 80 bytes are copied, child / triangle base indices moved by the object's offset in the combined arrays.
+__global__ __launch_bounds__(256) void rebase_nodes(const uint4* src, uint4* dst, uint32_t n, uint32_t nodeOfs, uint32_t triOfs) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  uint4 w0 = src[5u * i], w1 = src[5u * i + 1u];
+  w1.x += nodeOfs; w1.y += triOfs;
+  dst[5u * i] = w0; dst[5u * i + 1u] = w1; dst[5u * i + 2u] = src[5u * i + 2u]; dst[5u * i + 3u] = src[5u * i + 3u]; dst[5u * i + 4u] = src[5u * i + 4u];
+}
+
 // Build scratch comes from a per-device arena that survives the commit: rtcCommitScene is timed on the wall clock
 // (tutorials/buildbench/buildbench_device.cpp:385-387) and ~20 hipMalloc/hipFree pairs cost 3 ms of a 10.7 ms commit of 4.76 M
 // triangles.  Blocks are kept until mi355_release_build_scratch(); commits on one device are serialised by the arena's mutex
@@ -1431,6 +1441,7 @@ Bvh::~Bvh() {
   if (d_nodes) hipFree(d_nodes);
   if (d_tris) hipFree(d_tris);
   if (d_ids) hipFree(d_ids);
+  if (d_insts) hipFree(d_insts);
 }
 
 static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, const mi355_build_params* bp, hipStream_t st, Bvh** out) {
@@ -1684,6 +1695,122 @@ static int refit_impl(Bvh* bvh, const mi355_mesh* meshes, uint32_t numMeshes, hi
   return 0;
 }
 
+// ---- scenes with RTC_GEOMETRY_TYPE_INSTANCE (one level).  Host arithmetic of Instance::commit / Instance::bounds:
+// world2local = rcp(local2world) = (il = adjoint / det, -(il * p)) (kernels/common/scene_instance.cpp:150-153, common/math/affinespace.h:83,
+// linearspace3.h:44-51; cross = fma(a.y, b.z, -(a.z * b.y)) ..., vec3fa.h:334-341; det = DPPS), world box = xfmBounds (affinespace.h:106-118).
+static void affine_inverse(const float* m, float* o) {
+  const float *vx = m, *vy = m + 3, *vz = m + 6, *p = m + 9;
+  auto cross = [](const float* a, const float* b, float* c) { c[0] = fmaf(a[1], b[2], -(a[2] * b[1])); c[1] = fmaf(a[2], b[0], -(a[0] * b[2])); c[2] = fmaf(a[0], b[1], -(a[1] * b[0])); };
+  float c0[3], c1[3], c2[3]; cross(vy, vz, c0); cross(vz, vx, c1); cross(vx, vy, c2);
+  const float det = (vx[0] * c0[0] + vx[1] * c0[1]) + (vx[2] * c0[2] + 0.0f);
+  for (int r = 0; r < 3; r++) { const float a = r == 0 ? c0[0] : r == 1 ? c1[0] : c2[0], b = r == 0 ? c0[1] : r == 1 ? c1[1] : c2[1], c = r == 0 ? c0[2] : r == 1 ? c1[2] : c2[2]; o[r] = a / det; o[3 + r] = b / det; o[6 + r] = c / det; }
+  for (int r = 0; r < 3; r++) o[9 + r] = -fmaf(p[0], o[r], fmaf(p[1], o[3 + r], p[2] * o[6 + r]));
+}
+static void affine_point(const float* m, const float* p, float* o) { for (int r = 0; r < 3; r++) o[r] = fmaf(p[0], m[r], fmaf(p[1], m[3 + r], fmaf(p[2], m[6 + r], m[9 + r]))); }
+
+struct InstRec { float w2l[12]; uint32_t root, instID, mask, flags; };
+static_assert(sizeof(InstRec) == 64, "InstRec must be 64 bytes");
+
+static int build_instanced_impl(int device, Bvh* own, const mi355_instance* insts, uint32_t numInsts, const mi355_build_params* bp, hipStream_t st, Bvh** out) {
+  HIP_TRY(hipSetDevice(device));
+  // ---- the trees that go into the combined arrays: the scene's own geometry first, then every distinct instanced tree
+  std::vector<Bvh*> objs; std::map<Bvh*, uint32_t> objIndex;
+  auto use = [&](Bvh* b) -> int {
+    if (objIndex.count(b)) return 0;
+    if (b->device != device) return set_error(hipErrorInvalidValue, "instanced scene lives on another device");
+    if (b->d_insts) return set_error(hipErrorInvalidValue, "the tree of an instanced scene must be flat");
+    if (b->robust != (bp->robust != 0)) return set_error(hipErrorInvalidValue, "RTC_SCENE_FLAG_ROBUST must be the same for a scene and the scenes it instances");
+    objIndex[b] = (uint32_t)objs.size(); objs.push_back(b); return 0;
+  };
+  const bool hasOwn = own && own->info.num_triangles > 0;
+  if (hasOwn) { const int rc = use(own); if (rc) return rc; }
+  std::vector<InstRec> recs; std::vector<float> boxes;           // boxes: lo.xyz hi.xyz per record
+  float blo[3] = {INFINITY, INFINITY, INFINITY}, bhi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  auto add_rec = [&](const InstRec& r, const float* lo, const float* hi) {
+    recs.push_back(r); for (int d = 0; d < 3; d++) boxes.push_back(lo[d]); for (int d = 0; d < 3; d++) boxes.push_back(hi[d]);
+    for (int d = 0; d < 3; d++) { blo[d] = fminf(blo[d], lo[d]); bhi[d] = fmaxf(bhi[d], hi[d]); }
+  };
+  if (hasOwn) {
+    InstRec r{}; r.w2l[0] = r.w2l[4] = r.w2l[8] = 1.0f; r.root = 0; r.instID = MI355_EMPTY_REF; r.mask = 0xFFFFFFFFu; r.flags = 1u;
+    add_rec(r, own->info.bounds_lower, own->info.bounds_upper);
+  }
+  std::vector<Bvh*> recObj; if (hasOwn) recObj.push_back(own);
+  for (uint32_t i = 0; i < numInsts; i++) {
+    Bvh* ob = (Bvh*)insts[i].object;
+    if (!ob || ob->info.num_triangles == 0) continue;              // an empty object scene has empty bounds: Instance::buildBounds says invalid
+    const float* l2w = insts[i].local2world;
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int c = 0; c < 8; c++) {
+      const float p[3] = {(c & 4) ? ob->info.bounds_upper[0] : ob->info.bounds_lower[0], (c & 2) ? ob->info.bounds_upper[1] : ob->info.bounds_lower[1], (c & 1) ? ob->info.bounds_upper[2] : ob->info.bounds_lower[2]};
+      float q[3]; affine_point(l2w, p, q);
+      for (int d = 0; d < 3; d++) { lo[d] = fminf(lo[d], q[d]); hi[d] = fmaxf(hi[d], q[d]); }
+    }
+    bool ok = true; for (int d = 0; d < 3; d++) ok = ok && lo[d] > -1.844E18f && hi[d] < 1.844E18f && lo[d] <= hi[d];
+    if (!ok) continue;
+    const int rc = use(ob); if (rc) return rc;
+    InstRec r{}; affine_inverse(l2w, r.w2l); r.root = 0; r.instID = insts[i].inst_id; r.mask = insts[i].mask; r.flags = 0u;
+    add_rec(r, lo, hi); recObj.push_back(ob);
+  }
+  Bvh* bvh = new Bvh; bvh->device = device;
+  struct Guard { Bvh*& b; bool ok = false; ~Guard() { if (!ok) { delete b; b = nullptr; } } } guard{bvh};
+  bvh->robust = bp->robust != 0;
+  mi355_bvh_info& info = bvh->info; memset(&info, 0, sizeof(info));
+  info.root_ref = MI355_EMPTY_REF; info.max_leaf = MI355_MAX_LEAF;
+  for (int d = 0; d < 3; d++) { info.bounds_lower[d] = blo[d]; info.bounds_upper[d] = bhi[d]; }
+  if (recs.empty()) { bvh->numCUs = own ? own->numCUs : 256; guard.ok = true; *out = bvh; return 0; }
+
+  // ---- top tree: the SAH builder over one box per record.  The box enters as a triangle (lo, hi, lo): its PrimRef is exactly the box.
+  const uint32_t R = (uint32_t)recs.size();
+  std::vector<float> fv((size_t)R * 9 + 4, 0.0f); std::vector<uint32_t> fi((size_t)R * 3);
+  for (uint32_t k = 0; k < R; k++) {
+    const float* b = &boxes[(size_t)k * 6];
+    for (int d = 0; d < 3; d++) { fv[(size_t)k * 9 + d] = b[d]; fv[(size_t)k * 9 + 3 + d] = b[3 + d]; fv[(size_t)k * 9 + 6 + d] = b[d]; }
+    fi[(size_t)k * 3] = 3 * k; fi[(size_t)k * 3 + 1] = 3 * k + 1; fi[(size_t)k * 3 + 2] = 3 * k + 2;
+  }
+  float* dfv = nullptr; uint32_t* dfi = nullptr; InstRec* dRecs = nullptr;
+  struct TmpGuard { float*& a; uint32_t*& b; ~TmpGuard() { if (a) hipFree(a); if (b) hipFree(b); } } tmpGuard{dfv, dfi};
+  HIP_TRY(hipMalloc((void**)&dfv, fv.size() * 4)); HIP_TRY(hipMalloc((void**)&dfi, fi.size() * 4));
+  HIP_TRY(hipMemcpyAsync(dfv, fv.data(), fv.size() * 4, hipMemcpyHostToDevice, st)); HIP_TRY(hipMemcpyAsync(dfi, fi.data(), fi.size() * 4, hipMemcpyHostToDevice, st));
+  mi355_mesh fake{}; fake.d_vertices = dfv; fake.vertex_stride = 12; fake.num_vertices = 3 * R; fake.d_indices = dfi; fake.index_stride = 12; fake.num_triangles = R; fake.geom_id = 0; fake.mask = 0xFFFFFFFFu;
+  mi355_build_params tp = *bp; tp.refit = 0; tp.quality = 0;
+  Bvh* top = nullptr;
+  { const int rc = build_impl(device, &fake, 1, &tp, st, &top); if (rc) return rc; }
+  struct TopGuard { Bvh* t; ~TopGuard() { delete t; } } topGuard{top};
+  if (top->info.num_triangles != R) return set_error(hipErrorInvalidValue, "top-level build dropped an instance");
+  bvh->numCUs = top->numCUs;
+
+  // ---- combined arrays: [top | object 0 | object 1 ...], the objects' indices moved behind
+  std::vector<uint32_t> nodeOfs(objs.size()), triOfs(objs.size());
+  uint64_t nNodes = top->info.num_nodes, nTris = top->info.num_triangles; uint32_t maxDepth = 0; uint64_t objTris = 0;
+  for (size_t k = 0; k < objs.size(); k++) {
+    nodeOfs[k] = (uint32_t)nNodes; triOfs[k] = (uint32_t)nTris;
+    nNodes += objs[k]->info.num_nodes; nTris += objs[k]->info.num_triangles; objTris += objs[k]->info.num_triangles;
+    if (objs[k]->info.depth > maxDepth) maxDepth = objs[k]->info.depth;
+  }
+  if (nNodes >= (1ull << 32) || nTris >= (1ull << 32)) return set_error(hipErrorInvalidValue, "instanced scene exceeds the 32-bit node / triangle index");
+  HIP_TRY(hipMalloc(&bvh->d_nodes, (size_t)nNodes * sizeof(CNode)));
+  HIP_TRY(hipMalloc(&bvh->d_tris, (size_t)nTris * sizeof(TriRec) + 128));
+  HIP_TRY(hipMemcpyAsync(bvh->d_nodes, top->d_nodes, (size_t)top->info.num_nodes * sizeof(CNode), hipMemcpyDeviceToDevice, st));
+  HIP_TRY(hipMemcpyAsync(bvh->d_tris, top->d_tris, (size_t)top->info.num_triangles * sizeof(TriRec), hipMemcpyDeviceToDevice, st));
+  for (size_t k = 0; k < objs.size(); k++) {
+    const uint32_t n = (uint32_t)objs[k]->info.num_nodes;
+    if (n) hipLaunchKernelGGL(rebase_nodes, dim3((n + 255u) / 256u), dim3(256), 0, st, (const uint4*)objs[k]->d_nodes, (uint4*)bvh->d_nodes + 5ull * nodeOfs[k], n, nodeOfs[k], triOfs[k]);
+    HIP_TRY(hipMemcpyAsync((char*)bvh->d_tris + (size_t)triOfs[k] * sizeof(TriRec), objs[k]->d_tris, (size_t)objs[k]->info.num_triangles * sizeof(TriRec), hipMemcpyDeviceToDevice, st));
+  }
+  for (uint32_t k = 0; k < R; k++) recs[k].root = nodeOfs[objIndex[recObj[k]]];
+  HIP_TRY(hipMalloc((void**)&dRecs, (size_t)R * sizeof(InstRec))); bvh->d_insts = dRecs;
+  HIP_TRY(hipMemcpyAsync(dRecs, recs.data(), (size_t)R * sizeof(InstRec), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(st));
+  bvh->root = 0;
+  info.root_ref = 0; info.num_triangles = objTris; info.num_nodes = nNodes; info.num_leaves = top->info.num_leaves;
+  info.bytes_nodes = nNodes * sizeof(CNode); info.bytes_triangles = nTris * sizeof(TriRec) + (uint64_t)R * sizeof(InstRec);
+  info.sah = top->info.sah; info.build_ms = top->info.build_ms; info.top_levels = top->info.top_levels;
+  info.depth = 2u * top->info.depth + maxDepth + 2u;             // a top level leaves up to two entries on a lane's stack (inner children, other instances)
+  guard.ok = true; *out = bvh;
+  return 0;
+}
+
 }  // namespace mi355
 
 extern "C" {
@@ -1705,6 +1832,12 @@ int mi355_bvh_build(int device, const mi355_mesh* meshes, uint32_t num_meshes, c
   *out = (mi355_bvh_t)b; return rc;
 }
 void mi355_bvh_destroy(mi355_bvh_t bvh) { delete (mi355::Bvh*)bvh; }
+int mi355_bvh_build_instanced(int device, mi355_bvh_t own, const mi355_instance* instances, uint32_t num_instances, const mi355_build_params* params, void* stream, mi355_bvh_t* out) {
+  mi355_build_params def; if (!params) { mi355_default_build_params(&def); params = &def; }
+  mi355::Bvh* b = nullptr;
+  const int rc = mi355::build_instanced_impl(device, (mi355::Bvh*)own, instances, num_instances, params, (hipStream_t)stream, &b);
+  *out = (mi355_bvh_t)b; return rc;
+}
 int mi355_bvh_refit(mi355_bvh_t bvh, const mi355_mesh* meshes, uint32_t num_meshes, void* stream) {
   if (!bvh) return MI355_REFIT_IMPOSSIBLE;
   return mi355::refit_impl((mi355::Bvh*)bvh, meshes, num_meshes, (hipStream_t)stream);

@@ -30,6 +30,7 @@ struct Bvh {
   void* d_nodes = nullptr;       // CNode[numNodes]
   void* d_tris = nullptr;        // TriRec[numTris]
   uint32_t root = 0xFFFFFFFFu;
+  void* d_insts = nullptr;       // scenes with instances: InstRec[] (64 B: world2local | root node, instID, mask, flags); d_nodes / d_tris = top tree + the objects' trees
   bool robust = false;           // TriRec holds v0,v1,v2 (instead of v0,e1,e2); traversal = conservative node test + Pluecker
   mi355_bvh_info info{};
   // refit data (params.refit): leaf order (geometry table index, internal triangle) per TriRec, first node of every level, the mesh list it was built from

@@ -120,6 +120,7 @@ struct Buffer : RefCounted {
 
 struct BufferView { Buffer* buf = nullptr; size_t offset = 0, stride = 0; unsigned num = 0; };
 
+struct Scene;
 struct Geometry : RefCounted {
   Device* device; RTCGeometryType type;
   BufferView vertices, indices;
@@ -127,11 +128,14 @@ struct Geometry : RefCounted {
   unsigned mask = 1;                                        // Geometry ctor, geometry.cpp:48
   bool enabled = true, modified = true, committed = false;
   RTCBuildQuality quality = RTC_BUILD_QUALITY_MEDIUM;
+  Scene* object = nullptr;                           // RTC_GEOMETRY_TYPE_INSTANCE: the instanced scene (retained) and local2world as vx, vy, vz, p
+  float l2w[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0};
   unsigned topoCounter = 0, dataCounter = 0;                // bumped when buffers are (re)bound / the index data changes; when vertex data or the mask changes
   void* userPtr = nullptr;
   std::atomic<int> attached{0};
   Geometry(Device* d, RTCGeometryType t) : device(d), type(t) { d->retain(); }
-  ~Geometry() override {
+  ~Geometry() override;
+  void dtor_body() {
     if (vertices.buf) vertices.buf->release();
     if (indices.buf) indices.buf->release();
     for (auto& kv : attribs) kv.second->release();
@@ -174,6 +178,8 @@ struct Scene : RefCounted {
   std::map<unsigned, Geometry*> geoms;
   RTCSceneFlags flags = RTC_SCENE_FLAG_NONE; RTCBuildQuality quality = RTC_BUILD_QUALITY_MEDIUM;
   mi355_bvh_t bvh = nullptr; ssize_t bvhBytes = 0; bool committed = false, modified = true;
+  ssize_t flatBytes = 0;
+  mi355_bvh_t flat = nullptr;                               // the tree of this scene's own triangles / quads: what an instance of this scene refers to (== bvh unless the scene has instances)
   struct BuiltFrom { unsigned id; Geometry* g; unsigned topo, data; };   // what the current tree was built from: decides rebuild vs refit
   std::vector<BuiltFrom> builtFrom; unsigned builtFlags = 0;
   RTCBounds bounds;
@@ -189,7 +195,8 @@ struct Scene : RefCounted {
   ~Scene() override {
     for (auto& kv : geoms) { kv.second->attached--; kv.second->release(); }
     hipSetDevice(device->gpu);
-    if (bvh) { mi355_bvh_destroy(bvh); device->memoryMonitor(-bvhBytes, true); }
+    if (bvh && bvh != flat) { mi355_bvh_destroy(bvh); device->memoryMonitor(-bvhBytes, true); }
+    if (flat) { mi355_bvh_destroy(flat); device->memoryMonitor(-flatBytes, true); }
     for (auto& kv : staging) if (kv.second.d) hipFree(kv.second.d);
     device->release();
   }
@@ -234,7 +241,7 @@ struct Scene : RefCounted {
     const unsigned nowFlags = (bp.robust ? 1u : 0u) | (bp.quality << 1);
     // Refit instead of rebuild (the reference: BVHNRefitT for RTC_BUILD_QUALITY_REFIT meshes of a dynamic scene, kernels/bvh/bvh_refit.cpp):
     // same geometries with the same buffer bindings and index data, and every geometry whose vertices / mask changed asks for REFIT.
-    bool refit = bvh && committed && from.size() == builtFrom.size() && nowFlags == builtFlags && !from.empty();
+    bool refit = flat && committed && from.size() == builtFrom.size() && nowFlags == builtFlags && !from.empty();
     for (size_t i = 0; refit && i < from.size(); i++) {
       const BuiltFrom &a = from[i], &b = builtFrom[i];
       refit = a.id == b.id && a.g == b.g && a.topo == b.topo && (a.data == b.data || a.g->quality == RTC_BUILD_QUALITY_REFIT);
@@ -242,7 +249,7 @@ struct Scene : RefCounted {
     mi355_bvh_info info;
     bool done = false;
     if (refit) {
-      const int rc = mi355_bvh_refit(bvh, meshes.data(), (uint32_t)meshes.size(), nullptr);
+      const int rc = mi355_bvh_refit(flat, meshes.data(), (uint32_t)meshes.size(), nullptr);
       if (rc == 0) done = true;
       else { committed = false; if (rc != MI355_REFIT_IMPOSSIBLE) core_check(rc, "BVH refit"); }   // a refit that stopped half way leaves no usable tree
     }
@@ -252,11 +259,33 @@ struct Scene : RefCounted {
       mi355_bvh_get_info(nb, &info);
       const ssize_t newBytes = (ssize_t)(info.bytes_nodes + info.bytes_triangles + info.bytes_refit);
       try { device->memoryMonitor(newBytes, false); } catch (...) { mi355_bvh_destroy(nb); throw; }   // the old tree stays in place
-      if (bvh) { mi355_bvh_destroy(bvh); device->memoryMonitor(-bvhBytes, true); }
+      if (flat) { mi355_bvh_destroy(flat); device->memoryMonitor(-flatBytes, true); if (bvh == flat) bvh = nullptr; }
+      flat = nb; flatBytes = newBytes;
+    }
+    builtFrom = from; builtFlags = nowFlags;
+    // ---- instances (RTC_GEOMETRY_TYPE_INSTANCE, one level): top tree over their world boxes + copies of the instanced scenes' flat trees
+    std::vector<mi355_instance> insts;
+    for (auto& kv : geoms) {
+      Geometry* g = kv.second;
+      if (g->type != RTC_GEOMETRY_TYPE_INSTANCE || !g->enabled || !g->object) continue;
+      if (!g->committed) THROW(RTC_ERROR_INVALID_OPERATION, "geometry attached to the scene was modified but not committed");
+      if (g->object == this) THROW(RTC_ERROR_INVALID_OPERATION, "a scene cannot instance itself");
+      if (!g->object->committed || !g->object->flat) THROW(RTC_ERROR_INVALID_OPERATION, "the instanced scene has to be committed before the scene that instances it");
+      mi355_instance in; in.object = g->object->flat;           // a second level inside the object is dropped, like the reference does at RTC_MAX_INSTANCE_LEVEL_COUNT = 1 (instance_stack.h:36-47)
+      memcpy(in.local2world, g->l2w, sizeof(in.local2world)); in.inst_id = kv.first; in.mask = g->mask;
+      insts.push_back(in);
+    }
+    if (bvh && bvh != flat) { mi355_bvh_destroy(bvh); device->memoryMonitor(-bvhBytes, true); bvhBytes = 0; }
+    bvh = flat;
+    if (!insts.empty()) {
+      mi355_bvh_t nb = nullptr;
+      core_check(mi355_bvh_build_instanced(device->gpu, flat, insts.data(), (uint32_t)insts.size(), &bp, nullptr, &nb), "instanced BVH build");
+      mi355_bvh_get_info(nb, &info);
+      const ssize_t newBytes = (ssize_t)(info.bytes_nodes + info.bytes_triangles);
+      try { device->memoryMonitor(newBytes, false); } catch (...) { mi355_bvh_destroy(nb); committed = false; throw; }
       bvh = nb; bvhBytes = newBytes;
     }
     mi355_bvh_get_info(bvh, &info);
-    builtFrom = from; builtFlags = nowFlags;
     setEmptyBounds();
     if (info.num_triangles) {
       bounds.lower_x = info.bounds_lower[0]; bounds.lower_y = info.bounds_lower[1]; bounds.lower_z = info.bounds_lower[2];
@@ -270,6 +299,8 @@ struct Scene : RefCounted {
     committed = true; modified = false;
   }
 };
+
+Geometry::~Geometry() { if (object) object->release(); dtor_body(); }
 
 Device* dev_of(RTCDevice h) { if (!h) THROW(RTC_ERROR_INVALID_ARGUMENT, "invalid argument"); return (Device*)h; }
 Scene* scene_of(RTCScene h) { if (!h) THROW(RTC_ERROR_INVALID_ARGUMENT, "invalid argument"); return (Scene*)h; }
@@ -422,8 +453,8 @@ RTC_API void rtcReleaseBuffer(RTCBuffer b) { if (b) ((Buffer*)b)->release(); }
 RTC_API RTCGeometry rtcNewGeometry(RTCDevice h, enum RTCGeometryType type) {
   CATCH_BEGIN
   Device* d = dev_of(h);
-  if (type != RTC_GEOMETRY_TYPE_TRIANGLE && type != RTC_GEOMETRY_TYPE_QUAD)
-    THROW(RTC_ERROR_INVALID_OPERATION, "only RTC_GEOMETRY_TYPE_TRIANGLE and RTC_GEOMETRY_TYPE_QUAD are supported by the MI355X core");
+  if (type != RTC_GEOMETRY_TYPE_TRIANGLE && type != RTC_GEOMETRY_TYPE_QUAD && type != RTC_GEOMETRY_TYPE_INSTANCE)
+    THROW(RTC_ERROR_INVALID_OPERATION, "only RTC_GEOMETRY_TYPE_TRIANGLE, RTC_GEOMETRY_TYPE_QUAD and RTC_GEOMETRY_TYPE_INSTANCE are supported by the MI355X core");
   return (RTCGeometry) new Geometry(d, type);
   CATCH_END((Device*)h)
   return nullptr;
@@ -512,6 +543,40 @@ RTC_API void rtcUpdateGeometryBuffer(RTCGeometry h, enum RTCBufferType type, uns
   if (v->buf && !v->buf->dev) v->buf->devDirty = true;
   g->modified = true; g->committed = false;
   if (type == RTC_BUFFER_TYPE_VERTEX) g->dataCounter++; else g->topoCounter++;
+  CATCH_END(GEOM_DEV(h))
+}
+// ---- RTC_GEOMETRY_TYPE_INSTANCE (kernels/common/scene_instance.cpp; rtcore.cpp:1408-1495 for the matrix formats)
+RTC_API void rtcSetGeometryInstancedScene(RTCGeometry h, RTCScene sc) {
+  CATCH_BEGIN Geometry* g = geom_of(h);
+  if (g->type != RTC_GEOMETRY_TYPE_INSTANCE) THROW(RTC_ERROR_INVALID_OPERATION, "operation not supported for this geometry");
+  Scene* s = scene_of(sc);
+  if (s->device != g->device) THROW(RTC_ERROR_INVALID_ARGUMENT, "inputs are from different devices");
+  s->retain(); if (g->object) g->object->release();
+  g->object = s; g->committed = false; g->topoCounter++;
+  CATCH_END(GEOM_DEV(h))
+}
+RTC_API void rtcSetGeometryTransform(RTCGeometry h, unsigned timeStep, enum RTCFormat fmt, const void* xfm) {
+  CATCH_BEGIN Geometry* g = geom_of(h);
+  if (g->type != RTC_GEOMETRY_TYPE_INSTANCE) THROW(RTC_ERROR_INVALID_OPERATION, "operation not supported for this geometry");
+  if (!xfm) THROW(RTC_ERROR_INVALID_ARGUMENT, "invalid argument");
+  if (timeStep != 0) THROW(RTC_ERROR_INVALID_OPERATION, "motion blur is not supported by the MI355X core");
+  const float* x = (const float*)xfm; float* m = g->l2w;       // vx, vy, vz, p
+  if (fmt == RTC_FORMAT_FLOAT3X4_ROW_MAJOR) { for (int c = 0; c < 4; c++) for (int r = 0; r < 3; r++) m[3 * c + r] = x[4 * r + c]; }
+  else if (fmt == RTC_FORMAT_FLOAT3X4_COLUMN_MAJOR) memcpy(m, x, 48);
+  else if (fmt == RTC_FORMAT_FLOAT4X4_COLUMN_MAJOR) { for (int c = 0; c < 4; c++) for (int r = 0; r < 3; r++) m[3 * c + r] = x[4 * c + r]; }
+  else THROW(RTC_ERROR_INVALID_OPERATION, "invalid matrix format");
+  g->committed = false; g->dataCounter++;
+  CATCH_END(GEOM_DEV(h))
+}
+RTC_API void rtcGetGeometryTransform(RTCGeometry h, float, enum RTCFormat fmt, void* out) {
+  CATCH_BEGIN Geometry* g = geom_of(h);
+  if (g->type != RTC_GEOMETRY_TYPE_INSTANCE) THROW(RTC_ERROR_INVALID_OPERATION, "operation not supported for this geometry");
+  if (!out) THROW(RTC_ERROR_INVALID_ARGUMENT, "invalid argument");
+  const float* m = g->l2w; float* x = (float*)out;
+  if (fmt == RTC_FORMAT_FLOAT3X4_ROW_MAJOR) { for (int c = 0; c < 4; c++) for (int r = 0; r < 3; r++) x[4 * r + c] = m[3 * c + r]; }
+  else if (fmt == RTC_FORMAT_FLOAT3X4_COLUMN_MAJOR) memcpy(x, m, 48);
+  else if (fmt == RTC_FORMAT_FLOAT4X4_COLUMN_MAJOR) { for (int c = 0; c < 4; c++) { for (int r = 0; r < 3; r++) x[4 * c + r] = m[3 * c + r]; x[4 * c + 3] = c == 3 ? 1.0f : 0.0f; } }
+  else THROW(RTC_ERROR_INVALID_OPERATION, "invalid matrix format");
   CATCH_END(GEOM_DEV(h))
 }
 RTC_API void rtcSetGeometryUserData(RTCGeometry h, void* p) { CATCH_BEGIN geom_of(h)->userPtr = p; CATCH_END(GEOM_DEV(h)) }
@@ -637,8 +702,6 @@ UNSUPPORTED_GEOM(rtcSetGeometryUserPrimitiveCount, unsigned)
 UNSUPPORTED_GEOM(rtcSetGeometryBoundsFunction, void*, void*)
 UNSUPPORTED_GEOM(rtcSetGeometryIntersectFunction, void*)
 UNSUPPORTED_GEOM(rtcSetGeometryOccludedFunction, void*)
-UNSUPPORTED_GEOM(rtcSetGeometryInstancedScene, RTCScene)
-UNSUPPORTED_GEOM(rtcSetGeometryTransform, unsigned, enum RTCFormat, const void*)
 UNSUPPORTED_GEOM(rtcSetGeometryTessellationRate, float)
 UNSUPPORTED_GEOM(rtcSetGeometryTopologyCount, unsigned)
 UNSUPPORTED_GEOM(rtcSetGeometrySubdivisionMode, unsigned, int)

@@ -67,6 +67,7 @@ struct TraceArgs {
   uint32_t spillPerLane;
   uint32_t refillMin, pushRounds, numCursors;
   unsigned long long* stats;  // optional counters
+  const float4* insts;   // INST kernels: InstRec[] as 4 x float4 (world2local vx,vy,vz,p | root node, instID, mask, flags)
 };
 
 // slab test of the 4 children whose quantised planes sit in one dword per plane; returns their contribution to the hit word.
@@ -227,7 +228,41 @@ constexpr uint32_t CURSOR_STRIDE = 64;     // words between cursors: each one in
 #ifndef MI355_TRACE_ATTR
 #define MI355_TRACE_ATTR
 #endif
-template <bool ANY, bool STATS, bool ROBUST>
+constexpr uint32_t NO_INST = 0xFFFFFFFFu;
+// InstanceIntersector1 (kernels/geometry/instance_intersector.cpp:26-31): org' = xfmPoint(world2local, org), dir' = xfmVector(world2local, dir),
+// nested FMAs exactly like common/math/affinespace.h:102 and linearspace3.h:159; tnear / tfar (and so every t) are unchanged.
+__device__ __forceinline__ void xfm_ray(const float4 m0, const float4 m1, const float4 m2, float& ox, float& oy, float& oz, float& dx, float& dy, float& dz) {
+  const float px = ox, py = oy, pz = oz, vx = dx, vy = dy, vz = dz;
+  ox = fmaf(px, m0.x, fmaf(py, m0.w, fmaf(pz, m1.z, m2.y)));
+  oy = fmaf(px, m0.y, fmaf(py, m1.x, fmaf(pz, m1.w, m2.z)));
+  oz = fmaf(px, m0.z, fmaf(py, m1.y, fmaf(pz, m2.x, m2.w)));
+  dx = fmaf(vx, m0.x, fmaf(vy, m0.w, vz * m1.z));
+  dy = fmaf(vx, m0.y, fmaf(vy, m1.x, vz * m1.w));
+  dz = fmaf(vx, m0.z, fmaf(vy, m1.y, vz * m2.x));
+}
+// TravRay: rdir = rcp_safe(dir) (|d| < 1e-18 -> +1e-18)  kernels/bvh/node_intersector1.h:29-57, common/math/vec3fa.h:167-172;
+// robust (TravRayBase<N,true>, :98-121): a true division, then 3 ulp down / up.  A ray travelling towards +x meets the children on the
+// -x side first: priority of slot s = s ^ octinv.
+template <bool ROBUST>
+__device__ __forceinline__ void setup_rdir(float dx, float dy, float dz, float& rdx, float& rdy, float& rdz, float& rfx, float& rfy, float& rfz, uint32_t& octinv4) {
+  if (ROBUST) {
+    const float rx = 1.0f / (fabsf(dx) < 1e-18f ? 1e-18f : dx), ry = 1.0f / (fabsf(dy) < 1e-18f ? 1e-18f : dy), rz = 1.0f / (fabsf(dz) < 1e-18f ? 1e-18f : dz);
+    const float down = 1.0f - 3.0f * 1.1920929e-07f, up = 1.0f + 3.0f * 1.1920929e-07f;
+    rdx = down * rx; rdy = down * ry; rdz = down * rz; rfx = up * rx; rfy = up * ry; rfz = up * rz;
+  } else {
+    rdx = rcp_nr(fabsf(dx) < 1e-18f ? 1e-18f : dx);
+    rdy = rcp_nr(fabsf(dy) < 1e-18f ? 1e-18f : dy);
+    rdz = rcp_nr(fabsf(dz) < 1e-18f ? 1e-18f : dz);
+  }
+  octinv4 = ((rdx < 0.0f ? 0u : 1u) | (rdy < 0.0f ? 0u : 2u) | (rdz < 0.0f ? 0u : 4u)) * 0x01010101u;
+}
+// INST (scenes with RTC_GEOMETRY_TYPE_INSTANCE, one level): nodes[] / tris[] hold the top tree over the instances' world boxes followed by the trees of
+// the instanced scenes (indices rebased), a.insts the instance records.  A "triangle" of the top tree is an instance: a lane that finds one
+// pushes what is left of its node, transforms ITS ray into the instance (the world ray is re-read from the ray array on the way out), and walks
+// the object's tree with the same loop; ring pairs are tested with the owner's CURRENT ray, so a lane changes space only after the ring has
+// passed its last pair.  The winning triangle's instance is remembered per lane (the key in best[] changed while inside) and the hit is
+// recomputed in that instance's space when the ray retires.  Tail helpers (1b) are off: a helper would have to change space for its owner.
+template <bool ANY, bool STATS, bool ROBUST, bool INST>
 __global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceArgs a) {
   __shared__ uint2 s_stack[BLOCK / 64][QSTACK_LDS][64];
   __shared__ uint2 s_queue[BLOCK / 64][QCAP];
@@ -252,6 +287,7 @@ __global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceAr
   uint32_t resV = 0; bool resValid = false;                              // the block reserved ahead (lane 0 holds the atomic's result)
   float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0, rdx = 0, rdy = 0, rdz = 0, tnear = 0, tnearTrav = 0, tfar = 0;
   float rfx = 0, rfy = 0, rfz = 0;                                       // ROBUST: rdir_far (rdx.. hold rdir_near)
+  uint32_t inst = NO_INST, topSp = 0, bestInst = NO_INST, entryLo = 0, entryHi = 0;   // INST: instance the lane is in, stack depth at entry, instance of the best hit, best[] key at entry
   uint32_t stNodes = 0, stTris = 0, stRays = 0, stSpill = 0, stDepth = 0, stIter = 0, stNodeBlk = 0, stTriBlk = 0;
   uint32_t stIdle = 0, stWaitBatch = 0, stWaitDrain = 0, stBlocked = 0, stEmpty = 0, stCulled = 0;
 
@@ -274,10 +310,11 @@ __global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceAr
         const uint32_t G = a.refillMin;
         // (a) retiring rays: read the winner, issue the loads of its triangle record
         uint32_t htri = MI355_EMPTY_REF;
-        float4 q0 = make_float4(0, 0, 0, 0), q1 = q0, q2 = q0;
+        float4 q0 = make_float4(0, 0, 0, 0), q1 = q0, q2 = q0, i0 = q0, i1 = q0, i2 = q0, i3 = q0;
         if (retirable) {
           htri = (uint32_t)best[lane];
           if (!ANY && htri != MI355_EMPTY_REF) { const float4* tp = a.tris + (size_t)htri * 3u; q0 = tp[0]; q1 = tp[1]; q2 = tp[2]; }
+          if (INST && !ANY && htri != MI355_EMPTY_REF && bestInst != NO_INST) { const float4* ip = a.insts + (size_t)bestInst * 4u; i0 = ip[0]; i1 = ip[1]; i2 = ip[2]; i3 = ip[3]; }
         }
         bool retiredDone = false, more = true;
         while (more) {
@@ -319,12 +356,17 @@ __global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceAr
                   // recompute the winner's t, u, v, Ng (same arithmetic as the test in step 4; Intersect1EpilogM, intersector_epilog.h:235-300)
                   TriOut w;
                   const uint32_t pid = __float_as_uint(q2.y);            // bit 31: second triangle of a quad (tri_records, build.hip)
-                  if (ROBUST) tri_pluecker<true>(q0, q1, q2, ox, oy, oz, dx, dy, dz, tnear, tfar, w, (pid >> 31) != 0u);
-                  else tri_moeller<true>(q0, q1, q2, ox, oy, oz, dx, dy, dz, tnear, tfar, w, (pid >> 31) != 0u);
+                  float hx = ox, hy = oy, hz = oz, gx = dx, gy = dy, gz = dz;
+                  uint32_t hitInst = MI355_EMPTY_REF, hitInstPrim = MI355_EMPTY_REF;
+                  if (INST && bestInst != NO_INST && (__float_as_uint(i3.w) & 1u) == 0u) {   // the hit lies in an instance: its space, its id (instPrimID 0: instance_stack.h:19-50)
+                    xfm_ray(i0, i1, i2, hx, hy, hz, gx, gy, gz); hitInst = __float_as_uint(i3.y); hitInstPrim = 0u;
+                  }
+                  if (ROBUST) tri_pluecker<true>(q0, q1, q2, hx, hy, hz, gx, gy, gz, tnear, tfar, w, (pid >> 31) != 0u);
+                  else tri_moeller<true>(q0, q1, q2, hx, hy, hz, gx, gy, gz, tnear, tfar, w, (pid >> 31) != 0u);
                   *(float*)(rp + 32) = w.t;
                   *(float4*)(rp + 48) = make_float4(w.Ngx, w.Ngy, w.Ngz, w.u);
-                  *(uint4*)(rp + 64) = make_uint4(__float_as_uint(w.v), pid & 0x7FFFFFFFu, __float_as_uint(q2.z), MI355_EMPTY_REF);
-                  *(uint32_t*)(rp + 80) = MI355_EMPTY_REF;
+                  *(uint4*)(rp + 64) = make_uint4(__float_as_uint(w.v), pid & 0x7FFFFFFFu, __float_as_uint(q2.z), hitInst);
+                  *(uint32_t*)(rp + 80) = hitInstPrim;
                 }
               }
               active = false;
@@ -336,20 +378,9 @@ __global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceAr
             ox = r0.x; oy = r0.y; oz = r0.z; tnear = r0.w;
             dx = r1.x; dy = r1.y; dz = r1.z;
             tfar = r2.x; rmask = __float_as_uint(r2.y);
-            // TravRay: rdir = rcp_safe(dir) (|d| < 1e-18 -> +1e-18), tnear/tfar clamped to >= 0 for traversal
-            // kernels/bvh/node_intersector1.h:29-57, common/math/vec3fa.h:167-172, bvh_intersector1.cpp:65
-            if (ROBUST) {                                                // TravRayBase<N,true>: a true division, then 3 ulp down / up
-              const float rx = 1.0f / (fabsf(dx) < 1e-18f ? 1e-18f : dx), ry = 1.0f / (fabsf(dy) < 1e-18f ? 1e-18f : dy), rz = 1.0f / (fabsf(dz) < 1e-18f ? 1e-18f : dz);
-              const float down = 1.0f - 3.0f * 1.1920929e-07f, up = 1.0f + 3.0f * 1.1920929e-07f;
-              rdx = down * rx; rdy = down * ry; rdz = down * rz; rfx = up * rx; rfy = up * ry; rfz = up * rz;
-            } else {
-              rdx = rcp_nr(fabsf(dx) < 1e-18f ? 1e-18f : dx);
-              rdy = rcp_nr(fabsf(dy) < 1e-18f ? 1e-18f : dy);
-              rdz = rcp_nr(fabsf(dz) < 1e-18f ? 1e-18f : dz);
-            }
-            tnearTrav = fmaxf(tnear, 0.0f);
-            // a ray travelling towards +x meets the children on the -x side first: priority of slot s = s ^ octinv
-            octinv4 = ((rdx < 0.0f ? 0u : 1u) | (rdy < 0.0f ? 0u : 2u) | (rdz < 0.0f ? 0u : 4u)) * 0x01010101u;
+            setup_rdir<ROBUST>(dx, dy, dz, rdx, rdy, rdz, rfx, rfy, rfz, octinv4);
+            tnearTrav = fmaxf(tnear, 0.0f);                               // tnear/tfar clamped to >= 0 for traversal (bvh_intersector1.cpp:65)
+            if (INST) { inst = NO_INST; bestInst = NO_INST; }
             sp = 0; ngBase = 0; ngHits = 0x80000000u; tgBase = 0; tgHits = 0;   // "the root is the one hit child of a virtual node"
             lastTicket = qHead; travDone = false;
             best[lane] = ((unsigned long long)__float_as_uint(tfar) << 32) | 0xFFFFFFFFull;
@@ -370,7 +401,7 @@ __global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceAr
     // owner's own (ring pairs carry the owner, the testers fetch the ray from the owner's registers), the owner retires when its own
     // traversal is done, pend[owner] == 0 and the ring has passed the last ticket any of its helpers drew.  The result is the same
     // minimum over all accepted candidates; only the order in which sub-trees are visited changes.
-    if (exhausted) {
+    if (!INST && exhausted) {
       const unsigned long long freeM = __ballot(!active);
       const bool canGive = active && !travDone && sp > 0u && sp <= (uint32_t)QSTACK_LDS && !(ANY && (uint32_t)best[owner] != MI355_EMPTY_REF);
       const unsigned long long giveM = __ballot(canGive);
@@ -410,17 +441,28 @@ __global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceAr
     if (STATS && lane == 0u) stIter++;
 
     // ------------------------------------------------------------------ 2. current tfar = what the testers published; pop / finish traversal
+    bool waitDrain = false;                                     // INST: this lane waits for the ring before it may change space
     if (active && !travDone) {
       const unsigned long long b = best[owner];
       tfar = __uint_as_float((uint32_t)(b >> 32));
       bool finished = false;
       if (ANY && (uint32_t)b != MI355_EMPTY_REF) { finished = true; tgHits = 0; ngHits = 0; sp = 0; lastTicket = qHead; }   // occluded: nothing left to wait for
       else if (tgHits == 0u && ngHits <= 0x00FFFFFFu) {
-        if (sp != 0u) {
+        if (INST && inst != NO_INST && sp == topSp) {              // the instance's sub-tree is done: back to world space once my queued pairs are tested
+          if ((int)(qHead - lastTicket) >= 0) {
+            if ((uint32_t)b != entryLo || (uint32_t)(b >> 32) != entryHi) bestInst = inst;
+            inst = NO_INST;
+            const float4* rp = (const float4*)(a.rays + (size_t)rayIdx * a.stride);
+            const float4 r0 = rp[0], r1 = rp[1];
+            ox = r0.x; oy = r0.y; oz = r0.z; dx = r1.x; dy = r1.y; dz = r1.z;
+            setup_rdir<ROBUST>(dx, dy, dz, rdx, rdy, rdz, rfx, rfy, rfz, octinv4);
+          } else waitDrain = true;
+        } else if (sp != 0u) {
           sp--;
           uint2 e = stk[min(sp, (uint32_t)(QSTACK_LDS - 1)) * 64u];
           if (__builtin_expect(sp >= (uint32_t)QSTACK_LDS, 0)) e = spill[sp - QSTACK_LDS];
-          ngBase = e.x; ngHits = e.y;
+          if (INST && e.y <= 0x00FFFFFFu) { tgBase = e.x; tgHits = e.y; }   // instances of a top node that are still to be visited
+          else { ngBase = e.x; ngHits = e.y; }
         } else finished = true;
       }
       if (finished) {
@@ -428,6 +470,38 @@ __global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceAr
           atomicMax(&lastT[owner], lastTicket); atomicSub(&pend[owner], 1u);
           active = false; helper = false; owner = lane;
         } else travDone = true;                                    // lastTicket already names this ray's last queued pair
+      }
+    }
+
+    // ------------------------------------------------------------------ 2b. INST: in world space the "triangle" bits of a node are instances: enter the first one
+    if (INST && active && !travDone && inst == NO_INST && tgHits != 0u) {
+      const uint32_t k = (uint32_t)__builtin_ctz(tgHits);
+      tgHits &= tgHits - 1u;
+      if (ngHits > 0x00FFFFFFu) {                                  // what is left of the node: its inner children ...
+        const uint2 e = make_uint2(ngBase, ngHits);
+        if (sp < (uint32_t)QSTACK_LDS) stk[sp * 64u] = e;
+        else { if (sp - QSTACK_LDS < a.spillPerLane) spill[sp - QSTACK_LDS] = e; if (STATS) stSpill++; }
+        sp++;
+      }
+      if (tgHits != 0u) {                                          // ... and its other instances (an entry with no inner-child bits)
+        const uint2 e = make_uint2(tgBase, tgHits);
+        if (sp < (uint32_t)QSTACK_LDS) stk[sp * 64u] = e;
+        else { if (sp - QSTACK_LDS < a.spillPerLane) spill[sp - QSTACK_LDS] = e; if (STATS) stSpill++; }
+        sp++;
+      }
+      if (STATS) stDepth = max(stDepth, sp);
+      ngHits = 0u; tgHits = 0u;
+      const uint32_t ii = __float_as_uint(a.tris[(size_t)(tgBase + k) * 3u + 2u].y);   // the top tree's leaf record: primID = index into insts[]
+      const float4* ip = a.insts + (size_t)ii * 4u;
+      const float4 m0 = ip[0], m1 = ip[1], m2 = ip[2], m3 = ip[3];
+      if ((__float_as_uint(m3.z) & rmask) != 0u) {                 // ray mask test, instance_intersector.cpp:19-23
+        if ((__float_as_uint(m3.w) & 1u) == 0u) {                  // (bit 0: the scene's own geometry, no transform)
+          xfm_ray(m0, m1, m2, ox, oy, oz, dx, dy, dz);
+          setup_rdir<ROBUST>(dx, dy, dz, rdx, rdy, rdz, rfx, rfy, rfz, octinv4);
+        }
+        const unsigned long long b = best[lane];
+        inst = ii; topSp = sp; entryLo = (uint32_t)b; entryHi = (uint32_t)(b >> 32);
+        ngBase = __float_as_uint(m3.x); ngHits = 0x80000000u;      // the object's root, as at ray start
       }
     }
 
@@ -452,7 +526,7 @@ __global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceAr
     }
 
     // ------------------------------------------------------------------ 4. test queued pairs (queued in earlier iterations), 64 at a time (fewer only when nothing else can run)
-    const bool anyTraversing = __ballot(active && !travDone) != 0ull;
+    const bool anyTraversing = __ballot(active && !travDone && !waitDrain) != 0ull;
     for (;;) {
       const uint32_t count = qTail - qHead;
       if (count == 0u || (count < 64u && anyTraversing)) break;
@@ -519,7 +593,7 @@ __global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceAr
 
     // ------------------------------------------------------------------ 5. queue triangle bits: one pair per lane and round
     for (uint32_t r = 0; r < a.pushRounds; r++) {
-      const bool has = tgHits != 0u;                                     // only active, traversing lanes hold triangle bits
+      const bool has = tgHits != 0u && (!INST || inst != NO_INST);       // only active, traversing lanes hold triangle bits (INST: in world space they are instances, see 2b)
       const unsigned long long m = __ballot(has);
       if (m == 0ull) break;
       const uint32_t n = (uint32_t)__popcll(m);
@@ -591,10 +665,11 @@ static uint32_t env_u32(const char* name, uint32_t def, uint32_t lo, uint32_t hi
   const char* e = getenv(name); if (!e) return def;
   const long v = atol(e); return v < (long)lo || v > (long)hi ? def : (uint32_t)v;
 }
-static TraceFn pick_kernel(bool any, bool stats, bool robust) {
-  if (robust) return any ? (stats ? trace_kernel_q<true, true, true> : trace_kernel_q<true, false, true>) : (stats ? trace_kernel_q<false, true, true> : trace_kernel_q<false, false, true>);
-  return any ? (stats ? trace_kernel_q<true, true, false> : trace_kernel_q<true, false, false>) : (stats ? trace_kernel_q<false, true, false> : trace_kernel_q<false, false, false>);
+template <bool INST> static TraceFn pick_kernel_i(bool any, bool stats, bool robust) {
+  if (robust) return any ? (stats ? trace_kernel_q<true, true, true, INST> : trace_kernel_q<true, false, true, INST>) : (stats ? trace_kernel_q<false, true, true, INST> : trace_kernel_q<false, false, true, INST>);
+  return any ? (stats ? trace_kernel_q<true, true, false, INST> : trace_kernel_q<true, false, false, INST>) : (stats ? trace_kernel_q<false, true, false, INST> : trace_kernel_q<false, false, false, INST>);
 }
+static TraceFn pick_kernel(bool any, bool stats, bool robust, bool inst) { return inst ? pick_kernel_i<true>(any, stats, robust) : pick_kernel_i<false>(any, stats, robust); }
 // persistent grid = exactly the blocks that are resident at once (a larger grid would run a second, ragged round)
 static uint32_t resident_blocks(Bvh* b, TraceFn fn) {
   static std::mutex m; static std::map<std::pair<int, TraceFn>, uint32_t> cache;
@@ -620,7 +695,7 @@ static int launch_trace(Bvh* b, void* d_rays, uint32_t count, size_t stride, boo
   if (count == 0) return 0;
   if (stride < (any ? 48u : 96u) || (stride & 15u) || ((uintptr_t)d_rays & 15u)) return set_error(hipErrorInvalidValue, "ray array must be 16-byte aligned with a 16-byte-multiple stride");
   HIP_TRY(hipSetDevice(b->device));
-  const TraceFn fn = pick_kernel(any, statsOut != nullptr, b->robust);
+  const TraceFn fn = pick_kernel(any, statsOut != nullptr, b->robust, b->d_insts != nullptr);
   const uint32_t maxBlocks = resident_blocks(b, fn);
   uint32_t blocks = (count + BLOCK - 1) / BLOCK;
   if (blocks > maxBlocks) blocks = maxBlocks;
@@ -630,7 +705,7 @@ static int launch_trace(Bvh* b, void* d_rays, uint32_t count, size_t stride, boo
   HIP_TRY(hipMemsetAsync(sc->counter, 0, NUM_CURSORS * CURSOR_STRIDE * sizeof(uint32_t), s));
   TraceArgs a;
   a.nodes = (const uint4*)b->d_nodes; a.tris = (const float4*)b->d_tris; a.hasRoot = b->root != MI355_EMPTY_REF ? 1u : 0u;
-  a.rays = (char*)d_rays; a.count = count; a.stride = (uint32_t)stride;
+  a.rays = (char*)d_rays; a.count = count; a.stride = (uint32_t)stride; a.insts = (const float4*)b->d_insts;
   a.counter = sc->counter; a.spill = (uint2*)sc->spill; a.spillPerLane = trace_spill_per_lane(b->info.depth); a.stats = nullptr;
   static const uint32_t refillMin = env_u32("MI355_REFILL_MIN", REFILL_MIN_DEFAULT, 1, 64);
   static const uint32_t pushRounds = env_u32("MI355_PUSH_ROUNDS", PUSH_ROUNDS_DEFAULT, 1, 24);

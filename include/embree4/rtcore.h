@@ -83,6 +83,8 @@ enum RTCFormat {
   RTC_FORMAT_FLOAT5, RTC_FORMAT_FLOAT6, RTC_FORMAT_FLOAT7, RTC_FORMAT_FLOAT8,
   RTC_FORMAT_FLOAT9, RTC_FORMAT_FLOAT10, RTC_FORMAT_FLOAT11, RTC_FORMAT_FLOAT12,
   RTC_FORMAT_FLOAT13, RTC_FORMAT_FLOAT14, RTC_FORMAT_FLOAT15, RTC_FORMAT_FLOAT16,
+  /* matrix formats accepted by rtcSetGeometryTransform [ref: rtcore_common.h:128-147] */
+  RTC_FORMAT_FLOAT3X4_ROW_MAJOR = 0x9134, RTC_FORMAT_FLOAT3X4_COLUMN_MAJOR = 0x9234, RTC_FORMAT_FLOAT4X4_COLUMN_MAJOR = 0x9244,
   RTC_FORMAT_GRID = 0xA001,
   RTC_FORMAT_QUATERNION_DECOMPOSITION = 0xB001
 };
@@ -321,6 +323,10 @@ RTC_API void rtcDisableGeometry(RTCGeometry geometry);
 RTC_API void rtcSetGeometryTimeStepCount(RTCGeometry geometry, unsigned int timeStepCount);
 RTC_API void rtcSetGeometryVertexAttributeCount(RTCGeometry geometry, unsigned int vertexAttributeCount);
 RTC_API void rtcSetGeometryMask(RTCGeometry geometry, unsigned int mask);
+/* RTC_GEOMETRY_TYPE_INSTANCE, one level, one time step [ref: rtcore_geometry.h: rtcSetGeometryInstancedScene, rtcSetGeometryTransform, rtcGetGeometryTransform] */
+RTC_API void rtcSetGeometryInstancedScene(RTCGeometry geometry, RTCScene scene);
+RTC_API void rtcSetGeometryTransform(RTCGeometry geometry, unsigned int timeStep, enum RTCFormat format, const void* xfm);
+RTC_API void rtcGetGeometryTransform(RTCGeometry geometry, float time, enum RTCFormat format, void* xfm);
 RTC_API void rtcSetGeometryBuildQuality(RTCGeometry geometry, enum RTCBuildQuality quality);
 RTC_API void rtcSetGeometryBuffer(RTCGeometry geometry, enum RTCBufferType type, unsigned int slot,
                                   enum RTCFormat format, RTCBuffer buffer, size_t byteOffset,

@@ -82,6 +82,19 @@ MI355_API int mi355_device_name(int device, char* out, size_t n);
 MI355_API int mi355_bvh_build(int device, const mi355_mesh* meshes, uint32_t num_meshes,
                               const mi355_build_params* params, void* stream, mi355_bvh_t* out);
 MI355_API void mi355_bvh_destroy(mi355_bvh_t bvh);
+/* Scenes with RTC_GEOMETRY_TYPE_INSTANCE, one level (the reference: kernels/common/scene_instance.h, kernels/geometry/instance_intersector.cpp).
+   `own` = the flat tree of the scene's own triangles / quads (or NULL), `instances` = the instance geometries: the flat tree of the instanced scene,
+   local2world as the reference's AffineSpace3fa (vx, vy, vz, p), the geometry id reported in RTCHit.instID[0], the geometry mask.  The result holds a
+   top tree over the instances' world boxes and a COPY of every distinct tree (node / triangle indices rebased), so it stays valid when `own` or an
+   object tree is destroyed or rebuilt -- and has to be built again to see their changes, like the reference needs a new commit.  Queries use the same
+   entry points; hits inside an instance report object-space Ng, instID[0] = inst_id, instPrimID[0] = 0.  All trees must share params->robust. */
+typedef struct mi355_instance {
+  mi355_bvh_t object;
+  float       local2world[12];
+  uint32_t    inst_id, mask;
+} mi355_instance;
+MI355_API int mi355_bvh_build_instanced(int device, mi355_bvh_t own, const mi355_instance* instances, uint32_t num_instances,
+                                        const mi355_build_params* params, void* stream, mi355_bvh_t* out);
 /* Refit (RTC_BUILD_QUALITY_REFIT; the reference: kernels/bvh/bvh_refit.cpp, BVHNRefitT): the vertices moved, the topology did not.
    `meshes` must list the same geometries (ids, primitive counts, types) in the same order as at the build; vertex pointers, strides and
    masks are taken anew.  Triangle records are rewritten and the node boxes recomputed bottom-up, in place; blocking.

@@ -342,3 +342,130 @@ def test_refit_equals_rebuild(api, dev, flags):
     _same_hits(a, b)
     fresh.release()
     s.release()
+
+
+def _instanced_scenes(api, dev, g, flags):
+    """the scene of tests/golden/ref_instances.npz through the C API: (top, [object scenes])"""
+    oa, ob = api.Scene(dev, flags), api.Scene(dev, flags)
+    oa.add_triangle_mesh(g["a_v"], g["a_t"]); oa.commit()
+    ob.add_triangle_mesh(g["cube_v"], g["cube_t"]); ob.add_quad_mesh(g["qv"], g["qq"]); ob.commit()
+    top = api.Scene(dev, flags)
+    assert top.add_triangle_mesh(g["ground_v"], g["ground_t"]) == 0 and top.add_triangle_mesh(g["sphere_v"], g["sphere_t"]) == 1
+    for i in range(g["xfm"].shape[0]):
+        assert top.add_instance(ob if g["inst_obj"][i] else oa, g["xfm"][i], int(g["inst_mask"][i])) == 2 + i
+    top.commit()
+    return top, [oa, ob]
+
+
+def _compare_instanced(got, want, rays, label):
+    RT = 1e-4
+    rel = lambda a, b: np.abs(a - b) <= RT * np.maximum(np.abs(a), np.abs(b)) + 1e-30
+    gh, wh = got["geomID"] != INVALID_ID, want["geomID"] != INVALID_ID
+    assert (gh == wh).all(), "%s: %d hit/miss disagreements" % (label, (gh != wh).sum())
+    same = (got["geomID"] == want["geomID"]) & (got["primID"] == want["primID"]) & (got["instID"] == want["instID"])
+    ties = ~same
+    assert rel(got["tfar"][ties], want["tfar"][ties]).all(), "%s: different primitive at a different t" % label
+    assert ties.sum() <= 40, "%s: %d ties" % (label, ties.sum())
+    m = same & wh
+    assert (got["instPrimID"][m] == want["instPrimID"][m]).all()
+    assert rel(got["tfar"][m], want["tfar"][m]).all()
+    ng = np.sqrt(want["Ng_x"][m] ** 2 + want["Ng_y"][m] ** 2 + want["Ng_z"][m] ** 2)
+    for f in ("Ng_x", "Ng_y", "Ng_z"):
+        assert (np.abs(got[f][m] - want[f][m]) <= RT * ng + 1e-30).all(), f
+    assert (np.abs(got["u"][m] - want["u"][m]) <= 1e-4).all() and (np.abs(got["v"][m] - want["v"][m]) <= 1e-4).all()
+    miss = ~wh
+    assert got[miss].tobytes() == rays[miss].tobytes(), "%s: a missed ray was modified" % label
+    exact = sum(int((got[f][m].view(np.uint32) == want[f][m].view(np.uint32)).all()) for f in ("tfar", "u", "v", "Ng_x", "Ng_y", "Ng_z"))
+    return int(ties.sum()), exact
+
+
+@pytest.mark.parametrize("flags", [0, 4])
+def test_instances_vs_golden(api, dev, flags):
+    """RTC_GEOMETRY_TYPE_INSTANCE (tutorials/instanced_geometry; InstanceIntersector1, kernels/geometry/instance_intersector.cpp): 24 instances of two object
+    scenes (triangles; triangles + quads) under rotation / non-uniform scale / shear, geometry masks, next to the scene's own geometry -- against the
+    REAL reference's outputs (tests/golden/ref_instances.npz): geomID / primID / instID[0] / instPrimID[0], object-space Ng, u, v, t, occlusion, bounds."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_instances.npz"))
+    top, objs = _instanced_scenes(api, dev, g, flags)
+    suffix = "_robust" if flags else ""
+    rays, want = g["rays"], g["hits" + suffix]
+    got = rays.copy()
+    top.intersect1M(got)
+    ties, exact = _compare_instanced(got, want, rays, "instances flags=%d" % flags)
+    assert (want["instID"] != INVALID_ID).sum() > 6000
+    r = rays_of(rays)
+    top.occluded1M(r)
+    assert (np.isneginf(r["tfar"]) == np.isneginf(g["occl" + suffix])).all()
+    assert (r["tfar"][~np.isneginf(r["tfar"])] == rays["tfar"][~np.isneginf(r["tfar"])]).all()
+    lo, hi = top.bounds()
+    assert (lo == g["bounds_lo"]).all() and (hi == g["bounds_hi"]).all()
+    # packets go through the same kernel: rtcIntersect8 on the first 64 rays
+    L = api.load()
+    # the object scenes may be released: the committed top scene holds its own copy of their trees
+    for o in objs:
+        o.release()
+    again = rays.copy()
+    top.intersect1M(again)
+    assert again.tobytes() == got.tobytes()
+    # transform round trip through the three matrix formats (rtcore.cpp:1408-1439)
+    geom = L.rtcGetGeometry(top.h, 2)
+    out = np.zeros(16, np.float32)
+    L.rtcGetGeometryTransform(geom, 0.0, api.RTC_FORMAT_FLOAT3X4_COLUMN_MAJOR, out.ctypes.data)
+    assert (out[:12] == g["xfm"][0]).all()
+    L.rtcGetGeometryTransform(geom, 0.0, api.RTC_FORMAT_FLOAT3X4_ROW_MAJOR, out.ctypes.data)
+    assert (out[:12].reshape(3, 4) == g["xfm"][0].reshape(4, 3).T).all()
+    L.rtcGetGeometryTransform(geom, 0.0, api.RTC_FORMAT_FLOAT4X4_COLUMN_MAJOR, out.ctypes.data)
+    assert (out.reshape(4, 4)[:, :3] == g["xfm"][0].reshape(4, 3)).all() and (out.reshape(4, 4)[:, 3] == [0, 0, 0, 1]).all()
+    top.release()
+    print("instances flags=%d: %d ties, %d/6 float fields bit-identical to the reference" % (flags, ties, exact))
+
+
+def test_instances_edge_cases(api, dev):
+    """an instance of an empty scene is skipped; a disabled instance disappears; only instances (no own geometry); a masked-out instance is invisible;
+    committing the top scene before the object scene is an error; one object scene instanced 4096 times."""
+    L = api.load()
+    empty, obj = api.Scene(dev), api.Scene(dev)
+    empty.commit()
+    v, t = W.triangle_sphere(np.zeros(3, np.float32), 1.0, 6)
+    obj.add_triangle_mesh(v, t); obj.commit()
+    ident = np.array([1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0], np.float32)
+    top = api.Scene(dev)
+    a = top.add_instance(empty, ident)
+    x1 = ident.copy(); x1[9] = 5.0
+    b = top.add_instance(obj, x1, mask=2)
+    top.commit()
+    rh = make_rayhits([[5, 0, -4], [0, 0, -4], [5, 0, -4]], [[0, 0, 1]] * 3)
+    rh["mask"] = [0xFFFFFFFF, 0xFFFFFFFF, 1]
+    top.intersect1M(rh)
+    assert rh["instID"][0] == b and rh["geomID"][0] == 0 and abs(rh["tfar"][0] - 3.0) < 1e-3
+    assert rh["geomID"][1] == INVALID_ID and rh["geomID"][2] == INVALID_ID
+    L.rtcDisableGeometry(L.rtcGetGeometry(top.h, b)); top.commit()
+    rh = make_rayhits([[5, 0, -4]], [[0, 0, 1]])
+    top.intersect1M(rh)
+    assert rh["geomID"][0] == INVALID_ID
+    r = rays_of(rh); top.occluded1M(r)
+    assert not np.isneginf(r["tfar"]).any()
+    top.release()
+    # object not committed yet
+    late = api.Scene(dev)
+    late.add_triangle_mesh(v, t)
+    top = api.Scene(dev)
+    top.add_instance(late, ident)
+    L.rtcCommitScene(top.h)
+    assert L.rtcGetDeviceError(dev.h) == 3                      # RTC_ERROR_INVALID_OPERATION
+    late.commit(); top.commit()
+    rh = make_rayhits([[0, 0, -4]], [[0, 0, 1]]); top.intersect1M(rh)
+    assert rh["instID"][0] == 0 and abs(rh["tfar"][0] - 3.0) < 1e-3
+    top.release(); late.release()
+    # many instances of one object: a 64 x 64 grid, one ray down onto each
+    top = api.Scene(dev)
+    n = 64
+    for i in range(n * n):
+        x = ident.copy() * 0.4; x[9], x[10], x[11] = (i % n) * 1.5, 0.0, (i // n) * 1.5
+        top.add_instance(obj, x)
+    top.commit()
+    org = np.stack([(np.arange(n * n) % n) * 1.5, np.full(n * n, 3.0), (np.arange(n * n) // n) * 1.5], -1).astype(np.float32)
+    rh = make_rayhits(org, np.tile(np.array([[0.01, -1, 0.02]], np.float32), (n * n, 1)))
+    top.intersect1M(rh)
+    assert (rh["instID"] == np.arange(n * n)).all() and (np.abs(rh["tfar"] - 2.6) < 0.02).all()
+    top.release(); obj.release(); empty.release()
