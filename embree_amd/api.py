@@ -53,7 +53,7 @@ mi355_stream_destroy mi355_event_create mi355_event_record mi355_event_elapsed_m
 class BuildParams(C.Structure):
     _fields_ = [("sah_block_shift", C.c_uint32), ("min_leaf", C.c_uint32), ("max_leaf", C.c_uint32),
                 ("small_threshold", C.c_uint32), ("trav_cost", C.c_float), ("int_cost", C.c_float),
-                ("robust", C.c_uint32), ("quality", C.c_uint32), ("refit", C.c_uint32)]
+                ("robust", C.c_uint32), ("quality", C.c_uint32), ("split_factor", C.c_float), ("refit", C.c_uint32)]
 
 
 class BvhInfo(C.Structure):
@@ -62,7 +62,7 @@ class BvhInfo(C.Structure):
                 ("bounds_lower", C.c_float * 3), ("bounds_upper", C.c_float * 3), ("sah", C.c_float),
                 ("build_ms", C.c_float), ("root_ref", C.c_uint32), ("top_levels", C.c_uint32),
                 ("max_leaf", C.c_uint32), ("depth", C.c_uint32),
-                ("bytes_refit", C.c_uint64), ("num_refits", C.c_uint32), ("reserved", C.c_uint32)]
+                ("bytes_refit", C.c_uint64), ("num_refits", C.c_uint32), ("num_presplit", C.c_uint32)]
 
     def as_dict(self):
         d = {k: getattr(self, k) for k, _ in self._fields_ if not k.startswith("bounds")}

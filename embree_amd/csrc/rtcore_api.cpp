@@ -230,6 +230,7 @@ struct Scene : RefCounted {
     mi355_build_params bp = device->build;
     bp.robust = (flags & RTC_SCENE_FLAG_ROBUST) ? 1u : 0u;   // scene.cpp:180-188: robust scenes get Triangle4v leaves + the Pluecker intersector
     if (quality == RTC_BUILD_QUALITY_LOW) bp.quality = 1u;    // scene.cpp:195-206: low quality = the Morton builder
+    if (quality == RTC_BUILD_QUALITY_HIGH) bp.quality = 2u;   // high quality = the presplit SAH builder (bvh_builder_sah_spatial.cpp:93-125)
     std::vector<BuiltFrom> from; bool wantRefit = (flags & RTC_SCENE_FLAG_DYNAMIC) != 0;
     for (auto& kv : geoms) {
       Geometry* g = kv.second;
@@ -322,7 +323,8 @@ void parse_config(Device* d, const char* cfg) {
     else if (k == "min_leaf") d->build.min_leaf = (uint32_t)atoi(v.c_str());
     else if (k == "leaf_block_shift") d->build.sah_block_shift = (uint32_t)atoi(v.c_str());
     else if (k == "small_threshold") d->build.small_threshold = (uint32_t)atoi(v.c_str());
-    else if (k == "quality") d->build.quality = (v == "low" || v == "1") ? 1u : 0u;
+    else if (k == "quality") d->build.quality = (v == "low" || v == "1") ? 1u : (v == "high" || v == "2") ? 2u : 0u;
+    else if (k == "max_spatial_split_replications") d->build.split_factor = (float)atof(v.c_str());   // state.cpp:437
     else if (k == "int_cost") d->build.int_cost = (float)atof(v.c_str());
     else if (k == "trav_cost") d->build.trav_cost = (float)atof(v.c_str());
     // CPU-only keys of the reference (threads, isa, tri_accel, hugepages, ...) are accepted and ignored
@@ -640,7 +642,7 @@ RTC_API void rtcSetSceneProgressMonitorFunction(RTCScene h, RTCProgressMonitorFu
 RTC_API void rtcSetSceneBuildQuality(RTCScene h, enum RTCBuildQuality q) {
   CATCH_BEGIN Scene* s = scene_of(h);
   if (q != RTC_BUILD_QUALITY_LOW && q != RTC_BUILD_QUALITY_MEDIUM && q != RTC_BUILD_QUALITY_HIGH) THROW(RTC_ERROR_INVALID_OPERATION, "invalid build quality");
-  s->quality = q;                                          // every quality is served by the binned-SAH builder
+  s->quality = q;
   CATCH_END(SCENE_DEV(h))
 }
 RTC_API void rtcSetSceneFlags(RTCScene h, enum RTCSceneFlags f) { CATCH_BEGIN scene_of(h)->flags = f; CATCH_END(SCENE_DEV(h)) }

@@ -54,7 +54,10 @@ typedef struct mi355_build_params {
                                 conservative node test (node_intersector1.h:539-554) and the Pluecker triangle test
                                 (triangle_intersector_pluecker.h:68-118).  default 0 */
   uint32_t quality;          /* 0 = RTC_BUILD_QUALITY_MEDIUM (binned SAH, the default); 1 = RTC_BUILD_QUALITY_LOW: Morton-code build like the
-                                reference's fast builder (kernels/builders/bvh_builder_morton.h), same node and leaf layout */
+                                reference's fast builder (kernels/builders/bvh_builder_morton.h), same node and leaf layout;
+                                2 = RTC_BUILD_QUALITY_HIGH: large triangles are pre-split into several references with clipped boxes before the SAH
+                                build (the reference's presplit builder, kernels/builders/primrefgen_presplit.h); no refit data is kept */
+  float    split_factor;     /* quality 2 only: references may grow to split_factor * triangles (reference: max_spatial_split_replications = 1.2).  default 1.2 */
   uint32_t refit;            /* 1: keep what mi355_bvh_refit needs (8 B per triangle: the leaf order, and the level table).  default 0 */
 } mi355_build_params;
 
@@ -70,7 +73,7 @@ typedef struct mi355_bvh_info {
   uint32_t root_ref, top_levels, max_leaf, depth;
   uint64_t bytes_refit;      /* extra device memory kept for mi355_bvh_refit (0 unless built with params.refit) */
   uint32_t num_refits;       /* refits since the build; build_ms is the GPU time of the last build OR refit */
-  uint32_t reserved;
+  uint32_t num_presplit;     /* quality 2: references added by pre-splitting (num_triangles counts references = leaf records) */
 } mi355_bvh_info;
 
 MI355_API void mi355_default_build_params(mi355_build_params* p);

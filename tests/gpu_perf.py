@@ -22,6 +22,7 @@ ap.add_argument("--reps", type=int, default=10)
 ap.add_argument("--any", action="store_true")
 ap.add_argument("--robust", action="store_true", help="RTC_SCENE_FLAG_ROBUST scene")
 ap.add_argument("--low", action="store_true", help="RTC_BUILD_QUALITY_LOW (Morton build)")
+ap.add_argument("--high", action="store_true", help="RTC_BUILD_QUALITY_HIGH (presplit build)")
 ap.add_argument("--sort", default="", help="experiment: reorder the rays on the host before the upload: origin | origin+octant | octant")
 ap.add_argument("--powerplant", action="store_true", help="configs[4]: the 12.7 M triangle powerplant stand-in instead of the crown stand-in")
 ap.add_argument("--primary", action="store_true")
@@ -31,7 +32,7 @@ a = ap.parse_args()
 L = api.load()
 dev = api.Device(a.config)
 meshes = W.synthetic_powerplant() if a.powerplant else W.synthetic_crown(num_phi=a.phi)
-s = api.Scene(dev, api.RTC_SCENE_FLAG_ROBUST if a.robust else 0, api.RTC_BUILD_QUALITY_LOW if a.low else None)
+s = api.Scene(dev, api.RTC_SCENE_FLAG_ROBUST if a.robust else 0, api.RTC_BUILD_QUALITY_LOW if a.low else (api.RTC_BUILD_QUALITY_HIGH if a.high else None))
 for v, t in meshes:
     s.add_triangle_mesh(v, t, device_resident=True)
 s.commit()

@@ -469,3 +469,64 @@ def test_instances_edge_cases(api, dev):
     top.intersect1M(rh)
     assert (rh["instID"] == np.arange(n * n)).all() and (np.abs(rh["tfar"] - 2.6) < 0.02).all()
     top.release(); obj.release(); empty.release()
+
+
+def _sticks(n, seed):
+    """long thin diagonal triangles: the case pre-splitting is for (their boxes are mostly empty)"""
+    rng = np.random.default_rng(seed)
+    a = rng.random((n, 3), dtype=np.float32)
+    d = (rng.random((n, 3), dtype=np.float32) - 0.5) * np.float32(1.2)
+    w = (rng.random((n, 3), dtype=np.float32) - 0.5) * np.float32(0.02)
+    v = np.stack([a, a + d, a + d * 0.5 + w], 1).reshape(-1, 3).astype(np.float32)
+    return v, np.arange(3 * n, dtype=np.uint32).reshape(-1, 3)
+
+
+@pytest.mark.parametrize("flags", [0, 4])
+def test_high_quality_presplit(api, dev, flags):
+    """rtcSetSceneBuildQuality(HIGH) = the reference's presplit builder (kernels/builders/primrefgen_presplit.h + the binned SAH build): big triangles enter
+    the build as several references with clipped boxes.  Hits do not depend on the tree: they must equal the MEDIUM scene's bit for bit (closest hit, any hit,
+    masks); the reference count stays within max_spatial_split_replications; the SAH cost drops; rebuilds are bit-identical; refit data is not kept."""
+    # few big triangles among many small ones: the budget (20 % of all references) goes to the big ones (a scene of ONLY big triangles gets no
+    # splits at all: every relative priority is below 1, primrefgen_presplit.h:301-305)
+    meshes = [_sticks(300, 5), W.triangle_sphere(np.array([0.5, 0.5, 0.5], np.float32), 0.25, 80, noise=0.1, seed=2)]
+    ntri = sum(t.shape[0] for _, t in meshes)
+    med = api.make_scene(dev, meshes, masks=[1, 2], flags=flags)
+    blobs = []
+    for rep in range(2):
+        high = api.make_scene(dev, meshes, masks=[1, 2], flags=flags, quality=api.RTC_BUILD_QUALITY_HIGH)
+        nodes, tris = high.download_bvh()
+        blobs.append(nodes.tobytes() + tris.tobytes())
+        if rep == 0:
+            ih, im = high.info(), med.info()
+            assert im["num_presplit"] == 0 and im["num_triangles"] == ntri
+            assert 0 < ih["num_presplit"] <= int(0.2 * ntri) and ih["num_triangles"] == ntri + ih["num_presplit"]
+            assert ih["sah"] < 0.8 * im["sah"], (ih["sah"], im["sah"])
+            assert ih["bytes_refit"] == 0
+            ids = tris["geomID"].astype(np.uint64) << 32 | (tris["primID"] & 0x7FFFFFFF)
+            assert np.unique(ids).shape[0] == ntri                  # every triangle is still there; some are named more than once
+            org = np.random.default_rng(3).random((80000, 3), dtype=np.float32) * 1.6 - 0.3
+            tgt = np.random.default_rng(4).random((80000, 3), dtype=np.float32)
+            rays = make_rayhits(org, tgt - org)
+            rays["mask"] = np.where(np.arange(80000) % 3 == 0, 1, np.where(np.arange(80000) % 3 == 1, 2, 3)).astype(np.uint32)
+            a, b = rays.copy(), rays.copy()
+            high.intersect1M(a); med.intersect1M(b)
+            assert (b["geomID"] != INVALID_ID).sum() > 20000
+            _same_hits(a, b)
+            sh, sm = high.trace_stats(api.DeviceArray.from_numpy(rays).ptr, rays.shape[0], 96), med.trace_stats(api.DeviceArray.from_numpy(rays).ptr, rays.shape[0], 96)
+            assert sh["nodes"] < sm["nodes"]                       # the point of it: fewer node visits for the same answers
+            ra, rb = rays_of(rays), rays_of(rays)
+            high.occluded1M(ra); med.occluded1M(rb)
+            assert (np.isneginf(ra["tfar"]) == np.isneginf(rb["tfar"])).all()
+            print("presplit flags=%d: %d + %d references, SAH %.2f -> %.2f, nodes/ray %.2f -> %.2f, tris/ray %.2f -> %.2f" % (flags, ntri, ih["num_presplit"], im["sah"], ih["sah"], sm["nodes"] / 8e4, sh["nodes"] / 8e4, sm["tris"] / 8e4, sh["tris"] / 8e4))
+        high.release()
+    assert blobs[0] == blobs[1]
+    med.release()
+    # the golden scenes answer the same through a HIGH-quality tree
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_cornell_4k.npz"))
+    s = api.make_scene(dev, W.cornell_box(), flags=flags, quality=api.RTC_BUILD_QUALITY_HIGH)
+    got = g["rays"].copy()
+    s.intersect1M(got)
+    same = (got["geomID"] == g["hits"]["geomID"]) & (got["primID"] == g["hits"]["primID"])
+    assert same.mean() > 0.995 and np.allclose(got["tfar"][same], g["hits"]["tfar"][same], rtol=1e-4)
+    s.release()
