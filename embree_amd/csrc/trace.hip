@@ -261,7 +261,7 @@ __device__ __forceinline__ void setup_rdir(float dx, float dy, float dz, float& 
 // pushes what is left of its node, transforms ITS ray into the instance (the world ray is re-read from the ray array on the way out), and walks
 // the object's tree with the same loop; ring pairs are tested with the owner's CURRENT ray, so a lane changes space only after the ring has
 // passed its last pair.  The winning triangle's instance is remembered per lane (the key in best[] changed while inside) and the hit is
-// recomputed in that instance's space when the ray retires.  Tail helpers (1b) are off: a helper would have to change space for its owner.
+// recomputed in that instance's space when the ray retires.  Tail helpers (1b) only take sub-trees that lie inside an instance.
 template <bool ANY, bool STATS, bool ROBUST, bool INST>
 __global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceArgs a) {
   __shared__ uint2 s_stack[BLOCK / 64][QSTACK_LDS][64];
@@ -401,9 +401,11 @@ __global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceAr
     // owner's own (ring pairs carry the owner, the testers fetch the ray from the owner's registers), the owner retires when its own
     // traversal is done, pend[owner] == 0 and the ring has passed the last ticket any of its helpers drew.  The result is the same
     // minimum over all accepted candidates; only the order in which sub-trees are visited changes.
-    if (!INST && exhausted) {
+    if (exhausted) {
       const unsigned long long freeM = __ballot(!active);
-      const bool canGive = active && !travDone && sp > 0u && sp <= (uint32_t)QSTACK_LDS && !(ANY && (uint32_t)best[owner] != MI355_EMPTY_REF);
+      // INST: only sub-trees INSIDE an instance are given away (entries above the depth at which the donor entered it): the helper copies the donor's
+      // object-space ray and never changes space; the donor stays in the instance until its helpers are done (step 2)
+      const bool canGive = active && !travDone && sp > (INST ? topSp : 0u) && sp <= (uint32_t)QSTACK_LDS && !(ANY && (uint32_t)best[owner] != MI355_EMPTY_REF) && (!INST || inst != NO_INST);
       const unsigned long long giveM = __ballot(canGive);
       if (freeM != 0ull && giveM != 0ull) {
         helpersUsed = true;
@@ -427,12 +429,14 @@ __global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceAr
         const float h0 = __shfl(ox, src, 64), h1 = __shfl(oy, src, 64), h2 = __shfl(oz, src, 64), h3 = __shfl(dx, src, 64), h4 = __shfl(dy, src, 64), h5 = __shfl(dz, src, 64);
         const float h6 = __shfl(rdx, src, 64), h7 = __shfl(rdy, src, 64), h8 = __shfl(rdz, src, 64), h9 = __shfl(tnear, src, 64), h10 = __shfl(tnearTrav, src, 64);
         const uint32_t hm = (uint32_t)__shfl((int)rmask, src, 64), ho = (uint32_t)__shfl((int)octinv4, src, 64);
+        const uint32_t hinst = INST ? (uint32_t)__shfl((int)inst, src, 64) : 0u;
         float h11 = 0, h12 = 0, h13 = 0;
         if (ROBUST) { h11 = __shfl(rfx, src, 64); h12 = __shfl(rfy, src, 64); h13 = __shfl(rfz, src, 64); }
         if (takes) {
           ox = h0; oy = h1; oz = h2; dx = h3; dy = h4; dz = h5; rdx = h6; rdy = h7; rdz = h8; tnear = h9; tnearTrav = h10; rmask = hm; octinv4 = ho;
           if (ROBUST) { rfx = h11; rfy = h12; rfz = h13; }
           owner = gown; helper = true; active = true; travDone = false;
+          if (INST) { inst = hinst; topSp = 0u; }
           sp = 0; ngBase = gx; ngHits = gy; tgBase = 0; tgHits = 0; lastTicket = qHead;
           atomicAdd(&pend[owner], 1u);
         }
@@ -448,27 +452,31 @@ __global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceAr
       bool finished = false;
       if (ANY && (uint32_t)b != MI355_EMPTY_REF) { finished = true; tgHits = 0; ngHits = 0; sp = 0; lastTicket = qHead; }   // occluded: nothing left to wait for
       else if (tgHits == 0u && ngHits <= 0x00FFFFFFu) {
-        if (INST && inst != NO_INST && sp == topSp) {              // the instance's sub-tree is done: back to world space once my queued pairs are tested
-          if ((int)(qHead - lastTicket) >= 0) {
+        bool mayPop = true;
+        if (INST && inst != NO_INST && sp == topSp && !helper) {   // the instance's sub-tree is done: back to world space once my queued pairs are tested (and my helpers' too)
+          if ((int)(qHead - lastTicket) >= 0 && (!helpersUsed || (pend[lane] == 0u && (int)(qHead - lastT[lane]) >= 0))) {
             if ((uint32_t)b != entryLo || (uint32_t)(b >> 32) != entryHi) bestInst = inst;
             inst = NO_INST;
             const float4* rp = (const float4*)(a.rays + (size_t)rayIdx * a.stride);
             const float4 r0 = rp[0], r1 = rp[1];
             ox = r0.x; oy = r0.y; oz = r0.z; dx = r1.x; dy = r1.y; dz = r1.z;
             setup_rdir<ROBUST>(dx, dy, dz, rdx, rdy, rdz, rfx, rfy, rfz, octinv4);
-          } else waitDrain = true;
-        } else if (sp != 0u) {
-          sp--;
-          uint2 e = stk[min(sp, (uint32_t)(QSTACK_LDS - 1)) * 64u];
-          if (__builtin_expect(sp >= (uint32_t)QSTACK_LDS, 0)) e = spill[sp - QSTACK_LDS];
-          if (INST && e.y <= 0x00FFFFFFu) { tgBase = e.x; tgHits = e.y; }   // instances of a top node that are still to be visited
-          else { ngBase = e.x; ngHits = e.y; }
-        } else finished = true;
+          } else { waitDrain = true; mayPop = false; }
+        }
+        if (mayPop) {                                              // (a lane that has just left an instance pops in the same iteration)
+          if (sp != 0u) {
+            sp--;
+            uint2 e = stk[min(sp, (uint32_t)(QSTACK_LDS - 1)) * 64u];
+            if (__builtin_expect(sp >= (uint32_t)QSTACK_LDS, 0)) e = spill[sp - QSTACK_LDS];
+            if (INST && e.y <= 0x00FFFFFFu) { tgBase = e.x; tgHits = e.y; }   // instances of a top node that are still to be visited
+            else { ngBase = e.x; ngHits = e.y; }
+          } else finished = true;
+        }
       }
       if (finished) {
         if (helper) {                                             // hand the sub-tree back: my tickets first, then my share of pend
           atomicMax(&lastT[owner], lastTicket); atomicSub(&pend[owner], 1u);
-          active = false; helper = false; owner = lane;
+          active = false; helper = false; owner = lane; if (INST) inst = NO_INST;
         } else travDone = true;                                    // lastTicket already names this ray's last queued pair
       }
     }

@@ -83,5 +83,11 @@ for name, rays in (("primary", prim), ("diffuse", bounce)):
     oi, _ = rate(top, rays_of(rays), True)
     of, _ = rate(fs, rays_of(rays), True)
     st_i = top.trace_stats(api.DeviceArray.from_numpy(rays).ptr, rays.shape[0], 96)
+    st_f = fs.trace_stats(api.DeviceArray.from_numpy(rays).ptr, rays.shape[0], 96)
+    for tag, q in (("inst", st_i), ("flat", st_f)):
+        li = 64.0 * q["wave_iters"]
+        print("CENSUS %s %-8s wave_iters %d node-step util %.2f | lanes: node %.3f idle %.3f wait_batch %.3f wait_drain %.3f blocked %.3f | spills %d depth %d"
+              % (tag, name, q["wave_iters"], q["nodes"] / max(1, 64 * q["node_blocks"]), q["nodes"] / li, q["lanes_idle"] / li, q["lanes_wait_batch"] / li,
+                 q["lanes_wait_drain"] / li, q["lanes_blocked"] / li, q["spills"], q["max_depth"]))
     print("INST %-8s closest %.0f Mrays/s (flat %.0f) | any hit %.0f (flat %.0f) | same primitive and t: %.5f of %d hits | nodes/ray %.1f tris/ray %.1f"
           % (name, ri, rf, oi, of, agree.mean(), both.sum(), st_i["nodes"] / st_i["rays"], st_i["tris"] / st_i["rays"]))
