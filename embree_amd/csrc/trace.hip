@@ -65,7 +65,7 @@ struct TraceArgs {
   uint32_t* counter;     // global ray cursor (zeroed before launch)
   uint2* spill;          // [gridDim.x * BLOCK][spillPerLane]
   uint32_t spillPerLane;
-  uint32_t refillMin, pushRounds, numCursors;
+  uint32_t refillMin, pushRounds, numCursors, drainWaiters;
   unsigned long long* stats;  // optional counters
   const float4* insts;   // INST kernels: InstRec[] as 4 x float4 (world2local vx,vy,vz,p | root node, instID, mask, flags)
 };
@@ -537,7 +537,8 @@ __global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceAr
     const bool anyTraversing = __ballot(active && !travDone && !waitDrain) != 0ull;
     for (;;) {
       const uint32_t count = qTail - qHead;
-      if (count == 0u || (count < 64u && anyTraversing)) break;
+      if (count == 0u) break;
+      if (count < 64u && anyTraversing && (!INST || (uint32_t)__popcll(__ballot(waitDrain)) < a.drainWaiters)) break;   // INST: lanes that wait to leave an instance force a partial batch
       const uint32_t n = min(count, 64u);
       const bool mine = lane < n;
       const uint2 e = queue[(qHead + (mine ? lane : 0u)) & (QCAP - 1u)];
@@ -718,7 +719,8 @@ static int launch_trace(Bvh* b, void* d_rays, uint32_t count, size_t stride, boo
   static const uint32_t refillMin = env_u32("MI355_REFILL_MIN", REFILL_MIN_DEFAULT, 1, 64);
   static const uint32_t pushRounds = env_u32("MI355_PUSH_ROUNDS", PUSH_ROUNDS_DEFAULT, 1, 24);
   static const uint32_t numCursors = env_u32("MI355_NUM_CURSORS", NUM_CURSORS, 1, NUM_CURSORS);
-  a.refillMin = refillMin; a.pushRounds = pushRounds; a.numCursors = numCursors;
+  static const uint32_t drainWaiters = env_u32("MI355_DRAIN_WAITERS", 3, 1, 65);
+  a.refillMin = refillMin; a.pushRounds = pushRounds; a.numCursors = numCursors; a.drainWaiters = drainWaiters;
   if (statsOut) {
     HIP_TRY(hipMemsetAsync(sc->stats, 0, 16 * sizeof(uint64_t), s));
     a.stats = (unsigned long long*)sc->stats;
