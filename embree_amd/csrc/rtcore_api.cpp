@@ -713,3 +713,62 @@ RTC_API bool rtcPointQuery(RTCScene h, void*, void*, void*, void*) { process_err
 RTC_API void rtcCollide(RTCScene h, RTCScene, void*, void*) { process_error(SCENE_DEV(h), RTC_ERROR_INVALID_OPERATION, "rtcCollide is not supported by the MI355X triangle core"); }
 RTC_API void rtcInterpolate(const void*) { process_error(nullptr, RTC_ERROR_INVALID_OPERATION, "rtcInterpolate is not supported by the MI355X triangle core"); }
 RTC_API void rtcGetSceneLinearBounds(RTCScene h, void*) { process_error(SCENE_DEV(h), RTC_ERROR_INVALID_OPERATION, "rtcGetSceneLinearBounds is not supported by the MI355X triangle core"); }
+
+// ---- the rest of the reference library's export table (oracle/_ref/libembree4.so exports 154 rtc* symbols): an application linked against libembree4
+// resolves every one of them here.  The host/device buffer calls of Embree 4.4 map onto this library's device copies; what lies outside the triangle /
+// quad / instance path records RTC_ERROR_INVALID_OPERATION like an Embree built without that feature.
+RTC_API RTCBuffer rtcNewBufferHostDevice(RTCDevice h, size_t bytes) { return rtcNewBuffer(h, bytes); }
+RTC_API RTCBuffer rtcNewSharedBufferHostDevice(RTCDevice h, void* ptr, size_t bytes) { return rtcNewSharedBuffer(h, ptr, bytes); }
+RTC_API void rtcCommitBuffer(RTCBuffer b) {                  // host -> device copy (rtcore_buffer.h:51)
+  if (!b) return;
+  Buffer* buf = (Buffer*)b;
+  CATCH_BEGIN if (buf->ownsDev || !buf->dev) buf->devDirty = true; buf->upload(); CATCH_END(buf->device)
+}
+RTC_API void* rtcGetBufferDataDevice(RTCBuffer b) { if (!b) return nullptr; Buffer* buf = (Buffer*)b; return buf->dev; }
+RTC_API void* rtcGetGeometryBufferDataDevice(RTCGeometry h, enum RTCBufferType type, unsigned slot) {
+  CATCH_BEGIN
+  Geometry* g = geom_of(h); if (slot != 0) THROW(RTC_ERROR_INVALID_ARGUMENT, "invalid buffer slot");
+  BufferView* v = type == RTC_BUFFER_TYPE_VERTEX ? &g->vertices : type == RTC_BUFFER_TYPE_INDEX ? &g->indices : nullptr;
+  if (!v) THROW(RTC_ERROR_INVALID_ARGUMENT, "unknown buffer type");
+  return v->buf && v->buf->dev ? v->buf->dev + v->offset : nullptr;
+  CATCH_END(GEOM_DEV(h))
+  return nullptr;
+}
+RTC_API void rtcSetNewGeometryBufferHostDevice(RTCGeometry h, enum RTCBufferType type, unsigned slot, enum RTCFormat fmt, size_t byteStride, size_t itemCount, void** ptr, void** dptr) {
+  void* p = rtcSetNewGeometryBuffer(h, type, slot, fmt, byteStride, itemCount);
+  if (ptr) *ptr = p;
+  if (dptr) {                                               // the device copy exists from now on; rtcCommitGeometry / rtcCommitBuffer fill it
+    *dptr = nullptr;
+    CATCH_BEGIN
+    Geometry* g = geom_of(h);
+    BufferView* v = type == RTC_BUFFER_TYPE_VERTEX ? &g->vertices : type == RTC_BUFFER_TYPE_INDEX ? &g->indices : nullptr;
+    if (p && v && v->buf) { v->buf->upload(); v->buf->devDirty = true; *dptr = v->buf->dev + v->offset; }
+    CATCH_END(GEOM_DEV(h))
+  }
+}
+RTC_API void rtcGetGeometryTransformEx(RTCGeometry h, unsigned, float time, enum RTCFormat fmt, void* xfm) { rtcGetGeometryTransform(h, time, fmt, xfm); }
+RTC_API void rtcGetGeometryTransformFromScene(RTCScene h, unsigned geomID, float time, enum RTCFormat fmt, void* xfm) {
+  RTCGeometry g = rtcGetGeometry(h, geomID); if (g) rtcGetGeometryTransform(g, time, fmt, xfm);
+}
+RTC_API void rtcGetGeometryTransformFromTraversable(RTCTraversable t, unsigned geomID, float time, enum RTCFormat fmt, void* xfm) { rtcGetGeometryTransformFromScene((RTCScene)t, geomID, time, fmt, xfm); }
+RTC_API void* rtcGetGeometryUserDataFromScene(RTCScene h, unsigned geomID) { RTCGeometry g = rtcGetGeometry(h, geomID); return g ? rtcGetGeometryUserData(g) : nullptr; }
+RTC_API void* rtcGetGeometryUserDataFromTraversable(RTCTraversable t, unsigned geomID) { return rtcGetGeometryUserDataFromScene((RTCScene)t, geomID); }
+UNSUPPORTED_GEOM(rtcSetGeometryInstancedScenes, RTCScene*, size_t)
+UNSUPPORTED_GEOM(rtcSetGeometryTransformQuaternion, unsigned, const void*)
+#define UNSUPPORTED_VOID(name) RTC_API void name(void) { process_error(nullptr, RTC_ERROR_INVALID_OPERATION, #name " is not supported by the MI355X triangle core"); }
+#define UNSUPPORTED_ZERO(T, name) RTC_API T name(void) { process_error(nullptr, RTC_ERROR_INVALID_OPERATION, #name " is not supported by the MI355X triangle core"); return (T)0; }
+// (C symbols carry no signature: the callers' arguments are simply not read)
+UNSUPPORTED_VOID(rtcForwardIntersect1) UNSUPPORTED_VOID(rtcForwardIntersect4) UNSUPPORTED_VOID(rtcForwardIntersect8) UNSUPPORTED_VOID(rtcForwardIntersect16)
+UNSUPPORTED_VOID(rtcForwardIntersect1Ex) UNSUPPORTED_VOID(rtcForwardIntersect4Ex) UNSUPPORTED_VOID(rtcForwardIntersect8Ex) UNSUPPORTED_VOID(rtcForwardIntersect16Ex)
+UNSUPPORTED_VOID(rtcForwardOccluded1) UNSUPPORTED_VOID(rtcForwardOccluded4) UNSUPPORTED_VOID(rtcForwardOccluded8) UNSUPPORTED_VOID(rtcForwardOccluded16)
+UNSUPPORTED_VOID(rtcForwardOccluded1Ex) UNSUPPORTED_VOID(rtcForwardOccluded4Ex) UNSUPPORTED_VOID(rtcForwardOccluded8Ex) UNSUPPORTED_VOID(rtcForwardOccluded16Ex)
+UNSUPPORTED_VOID(rtcTraversableForwardIntersect1) UNSUPPORTED_VOID(rtcTraversableForwardIntersect4) UNSUPPORTED_VOID(rtcTraversableForwardIntersect8) UNSUPPORTED_VOID(rtcTraversableForwardIntersect16)
+UNSUPPORTED_VOID(rtcTraversableForwardIntersect1Ex) UNSUPPORTED_VOID(rtcTraversableForwardIntersect4Ex) UNSUPPORTED_VOID(rtcTraversableForwardIntersect8Ex) UNSUPPORTED_VOID(rtcTraversableForwardIntersect16Ex)
+UNSUPPORTED_VOID(rtcTraversableForwardOccluded1) UNSUPPORTED_VOID(rtcTraversableForwardOccluded4) UNSUPPORTED_VOID(rtcTraversableForwardOccluded8) UNSUPPORTED_VOID(rtcTraversableForwardOccluded16)
+UNSUPPORTED_VOID(rtcTraversableForwardOccluded1Ex) UNSUPPORTED_VOID(rtcTraversableForwardOccluded4Ex) UNSUPPORTED_VOID(rtcTraversableForwardOccluded8Ex) UNSUPPORTED_VOID(rtcTraversableForwardOccluded16Ex)
+UNSUPPORTED_ZERO(bool, rtcPointQuery4) UNSUPPORTED_ZERO(bool, rtcPointQuery8) UNSUPPORTED_ZERO(bool, rtcPointQuery16)
+UNSUPPORTED_ZERO(bool, rtcTraversablePointQuery) UNSUPPORTED_ZERO(bool, rtcTraversablePointQuery4) UNSUPPORTED_ZERO(bool, rtcTraversablePointQuery8) UNSUPPORTED_ZERO(bool, rtcTraversablePointQuery16)
+UNSUPPORTED_VOID(rtcInterpolateN) UNSUPPORTED_VOID(rtcInvokeIntersectFilterFromGeometry) UNSUPPORTED_VOID(rtcInvokeOccludedFilterFromGeometry)
+UNSUPPORTED_ZERO(unsigned, rtcGetGeometryFirstHalfEdge) UNSUPPORTED_ZERO(unsigned, rtcGetGeometryFace) UNSUPPORTED_ZERO(unsigned, rtcGetGeometryNextHalfEdge)
+UNSUPPORTED_ZERO(unsigned, rtcGetGeometryPreviousHalfEdge) UNSUPPORTED_ZERO(unsigned, rtcGetGeometryOppositeHalfEdge)
+UNSUPPORTED_ZERO(void*, rtcNewBVH) UNSUPPORTED_ZERO(void*, rtcBuildBVH) UNSUPPORTED_ZERO(void*, rtcThreadLocalAlloc) UNSUPPORTED_VOID(rtcMakeStaticBVH) UNSUPPORTED_VOID(rtcRetainBVH) UNSUPPORTED_VOID(rtcReleaseBVH)

@@ -120,3 +120,14 @@ def test_product_never_imports_the_oracle():
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "oracle" not in txt.replace("oracle/_ref", "").replace("# oracle", "") or f == "workloads.py" and "oracle in tests" in txt, \
                     os.path.join(dirpath, f) + " mentions the oracle"
+
+
+def test_every_export_of_the_reference_library_resolves(lib_path):
+    """tests/golden/ref_exports.txt = `nm -D` of the real libembree4.so built by oracle/ref.mk (154 rtc* symbols, default CPU build): an application linked
+    against the reference resolves every one of them in this library (what is outside the triangle / quad / instance path records an error when called)."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    want = set(open(os.path.join(here, "golden", "ref_exports.txt")).read().split())
+    assert len(want) == 154
+    out = subprocess.run(["nm", "-D", "--defined-only", lib_path], capture_output=True, text=True, check=True).stdout
+    have = {ln.split()[-1] for ln in out.splitlines() if " T " in ln}
+    assert not (want - have), sorted(want - have)
