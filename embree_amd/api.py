@@ -32,7 +32,7 @@ rtcGetDeviceError rtcGetDeviceLastErrorMessage rtcSetDeviceErrorFunction rtcSetD
 rtcNewBuffer rtcNewSharedBuffer rtcGetBufferData rtcRetainBuffer rtcReleaseBuffer
 rtcNewGeometry rtcRetainGeometry rtcReleaseGeometry rtcCommitGeometry rtcEnableGeometry rtcDisableGeometry
 rtcSetGeometryTimeStepCount rtcSetGeometryVertexAttributeCount rtcSetGeometryMask rtcSetGeometryBuildQuality
-rtcSetGeometryInstancedScene rtcSetGeometryTransform rtcGetGeometryTransform
+rtcSetGeometryInstancedScene rtcSetGeometryTransform rtcGetGeometryTransform rtcInterpolate rtcInterpolateN
 rtcSetGeometryBuffer rtcSetSharedGeometryBuffer rtcSetSharedGeometryBufferHostDevice rtcSetNewGeometryBuffer
 rtcGetGeometryBufferData rtcUpdateGeometryBuffer rtcSetGeometryUserData rtcGetGeometryUserData
 rtcSetGeometryIntersectFilterFunction rtcSetGeometryOccludedFilterFunction
@@ -69,6 +69,19 @@ class BvhInfo(C.Structure):
         d["bounds_lower"] = list(self.bounds_lower)
         d["bounds_upper"] = list(self.bounds_upper)
         return d
+
+
+class RTCInterpolateArguments(C.Structure):
+    _fields_ = [("geometry", C.c_void_p), ("primID", C.c_uint32), ("u", C.c_float), ("v", C.c_float), ("bufferType", C.c_int), ("bufferSlot", C.c_uint32),
+                ("P", C.c_void_p), ("dPdu", C.c_void_p), ("dPdv", C.c_void_p), ("ddPdudu", C.c_void_p), ("ddPdvdv", C.c_void_p), ("ddPdudv", C.c_void_p),
+                ("valueCount", C.c_uint32)]
+
+
+class RTCInterpolateNArguments(C.Structure):
+    _fields_ = [("geometry", C.c_void_p), ("valid", C.c_void_p), ("primIDs", C.c_void_p), ("u", C.c_void_p), ("v", C.c_void_p), ("N", C.c_uint32),
+                ("bufferType", C.c_int), ("bufferSlot", C.c_uint32),
+                ("P", C.c_void_p), ("dPdu", C.c_void_p), ("dPdv", C.c_void_p), ("ddPdudu", C.c_void_p), ("ddPdvdv", C.c_void_p), ("ddPdudv", C.c_void_p),
+                ("valueCount", C.c_uint32)]
 
 
 class RTCBounds(C.Structure):
@@ -115,6 +128,8 @@ def load():
     L.rtcSetGeometryMask.argtypes = [vp, u32]
     L.rtcSetGeometryBuildQuality.argtypes = [vp, C.c_int]
     L.rtcSetGeometryInstancedScene.argtypes = [vp, vp]
+    L.rtcInterpolate.argtypes = [C.POINTER(RTCInterpolateArguments)]
+    L.rtcInterpolateN.argtypes = [C.POINTER(RTCInterpolateNArguments)]
     L.rtcSetGeometryTransform.argtypes = [vp, u32, C.c_int, vp]
     L.rtcGetGeometryTransform.argtypes = [vp, C.c_float, C.c_int, vp]
     L.rtcSetGeometryTimeStepCount.argtypes = [vp, u32]

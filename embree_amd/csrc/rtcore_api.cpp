@@ -124,7 +124,8 @@ struct Scene;
 struct Geometry : RefCounted {
   Device* device; RTCGeometryType type;
   BufferView vertices, indices;
-  std::map<unsigned, Buffer*> attribs;                     // vertex attributes: kept alive for the caller, unused by the kernels
+  std::map<unsigned, Buffer*> attribs;                     // vertex attributes: kept alive for the caller, unused by the kernels (rtcInterpolate reads them on the host)
+  std::map<unsigned, BufferView> attribViews;
   unsigned mask = 1;                                        // Geometry ctor, geometry.cpp:48
   bool enabled = true, modified = true, committed = false;
   RTCBuildQuality quality = RTC_BUILD_QUALITY_MEDIUM;
@@ -160,6 +161,7 @@ struct Geometry : RefCounted {
       b->retain();                                          // accepted and kept alive, unused on the GPU path (no rtcInterpolate)
       if (attribs.count(slot)) attribs[slot]->release();
       attribs[slot] = b;
+      { BufferView av; av.buf = b; av.offset = off; av.stride = stride; av.num = (unsigned)num; attribViews[slot] = av; }
       return;
     } else THROW(RTC_ERROR_INVALID_ARGUMENT, "unknown buffer type");
     const size_t elem = (t == RTC_BUFFER_TYPE_INDEX && type == RTC_GEOMETRY_TYPE_QUAD) ? 16 : 12;
@@ -711,7 +713,63 @@ UNSUPPORTED_GEOM(rtcSetGeometryVertexAttributeTopology, unsigned, unsigned)
 UNSUPPORTED_GEOM(rtcSetGeometryDisplacementFunction, void*)
 RTC_API bool rtcPointQuery(RTCScene h, void*, void*, void*, void*) { process_error(SCENE_DEV(h), RTC_ERROR_INVALID_OPERATION, "rtcPointQuery is not supported by the MI355X triangle core"); return false; }
 RTC_API void rtcCollide(RTCScene h, RTCScene, void*, void*) { process_error(SCENE_DEV(h), RTC_ERROR_INVALID_OPERATION, "rtcCollide is not supported by the MI355X triangle core"); }
-RTC_API void rtcInterpolate(const void*) { process_error(nullptr, RTC_ERROR_INVALID_OPERATION, "rtcInterpolate is not supported by the MI355X triangle core"); }
+// rtcInterpolate / rtcInterpolateN: host arithmetic on the host copies of the buffers, as in the reference (TriangleMesh::interpolate_impl,
+// kernels/common/scene_triangle_mesh.h:49-100: P = madd(w, p0, madd(u, p1, v * p2)), dPdu = p1 - p0, dPdv = p2 - p0, second derivatives 0;
+// QuadMesh::interpolate_impl, scene_quad_mesh.h:55-112: the triangle (p0,p1,p3) for u + v <= 1, else (p2,p3,p1) with 1-u, 1-v and flipped derivatives).
+static void interpolate_one(Geometry* g, const RTCInterpolateArguments* a) {
+  if (g->type != RTC_GEOMETRY_TYPE_TRIANGLE && g->type != RTC_GEOMETRY_TYPE_QUAD) THROW(RTC_ERROR_INVALID_OPERATION, "operation not supported for this geometry");
+  const BufferView* src = nullptr;
+  if (a->bufferType == RTC_BUFFER_TYPE_VERTEX) { if (a->bufferSlot != 0) THROW(RTC_ERROR_INVALID_ARGUMENT, "invalid buffer slot"); src = &g->vertices; }
+  else if (a->bufferType == RTC_BUFFER_TYPE_VERTEX_ATTRIBUTE) { auto it = g->attribViews.find(a->bufferSlot); if (it == g->attribViews.end()) THROW(RTC_ERROR_INVALID_ARGUMENT, "invalid buffer slot"); src = &it->second; }
+  else THROW(RTC_ERROR_INVALID_ARGUMENT, "invalid buffer type");
+  if (!src->buf || !g->indices.buf) THROW(RTC_ERROR_INVALID_OPERATION, "geometry has no such buffer");
+  if ((size_t)src->buf->host < 4096 || (size_t)g->indices.buf->host < 4096) THROW(RTC_ERROR_INVALID_OPERATION, "rtcInterpolate needs host-visible buffers (this buffer was shared as device memory only)");
+  if (a->primID >= g->indices.num) THROW(RTC_ERROR_INVALID_ARGUMENT, "invalid primitive");
+  const unsigned* idx = (const unsigned*)(g->indices.buf->host + g->indices.offset + (size_t)a->primID * g->indices.stride);
+  const char* base = src->buf->host + src->offset;
+  const bool quad = g->type == RTC_GEOMETRY_TYPE_QUAD;
+  const unsigned nidx = quad ? 4u : 3u;
+  for (unsigned k = 0; k < nidx; k++) if (idx[k] >= src->num) THROW(RTC_ERROR_INVALID_ARGUMENT, "vertex index out of range");
+  const float *p0 = (const float*)(base + (size_t)idx[0] * src->stride), *p1 = (const float*)(base + (size_t)idx[1] * src->stride), *p2 = (const float*)(base + (size_t)idx[2] * src->stride);
+  float u = a->u, v = a->v; bool left = true;
+  const float *q0 = p0, *q1 = p1, *q2 = p2;
+  if (quad) {
+    const float* p3 = (const float*)(base + (size_t)idx[3] * src->stride);
+    left = u + v <= 1.0f;
+    q0 = left ? p0 : p2; q1 = left ? p1 : p3; q2 = left ? p3 : p1;
+    if (!left) { u = 1.0f - u; v = 1.0f - v; }
+  }
+  const float w = 1.0f - u - v;
+  for (unsigned i = 0; i < a->valueCount; i++) {
+    if (a->P) a->P[i] = fmaf(w, q0[i], fmaf(u, q1[i], v * q2[i]));
+    if (a->dPdu) { a->dPdu[i] = left ? q1[i] - q0[i] : q0[i] - q1[i]; a->dPdv[i] = left ? q2[i] - q0[i] : q0[i] - q2[i]; }
+    if (a->ddPdudu) { a->ddPdudu[i] = 0.0f; a->ddPdvdv[i] = 0.0f; a->ddPdudv[i] = 0.0f; }
+  }
+}
+RTC_API void rtcInterpolate(const struct RTCInterpolateArguments* a) {
+  Geometry* g = a ? (Geometry*)a->geometry : nullptr;
+  CATCH_BEGIN if (!a) THROW(RTC_ERROR_INVALID_ARGUMENT, "invalid argument"); interpolate_one(geom_of(a->geometry), a); CATCH_END(g ? g->device : nullptr)
+}
+RTC_API void rtcInterpolateN(const struct RTCInterpolateNArguments* a) {   // Geometry::interpolateN, kernels/common/geometry.cpp:163-235: outputs are SoA, value j of point i at [j * N + i]
+  Geometry* g = a ? (Geometry*)a->geometry : nullptr;
+  CATCH_BEGIN
+  if (!a) THROW(RTC_ERROR_INVALID_ARGUMENT, "invalid argument");
+  if (a->valueCount > 256) THROW(RTC_ERROR_INVALID_OPERATION, "maximally 256 floating point values can be interpolated per vertex");
+  float P[256], du[256], dv[256], duu[256], dvv[256], duv[256];
+  const int* valid = (const int*)a->valid;
+  for (unsigned i = 0; i < a->N; i++) {
+    if (valid && !valid[i]) continue;
+    RTCInterpolateArguments one{a->geometry, a->primIDs[i], a->u[i], a->v[i], a->bufferType, a->bufferSlot, a->P ? P : nullptr, a->dPdu ? du : nullptr, a->dPdu ? dv : nullptr,
+                                a->ddPdudu ? duu : nullptr, a->ddPdudu ? dvv : nullptr, a->ddPdudu ? duv : nullptr, a->valueCount};
+    interpolate_one(geom_of(a->geometry), &one);
+    for (unsigned j = 0; j < a->valueCount; j++) {
+      if (a->P) a->P[(size_t)j * a->N + i] = P[j];
+      if (a->dPdu) { a->dPdu[(size_t)j * a->N + i] = du[j]; a->dPdv[(size_t)j * a->N + i] = dv[j]; }
+      if (a->ddPdudu) { a->ddPdudu[(size_t)j * a->N + i] = duu[j]; a->ddPdvdv[(size_t)j * a->N + i] = dvv[j]; a->ddPdudv[(size_t)j * a->N + i] = duv[j]; }
+    }
+  }
+  CATCH_END(g ? g->device : nullptr)
+}
 RTC_API void rtcGetSceneLinearBounds(RTCScene h, void*) { process_error(SCENE_DEV(h), RTC_ERROR_INVALID_OPERATION, "rtcGetSceneLinearBounds is not supported by the MI355X triangle core"); }
 
 // ---- the rest of the reference library's export table (oracle/_ref/libembree4.so exports 154 rtc* symbols): an application linked against libembree4
@@ -768,7 +826,7 @@ UNSUPPORTED_VOID(rtcTraversableForwardOccluded1) UNSUPPORTED_VOID(rtcTraversable
 UNSUPPORTED_VOID(rtcTraversableForwardOccluded1Ex) UNSUPPORTED_VOID(rtcTraversableForwardOccluded4Ex) UNSUPPORTED_VOID(rtcTraversableForwardOccluded8Ex) UNSUPPORTED_VOID(rtcTraversableForwardOccluded16Ex)
 UNSUPPORTED_ZERO(bool, rtcPointQuery4) UNSUPPORTED_ZERO(bool, rtcPointQuery8) UNSUPPORTED_ZERO(bool, rtcPointQuery16)
 UNSUPPORTED_ZERO(bool, rtcTraversablePointQuery) UNSUPPORTED_ZERO(bool, rtcTraversablePointQuery4) UNSUPPORTED_ZERO(bool, rtcTraversablePointQuery8) UNSUPPORTED_ZERO(bool, rtcTraversablePointQuery16)
-UNSUPPORTED_VOID(rtcInterpolateN) UNSUPPORTED_VOID(rtcInvokeIntersectFilterFromGeometry) UNSUPPORTED_VOID(rtcInvokeOccludedFilterFromGeometry)
+UNSUPPORTED_VOID(rtcInvokeIntersectFilterFromGeometry) UNSUPPORTED_VOID(rtcInvokeOccludedFilterFromGeometry)
 UNSUPPORTED_ZERO(unsigned, rtcGetGeometryFirstHalfEdge) UNSUPPORTED_ZERO(unsigned, rtcGetGeometryFace) UNSUPPORTED_ZERO(unsigned, rtcGetGeometryNextHalfEdge)
 UNSUPPORTED_ZERO(unsigned, rtcGetGeometryPreviousHalfEdge) UNSUPPORTED_ZERO(unsigned, rtcGetGeometryOppositeHalfEdge)
 UNSUPPORTED_ZERO(void*, rtcNewBVH) UNSUPPORTED_ZERO(void*, rtcBuildBVH) UNSUPPORTED_ZERO(void*, rtcThreadLocalAlloc) UNSUPPORTED_VOID(rtcMakeStaticBVH) UNSUPPORTED_VOID(rtcRetainBVH) UNSUPPORTED_VOID(rtcReleaseBVH)

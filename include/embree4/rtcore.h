@@ -323,6 +323,18 @@ RTC_API void rtcDisableGeometry(RTCGeometry geometry);
 RTC_API void rtcSetGeometryTimeStepCount(RTCGeometry geometry, unsigned int timeStepCount);
 RTC_API void rtcSetGeometryVertexAttributeCount(RTCGeometry geometry, unsigned int vertexAttributeCount);
 RTC_API void rtcSetGeometryMask(RTCGeometry geometry, unsigned int mask);
+/* Vertex data interpolation at (u, v) of a triangle / quad, on the host [ref: rtcore_geometry.h:284-387] */
+struct RTCInterpolateArguments {
+  RTCGeometry geometry; unsigned int primID; float u; float v; enum RTCBufferType bufferType; unsigned int bufferSlot;
+  float* P; float* dPdu; float* dPdv; float* ddPdudu; float* ddPdvdv; float* ddPdudv; unsigned int valueCount;
+};
+RTC_API void rtcInterpolate(const struct RTCInterpolateArguments* args);
+struct RTCInterpolateNArguments {
+  RTCGeometry geometry; const void* valid; const unsigned int* primIDs; const float* u; const float* v; unsigned int N;
+  enum RTCBufferType bufferType; unsigned int bufferSlot;
+  float* P; float* dPdu; float* dPdv; float* ddPdudu; float* ddPdvdv; float* ddPdudv; unsigned int valueCount;
+};
+RTC_API void rtcInterpolateN(const struct RTCInterpolateNArguments* args);
 /* RTC_GEOMETRY_TYPE_INSTANCE, one level, one time step [ref: rtcore_geometry.h: rtcSetGeometryInstancedScene, rtcSetGeometryTransform, rtcGetGeometryTransform] */
 RTC_API void rtcSetGeometryInstancedScene(RTCGeometry geometry, RTCScene scene);
 RTC_API void rtcSetGeometryTransform(RTCGeometry geometry, unsigned int timeStep, enum RTCFormat format, const void* xfm);

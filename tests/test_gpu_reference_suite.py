@@ -530,3 +530,78 @@ def test_high_quality_presplit(api, dev, flags):
     same = (got["geomID"] == g["hits"]["geomID"]) & (got["primID"] == g["hits"]["primID"])
     assert same.mean() > 0.995 and np.allclose(got["tfar"][same], g["hits"]["tfar"][same], rtol=1e-4)
     s.release()
+
+
+def test_interpolate(api, dev):
+    """rtcInterpolate / rtcInterpolateN (tutorials/interpolation; InterpolateTrianglesTest verify.cpp:1385): vertex positions and a 5-float vertex attribute
+    of a triangle mesh and a quad mesh at hit points; P must be the point the ray hit (org + t dir), dPdu / dPdv the edges, second derivatives 0;
+    the N-variant writes SoA and honours the valid mask."""
+    L = api.load()
+    sv, st = W.triangle_sphere(np.zeros(3, np.float32), 1.0, 12)
+    k = 6
+    gy, gx = np.meshgrid(np.arange(k + 1, dtype=np.float32), np.arange(k + 1, dtype=np.float32), indexing="ij")
+    qv = np.stack([gx / k * 2 + 2, gy / k * 2 - 1, 0.3 * np.sin(gx + gy)], -1).reshape(-1, 3).astype(np.float32)
+    ii = (np.arange(k)[:, None] * (k + 1) + np.arange(k)[None, :]).ravel()
+    qq = np.stack([ii, ii + 1, ii + k + 2, ii + k + 1], -1).astype(np.uint32)
+    s = api.Scene(dev)
+    gt, gq = s.add_triangle_mesh(sv, st), s.add_quad_mesh(qv, qq)
+    attr = {gt: (np.arange(sv.shape[0] * 5, dtype=np.float32).reshape(-1, 5) * 0.25), gq: (np.cos(np.arange(qv.shape[0] * 5, dtype=np.float32)).reshape(-1, 5))}
+    keep = []
+    for gid, a in attr.items():
+        g = L.rtcGetGeometry(s.h, gid)
+        L.rtcSetGeometryVertexAttributeCount(g, 1)
+        pad = np.concatenate([a.ravel(), np.zeros(4, np.float32)]); keep.append(pad)
+        L.rtcSetSharedGeometryBuffer(g, api.RTC_BUFFER_TYPE_VERTEX_ATTRIBUTE, 0, 0x9005, pad.ctypes.data, 0, 20, a.shape[0])   # RTC_FORMAT_FLOAT5
+        L.rtcCommitGeometry(g)
+    dev.check()
+    s.commit()
+    rng = np.random.default_rng(9)
+    org = np.stack([rng.uniform(-1, 4, 4000), rng.uniform(-1, 1, 4000), np.full(4000, -5.0)], -1).astype(np.float32)
+    rh = make_rayhits(org, np.tile(np.array([[0.01, 0.02, 1]], np.float32), (4000, 1)))
+    s.intersect1M(rh)
+    hit = np.nonzero(rh["geomID"] != INVALID_ID)[0]
+    assert (rh["geomID"][hit] == gt).sum() > 300 and (rh["geomID"][hit] == gq).sum() > 300
+    verts = {gt: (sv, st), gq: (qv, qq)}
+    for i in hit[:600]:
+        gid, pid, u, v = int(rh["geomID"][i]), int(rh["primID"][i]), float(rh["u"][i]), float(rh["v"][i])
+        g = L.rtcGetGeometry(s.h, gid)
+        P, du, dv, z0, z1, z2 = (np.full(3, 7, np.float32) for _ in range(6))
+        a = api.RTCInterpolateArguments(g, pid, u, v, api.RTC_BUFFER_TYPE_VERTEX, 0, P.ctypes.data, du.ctypes.data, dv.ctypes.data, z0.ctypes.data, z1.ctypes.data, z2.ctypes.data, 3)
+        L.rtcInterpolate(C.byref(a))
+        want = np.array([rh["org_x"][i], rh["org_y"][i], rh["org_z"][i]]) + rh["tfar"][i] * np.array([rh["dir_x"][i], rh["dir_y"][i], rh["dir_z"][i]])
+        assert np.abs(P - want).max() < 2e-5, (gid, pid, P, want)
+        assert (z0 == 0).all() and (z1 == 0).all() and (z2 == 0).all()
+        vv, idx = verts[gid]
+        p = vv[idx[pid]]
+        if gid == gt or u + v <= 1.0:
+            assert np.allclose(du, p[1] - p[0], atol=1e-6) and np.allclose(dv, p[-1 if gid == gq else 2] - p[0], atol=1e-6)
+        A = np.zeros(5, np.float32)
+        a = api.RTCInterpolateArguments(g, pid, u, v, api.RTC_BUFFER_TYPE_VERTEX_ATTRIBUTE, 0, A.ctypes.data, None, None, None, None, None, 5)
+        L.rtcInterpolate(C.byref(a))
+        at = attr[gid][idx[pid]]
+        if gid == gt:
+            ref = (1 - u - v) * at[0] + u * at[1] + v * at[2]
+        elif u + v <= 1.0:
+            ref = (1 - u - v) * at[0] + u * at[1] + v * at[3]
+        else:
+            ref = (u + v - 1) * at[2] + (1 - u) * at[3] + (1 - v) * at[1]
+        assert np.allclose(A, ref, rtol=1e-5, atol=1e-5)
+    dev.check()
+    # N-variant on the triangle mesh: SoA outputs, masked entries untouched
+    sel = hit[rh["geomID"][hit] == gt][:64]
+    n = sel.shape[0]
+    valid = np.where(np.arange(n) % 5 == 0, 0, -1).astype(np.int32)
+    pids, uu, vv_ = rh["primID"][sel].copy(), rh["u"][sel].copy(), rh["v"][sel].copy()
+    P = np.full((3, n), 9, np.float32)
+    a = api.RTCInterpolateNArguments(L.rtcGetGeometry(s.h, gt), valid.ctypes.data, pids.ctypes.data, uu.ctypes.data, vv_.ctypes.data, n, api.RTC_BUFFER_TYPE_VERTEX, 0,
+                                     P.ctypes.data, None, None, None, None, None, 3)
+    L.rtcInterpolateN(C.byref(a))
+    dev.check()
+    want = np.stack([rh["org_x"][sel] + rh["tfar"][sel] * rh["dir_x"][sel], rh["org_y"][sel] + rh["tfar"][sel] * rh["dir_y"][sel], rh["org_z"][sel] + rh["tfar"][sel] * rh["dir_z"][sel]])
+    on = valid != 0
+    assert np.abs(P[:, on] - want[:, on]).max() < 2e-5 and (P[:, ~on] == 9).all()
+    # errors: bad slot, instance geometry
+    a = api.RTCInterpolateArguments(L.rtcGetGeometry(s.h, gt), 0, 0.1, 0.1, api.RTC_BUFFER_TYPE_VERTEX_ATTRIBUTE, 3, P.ctypes.data, None, None, None, None, None, 3)
+    L.rtcInterpolate(C.byref(a))
+    assert L.rtcGetDeviceError(dev.h) == 2                      # RTC_ERROR_INVALID_ARGUMENT
+    s.release()
