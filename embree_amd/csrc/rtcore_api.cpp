@@ -400,12 +400,12 @@ RTC_API ssize_t rtcGetDeviceProperty(RTCDevice h, enum RTCDeviceProperty prop) {
     case RTC_DEVICE_PROPERTY_NATIVE_RAY4_SUPPORTED: case RTC_DEVICE_PROPERTY_NATIVE_RAY8_SUPPORTED:
     case RTC_DEVICE_PROPERTY_NATIVE_RAY16_SUPPORTED: return 1;
     case RTC_DEVICE_PROPERTY_RAY_MASK_SUPPORTED: return 1;
-    case RTC_DEVICE_PROPERTY_TRIANGLE_GEOMETRY_SUPPORTED: return 1;
+    case RTC_DEVICE_PROPERTY_TRIANGLE_GEOMETRY_SUPPORTED: case RTC_DEVICE_PROPERTY_QUAD_GEOMETRY_SUPPORTED: return 1;
     case RTC_DEVICE_PROPERTY_HIP_DEVICE: return 1;
     case RTC_DEVICE_PROPERTY_BACKFACE_CULLING_ENABLED: case RTC_DEVICE_PROPERTY_BACKFACE_CULLING_CURVES_ENABLED:
     case RTC_DEVICE_PROPERTY_BACKFACE_CULLING_SPHERES_ENABLED: case RTC_DEVICE_PROPERTY_FILTER_FUNCTION_SUPPORTED:
     case RTC_DEVICE_PROPERTY_IGNORE_INVALID_RAYS_ENABLED: case RTC_DEVICE_PROPERTY_COMPACT_POLYS_ENABLED:
-    case RTC_DEVICE_PROPERTY_QUAD_GEOMETRY_SUPPORTED: case RTC_DEVICE_PROPERTY_SUBDIVISION_GEOMETRY_SUPPORTED:
+    case RTC_DEVICE_PROPERTY_SUBDIVISION_GEOMETRY_SUPPORTED:
     case RTC_DEVICE_PROPERTY_CURVE_GEOMETRY_SUPPORTED: case RTC_DEVICE_PROPERTY_USER_GEOMETRY_SUPPORTED:
     case RTC_DEVICE_PROPERTY_POINT_GEOMETRY_SUPPORTED: case RTC_DEVICE_PROPERTY_TASKING_SYSTEM:
     case RTC_DEVICE_PROPERTY_JOIN_COMMIT_SUPPORTED: case RTC_DEVICE_PROPERTY_PARALLEL_COMMIT_SUPPORTED:
