@@ -1896,7 +1896,7 @@ static int refit_impl(Bvh* bvh, const mi355_mesh* meshes, uint32_t numMeshes, hi
   HIP_TRY(hipMemcpyAsync(rb, boxes.p, sizeof(rb), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
-  if (hflag) return MI355_REFIT_IMPOSSIBLE;
+  if (hflag) return MI355_REFIT_BROKEN;
   mi355_bvh_info& info = bvh->info;
   info.bounds_lower[0] = rb[0].x; info.bounds_lower[1] = rb[0].y; info.bounds_lower[2] = rb[0].z;
   info.bounds_upper[0] = rb[1].x; info.bounds_upper[1] = rb[1].y; info.bounds_upper[2] = rb[1].z;

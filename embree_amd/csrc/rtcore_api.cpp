@@ -251,10 +251,11 @@ struct Scene : RefCounted {
     }
     mi355_bvh_info info;
     bool done = false;
+    if (refit) { mi355_bvh_get_info(flat, &info); refit = info.bytes_refit != 0; }   // the tree was built to be refitted
     if (refit) {
       const int rc = mi355_bvh_refit(flat, meshes.data(), (uint32_t)meshes.size(), nullptr);
       if (rc == 0) done = true;
-      else { committed = false; if (rc != MI355_REFIT_IMPOSSIBLE) core_check(rc, "BVH refit"); }   // a refit that stopped half way leaves no usable tree
+      else if (rc != MI355_REFIT_IMPOSSIBLE) { committed = false; if (rc != MI355_REFIT_BROKEN) core_check(rc, "BVH refit"); }   // a refit that stopped half way leaves no usable tree
     }
     if (!done) {
       mi355_bvh_t nb = nullptr;

@@ -101,9 +101,11 @@ MI355_API int mi355_bvh_build_instanced(int device, mi355_bvh_t own, const mi355
 /* Refit (RTC_BUILD_QUALITY_REFIT; the reference: kernels/bvh/bvh_refit.cpp, BVHNRefitT): the vertices moved, the topology did not.
    `meshes` must list the same geometries (ids, primitive counts, types) in the same order as at the build; vertex pointers, strides and
    masks are taken anew.  Triangle records are rewritten and the node boxes recomputed bottom-up, in place; blocking.
-   Returns 0 on success; MI355_REFIT_IMPOSSIBLE when the tree was built without params.refit, the mesh list differs, the build had skipped
-   invalid triangles, or a triangle has become invalid -- the tree is then UNUSABLE and the caller must build again; other values: HIP errors. */
+   Returns 0 on success; MI355_REFIT_IMPOSSIBLE when the tree was built without params.refit, the mesh list differs or the build had skipped invalid
+   triangles (the tree is untouched); MI355_REFIT_BROKEN when a triangle has become invalid (the boxes are half rewritten: the tree is UNUSABLE and the
+   caller must build again); other values: HIP errors. */
 #define MI355_REFIT_IMPOSSIBLE (-2)
+#define MI355_REFIT_BROKEN (-3)
 MI355_API int mi355_bvh_refit(mi355_bvh_t bvh, const mi355_mesh* meshes, uint32_t num_meshes, void* stream);
 /* Build scratch (prim refs, binary tree, work lists) is kept per device between commits; this returns it to the driver. */
 MI355_API void mi355_release_build_scratch(int device);

@@ -399,8 +399,21 @@ def test_instances_vs_golden(api, dev, flags):
     assert (r["tfar"][~np.isneginf(r["tfar"])] == rays["tfar"][~np.isneginf(r["tfar"])]).all()
     lo, hi = top.bounds()
     assert (lo == g["bounds_lo"]).all() and (hi == g["bounds_hi"]).all()
-    # packets go through the same kernel: rtcIntersect8 on the first 64 rays
+    # packets go through the same kernel: rtcIntersect8 on eight rays that hit instances
     L = api.load()
+    from embree_amd.rtypes import RAYHIT_DTYPE
+    sel = np.nonzero(want["instID"] != INVALID_ID)[0][:8]
+    fields = list(RAYHIT_DTYPE.names[:21])
+    raw = np.zeros(21 * 8 + 16, np.uint32)
+    ofs = (-raw.ctypes.data % 32) // 4
+    pk = raw[ofs:ofs + 21 * 8].reshape(21, 8)
+    for fi, f in enumerate(fields):
+        pk[fi] = rays[sel][f].view(np.uint32)
+    valid = np.full(8, -1, np.int32)
+    L.rtcIntersect8(valid.ctypes.data, top.h, pk.ctypes.data, None)
+    dev.check()
+    for fi, f in enumerate(fields):
+        assert (pk[fi] == got[sel][f].view(np.uint32)).all(), "rtcIntersect8 on an instanced scene: " + f
     # the object scenes may be released: the committed top scene holds its own copy of their trees
     for o in objs:
         o.release()
