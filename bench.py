@@ -135,7 +135,16 @@ def main():
     if world > 1:
         import torch.distributed as dist_mod              # host-side rendezvous only (gloo); the HIP library is already bound
         import torch
-        dist_mod.init_process_group("gloo", rank=rank, world_size=world)
+        # Gloo announces its connections on the C-level stdout: keep stdout for the one JSON line (fd 1 -> stderr while the group forms)
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist_mod.init_process_group("gloo", rank=rank, world_size=world)
+            dist_mod.barrier()
+        finally:
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
         dist = (dist_mod, torch)
 
     # ---- scene: replicated BVH, geometry resident on the device
