@@ -45,6 +45,7 @@ struct Device : RefCounted {
   int gpu = 0;
   int verbose = 0;
   bool benchmark = false;
+  unsigned pipelineMin = 262144, pipelineChunk = 131072;   // host-array queries of at least pipelineMin rays are cut into chunks of pipelineChunk rays (config keys host_pipeline_min / host_pipeline_chunk)
   mi355_build_params build;
   RTCErrorFunction errorFn = nullptr; void* errorFnPtr = nullptr;
   RTCMemoryMonitorFunction memFn = nullptr; void* memFnPtr = nullptr;
@@ -187,6 +188,7 @@ struct Scene : RefCounted {
   RTCBounds bounds;
   RTCProgressMonitorFunction progress = nullptr; void* progressPtr = nullptr;
   // host-pointer query staging (device memory), one per calling thread
+  hipStream_t pipe[2] = {nullptr, nullptr};                 // large host-array queries: two streams that alternate chunks (pipelined_query)
   struct Staging { char* d = nullptr; size_t cap = 0; };
   std::map<size_t, Staging> staging;
   Scene(Device* d) : device(d) { d->retain(); setEmptyBounds(); }
@@ -200,6 +202,7 @@ struct Scene : RefCounted {
     if (bvh && bvh != flat) { mi355_bvh_destroy(bvh); device->memoryMonitor(-bvhBytes, true); }
     if (flat) { mi355_bvh_destroy(flat); device->memoryMonitor(-flatBytes, true); }
     for (auto& kv : staging) if (kv.second.d) hipFree(kv.second.d);
+    for (int k = 0; k < 2; k++) if (pipe[k]) hipStreamDestroy(pipe[k]);
     device->release();
   }
   char* stage(size_t bytes) {
@@ -328,6 +331,8 @@ void parse_config(Device* d, const char* cfg) {
     else if (k == "small_threshold") d->build.small_threshold = (uint32_t)atoi(v.c_str());
     else if (k == "quality") d->build.quality = (v == "low" || v == "1") ? 1u : (v == "high" || v == "2") ? 2u : 0u;
     else if (k == "max_spatial_split_replications") d->build.split_factor = (float)atof(v.c_str());   // state.cpp:437
+    else if (k == "host_pipeline_min") d->pipelineMin = (unsigned)atol(v.c_str());
+    else if (k == "host_pipeline_chunk") d->pipelineChunk = atol(v.c_str()) >= 1024 ? (unsigned)atol(v.c_str()) : 1024u;
     else if (k == "int_cost") d->build.int_cost = (float)atof(v.c_str());
     else if (k == "trav_cost") d->build.trav_cost = (float)atof(v.c_str());
     // CPU-only keys of the reference (threads, isa, tri_accel, hugepages, ...) are accepted and ignored
@@ -342,6 +347,31 @@ mi355_bvh_t committed_bvh(Scene* s) {
   return s->bvh;
 }
 
+// Large host arrays: the caller's array is pinned for the duration of the call and cut into chunks that alternate between two streams, so that the upload
+// of one chunk, the traversal of the previous one and the download of the one before overlap (PCIe is full duplex; pageable copies would serialise).
+// Returns false when the array cannot be pinned (the plain path takes over).
+static bool pipelined_query(Scene* s, mi355_bvh_t b, char* data, char* d, unsigned M, size_t stride, bool any, size_t bytes) {
+  if (hipHostRegister(data, bytes, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); return false; }
+  struct Unpin { void* p; ~Unpin() { hipHostUnregister(p); } } unpin{data};
+  hipStream_t st[2];
+  { std::lock_guard<std::mutex> lk(s->mtx);
+    for (int k = 0; k < 2; k++) if (!s->pipe[k]) hip_check(hipStreamCreateWithFlags(&s->pipe[k], hipStreamNonBlocking), "hipStreamCreate");
+    st[0] = s->pipe[0]; st[1] = s->pipe[1]; }
+  const size_t rec = any ? 48 : 96;
+  const unsigned chunk = s->device->pipelineChunk;
+  unsigned c = 0;
+  for (unsigned first = 0; first < M; first += chunk, c++) {
+    const unsigned n = M - first < chunk ? M - first : chunk;
+    const size_t ofs = (size_t)first * stride, nb = (size_t)(n - 1) * stride + rec;
+    hipStream_t q = st[c & 1];
+    hip_check(hipMemcpyAsync(d + ofs, data + ofs, nb, hipMemcpyHostToDevice, q), "hipMemcpyAsync(rays H2D)");
+    core_check(any ? mi355_trace_any(b, d + ofs, n, stride, q) : mi355_trace_closest(b, d + ofs, n, stride, q), "trace");
+    hip_check(hipMemcpyAsync(data + ofs, d + ofs, nb, hipMemcpyDeviceToHost, q), "hipMemcpyAsync(rays D2H)");
+  }
+  hip_check(hipStreamSynchronize(st[0]), "hipStreamSynchronize"); hip_check(hipStreamSynchronize(st[1]), "hipStreamSynchronize");
+  return true;
+}
+
 // host-pointer AoS query: upload, trace, download the mutable parts
 void host_query(Scene* s, void* data, unsigned M, size_t stride, bool any) {
   if (M == 0) return;
@@ -353,6 +383,7 @@ void host_query(Scene* s, void* data, unsigned M, size_t stride, bool any) {
   if (repack) THROW(RTC_ERROR_INVALID_ARGUMENT, "ray records must be 16-byte aligned (include/embree4/rtcore.h)");
   const size_t bytes = (size_t)(M - 1) * stride + rec;
   char* d = s->stage(bytes);
+  if (M >= s->device->pipelineMin && pipelined_query(s, b, (char*)data, d, M, stride, any, bytes)) return;
   hip_check(hipMemcpy(d, data, bytes, hipMemcpyHostToDevice), "hipMemcpy(rays H2D)");
   core_check(any ? mi355_trace_any(b, d, M, stride, nullptr) : mi355_trace_closest(b, d, M, stride, nullptr), "trace");
   hip_check(hipMemcpy(data, d, bytes, hipMemcpyDeviceToHost), "hipMemcpy(rays D2H)");

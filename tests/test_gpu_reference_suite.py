@@ -618,3 +618,33 @@ def test_interpolate(api, dev):
     L.rtcInterpolate(C.byref(a))
     assert L.rtcGetDeviceError(dev.h) == 2                      # RTC_ERROR_INVALID_ARGUMENT
     s.release()
+
+
+def test_large_host_arrays_take_the_pipelined_path(api):
+    """rtcIntersect1M / rtcOccluded1M on host arrays of >= host_pipeline_min rays: the array is pinned for the call and cut into chunks on two streams.
+    Same answers as one device-resident launch (ragged last chunk, 3 chunk sizes, a strided RTCRayHit array), and the array is left unpinned."""
+    L = api.load()
+    meshes = W.synthetic_crown(num_phi=20)
+    rays = W.incoherent_rays(300001, [2, 2, 1.5], seed=4)
+    ref_dev = api.Device("host_pipeline_min=4000000000")
+    s0 = api.make_scene(ref_dev, meshes)
+    want = rays.copy(); s0.intersect1M(want)
+    wo = rays_of(rays); s0.occluded1M(wo)
+    s0.release(); ref_dev.release()
+    for chunk in (1024, 65536, 131072):
+        d = api.Device("host_pipeline_min=100000,host_pipeline_chunk=%d" % chunk)
+        s = api.make_scene(d, meshes)
+        got = rays.copy(); s.intersect1M(got)
+        assert got.tobytes() == want.tobytes(), chunk
+        go = rays_of(rays); s.occluded1M(go)
+        assert go.tobytes() == wo.tobytes(), chunk
+        # byteStride 128: records 128 bytes apart inside a larger array (the gaps must come back untouched)
+        wide = np.zeros((rays.shape[0], 32), np.uint32)
+        wide[:, :24] = rays.view(np.uint32).reshape(-1, 24)
+        wide[:, 24:] = 0xABCD1234
+        L.rtcIntersect1M(s.h, wide.ctypes.data, rays.shape[0], 128, None)
+        d.check()
+        assert wide[:, :24].tobytes() == want.tobytes() and (wide[:, 24:] == 0xABCD1234).all()
+        got2 = rays.copy(); s.intersect1M(got2)                 # the same array again: it was unpinned, pinning it again must work
+        assert got2.tobytes() == want.tobytes()
+        s.release(); d.release()
