@@ -372,6 +372,9 @@ __global__ __launch_bounds__(256) void presplit_emit(PrimRef* prims, uint32_t n,
   presplit_walk<true>(r, want, v, g, prims + i, prims + off);
 }
 __global__ __launch_bounds__(256) void centroid_bounds(const PrimRef* prims, uint32_t n, Counters* ctr) {
+  __shared__ uint32_t s_acc[6];                                  // one global atomic per block and word: same-address atomics from every wave cost 0.4 ms here
+  if (threadIdx.x < 6u) s_acc[threadIdx.x] = threadIdx.x < 3u ? 0xFFFFFFFFu : 0u;
+  __syncthreads();
   uint32_t acc[6]; for (int k = 0; k < 6; k++) acc[k] = k < 3 ? 0xFFFFFFFFu : 0u;
   for (uint32_t p = blockIdx.x * 256u + threadIdx.x; p < n; p += gridDim.x * 256u) {
     const PrimRef r = load_prim(prims + p);
@@ -379,8 +382,10 @@ __global__ __launch_bounds__(256) void centroid_bounds(const PrimRef* prims, uin
   }
   for (int k = 0; k < 6; k++) {
     const uint32_t x = k < 3 ? wave_umin63(acc[k]) : wave_umax63(acc[k]);
-    if ((threadIdx.x & 63u) == 63u) { if (k < 3) atomicMin(&ctr->bounds[6 + k], x); else atomicMax(&ctr->bounds[6 + k], x); }
+    if ((threadIdx.x & 63u) == 63u) { if (k < 3) atomicMin(&s_acc[k], x); else atomicMax(&s_acc[k], x); }
   }
+  __syncthreads();
+  if (threadIdx.x < 6u) { if (threadIdx.x < 3u) atomicMin(&ctr->bounds[6 + threadIdx.x], s_acc[threadIdx.x]); else atomicMax(&ctr->bounds[6 + threadIdx.x], s_acc[threadIdx.x]); }
 }
 
 // -------------------------------------------------------------------------------- binning helpers
@@ -1719,7 +1724,7 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
       n += extra;
       Counters hb = h; for (int k = 6; k < 12; k++) hb.bounds[k] = (k < 9) ? ENC_POS_INF : ENC_NEG_INF;
       HIP_TRY(hipMemcpyAsync(ctr.p, &hb, sizeof(hb), hipMemcpyHostToDevice, st));
-      const uint32_t cb = (n + 255u) / 256u < 2048u ? (n + 255u) / 256u : 2048u;
+      const uint32_t cb = (n + 255u) / 256u < 1024u ? (n + 255u) / 256u : 1024u;
       hipLaunchKernelGGL(centroid_bounds, dim3(cb), dim3(256), 0, st, bufA.p, n, ctr.p);
       HIP_TRY(hipGetLastError());
       HIP_TRY(hipMemcpyAsync(&hb, ctr.p, sizeof(hb), hipMemcpyDeviceToHost, st)); HIP_TRY(hipStreamSynchronize(st));
