@@ -648,3 +648,65 @@ def test_large_host_arrays_take_the_pipelined_path(api):
         got2 = rays.copy(); s.intersect1M(got2)                 # the same array again: it was unpinned, pinning it again must work
         assert got2.tobytes() == want.tobytes()
         s.release(); d.release()
+
+
+def test_host_device_buffer_calls_and_scene_getters(api, dev):
+    """Embree 4.4's host/device buffer API on this library's device copies (rtcore_buffer.h:42-65, rtcore_geometry.h:175-189): rtcNewBufferHostDevice +
+    rtcCommitBuffer + rtcGetBufferDataDevice, rtcSetNewGeometryBufferHostDevice, rtcGetGeometryBufferDataDevice; rtcGetGeometryUserDataFromScene and
+    rtcGetGeometryTransformFromScene; entry points outside the path record RTC_ERROR_INVALID_OPERATION instead of failing to link."""
+    L = api.load()
+    vp = C.c_void_p
+    L.rtcNewBufferHostDevice.restype = vp; L.rtcNewBufferHostDevice.argtypes = [vp, C.c_size_t]
+    L.rtcGetBufferData.restype = vp; L.rtcGetBufferData.argtypes = [vp]
+    L.rtcGetBufferDataDevice.restype = vp; L.rtcGetBufferDataDevice.argtypes = [vp]
+    L.rtcCommitBuffer.argtypes = [vp]; L.rtcReleaseBuffer.argtypes = [vp]
+    L.rtcSetGeometryBuffer.argtypes = [vp, C.c_int, C.c_uint, C.c_int, vp, C.c_size_t, C.c_size_t, C.c_size_t]
+    L.rtcSetNewGeometryBufferHostDevice.argtypes = [vp, C.c_int, C.c_uint, C.c_int, C.c_size_t, C.c_size_t, C.POINTER(vp), C.POINTER(vp)]
+    L.rtcGetGeometryBufferDataDevice.restype = vp; L.rtcGetGeometryBufferDataDevice.argtypes = [vp, C.c_int, C.c_uint]
+    L.rtcGetGeometryUserDataFromScene.restype = vp; L.rtcGetGeometryUserDataFromScene.argtypes = [vp, C.c_uint]
+    L.rtcGetGeometryTransformFromScene.argtypes = [vp, C.c_uint, C.c_float, C.c_int, vp]
+    L.rtcSetGeometryUserData.argtypes = [vp, vp]
+    v, t = W.triangle_sphere(np.zeros(3, np.float32), 1.0, 8)
+    # vertex buffer: an RTCBuffer created host/device, filled on the host, committed, bound to the geometry
+    vb = L.rtcNewBufferHostDevice(dev.h, v.nbytes + 16)
+    C.memmove(L.rtcGetBufferData(vb), v.ctypes.data, v.nbytes)
+    L.rtcCommitBuffer(vb)
+    dptr = L.rtcGetBufferDataDevice(vb)
+    assert dptr
+    back = np.zeros_like(v)
+    assert L.mi355_memcpy_d2h(back.ctypes.data, dptr, v.nbytes) == 0 and (back == v).all()
+    g = L.rtcNewGeometry(dev.h, api.RTC_GEOMETRY_TYPE_TRIANGLE)
+    L.rtcSetGeometryBuffer(g, api.RTC_BUFFER_TYPE_VERTEX, 0, api.RTC_FORMAT_FLOAT3, vb, 0, 12, v.shape[0])
+    L.rtcReleaseBuffer(vb)
+    # index buffer: host and device pointer handed out together
+    hp, dp = vp(), vp()
+    L.rtcSetNewGeometryBufferHostDevice(g, api.RTC_BUFFER_TYPE_INDEX, 0, api.RTC_FORMAT_UINT3, 12, t.shape[0], C.byref(hp), C.byref(dp))
+    dev.check()
+    assert hp.value and dp.value
+    C.memmove(hp.value, t.ctypes.data, t.nbytes)
+    L.rtcSetGeometryUserData(g, 0x1234)
+    L.rtcCommitGeometry(g)
+    assert L.rtcGetGeometryBufferDataDevice(g, api.RTC_BUFFER_TYPE_INDEX, 0) == dp.value
+    tb = np.zeros_like(t)
+    assert L.mi355_memcpy_d2h(tb.ctypes.data, dp.value, t.nbytes) == 0 and (tb == t).all()      # rtcCommitGeometry brought the indices over
+    s = api.Scene(dev)
+    gid = L.rtcAttachGeometry(s.h, g)
+    L.rtcReleaseGeometry(g)
+    obj = api.Scene(dev); obj.add_triangle_mesh(v, t); obj.commit()
+    x = np.array([2, 0, 0, 0, 2, 0, 0, 0, 2, 5, 0, 0], np.float32)
+    iid = s.add_instance(obj, x)
+    s.commit()
+    assert L.rtcGetGeometryUserDataFromScene(s.h, gid) == 0x1234
+    out = np.zeros(12, np.float32)
+    L.rtcGetGeometryTransformFromScene(s.h, iid, 0.0, api.RTC_FORMAT_FLOAT3X4_COLUMN_MAJOR, out.ctypes.data)
+    assert (out == x).all()
+    rh = make_rayhits([[0, 0, -4], [5, 0, -4]], [[0, 0, 1]] * 2)
+    s.intersect1M(rh)
+    assert rh["geomID"][0] == gid and rh["instID"][0] == INVALID_ID and abs(rh["tfar"][0] - 3.0) < 1e-3
+    assert rh["instID"][1] == iid and abs(rh["tfar"][1] - 2.0) < 1e-3
+    dev.check()
+    for name in ("rtcForwardIntersect1", "rtcSetGeometryTransformQuaternion", "rtcNewBVH", "rtcPointQuery4"):
+        getattr(L, name).restype = vp
+        getattr(L, name)(None, None, None, None)
+        assert L.rtcGetDeviceError(None) == 3, name              # RTC_ERROR_INVALID_OPERATION, recorded for the calling thread (no device in these calls)
+    s.release(); obj.release()
