@@ -1,0 +1,251 @@
+// build_binning.inl -- bin mapping, binning helpers (rows / runs), SAH sweep of one wavefront.
+// Part of build.hip (included inside its anonymous namespace); see the header of build.hip for the pipeline.
+// -------------------------------------------------------------------------------- binning helpers
+struct Mapping { float ofs[3], scale[3]; uint32_t nb; };
+// BinMapping(pinfo): num = min(32, 4 + 0.05 n), scale = 0.99 num / diag (0 if diag <= 1e-34)  heuristic_binning.h:46-55
+__device__ __forceinline__ Mapping make_mapping(uint32_t n, const float* cmin, const float* cmax) {
+  Mapping m; const uint32_t num = (uint32_t)(4.0f + 0.05f * (float)n); m.nb = num < (uint32_t)NBINS ? num : (uint32_t)NBINS;
+  for (int d = 0; d < 3; d++) {
+    const float diag = fmaxf(1E-34f, cmax[d] - cmin[d]);
+    m.scale[d] = diag > 1E-34f ? (0.99f * (float)m.nb) / diag : 0.0f;
+    m.ofs[d] = cmin[d];
+  }
+  return m;
+}
+__device__ __forceinline__ int bin_unsafe(float c2, float ofs, float scale) { return (int)floorf((c2 - ofs) * scale); }
+__device__ __forceinline__ int bin_clamped(float c2, float ofs, float scale, uint32_t nb) {
+  int i = bin_unsafe(c2, ofs, scale); i = i < 0 ? 0 : i; return i > (int)nb - 1 ? (int)nb - 1 : i;
+}
+__device__ __forceinline__ void bins_clear(uint32_t* bins, uint32_t tid, uint32_t nthreads) {
+  for (uint32_t w = tid; w < (uint32_t)BINS_WORDS; w += nthreads) { const uint32_t k = w % BINW; bins[w] = k < 3 ? ENC_POS_INF : (k < 6 ? ENC_NEG_INF : 0u); }
+}
+
+__device__ __forceinline__ uint32_t wave_uadd63(uint32_t v) {
+  v += dpp_u<0xB1, 0xF>(0u, v); v += dpp_u<0x4E, 0xF>(0u, v); v += dpp_u<0x114, 0xF>(0u, v);
+  v += dpp_u<0x118, 0xF>(0u, v); v += dpp_u<0x142, 0xA>(0u, v); v += dpp_u<0x143, 0xC>(0u, v);
+  return v;
+}
+
+// BinInfoT::bin (heuristic_binning.h:210-257) with run merging in front of the bins.  Same-word LDS atomics are what the binning
+// kernels wait for (PMC: SQ_WAIT_INST_LDS = 73 % of top_bin's wave cycles with one atomic per triangle, profiles/r01_build_history.md).
+// A batch of 64 consecutive triangles of a mesh almost always falls into ONE bin per axis, so the wave keeps a current bin per axis
+// (uniform) and every lane a private partial (bounds + count) of it in registers; only when the wave's bin changes, or at the end
+// of the span, the partials are folded across the wave with DPP and lane 63 issues the run's 7 atomics.  Lanes of a batch that
+// straddles bins and are not in the wave's bin go to the LDS bins directly.
+struct BinRuns { int b[3]; uint32_t lo[3][3], hi[3][3], n[3]; };   // b: the WAVE's current bin per axis (uniform); the rest: this lane's partial of that bin
+__device__ __forceinline__ void runs_init(BinRuns& r) { for (int d = 0; d < 3; d++) { r.b[d] = -1; r.n[d] = 0u; for (int k = 0; k < 3; k++) { r.lo[d][k] = 0xFFFFFFFFu; r.hi[d][k] = 0u; } } }
+// fold the lanes' partials of axis d across the wave (DPP), lane 63 issues the 7 atomics of the run
+__device__ __forceinline__ void runs_flush_axis(BinRuns& r, int d, uint32_t* bins, uint32_t lane) {
+  if (r.b[d] >= 0) {                                            // wave-uniform
+    uint32_t v[6];
+    for (int k = 0; k < 3; k++) { v[k] = wave_umin63(r.lo[d][k]); v[3 + k] = wave_umax63(r.hi[d][k]); }
+    const uint32_t cnt = wave_uadd63(r.n[d]);
+    if (lane == 63u && cnt) {
+      uint32_t* e = bins + (d * NBINS + r.b[d]) * BINW;
+      atomicMin(&e[0], v[0]); atomicMin(&e[1], v[1]); atomicMin(&e[2], v[2]);
+      atomicMax(&e[3], v[3]); atomicMax(&e[4], v[4]); atomicMax(&e[5], v[5]);
+      atomicAdd(&e[6], cnt);
+    }
+  }
+  r.n[d] = 0u; for (int k = 0; k < 3; k++) { r.lo[d][k] = 0xFFFFFFFFu; r.hi[d][k] = 0u; }
+}
+// every lane of the wave calls it with its triangle of the batch (valid = holds one)
+__device__ __forceinline__ void runs_add(BinRuns& r, uint32_t* bins, const Mapping& m, const PrimRef& p, bool valid, uint32_t lane) {
+  const unsigned long long vm = __ballot(valid);
+  if (vm == 0ull) return;
+  const int first = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(vm));
+  uint32_t c[6];
+  for (int k = 0; k < 3; k++) { c[k] = enc(p.lo[k]); c[3 + k] = enc(p.hi[k]); }
+#pragma unroll
+  for (int d = 0; d < 3; d++) {
+    const int b = valid ? bin_clamped(p.lo[d] + p.hi[d], m.ofs[d], m.scale[d], m.nb) : -1;
+    const int b0 = __builtin_amdgcn_readlane(b, first);
+    const bool uniform = __ballot(valid && b == b0) == vm;      // the usual case: 64 consecutive triangles, one bin
+    if (uniform && b0 != r.b[d]) { runs_flush_axis(r, d, bins, lane); r.b[d] = b0; }
+    if (valid) {
+      if (b == r.b[d]) {                                        // into my partial of the wave's bin: registers only
+        r.n[d]++;
+        for (int k = 0; k < 3; k++) { r.lo[d][k] = min(r.lo[d][k], c[k]); r.hi[d][k] = max(r.hi[d][k], c[3 + k]); }
+      } else {                                                  // the batch straddles bins: this lane goes to the LDS bins directly
+        uint32_t* e = bins + (d * NBINS + b) * BINW;
+        atomicMin(&e[0], c[0]); atomicMin(&e[1], c[1]); atomicMin(&e[2], c[2]);
+        atomicMax(&e[3], c[3]); atomicMax(&e[4], c[4]); atomicMax(&e[5], c[5]);
+        atomicAdd(&e[6], 1u);
+      }
+    }
+  }
+}
+__device__ __forceinline__ void runs_flush_wave(BinRuns& r, uint32_t* bins, uint32_t lane) {
+  for (int d = 0; d < 3; d++) runs_flush_axis(r, d, bins, lane);
+}
+
+// Lane-private variant for top_bin: a lane sees triangles i, i + 64, ... of its wave's span and keeps its OWN current bin per axis; a run
+// ends with 7 LDS atomics of that lane, what is pending at the end of the span is folded across the wave.  Measured on the full-size
+// passes of top_bin: 110 us against 129 us for the wave-uniform runs above (batches straddling a bin boundary send most lanes to the LDS
+// bins there), while the wave-uniform runs are the faster ones inside small_build (2.65 against 2.85 ms).
+struct LaneRuns { int b[3]; uint32_t lo[3][3], hi[3][3], n[3]; };
+__device__ __forceinline__ void lane_runs_init(LaneRuns& r) { for (int d = 0; d < 3; d++) { r.b[d] = -1; r.n[d] = 0u; for (int k = 0; k < 3; k++) { r.lo[d][k] = 0xFFFFFFFFu; r.hi[d][k] = 0u; } } }
+__device__ __forceinline__ void lane_runs_add(LaneRuns& r, uint32_t* bins, const Mapping& m, const PrimRef& p, bool valid) {
+  if (!valid) return;
+  uint32_t c[6];
+  for (int k = 0; k < 3; k++) { c[k] = enc(p.lo[k]); c[3 + k] = enc(p.hi[k]); }
+#pragma unroll
+  for (int d = 0; d < 3; d++) {
+    const int b = bin_clamped(p.lo[d] + p.hi[d], m.ofs[d], m.scale[d], m.nb);
+    if (b != r.b[d]) {
+      if (r.n[d]) {                                             // the run ends: its 7 atomics
+        uint32_t* e = bins + (d * NBINS + r.b[d]) * BINW;
+        atomicMin(&e[0], r.lo[d][0]); atomicMin(&e[1], r.lo[d][1]); atomicMin(&e[2], r.lo[d][2]);
+        atomicMax(&e[3], r.hi[d][0]); atomicMax(&e[4], r.hi[d][1]); atomicMax(&e[5], r.hi[d][2]);
+        atomicAdd(&e[6], r.n[d]);
+      }
+      r.b[d] = b; r.n[d] = 1u;
+      for (int k = 0; k < 3; k++) { r.lo[d][k] = c[k]; r.hi[d][k] = c[3 + k]; }
+    } else {
+      r.n[d]++;
+      for (int k = 0; k < 3; k++) { r.lo[d][k] = min(r.lo[d][k], c[k]); r.hi[d][k] = max(r.hi[d][k], c[3 + k]); }
+    }
+  }
+}
+// every lane of the wave calls it: the pending runs of the lanes that share a bin are reduced in registers, lane 63 issues the atomics
+__device__ __forceinline__ void lane_runs_flush_wave(LaneRuns& r, uint32_t* bins, uint32_t lane) {
+#pragma unroll
+  for (int d = 0; d < 3; d++) {
+    int b = r.n[d] ? r.b[d] : -1;
+    unsigned long long rem = __ballot(b >= 0);
+    for (int round = 0; round < 3; round++) {
+      if (__popcll(rem) < 8) break;
+      const int b0 = __builtin_amdgcn_readlane(b, __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(rem)));
+      const bool mt = b == b0;
+      const unsigned long long mm = __ballot(mt);
+      if (__popcll(mm) < 4) break;
+      uint32_t v[6];
+      for (int k = 0; k < 3; k++) { v[k] = wave_umin63(mt ? r.lo[d][k] : 0xFFFFFFFFu); v[3 + k] = wave_umax63(mt ? r.hi[d][k] : 0u); }
+      const uint32_t cnt = wave_uadd63(mt ? r.n[d] : 0u);
+      if (lane == 63u) {
+        uint32_t* e = bins + (d * NBINS + b0) * BINW;
+        atomicMin(&e[0], v[0]); atomicMin(&e[1], v[1]); atomicMin(&e[2], v[2]);
+        atomicMax(&e[3], v[3]); atomicMax(&e[4], v[4]); atomicMax(&e[5], v[5]);
+        atomicAdd(&e[6], cnt);
+      }
+      if (mt) b = -1;
+      rem &= ~mm;
+    }
+    if (b >= 0) {
+      uint32_t* e = bins + (d * NBINS + b) * BINW;
+      atomicMin(&e[0], r.lo[d][0]); atomicMin(&e[1], r.lo[d][1]); atomicMin(&e[2], r.lo[d][2]);
+      atomicMax(&e[3], r.hi[d][0]); atomicMax(&e[4], r.hi[d][1]); atomicMax(&e[5], r.hi[d][2]);
+      atomicAdd(&e[6], r.n[d]);
+    }
+  }
+}
+
+// Row aggregation for top_bin: the 16 lanes of a DPP row hold 16 consecutive triangles, which sit in one bin per axis or straddle ONE bin
+// boundary (measured with cycle counters on the crown stand-in: consecutive triangles march along a ring of a sphere, 16 of them cover
+// about one bin width, so "everything in one bin" is the exception there).  A row therefore forms two groups, the lanes in its lowest and
+// in its highest bin, reduces each with four row_shr steps (result in lane 15 of the row) and that lane issues 7 atomics per group;
+// a lane strictly between the two, and rows holding the end of the chunk, go lane by lane.  At most 4 x 14 instead of 64 x 7 same-word
+// LDS atomics per axis and batch -- the atomics are what top_bin waits for (PMC: SQ_WAIT_INST_LDS 73 % of the wave cycles).
+__device__ __forceinline__ uint32_t row_umin15(uint32_t v) {
+  v = min(v, dpp_u<0x111, 0xF>(v, v)); v = min(v, dpp_u<0x112, 0xF>(v, v)); v = min(v, dpp_u<0x114, 0xF>(v, v)); v = min(v, dpp_u<0x118, 0xF>(v, v));
+  return v;
+}
+__device__ __forceinline__ uint32_t row_umax15(uint32_t v) {
+  v = max(v, dpp_u<0x111, 0xF>(v, v)); v = max(v, dpp_u<0x112, 0xF>(v, v)); v = max(v, dpp_u<0x114, 0xF>(v, v)); v = max(v, dpp_u<0x118, 0xF>(v, v));
+  return v;
+}
+__device__ __forceinline__ void bins_add_rows(uint32_t* bins, const Mapping& m, const PrimRef& p, bool valid, uint32_t lane) {
+  uint32_t c[6];
+  for (int k = 0; k < 3; k++) { c[k] = enc(p.lo[k]); c[3 + k] = enc(p.hi[k]); }
+  const unsigned long long vm = __ballot(valid);
+  const uint32_t rowBase = lane & 48u;
+  const bool rowFull = ((vm >> rowBase) & 0xFFFFull) == 0xFFFFull;          // all 16 lanes of my row hold a triangle
+#pragma unroll
+  for (int d = 0; d < 3; d++) {
+    const uint32_t b = valid ? (uint32_t)bin_clamped(p.lo[d] + p.hi[d], m.ofs[d], m.scale[d], m.nb) : 0u;
+    // the row's lowest and highest bin (lane 15 holds the reduction; everybody reads it from there)
+    const uint32_t bmin = (uint32_t)__shfl((int)row_umin15(b), (int)(lane | 15u), 64), bmax = (uint32_t)__shfl((int)row_umax15(b), (int)(lane | 15u), 64);
+    const bool inLo = rowFull && b == bmin, inHi = rowFull && b == bmax && bmax != bmin;
+    // 16 consecutive triangles sit in one bin or straddle one boundary: two groups cover the row; a lane strictly between goes alone
+    uint32_t lo[6], hi[6];
+    for (int k = 0; k < 3; k++) {
+      lo[k] = row_umin15(inLo ? c[k] : 0xFFFFFFFFu); lo[3 + k] = row_umax15(inLo ? c[3 + k] : 0u);
+      hi[k] = row_umin15(inHi ? c[k] : 0xFFFFFFFFu); hi[3 + k] = row_umax15(inHi ? c[3 + k] : 0u);
+    }
+    const uint32_t nLo = (uint32_t)__popcll((__ballot(inLo) >> rowBase) & 0xFFFFull), nHi = (uint32_t)__popcll((__ballot(inHi) >> rowBase) & 0xFFFFull);
+    if ((lane & 15u) == 15u && rowFull) {
+      uint32_t* e = bins + (d * NBINS + bmin) * BINW;
+      atomicMin(&e[0], lo[0]); atomicMin(&e[1], lo[1]); atomicMin(&e[2], lo[2]);
+      atomicMax(&e[3], lo[3]); atomicMax(&e[4], lo[4]); atomicMax(&e[5], lo[5]);
+      atomicAdd(&e[6], nLo);
+      if (nHi) {
+        uint32_t* f = bins + (d * NBINS + bmax) * BINW;
+        atomicMin(&f[0], hi[0]); atomicMin(&f[1], hi[1]); atomicMin(&f[2], hi[2]);
+        atomicMax(&f[3], hi[3]); atomicMax(&f[4], hi[4]); atomicMax(&f[5], hi[5]);
+        atomicAdd(&f[6], nHi);
+      }
+    }
+    if (valid && !inLo && !inHi) {
+      uint32_t* e = bins + (d * NBINS + b) * BINW;
+      atomicMin(&e[0], c[0]); atomicMin(&e[1], c[1]); atomicMin(&e[2], c[2]);
+      atomicMax(&e[3], c[3]); atomicMax(&e[4], c[4]); atomicMax(&e[5], c[5]);
+      atomicAdd(&e[6], 1u);
+    }
+  }
+}
+
+struct SplitResult { float sah; int dim, pos; uint32_t nL; float llo[3], lhi[3], rlo[3], rhi[3]; };
+
+// BinInfoT::best (heuristic_binning.h:339-386) by ONE wavefront as two scans: lanes 0-31 hold the 32 bins of one axis, lanes
+// 32-63 those of the next (second pass: the third axis).  An inclusive prefix scan gives "everything left of the plane", a
+// suffix scan "everything right of it"; lane pos then prices the candidate (axis, pos).  The reference's "first strict minimum
+// per axis, then first better axis" is the lexicographic minimum of (sah, axis, pos).  Result lands in `res` (LDS).
+// (The first version let every candidate loop over all bins: 3 x 31 x 32 bin visits, ~1900 instructions per lane.)
+__device__ void sah_best_wave(const uint32_t* bins, const Mapping& m, uint32_t shift, SplitResult* res, uint32_t lane) {
+  const uint32_t b = lane & 31u, half = lane >> 5;
+  const uint32_t add = (1u << shift) - 1u;
+  unsigned long long bestKey = ~0ull; uint32_t bestNL = 0;
+  float bl[3] = {0, 0, 0}, bh[3] = {0, 0, 0}, rl[3] = {0, 0, 0}, rh[3] = {0, 0, 0};
+#pragma unroll
+  for (uint32_t pass = 0; pass < 2u; pass++) {
+    const uint32_t axis = pass * 2u + half;
+    const bool live = axis < 3u && b < m.nb;
+    float plo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, phi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+    uint32_t pn = 0;
+    if (live) {
+      const uint32_t* e = bins + (axis * NBINS + b) * BINW;
+      pn = e[6];
+      if (pn) for (int d = 0; d < 3; d++) { plo[d] = dec(e[d]); phi[d] = dec(e[3 + d]); }
+    }
+    float slo[3] = {plo[0], plo[1], plo[2]}, shi[3] = {phi[0], phi[1], phi[2]}; uint32_t sn = pn;
+    for (int o = 1; o < 32; o <<= 1) {
+      const uint32_t un = (uint32_t)__shfl_up((int)pn, o, 32), dn = (uint32_t)__shfl_down((int)sn, o, 32);
+      float ul[3], uh[3], dl[3], dh[3];
+      for (int d = 0; d < 3; d++) { ul[d] = __shfl_up(plo[d], o, 32); uh[d] = __shfl_up(phi[d], o, 32); dl[d] = __shfl_down(slo[d], o, 32); dh[d] = __shfl_down(shi[d], o, 32); }
+      if (b >= (uint32_t)o) { pn += un; for (int d = 0; d < 3; d++) { plo[d] = fminf(plo[d], ul[d]); phi[d] = fmaxf(phi[d], uh[d]); } }
+      if (b + (uint32_t)o < 32u) { sn += dn; for (int d = 0; d < 3; d++) { slo[d] = fminf(slo[d], dl[d]); shi[d] = fmaxf(shi[d], dh[d]); } }
+    }
+    // candidate pos = b: left = prefix of lane b-1, right = my suffix
+    const uint32_t lN = (uint32_t)__shfl_up((int)pn, 1, 32);
+    float llo[3], lhi[3];
+    for (int d = 0; d < 3; d++) { llo[d] = __shfl_up(plo[d], 1, 32); lhi[d] = __shfl_up(phi[d], 1, 32); }
+    const bool cand = live && b != 0u && sel3(axis, m.scale[0], m.scale[1], m.scale[2]) != 0.0f && lN != 0u && sn != 0u;   // mapping.invalid(dim) :375, pos != 0 :379; an empty side is never selected
+    if (cand) {
+      const float lA = half_area3(lhi[0] - llo[0], lhi[1] - llo[1], lhi[2] - llo[2]);
+      const float rA = half_area3(shi[0] - slo[0], shi[1] - slo[1], shi[2] - slo[2]);
+      const float sah = fmaf(lA, (float)((lN + add) >> shift), rA * (float)((sn + add) >> shift));   // :367
+      const unsigned long long key = ((unsigned long long)__float_as_uint(sah) << 32) | ((axis << 5) | b);   // sah >= 0: its bit pattern is order preserving
+      if (key < bestKey) {
+        bestKey = key; bestNL = lN;
+        for (int d = 0; d < 3; d++) { bl[d] = llo[d]; bh[d] = lhi[d]; rl[d] = slo[d]; rh[d] = shi[d]; }
+      }
+    }
+  }
+  unsigned long long k = bestKey;
+  for (int o = 32; o >= 1; o >>= 1) { const unsigned long long other = __shfl_xor(k, o, 64); k = other < k ? other : k; }
+  if (lane == 0) { res->sah = __builtin_inff(); res->dim = -1; res->pos = 0; res->nL = 0; }
+  if (k != ~0ull && bestKey == k) {                              // exactly one lane owns the minimum (the candidate index is unique)
+    res->sah = __uint_as_float((uint32_t)(k >> 32)); res->dim = (int)((k >> 5) & 3u); res->pos = (int)(k & 31u); res->nL = bestNL;
+    for (int d = 0; d < 3; d++) { res->llo[d] = bl[d]; res->lhi[d] = bh[d]; res->rlo[d] = rl[d]; res->rhi[d] = rh[d]; }
+  }
+}

@@ -1,0 +1,86 @@
+// build_common.inl -- constants, build-time structs, ordered-uint float codes, wave64 DPP reductions.
+// Part of build.hip (included inside its anonymous namespace); see the header of build.hip for the pipeline.
+
+
+constexpr uint32_t NIL = 0xFFFFFFFFu;
+constexpr int NBINS = 32;                       // NUM_OBJECT_BINS, kernels/builders/bvh_builder_sah.h:10
+constexpr int BINW = 7;                         // lo.xyz, hi.xyz (ordered uint), count
+constexpr int BINS_WORDS = 3 * NBINS * BINW;    // 672 words = 2688 B per segment
+#ifndef MI355_CHUNK
+#define MI355_CHUNK 2048
+#endif
+constexpr uint32_t CHUNK = MI355_CHUNK;         // triangles per top-phase workgroup
+constexpr int CHUNK_ROUNDS = CHUNK / 256;       // triangles per thread of top_partition
+constexpr uint32_t ENC_POS_INF = 0xFF800000u;   // enc(+inf)
+constexpr uint32_t ENC_NEG_INF = 0x007FFFFFu;   // enc(-inf)
+
+struct PrimRef { float lo[3]; uint32_t geom; float hi[3]; uint32_t prim; };   // kernels/builders/primref.h:11-107 (geom = table index)
+struct GeomDesc { const char* verts; const char* idx; uint32_t vstride, istride, nv, nt, geomID, mask, primOffset, quad; };   // nt = internal triangles (2 per quad)
+// internal triangle j of a geometry -> its three vertex indices; quads: j>>1 = quad, odd j = second half (v2,v1,v3), even = (v0,v1,v3)
+__device__ __forceinline__ void prim_indices(const GeomDesc& g, uint32_t j, uint32_t& i0, uint32_t& i1, uint32_t& i2, uint32_t& id) {
+  if (g.quad) {
+    const uint32_t* q = (const uint32_t*)(g.idx + (size_t)(j >> 1) * g.istride);
+    i0 = (j & 1u) ? q[2] : q[0]; i1 = q[1]; i2 = q[3]; id = (j >> 1) | ((j & 1u) << 31);
+    if (q[0] >= g.nv || q[2] >= g.nv) i0 = 0xFFFFFFFFu;           // a quad with ANY invalid index is skipped as a whole (QuadMesh::buildBounds)
+  } else {
+    const uint32_t* t = (const uint32_t*)(g.idx + (size_t)j * g.istride);
+    i0 = t[0]; i1 = t[1]; i2 = t[2]; id = j;
+  }
+}
+struct BNode { float lo[3]; uint32_t begin; float hi[3]; uint32_t end; uint32_t left, right; float splitSah; uint32_t pad; };
+struct Seg {
+  uint32_t begin, end, bnode, flags;            // flags bit0: fallback (median) split
+  float cmin[3]; uint32_t dim;
+  float cmax[3]; uint32_t pos;
+  float ofs[3]; uint32_t nb;
+  float scale[3]; uint32_t nL;
+  uint32_t childL, childR, curL, curR;
+  uint32_t acc[2][12];                          // per side: centroid lo/hi (6) + geometry lo/hi (6), ordered uint
+};
+struct SmallEntry { uint32_t begin, end, bnode, buf; float cmin[3], cmax[3]; };
+struct Chunk { uint32_t seg, begin, end; };
+struct WideItem { uint32_t bnode, node; };
+struct Counters {
+  uint32_t numPrims, numBLeaves, numSegsNext, numChunks, numSmall, numWide, numWideNext, numLeaves;
+  uint32_t bounds[12];                          // scene geom lo/hi + centroid lo/hi (ordered uint)
+  uint32_t overflow, rootRef, numTrisOut, numInvalid;
+  uint32_t numSegs, topLevels, wideDepth, lvlNodeBase, lvlTriBase, wideCount[2];      // level loops are driven from the device: no host readback per level
+  unsigned long long sahFixed;                    // SAH statistics, 2^-24 fixed point (order-independent sum)
+  uint32_t lvlStart[64];                          // first node of every level of the wide tree (numbering is breadth first): what a refit walks bottom-up
+};
+struct Params { uint32_t shift, minLeaf, maxLeaf, small; float travCost, intCost; uint32_t quality; };
+
+// order-preserving float <-> uint so that integer atomicMin/Max reduce floats exactly
+__device__ __forceinline__ uint32_t enc(float f) { uint32_t u = __float_as_uint(f); return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u); }
+__device__ __forceinline__ float dec(uint32_t u) { return __uint_as_float(u ^ ((u >> 31) ? 0x80000000u : 0xFFFFFFFFu)); }
+__device__ __forceinline__ float half_area3(float dx, float dy, float dz) { return fmaf(dx, dy + dz, dy * dz); }  // common/math/vec3fa.h:349
+__device__ __forceinline__ float sel3(uint32_t d, float a, float b, float c) { return d == 0u ? a : (d == 1u ? b : c); }   // no dynamically indexed register arrays (scratch)
+__device__ __forceinline__ bool valid_f(float x) { return x > -1.844E18f && x < 1.844E18f; }  // isvalid, FLT_LARGE constants.h:21
+
+__device__ __forceinline__ PrimRef load_prim(const PrimRef* p) {
+  const float4 a = ((const float4*)p)[0], b = ((const float4*)p)[1];
+  PrimRef r; r.lo[0] = a.x; r.lo[1] = a.y; r.lo[2] = a.z; r.geom = __float_as_uint(a.w);
+  r.hi[0] = b.x; r.hi[1] = b.y; r.hi[2] = b.z; r.prim = __float_as_uint(b.w); return r;
+}
+__device__ __forceinline__ void store_prim(PrimRef* p, const PrimRef& r) {
+  ((float4*)p)[0] = make_float4(r.lo[0], r.lo[1], r.lo[2], __uint_as_float(r.geom));
+  ((float4*)p)[1] = make_float4(r.hi[0], r.hi[1], r.hi[2], __uint_as_float(r.prim));
+}
+
+// ---- wave64 reductions on ordered-uint codes (DPP: quad_perm, row_shr:4/8, row_bcast:15/31); the result is valid in lane 63.
+// LDS/L2 atomics of a wave that all hit the same word are executed one lane after the other (measured: ~1 lane-atomic per
+// clock per CU on mesh-ordered input, where neighbouring triangles fall into the same bin), so the lanes are combined
+// in registers first and one lane issues the atomic.
+template <int CTRL, int ROWMASK> __device__ __forceinline__ uint32_t dpp_u(uint32_t old, uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, ROWMASK, 0xF, false);
+}
+__device__ __forceinline__ uint32_t wave_umin63(uint32_t v) {
+  v = min(v, dpp_u<0xB1, 0xF>(v, v)); v = min(v, dpp_u<0x4E, 0xF>(v, v)); v = min(v, dpp_u<0x114, 0xF>(v, v));
+  v = min(v, dpp_u<0x118, 0xF>(v, v)); v = min(v, dpp_u<0x142, 0xA>(v, v)); v = min(v, dpp_u<0x143, 0xC>(v, v));
+  return v;
+}
+__device__ __forceinline__ uint32_t wave_umax63(uint32_t v) {
+  v = max(v, dpp_u<0xB1, 0xF>(v, v)); v = max(v, dpp_u<0x4E, 0xF>(v, v)); v = max(v, dpp_u<0x114, 0xF>(v, v));
+  v = max(v, dpp_u<0x118, 0xF>(v, v)); v = max(v, dpp_u<0x142, 0xA>(v, v)); v = max(v, dpp_u<0x143, 0xC>(v, v));
+  return v;
+}

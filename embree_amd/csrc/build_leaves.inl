@@ -1,0 +1,100 @@
+// build_leaves.inl -- K5: leaf records; refit; node rebasing for instanced scenes.
+// Part of build.hip (included inside its anonymous namespace); see the header of build.hip for the pipeline.
+// --------------------------------------------------------------------------------- K5 tri_records
+__global__ __launch_bounds__(256) void tri_records(const uint2* finalIds, uint32_t n, const GeomDesc* geoms, TriRec* out, uint32_t robust) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  uint2 id = finalIds[i];
+  const GeomDesc g = geoms[id.x];
+  uint32_t i0, i1, i2, pid;
+  prim_indices(g, id.y, i0, i1, i2, pid);
+  id.y = pid;                                                   // quads: quad index, bit 31 = second half (cleared again when a hit is written)
+  const float* a = (const float*)(g.verts + (size_t)i0 * g.vstride);
+  const float* b = (const float*)(g.verts + (size_t)i1 * g.vstride);
+  const float* c = (const float*)(g.verts + (size_t)i2 * g.vstride);
+  float4* o = (float4*)(out + i);
+  if (robust) {   // TriangleMv: the three vertices (kernels/geometry/trianglev.h), same 48-byte record
+    o[0] = make_float4(a[0], a[1], a[2], b[0]);
+    o[1] = make_float4(b[1], b[2], c[0], c[1]);
+    o[2] = make_float4(c[2], __uint_as_float(id.y), __uint_as_float(g.geomID), __uint_as_float(g.mask));
+    return;
+  }
+  // TriangleM ctor: e1 = v0 - v1, e2 = v2 - v0 (kernels/geometry/triangle.h:40-41)
+  o[0] = make_float4(a[0], a[1], a[2], a[0] - b[0]);
+  o[1] = make_float4(a[1] - b[1], a[2] - b[2], c[0] - a[0], c[1] - a[1]);
+  o[2] = make_float4(c[2] - a[2], __uint_as_float(id.y), __uint_as_float(g.geomID), __uint_as_float(g.mask));
+}
+
+// --------------------------------------------------------------------------------- refit (RTC_BUILD_QUALITY_REFIT, kernels/bvh/bvh_refit.cpp)
+// The topology of the tree stays; the triangle records are rewritten from the moved vertices (tri_records) and the boxes are
+// recomputed bottom-up, one launch per level of the wide tree (nodes are numbered breadth first, so a level is a contiguous range).
+// Eight lanes per node as in wide_emit: lane = child slot; a leaf slot bounds its <= 3 triangles from the vertex buffers (the same
+// min/max as primref_gen), an inner slot takes the exact box its child wrote one launch earlier; the node is re-quantised with the
+// builder's own routine.  A triangle that has become invalid (non-finite / huge coordinate) raises *flag: the caller rebuilds.
+__global__ __launch_bounds__(64) void refit_level(CNode* nodes, float4* boxes, const uint2* ids, const GeomDesc* geoms, uint32_t first, uint32_t count, uint32_t* flag) {
+  __shared__ uint32_t s_node[8][20];
+  const uint32_t lane = threadIdx.x, s = lane & 7u, g = lane >> 3;
+  for (uint32_t base = blockIdx.x * 8u; base < count; base += gridDim.x * 8u) {
+    const uint32_t t = base + g; const bool valid = t < count;
+    const uint32_t node = first + (valid ? t : 0u);
+    __syncthreads();
+    if (valid && s < 5u) ((uint4*)&s_node[g][0])[s] = ((const uint4*)(nodes + node))[s];
+    __syncthreads();
+    const uint8_t* nbr = (const uint8_t*)&s_node[g][0];
+    const uint32_t meta = valid ? nbr[24 + s] : 0u, imask = s_node[g][3] >> 24, childBase = s_node[g][4], triBase = s_node[g][5];
+    const bool has = meta != 0u, inner = has && ((imask >> s) & 1u) != 0u;
+    float lo[3], hi[3], olo[3], ohi[3];
+    for (int d = 0; d < 3; d++) { lo[d] = __builtin_inff(); hi[d] = -__builtin_inff(); }
+    if (inner) {
+      const uint32_t c = childBase + (uint32_t)__popc(imask & ((1u << s) - 1u));
+      const float4 a = boxes[2u * c], b = boxes[2u * c + 1u];
+      lo[0] = a.x; lo[1] = a.y; lo[2] = a.z; hi[0] = b.x; hi[1] = b.y; hi[2] = b.z;
+    } else if (has) {
+      const uint32_t cnt = (uint32_t)__popc(meta >> 5), t0 = triBase + (meta & 31u);
+      bool ok = true;
+      for (uint32_t k = 0; k < cnt; k++) {
+        const uint2 id = ids[t0 + k];
+        const GeomDesc gd = geoms[id.x];
+        uint32_t i0, i1, i2, pid;
+        prim_indices(gd, id.y, i0, i1, i2, pid);
+        const float* a = (const float*)(gd.verts + (size_t)i0 * gd.vstride);
+        const float* b = (const float*)(gd.verts + (size_t)i1 * gd.vstride);
+        const float* c = (const float*)(gd.verts + (size_t)i2 * gd.vstride);
+        for (int d = 0; d < 3; d++) {
+          const float x = a[d], y = b[d], z = c[d];
+          ok = ok && valid_f(x) && valid_f(y) && valid_f(z);
+          lo[d] = fminf(lo[d], fminf(fminf(x, y), z)); hi[d] = fmaxf(hi[d], fmaxf(fmaxf(x, y), z));
+        }
+        if (gd.quad) {
+          const uint32_t* q = (const uint32_t*)(gd.idx + (size_t)(id.y >> 1) * gd.istride);
+          const float* o4 = (const float*)(gd.verts + (size_t)((id.y & 1u) ? q[0] : q[2]) * gd.vstride);
+          ok = ok && valid_f(o4[0]) && valid_f(o4[1]) && valid_f(o4[2]);
+        }
+      }
+      if (!ok) { atomicOr(flag, 1u); for (int d = 0; d < 3; d++) { lo[d] = 0.0f; hi[d] = 0.0f; } }
+    }
+    for (int d = 0; d < 3; d++) { olo[d] = grp_min(lo[d]); ohi[d] = grp_max(hi[d]); }
+    uint32_t ex[3], qa[3], qb[3];
+    quantise_slots(has, lane, lo, hi, olo, ohi, ex, qa, qb);
+    __syncthreads();
+    uint8_t* nb = (uint8_t*)&s_node[g][0];
+    for (int d = 0; d < 3; d++) { nb[32 + d * 8 + s] = (uint8_t)qa[d]; nb[56 + d * 8 + s] = (uint8_t)qb[d]; }
+    if (s == 0u) {
+      s_node[g][0] = __float_as_uint(olo[0]); s_node[g][1] = __float_as_uint(olo[1]); s_node[g][2] = __float_as_uint(olo[2]);
+      s_node[g][3] = ex[0] | (ex[1] << 8) | (ex[2] << 16) | (imask << 24);
+      if (valid) { boxes[2u * node] = make_float4(olo[0], olo[1], olo[2], 0.0f); boxes[2u * node + 1u] = make_float4(ohi[0], ohi[1], ohi[2], 0.0f); }
+    }
+    __syncthreads();
+    if (valid && s < 5u) ((uint4*)(nodes + node))[s] = ((const uint4*)&s_node[g][0])[s];
+  }
+}
+
+// --------------------------------------------------------------------------------- instanced scenes: object trees copied behind the top tree
+// One thread per node: the 80 bytes are copied, child / triangle base indices moved by the object's offset in the combined arrays.
+__global__ __launch_bounds__(256) void rebase_nodes(const uint4* src, uint4* dst, uint32_t n, uint32_t nodeOfs, uint32_t triOfs) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  uint4 w0 = src[5u * i], w1 = src[5u * i + 1u];
+  w1.x += nodeOfs; w1.y += triOfs;
+  dst[5u * i] = w0; dst[5u * i + 1u] = w1; dst[5u * i + 2u] = src[5u * i + 2u]; dst[5u * i + 3u] = src[5u * i + 3u]; dst[5u * i + 4u] = src[5u * i + 4u];
+}

@@ -1,0 +1,179 @@
+// build_presplit.inl -- RTC_BUILD_QUALITY_HIGH: pre-splitting of large triangles.
+// Part of build.hip (included inside its anonymous namespace); see the header of build.hip for the pipeline.
+// --------------------------------------------------------------------------------- presplit (RTC_BUILD_QUALITY_HIGH)
+// The reference's high-quality builder in its "presplits" form (BVHNBuilderFastSpatialSAH with usePreSplits, kernels/bvh/bvh_builder_sah_spatial.cpp:93-125):
+// before the ordinary binned-SAH build, triangles whose box is much larger than the triangle are cut along the planes of a 1024^3 grid over the scene
+// (kernels/builders/primrefgen_presplit.h): every piece is a PrimRef of the SAME triangle with the box of the clipped piece.  The tree gets tighter boxes
+// where long or diagonal triangles used to blow them up; the leaves may name a triangle several times (each reference becomes a leaf record).
+//   priority(ref) = sqrt(sqrt((area(box) - projected area(triangle)) * 1.5^(highest differing Morton bit)))           :125-143
+//   pieces(ref)   = 2^clamp(ceil(log2(budget * priority / sum of priorities)), 1, 5), 1 if that ratio is < 1                :296-313
+//   a piece is cut at the grid plane of the highest Morton bit in which its corners differ (SplittingGrid::split_pos :39-78), the triangle is
+//   clipped edge by edge (splitPolygon, kernels/builders/splitter.h:16-49) and the piece's box is the clipped box intersected with the parent's.
+// The budget is max_spatial_split_replications - 1 = 20 % extra references (kernels/common/state.cpp:87).  Where the reference sorts the candidates
+// and drops the lowest ones when the pieces exceed the budget, this build halves the budget and counts again (at most 6 times): no sort.
+struct SplitGrid { float base[3]; float scale, extend; };
+__device__ __forceinline__ uint32_t part1by2(uint32_t x) { x &= 0x3FFu; x = (x | (x << 16)) & 0x030000FFu; x = (x | (x << 8)) & 0x0300F00Fu; x = (x | (x << 4)) & 0x030C30C3u; x = (x | (x << 2)) & 0x09249249u; return x; }
+__device__ __forceinline__ void grid_codes(const SplitGrid& g, const float* lo, const float* hi, int (&iu)[3], uint32_t& lc, uint32_t& uc) {
+  int il[3];
+  for (int d = 0; d < 3; d++) {
+    const float gl = (lo[d] - g.base[d]) * g.scale + 0.2f, gu = (hi[d] - g.base[d]) * g.scale - 0.2f;
+    il[d] = (int)floorf(gl); iu[d] = (int)floorf(gu);
+    if ((int)rintf(gl) >= (int)rintf(gu)) iu[d] = il[d];          // "this ignores dimensions that are empty"
+  }
+  lc = part1by2((uint32_t)il[0]) | (part1by2((uint32_t)il[1]) << 1) | (part1by2((uint32_t)il[2]) << 2);
+  uc = part1by2((uint32_t)iu[0]) | (part1by2((uint32_t)iu[1]) << 1) | (part1by2((uint32_t)iu[2]) << 2);
+}
+__device__ __forceinline__ void load_tri(const GeomDesc* geoms, const PrimRef& r, float (&v)[3][3]) {
+  const GeomDesc g = geoms[r.geom];
+  uint32_t i0, i1, i2, pid; prim_indices(g, r.prim, i0, i1, i2, pid);
+  const float* a = (const float*)(g.verts + (size_t)i0 * g.vstride); const float* b = (const float*)(g.verts + (size_t)i1 * g.vstride); const float* c = (const float*)(g.verts + (size_t)i2 * g.vstride);
+  for (int d = 0; d < 3; d++) { v[0][d] = a[d]; v[1][d] = b[d]; v[2][d] = c[d]; }
+}
+struct Piece { float lo[3], hi[3]; uint32_t want; };
+// splitPrimitive (primrefgen_presplit.h:144-181) without recursion: pieces come out in the reference's order (left before right)
+template <bool EMIT>
+__device__ uint32_t presplit_walk(const PrimRef& ref, uint32_t want, const float (&v)[3][3], const SplitGrid& g, PrimRef* first, PrimRef* rest) {
+  Piece stack[7]; int sp = 0;
+  Piece p0; for (int d = 0; d < 3; d++) { p0.lo[d] = ref.lo[d]; p0.hi[d] = ref.hi[d]; } p0.want = want;
+  stack[sp++] = p0;
+  uint32_t num = 0;
+  while (sp > 0) {
+    const Piece cur = stack[--sp];
+    bool leaf = cur.want <= 1u; uint32_t dim = 0; float pos = 0.0f;
+    if (!leaf) {
+      int iu[3]; uint32_t lc, uc; grid_codes(g, cur.lo, cur.hi, iu, lc, uc);
+      if (lc == uc) leaf = true;
+      else {
+        const uint32_t diff = 31u - (uint32_t)__clz((int)(lc ^ uc)), level = diff / 3u; dim = diff % 3u;
+        const int isplit = (dim == 0u ? iu[0] : dim == 1u ? iu[1] : iu[2]) & ~((1 << level) - 1);
+        pos = sel3(dim, g.base[0], g.base[1], g.base[2]) + (float)isplit * (1.0f / 1024.0f) * g.extend;
+      }
+    }
+    if (leaf || sp + 2 > 7) {
+      if (EMIT) { PrimRef o = ref; for (int d = 0; d < 3; d++) { o.lo[d] = cur.lo[d]; o.hi[d] = cur.hi[d]; } store_prim(num == 0u ? first : rest + (num - 1u), o); }
+      num++; continue;
+    }
+    Piece L, R;
+    for (int d = 0; d < 3; d++) { L.lo[d] = __builtin_inff(); L.hi[d] = -__builtin_inff(); R.lo[d] = __builtin_inff(); R.hi[d] = -__builtin_inff(); }
+    for (int e = 0; e < 3; e++) {                                  // splitPolygon<3>: every edge (v[e], v[e+1])
+      const int e1 = e == 2 ? 0 : e + 1;
+      const float a0 = sel3(dim, v[e][0], v[e][1], v[e][2]), a1 = sel3(dim, v[e1][0], v[e1][1], v[e1][2]);
+      if (a0 <= pos) for (int d = 0; d < 3; d++) { L.lo[d] = fminf(L.lo[d], v[e][d]); L.hi[d] = fmaxf(L.hi[d], v[e][d]); }
+      if (a0 >= pos) for (int d = 0; d < 3; d++) { R.lo[d] = fminf(R.lo[d], v[e][d]); R.hi[d] = fmaxf(R.hi[d], v[e][d]); }
+      if ((a0 < pos && pos < a1) || (a1 < pos && pos < a0)) {
+        const float t = (pos - a0) * (1.0f / (a1 - a0));
+        for (int d = 0; d < 3; d++) { const float c = fmaf(t, v[e1][d] - v[e][d], v[e][d]); L.lo[d] = fminf(L.lo[d], c); L.hi[d] = fmaxf(L.hi[d], c); R.lo[d] = fminf(R.lo[d], c); R.hi[d] = fmaxf(R.hi[d], c); }
+      }
+    }
+    bool okL = true, okR = true;
+    for (int d = 0; d < 3; d++) {                                  // intersect with the piece that is being split
+      L.lo[d] = fmaxf(L.lo[d], cur.lo[d]); L.hi[d] = fminf(L.hi[d], cur.hi[d]); R.lo[d] = fmaxf(R.lo[d], cur.lo[d]); R.hi[d] = fminf(R.hi[d], cur.hi[d]);
+      okL = okL && L.lo[d] <= L.hi[d]; okR = okR && R.lo[d] <= R.hi[d];
+    }
+    if (!okL || !okR) {                                            // (the reference asserts this away) keep the piece whole
+      if (EMIT) { PrimRef o = ref; for (int d = 0; d < 3; d++) { o.lo[d] = cur.lo[d]; o.hi[d] = cur.hi[d]; } store_prim(num == 0u ? first : rest + (num - 1u), o); }
+      num++; continue;
+    }
+    L.want = cur.want / 2u; R.want = cur.want - L.want;
+    stack[sp++] = R; stack[sp++] = L;
+  }
+  return num;
+}
+__global__ __launch_bounds__(256) void presplit_priority(const PrimRef* prims, uint32_t n, const GeomDesc* geoms, SplitGrid g, float* prio, float* partial) {
+  __shared__ float s_w[4];
+  const uint32_t tid = threadIdx.x, i = blockIdx.x * 256u + tid;
+  float p = 0.0f;
+  if (i < n) {
+    const PrimRef r = load_prim(prims + i);
+    int iu[3]; uint32_t lc, uc; grid_codes(g, r.lo, r.hi, iu, lc, uc);
+    if (lc != uc) {
+      float v[3][3]; load_tri(geoms, r, v);
+      const float e0[3] = {v[1][0] - v[0][0], v[1][1] - v[0][1], v[1][2] - v[0][2]}, e1[3] = {v[2][0] - v[0][0], v[2][1] - v[0][1], v[2][2] - v[0][2]};
+      const float cx = fmaf(e0[1], e1[2], -(e0[2] * e1[1])), cy = fmaf(e0[2], e1[0], -(e0[0] * e1[2])), cz = fmaf(e0[0], e1[1], -(e0[1] * e1[0]));
+      const float areaPrim = fabsf(cx) + fabsf(cy) + fabsf(cz);        // areaProjectedTriangle, kernels/builders/priminfo.h:11-17
+      const float areaBox = 2.0f * half_area3(r.hi[0] - r.lo[0], r.hi[1] - r.lo[1], r.hi[2] - r.lo[2]);
+      if (areaPrim != 0.0f) {
+        const int diff = 31 - __clz((int)(lc ^ uc));
+        p = sqrtf(sqrtf(fmaxf(0.0f, areaBox - areaPrim) * powf(1.5f, (float)diff)));
+        if (!(p >= 0.0f && p < 1.844E18f)) p = 0.0f;
+      }
+    }
+    prio[i] = p;
+  }
+  // block sum in a fixed order (the reference's sum is "undeterministic", :289; this one is not)
+  for (int o = 32; o > 0; o >>= 1) p += __shfl_down(p, o, 64);
+  if ((tid & 63u) == 0u) s_w[tid >> 6] = p;
+  __syncthreads();
+  if (tid == 0u) partial[blockIdx.x] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+}
+__global__ __launch_bounds__(1024) void presplit_sum(const float* partial, uint32_t nb, float* out) {
+  __shared__ float s_p[1024];
+  const uint32_t tid = threadIdx.x, per = (nb + 1023u) / 1024u, b = min(tid * per, nb), e = min(b + per, nb);
+  float sum = 0.0f; for (uint32_t i = b; i < e; i++) sum += partial[i];
+  s_p[tid] = sum; __syncthreads();
+  for (uint32_t o = 512u; o > 0u; o >>= 1) { if (tid < o) s_p[tid] += s_p[tid + o]; __syncthreads(); }
+  if (tid == 0u) out[0] = s_p[0];
+}
+// pieces per reference (cnt = pieces - 1 = extra references), tile sums for the scan
+__global__ __launch_bounds__(256) void presplit_count(const PrimRef* prims, uint32_t n, const GeomDesc* geoms, SplitGrid g, const float* prio, const float* psum, float budget,
+                                                      uint32_t* cnt, uint32_t* tileSum) {
+  __shared__ uint32_t s_w[4];
+  const uint32_t tid = threadIdx.x, i = blockIdx.x * 256u + tid;
+  uint32_t extra = 0u;
+  if (i < n) {
+    const float p = prio[i], inv = psum[0] > 0.0f ? 1.0f / psum[0] : 1.0f;
+    uint32_t want = 1u;
+    if (p > 0.0f) {
+      const float rel = budget * p * inv;
+      if (rel >= 1.0f) { const float l = fmaxf(fminf(ceilf(logf(rel) / logf(2.0f)), 5.0f), 1.0f); want = 1u << (uint32_t)l; }
+    }
+    if (want > 1u) {
+      const PrimRef r = load_prim(prims + i);
+      float v[3][3]; load_tri(geoms, r, v);
+      extra = presplit_walk<false>(r, want, v, g, nullptr, nullptr) - 1u;
+    }
+    cnt[i] = extra | (want << 16);
+  }
+  uint32_t x = extra; for (int o = 32; o > 0; o >>= 1) x += (uint32_t)__shfl_down((int)x, o, 64);
+  if ((tid & 63u) == 0u) s_w[tid >> 6] = x;
+  __syncthreads();
+  if (tid == 0u) tileSum[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+__global__ __launch_bounds__(1024) void presplit_scan(uint32_t* tileSum, uint32_t numTiles, uint32_t* total) {
+  __shared__ uint32_t s_part[1024];
+  const uint32_t tid = threadIdx.x, per = (numTiles + 1023u) / 1024u, b = min(tid * per, numTiles), e = min(b + per, numTiles);
+  uint32_t sum = 0; for (uint32_t i = b; i < e; i++) sum += tileSum[i];
+  s_part[tid] = sum; __syncthreads();
+  if (tid == 0) { uint32_t run = 0; for (int i = 0; i < 1024; i++) { const uint32_t t = s_part[i]; s_part[i] = run; run += t; } total[0] = run; }
+  __syncthreads();
+  uint32_t run = s_part[tid]; for (uint32_t i = b; i < e; i++) { const uint32_t t = tileSum[i]; tileSum[i] = run; run += t; }
+}
+// piece 0 replaces the reference, the others go behind the n original references at the scanned offset
+__global__ __launch_bounds__(256) void presplit_emit(PrimRef* prims, uint32_t n, const GeomDesc* geoms, SplitGrid g, const uint32_t* cnt, const uint32_t* tileOfs) {
+  __shared__ uint32_t s_scan[256];
+  const uint32_t tid = threadIdx.x, i = blockIdx.x * 256u + tid;
+  const uint32_t c = i < n ? cnt[i] : 0u, extra = c & 0xFFFFu, want = c >> 16;
+  s_scan[tid] = extra; __syncthreads();
+  for (uint32_t o = 1; o < 256u; o <<= 1) { uint32_t x = 0; if (tid >= o) x = s_scan[tid - o]; __syncthreads(); s_scan[tid] += x; __syncthreads(); }
+  if (extra == 0u) return;
+  const uint32_t off = n + tileOfs[blockIdx.x] + s_scan[tid] - extra;
+  const PrimRef r = load_prim(prims + i);
+  float v[3][3]; load_tri(geoms, r, v);
+  presplit_walk<true>(r, want, v, g, prims + i, prims + off);
+}
+__global__ __launch_bounds__(256) void centroid_bounds(const PrimRef* prims, uint32_t n, Counters* ctr) {
+  __shared__ uint32_t s_acc[6];                                  // one global atomic per block and word: same-address atomics from every wave cost 0.4 ms here
+  if (threadIdx.x < 6u) s_acc[threadIdx.x] = threadIdx.x < 3u ? 0xFFFFFFFFu : 0u;
+  __syncthreads();
+  uint32_t acc[6]; for (int k = 0; k < 6; k++) acc[k] = k < 3 ? 0xFFFFFFFFu : 0u;
+  for (uint32_t p = blockIdx.x * 256u + threadIdx.x; p < n; p += gridDim.x * 256u) {
+    const PrimRef r = load_prim(prims + p);
+    for (int d = 0; d < 3; d++) { const uint32_t c2 = enc(r.lo[d] + r.hi[d]); acc[d] = min(acc[d], c2); acc[3 + d] = max(acc[3 + d], c2); }
+  }
+  for (int k = 0; k < 6; k++) {
+    const uint32_t x = k < 3 ? wave_umin63(acc[k]) : wave_umax63(acc[k]);
+    if ((threadIdx.x & 63u) == 63u) { if (k < 3) atomicMin(&s_acc[k], x); else atomicMax(&s_acc[k], x); }
+  }
+  __syncthreads();
+  if (threadIdx.x < 6u) { if (threadIdx.x < 3u) atomicMin(&ctr->bounds[6 + threadIdx.x], s_acc[threadIdx.x]); else atomicMax(&ctr->bounds[6 + threadIdx.x], s_acc[threadIdx.x]); }
+}

@@ -1,0 +1,311 @@
+// build_small.inl -- K3: sub-trees finished by one wavefront in LDS.
+// Part of build.hip (included inside its anonymous namespace); see the header of build.hip for the pipeline.
+// ---------------------------------------------------------------------------------- K3 small phase
+// One wavefront finishes a sub-tree of <= small_threshold triangles.  Two modes:
+//   * segments of more than MICRO triangles: the wave splits ONE segment at a time (bins in LDS, ping-pong partition
+//     through HBM/L2, explicit stack), exactly like the top phase but without leaving the CU;
+//   * segments of <= MICRO (= 64) triangles -- 94 % of all binary nodes of a scene -- are finished by micro_subtree():
+//     one triangle per lane, and ALL segments of a level are split in the same pass (per-segment bins, candidate
+//     evaluation, argmin and partition all live in LDS; segments are contiguous lane ranges).  A wave instruction thus
+//     serves up to 32 splits instead of one: the first version of this kernel spent 35 of the 45 ms of a 4.8 M triangle
+//     commit walking those tiny segments one by one (profiles/r01_bench_kernel_stats_v2.md).
+// Binary node numbering is implicit -- the children of node k over nL + nR triangles are k + 1 and k + 2 nL (pre-order,
+// a sub-tree of n triangles owns ids [k, k + 2n - 1)) -- so no global counter is touched and the numbering is the same
+// on every run.
+struct StackEntry { uint32_t begin, end, bnode, buf; float cmin[3], cmax[3]; };
+constexpr uint32_t MICRO = 64;
+
+// zero-identity encodings for LDS atomicMax accumulators that are cleared with plain zero stores
+__device__ __forceinline__ uint32_t zlo(float f) { return ~enc(f); }          // max of zlo = min of f
+__device__ __forceinline__ float unzlo(uint32_t u) { return dec(~u); }
+__device__ __forceinline__ uint32_t zhi(float f) { return enc(f); }           // enc(x) > 0 for every float
+__device__ __forceinline__ float unzhi(uint32_t u) { return dec(u); }
+
+// R: per-wave LDS scratch of 64 * W words (W = 32 words per triangle when min_leaf >= 2, 48 for min_leaf = 1):
+//   bins of the segment starting at lane b live at R + b * W as [axis][bin][8] (3 * nb * 8 <= n * W words for every
+//   splittable n); once the candidates are evaluated the same memory holds the split records (16 words per segment at
+//   R + b * 16) and the exchange buffer the partition moves the triangles through (10 x 64 words at R + 1024).
+__device__ void micro_subtree(uint32_t* R, uint32_t W, uint32_t (*s_cb)[64][6], unsigned long long* s_key, const PrimRef* src,
+                              uint32_t gbegin, uint32_t n0, uint32_t rootNode, const float* cmin0, const float* cmax0,
+                              BNode* bnodes, uint2* finalIds, Counters* ctr, const Params& prm, uint32_t lane) {
+  PrimRef p{};
+  if (lane < n0) p = load_prim(src + gbegin + lane);
+  uint32_t segB = 0, segE = n0, node = rootNode;
+  bool act = lane < n0 && n0 > prm.minLeaf;
+  if (lane == 0u) for (int d = 0; d < 3; d++) { s_cb[0][0][d] = zlo(cmin0[d]); s_cb[0][0][3 + d] = zhi(cmax0[d]); }
+  __syncthreads();
+  const uint32_t addBlk = (1u << prm.shift) - 1u;
+  uint32_t pp = 0;
+  for (uint32_t level = 0; level < 64u; level++) {
+    if (__ballot(act) == 0ull) break;
+    // ---- L0: bin mapping of my segment (BinMapping, heuristic_binning.h:46-55); clear bins, keys, next level's centroid bounds
+    const uint32_t n = segE - segB;
+    float ofs[3] = {0, 0, 0}, scale[3] = {0, 0, 0}; uint32_t nb = 4;
+    if (act) {
+      float cmin[3], cmax[3];
+      for (int d = 0; d < 3; d++) { cmin[d] = unzlo(s_cb[pp][segB][d]); cmax[d] = unzhi(s_cb[pp][segB][3 + d]); }
+      const Mapping m = make_mapping(n, cmin, cmax);
+      for (int d = 0; d < 3; d++) { ofs[d] = m.ofs[d]; scale[d] = m.scale[d]; }
+      nb = m.nb;
+    }
+    __syncthreads();                                             // everybody has read s_cb[pp] and is done with the exchange buffer
+    for (uint32_t i = 0; i < W / 4u; i++) ((uint4*)R)[i * 64u + lane] = make_uint4(0u, 0u, 0u, 0u);
+    s_key[lane] = ~0ull;
+    for (int k = 0; k < 6; k++) s_cb[pp ^ 1u][lane][k] = 0u;
+    __syncthreads();
+    // ---- L1: bin (BinInfoT::bin, heuristic_binning.h:210-257)
+    uint32_t* const sb = R + segB * W;
+    if (act) {
+      for (int d = 0; d < 3; d++) {
+        const int b = bin_clamped(p.lo[d] + p.hi[d], ofs[d], scale[d], nb);
+        uint32_t* e = sb + ((uint32_t)d * nb + (uint32_t)b) * 8u;     // 8-word entries: lo.xyz hi.xyz count pad (two 16-byte reads)
+        atomicMax(&e[0], zlo(p.lo[0])); atomicMax(&e[1], zlo(p.lo[1])); atomicMax(&e[2], zlo(p.lo[2]));
+        atomicMax(&e[3], zhi(p.hi[0])); atomicMax(&e[4], zhi(p.hi[1])); atomicMax(&e[5], zhi(p.hi[2]));
+        atomicAdd(&e[6], 1u);
+      }
+    }
+    __syncthreads();
+    // ---- L2: candidates (BinInfoT::best :339-386): lane j of a segment evaluates candidates j, j + n, ...;
+    //      candidate c = axis * (nb - 1) + (pos - 1), so the minimum of (sah, c) is the reference's choice
+    float bestSah = __builtin_inff(); uint32_t bestC = NIL, bestNL = 0;
+    float bl[3] = {0, 0, 0}, bh[3] = {0, 0, 0}, rl[3] = {0, 0, 0}, rh[3] = {0, 0, 0};
+    if (act && nb == 4u) {
+      // the common case (n < 20): lane j of the segment sweeps axis j once -- suffix bounds S1..S3, then a running prefix; 4 bins are read
+      // once (8 x 16 bytes) instead of once per candidate
+      for (uint32_t axis = lane - segB; axis < 3u; axis += n) {
+        if (sel3(axis, scale[0], scale[1], scale[2]) == 0.0f) continue;          // mapping.invalid(dim) :375
+        const uint4* e = (const uint4*)(sb + axis * 32u);
+        float lo[4][3], hi[4][3]; uint32_t cn[4];
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+          const uint4 x = e[2 * b], y = e[2 * b + 1];
+          cn[b] = y.z;
+          const bool any = cn[b] != 0u;
+          lo[b][0] = any ? unzlo(x.x) : __builtin_inff(); lo[b][1] = any ? unzlo(x.y) : __builtin_inff(); lo[b][2] = any ? unzlo(x.z) : __builtin_inff();
+          hi[b][0] = any ? unzhi(x.w) : -__builtin_inff(); hi[b][1] = any ? unzhi(y.x) : -__builtin_inff(); hi[b][2] = any ? unzhi(y.y) : -__builtin_inff();
+        }
+        float slo[4][3], shi[4][3]; uint32_t sn[4];                            // suffix: bins pos..3
+        for (int d = 0; d < 3; d++) { slo[3][d] = lo[3][d]; shi[3][d] = hi[3][d]; } sn[3] = cn[3];
+#pragma unroll
+        for (int b = 2; b >= 1; b--) { for (int d = 0; d < 3; d++) { slo[b][d] = fminf(lo[b][d], slo[b + 1][d]); shi[b][d] = fmaxf(hi[b][d], shi[b + 1][d]); } sn[b] = cn[b] + sn[b + 1]; }
+        float llo[3] = {lo[0][0], lo[0][1], lo[0][2]}, lhi[3] = {hi[0][0], hi[0][1], hi[0][2]}; uint32_t lN = cn[0];
+#pragma unroll
+        for (int pos = 1; pos < 4; pos++) {
+          if (lN != 0u && sn[pos] != 0u) {
+            const float lA = half_area3(lhi[0] - llo[0], lhi[1] - llo[1], lhi[2] - llo[2]);
+            const float rA = half_area3(shi[pos][0] - slo[pos][0], shi[pos][1] - slo[pos][1], shi[pos][2] - slo[pos][2]);
+            const float sah = fmaf(lA, (float)((lN + addBlk) >> prm.shift), rA * (float)((sn[pos] + addBlk) >> prm.shift));
+            if (sah < bestSah) {
+              bestSah = sah; bestC = axis * 3u + (uint32_t)(pos - 1); bestNL = lN;
+              for (int d = 0; d < 3; d++) { bl[d] = llo[d]; bh[d] = lhi[d]; rl[d] = slo[pos][d]; rh[d] = shi[pos][d]; }
+            }
+          }
+          for (int d = 0; d < 3; d++) { llo[d] = fminf(llo[d], lo[pos][d]); lhi[d] = fmaxf(lhi[d], hi[pos][d]); }
+          lN += cn[pos];
+        }
+      }
+    } else if (act) {
+      const uint32_t nb1 = nb - 1u, ncand = 3u * nb1;
+      for (uint32_t c = lane - segB; c < ncand; c += n) {
+        const uint32_t axis = (c >= nb1 ? 1u : 0u) + (c >= 2u * nb1 ? 1u : 0u), pos = c - axis * nb1 + 1u;
+        if (sel3(axis, scale[0], scale[1], scale[2]) == 0.0f) continue;          // mapping.invalid(dim) :375
+        float llo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, lhi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+        float rlo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, rhi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+        uint32_t lN = 0, rN = 0;
+        for (uint32_t b = 0; b < nb; b++) {
+          const uint32_t* e = sb + (axis * nb + b) * 8u;
+          const uint32_t cnt = e[6];
+          if (cnt == 0u) continue;
+          if (b < pos) { lN += cnt; for (int d = 0; d < 3; d++) { llo[d] = fminf(llo[d], unzlo(e[d])); lhi[d] = fmaxf(lhi[d], unzhi(e[3 + d])); } }
+          else         { rN += cnt; for (int d = 0; d < 3; d++) { rlo[d] = fminf(rlo[d], unzlo(e[d])); rhi[d] = fmaxf(rhi[d], unzhi(e[3 + d])); } }
+        }
+        if (lN == 0u || rN == 0u) continue;
+        const float lA = half_area3(lhi[0] - llo[0], lhi[1] - llo[1], lhi[2] - llo[2]);
+        const float rA = half_area3(rhi[0] - rlo[0], rhi[1] - rlo[1], rhi[2] - rlo[2]);
+        const float sah = fmaf(lA, (float)((lN + addBlk) >> prm.shift), rA * (float)((rN + addBlk) >> prm.shift));
+        if (sah < bestSah) {
+          bestSah = sah; bestC = c; bestNL = lN;
+          for (int d = 0; d < 3; d++) { bl[d] = llo[d]; bh[d] = lhi[d]; rl[d] = rlo[d]; rh[d] = rhi[d]; }
+        }
+      }
+    }
+    const unsigned long long key = bestC == NIL ? ~0ull : (((unsigned long long)__float_as_uint(bestSah) << 32) | bestC);
+    if (act && key != ~0ull) atomicMin(&s_key[segB], key);
+    __syncthreads();                                             // bins are dead from here on: R now holds split records + exchange buffer
+    const unsigned long long win = act ? s_key[segB] : 0ull;
+    const bool fb = act && win == ~0ull;                          // no valid candidate -> median split (split_template :144-147)
+    uint32_t* const rec = R + segB * 16u;
+    if (act && !fb && key == win) {
+      const uint32_t nb1 = nb - 1u, axis = (bestC >= nb1 ? 1u : 0u) + (bestC >= 2u * nb1 ? 1u : 0u), pos = bestC - axis * nb1 + 1u;
+      rec[0] = axis | (pos << 8); rec[1] = bestNL; rec[2] = __float_as_uint(bestSah);
+      for (int d = 0; d < 3; d++) { rec[4 + d] = __float_as_uint(bl[d]); rec[7 + d] = __float_as_uint(bh[d]); rec[10 + d] = __float_as_uint(rl[d]); rec[13 + d] = __float_as_uint(rh[d]); }
+    }
+    if (fb && lane == segB) {
+      rec[0] = 1u << 16; rec[1] = (gbegin + segB + gbegin + segE) / 2u - (gbegin + segB); rec[2] = __float_as_uint(__builtin_inff());
+      for (int k = 4; k < 16; k++) rec[k] = 0u;
+    }
+    __syncthreads();
+    if (__ballot(fb) != 0ull) {                                   // child geometry bounds of a median split: reduce over the triangles
+      if (fb) {
+        const uint32_t o = lane < segB + rec[1] ? 4u : 10u;
+        for (int d = 0; d < 3; d++) { atomicMax(&rec[o + d], zlo(p.lo[d])); atomicMax(&rec[o + 3 + d], zhi(p.hi[d])); }
+      }
+      __syncthreads();
+    }
+    // ---- L4: partition (heuristic_binning_array_aligned.h:150-176): new lane of my triangle, child centroid bounds, node records
+    bool left = false; uint32_t nL = 0;
+    if (act) {
+      const uint32_t w0 = rec[0], dim = w0 & 3u, pos = (w0 >> 8) & 0xFFu; nL = rec[1];
+      const float c2 = sel3(dim, p.lo[0] + p.hi[0], p.lo[1] + p.hi[1], p.lo[2] + p.hi[2]);
+      left = (w0 >> 16) ? (lane < segB + nL) : (bin_unsafe(c2, sel3(dim, ofs[0], ofs[1], ofs[2]), sel3(dim, scale[0], scale[1], scale[2])) < (int)pos);
+    }
+    const unsigned long long segMask = act ? ((n >= 64u ? ~0ull : ((1ull << n) - 1ull)) << segB) : 0ull;
+    const unsigned long long lm = __ballot(act && left) & segMask, rm = __ballot(act && !left) & segMask, lt = (1ull << lane) - 1ull;
+    if (act) {
+      const uint32_t nSegB = left ? segB : segB + nL, nSegE = left ? segB + nL : segE, nNode = left ? node + 1u : node + 2u * nL;
+      const uint32_t npos = left ? segB + (uint32_t)__popcll(lm & lt) : segB + nL + (uint32_t)__popcll(rm & lt);
+      for (int d = 0; d < 3; d++) { const float cc = p.lo[d] + p.hi[d]; atomicMax(&s_cb[pp ^ 1u][nSegB][d], zlo(cc)); atomicMax(&s_cb[pp ^ 1u][nSegB][3 + d], zhi(cc)); }
+      uint32_t* X = R + 1024u + npos;
+      X[0] = __float_as_uint(p.lo[0]); X[64] = __float_as_uint(p.lo[1]); X[128] = __float_as_uint(p.lo[2]); X[192] = p.geom;
+      X[256] = __float_as_uint(p.hi[0]); X[320] = __float_as_uint(p.hi[1]); X[384] = __float_as_uint(p.hi[2]); X[448] = p.prim;
+      X[512] = nSegB | (nSegE << 8); X[576] = nNode;
+      if (lane == segB) {                                        // one lane per segment: my links, my children's boxes and ranges
+        const bool isfb = (rec[0] >> 16) != 0u;
+        float cb[12];
+        for (int k = 0; k < 12; k++) cb[k] = isfb ? ((k % 6) < 3 ? unzlo(rec[4 + k]) : unzhi(rec[4 + k])) : __uint_as_float(rec[4 + k]);
+        const uint32_t L = node + 1u, Rr = node + 2u * nL;
+        ((uint4*)(bnodes + node))[2] = make_uint4(L, Rr, rec[2], 0u);
+        ((float4*)(bnodes + L))[0] = make_float4(cb[0], cb[1], cb[2], __uint_as_float(gbegin + segB));
+        ((float4*)(bnodes + L))[1] = make_float4(cb[3], cb[4], cb[5], __uint_as_float(gbegin + segB + nL));
+        ((float4*)(bnodes + Rr))[0] = make_float4(cb[6], cb[7], cb[8], __uint_as_float(gbegin + segB + nL));
+        ((float4*)(bnodes + Rr))[1] = make_float4(cb[9], cb[10], cb[11], __uint_as_float(gbegin + segE));
+      }
+    }
+    __syncthreads();
+    // ---- L5: pick up the triangle that moved to my lane
+    if (act) {
+      const uint32_t* X = R + 1024u + lane;
+      p.lo[0] = __uint_as_float(X[0]); p.lo[1] = __uint_as_float(X[64]); p.lo[2] = __uint_as_float(X[128]); p.geom = X[192];
+      p.hi[0] = __uint_as_float(X[256]); p.hi[1] = __uint_as_float(X[320]); p.hi[2] = __uint_as_float(X[384]); p.prim = X[448];
+      segB = X[512] & 0xFFu; segE = X[512] >> 8; node = X[576];
+      act = segE - segB > prm.minLeaf;
+    }
+    pp ^= 1u;
+  }
+  // every remaining segment is a binary leaf (the reference never splits sets of <= minLeafSize, bvh_builder_sah.h:253)
+  if (lane < n0) {
+    finalIds[gbegin + lane] = make_uint2(p.geom, p.prim);
+    if (lane == segB) ((uint4*)(bnodes + node))[2] = make_uint4(NIL, NIL, __float_as_uint(__builtin_inff()), 0u);
+  }
+  const unsigned long long leaves = __ballot(lane < n0 && lane == segB);
+  if (lane == 0u) atomicAdd(&ctr->numBLeaves, (uint32_t)__popcll(leaves));
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(64) void small_build(const SmallEntry* entries, PrimRef* bufA, PrimRef* bufB, BNode* bnodes,
+                                                  uint2* finalIds, Counters* ctr, Params prm, uint32_t W) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t s_R[];   // max(BINS_WORDS, 64 * W) words: bins / micro scratch
+  __shared__ SplitResult s_res;
+  __shared__ uint32_t s_acc[2][12];
+  __shared__ StackEntry s_stack[24];
+  __shared__ uint32_t s_cb[2][64][6];
+  __shared__ unsigned long long s_key[64];
+  uint32_t* const s_bins = s_R;
+  const uint32_t lane = threadIdx.x;
+  const SmallEntry e0 = entries[blockIdx.x];
+  StackEntry cur; cur.begin = e0.begin; cur.end = e0.end; cur.bnode = e0.bnode; cur.buf = e0.buf;
+  for (int d = 0; d < 3; d++) { cur.cmin[d] = e0.cmin[d]; cur.cmax[d] = e0.cmax[d]; }
+  uint32_t sp = 0;
+  for (uint32_t iter = 0; iter < (1u << 20); iter++) {         // the cap is a safety net only: <= 2*small_threshold iterations are possible
+    const uint32_t n = cur.end - cur.begin;
+    PrimRef* src = cur.buf ? bufB : bufA;
+    PrimRef* dst = cur.buf ? bufA : bufB;
+    if (n <= MICRO) {
+      micro_subtree(s_R, W, s_cb, s_key, src, cur.begin, n, cur.bnode, cur.cmin, cur.cmax, bnodes, finalIds, ctr, prm, lane);
+      if (sp == 0) break;
+      cur = s_stack[--sp];
+      __syncthreads();
+      continue;
+    }
+    const Mapping m = make_mapping(n, cur.cmin, cur.cmax);
+    bins_clear(s_bins, lane, 64u);
+    if (lane < 24) s_acc[lane / 12][lane % 12] = (lane % 6 < 3) ? ENC_POS_INF : ENC_NEG_INF;
+    __syncthreads();
+    {
+      BinRuns runs; runs_init(runs);
+      for (uint32_t i0 = 0; i0 < n; i0 += 64u) {
+        const bool v = i0 + lane < n;
+        PrimRef r{}; if (v) r = load_prim(src + cur.begin + i0 + lane);
+        runs_add(runs, s_bins, m, r, v, lane);
+      }
+      runs_flush_wave(runs, s_bins, lane);
+    }
+    __syncthreads();
+    sah_best_wave(s_bins, m, prm.shift, &s_res, lane);
+    __syncthreads();
+    const SplitResult r = s_res;
+    const bool fallback = r.dim < 0;
+    const uint32_t mid = fallback ? (cur.begin + cur.end) / 2u : cur.begin + r.nL;
+    const uint32_t dim = fallback ? 0u : (uint32_t)r.dim;
+    // partition into the other buffer (wave-synchronous compaction)
+    uint32_t curL = cur.begin, curR = mid;
+    uint32_t aL[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u}, aR[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
+    for (uint32_t i0 = 0; i0 < n; i0 += 64u) {
+      const uint32_t i = cur.begin + i0 + lane;
+      const bool v = i < cur.end;
+      PrimRef p{}; bool left = false;
+      if (v) {
+        p = load_prim(src + i);
+        left = fallback ? (i < mid) : (bin_unsafe(sel3(dim, p.lo[0] + p.hi[0], p.lo[1] + p.hi[1], p.lo[2] + p.hi[2]), sel3(dim, m.ofs[0], m.ofs[1], m.ofs[2]), sel3(dim, m.scale[0], m.scale[1], m.scale[2])) < r.pos);
+        const int side = left ? 0 : 1;
+        for (int d = 0; d < 3; d++) {
+          const uint32_t cc = enc(p.lo[d] + p.hi[d]);
+          if (left) { aL[d] = min(aL[d], cc); aL[3 + d] = max(aL[3 + d], cc); } else { aR[d] = min(aR[d], cc); aR[3 + d] = max(aR[3 + d], cc); }
+          if (fallback) { atomicMin(&s_acc[side][6 + d], enc(p.lo[d])); atomicMax(&s_acc[side][9 + d], enc(p.hi[d])); }
+        }
+      }
+      const unsigned long long lm = __ballot(v && left), rm = __ballot(v && !left), lt = (1ull << lane) - 1ull;
+      if (v) store_prim(dst + (left ? curL + (uint32_t)__popcll(lm & lt) : curR + (uint32_t)__popcll(rm & lt)), p);
+      curL += (uint32_t)__popcll(lm); curR += (uint32_t)__popcll(rm);
+    }
+    for (int k = 0; k < 6; k++) {
+      const uint32_t x = k < 3 ? wave_umin63(aL[k]) : wave_umax63(aL[k]), y = k < 3 ? wave_umin63(aR[k]) : wave_umax63(aR[k]);
+      if (lane == 63u) { s_acc[0][k] = x; s_acc[1][k] = y; }
+    }
+    __syncthreads();
+    const uint32_t idL = cur.bnode + 1u, idR = cur.bnode + 2u * (mid - cur.begin);
+    StackEntry L, R;
+    L.begin = cur.begin; L.end = mid; L.bnode = idL; L.buf = cur.buf ^ 1u;
+    R.begin = mid; R.end = cur.end; R.bnode = idR; R.buf = cur.buf ^ 1u;
+    for (int d = 0; d < 3; d++) {
+      L.cmin[d] = dec(s_acc[0][d]); L.cmax[d] = dec(s_acc[0][3 + d]);
+      R.cmin[d] = dec(s_acc[1][d]); R.cmax[d] = dec(s_acc[1][3 + d]);
+    }
+    if (lane == 0) {
+      BNode* par = bnodes + cur.bnode;
+      par->left = idL; par->right = idR; par->splitSah = r.sah;
+      BNode bl{}, br{};
+      bl.begin = L.begin; bl.end = L.end; br.begin = R.begin; br.end = R.end;
+      bl.left = bl.right = br.left = br.right = NIL; bl.splitSah = br.splitSah = __builtin_inff();
+      for (int d = 0; d < 3; d++) {
+        bl.lo[d] = fallback ? dec(s_acc[0][6 + d]) : r.llo[d]; bl.hi[d] = fallback ? dec(s_acc[0][9 + d]) : r.lhi[d];
+        br.lo[d] = fallback ? dec(s_acc[1][6 + d]) : r.rlo[d]; br.hi[d] = fallback ? dec(s_acc[1][9 + d]) : r.rhi[d];
+      }
+      bnodes[idL] = bl; bnodes[idR] = br;
+    }
+    // continue with the smaller child, push the larger: the stack stays <= log2(small_threshold) deep
+    const bool leftSmaller = (L.end - L.begin) <= (R.end - R.begin);
+    StackEntry keep, push;                                       // field-wise selects: a struct-valued ?: goes through scratch memory
+    keep.begin = leftSmaller ? L.begin : R.begin; keep.end = leftSmaller ? L.end : R.end; keep.bnode = leftSmaller ? L.bnode : R.bnode; keep.buf = L.buf;
+    push.begin = leftSmaller ? R.begin : L.begin; push.end = leftSmaller ? R.end : L.end; push.bnode = leftSmaller ? R.bnode : L.bnode; push.buf = L.buf;
+    for (int d = 0; d < 3; d++) {
+      keep.cmin[d] = leftSmaller ? L.cmin[d] : R.cmin[d]; keep.cmax[d] = leftSmaller ? L.cmax[d] : R.cmax[d];
+      push.cmin[d] = leftSmaller ? R.cmin[d] : L.cmin[d]; push.cmax[d] = leftSmaller ? R.cmax[d] : L.cmax[d];
+    }
+    __syncthreads();
+    if (lane == 0) s_stack[sp] = push;
+    sp++;
+    cur = keep;
+    __syncthreads();
+  }
+}

@@ -1,0 +1,170 @@
+// build_top.inl -- K2: level-synchronous top phase.
+// Part of build.hip (included inside its anonymous namespace); see the header of build.hip for the pipeline.
+// ------------------------------------------------------------------------------------ K2 top phase
+__global__ __launch_bounds__(256) void top_setup(Seg* segs, uint32_t* bins, Chunk* chunks, Counters* ctr) {
+  __shared__ uint32_t s_base;
+  const uint32_t s = blockIdx.x, tid = threadIdx.x;
+  if (s >= ctr->numSegs) return;                                // the grid is an upper bound (2^level segments at most)
+  Seg* sg = segs + s;
+  const uint32_t begin = sg->begin, end = sg->end, n = end - begin;
+  bins_clear(bins + (size_t)s * BINS_WORDS, tid, 256u);
+  const uint32_t nch = (n + CHUNK - 1u) / CHUNK;
+  if (tid == 0) {
+    const Mapping m = make_mapping(n, sg->cmin, sg->cmax);
+    for (int d = 0; d < 3; d++) { sg->ofs[d] = m.ofs[d]; sg->scale[d] = m.scale[d]; }
+    sg->nb = m.nb;
+    s_base = atomicAdd(&ctr->numChunks, nch);
+  }
+  __syncthreads();
+  for (uint32_t c = tid; c < nch; c += 256u) {
+    Chunk ck; ck.seg = s; ck.begin = begin + c * CHUNK; ck.end = min(ck.begin + CHUNK, end);
+    chunks[s_base + c] = ck;
+  }
+}
+
+__global__ __launch_bounds__(256) void top_bin(const Seg* segs, const Chunk* chunks, const PrimRef* src, uint32_t* bins, const Counters* ctr) {
+  __shared__ uint32_t s_bins[BINS_WORDS];
+  const uint32_t tid = threadIdx.x;
+  if (blockIdx.x >= ctr->numChunks) return;
+  const Chunk ck = chunks[blockIdx.x];
+  const Seg* sg = segs + ck.seg;
+  Mapping m; for (int d = 0; d < 3; d++) { m.ofs[d] = sg->ofs[d]; m.scale[d] = sg->scale[d]; } m.nb = sg->nb;
+  bins_clear(s_bins, tid, 256u);
+  __syncthreads();
+  {                                                             // each wave owns a contiguous quarter of the chunk (see BinRuns)
+    const uint32_t lane = tid & 63u, span = ck.begin + (tid >> 6) * (CHUNK / 4u), spanEnd = min(span + CHUNK / 4u, ck.end);
+    for (uint32_t i0 = span; i0 < spanEnd; i0 += 64u) {         // wave-uniform trip count
+      const uint32_t i = i0 + lane; const bool v = i < spanEnd;
+      PrimRef r{}; if (v) r = load_prim(src + i);
+      bins_add_rows(s_bins, m, r, v, lane);
+    }
+  }
+  __syncthreads();
+  uint32_t* g = bins + (size_t)ck.seg * BINS_WORDS;
+  for (uint32_t w = tid; w < (uint32_t)BINS_WORDS; w += 256u) {      // BinInfoT::merge :312-321
+    const uint32_t k = w % BINW, cnt = s_bins[w - k + 6];
+    if (cnt == 0u) continue;
+    if (k < 3) atomicMin(&g[w], s_bins[w]); else if (k < 6) atomicMax(&g[w], s_bins[w]); else atomicAdd(&g[w], s_bins[w]);
+  }
+}
+
+__global__ __launch_bounds__(64) void top_split(Seg* segs, const uint32_t* bins, BNode* bnodes, Counters* ctr, Params prm, uint32_t forceFallback) {
+  __shared__ SplitResult s_res;
+  const uint32_t s = blockIdx.x, lane = threadIdx.x;
+  if (s >= ctr->numSegs) return;
+  Seg* sg = segs + s;
+  Mapping m; for (int d = 0; d < 3; d++) { m.ofs[d] = sg->ofs[d]; m.scale[d] = sg->scale[d]; } m.nb = sg->nb;
+  sah_best_wave(bins + (size_t)s * BINS_WORDS, m, prm.shift, &s_res, lane);
+  __syncthreads();
+  if (lane == 0) {
+    const uint32_t begin = sg->begin, end = sg->end, n = end - begin;
+    SplitResult r = s_res;
+    const bool fallback = (r.dim < 0) || forceFallback;        // split invalid -> median split (split_template :144-147)
+    const uint32_t nL = fallback ? ((begin + end) / 2u - begin) : r.nL;
+    const uint32_t idL = sg->bnode + 1u, idR = sg->bnode + 2u * nL;   // implicit pre-order numbering (see K3)
+    BNode* par = bnodes + sg->bnode;
+    par->left = idL; par->right = idR; par->splitSah = r.sah;
+    BNode L{}, R{};
+    L.begin = begin; L.end = begin + nL; R.begin = begin + nL; R.end = end;
+    L.left = L.right = R.left = R.right = NIL; L.splitSah = R.splitSah = __builtin_inff();
+    for (int d = 0; d < 3; d++) { L.lo[d] = r.llo[d]; L.hi[d] = r.lhi[d]; R.lo[d] = r.rlo[d]; R.hi[d] = r.rhi[d]; }
+    bnodes[idL] = L; bnodes[idR] = R;
+    sg->flags = fallback ? 1u : 0u; sg->dim = fallback ? 0u : (uint32_t)r.dim; sg->pos = (uint32_t)r.pos; sg->nL = nL;
+    sg->childL = idL; sg->childR = idR; sg->curL = begin; sg->curR = begin + nL;
+    for (int side = 0; side < 2; side++) for (int k = 0; k < 12; k++) sg->acc[side][k] = (k % 6 < 3) ? ENC_POS_INF : ENC_NEG_INF;
+    (void)n;
+  }
+}
+
+__global__ __launch_bounds__(256) void top_partition(Seg* segs, const Chunk* chunks, const PrimRef* src, PrimRef* dst, const Counters* ctr) {
+  __shared__ uint32_t s_cnt[CHUNK_ROUNDS][4][2], s_off[CHUNK_ROUNDS][4][2], s_acc[2][12], s_baseL, s_baseR;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  if (blockIdx.x >= ctr->numChunks) return;
+  const Chunk ck = chunks[blockIdx.x];
+  Seg* sg = segs + ck.seg;
+  const bool fallback = (sg->flags & 1u) != 0u;
+  const uint32_t dim = sg->dim, pos = sg->pos, mid = sg->begin + sg->nL;
+  const float ofs = sg->ofs[dim], scale = sg->scale[dim];
+  if (tid < 24) s_acc[tid / 12][tid % 12] = (tid % 6 < 3) ? ENC_POS_INF : ENC_NEG_INF;
+  __syncthreads();
+  PrimRef pr[CHUNK_ROUNDS]; uint32_t sideBits = 0, validBits = 0; unsigned long long lm[CHUNK_ROUNDS], rm[CHUNK_ROUNDS];
+  uint32_t aL[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u}, aR[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
+#pragma unroll
+  for (int r = 0; r < CHUNK_ROUNDS; r++) {
+    const uint32_t i = ck.begin + (uint32_t)r * 256u + tid;
+    const bool v = i < ck.end;
+    if (v) pr[r] = load_prim(src + i);
+    bool left = false;
+    if (v) {
+      const float c2 = sel3(dim, pr[r].lo[0] + pr[r].hi[0], pr[r].lo[1] + pr[r].hi[1], pr[r].lo[2] + pr[r].hi[2]);
+      left = fallback ? (i < mid) : (bin_unsafe(c2, ofs, scale) < (int)pos);     // isLeft: bin_unsafe(center2) < pos (:161)
+      const int side = left ? 0 : 1;
+      for (int d = 0; d < 3; d++) {                                              // extend_center2 of the child (:168), thread-private first
+        const uint32_t cc = enc(pr[r].lo[d] + pr[r].hi[d]);
+        if (left) { aL[d] = min(aL[d], cc); aL[3 + d] = max(aL[3 + d], cc); } else { aR[d] = min(aR[d], cc); aR[3 + d] = max(aR[3 + d], cc); }
+      }
+      if (fallback) for (int d = 0; d < 3; d++) { atomicMin(&s_acc[side][6 + d], enc(pr[r].lo[d])); atomicMax(&s_acc[side][9 + d], enc(pr[r].hi[d])); }
+    }
+    lm[r] = __ballot(v && left); rm[r] = __ballot(v && !left);
+    if (lane == 0) { s_cnt[r][wave][0] = (uint32_t)__popcll(lm[r]); s_cnt[r][wave][1] = (uint32_t)__popcll(rm[r]); }
+    if (v) validBits |= 1u << r;
+    if (left) sideBits |= 1u << r;
+  }
+  for (int k = 0; k < 6; k++) {                                                  // wave-reduce the private bounds, one lane publishes
+    const uint32_t x = k < 3 ? wave_umin63(aL[k]) : wave_umax63(aL[k]), y = k < 3 ? wave_umin63(aR[k]) : wave_umax63(aR[k]);
+    if (lane == 63u) { if (k < 3) { atomicMin(&s_acc[0][k], x); atomicMin(&s_acc[1][k], y); } else { atomicMax(&s_acc[0][k], x); atomicMax(&s_acc[1][k], y); } }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    uint32_t l = 0, rr = 0;
+    for (int r = 0; r < CHUNK_ROUNDS; r++) for (int w = 0; w < 4; w++) { s_off[r][w][0] = l; s_off[r][w][1] = rr; l += s_cnt[r][w][0]; rr += s_cnt[r][w][1]; }
+    s_baseL = l ? atomicAdd(&sg->curL, l) : 0u; s_baseR = rr ? atomicAdd(&sg->curR, rr) : 0u;
+  }
+  __syncthreads();
+  const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int r = 0; r < CHUNK_ROUNDS; r++) {
+    if (!(validBits & (1u << r))) continue;
+    const bool left = (sideBits >> r) & 1u;
+    const uint32_t o = left ? s_baseL + s_off[r][wave][0] + (uint32_t)__popcll(lm[r] & lt)
+                            : s_baseR + s_off[r][wave][1] + (uint32_t)__popcll(rm[r] & lt);
+    store_prim(dst + o, pr[r]);
+  }
+  if (tid < 24) {
+    const uint32_t side = tid / 12, k = tid % 12, v = s_acc[side][k];
+    if (k % 6 < 3) { if (v != ENC_POS_INF) atomicMin(&sg->acc[side][k], v); } else { if (v != ENC_NEG_INF) atomicMax(&sg->acc[side][k], v); }
+  }
+}
+
+__global__ void top_emit(const Seg* segs, BNode* bnodes, Seg* next, SmallEntry* small, Counters* ctr,
+                         Params prm, uint32_t dstBuf, uint32_t maxNext, uint32_t maxSmall) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= ctr->numSegs) return;
+  const Seg* sg = segs + s;
+  for (int side = 0; side < 2; side++) {
+    const uint32_t b = side ? sg->begin + sg->nL : sg->begin, e = side ? sg->end : sg->begin + sg->nL;
+    const uint32_t child = side ? sg->childR : sg->childL;
+    float cmin[3], cmax[3];
+    for (int d = 0; d < 3; d++) { cmin[d] = dec(sg->acc[side][d]); cmax[d] = dec(sg->acc[side][3 + d]); }
+    if (sg->flags & 1u) for (int d = 0; d < 3; d++) { bnodes[child].lo[d] = dec(sg->acc[side][6 + d]); bnodes[child].hi[d] = dec(sg->acc[side][9 + d]); }
+    if (e - b <= prm.small) {
+      const uint32_t k = atomicAdd(&ctr->numSmall, 1u);
+      if (k >= maxSmall) { ctr->overflow = 1u; continue; }
+      SmallEntry se; se.begin = b; se.end = e; se.bnode = child; se.buf = dstBuf;
+      for (int d = 0; d < 3; d++) { se.cmin[d] = cmin[d]; se.cmax[d] = cmax[d]; }
+      small[k] = se;
+    } else {
+      const uint32_t k = atomicAdd(&ctr->numSegsNext, 1u);
+      if (k >= maxNext) { ctr->overflow = 1u; continue; }
+      Seg ns{}; ns.begin = b; ns.end = e; ns.bnode = child;
+      for (int d = 0; d < 3; d++) { ns.cmin[d] = cmin[d]; ns.cmax[d] = cmax[d]; }
+      next[k] = ns;
+    }
+  }
+}
+
+__global__ void top_advance(Counters* ctr, uint32_t maxNext) {      // end of a top level: next level's work list becomes current
+  if (ctr->numSegs) ctr->topLevels++;
+  if (ctr->numSegsNext > maxNext) ctr->overflow = 1u;
+  ctr->numSegs = ctr->numSegsNext < maxNext ? ctr->numSegsNext : maxNext; ctr->numSegsNext = 0; ctr->numChunks = 0;
+}
