@@ -198,6 +198,62 @@ __attribute__((visibility("default"))) double refd_occluded1(void* h, RTCRay* r,
 REFD_PACKET(4, 16)
 REFD_PACKET(8, 32)
 
+
+// General packet driver: rtcIntersectK / rtcOccludedK (K = 4, 8, 16) of the REAL library over an AoS array, with a per-ray
+// valid flag (valid[i] != 0 -> lane active = -1, else 0: InactiveRaysTest, tutorials/verify/verify.cpp:3553) so that the GPU
+// packet entry points can be compared with the reference's packet code path (BVHNIntersectorKHybrid, bvh_intersector_hybrid.cpp:106-369;
+// rtcIntersect16 on an AVX2 build takes the library's own single-ray fallback, rtcore.cpp:889-897).  Returns seconds.
+}  // extern "C"
+namespace {
+template <int K> struct PK;
+template <> struct PK<4>  { typedef RTCRayHit4 RH;  typedef RTCRay4 R;  static void isect(const int* v, RTCScene s, RH* p) { rtcIntersect4(v, s, p); }  static void occl(const int* v, RTCScene s, R* p) { rtcOccluded4(v, s, p); } };
+template <> struct PK<8>  { typedef RTCRayHit8 RH;  typedef RTCRay8 R;  static void isect(const int* v, RTCScene s, RH* p) { rtcIntersect8(v, s, p); }  static void occl(const int* v, RTCScene s, R* p) { rtcOccluded8(v, s, p); } };
+template <> struct PK<16> { typedef RTCRayHit16 RH; typedef RTCRay16 R; static void isect(const int* v, RTCScene s, RH* p) { rtcIntersect16(v, s, p); } static void occl(const int* v, RTCScene s, R* p) { rtcOccluded16(v, s, p); } };
+template <int K, typename RayK> void load_ray(RayK& p, unsigned k, const RTCRay& r) {
+  p.org_x[k] = r.org_x; p.org_y[k] = r.org_y; p.org_z[k] = r.org_z; p.tnear[k] = r.tnear;
+  p.dir_x[k] = r.dir_x; p.dir_y[k] = r.dir_y; p.dir_z[k] = r.dir_z; p.time[k] = r.time;
+  p.tfar[k] = r.tfar; p.mask[k] = r.mask; p.id[k] = r.id; p.flags[k] = r.flags;
+}
+template <int K> double packet_run(RefScene* s, void* rays, unsigned M, size_t stride, const int* valid, int any, int threads) {
+  return run_blocks(M, threads, [&](unsigned lo, unsigned hi) {
+    for (unsigned b = lo; b < hi; b += K) {
+      alignas(64) typename PK<K>::RH p;
+      alignas(64) int v[K];
+      memset(&p, 0, sizeof(p));
+      for (unsigned k = 0; k < K; k++) {
+        const unsigned i = b + k;
+        v[k] = (i < hi && (!valid || valid[i])) ? -1 : 0;
+        const char* rec = (const char*)rays + (size_t)(i < hi ? i : hi - 1) * stride;
+        load_ray<K>(p.ray, k, *(const RTCRay*)rec);
+        if (!any) { const RTCRayHit& rh = *(const RTCRayHit*)rec; p.hit.geomID[k] = rh.hit.geomID; p.hit.primID[k] = rh.hit.primID; p.hit.instID[0][k] = rh.hit.instID[0]; }
+      }
+      if (any) PK<K>::occl(v, s->scene, &p.ray); else PK<K>::isect(v, s->scene, &p);
+      for (unsigned k = 0; k < K && b + k < hi; k++) {
+        char* rec = (char*)rays + (size_t)(b + k) * stride;
+        // inactive lanes: the packet's tfar / hit.geomID ARE copied back (so that the caller sees whether the library touched them), the fields this
+        // driver zero-filled are not
+        if (any) { ((RTCRay*)rec)->tfar = p.ray.tfar[k]; continue; }
+        if (v[k] != -1) { RTCRayHit& r = *(RTCRayHit*)rec; r.ray.tfar = p.ray.tfar[k]; r.hit.primID = p.hit.primID[k]; r.hit.geomID = p.hit.geomID[k]; r.hit.instID[0] = p.hit.instID[0][k]; continue; }
+        RTCRayHit& r = *(RTCRayHit*)rec;
+        r.ray.tfar = p.ray.tfar[k];
+        r.hit.Ng_x = p.hit.Ng_x[k]; r.hit.Ng_y = p.hit.Ng_y[k]; r.hit.Ng_z = p.hit.Ng_z[k];
+        r.hit.u = p.hit.u[k]; r.hit.v = p.hit.v[k];
+        r.hit.primID = p.hit.primID[k]; r.hit.geomID = p.hit.geomID[k]; r.hit.instID[0] = p.hit.instID[0][k];
+      }
+    }
+  });
+}
+}  // namespace
+extern "C" {
+__attribute__((visibility("default"))) double refd_packet(void* h, int K, int any, void* rays, unsigned M, const int* valid, int threads) {
+  RefScene* s = (RefScene*)h;
+  const size_t stride = any ? sizeof(RTCRay) : sizeof(RTCRayHit);
+  if (K == 4) return packet_run<4>(s, rays, M, stride, valid, any, threads);
+  if (K == 8) return packet_run<8>(s, rays, M, stride, valid, any, threads);
+  if (K == 16) return packet_run<16>(s, rays, M, stride, valid, any, threads);
+  return -1.0;
+}
+
 __attribute__((visibility("default"))) void refd_free(void* h) {
   RefScene* s = (RefScene*)h;
   if (!s) return;

@@ -44,6 +44,8 @@ def _load():
             f = getattr(L, name)
             f.restype = ctypes.c_double
             f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint, ctypes.c_int]
+        L.refd_packet.restype = ctypes.c_double
+        L.refd_packet.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_uint, ctypes.c_void_p, ctypes.c_int]
         L.refd_free.argtypes = [ctypes.c_void_p]
         L.refd_hw_threads.restype = ctypes.c_uint
         _lib = L
@@ -106,6 +108,18 @@ class RefScene:
 
     def intersect8(self, rayhits, threads=1):
         return self._run("refd_intersect8", rayhits, threads)
+
+    def packet(self, K, rays, valid=None, any_hit=False, threads=1):
+        """rtcIntersectK / rtcOccludedK (K = 4, 8, 16) of the real library over an AoS array (RTCRayHit, or RTCRay when any_hit);
+        valid: optional int32 array, one flag per ray (0 = inactive lane)."""
+        assert rays.flags["C_CONTIGUOUS"] and rays.dtype.itemsize == (48 if any_hit else 96)
+        v = None
+        if valid is not None:
+            v = np.ascontiguousarray(valid, np.int32)
+            assert v.shape[0] == rays.shape[0]
+        dt = _load().refd_packet(self._h, K, 1 if any_hit else 0, rays.ctypes.data, rays.shape[0], v.ctypes.data if v is not None else None, threads)
+        assert dt >= 0.0, "unsupported packet size"
+        return dt
 
     def occluded1(self, rays, threads=1):
         return self._run("refd_occluded1", rays, threads)

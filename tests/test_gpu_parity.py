@@ -280,6 +280,9 @@ def test_errors_and_state_machine(api, dev):
     L.rtcNewGeometry(dev.h, 2)
     L.rtcSetSharedGeometryBuffer(None, 0, 0, 0, None, 0, 0, 0)
     assert dev.get_error() == api.RTC_ERROR_INVALID_OPERATION
+    # the NULL-handle call has no device: its error lands in the calling thread's device-less slot (device.cpp:273-279), first error wins, cleared on read
+    assert L.rtcGetDeviceError(None) == api.RTC_ERROR_INVALID_ARGUMENT
+    assert L.rtcGetDeviceError(None) == api.RTC_ERROR_NONE
     s.release()
     assert L.rtcGetErrorString(3) == b"Invalid operation"
 

@@ -705,6 +705,7 @@ def test_host_device_buffer_calls_and_scene_getters(api, dev):
     assert rh["geomID"][0] == gid and rh["instID"][0] == INVALID_ID and abs(rh["tfar"][0] - 3.0) < 1e-3
     assert rh["instID"][1] == iid and abs(rh["tfar"][1] - 2.0) < 1e-3
     dev.check()
+    assert L.rtcGetDeviceError(None) == 0                    # nothing stale in the calling thread's device-less slot (tests/conftest.py checks this after every test)
     for name in ("rtcForwardIntersect1", "rtcSetGeometryTransformQuaternion", "rtcNewBVH", "rtcPointQuery4"):
         getattr(L, name).restype = vp
         getattr(L, name)(None, None, None, None)
