@@ -1,40 +1,47 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the MI355X ray-tracing core (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W                       # configs[2], the headline
+    python bench.py --gpus N --workload shadow16m --gather rccl         # configs[3]: 16 Mi shadow rays, strong scaling, results gathered over RCCL
 
-Workload (config.workload): BASELINE.json configs[2] = "crown, 2^20 incoherent diffuse-bounce rays,
-closest-hit, 1 x MI355X".  crown.ecs is not shipped with the reference, so the scene is the seeded
-synthetic stand-in of embree_amd/workloads.py (4,762,764 triangles, 49 geometries); rays are the
-cosine-weighted bounce rays of a 1024x1024 camera image, generated with the reference's RandomSampler.
-A "step" = one closest-hit pass over one batch of 2^20 rays through rtcIntersect1MDevice, rays already
-resident in HBM (every step has its own pristine copy of the batch, staged before the timed region).
-Steps are issued round-robin on --streams HIP streams (default 4), the way a wavefront renderer keeps several
-ray batches in flight: the persistent traversal kernel fills the chip, so the next batch's blocks start as the
-blocks of the previous one retire and the tail of a batch (lanes that have run out of rays, 22 % of the
-lane-iterations of a lone 2^20-ray launch) overlaps with useful work.  --streams 1 gives the lone-launch number;
-it is measured in every run as well and reported under roofline.serial.
+Workload `crown` (default; config.workload): BASELINE.json configs[2] = "crown, 2^20 incoherent diffuse-bounce rays, closest-hit, 1 x MI355X".
+crown.ecs is not shipped with the reference, so the scene is the seeded synthetic stand-in of embree_amd/workloads.py (4,762,764 triangles,
+49 geometries) unless $EMBREE_MODEL_DIR/crown/crown.ecs exists; rays are the cosine-weighted bounce rays of a 1024 x 1024 camera image, generated
+with the reference's RandomSampler.  A "step" = one closest-hit pass over one batch of 2^20 rays through rtcIntersect1MDevice, rays already
+resident in HBM (every step has its own pristine copy of the batch, staged before the timed region).  The timed region issues the K steps back to
+back on ONE stream (--streams 1, the default): one 2^20-ray batch at a time is the configuration north_star names, the kernel's own duration
+(HIP events on its stream) is then the step time, and the roofline of the line is computed from exactly the launches that were timed.
+What a wavefront renderer does in practice -- several batches in flight on several streams, so that the tail of one batch overlaps the next --
+is measured right after the timed region and reported under "pipelined" (same kernel, same buffers, 4 streams).
 
-Multi-GPU (--gpus N, launched by torch.distributed.run, one process per GPU): the BVH is replicated
-(every rank builds it from the same inputs), each rank traces its own 2^20-ray batch (weak scaling);
-the ray path has no exchange step, so there is no data-path collective; the barrier / max-over-ranks
-uses torch.distributed (gloo) on the host.
+Workload `shadow16m`: configs[3] = 16 Mi shadow rays (16 per hit point of the configs[2] rays) through rtcOccluded1MDevice, STRONG scaling: the
+16,777,216 rays are sharded contiguously over the N ranks (embree_amd/shard.py), each rank packs its 4-byte results and the shards are gathered on
+every GPU with one ncclAllGather over xGMI (--gather rccl; 64 MB in total); a step = the whole 16 Mi-ray job incl. pack + gather.
+
+Multi-GPU (--gpus N, launched by torch.distributed.run, one process per GPU): the BVH is replicated (every rank builds it from the same inputs:
+the build is deterministic), `crown` is weak scaling (2^20 rays per rank per step, no exchange inside the timed region; the RCCL gather of the
+packed hit records is exercised and timed AFTER it, reported under "gather"), `shadow16m` is strong scaling with the gather inside.  Rendezvous,
+barrier and MAX-over-ranks use torch.distributed (gloo) on the host; the data path uses RCCL through the library's own C ABI (mi355_comm_*).
 
 Printed JSON (rank 0, one line): metric/value/... as the driver contract, plus
-  roofline      achieved = ALGORITHMIC bytes per launch / (average kernel time / launches in flight), kernel time
-                measured with HIP events on the stream each launch is issued on (kernel_ms_avg: agrees with rocprofv3
-                --kernel-trace of this command); launches in flight = sum of kernel times / wall time of the timed
-                region (concurrency).  roofline.serial = the same kernel launched alone, back to back on one stream.
-                bytes = rays*(48 read + 52 written on hit) + visited nodes*80 + fetched
-                triangle records*48 (visit counts from the counting build of the same kernel, same rays).
-  cpu_baseline  the REAL reference (oracle/_ref, Embree 4.4.1 AVX2) looping rtcIntersect1 over the same
-                rays on all host threads (kind "reference"), or the scalar C restatement on a sample (kind "port").
+  roofline      bound "hbm" as SURVEY 8(d) prescribes: achieved = ALGORITHMIC bytes per launch / average kernel duration of the TIMED launches
+                (HIP events on the launch stream; agrees with rocprofv3 --kernel-trace of this command); bytes = rays*(48 read + 52 written on
+                hit) + visited nodes*80 + fetched triangle records*48, visit counts from the counting build of the same kernel on the same rays.
+                Most of those bytes are L1/L2/Infinity-Cache hits, so next to it: `hbm_counter` (PMC FETCH_SIZE x2 + WRITE_SIZE per launch, from
+                profiles/pmc_bench_latest.json, only if that file was collected for THIS kernel source -- else null) and `valu`, the roof that
+                actually binds (SQ_INSTS_VALU per launch x 4 cycles / (1024 SIMDs x measured clock) / kernel time).
+  pipelined     the same kernel with --pipeline-streams batches in flight (throughput, concurrency)
+  end_to_end    rtcIntersect1M on a pageable host array: H2D + kernel + D2H (PCIe-inclusive; never `value`)
+  cpu_baseline  the REAL reference (oracle/_ref, Embree 4.4.1 AVX2) looping rtcIntersect1 over the same rays on the host threads (kind
+                "reference") with its rtcCommitScene timed 1 + 5 times, or the scalar C restatement on a sample (kind "port")
+  parity_vs_reference  the timed kernel's output against the reference on all rays, exact-t ties classified (tests/helpers.py); bench.py FAILS on a mismatch
 """
 import argparse
 import ctypes as C
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -44,50 +51,79 @@ sys.path.insert(0, ROOT)
 # HIP multiplexes its streams onto 4 hardware queues by default, one of them the null stream's: streams that share a queue
 # run one after the other.  Ask for 8 so that every batch stream gets its own queue (must be set before the runtime starts).
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-from embree_amd import api, loaders, workloads as W           # noqa: E402  (loads the HIP library before anything else)
-from embree_amd.rtypes import RAYHIT_DTYPE, INVALID_ID         # noqa: E402
+from embree_amd import api, loaders, shard, workloads as W           # noqa: E402  (loads the HIP library before anything else)
+from embree_amd.rtypes import RAYHIT_DTYPE, RAY_DTYPE, INVALID_ID, rays_of   # noqa: E402
+from tools.kernel_hash import trace_kernel_hash                        # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md (6.29 TB/s measured copy rate)
+NUM_SIMDS = 256 * 4     # CUs x SIMDs
 PMC_JSON = os.path.join(ROOT, "profiles", "pmc_bench_latest.json")   # written by tools/pmc_summary.py from rocprofv3 --pmc passes of THIS command
-
-
-def pmc_traffic():
-    """HBM bytes per launch of the traversal kernel from the committed PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE), or None."""
-    try:
-        d = json.load(open(PMC_JSON))
-        return int(d["hbm_traffic_bytes_per_launch"])
-    except Exception:
-        return None
-
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def cpu_baseline(meshes, rays, budget_s=25.0):
-    """Reference leg, rank 0 / N=1 only.  Never touches the GPU path."""
+def load_pmc():
+    """PMC counters per launch of the closest-hit kernel, but only if they were collected for the kernel source that is being run."""
+    try:
+        d = json.load(open(PMC_JSON))
+    except Exception:
+        return None, "no PMC file"
+    if d.get("source_hash") != trace_kernel_hash():
+        return None, "profiles/pmc_bench_latest.json was collected for another build of the kernel (source hash %s, now %s)" % (d.get("source_hash"), trace_kernel_hash())
+    return d, None
+
+
+# ----------------------------------------------------------------------------------------------------------------- CPU leg (rank 0, N = 1)
+def cpu_baseline(meshes, rays, any_hit=False, budget_s=25.0):
+    """Reference leg.  Never touches the GPU path."""
     from oracle import refembree, restate
+    ntri = W.num_triangles(meshes)
     if refembree.available():
-        threads = refembree.hw_threads()
-        s = refembree.RefScene("threads=%d" % threads)
+        hw = refembree.hw_threads()
+        # ---- build: rtcCommitScene wall time, a NEW scene per repetition (buildbench_device.cpp:385-387), 1 warm-up + 5 timed, for a few thread counts
+        # (the internal tasking system does not scale to every box's full thread count)
+        build = {}
+        t_start = time.time()
+        for th in sorted({hw, min(hw, 64), min(hw, 16)}, reverse=True):
+            times = []
+            for rep in range(6):
+                sc = refembree.RefScene("threads=%d" % th)
+                for v, t in meshes:
+                    sc.add_mesh(v, t)
+                dt = sc.commit()
+                sc.close()
+                if rep:
+                    times.append(dt)
+                if time.time() - t_start > 60.0 and len(times) >= 2:
+                    break
+            build[th] = times
+        best_th = min(build, key=lambda k: min(build[k]))
+        bt = build[best_th]
+        s = refembree.RefScene("threads=%d" % hw)
         for v, t in meshes:
             s.add_mesh(v, t)
-        build_s = s.commit()
+        s.commit()
         n = rays.shape[0]
-        best, reps, spent = None, 0, 0.0
+        run = s.occluded1 if any_hit else s.intersect1
         warm = rays.copy()
-        s.intersect1(warm, threads)
+        run(warm, hw)
+        best, reps, spent, all_dt = None, 0, 0.0, []
         while reps < 5 and spent < budget_s:
             r = rays.copy()
-            dt = s.intersect1(r, threads)
+            dt = run(r, hw)
+            all_dt.append(dt)
             best = dt if best is None else min(best, dt)
             spent += dt
             reps += 1
-        out = dict(value=n / best / 1e6, unit="Mrays/s", cores=threads, kind="reference",
-                   sample="all %d rays of the step, rtcIntersect1 in 1024-ray blocks on %d threads, best of %d; "
-                          "Embree 4.4.1 AVX2 single-ISA build (oracle/ref.mk); CPU build %.2f s = %.1f Mprims/s"
-                          % (n, threads, reps, build_s, W.num_triangles(meshes) / build_s / 1e6))
+        out = dict(value=n / best / 1e6, unit="Mrays/s", cores=hw, kind="reference",
+                   median=n / float(np.median(all_dt)) / 1e6,
+                   sample="all %d rays of the step, %s in 1024-ray blocks on %d threads (FTZ/DAZ), 1 warm-up + best of %d; Embree 4.4.1 AVX2 single-ISA build (oracle/ref.mk)"
+                          % (n, "rtcOccluded1" if any_hit else "rtcIntersect1", hw, reps),
+                   build=dict(mprims_per_s=ntri / min(bt) / 1e6, best_s=min(bt), median_s=float(np.median(bt)), threads=best_th, reps=len(bt),
+                              what="rtcCommitScene wall time, new scene per repetition, 1 warm-up + %d timed; thread counts tried: %s"
+                                   % (len(bt), {k: round(min(v), 3) for k, v in build.items()})))
         s.close()
         return out, warm
     if not restate.available():
@@ -99,31 +135,88 @@ def cpu_baseline(meshes, rays, budget_s=25.0):
     n = min(rays.shape[0], 65536)
     r = rays[:n].copy()
     t0 = time.time()
-    s.intersect1(r)
+    (s.occluded1 if any_hit else s.intersect1)(r)
     dt = time.time() - t0
     return dict(value=n / dt / 1e6, unit="Mrays/s", cores=1, kind="port",
                 sample="first %d rays of the step, scalar C restatement (oracle/restate.c)" % n), None
 
 
+def classify_parity(got, want, rays_in, meshes):
+    """IDs bit-exact except classified exact-t ties, t within 1e-4: the same check the GPU tests use; raises AssertionError on a real difference."""
+    from oracle import restate
+    from tests.helpers import compare_closest
+    o = restate.OracleScene()
+    for v, t in meshes:
+        o.add_mesh(v, t)
+    st = compare_closest(got, want, rays_in, o.triangle_t, max_tie_frac=1e-3, label="bench vs reference")
+    same = (got["primID"] == want["primID"]) & (got["geomID"] == want["geomID"])
+    hit = same & (want["geomID"] != INVALID_ID)
+    rel = float(np.max(np.abs(got["tfar"][hit] - want["tfar"][hit]) / np.maximum(np.abs(want["tfar"][hit]), 1e-30))) if hit.any() else None
+    return dict(rays=int(got.shape[0]), id_mismatch=int((~same).sum()), classified_exact_t_ties=st["ties"], unexplained=0, max_rel_t_err=rel)
+
+
+# ----------------------------------------------------------------------------------------------------------------- helpers
+class Events:
+    def __init__(self, L, n):
+        self.L, self.ev = L, [C.c_void_p() for _ in range(2 * n)]
+        for e in self.ev:
+            L.mi355_event_create(C.byref(e))
+
+    def ms(self, k):
+        v = C.c_float()
+        self.L.mi355_event_elapsed_ms(self.ev[2 * k], self.ev[2 * k + 1], C.byref(v))
+        return v.value
+
+    def free(self):
+        for e in self.ev:
+            self.L.mi355_event_destroy(e)
+
+
+def run_guarded(fn, timeout_s):
+    """Runs fn() on a helper thread and gives up waiting after timeout_s (a collective that never completes must not take the result line down)."""
+    box = {}
+
+    def body():
+        try:
+            box["value"] = fn()
+        except Exception as e:                                 # noqa: BLE001
+            box["error"] = repr(e)
+    th = threading.Thread(target=body, daemon=True)
+    th.start()
+    th.join(timeout_s)
+    if th.is_alive():
+        return dict(error="timed out after %d s" % timeout_s)
+    return box.get("value") if "value" in box else dict(error=box.get("error", "unknown"))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=60)
-    ap.add_argument("--warmup", type=int, default=12)
-    ap.add_argument("--rays", type=int, default=1 << 20)
-    ap.add_argument("--streams", type=int, default=4, help="HIP streams the steps are issued on round-robin (ray batches in flight)")
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--workload", default="crown", choices=["crown", "shadow16m"])
+    ap.add_argument("--rays", type=int, default=1 << 20, help="crown: rays per batch and GPU; shadow16m: hit points (x16 shadow rays), all GPUs together")
+    ap.add_argument("--streams", type=int, default=1, help="HIP streams the TIMED steps are issued on round-robin (1 = one batch at a time)")
+    ap.add_argument("--pipeline-streams", type=int, default=4, help="batches in flight of the extra `pipelined` leg (0 = skip it)")
+    ap.add_argument("--gather", default="auto", choices=["auto", "rccl", "none"], help="results gathered on the GPUs over RCCL (auto: rccl when more than one rank)")
     ap.add_argument("--phi", type=int, default=158, help="sphere tessellation of the synthetic crown (158 -> 4.76M triangles)")
     ap.add_argument("--config", default="", help="extra rtcNewDevice config, e.g. max_leaf=2,int_cost=0.5")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--scene", default="", help=".ecs / .xml / .obj scene file; default: $EMBREE_MODEL_DIR/crown/crown.ecs if it exists, "
                                                  "else the synthetic crown stand-in")
     args = ap.parse_args()
+    shadow = args.workload == "shadow16m"
+    if args.steps is None:
+        args.steps = 10 if shadow else 60
+    if args.warmup is None:
+        args.warmup = 2 if shadow else 12
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world and world > 1:
         log("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world))
+    use_rccl = args.gather == "rccl" or (args.gather == "auto" and world > 1)
     L = api.load()
     ngpu = L.mi355_device_count()
     if ngpu <= 0:
@@ -147,8 +240,18 @@ def main():
             os.close(saved_fd)
         dist = (dist_mod, torch)
 
+    def barrier():
+        if dist:
+            dist[0].barrier()
+
+    def max_over_ranks(x):
+        if not dist:
+            return float(x)
+        tt = dist[1].tensor([x], dtype=dist[1].float64)
+        dist[0].all_reduce(tt, op=dist[0].ReduceOp.MAX)
+        return float(tt[0])
+
     # ---- scene: replicated BVH, geometry resident on the device
-    t0 = time.time()
     scene_path = args.scene or loaders.find_model("crown")
     if scene_path:                                         # the real asset when the box has it (the reference does not ship it)
         loaded = loaders.load_scene(scene_path)
@@ -158,169 +261,302 @@ def main():
         meshes, camera = W.synthetic_crown(num_phi=args.phi), None
         scene_name = "synthetic-crown (crown.ecs is not shipped)"
     ntri = W.num_triangles(meshes)
-    gen_s = time.time() - t0
     scene = api.Scene(dev)
     for v, t in meshes:
         scene.add_triangle_mesh(v, t, device_resident=True)      # rtcSetSharedGeometryBufferHostDevice: no upload at commit
     build_ms, commit_wall = [], []
-    for rep in range(3):                                   # rtcCommitScene timed like buildbench (buildbench_device.cpp:385-387)
-        t0 = time.time()
+    for rep in range(1 + 5):                               # rtcCommitScene timed like buildbench (buildbench_device.cpp:385-387): 1 warm-up + 5
+        scene.touch()                                      # a commit of an unmodified scene returns at once (scene.cpp:831): mark it modified
+        t0 = time.perf_counter()
         scene.commit()
-        commit_wall.append(time.time() - t0)
-        build_ms.append(scene.info()["build_ms"])
+        if rep:
+            commit_wall.append(time.perf_counter() - t0)
+            build_ms.append(scene.info()["build_ms"])
     info = scene.info()
     # the same scene with RTC_BUILD_QUALITY_LOW (Morton build), reported next to the SAH build; the timed rays use the SAH tree
     low_ms = []
     L.rtcSetSceneBuildQuality(scene.h, api.RTC_BUILD_QUALITY_LOW)
-    for rep in range(3):
+    for rep in range(4):
+        scene.touch()
         scene.commit()
-        low_ms.append(scene.info()["build_ms"])
+        if rep:
+            low_ms.append(scene.info()["build_ms"])
     low_info = scene.info()
     L.rtcSetSceneBuildQuality(scene.h, api.RTC_BUILD_QUALITY_MEDIUM)
     scene.commit()
     assert scene.info()["num_nodes"] == info["num_nodes"]
+    bvh = scene.bvh()
 
-    # ---- rays: primary image traced on the GPU -> diffuse bounce rays (this rank's own seed)
+    # ---- rays: primary image traced on the GPU -> diffuse bounce rays
     side = int(round(args.rays ** 0.5))
     prim = (W.camera_rays(camera["vp"], camera["vi"], camera["vu"], camera["fov"], side, side) if camera
             else W.crown_camera_rays(meshes, side, side))
-    M = prim.shape[0]
     dprim = api.DeviceArray.from_numpy(prim, gpu)
-    scene.intersect1M_device(dprim.ptr, M)
+    scene.intersect1M_device(dprim.ptr, prim.shape[0])
     L.mi355_device_synchronize(gpu)
     traced = dprim.download(RAYHIT_DTYPE)
     dprim.free()
-    rays = W.diffuse_bounce_rays(traced, meshes, seed=1 + rank)
+    if shadow:                                             # configs[3]: 16 shadow rays per hit point of the bounce rays; this rank's contiguous shard of the 16 * rays
+        bounce = W.diffuse_bounce_rays(traced, meshes, seed=1)
+        db = api.DeviceArray.from_numpy(bounce, gpu)
+        scene.intersect1M_device(db.ptr, bounce.shape[0])
+        L.mi355_device_synchronize(gpu)
+        bounce = db.download(RAYHIT_DTYPE)
+        db.free()
+        total_rays = 16 * bounce.shape[0]
+        lo, hi = shard.shard_range(total_rays, rank, world)
+        assert lo % 16 == 0 and hi % 16 == 0 and (hi - lo) * world == total_rays, "the ray count must split evenly over the ranks"
+        rays = W.shadow_rays(bounce[lo // 16: hi // 16], meshes, samples=16, first=lo)
+        rec, dtype, any_hit = 48, RAY_DTYPE, 1
+    else:
+        rays = W.diffuse_bounce_rays(traced, meshes, seed=1 + rank)   # this rank's own batch (weak scaling)
+        total_rays = rays.shape[0] * world
+        rec, dtype, any_hit = 96, RAYHIT_DTYPE, 0
+    M = rays.shape[0]
 
+    npipe = max(0, args.pipeline_streams) if not shadow else 0
     streams = []
-    for _ in range(max(1, args.streams)):
+    for _ in range(max(1, args.streams, npipe)):
         st_ = C.c_void_p()
         L.mi355_stream_create(gpu, C.byref(st_))
         streams.append(st_)
-    stream = streams[0]
-    nserial = min(args.steps, 10)                             # lone-launch leg (roofline.serial), after the timed region
-    nbuf = args.steps + args.warmup + nserial
+    tstreams = streams[:max(1, args.streams)]
+    nbuf = args.steps + args.warmup
     pristine = api.DeviceArray.from_numpy(rays, gpu)
     bufs = [api.DeviceArray(rays.nbytes, gpu) for _ in range(nbuf)]
-    for b in bufs:
-        L.mi355_memcpy_d2d_async(b.ptr, pristine.ptr, rays.nbytes, stream)
-    L.mi355_synchronize(stream)
+
+    def restore(which):
+        for b in which:
+            L.mi355_memcpy_d2d_async(b.ptr, pristine.ptr, rays.nbytes, streams[0])
+        L.mi355_synchronize(streams[0])
+    restore(bufs)
 
     # ---- visit counts for the algorithmic-bytes figure (counting build of the same kernel, same rays)
     dstat = api.DeviceArray.from_numpy(rays, gpu)
-    st = scene.trace_stats(dstat.ptr, M, 96)
-    result = dstat.download(RAYHIT_DTYPE)
+    st = scene.trace_stats(dstat.ptr, M, rec, any_hit=bool(any_hit))
+    result = dstat.download(dtype)
     dstat.free()
-    nhit = int((result["geomID"] != INVALID_ID).sum())
-    alg_bytes = M * 48 + nhit * 52 + st["nodes"] * 80 + st["tris"] * 48
+    if shadow:
+        nhit = int(np.isneginf(result["tfar"]).sum())
+        alg_bytes = M * 48 + M * 4 + st["nodes"] * 80 + st["tris"] * 48
+    else:
+        nhit = int((result["geomID"] != INVALID_ID).sum())
+        alg_bytes = M * 48 + nhit * 52 + st["nodes"] * 80 + st["tris"] * 48
 
-    def barrier():
-        if dist:
-            dist[0].barrier()
+    # ---- RCCL: communicator + result buffers (shadow16m: used inside the timed region; crown: exercised after it)
+    comm, comm_err, packed, gathered = None, None, None, None
+    pack_bytes = M * (4 if shadow else 32)
+    if use_rccl:
+        res = run_guarded(lambda: shard.Communicator(gpu, rank, world, dist[0] if dist else None), 120)
+        if isinstance(res, dict):
+            comm_err = res["error"]
+            log("rank %d: RCCL communicator unavailable (%s): results stay in the per-rank buffers" % (rank, comm_err))
+        else:
+            comm = res
+        ok = 0.0 if comm is None else 1.0
+        if dist:                                           # every rank must agree before a collective is issued
+            tt = dist[1].tensor([ok], dtype=dist[1].float64)
+            dist[0].all_reduce(tt, op=dist[0].ReduceOp.MIN)
+            ok = float(tt[0])
+        if ok < 1.0 and comm is not None:
+            comm.close()
+            comm, comm_err = None, comm_err or "another rank has no communicator"
+        if comm is not None:
+            packed = api.DeviceArray(pack_bytes, gpu)
+            gathered = api.DeviceArray(pack_bytes * world, gpu)
+
+    def step(buf, stream, ev_a=None, ev_b=None):
+        """one pass of the hot path over one batch (+ pack and gather where the workload has them)"""
+        rc = L.mi355_trace_timed(bvh, buf.ptr, M, rec, any_hit, stream, ev_a, ev_b)
+        assert rc == 0, L.mi355_last_error()
+        if shadow and comm is not None:
+            assert L.mi355_pack_occluded(buf.ptr, M, rec, packed.ptr, stream) == 0, L.mi355_last_error()
+            comm.allgather(packed.ptr, gathered.ptr, pack_bytes, stream)
 
     for st_ in streams:                                     # per-stream traversal scratch exists before anything is timed (also when --warmup 0)
-        assert L.mi355_trace_prepare(scene.bvh(), st_) == 0, L.mi355_last_error()
+        assert L.mi355_trace_prepare(bvh, st_) == 0, L.mi355_last_error()
     for i in range(args.warmup):
-        scene.intersect1M_device(bufs[i].ptr, M, 96, streams[i % len(streams)])
+        step(bufs[i], tstreams[i % len(tstreams)])
     L.mi355_device_synchronize(gpu)
 
-    ev = [C.c_void_p() for _ in range(2 * args.steps)]
-    for e in ev:
-        L.mi355_event_create(C.byref(e))
-    bvh = scene.bvh()
+    # ================================================================================================ the timed region
+    ev = Events(L, args.steps)
     barrier()
     L.mi355_device_synchronize(gpu)
     t0 = time.perf_counter()
     for k in range(args.steps):
-        # rtcIntersect1MDevice's launch (mi355_trace_closest) with a HIP event on either side of the kernel
-        rc = L.mi355_trace_timed(bvh, bufs[args.warmup + k].ptr, M, 96, 0, streams[k % len(streams)], ev[2 * k], ev[2 * k + 1])
-        assert rc == 0, L.mi355_last_error()
+        step(bufs[args.warmup + k], tstreams[k % len(tstreams)], ev.ev[2 * k], ev.ev[2 * k + 1])
     L.mi355_device_synchronize(gpu)
     barrier()
-    elapsed = time.perf_counter() - t0
-    if dist:
-        tt = dist[1].tensor([elapsed], dtype=dist[1].float64)
-        dist[0].all_reduce(tt, op=dist[0].ReduceOp.MAX)
-        elapsed = float(tt[0])
-    kernel_ms = []
-    for k in range(args.steps):
-        ms = C.c_float()
-        L.mi355_event_elapsed_ms(ev[2 * k], ev[2 * k + 1], C.byref(ms))
-        kernel_ms.append(ms.value)
-    # lone launches, back to back on one stream (outside the timed region): the kernel's own duration
-    evs = [C.c_void_p() for _ in range(2 * nserial)]
-    for e in evs:
-        L.mi355_event_create(C.byref(e))
-    t1 = time.perf_counter()
-    for k in range(nserial):
-        rc = L.mi355_trace_timed(bvh, bufs[args.warmup + args.steps + k].ptr, M, 96, 0, stream, evs[2 * k], evs[2 * k + 1])
-        assert rc == 0, L.mi355_last_error()
-    L.mi355_device_synchronize(gpu)
-    serial_elapsed = time.perf_counter() - t1
-    serial_ms = []
-    for k in range(nserial):
-        ms = C.c_float()
-        L.mi355_event_elapsed_ms(evs[2 * k], evs[2 * k + 1], C.byref(ms))
-        serial_ms.append(ms.value)
+    elapsed = max_over_ranks(time.perf_counter() - t0)
+    # ================================================================================================
+    kernel_ms = [ev.ms(k) for k in range(args.steps)]
+    ev.free()
+    for st_ in tstreams:
+        assert scene.trace_status(st_) == 0, "a traversal safety net dropped work"
     # every timed buffer must hold the same answer as the counting run (same rays, same tree)
-    for b in (bufs[args.warmup], bufs[args.warmup + args.steps - 1], bufs[-1]):
-        assert b.download(RAYHIT_DTYPE).tobytes() == result.tobytes(), "timed kernel and counting kernel disagree"
+    for b in (bufs[args.warmup], bufs[-1]):
+        assert b.download(dtype).tobytes() == result.tobytes(), "timed kernel and counting kernel disagree"
+    gather_check = None
+    if shadow and comm is not None:                        # every rank holds all shards: rank r's part must be what rank r computed
+        g = gathered.download(np.uint32).reshape(world, M)
+        assert (g[rank] == result["tfar"].view(np.uint32)).all(), "gathered shard differs from the local result"
+        occl = np.array([int((g[r] == 0xFF800000).sum()) for r in range(world)], np.int64)
+        mine = dist[1].tensor([int(np.isneginf(result["tfar"]).sum())], dtype=dist[1].int64) if dist else None
+        if dist:
+            allc = [dist[1].zeros(1, dtype=dist[1].int64) for _ in range(world)]
+            dist[0].all_gather(allc, mine)
+            assert [int(a[0]) for a in allc] == occl.tolist(), "gathered occlusion counts differ from what the ranks computed"
+        gather_check = dict(transport="RCCL ncclAllGather over xGMI", bytes_total=pack_bytes * world, occluded_per_rank=occl.tolist())
+
+    # ---- extra legs, outside the timed region --------------------------------------------------------------------------------------
+    pipelined = None
+    if npipe > 1 and not shadow:                           # several batches in flight, as a wavefront renderer keeps them
+        nps = min(args.steps, 40)
+        restore(bufs[:nps])
+        evp = Events(L, nps)
+        for i in range(min(8, nps)):                       # warm the extra streams
+            step(bufs[i], streams[i % npipe])
+        L.mi355_device_synchronize(gpu)
+        restore(bufs[:nps])
+        t1 = time.perf_counter()
+        for k in range(nps):
+            step(bufs[k], streams[k % npipe], evp.ev[2 * k], evp.ev[2 * k + 1])
+        L.mi355_device_synchronize(gpu)
+        pel = time.perf_counter() - t1
+        pms = [evp.ms(k) for k in range(nps)]
+        evp.free()
+        assert bufs[0].download(dtype).tobytes() == result.tobytes()
+        pipelined = dict(value=round(M * nps / pel / 1e6, 1), unit="Mrays/s", batches_in_flight=npipe, steps=nps, ms_per_step=round(1e3 * pel / nps, 4),
+                         kernel_ms_avg=round(float(np.mean(pms)), 4), concurrency=round(float(np.sum(pms)) * 1e-3 / pel, 3),
+                         what="the same launches issued round-robin on %d HIP streams: the tail of one batch overlaps the next; per-GPU figure" % npipe)
+    e2e = None
+    if not shadow and rank == 0:                           # PCIe-inclusive: the blocking host-array entry point on a pageable numpy array
+        times = []
+        for _ in range(3):
+            h = rays.copy()
+            t1 = time.perf_counter()
+            scene.intersect1M(h)
+            times.append(time.perf_counter() - t1)
+        assert h.tobytes() == result.tobytes()
+        e2e = dict(value=round(M / min(times) / 1e6, 1), unit="Mrays/s", ms=round(1e3 * min(times), 3),
+                   what="rtcIntersect1M on a pageable host array of %d RTCRayHit: pin + H2D (96 MB) + kernel + D2H (96 MB), pipelined in chunks; best of 3" % M)
+    gather = None
+    if not shadow and comm is not None:                    # crown: the north-star gather of the packed hit records, exercised and timed outside the headline
+        def do_gather():
+            evg = Events(L, 1)
+            L.mi355_event_record(evg.ev[0], streams[0])
+            assert L.mi355_pack_hits(bufs[-1].ptr, M, rec, packed.ptr, streams[0]) == 0, L.mi355_last_error()
+            comm.gather(packed.ptr, gathered.ptr, pack_bytes, 0, streams[0])
+            L.mi355_event_record(evg.ev[1], streams[0])
+            deadline = time.time() + 60
+            while L.mi355_stream_query(streams[0]) == 1:
+                if time.time() > deadline:
+                    return dict(error="gather did not complete within 60 s")
+                time.sleep(0.001)
+            ms = evg.ms(0)
+            out = dict(transport="RCCL ncclGather to GPU 0 over xGMI", bytes_per_rank=pack_bytes, ms=round(ms, 3))
+            if rank == 0:
+                g = gathered.download(np.uint32).reshape(world, M, 8)
+                assert (g[0][:, 0] == result["tfar"].view(np.uint32)).all() and (g[0][:, 3] == result["primID"]).all() and (g[0][:, 4] == result["geomID"]).all()
+                out["gb_per_s_into_root"] = round(pack_bytes * (world - 1) / (ms * 1e-3) / 1e9, 1) if world > 1 else None
+            return out
+        gather = run_guarded(do_gather, 90)
 
     if rank == 0:
         avg_ms = float(np.mean(kernel_ms))
-        conc = float(np.sum(kernel_ms)) * 1e-3 / elapsed       # launches in flight, averaged over the timed region
-        eff_ms = avg_ms / max(conc, 1.0)                       # a launch that shares the chip with c-1 others gets 1/c of it
-        ser_ms = float(np.mean(serial_ms)) if serial_ms else avg_ms
-        value = world * M * args.steps / elapsed / 1e6
+        conc = float(np.sum(kernel_ms)) * 1e-3 / elapsed
+        value = total_rays * args.steps / elapsed / 1e6 if shadow else world * M * args.steps / elapsed / 1e6
+        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+        pmc, pmc_note = load_pmc() if not shadow else (None, "PMC passes are collected for the closest-hit kernel only")
+        roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": int(pmc["hbm_traffic_bytes_per_launch"]) if pmc and "hbm_traffic_bytes_per_launch" in pmc else None,
+                "kernel": "trace_kernel_q<%s>" % ("any" if shadow else "closest"), "kernel_ms_avg": round(avg_ms, 4), "kernel_ms_min": round(float(np.min(kernel_ms)), 4),
+                "launches_timed": args.steps, "launches_in_flight": round(conc, 3),
+                "algorithmic_bytes_per_launch": int(alg_bytes),
+                "per_ray": {"nodes": round(st["nodes"] / M, 2), "node_step_simd_util": round(st["nodes"] / max(1, 64 * st["node_blocks"]), 3),
+                            "tri_step_simd_util": round(st["tris"] / max(1, 64 * st["tri_blocks"]), 3),
+                            "triangles": round(st["tris"] / M, 2), "empty_node_visits": round(st["empty_nodes"] / M, 2), "bytes": round(alg_bytes / M, 1)},
+                "note": "achieved = algorithmic bytes (SURVEY 8d) per launch / average duration of the timed launches (HIP events on the launch stream). Most of these bytes are "
+                        "served by L1 / L2 / Infinity Cache: hbm_counter is what reaches the memory side, valu is the roof that binds."}
+        if len(tstreams) > 1:
+            roof["note"] += " The timed launches overlap (launches_in_flight): a launch then owns 1/launches_in_flight of the chip."
+        if pmc:
+            c = pmc["counters"]
+            clock_hz = pmc.get("kernel_cycles", 0.0) / (avg_ms * 1e-3) if pmc.get("kernel_cycles") else 2.4e9
+            clock_hz = min(max(clock_hz, 1.0e9), 2.4e9)
+            roof["hbm_counter"] = {"bytes_per_launch": int(pmc["hbm_traffic_bytes_per_launch"]), "achieved": round(pmc["hbm_traffic_bytes_per_launch"] / (avg_ms * 1e-3) / 1e9, 1),
+                                   "frac": round(pmc["hbm_traffic_bytes_per_launch"] / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                   "what": "rocprofv3 --pmc FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE per launch of this kernel source (profiles/pmc_bench_latest.json, hash %s); includes Infinity-Cache hits" % pmc["source_hash"]}
+            if "SQ_INSTS_VALU" in c:
+                valu_s = c["SQ_INSTS_VALU"] * 4.0 / (NUM_SIMDS * clock_hz)
+                roof["valu"] = {"wave_instructions_per_launch": int(c["SQ_INSTS_VALU"]), "cycles_per_instruction": 4, "clock_ghz": round(clock_hz / 1e9, 3),
+                                "issue_ms": round(valu_s * 1e3, 4), "frac": round(valu_s / (avg_ms * 1e-3), 4),
+                                "what": "SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x clock) / kernel time: the share of the launch in which the VALU pipes issue (clock = GRBM_GUI_ACTIVE / 8 / kernel time of the PMC run, capped at 2.4 GHz)"}
+        else:
+            roof["pmc_note"] = pmc_note
         out = {
-            "metric": "Mrays/s (incoherent diffuse, closest-hit) on crown", "value": round(value, 2), "unit": "Mrays/s",
+            "metric": ("Mrays/s (shadow rays, any-hit) on crown, 16 Mi rays sharded" if shadow else "Mrays/s (incoherent diffuse, closest-hit) on crown"),
+            "value": round(value, 2), "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic" if not scene_path else "file",
-            "config": {"workload": "configs[2]: %s, %d triangles, %d geometries, "
-                                   "%d incoherent diffuse-bounce rays per GPU, closest-hit, rays + BVH resident in HBM"
-                                   % (scene_name, ntri, len(meshes), M),
-                       "rays_per_gpu": M, "triangles": ntri, "batches_in_flight": len(streams),
-                       "parallelism": "rays sharded x%d, BVH replicated, no collective" % world,
+            "higher_is_better": True, "scaling": "strong" if shadow else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic" if not scene_path else "file",
+            "config": {"workload": ("configs[3]: %s, %d triangles, %d shadow rays (16 per hit point) in total, %d per GPU, rtcOccluded1MDevice, rays + BVH resident in HBM, results %s"
+                                    % (scene_name, ntri, total_rays, M, "packed and all-gathered over RCCL" if comm is not None else "left in the per-rank buffers")) if shadow else
+                                   ("configs[2]: %s, %d triangles, %d geometries, %d incoherent diffuse-bounce rays per GPU and step, closest-hit, rays + BVH resident in HBM, one batch at a time"
+                                    % (scene_name, ntri, len(meshes), M)),
+                       "rays_per_gpu": M, "triangles": ntri, "batches_in_flight": len(tstreams),
+                       "parallelism": "rays sharded x%d, BVH replicated (deterministic build on every rank), %s" % (world, "RCCL all-gather of the 4-byte results inside the step" if (shadow and comm is not None) else "no collective inside the step"),
                        "device_config": args.config},
-            "roofline": {"bound": "hbm", "achieved": round(alg_bytes / (eff_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(alg_bytes / (eff_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(),
-                         "kernel": "trace_kernel_q<closest>", "kernel_ms_avg": round(avg_ms, 4), "kernel_ms_min": round(float(np.min(kernel_ms)), 4),
-                         "concurrency": round(conc, 3),
-                         "note": "achieved = algorithmic bytes (SURVEY 8d) per launch / (kernel time / launches in flight); most of these bytes are served by L1/L2/Infinity "
-                                 "Cache (traffic = HBM bytes per launch from the PMC passes), so the fraction of the HBM peak can exceed 1; the kernel is VALU-issue bound",
-                         "serial": {"kernel_ms_avg": round(ser_ms, 4), "kernel_ms_min": round(float(np.min(serial_ms)), 4) if serial_ms else None,
-                                    "achieved": round(alg_bytes / (ser_ms * 1e-3) / 1e9, 1), "frac": round(alg_bytes / (ser_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                    "mrays_per_s": round(M * nserial / serial_elapsed / 1e6, 1) if nserial else None, "launches": nserial},
-                         "algorithmic_bytes_per_launch": int(alg_bytes),
-                         "per_ray": {"nodes": round(st["nodes"] / M, 2), "node_step_simd_util": round(st["nodes"] / max(1, 64 * st["node_blocks"]), 3),
-                                     "tri_step_simd_util": round(st["tris"] / max(1, 64 * st["tri_blocks"]), 3),
-                                     "triangles": round(st["tris"] / M, 2), "bytes": round(alg_bytes / M, 1)}},
-            "build": {"metric": "BVH build Mprims/s", "gpu_build_ms": round(float(np.min(build_ms)), 3),
+            "roofline": roof,
+            "build": {"metric": "BVH build Mprims/s", "gpu_build_ms": round(float(np.min(build_ms)), 3), "gpu_build_ms_median": round(float(np.median(build_ms)), 3),
                       "mprims_per_s_gpu": round(ntri / (float(np.min(build_ms)) * 1e-3) / 1e6, 1),
-                      "commit_wall_ms": round(1e3 * float(np.min(commit_wall)), 3),
-                      "mprims_per_s_commit": round(ntri / float(np.min(commit_wall)) / 1e6, 1),
+                      "commit_wall_ms": round(1e3 * float(np.min(commit_wall)), 3), "commit_wall_ms_median": round(1e3 * float(np.median(commit_wall)), 3),
+                      "mprims_per_s_commit": round(ntri / float(np.min(commit_wall)) / 1e6, 1), "reps": "1 warm-up + %d timed (buildbench_device.cpp:385-387)" % len(build_ms),
+                      "kernel_launches": info.get("num_launches"), "host_syncs": info.get("num_host_syncs"),
                       "nodes": info["num_nodes"], "leaves": info["num_leaves"], "sah": round(info["sah"], 3),
                       "bvh_bytes": info["bytes_nodes"] + info["bytes_triangles"],
                       "low_quality": {"what": "RTC_BUILD_QUALITY_LOW: Morton-code build, same node/leaf layout", "gpu_build_ms": round(float(np.min(low_ms)), 3),
                                       "mprims_per_s_gpu": round(ntri / (float(np.min(low_ms)) * 1e-3) / 1e6, 1), "sah": round(low_info["sah"], 3)}},
             "hit_fraction": round(nhit / M, 4),
         }
+        if pipelined:
+            out["pipelined"] = pipelined
+        if e2e:
+            out["end_to_end"] = e2e
+        if gather is not None:
+            out["gather"] = gather
+        if gather_check is not None:
+            out["gather"] = gather_check
+        if use_rccl and comm is None:
+            out["gather"] = {"error": comm_err}
+        failed = None
         if world == 1 and not args.no_cpu:
             try:
-                cb, ref_traced = cpu_baseline(meshes, rays)
+                cb, ref_traced = cpu_baseline(meshes, rays, any_hit=shadow)
                 if cb:
                     out["cpu_baseline"] = cb
-                if ref_traced is not None:                    # free parity check at full size against the real reference
-                    same = (ref_traced["primID"] == result["primID"]) & (ref_traced["geomID"] == result["geomID"])
-                    out["parity_vs_reference"] = {"rays": M, "id_mismatch": int((~same).sum()),
-                                                  "max_rel_t_err": float(np.max(np.abs(ref_traced["tfar"][same] - result["tfar"][same]) /
-                                                                                np.maximum(np.abs(ref_traced["tfar"][same]), 1e-30))) if same.any() else None}
+                if ref_traced is not None and not shadow:        # parity at full size against the real reference, ties classified
+                    try:
+                        out["parity_vs_reference"] = classify_parity(result, ref_traced, rays, meshes)
+                    except AssertionError as e:
+                        out["parity_vs_reference"] = {"FAILED": str(e)}
+                        failed = str(e)
+                elif ref_traced is not None:
+                    flips = int((np.isneginf(ref_traced["tfar"]) != np.isneginf(result["tfar"])).sum())
+                    out["parity_vs_reference"] = {"rays": M, "occlusion_flips": flips}
+                    if flips > 1e-5 * M:
+                        failed = "%d occlusion results differ from the reference" % flips
             except Exception as e:                            # the baseline leg must never take the GPU number down
                 out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
+        if failed:
+            log("PARITY FAILURE: " + failed)
+            os._exit(1)
     barrier()
     if dist:
         dist[0].destroy_process_group()
+    sys.stdout.flush()
+    os._exit(0)                                              # (a helper thread stuck in a collective must not keep the process alive)
 
 
 if __name__ == "__main__":

@@ -45,9 +45,10 @@ rtcTraversableOccluded1 rtcTraversableOccluded4 rtcTraversableOccluded8 rtcTrave
 rtcIntersect1M rtcOccluded1M rtcIntersect1MDevice rtcOccluded1MDevice""".split()
 MI355_SYMBOLS = """mi355_default_build_params mi355_last_error mi355_device_count mi355_device_name mi355_bvh_build
 mi355_bvh_destroy mi355_bvh_build_instanced mi355_bvh_refit mi355_release_build_scratch mi355_bvh_get_info mi355_bvh_download mi355_trace_prepare mi355_trace_closest mi355_trace_any
-mi355_trace_closest_packet mi355_trace_any_packet mi355_trace_stats mi355_trace_timed mi355_malloc mi355_free mi355_memcpy_h2d
+mi355_trace_closest_packet mi355_trace_any_packet mi355_trace_stats mi355_trace_timed mi355_trace_status mi355_malloc mi355_free mi355_memcpy_h2d
 mi355_memcpy_d2h mi355_synchronize mi355_device_synchronize mi355_memcpy_d2d_async mi355_stream_create
-mi355_stream_destroy mi355_event_create mi355_event_record mi355_event_elapsed_ms mi355_event_destroy""".split()
+mi355_stream_destroy mi355_event_create mi355_event_record mi355_event_elapsed_ms mi355_event_destroy
+mi355_comm_unique_id mi355_comm_init mi355_comm_destroy mi355_comm_allgather mi355_comm_gather mi355_pack_hits mi355_pack_occluded mi355_stream_query""".split()
 
 
 class BuildParams(C.Structure):
@@ -179,6 +180,9 @@ def load():
     L.mi355_trace_any.argtypes = [vp, vp, u32, sz, vp]
     L.mi355_trace_timed.argtypes = [vp, vp, u32, sz, C.c_int, vp, vp, vp]
     L.mi355_trace_stats.argtypes = [vp, vp, u32, sz, C.c_int, C.POINTER(C.c_uint64)]
+    L.mi355_trace_status.argtypes = [vp, vp, C.POINTER(u32)]
+    L.mi355_trace_closest_packet.argtypes = [vp, vp, vp, u32, u32, sz, vp]
+    L.mi355_trace_any_packet.argtypes = [vp, vp, vp, u32, u32, sz, vp]
     L.mi355_malloc.argtypes = [C.c_int, sz, C.POINTER(vp)]
     L.mi355_free.argtypes = [vp]
     L.mi355_memcpy_h2d.argtypes = [vp, vp, sz]
@@ -193,6 +197,14 @@ def load():
     L.mi355_event_record.argtypes = [vp, vp]
     L.mi355_event_elapsed_ms.argtypes = [vp, vp, C.POINTER(C.c_float)]
     L.mi355_event_destroy.argtypes = [vp]
+    L.mi355_comm_unique_id.argtypes = [vp]
+    L.mi355_comm_init.argtypes = [C.c_int, vp, C.c_int, C.c_int, C.POINTER(vp)]
+    L.mi355_comm_destroy.argtypes = [vp]
+    L.mi355_comm_allgather.argtypes = [vp, vp, vp, sz, vp]
+    L.mi355_comm_gather.argtypes = [vp, vp, vp, sz, C.c_int, vp]
+    L.mi355_pack_hits.argtypes = [vp, u32, sz, vp, vp]
+    L.mi355_pack_occluded.argtypes = [vp, u32, sz, vp, vp]
+    L.mi355_stream_query.argtypes = [vp]
     _lib = L
     return L
 
@@ -383,6 +395,16 @@ class Scene:
         self.L.rtcCommitScene(self.h)
         self.dev.check()
 
+    def touch(self, gid=0):
+        """Marks the scene modified the way an application does: rtcUpdateGeometryBuffer(INDEX) + rtcCommitGeometry on one geometry, so that the
+        next rtcCommitScene builds again (a commit of an unmodified scene returns at once, kernels/common/scene.cpp:831).  Nothing is uploaded for
+        device-resident shared buffers."""
+        g = self.L.rtcGetGeometry(self.h, gid)
+        self.dev.check()
+        self.L.rtcUpdateGeometryBuffer(g, RTC_BUFFER_TYPE_INDEX, 0)
+        self.L.rtcCommitGeometry(g)
+        self.dev.check()
+
     def bounds(self):
         b = RTCBounds()
         self.L.rtcGetSceneBounds(self.h, C.byref(b))
@@ -433,6 +455,13 @@ class Scene:
     def occluded1M_device(self, dptr, count, stride=48, stream=None):
         self.L.rtcOccluded1MDevice(self.h, dptr, count, stride, None, stream)
         self.dev.check()
+
+    def trace_status(self, stream=None):
+        """mi355_trace_status: synchronises `stream`, returns (and clears) the flags the traversal kernels raised on it (0 = no work was dropped)."""
+        f = C.c_uint32(0)
+        if self.L.mi355_trace_status(self.bvh(), stream, C.byref(f)) != 0:
+            raise RuntimeError(self.L.mi355_last_error().decode())
+        return f.value
 
     def trace_stats(self, dptr, count, stride, any_hit=False):
         out = (C.c_uint64 * 16)()

@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libembree4_mi355.so")
-SOURCES = ["build.hip", "trace.hip", "rtcore_api.cpp"]
+SOURCES = ["build.hip", "trace.hip", "shard.hip", "rtcore_api.cpp"]
 HEADERS = ["bvh_common.h", "internal.h", "../../include/embree4/rtcore.h", "../../include/embree_amd_hip.h",
            "build_common.inl", "build_primref.inl", "build_presplit.inl", "build_binning.inl", "build_top.inl", "build_small.inl",
            "build_morton.inl", "build_wide.inl", "build_leaves.inl"]    # parts of build.hip (one translation unit)
@@ -39,7 +39,7 @@ def build(force=False, verbose=False):
             print(" ".join(cmd))
         subprocess.check_call(cmd)
         objs.append(obj)
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-z,now", "-o", LIB] + objs
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-z,now", "-o", LIB] + objs + ["-ldl"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -103,12 +103,17 @@ TraceScratch* Bvh::scratch_for(hipStream_t s) {
   if (hipMalloc((void**)&sc.counter, 4096) != hipSuccess) return nullptr;
   if (hipMalloc(&sc.spill, trace_spill_bytes(numCUs, info.depth)) != hipSuccess) return nullptr;
   if (hipMalloc((void**)&sc.stats, 128) != hipSuccess) return nullptr;
+  { void* h = nullptr; void* d = nullptr;
+    if (hipHostMalloc(&h, 64, hipHostMallocMapped) != hipSuccess) return nullptr;
+    memset(h, 0, 64);
+    if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) return nullptr;
+    sc.statusHost = (volatile uint32_t*)h; sc.statusDev = (volatile uint32_t*)d; }
   sc.enqueue = new std::mutex;
   return &(scratch[s] = sc);
 }
 Bvh::~Bvh() {
   hipSetDevice(device);
-  for (auto& kv : scratch) { hipFree(kv.second.counter); hipFree(kv.second.spill); hipFree(kv.second.stats); delete kv.second.enqueue; }
+  for (auto& kv : scratch) { hipFree(kv.second.counter); hipFree(kv.second.spill); hipFree(kv.second.stats); if (kv.second.pkt) hipFree(kv.second.pkt); hipHostFree((void*)kv.second.statusHost); delete kv.second.enqueue; }
   if (d_nodes) hipFree(d_nodes);
   if (d_tris) hipFree(d_tris);
   if (d_ids) hipFree(d_ids);

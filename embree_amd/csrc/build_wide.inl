@@ -168,10 +168,15 @@ __global__ __launch_bounds__(1024) void wide_scan(uint2* groupSum, Counters* ctr
 }
 
 // Quantises the child boxes of 8 nodes at once (lane = 8 * node + slot): plane = org + q * 2^(e-127), lower planes rounded down, upper planes
-// rounded up, verified in fp32.  Shared by wide_emit and refit_level so that a refitted node is what a build would have written for the same boxes.
+// rounded up, verified EXACTLY: org, q and the power-of-two scale span fewer than 53 bits, so org + q * scale is exact in fp64.  (An fp32 check
+// accepts fl(org + q * scale) == lo while the exact plane lies up to half an ulp of lo INSIDE the child box -- 0.004 at coordinates of 1e5 -- and the
+// fast traversal path evaluates the exact plane, q * (scale * rdir) + (org - ray.org) * rdir; the robust path's fmaf(q, scale, org) rounds a plane
+// that is <= lo to a value <= lo, so it stays conservative too.)  Shared by wide_emit and refit_level so that a refitted node is what a build would
+// have written for the same boxes.
+__device__ __forceinline__ double plane_exact(float q, float sc, float org) { return (double)org + (double)q * (double)sc; }
 __device__ __forceinline__ void quantise_slots(bool has, uint32_t lane, const float (&lo)[3], const float (&hi)[3], const float (&olo)[3], const float (&ohi)[3],
                                                uint32_t (&ex)[3], uint32_t (&qa)[3], uint32_t (&qb)[3]) {
-  // ---- quantise: plane = org + q * 2^(e-127), lower rounded down, upper rounded up, verified in fp32
+  // ---- quantise: plane = org + q * 2^(e-127), lower rounded down, upper rounded up
   for (int d = 0; d < 3; d++) {
     const float ext = ohi[d] - olo[d];
     int e = 1;                                                // biased exponent, scale = 2^(e-127)
@@ -179,7 +184,7 @@ __device__ __forceinline__ void quantise_slots(bool has, uint32_t lane, const fl
     for (;;) {                                                // grow the scale until every upper plane of the node fits in 8 bits
       const float sc = __uint_as_float((uint32_t)e << 23);
       bool fits = true;
-      if (has) { float q = ceilf((hi[d] - olo[d]) / sc); while (fmaf(q, sc, olo[d]) < hi[d]) q += 1.0f; fits = q <= 255.0f; }
+      if (has) { float q = ceilf((hi[d] - olo[d]) / sc); while (plane_exact(q, sc, olo[d]) < (double)hi[d]) q += 1.0f; fits = q <= 255.0f; }
       const bool grpFits = ((__ballot(!fits) >> (lane & ~7u)) & 0xFFull) == 0ull;
       const bool stop = grpFits || e >= 254;
       if (!stop) e++;
@@ -190,9 +195,9 @@ __device__ __forceinline__ void quantise_slots(bool has, uint32_t lane, const fl
     if (has) {
       const float sc = __uint_as_float(ex[d] << 23);
       float a = floorf((lo[d] - olo[d]) / sc); if (a < 0.0f) a = 0.0f; if (a > 255.0f) a = 255.0f;
-      while (a > 0.0f && fmaf(a, sc, olo[d]) > lo[d]) a -= 1.0f;
+      while (a > 0.0f && plane_exact(a, sc, olo[d]) > (double)lo[d]) a -= 1.0f;
       float b = ceilf((hi[d] - olo[d]) / sc); if (b < 0.0f) b = 0.0f;
-      while (b < 255.0f && fmaf(b, sc, olo[d]) < hi[d]) b += 1.0f;
+      while (b < 255.0f && plane_exact(b, sc, olo[d]) < (double)hi[d]) b += 1.0f;
       if (b > 255.0f) b = 255.0f;
       qa[d] = (uint32_t)a; qb[d] = (uint32_t)b;
     }

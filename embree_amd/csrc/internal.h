@@ -22,6 +22,9 @@ struct TraceScratch {
   uint32_t* counter = nullptr;   // ray cursor of the persistent kernel
   void* spill = nullptr;         // stack spill area
   uint64_t* stats = nullptr;     // 8 counters for the counting build
+  void* pkt = nullptr; size_t pktCap = 0;    // AoS staging of the packet entry points (grows on demand)
+  volatile uint32_t* statusHost = nullptr;   // pinned host memory the kernels raise their "work was dropped" words in (iteration cap, stack overflow) ...
+  volatile uint32_t* statusDev = nullptr;    // ... and its device address
 };
 
 struct Bvh {

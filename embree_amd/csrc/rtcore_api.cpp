@@ -122,6 +122,7 @@ struct Buffer : RefCounted {
 struct BufferView { Buffer* buf = nullptr; size_t offset = 0, stride = 0; unsigned num = 0; };
 
 struct Scene;
+static std::atomic<unsigned long long> g_commitSerial{0};
 struct Geometry : RefCounted {
   Device* device; RTCGeometryType type;
   BufferView vertices, indices;
@@ -183,8 +184,11 @@ struct Scene : RefCounted {
   mi355_bvh_t bvh = nullptr; ssize_t bvhBytes = 0; bool committed = false, modified = true;
   ssize_t flatBytes = 0;
   mi355_bvh_t flat = nullptr;                               // the tree of this scene's own triangles / quads: what an instance of this scene refers to (== bvh unless the scene has instances)
-  struct BuiltFrom { unsigned id; Geometry* g; unsigned topo, data; };   // what the current tree was built from: decides rebuild vs refit
+  struct BuiltFrom { unsigned id; Geometry* g; unsigned topo, data; };   // what the current tree was built from: decides rebuild vs refit vs nothing to do
   std::vector<BuiltFrom> builtFrom; unsigned builtFlags = 0;
+  struct InstFrom { unsigned id; Geometry* g; Scene* object; unsigned topo, data; unsigned long long objSerial; };
+  std::vector<InstFrom> builtInst;
+  unsigned long long commitSerial = 0;                       // changes with every commit that built or refitted something (instances of this scene notice)
   RTCBounds bounds;
   RTCProgressMonitorFunction progress = nullptr; void* progressPtr = nullptr;
   // host-pointer query staging (device memory), one per calling thread
@@ -244,7 +248,22 @@ struct Scene : RefCounted {
       wantRefit = wantRefit || g->quality == RTC_BUILD_QUALITY_REFIT;
     }
     bp.refit = wantRefit ? 1u : 0u;
-    const unsigned nowFlags = (bp.robust ? 1u : 0u) | (bp.quality << 1);
+    const unsigned nowFlags = (bp.robust ? 1u : 0u) | (bp.quality << 1) | (bp.refit << 8);
+    // Scene::commit returns at once when nothing was modified since the last commit (kernels/common/scene.cpp:831, isModified()): same geometries, same
+    // buffer bindings / index data / vertex data / masks / transforms (the per-geometry counters), same enable state, same flags and quality.  Instances
+    // also look at the scene they refer to: a re-committed object scene has a new commit number.
+    std::vector<InstFrom> instFrom;
+    for (auto& kv : geoms) {
+      Geometry* g = kv.second;
+      if (g->type != RTC_GEOMETRY_TYPE_INSTANCE || !g->enabled || !g->object) continue;
+      instFrom.push_back({kv.first, g, g->object, g->topoCounter, g->dataCounter, g->object->commitSerial});
+    }
+    if (committed && bvh && nowFlags == builtFlags && from.size() == builtFrom.size() && instFrom.size() == builtInst.size()) {
+      bool same = true;
+      for (size_t i = 0; same && i < from.size(); i++) { const BuiltFrom &a = from[i], &b = builtFrom[i]; same = a.id == b.id && a.g == b.g && a.topo == b.topo && a.data == b.data; }
+      for (size_t i = 0; same && i < instFrom.size(); i++) { const InstFrom &a = instFrom[i], &b = builtInst[i]; same = a.id == b.id && a.g == b.g && a.object == b.object && a.topo == b.topo && a.data == b.data && a.objSerial == b.objSerial; }
+      if (same) { if (progress) progress(progressPtr, 1.0); return; }
+    }
     // Refit instead of rebuild (the reference: BVHNRefitT for RTC_BUILD_QUALITY_REFIT meshes of a dynamic scene, kernels/bvh/bvh_refit.cpp):
     // same geometries with the same buffer bindings and index data, and every geometry whose vertices / mask changed asks for REFIT.
     bool refit = flat && committed && from.size() == builtFrom.size() && nowFlags == builtFlags && !from.empty();
@@ -254,6 +273,11 @@ struct Scene : RefCounted {
     }
     mi355_bvh_info info;
     bool done = false;
+    {                                                        // the scene's own triangles / quads are what they were: only instances moved, keep the flat tree
+      bool flatSame = flat && committed && from.size() == builtFrom.size() && nowFlags == builtFlags;
+      for (size_t i = 0; flatSame && i < from.size(); i++) { const BuiltFrom &a = from[i], &b = builtFrom[i]; flatSame = a.id == b.id && a.g == b.g && a.topo == b.topo && a.data == b.data; }
+      if (flatSame) { done = true; refit = false; }
+    }
     if (refit) { mi355_bvh_get_info(flat, &info); refit = info.bytes_refit != 0; }   // the tree was built to be refitted
     if (refit) {
       const int rc = mi355_bvh_refit(flat, meshes.data(), (uint32_t)meshes.size(), nullptr);
@@ -303,7 +327,8 @@ struct Scene : RefCounted {
              info.build_ms > 0 ? info.num_triangles / (info.build_ms * 1e3) : 0.0, info.sah, (unsigned long long)info.num_nodes,
              (unsigned long long)info.num_triangles, (unsigned long long)(info.bytes_nodes + info.bytes_triangles));
     if (progress) progress(progressPtr, 1.0);
-    committed = true; modified = false;
+    builtInst = instFrom;
+    committed = true; modified = false; commitSerial = ++g_commitSerial;
   }
 };
 
@@ -347,6 +372,14 @@ mi355_bvh_t committed_bvh(Scene* s) {
   return s->bvh;
 }
 
+// the kernels' safety nets (iteration cap, stack bound) drop work rather than hang; a blocking query that ran into one reports it instead of returning a wrong answer
+static void check_trace_status(mi355_bvh_t b, hipStream_t q) {
+  uint32_t flags = 0;
+  core_check(mi355_trace_status(b, q, &flags), "trace status");
+  if (flags & MI355_TRACE_ITER_CAP_HIT) THROW(RTC_ERROR_UNKNOWN, "traversal stopped at its iteration cap: results are incomplete");
+  if (flags & MI355_TRACE_STACK_OVERFLOW) THROW(RTC_ERROR_UNKNOWN, "traversal stack overflow: results are incomplete");
+}
+
 // Large host arrays: the caller's array is pinned for the duration of the call and cut into chunks that alternate between two streams, so that the upload
 // of one chunk, the traversal of the previous one and the download of the one before overlap (PCIe is full duplex; pageable copies would serialise).
 // Returns false when the array cannot be pinned (the plain path takes over).
@@ -369,6 +402,7 @@ static bool pipelined_query(Scene* s, mi355_bvh_t b, char* data, char* d, unsign
     hip_check(hipMemcpyAsync(data + ofs, d + ofs, nb, hipMemcpyDeviceToHost, q), "hipMemcpyAsync(rays D2H)");
   }
   hip_check(hipStreamSynchronize(st[0]), "hipStreamSynchronize"); hip_check(hipStreamSynchronize(st[1]), "hipStreamSynchronize");
+  check_trace_status(b, st[0]); if (c > 1) check_trace_status(b, st[1]);
   return true;
 }
 
@@ -387,17 +421,31 @@ void host_query(Scene* s, void* data, unsigned M, size_t stride, bool any) {
   hip_check(hipMemcpy(d, data, bytes, hipMemcpyHostToDevice), "hipMemcpy(rays H2D)");
   core_check(any ? mi355_trace_any(b, d, M, stride, nullptr) : mi355_trace_closest(b, d, M, stride, nullptr), "trace");
   hip_check(hipMemcpy(data, d, bytes, hipMemcpyDeviceToHost), "hipMemcpy(rays D2H)");
+  check_trace_status(b, nullptr);
 }
+// rtcIntersect4/8/16, rtcOccluded4/8/16 on a host packet: the K lanes are turned into AoS records on the host (RayHitK::get / set, kernels/common/ray.h:283-376),
+// the active ones go through the batch path as one launch, and only active lanes are written back (InactiveRaysTest, verify.cpp:3553).
 void host_packet_query(Scene* s, const int* valid, void* packet, unsigned K, bool any) {
-  mi355_bvh_t b = committed_bvh(s);
-  const size_t pbytes = (size_t)K * 4 * (any ? 12 : 21);
-  hip_check(hipSetDevice(s->device->gpu), "hipSetDevice");
-  char* d = s->stage(pbytes + 64 + K * 4);
-  hip_check(hipMemcpy(d, packet, pbytes, hipMemcpyHostToDevice), "hipMemcpy(packet H2D)");
-  int* dv = (int*)(d + ((pbytes + 63) / 64) * 64);
-  hip_check(hipMemcpy(dv, valid, K * 4, hipMemcpyHostToDevice), "hipMemcpy(valid H2D)");
-  core_check(any ? mi355_trace_any_packet(b, dv, d, K, 1, pbytes, nullptr) : mi355_trace_closest_packet(b, dv, d, K, 1, pbytes, nullptr), "trace packet");
-  hip_check(hipMemcpy(packet, d, pbytes, hipMemcpyDeviceToHost), "hipMemcpy(packet D2H)");
+  if (!valid || !packet) THROW(RTC_ERROR_INVALID_ARGUMENT, "invalid argument");
+  const unsigned nf = any ? 12u : 21u, recw = any ? 12u : 24u;
+  alignas(16) uint32_t aos[16 * 24];
+  unsigned lane[16], n = 0;
+  const uint32_t* pk = (const uint32_t*)packet;
+  for (unsigned k = 0; k < K; k++) {
+    if (valid[k] != -1) continue;
+    uint32_t* r = aos + (size_t)n * recw;
+    for (unsigned f = 0; f < nf; f++) r[f] = pk[f * K + k];
+    for (unsigned f = nf; f < recw; f++) r[f] = 0u;
+    lane[n++] = k;
+  }
+  if (n == 0) { committed_bvh(s); return; }
+  host_query(s, aos, n, recw * 4, any);
+  uint32_t* out = (uint32_t*)packet;
+  for (unsigned j = 0; j < n; j++) {
+    const uint32_t* r = aos + (size_t)j * recw; const unsigned k = lane[j];
+    out[8 * K + k] = r[8];                                   // tfar
+    if (!any && r[12 + 6] != RTC_INVALID_GEOMETRY_ID) for (unsigned f = 12; f < 21; f++) out[f * K + k] = r[f];
+  }
 }
 
 }  // namespace

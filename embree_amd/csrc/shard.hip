@@ -1,0 +1,152 @@
+// shard.hip -- multi-GPU result exchange for sharded ray batches (BASELINE.json north_star: "ray batches shard
+// embarrassingly across the 8 GPUs of one node with the BVH replicated and hits gathered over RCCL/xGMI").
+//
+// The reference has no multi-process code at all: a host application that wants N GPUs runs one process per GPU, every process commits the
+// same scene (the GPU build is deterministic, so the trees are bit-identical and nothing has to be broadcast), traces its contiguous ray
+// range [g*M/G, (g+1)*M/G) and hands the results to whoever consumes them.  This file is that last step when the consumer is a GPU:
+//   * pack kernels squeeze the fields a query WRITES out of the AoS ray records (RTCRayHit: tfar, Ng, u, v, primID, geomID = 32 B of the
+//     96-byte record; RTCRay after rtcOccluded: tfar = 4 B of 48), so that only results travel;
+//   * a thin wrapper over RCCL (librccl.so.1, loaded on first use so that single-GPU applications never map its 570 MB) gathers the packed
+//     shards on every GPU (ncclAllGather) or on one (ncclGather).  xGMI is point to point (7 links per GPU): a gather to one root uses the
+//     root's 7 links in parallel; an all-gather is a ring and costs (G-1)/G of the total per link, so it is meant for the 4-byte occlusion
+//     results (64 MB for 16 Mi shadow rays), not for full hit records.
+// The rendezvous (who is rank r, the 128-byte ncclUniqueId) is the host's business: bench.py / embree_amd/shard.py pass the id around with
+// torch.distributed (gloo).  Plain C ABI, declared in include/embree_amd_hip.h.
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <stdint.h>
+#include <string.h>
+#include <mutex>
+#include <string>
+#include "../../include/embree_amd_hip.h"
+#include "internal.h"
+
+namespace {
+
+// ---- result records -----------------------------------------------------------------------------------------------------------------
+// RTCRayHit (include/embree4/rtcore.h): tfar at byte 32, Ng_x..u at 48..63, v, primID, geomID at 64..75.  One lane per ray, two 16-byte stores.
+__global__ void pack_hits_kernel(const char* rays, uint32_t count, uint32_t stride, uint4* out) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+    const char* r = rays + (size_t)i * stride;
+    const uint32_t tfar = *(const uint32_t*)(r + 32);
+    const uint4 a = *(const uint4*)(r + 48);            // Ng_x, Ng_y, Ng_z, u
+    const uint4 b = *(const uint4*)(r + 64);            // v, primID, geomID, instID[0]
+    out[2 * (size_t)i] = make_uint4(tfar, a.w, b.x, b.y);       // tfar, u, v, primID
+    out[2 * (size_t)i + 1] = make_uint4(b.z, a.x, a.y, a.z);    // geomID, Ng
+  }
+}
+// RTCRay after an occlusion query: only tfar changed (-inf = occluded)
+__global__ void pack_occluded_kernel(const char* rays, uint32_t count, uint32_t stride, uint32_t* out) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x)
+    out[i] = *(const uint32_t*)(rays + (size_t)i * stride + 32);
+}
+
+// ---- RCCL, bound at run time ------------------------------------------------------------------------------------------------------------
+typedef struct { char internal[128]; } rcclUniqueId;        // ncclUniqueId, rccl.h: NCCL_UNIQUE_ID_BYTES = 128
+typedef void* rcclComm;
+struct Rccl {
+  void* lib = nullptr;
+  int (*GetUniqueId)(rcclUniqueId*) = nullptr;
+  int (*CommInitRank)(rcclComm*, int, rcclUniqueId, int) = nullptr;
+  int (*CommDestroy)(rcclComm) = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int, rcclComm, hipStream_t) = nullptr;
+  int (*Gather)(const void*, void*, size_t, int, int, rcclComm, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  std::string err;
+};
+Rccl* rccl() {
+  static std::mutex m; static Rccl* r = nullptr;
+  std::lock_guard<std::mutex> lk(m);
+  if (r) return r;
+  r = new Rccl;
+  const char* names[] = {getenv("MI355_RCCL_LIB"), "librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
+  for (const char* n : names) { if (!n) continue; r->lib = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (r->lib) break; r->err = dlerror(); }
+  if (!r->lib) return r;
+  auto sym = [&](const char* s) { void* p = dlsym(r->lib, s); if (!p) r->err = std::string("missing RCCL symbol ") + s; return p; };
+  r->GetUniqueId = (int (*)(rcclUniqueId*))sym("ncclGetUniqueId");
+  r->CommInitRank = (int (*)(rcclComm*, int, rcclUniqueId, int))sym("ncclCommInitRank");
+  r->CommDestroy = (int (*)(rcclComm))sym("ncclCommDestroy");
+  r->AllGather = (int (*)(const void*, void*, size_t, int, rcclComm, hipStream_t))sym("ncclAllGather");
+  r->Gather = (int (*)(const void*, void*, size_t, int, int, rcclComm, hipStream_t))sym("ncclGather");
+  r->GetErrorString = (const char* (*)(int))sym("ncclGetErrorString");
+  if (!r->GetUniqueId || !r->CommInitRank || !r->CommDestroy || !r->AllGather || !r->Gather) { dlclose(r->lib); r->lib = nullptr; }
+  return r;
+}
+int rccl_fail(const char* what, int rc) {
+  Rccl* r = rccl();
+  std::string m = std::string(what) + ": " + (r->lib && r->GetErrorString ? r->GetErrorString(rc) : r->err.c_str());
+  return mi355::set_error(hipErrorUnknown, m.c_str());
+}
+constexpr int RCCL_INT8 = 0;   // ncclInt8 = ncclChar = 0 (rccl.h): everything travels as bytes
+
+}  // namespace
+
+struct mi355_comm { rcclComm comm; int device, world, rank; };
+
+extern "C" {
+
+int mi355_pack_hits(const void* d_rayhit, uint32_t count, size_t stride, void* d_out, void* stream) {
+  if (count == 0) return 0;
+  if (stride < 96 || (stride & 15u) || ((uintptr_t)d_rayhit & 15u) || ((uintptr_t)d_out & 15u)) return mi355::set_error(hipErrorInvalidValue, "mi355_pack_hits: 16-byte aligned RTCRayHit records expected");
+  const uint32_t blocks = (count + 255u) / 256u < 4096u ? (count + 255u) / 256u : 4096u;
+  hipLaunchKernelGGL(pack_hits_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const char*)d_rayhit, count, (uint32_t)stride, (uint4*)d_out);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+int mi355_pack_occluded(const void* d_ray, uint32_t count, size_t stride, void* d_out, void* stream) {
+  if (count == 0) return 0;
+  if (stride < 48 || (stride & 3u)) return mi355::set_error(hipErrorInvalidValue, "mi355_pack_occluded: RTCRay records expected");
+  const uint32_t blocks = (count + 255u) / 256u < 4096u ? (count + 255u) / 256u : 4096u;
+  hipLaunchKernelGGL(pack_occluded_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const char*)d_ray, count, (uint32_t)stride, (uint32_t*)d_out);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int mi355_comm_unique_id(void* out128) {
+  Rccl* r = rccl();
+  if (!r->lib) return rccl_fail("RCCL is not available", 0);
+  rcclUniqueId id; memset(&id, 0, sizeof(id));
+  const int rc = r->GetUniqueId(&id);
+  if (rc) return rccl_fail("ncclGetUniqueId", rc);
+  memcpy(out128, &id, sizeof(id));
+  return 0;
+}
+int mi355_comm_init(int device, const void* id128, int world, int rank, mi355_comm_t* out) {
+  *out = nullptr;
+  Rccl* r = rccl();
+  if (!r->lib) return rccl_fail("RCCL is not available", 0);
+  if (world < 1 || rank < 0 || rank >= world) return mi355::set_error(hipErrorInvalidValue, "mi355_comm_init: rank outside the world");
+  HIP_TRY(hipSetDevice(device));
+  rcclUniqueId id; memcpy(&id, id128, sizeof(id));
+  rcclComm c = nullptr;
+  const int rc = r->CommInitRank(&c, world, id, rank);
+  if (rc) return rccl_fail("ncclCommInitRank", rc);
+  *out = new mi355_comm{c, device, world, rank};
+  return 0;
+}
+void mi355_comm_destroy(mi355_comm_t c) {
+  if (!c) return;
+  Rccl* r = rccl();
+  if (r->lib && c->comm) { hipSetDevice(c->device); r->CommDestroy(c->comm); }
+  delete c;
+}
+int mi355_comm_allgather(mi355_comm_t c, const void* d_send, void* d_recv, size_t bytes_per_rank, void* stream) {
+  if (!c) return mi355::set_error(hipErrorInvalidValue, "mi355_comm_allgather: no communicator");
+  HIP_TRY(hipSetDevice(c->device));
+  const int rc = rccl()->AllGather(d_send, d_recv, bytes_per_rank, RCCL_INT8, c->comm, (hipStream_t)stream);
+  return rc ? rccl_fail("ncclAllGather", rc) : 0;
+}
+int mi355_comm_gather(mi355_comm_t c, const void* d_send, void* d_recv, size_t bytes_per_rank, int root, void* stream) {
+  if (!c) return mi355::set_error(hipErrorInvalidValue, "mi355_comm_gather: no communicator");
+  HIP_TRY(hipSetDevice(c->device));
+  const int rc = rccl()->Gather(d_send, d_recv, bytes_per_rank, RCCL_INT8, root, c->comm, (hipStream_t)stream);
+  return rc ? rccl_fail("ncclGather", rc) : 0;
+}
+int mi355_stream_query(void* stream) {                           // 0 = everything enqueued on the stream has finished, 1 = still running, < 0 = error
+  const hipError_t e = hipStreamQuery((hipStream_t)stream);
+  if (e == hipSuccess) return 0;
+  if (e == hipErrorNotReady) { (void)hipGetLastError(); return 1; }
+  return -mi355::set_error(e, "hipStreamQuery");
+}
+
+}

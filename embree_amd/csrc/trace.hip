@@ -44,7 +44,10 @@ namespace {
 #endif
 constexpr int BLOCK = MI355_TRACE_BLOCK;   // one wave per workgroup (waves never synchronise): a CU slot frees as soon as ONE wave is done, which lets the next batch in earlier (+2.7 % with 4 batches in flight vs 256)
 constexpr int MAX_BLOCKS_PER_CU = MI355_MAX_BLOCKS_PER_CU * 256 / BLOCK;
-constexpr uint32_t ITER_CAP = 1u << 24;    // safety net only: a corrupt tree must not hang the GPU
+constexpr uint32_t ITER_CAP = 1u << 24;    // safety net only: a corrupt tree must not hang the GPU (env MI355_TRACE_ITER_CAP lowers it for the test of the flag below)
+// Neither safety net may fail silently: a wave that runs into the iteration cap, or a lane whose stack would outgrow its spill area, raises a word
+// in host-visible memory (TraceScratch::status); the blocking entry points turn it into RTC_ERROR_UNKNOWN, mi355_trace_status() reads it for device-pointer callers.
+constexpr uint32_t STATUS_ITER_CAP = 0, STATUS_SPILL = 1;
 constexpr uint32_t REFILL_MIN_DEFAULT = 32;  // rays are handed out in blocks of this many, once that many lanes are free (env MI355_REFILL_MIN)
 
 __device__ __forceinline__ float rcp_nr(float a) {  // v_rcp_f32 + one Newton step (reference: RCPPS + Newton, vfloat4_sse2.h:304)
@@ -66,16 +69,22 @@ struct TraceArgs {
   uint2* spill;          // [gridDim.x * BLOCK][spillPerLane]
   uint32_t spillPerLane;
   uint32_t refillMin, pushRounds, numCursors, drainWaiters;
+  uint32_t iterCap, helpers;
+  volatile uint32_t* status;  // host-mapped: [STATUS_ITER_CAP], [STATUS_SPILL] set to 1 when a safety net dropped work
   unsigned long long* stats;  // optional counters
   const float4* insts;   // INST kernels: InstRec[] as 4 x float4 (world2local vx,vy,vz,p | root node, instID, mask, flags)
 };
 
 // slab test of the 4 children whose quantised planes sit in one dword per plane; returns their contribution to the hit word.
-// The reference's fast node test compares exact fp32 planes (intersectNode<8>, node_intersector1.h:484-531); here the planes
-// are dequantised with two extra roundings, so the comparison gets 4 ulp of slack: a ray through the exact corner of a box
-// (cube corner of tutorials/triangle_geometry) must not lose the box to rounding.  Conservative = never wrong, only slower.
+// The reference's fast node test compares exact fp32 planes, t = plane * rdir - org * rdir (intersectNode<8>, node_intersector1.h:484-531).  Here a plane
+// distance is q * (scale * rdir) + (org_node - org_ray) * rdir: the plane itself is never rounded (quantise_slots keeps the EXACT plane outside the
+// child's geometry), but the two coefficients are, by up to 2^-22 (255 |a| + |b|) together with the FMA's own rounding and the 2 ulp of rcp_nr.  That
+// bound is taken off every near distance and added to every far distance (bn* / bf* below), so the test never loses a box that the exact arithmetic
+// accepts -- a ray through the exact corner of a box (cube corner of tutorials/triangle_geometry), a 40-unit pipe triangle seen from inside its node,
+// a scene 1e5 away from the origin.  Conservative = never wrong, only (very slightly) slower.  Measured on the 12.7 M triangle powerplant stand-in:
+// the reference's own fast mode loses 55 of 2^20 hits that its robust mode finds; this test loses none (tests/test_gpu_round2.py).
 typedef float f2 __attribute__((ext_vector_type(2)));   // v_pk_fma_f32: two fp32 FMAs per VALU issue on gfx950
-struct SlabCoef { f2 sxy, szx, syz, bxy, bzx, byz; };  // plane distance = q * scale + base, paired (x,y) (z,x) (y,z)
+struct SlabCoef { f2 sxy, szx, syz, bxy, bzx, byz; };  // plane distance = q * scale + base, paired (near x, near y) (near z, far x) (far y, far z)
 __device__ __forceinline__ uint32_t test4(uint32_t nx, uint32_t ny, uint32_t nz, uint32_t fx, uint32_t fy, uint32_t fz, uint32_t meta4,
                                           uint32_t octinv4, const SlabCoef& k, float tmin0, float tmax0) {
   // meta byte: inner = 001 11sss (bits 3 and 4 set), leaf = ccc ooooo with offset <= 23, empty = 0
@@ -94,7 +103,7 @@ __device__ __forceinline__ uint32_t test4(uint32_t nx, uint32_t ny, uint32_t nz,
     const float tN = fmaxf(fmaxf(a.x, a.y), fmaxf(b.x, tmin0));                                                \
     const float tF = fminf(fminf(b.y, c.x), fminf(c.y, tmax0));                                                \
     const uint32_t cb = (childBits4 >> (8 * J)) & 0xFFu, bi = (bitIndex4 >> (8 * J)) & 0x1Fu;                  \
-    hits |= (tN <= tF * 1.00000048f) ? (cb << bi) : 0u;   /* 4 ulp of slack: see note above test4 */             \
+    hits |= (tN <= tF) ? (cb << bi) : 0u;                                                                      \
   }
   MI355_CHILD(0) MI355_CHILD(1) MI355_CHILD(2) MI355_CHILD(3)
 #undef MI355_CHILD
@@ -291,7 +300,8 @@ __global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceAr
   uint32_t stNodes = 0, stTris = 0, stRays = 0, stSpill = 0, stDepth = 0, stIter = 0, stNodeBlk = 0, stTriBlk = 0;
   uint32_t stIdle = 0, stWaitBatch = 0, stWaitDrain = 0, stBlocked = 0, stEmpty = 0, stCulled = 0;
 
-  for (uint32_t iter = 0; iter < ITER_CAP; iter++) {
+  uint32_t iter = 0;
+  for (; iter < a.iterCap; iter++) {
     // ------------------------------------------------------------------ 1. retire finished rays, hand out new ones
     // Ray indices are handed out in blocks of G = refillMin consecutive rays.  Block B belongs to cursor B % numCursors, so
     // neighbouring blocks go to different cursors = different XCDs (a wave pulls from cursor blockIdx % 8 = its XCD): one
@@ -401,7 +411,7 @@ __global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceAr
     // owner's own (ring pairs carry the owner, the testers fetch the ray from the owner's registers), the owner retires when its own
     // traversal is done, pend[owner] == 0 and the ring has passed the last ticket any of its helpers drew.  The result is the same
     // minimum over all accepted candidates; only the order in which sub-trees are visited changes.
-    if (exhausted) {
+    if (exhausted && a.helpers) {
       const unsigned long long freeM = __ballot(!active);
       // INST: only sub-trees INSIDE an instance are given away (entries above the depth at which the donor entered it): the helper copies the donor's
       // object-space ray and never changes space; the donor stays in the instance until its helpers are done (step 2)
@@ -488,13 +498,13 @@ __global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceAr
       if (ngHits > 0x00FFFFFFu) {                                  // what is left of the node: its inner children ...
         const uint2 e = make_uint2(ngBase, ngHits);
         if (sp < (uint32_t)QSTACK_LDS) stk[sp * 64u] = e;
-        else { if (sp - QSTACK_LDS < a.spillPerLane) spill[sp - QSTACK_LDS] = e; if (STATS) stSpill++; }
+        else { if (sp - QSTACK_LDS < a.spillPerLane) spill[sp - QSTACK_LDS] = e; else a.status[STATUS_SPILL] = 1u; if (STATS) stSpill++; }
         sp++;
       }
       if (tgHits != 0u) {                                          // ... and its other instances (an entry with no inner-child bits)
         const uint2 e = make_uint2(tgBase, tgHits);
         if (sp < (uint32_t)QSTACK_LDS) stk[sp * 64u] = e;
-        else { if (sp - QSTACK_LDS < a.spillPerLane) spill[sp - QSTACK_LDS] = e; if (STATS) stSpill++; }
+        else { if (sp - QSTACK_LDS < a.spillPerLane) spill[sp - QSTACK_LDS] = e; else a.status[STATUS_SPILL] = 1u; if (STATS) stSpill++; }
         sp++;
       }
       if (STATS) stDepth = max(stDepth, sp);
@@ -523,7 +533,7 @@ __global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceAr
       if (ngHits > 0x00FFFFFFu) {
         const uint2 e = make_uint2(ngBase, ngHits);
         if (sp < (uint32_t)QSTACK_LDS) stk[sp * 64u] = e;
-        else { if (sp - QSTACK_LDS < a.spillPerLane) spill[sp - QSTACK_LDS] = e; if (STATS) stSpill++; }
+        else { if (sp - QSTACK_LDS < a.spillPerLane) spill[sp - QSTACK_LDS] = e; else a.status[STATUS_SPILL] = 1u; if (STATS) stSpill++; }
         sp++;
         if (STATS) stDepth = max(stDepth, sp);
       }
@@ -583,9 +593,11 @@ __global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceAr
         hits = test4_robust(nx0, ny0, nz0, fx0, fy0, fz0, n1.z, octinv4, scx, scy, scz, nox, noy, noz, ox, oy, oz, rdx, rdy, rdz, rfx, rfy, rfz, tnearTrav, tmax0) |
                test4_robust(nx1, ny1, nz1, fx1, fy1, fz1, n1.w, octinv4, scx, scy, scz, nox, noy, noz, ox, oy, oz, rdx, rdy, rdz, rfx, rfy, rfz, tnearTrav, tmax0);
       } else {
+      // error bound of a plane distance q * a + b (see test4): off the near side, onto the far side
+      const float ex = fmaf(fabsf(adx), 255.0f, fabsf(bx)) * 0x1p-21f, ey = fmaf(fabsf(ady), 255.0f, fabsf(by)) * 0x1p-21f, ez = fmaf(fabsf(adz), 255.0f, fabsf(bz)) * 0x1p-21f;
       SlabCoef k;
       k.sxy.x = adx; k.sxy.y = ady; k.szx.x = adz; k.szx.y = adx; k.syz.x = ady; k.syz.y = adz;
-      k.bxy.x = bx; k.bxy.y = by; k.bzx.x = bz; k.bzx.y = bx; k.byz.x = by; k.byz.y = bz;
+      k.bxy.x = bx - ex; k.bxy.y = by - ey; k.bzx.x = bz - ez; k.bzx.y = bx + ex; k.byz.x = by + ey; k.byz.y = bz + ez;
       hits = test4(nx0, ny0, nz0, fx0, fy0, fz0, n1.z, octinv4, k, tnearTrav, tmax0) |
              test4(nx1, ny1, nz1, fx1, fy1, fz1, n1.w, octinv4, k, tnearTrav, tmax0);
       }
@@ -618,6 +630,7 @@ __global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceAr
     }
   }
 
+  if (iter >= a.iterCap) a.status[STATUS_ITER_CAP] = 1u;        // left the loop through the cap, not through "no rays left": results are incomplete
   if (STATS) {
     atomicAdd(&a.stats[0], (unsigned long long)stNodes);
     atomicAdd(&a.stats[1], (unsigned long long)stTris);
@@ -637,28 +650,30 @@ __global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceAr
 }
 
 // ---- packet adaptor: SoA RTCRayHitK / RTCRayK <-> the AoS records the trace kernels consume ----
-// (RayHitK::get/set kernels/common/ray.h:283-376; packet calls never touch lanes whose valid[i] != -1)
-struct PacketArgs { const int* valid; char* packets; uint32_t K, numPackets; size_t packetStride; char* aos; uint32_t* index; uint32_t* numActive; };
+// (RayHitK::get/set kernels/common/ray.h:283-376; packet calls never touch lanes whose valid[i] != -1, InactiveRaysTest verify.cpp:3553)
+// Lane i of the packet array becomes AoS record i, active or not: an inactive lane is copied with tnear = +inf, tfar = -inf (it cannot enter the root's
+// box, so it costs one node visit and finds nothing) and is skipped on the way back.  No compaction, hence no counter to read back between the
+// kernels: the three launches are enqueued back to back.
+struct PacketArgs { const int* valid; char* packets; uint32_t K, numPackets; size_t packetStride; char* aos; };
 
 __global__ void packet_gather(PacketArgs p, int withHit) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= p.K * p.numPackets) return;
   const uint32_t pk = i / p.K, k = i % p.K;
-  if (p.valid && p.valid[i] != -1) return;
-  const uint32_t slot = atomicAdd(p.numActive, 1u);
-  p.index[slot] = i;
+  const bool on = !p.valid || p.valid[i] == -1;
   const uint32_t* src = (const uint32_t*)(p.packets + (size_t)pk * p.packetStride);
-  uint32_t* dst = (uint32_t*)(p.aos + (size_t)slot * (withHit ? 96 : 48));
+  uint32_t* dst = (uint32_t*)(p.aos + (size_t)i * (withHit ? 96 : 48));
   for (int f = 0; f < 12; f++) dst[f] = src[f * p.K + k];
+  if (!on) { dst[3] = 0x7F800000u; dst[8] = 0xFF800000u; }          // tnear = +inf, tfar = -inf
   if (withHit) for (int f = 0; f < 9; f++) dst[12 + f] = src[(12 + f) * p.K + k];
 }
 __global__ void packet_scatter(PacketArgs p, int withHit) {
-  const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
-  if (slot >= *p.numActive) return;
-  const uint32_t i = p.index[slot];
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= p.K * p.numPackets) return;
+  if (p.valid && p.valid[i] != -1) return;
   const uint32_t pk = i / p.K, k = i % p.K;
   uint32_t* dst = (uint32_t*)(p.packets + (size_t)pk * p.packetStride);
-  const uint32_t* src = (const uint32_t*)(p.aos + (size_t)slot * (withHit ? 96 : 48));
+  const uint32_t* src = (const uint32_t*)(p.aos + (size_t)i * (withHit ? 96 : 48));
   dst[8 * p.K + k] = src[8];   // tfar
   if (withHit && src[12 + 6] != MI355_EMPTY_REF)
     for (int f = 0; f < 9; f++) dst[(12 + f) * p.K + k] = src[12 + f];
@@ -696,7 +711,7 @@ static uint32_t resident_blocks(Bvh* b, TraceFn fn) {
 
 uint32_t trace_spill_per_lane(uint32_t depth) { return depth + 2u > (uint32_t)QSTACK_LDS ? depth + 2u - (uint32_t)QSTACK_LDS : 0u; }   // one entry per level at most
 size_t trace_spill_bytes(int numCUs, uint32_t depth) {
-  return (size_t)numCUs * MAX_BLOCKS_PER_CU * BLOCK * trace_spill_per_lane(depth) * sizeof(uint2) + 256;
+  return (size_t)numCUs * MAX_BLOCKS_PER_CU * BLOCK * trace_spill_per_lane(depth) * sizeof(uint2) + 1024;   // + slack: after a (flagged) overflow a lane still pops what it believes it pushed
 }
 
 static int launch_trace(Bvh* b, void* d_rays, uint32_t count, size_t stride, bool any, hipStream_t s, uint64_t* statsOut,
@@ -721,6 +736,9 @@ static int launch_trace(Bvh* b, void* d_rays, uint32_t count, size_t stride, boo
   static const uint32_t numCursors = env_u32("MI355_NUM_CURSORS", NUM_CURSORS, 1, NUM_CURSORS);
   static const uint32_t drainWaiters = env_u32("MI355_DRAIN_WAITERS", 3, 1, 65);
   a.refillMin = refillMin; a.pushRounds = pushRounds; a.numCursors = numCursors; a.drainWaiters = drainWaiters;
+  { const char* e = getenv("MI355_TRACE_ITER_CAP"); const long v = e ? atol(e) : 0; a.iterCap = v > 0 && v < (long)ITER_CAP ? (uint32_t)v : ITER_CAP; }
+  a.status = sc->statusDev;
+  { const char* e = getenv("MI355_TRACE_HELPERS"); a.helpers = e && atoi(e) == 0 ? 0u : 1u; }   // tail helpers (step 1b) on unless MI355_TRACE_HELPERS=0
   if (statsOut) {
     HIP_TRY(hipMemsetAsync(sc->stats, 0, 16 * sizeof(uint64_t), s));
     a.stats = (unsigned long long*)sc->stats;
@@ -742,20 +760,23 @@ static int launch_packets(Bvh* b, const int* d_valid, void* d_pk, uint32_t K, ui
   if (K != 4 && K != 8 && K != 16) return set_error(hipErrorInvalidValue, "packet size must be 4, 8 or 16");
   HIP_TRY(hipSetDevice(b->device));
   const size_t rec = any ? 48 : 96, total = (size_t)K * n;
-  char* aos = nullptr; uint32_t* index = nullptr; uint32_t* nact = nullptr;
-  HIP_TRY(hipMallocAsync((void**)&aos, total * rec, s));
-  HIP_TRY(hipMallocAsync((void**)&index, total * 4 + 16, s));
-  nact = index + total;
-  HIP_TRY(hipMemsetAsync(nact, 0, 4, s));
-  PacketArgs p{d_valid, (char*)d_pk, K, n, pstride, aos, index, nact};
+  if (total > 0xFFFFFFFFull) return set_error(hipErrorInvalidValue, "too many packets for one call");
+  TraceScratch* sc = b->scratch_for(s);
+  if (!sc) return set_error(hipErrorOutOfMemory, "trace scratch allocation failed");
+  char* aos = nullptr;
+  { std::lock_guard<std::mutex> lk(*sc->enqueue);               // the AoS staging area of this stream grows on demand and is reused by later calls (stream order keeps them apart)
+    if (sc->pktCap < total * rec) {
+      if (sc->pkt) { HIP_TRY(hipStreamSynchronize(s)); HIP_TRY(hipFree(sc->pkt)); sc->pkt = nullptr; sc->pktCap = 0; }
+      const size_t cap = total * rec < 65536 ? 65536 : total * rec;
+      HIP_TRY(hipMalloc(&sc->pkt, cap)); sc->pktCap = cap;
+    }
+    aos = (char*)sc->pkt; }
+  PacketArgs p{d_valid, (char*)d_pk, K, n, pstride, aos};
   const uint32_t g = (uint32_t)((total + 255) / 256);
   hipLaunchKernelGGL(packet_gather, dim3(g), dim3(256), 0, s, p, any ? 0 : 1);
-  uint32_t active = 0;
-  HIP_TRY(hipMemcpyAsync(&active, nact, 4, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
-  int rc = launch_trace(b, aos, active, rec, any, s, nullptr);
-  if (rc == 0 && active) hipLaunchKernelGGL(packet_scatter, dim3(g), dim3(256), 0, s, p, any ? 0 : 1);
-  hipFreeAsync(aos, s); hipFreeAsync(index, s);
+  const int rc = launch_trace(b, aos, (uint32_t)total, rec, any, s, nullptr);
+  if (rc == 0) hipLaunchKernelGGL(packet_scatter, dim3(g), dim3(256), 0, s, p, any ? 0 : 1);
+  HIP_TRY(hipGetLastError());
   return rc;
 }
 
@@ -765,6 +786,16 @@ extern "C" {
 int mi355_trace_prepare(mi355_bvh_t bvh, void* stream) {      // allocates the per-stream traversal scratch now instead of inside the first launch on that stream
   mi355::Bvh* b = (mi355::Bvh*)bvh; HIP_TRY(hipSetDevice(b->device));
   return b->scratch_for((hipStream_t)stream) ? 0 : mi355::set_error(hipErrorOutOfMemory, "trace scratch allocation failed");
+}
+int mi355_trace_status(mi355_bvh_t bvh, void* stream, uint32_t* out) {
+  mi355::Bvh* b = (mi355::Bvh*)bvh; HIP_TRY(hipSetDevice(b->device));
+  mi355::TraceScratch* sc = b->scratch_for((hipStream_t)stream);
+  if (!sc) return mi355::set_error(hipErrorOutOfMemory, "trace scratch allocation failed");
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  const uint32_t v = (sc->statusHost[0] ? MI355_TRACE_ITER_CAP_HIT : 0u) | (sc->statusHost[1] ? MI355_TRACE_STACK_OVERFLOW : 0u);
+  sc->statusHost[0] = 0u; sc->statusHost[1] = 0u;
+  if (out) *out = v;
+  return 0;
 }
 int mi355_trace_closest(mi355_bvh_t bvh, void* d, uint32_t n, size_t stride, void* stream) {
   return mi355::launch_trace((mi355::Bvh*)bvh, d, n, stride, false, (hipStream_t)stream, nullptr);

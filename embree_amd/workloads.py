@@ -318,9 +318,11 @@ def diffuse_bounce_rays(primary_traced, meshes, seed=1):
     return make_rayhits(o, dd, tnear=np.float32(1e-4) * s * np.float32(1e-3))
 
 
-def shadow_rays(bounce_traced, meshes, samples=16, seed=3):
+def shadow_rays(bounce_traced, meshes, samples=16, seed=3, first=0):
     """Config 4 ray set: `samples` rays per hit point of the traced bounce rays toward points on a
-    1x1 area light under the ceiling; tfar = dist*(1-1e-4).  Returns RTCRay records."""
+    1x1 area light under the ceiling; tfar = dist*(1-1e-4).  Returns RTCRay records.
+    `first` = global index of the first shadow ray (a rank that generates only its shard of the 16 Mi rays passes the start of
+    its range, so that the shards of N ranks are exactly the rays one rank would generate)."""
     b = bounce_traced
     lo, hi = scene_bounds(meshes)
     s = np.float32(np.sqrt(((hi - lo) ** 2).sum()))
@@ -331,7 +333,7 @@ def shadow_rays(bounce_traced, meshes, samples=16, seed=3):
     t = np.where(hit, b["tfar"], np.float32(1.0)).astype(np.float32)
     P = (org + t[:, None] * d).astype(np.float32)
     n = P.shape[0] * samples
-    rs = RandomSampler(np.arange(n, dtype=np.uint32), seed)
+    rs = RandomSampler(np.arange(first, first + n, dtype=np.uint32), seed)
     lx, lz = rs.get_float() - 0.5, rs.get_float() - 0.5
     L = np.stack([c[0] + lx, np.full(n, hi[1] - 0.26 * 1.0, np.float32), c[2] + lz], -1).astype(np.float32)
     Pr = np.repeat(P, samples, axis=0)

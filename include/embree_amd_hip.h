@@ -123,6 +123,14 @@ MI355_API int mi355_trace_any(mi355_bvh_t bvh, void* d_ray, uint32_t count, size
    (after the 4-byte cursor reset), so that the interval is the kernel alone.  any_hit selects the kernel. */
 MI355_API int mi355_trace_timed(mi355_bvh_t bvh, void* d_rays, uint32_t count, size_t byte_stride, int any_hit,
                                 void* stream, void* ev_start, void* ev_stop);
+/* The traversal kernels have two safety nets that drop work instead of hanging or corrupting memory: a per-wave iteration cap (a corrupt tree must not
+   hang the GPU) and a bound on the per-lane stack spill area.  Neither fails silently: the kernel raises a word in host-visible memory.  This call
+   synchronises `stream`, returns the OR of the flags raised by launches on it since the last call, and clears them.  The blocking host-array entry
+   points (rtcIntersect1M, ...) check it themselves and record RTC_ERROR_UNKNOWN (the reference: RTC_CATCH_END -> RTC_ERROR_UNKNOWN for anything
+   unexpected, kernels/common/rtcore.h:23-49). */
+#define MI355_TRACE_ITER_CAP_HIT   1u
+#define MI355_TRACE_STACK_OVERFLOW 2u
+MI355_API int mi355_trace_status(mi355_bvh_t bvh, void* stream, uint32_t* out_flags);
 /* SoA packets RTCRayHitK / RTCRayK (K = 4, 8, 16) on the device; d_valid = K ints per packet (-1 = active)
    or NULL for all-active; num_packets packets, packet_stride bytes apart. */
 MI355_API int mi355_trace_closest_packet(mi355_bvh_t bvh, const int* d_valid, void* d_rayhitK, uint32_t K,
@@ -137,6 +145,26 @@ MI355_API int mi355_trace_any_packet(mi355_bvh_t bvh, const int* d_valid, void* 
    triangle bits.  any_hit != 0 selects the occlusion kernel.  The rays ARE traced (results written). */
 MI355_API int mi355_trace_stats(mi355_bvh_t bvh, void* d_rays, uint32_t count, size_t byte_stride, int any_hit,
                                 uint64_t out[16]);
+
+/* ---- multi-GPU: sharded ray batches, results gathered over RCCL / xGMI (the reference has no multi-process code, so there is no
+   reference function these replace: they implement BASELINE.json's north_star, "ray batches shard embarrassingly across the 8 GPUs of one node with the
+   BVH replicated and hits gathered over RCCL/xGMI").  One process per GPU; every process commits the same scene (the build is deterministic: identical
+   trees, nothing to broadcast) and traces its contiguous ray range (embree_amd/shard.py shard_range).  The 128-byte id made by rank 0 has to reach the
+   other ranks through the host's own channel (bench.py: torch.distributed / gloo).  librccl.so.1 is loaded on first use of a mi355_comm_* call. */
+typedef struct mi355_comm* mi355_comm_t;
+#define MI355_COMM_ID_BYTES 128
+MI355_API int  mi355_comm_unique_id(void* out_id128);                                             /* ncclGetUniqueId (rank 0) */
+MI355_API int  mi355_comm_init(int device, const void* id128, int world, int rank, mi355_comm_t* out);   /* ncclCommInitRank: collective over all ranks, blocking */
+MI355_API void mi355_comm_destroy(mi355_comm_t comm);
+/* every rank contributes bytes_per_rank bytes at d_send; d_recv (world * bytes_per_rank bytes, rank order) is filled on every rank / on `root` only.
+   Asynchronous on `stream` (a hipStream_t); all ranks must issue the same sequence of calls. */
+MI355_API int  mi355_comm_allgather(mi355_comm_t comm, const void* d_send, void* d_recv, size_t bytes_per_rank, void* stream);
+MI355_API int  mi355_comm_gather(mi355_comm_t comm, const void* d_send, void* d_recv, size_t bytes_per_rank, int root, void* stream);
+/* The fields a query writes, squeezed out of the AoS records so that only results travel:
+   closest hit: 32 B per ray = { tfar, u, v, primID | geomID, Ng_x, Ng_y, Ng_z } (two 16-byte halves); occlusion: 4 B per ray = tfar (-inf = occluded). */
+MI355_API int  mi355_pack_hits(const void* d_rayhit, uint32_t count, size_t byte_stride, void* d_out, void* stream);
+MI355_API int  mi355_pack_occluded(const void* d_ray, uint32_t count, size_t byte_stride, void* d_out, void* stream);
+MI355_API int  mi355_stream_query(void* stream);             /* hipStreamQuery: 0 = idle, 1 = work pending, < 0 = error */
 
 /* raw device memory helpers for hosts without a HIP binding (ctypes tests / bench) */
 MI355_API int mi355_malloc(int device, size_t bytes, void** d_ptr);

@@ -15,9 +15,11 @@ EMPTY = 0xFFFFFFFF
 
 
 def decode_child_boxes(node):
-    scale = (node["exp"].astype(np.uint32) << 23).view(np.float32)          # 2^(e-127), one per axis
-    lo = (node["org"][None, :] + node["qlo"].T.astype(np.float32) * scale[None, :]).astype(np.float32)   # [slot][axis]
-    hi = (node["org"][None, :] + node["qhi"].T.astype(np.float32) * scale[None, :]).astype(np.float32)
+    # the EXACT planes org + q * 2^(e-127) (fp64 holds them exactly): the fast traversal path evaluates q * (scale * rdir) + (org - ray.org) * rdir,
+    # which never rounds the plane itself, so the exact plane is what must lie outside the child's geometry (build_wide.inl, quantise_slots)
+    scale = (node["exp"].astype(np.uint32) << 23).view(np.float32).astype(np.float64)          # 2^(e-127), one per axis
+    lo = node["org"][None, :].astype(np.float64) + node["qlo"].T.astype(np.float64) * scale[None, :]   # [slot][axis]
+    hi = node["org"][None, :].astype(np.float64) + node["qhi"].T.astype(np.float64) * scale[None, :]
     return lo, hi
 
 

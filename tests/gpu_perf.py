@@ -36,7 +36,7 @@ s = api.Scene(dev, api.RTC_SCENE_FLAG_ROBUST if a.robust else 0, api.RTC_BUILD_Q
 for v, t in meshes:
     s.add_triangle_mesh(v, t, device_resident=True)
 s.commit()
-s.commit()
+s.touch(); s.commit()
 info = s.info()
 prim = W.crown_camera_rays(meshes, 1024, 1024)
 d = api.DeviceArray.from_numpy(prim)

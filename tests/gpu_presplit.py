@@ -30,7 +30,7 @@ for name, q in (("MEDIUM", None), ("HIGH", api.RTC_BUILD_QUALITY_HIGH)):
     s = api.Scene(dev, 0, q)
     for v, t in meshes:
         s.add_triangle_mesh(v, t, device_resident=True)
-    s.commit(); s.commit()
+    s.commit(); s.touch(); s.commit()
     info = s.info()
     if rays is None:
         prim = W.crown_camera_rays(meshes, 1024, 1024)

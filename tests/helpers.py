@@ -61,3 +61,42 @@ def compare_occluded(got_tfar, want_tfar, rays_tfar_in, max_flip_frac=0.0, label
     keep = ~g
     assert (got_tfar[keep] == rays_tfar_in[keep]).all(), f"{label}: unoccluded ray was modified"
     return dict(rays=g.shape[0], occluded=int(w.sum()), flips=flips)
+
+
+def compare_closest_arbitrated(got, want_fast, want_robust, rays_in, tri_t, max_tie_frac=5e-3, max_ref_miss_frac=1e-3, label=""):
+    """Fast-mode parity on geometry where the REFERENCE's fast mode is itself not exact.  Embree's default node test (node_intersector1.h:484-531,
+    rdir from an approximate reciprocal, no safety margin) loses hits on long thin or axis-aligned geometry; RTC_SCENE_FLAG_ROBUST exists for that
+    reason.  A ray on which the tested path and the fast reference disagree is therefore accepted iff it is an exact-t tie or the tested
+    path reports exactly what the ROBUST reference reports (a hit the fast reference lost); and the tested path itself must never be farther than the
+    robust reference's hit (it must not lose anything).  Returns counts; asserts on anything else."""
+    n = got.shape[0]
+    same = (got["geomID"] == want_fast["geomID"]) & (got["primID"] == want_fast["primID"])
+    idx = np.nonzero(~same)[0]
+    g_hit, f_hit = got["geomID"][idx] != INVALID_ID, want_fast["geomID"][idx] != INVALID_ID
+    ties = ref_missed = 0
+    bad = []
+    if idx.size:
+        t_named = np.full(idx.size, np.inf, np.float32)
+        both = g_hit & f_hit
+        if both.any():
+            t_named[both] = tri_t(rays_in[idx[both]], got["geomID"][idx[both]], got["primID"][idx[both]])
+        is_tie = both & _rel(t_named, want_fast["tfar"][idx]) & _rel(got["tfar"][idx], want_fast["tfar"][idx])
+        # "what the robust reference reports": the same triangle, or one at the same distance (an exact-t tie with the robust answer)
+        r_hit = want_robust["geomID"][idx] != INVALID_ID
+        t_self = np.full(idx.size, np.inf, np.float32)
+        gh = np.nonzero(g_hit)[0]
+        if gh.size:
+            t_self[gh] = tri_t(rays_in[idx[gh]], got["geomID"][idx[gh]], got["primID"][idx[gh]])
+        as_robust = g_hit & r_hit & _rel(got["tfar"][idx], want_robust["tfar"][idx]) & _rel(t_self, want_robust["tfar"][idx]) & \
+            (got["tfar"][idx] < np.where(f_hit, want_fast["tfar"][idx], np.inf))
+        ties, ref_missed = int(is_tie.sum()), int((as_robust & ~is_tie).sum())
+        bad = idx[~(is_tie | as_robust)]
+    assert len(bad) == 0, f"{label}: {len(bad)}/{n} rays differ from the fast AND the robust reference (first {bad[:8]})"
+    r_hit = want_robust["geomID"] != INVALID_ID
+    lost = r_hit & ((got["geomID"] == INVALID_ID) | (got["tfar"] > want_robust["tfar"] * np.float32(1 + RTOL)))
+    assert not lost.any(), f"{label}: {int(lost.sum())} rays end farther than the robust reference's hit (first {np.nonzero(lost)[0][:8]})"
+    assert ties <= max(2, max_tie_frac * n), f"{label}: too many ties {ties}/{n}"
+    assert ref_missed <= max_ref_miss_frac * n, f"{label}: {ref_missed} hits missing in the fast reference"
+    m = same & (want_fast["geomID"] != INVALID_ID)
+    assert _rel(got["tfar"][m], want_fast["tfar"][m]).all(), f"{label}: tfar outside {RTOL}"
+    return dict(rays=n, hits=int((got["geomID"] != INVALID_ID).sum()), ties=ties, fast_reference_missed=ref_missed)

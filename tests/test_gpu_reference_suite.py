@@ -244,6 +244,7 @@ def test_memory_monitor(api):
     want = rays.copy()
     s.intersect1M(want)
     # now refuse the next allocation: the commit fails, the old tree keeps answering
+    s.touch()                                                  # (a commit of an unmodified scene returns at once and allocates nothing)
     state["break_at"] = state["calls"] + 1
     L.rtcCommitScene(s.h)
     assert d.get_error() == api.RTC_ERROR_OUT_OF_MEMORY and state["broke"] == 1

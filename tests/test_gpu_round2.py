@@ -1,0 +1,294 @@
+"""GPU parity tests added in round 2 (pytest -m gpu), all through the C ABI, all against the REAL reference (oracle/_ref, Embree 4.4.1
+built from /root/reference by oracle/ref.mk; it travels with the repo snapshot) unless stated otherwise:
+
+  * packets 4 / 8 / 16 against the reference's own packet entry points (BVHNIntersectorKHybrid, kernels/bvh/bvh_intersector_hybrid.cpp:106-369),
+    inactive lanes included (InactiveRaysTest, tutorials/verify/verify.cpp:3553), with the A.5 tie rule;
+  * configs[4] at FULL size (12.7 M triangles) against the live reference;
+  * fast-mode scenes far from the origin (1e4, 1e5): the quantised node test must stay conservative;
+  * the loader -> GPU -> reference chain on the reference's own cornell_box.ecs / .xml assets (tests/golden/models, copied by make_assets.py);
+  * the traversal kernels' safety nets report instead of returning wrong answers.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from embree_amd import loaders as Ld, workloads as W
+from embree_amd.rtypes import rays_of, INVALID_ID, RAYHIT_DTYPE, RAY_DTYPE
+from tests.helpers import compare_closest, compare_closest_arbitrated, compare_occluded
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def api():
+    from embree_amd import api as A
+    A.load()
+    assert A.load().mi355_device_count() > 0, "no HIP device: the product has no CPU fallback"
+    return A
+
+
+@pytest.fixture(scope="module")
+def dev(api):
+    d = api.Device("gpu=0")
+    yield d
+    d.release()
+
+
+@pytest.fixture(scope="module")
+def ref():
+    from oracle import refembree
+    if not refembree.available():
+        pytest.skip("oracle/_ref not present on this box (make -f oracle/ref.mk in the build container)")
+    return refembree
+
+
+def ref_scene(ref, meshes, masks=None, flags=0, threads=None):
+    R = ref.RefScene("threads=%d" % (threads or ref.hw_threads()), flags=flags)
+    for i, (v, t) in enumerate(meshes):
+        R.add_mesh(v, t, 1 if masks is None else masks[i])
+    R.commit()
+    assert R.error() == 0
+    return R
+
+
+def tri_t_of(meshes):
+    """t of a NAMED triangle as the checker computes it (tie rule, tests/helpers.py): the restatement's Moeller-Trumbore, no tree involved."""
+    from oracle import restate
+    o = restate.OracleScene()
+    for v, t in meshes:
+        o.add_mesh(v, t)
+    return o.triangle_t
+
+
+def small_crown_rays(ref, meshes, n_side=64, seed=5):
+    R = ref_scene(ref, meshes)
+    prim = W.crown_camera_rays(meshes, n_side, n_side)
+    R.intersect1(prim, ref.hw_threads())
+    rays = W.diffuse_bounce_rays(prim, meshes, seed=seed)
+    return R, rays
+
+
+# ------------------------------------------------------------------------------------------------- packets
+def to_packets(aos, K, nfields):
+    """AoS records -> SoA packets [npk][field][K] (RTCRayHitK: 21 dwords per lane, RTCRayK: 12)."""
+    n = aos.shape[0]
+    assert n % K == 0
+    w = aos.view(np.uint32).reshape(n, -1)[:, :nfields]
+    return np.ascontiguousarray(w.reshape(n // K, K, nfields).transpose(0, 2, 1))
+
+
+def from_packets(pk, like):
+    npk, nf, K = pk.shape
+    out = like.copy()
+    out.view(np.uint32).reshape(like.shape[0], -1)[:, :nf] = pk.transpose(0, 2, 1).reshape(npk * K, nf)
+    return out
+
+
+@pytest.mark.parametrize("K", [4, 8, 16])
+def test_packets_vs_real_reference(api, dev, ref, K):
+    """rtcIntersectK / rtcOccludedK (host packets) and mi355_trace_*_packet (device packets) against the reference's packet calls on the same
+    incoherent rays; every 5th lane inactive; IDs bit-exact up to classified exact-t ties (the packet path keeps the LAST equal-t triangle of a
+    block, kernels/geometry/triangle_intersector.h:52-60, so ties may legally differ from the single-ray answer)."""
+    L = api.load()
+    meshes = W.synthetic_crown(num_phi=24)
+    R, rays = small_crown_rays(ref, meshes)
+    n = (rays.shape[0] // 16) * 16
+    rays = rays[:n].copy()
+    valid = np.ones(n, np.int32)
+    valid[::5] = 0
+    act = valid != 0
+    want = rays.copy()
+    R.packet(K, want, valid)
+    assert want[~act].tobytes() == rays[~act].tobytes()            # the reference leaves inactive lanes alone
+    s = api.make_scene(dev, meshes)
+    tri_t = tri_t_of(meshes)
+
+    # (a) device packets: one call for all packets
+    pk = to_packets(rays, K, 21)
+    dpk = api.DeviceArray.from_numpy(pk, dev.gpu)
+    dvalid = api.DeviceArray.from_numpy(np.where(act, -1, 0).astype(np.int32), dev.gpu)
+    assert L.mi355_trace_closest_packet(s.bvh(), dvalid.ptr, dpk.ptr, K, n // K, 21 * 4 * K, None) == 0, L.mi355_last_error()
+    assert s.trace_status() == 0
+    got = from_packets(dpk.download(np.uint32).reshape(pk.shape), rays)
+    assert got[~act].tobytes() == rays[~act].tobytes(), "inactive lane modified (device packets)"
+    st = compare_closest(got[act], want[act], rays[act], tri_t, label="intersect%d device packets vs reference" % K)
+    assert st["hits"] > 0.9 * act.sum()
+    dpk.free()
+
+    # (b) host entry points rtcIntersectK, one call per packet (the first 48 packets)
+    m = 48 * K
+    for p in range(48):
+        sel = slice(p * K, (p + 1) * K)
+        buf = _aligned(to_packets(rays[sel], K, 21)[0])
+        v = _aligned(np.where(act[sel], -1, 0).astype(np.int32))
+        getattr(L, "rtcIntersect%d" % K)(v.ctypes.data, s.h, buf.ctypes.data, None)
+        one = from_packets(buf[None], rays[sel])
+        assert one.tobytes() == got[sel].tobytes(), "rtcIntersect%d and the device packet call disagree" % K
+    dev.check()
+
+    # (c) occlusion packets
+    r = rays_of(rays)
+    wr = r.copy()
+    R.packet(K, wr, valid, any_hit=True)
+    rk = to_packets(r, K, 12)
+    drk = api.DeviceArray.from_numpy(rk, dev.gpu)
+    assert L.mi355_trace_any_packet(s.bvh(), dvalid.ptr, drk.ptr, K, n // K, 12 * 4 * K, None) == 0, L.mi355_last_error()
+    gr = from_packets(drk.download(np.uint32).reshape(rk.shape), r)
+    assert gr[~act].tobytes() == r[~act].tobytes(), "inactive lane modified (occlusion packets)"
+    compare_occluded(gr["tfar"][act], wr["tfar"][act], r["tfar"][act], label="occluded%d device packets vs reference" % K)
+    for p in range(16):
+        sel = slice(p * K, (p + 1) * K)
+        buf = _aligned(to_packets(r[sel], K, 12)[0])
+        v = _aligned(np.where(act[sel], -1, 0).astype(np.int32))
+        getattr(L, "rtcOccluded%d" % K)(v.ctypes.data, s.h, buf.ctypes.data, None)
+        assert from_packets(buf[None], r[sel]).tobytes() == gr[sel].tobytes()
+    dev.check()
+    drk.free(); dvalid.free()
+    s.release(); R.close()
+
+
+def _aligned(a, align=64):
+    raw = np.zeros(a.nbytes + align, np.uint8)
+    off = (-raw.ctypes.data) % align
+    out = raw[off:off + a.nbytes].view(a.dtype).reshape(a.shape)
+    out[...] = a
+    return out
+
+
+# ------------------------------------------------------------------------------------------------- configs[4] at full size
+def test_powerplant_full_size_vs_real_reference(api, dev, ref):
+    """configs[4]: 12.7 M triangles (long thin pipe triangles + axis-aligned boxes), GPU SAH build + 2^20 incoherent rays, closest hit and occlusion,
+    against the reference building and tracing the same scene on the host cores -- in its default mode AND with RTC_SCENE_FLAG_ROBUST as the arbiter:
+    on this geometry the reference's fast mode loses ~50 of 2^20 hits its robust mode finds (measured), the GPU's fast mode must lose none."""
+    m = W.synthetic_powerplant()
+    s = api.make_scene(dev, m, device_resident=True)
+    assert s.info()["num_triangles"] == W.num_triangles(m) == 12699996
+    R = ref_scene(ref, m)
+    rlo, rhi = R.bounds()
+    blo, bhi = s.bounds()
+    assert (blo == rlo).all() and (bhi == rhi).all()                 # rtcGetSceneBounds, bit for bit
+    lo, hi = W.scene_bounds(m)
+    rays = W.incoherent_rays(1 << 20, (lo + hi) / 2, seed=11)
+    want, got = rays.copy(), rays.copy()
+    R.intersect1(want, ref.hw_threads())
+    s.intersect1M(got)
+    wr, gr = rays_of(rays), rays_of(rays)
+    R.occluded1(wr, ref.hw_threads())
+    s.occluded1M(gr)
+    R.close()
+    RR = ref_scene(ref, m, flags=4)                                  # RTC_SCENE_FLAG_ROBUST
+    robust = rays.copy()
+    RR.intersect1(robust, ref.hw_threads())
+    RR.close()
+    st = compare_closest_arbitrated(got, want, robust, rays, tri_t_of(m), max_tie_frac=2e-3, label="powerplant 12.7M vs reference")   # boxes: coplanar faces meet at edges
+    assert st["hits"] > 0.3 * st["rays"]
+    print("powerplant full size:", st)
+    # occlusion: a flip is acceptable only where the fast reference lost a hit (the GPU says occluded, the reference does not)
+    g, w = np.isneginf(gr["tfar"]), np.isneginf(wr["tfar"])
+    assert not (w & ~g).any(), "%d rays occluded for the reference are not occluded on the GPU" % int((w & ~g).sum())
+    assert (g & ~w).sum() <= 1e-4 * g.size
+    assert (gr["tfar"][~g] == rays_of(rays)["tfar"][~g]).all()
+    # and the GPU's own robust mode answers exactly like the robust reference
+    s.release()
+    sr = api.make_scene(dev, m, flags=api.RTC_SCENE_FLAG_ROBUST, device_resident=True)
+    g2 = rays.copy()
+    sr.intersect1M(g2)
+    compare_closest(g2, robust, rays, tri_t_of(m), max_tie_frac=2e-3, label="powerplant 12.7M robust vs robust reference")
+    sr.release()
+
+
+# ------------------------------------------------------------------------------------------------- far from the origin, fast mode
+@pytest.mark.parametrize("offset", [1.0e4, 1.0e5])
+def test_fast_mode_far_from_the_origin(api, dev, ref, offset):
+    """The crown stand-in translated by 1e4 / 1e5 in the default (fast) mode.  The triangle arithmetic is the reference's bit for bit, so every
+    difference to the reference would be a box the quantised node test lost: IDs must agree up to exact-t ties and NO hit may turn into a miss.
+    (The reference's own WatertightTest sits at 1.5e5, verify.cpp:3611; there it is the robust mode that is held to 2e-5, see test_gpu_parity.)"""
+    base = W.synthetic_crown(num_phi=32)
+    shift = np.array([offset, -0.5 * offset, 0.25 * offset], np.float32)
+    meshes = [((v + shift).astype(np.float32), t) for v, t in base]
+    R, rays = small_crown_rays(ref, meshes, n_side=128, seed=7)
+    s = api.make_scene(dev, meshes)
+    from tests import bvh_check
+    nodes, tris = s.download_bvh()
+    info = s.info()
+    bvh_check.validate(nodes, tris, info["root_ref"], meshes, max_leaf=info["max_leaf"])      # EXACT decoded planes contain the geometry
+    want, got = rays.copy(), rays.copy()
+    R.intersect1(want, ref.hw_threads())
+    s.intersect1M(got)
+    lost = (want["geomID"] != INVALID_ID) & (got["geomID"] == INVALID_ID)
+    assert not lost.any(), "%d hits of the reference are misses on the GPU" % int(lost.sum())
+    st = compare_closest(got, want, rays, tri_t_of(meshes), label="crown at %g" % offset)
+    assert st["hits"] > 0.9 * st["rays"]
+    wr, gr = rays_of(rays), rays_of(rays)
+    R.occluded1(wr, ref.hw_threads())
+    s.occluded1M(gr)
+    compare_occluded(gr["tfar"], wr["tfar"], rays_of(rays)["tfar"], label="crown at %g, occlusion" % offset)
+    s.release(); R.close()
+
+
+# ------------------------------------------------------------------------------------------------- loader -> GPU -> reference
+@pytest.mark.parametrize("fname", ["cornell_box.ecs", "cornell_box.xml"])
+def test_reference_assets_end_to_end(api, dev, ref, fname):
+    """The reference's own Cornell-box files (tutorials/models) through embree_amd/loaders.py onto the GPU: 512 x 512 primary rays from the camera the
+    .ecs names (configs[1]), closest hit + occlusion, against the reference tracing the same loaded meshes; the OBJ and the XML + .bin variants of the
+    asset must describe the same triangles."""
+    path = os.path.join(ROOT, "tests", "golden", "models", fname)
+    sc = Ld.load_scene(path)
+    assert W.num_triangles(sc.meshes) == 34
+    cam = sc.camera or Ld.load_scene(os.path.join(ROOT, "tests", "golden", "models", "cornell_box.ecs")).camera
+    assert np.allclose(cam["vp"], [278, 273, -800]) and cam["fov"] == 37.0
+    rays = W.camera_rays(cam["vp"], cam["vi"], cam["vu"], cam["fov"], 512, 512)
+    s = api.make_scene(dev, sc.meshes)
+    R = ref_scene(ref, sc.meshes)
+    want, got = rays.copy(), rays.copy()
+    R.intersect1(want, ref.hw_threads())
+    s.intersect1M(got)
+    st = compare_closest(got, want, rays, tri_t_of(sc.meshes), max_tie_frac=0.01, label=fname)      # wall seams are exact ties
+    assert st["hits"] > 0.5 * st["rays"]
+    # the image both produce: geomID / primID per pixel differ only on classified ties, so the eyelight shading (|dot(dir, normalize(Ng))|) agrees
+    hit = want["geomID"] != INVALID_ID
+    def shade(a):
+        ng = np.stack([a["Ng_x"], a["Ng_y"], a["Ng_z"]], -1)[hit]
+        d = np.stack([rays["dir_x"], rays["dir_y"], rays["dir_z"]], -1)[hit]
+        return np.abs((ng * d).sum(-1)) / np.sqrt((ng * ng).sum(-1))
+    assert np.abs(shade(got) - shade(want)).max() < 1e-4
+    wr, gr = rays_of(rays), rays_of(rays)
+    R.occluded1(wr, ref.hw_threads())
+    s.occluded1M(gr)
+    compare_occluded(gr["tfar"], wr["tfar"], rays_of(rays)["tfar"], label=fname)
+    blo, bhi = s.bounds()
+    rlo, rhi = R.bounds()
+    assert (blo == rlo).all() and (bhi == rhi).all()
+    s.release(); R.close()
+
+
+# ------------------------------------------------------------------------------------------------- safety nets report
+def test_iteration_cap_is_reported_not_silent(api, dev):
+    """A traversal that runs into its iteration cap has dropped rays: the blocking entry points record RTC_ERROR_UNKNOWN, the device-pointer
+    entry points raise the flag mi355_trace_status() returns.  (The cap exists so that a corrupt tree cannot hang the GPU.)"""
+    L = api.load()
+    meshes = W.synthetic_crown(num_phi=16)
+    s = api.make_scene(dev, meshes)
+    rays = W.incoherent_rays(4096, np.zeros(3, np.float32) + 0.5, seed=3)
+    ok = rays.copy()
+    s.intersect1M(ok)
+    assert (ok["geomID"] != INVALID_ID).any()
+    os.environ["MI355_TRACE_ITER_CAP"] = "3"
+    try:
+        r = rays.copy()
+        L.rtcIntersect1M(s.h, r.ctypes.data, r.shape[0], 96, None)
+        assert dev.get_error() == api.RTC_ERROR_UNKNOWN and "iteration cap" in dev.last_message()
+        d = api.DeviceArray.from_numpy(rays, dev.gpu)
+        s.intersect1M_device(d.ptr, rays.shape[0])                  # asynchronous: no error recorded here ...
+        assert s.trace_status() & 1                                 # ... the flag is there for the caller
+        assert s.trace_status() == 0                                # cleared on read
+        d.free()
+    finally:
+        del os.environ["MI355_TRACE_ITER_CAP"]
+    again = rays.copy()
+    s.intersect1M(again)
+    assert again.tobytes() == ok.tobytes()
+    s.release()

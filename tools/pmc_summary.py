@@ -14,6 +14,9 @@ import json
 import os
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from kernel_hash import trace_kernel_hash   # noqa: E402
+
 src, pattern, out = sys.argv[1], sys.argv[2], sys.argv[3]
 agg = collections.defaultdict(list)
 meta = {}
@@ -26,7 +29,7 @@ for p in sorted(glob.glob(os.path.join(src, "p*", "*counter_collection.csv"))):
                     vgpr=int(r["VGPR_Count"]), sgpr=int(r["SGPR_Count"]), scratch=int(r["Scratch_Size"]))
 avg = {k: sum(v) / len(v) for k, v in agg.items()}
 n = {k: len(v) for k, v in agg.items()}
-d = dict(meta=meta, counters=avg, launches=n)
+d = dict(meta=meta, counters=avg, launches=n, source_hash=trace_kernel_hash(), kernel_pattern=pattern)
 if "FETCH_SIZE" in avg:
     d["hbm_read_bytes_per_launch"] = 2.0 * avg["FETCH_SIZE"] * 1024.0
 if "WRITE_SIZE" in avg:
