@@ -120,7 +120,14 @@ Bvh::~Bvh() {
   if (d_insts) hipFree(d_insts);
 }
 
-static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, const mi355_build_params* bp, hipStream_t st, Bvh** out) {
+// A commit is enqueued as ONE sequence of launches with no host round trip inside (MEDIUM quality, the default): the number of valid triangles, the
+// scene bounds, the lengths of the work lists all stay on the device (build_begin, root_setup, guarded compaction, grids that are upper bounds), the level
+// loops are enqueued with a margin beyond the levels N implies, and the host waits ONCE, at the end, where it also learns whether the margins were
+// enough (top phase finished, wide levels finished, no overflow); if not -- pathological input -- the commit is repeated on the stepwise path, which
+// looks at the counters between groups of levels like the first generations of this builder did.  Why: a host round trip costs 20-40 us on an idle
+// box but was measured at ~0.8 ms each on the round-end driver's box (commit 13.9 ms there, 7.0 ms here, same code), and there were nine of them.
+// LOW (Morton: the sort needs n on the host) and HIGH (presplit: the budget loop) keep one round trip after primref_gen.
+static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, const mi355_build_params* bp, hipStream_t st, Bvh** out, bool allowFast = true) {
   HIP_TRY(hipSetDevice(device));
   Arena* arena = arena_of(device);
   std::lock_guard<std::mutex> arenaLock(arena->mtx);
@@ -153,6 +160,11 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
   for (int d = 0; d < 3; d++) { info.bounds_lower[d] = INFINITY; info.bounds_upper[d] = -INFINITY; }
   if (total == 0) { guard.ok = true; *out = bvh; return 0; }
   const uint32_t N = (uint32_t)total;
+  static const bool envSync = getenv("MI355_BUILD_STEPWISE") != nullptr;         // A/B: force the stepwise path
+  const bool fast = allowFast && !envSync && prm.quality == 0u;
+  uint32_t launches = 0, syncs = 0;
+#define LAUNCH(...) do { hipLaunchKernelGGL(__VA_ARGS__); launches++; } while (0)
+#define SYNC_READ(h) do { HIP_TRY(hipGetLastError()); HIP_TRY(hipMemcpyAsync(&(h), ctr.p, sizeof(h), hipMemcpyDeviceToHost, st)); HIP_TRY(hipStreamSynchronize(st)); syncs++; } while (0)
 
   DevBuf<GeomDesc> dGeoms; HIP_TRY(dGeoms.alloc(gd.size()));
   HIP_TRY(hipMemcpyAsync(dGeoms.p, gd.data(), gd.size() * sizeof(GeomDesc), hipMemcpyHostToDevice, st));
@@ -170,82 +182,90 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
   HIP_TRY(chunks.alloc(maxChunks)); HIP_TRY(small.alloc(maxSmall)); HIP_TRY(ctr.alloc(1));
   HIP_TRY(w0.alloc(maxWide)); HIP_TRY(w1.alloc(maxWide)); HIP_TRY(wnodes.alloc(maxWide)); HIP_TRY(outIds.alloc(NC));
   const uint32_t maxLevelItems = NC / 2u + 64u;                 // the nodes of one level are disjoint sub-trees of >= 2 triangles each
-  DevBuf<WidePlan> plans; DevBuf<uint2> itemCnt, groupSum;
+  DevBuf<WidePlan> plans; DevBuf<uint2> itemCnt, groupSum; DevBuf<uint32_t> tileCount;
   HIP_TRY(plans.alloc(maxLevelItems)); HIP_TRY(itemCnt.alloc(maxLevelItems)); HIP_TRY(groupSum.alloc(maxLevelItems / 8u + 16u));
+  const uint32_t tiles = (N + 255u) / 256u;
+  HIP_TRY(tileCount.alloc(tiles));
 
   hipEvent_t ev0, ev1; HIP_TRY(hipEventCreate(&ev0)); HIP_TRY(hipEventCreate(&ev1));
   struct EvGuard { hipEvent_t a, b; ~EvGuard() { hipEventDestroy(a); hipEventDestroy(b); } } evg{ev0, ev1};
   HIP_TRY(hipEventRecord(ev0, st));
 
-  Counters h{}; for (int k = 0; k < 12; k++) h.bounds[k] = (k % 6 < 3) ? ENC_POS_INF : ENC_NEG_INF; h.rootRef = MI355_EMPTY_REF;
-  HIP_TRY(hipMemcpyAsync(ctr.p, &h, sizeof(h), hipMemcpyHostToDevice, st));
+  Counters h{};
+  LAUNCH(build_begin, dim3(1), dim3(256), 0, st, ctr.p);
   const uint32_t genBlocks = (N + 255u) / 256u < 4096u ? (N + 255u) / 256u : 4096u;
-  hipLaunchKernelGGL(primref_gen, dim3(genBlocks), dim3(256), 0, st, dGeoms.p, (uint32_t)gd.size(), N, bufA.p, ctr.p);
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpyAsync(&h, ctr.p, sizeof(h), hipMemcpyDeviceToHost, st)); HIP_TRY(hipStreamSynchronize(st));
-  h.numPrims = N - h.numInvalid;
-  if (h.numInvalid) {                                          // rare: squeeze the invalid triangles out (stable)
-    const uint32_t tiles = (N + 255u) / 256u;
-    DevBuf<uint32_t> tileCount; HIP_TRY(tileCount.alloc(tiles));
-    hipLaunchKernelGGL(compact_count, dim3(tiles), dim3(256), 0, st, bufA.p, N, tileCount.p);
-    hipLaunchKernelGGL(compact_scan, dim3(1), dim3(1024), 0, st, tileCount.p, tiles, ctr.p);
-    hipLaunchKernelGGL(compact_scatter, dim3(tiles), dim3(256), 0, st, bufA.p, N, tileCount.p, bufB.p);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(bufA.p, bufB.p, (size_t)h.numPrims * sizeof(PrimRef), hipMemcpyDeviceToDevice, st));
-    HIP_TRY(hipStreamSynchronize(st));
-  }
-  uint32_t n = h.numPrims;
+  LAUNCH(primref_gen, dim3(genBlocks), dim3(256), 0, st, dGeoms.p, (uint32_t)gd.size(), N, bufA.p, ctr.p);
+  uint32_t n = N;                                              // fast path: an upper bound of the valid triangles (the device knows the number)
   auto decf = [](uint32_t u) { uint32_t v = u ^ ((u >> 31) ? 0x80000000u : 0xFFFFFFFFu); float f; memcpy(&f, &v, 4); return f; };
-  if (n == 0) { guard.ok = true; *out = bvh; return 0; }
   float glo[3], ghi[3], clo[3], chi[3];
-  for (int d = 0; d < 3; d++) { glo[d] = decf(h.bounds[d]); ghi[d] = decf(h.bounds[3 + d]); clo[d] = decf(h.bounds[6 + d]); chi[d] = decf(h.bounds[9 + d]); }
-  for (int d = 0; d < 3; d++) { info.bounds_lower[d] = glo[d]; info.bounds_upper[d] = ghi[d]; }
-  if (presplit && splitBudget > 0u && n > 0u) {
-    SplitGrid grid; float ext = 0.0f;
-    for (int d = 0; d < 3; d++) { grid.base[d] = glo[d]; ext = fmaxf(ext, ghi[d] - glo[d]); }
-    grid.extend = ext; grid.scale = ext == 0.0f ? 0.0f : 1024.0f / ext;
-    const uint32_t tiles = (n + 255u) / 256u;
-    DevBuf<float> prio, partial, psum; DevBuf<uint32_t> cnt, tileSum, total;
-    HIP_TRY(prio.alloc(n)); HIP_TRY(partial.alloc(tiles)); HIP_TRY(psum.alloc(1)); HIP_TRY(cnt.alloc(n)); HIP_TRY(tileSum.alloc(tiles)); HIP_TRY(total.alloc(1));
-    hipLaunchKernelGGL(presplit_priority, dim3(tiles), dim3(256), 0, st, bufA.p, n, dGeoms.p, grid, prio.p, partial.p);
-    hipLaunchKernelGGL(presplit_sum, dim3(1), dim3(1024), 0, st, partial.p, tiles, psum.p);
-    float budget = (float)splitBudget; uint32_t extra = 0; bool fits = false;
-    for (int attempt = 0; attempt < 6 && !fits; attempt++, budget *= 0.5f) {
-      hipLaunchKernelGGL(presplit_count, dim3(tiles), dim3(256), 0, st, bufA.p, n, dGeoms.p, grid, prio.p, psum.p, budget, cnt.p, tileSum.p);
-      hipLaunchKernelGGL(presplit_scan, dim3(1), dim3(1024), 0, st, tileSum.p, tiles, total.p);
-      HIP_TRY(hipGetLastError());
-      HIP_TRY(hipMemcpyAsync(&extra, total.p, 4, hipMemcpyDeviceToHost, st)); HIP_TRY(hipStreamSynchronize(st));
-      fits = extra <= splitBudget;
-    }
-    if (fits && extra > 0u) {
-      hipLaunchKernelGGL(presplit_emit, dim3(tiles), dim3(256), 0, st, bufA.p, n, dGeoms.p, grid, cnt.p, tileSum.p);
-      n += extra;
-      Counters hb = h; for (int k = 6; k < 12; k++) hb.bounds[k] = (k < 9) ? ENC_POS_INF : ENC_NEG_INF;
-      HIP_TRY(hipMemcpyAsync(ctr.p, &hb, sizeof(hb), hipMemcpyHostToDevice, st));
-      const uint32_t cb = (n + 255u) / 256u < 1024u ? (n + 255u) / 256u : 1024u;
-      hipLaunchKernelGGL(centroid_bounds, dim3(cb), dim3(256), 0, st, bufA.p, n, ctr.p);
-      HIP_TRY(hipGetLastError());
-      HIP_TRY(hipMemcpyAsync(&hb, ctr.p, sizeof(hb), hipMemcpyDeviceToHost, st)); HIP_TRY(hipStreamSynchronize(st));
-      for (int d = 0; d < 3; d++) { clo[d] = decf(hb.bounds[6 + d]); chi[d] = decf(hb.bounds[9 + d]); }
-      h.numPrims = n;
-    }
-    info.num_presplit = extra <= splitBudget ? extra : 0u;
-  }
-  info.num_triangles = n;
-
-  // root binary node + first work item
-  BNode rootB{}; for (int d = 0; d < 3; d++) { rootB.lo[d] = glo[d]; rootB.hi[d] = ghi[d]; } rootB.begin = 0; rootB.end = n; rootB.left = rootB.right = NIL; rootB.splitSah = INFINITY;
-  HIP_TRY(hipMemcpyAsync(bnodes.p, &rootB, sizeof(rootB), hipMemcpyHostToDevice, st));
-  h.numBLeaves = 0; h.numSegsNext = 0; h.numChunks = 0; h.numSmall = 0; h.numSegs = n > prm.small ? 1u : 0u; h.topLevels = 0;
   uint32_t numSegs = 0, numSmall = 0;
-  if (n > prm.small) {
-    Seg s0{}; s0.begin = 0; s0.end = n; s0.bnode = 0; for (int d = 0; d < 3; d++) { s0.cmin[d] = clo[d]; s0.cmax[d] = chi[d]; }
-    HIP_TRY(hipMemcpyAsync(segs0.p, &s0, sizeof(s0), hipMemcpyHostToDevice, st)); numSegs = 1;
+  if (fast) {
+    // invalid triangles are squeezed out on the device, if there are any; then the root
+    LAUNCH(compact_count, dim3(tiles), dim3(256), 0, st, bufA.p, N, tileCount.p, ctr.p);
+    LAUNCH(compact_scan, dim3(1), dim3(1024), 0, st, tileCount.p, tiles, ctr.p, 1u);
+    LAUNCH(compact_scatter, dim3(tiles), dim3(256), 0, st, bufA.p, N, tileCount.p, bufB.p, ctr.p);
+    LAUNCH(compact_copyback, dim3(tiles < 2048u ? tiles : 2048u), dim3(256), 0, st, bufB.p, bufA.p, ctr.p);
+    LAUNCH(root_setup, dim3(1), dim3(1), 0, st, ctr.p, bnodes.p, segs0.p, small.p, N, prm.small);
+    numSegs = N > prm.small ? 1u : 0u;
   } else {
-    SmallEntry se{}; se.begin = 0; se.end = n; se.bnode = 0; se.buf = 0; for (int d = 0; d < 3; d++) { se.cmin[d] = clo[d]; se.cmax[d] = chi[d]; }
-    HIP_TRY(hipMemcpyAsync(small.p, &se, sizeof(se), hipMemcpyHostToDevice, st)); h.numSmall = 1;
+    SYNC_READ(h);
+    h.numPrims = N - h.numInvalid;
+    if (h.numInvalid) {                                          // rare: squeeze the invalid triangles out (stable)
+      LAUNCH(compact_count, dim3(tiles), dim3(256), 0, st, bufA.p, N, tileCount.p, (const Counters*)nullptr);
+      LAUNCH(compact_scan, dim3(1), dim3(1024), 0, st, tileCount.p, tiles, ctr.p, 0u);
+      LAUNCH(compact_scatter, dim3(tiles), dim3(256), 0, st, bufA.p, N, tileCount.p, bufB.p, (const Counters*)nullptr);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipMemcpyAsync(bufA.p, bufB.p, (size_t)h.numPrims * sizeof(PrimRef), hipMemcpyDeviceToDevice, st));
+      HIP_TRY(hipStreamSynchronize(st)); syncs++;
+    }
+    n = h.numPrims;
+    if (n == 0) { guard.ok = true; *out = bvh; return 0; }
+    for (int d = 0; d < 3; d++) { glo[d] = decf(h.bounds[d]); ghi[d] = decf(h.bounds[3 + d]); clo[d] = decf(h.bounds[6 + d]); chi[d] = decf(h.bounds[9 + d]); }
+    for (int d = 0; d < 3; d++) { info.bounds_lower[d] = glo[d]; info.bounds_upper[d] = ghi[d]; }
+    if (presplit && splitBudget > 0u && n > 0u) {
+      SplitGrid grid; float ext = 0.0f;
+      for (int d = 0; d < 3; d++) { grid.base[d] = glo[d]; ext = fmaxf(ext, ghi[d] - glo[d]); }
+      grid.extend = ext; grid.scale = ext == 0.0f ? 0.0f : 1024.0f / ext;
+      const uint32_t ptiles = (n + 255u) / 256u;
+      DevBuf<float> prio, partial, psum; DevBuf<uint32_t> cnt, tileSum, totalExtra;
+      HIP_TRY(prio.alloc(n)); HIP_TRY(partial.alloc(ptiles)); HIP_TRY(psum.alloc(1)); HIP_TRY(cnt.alloc(n)); HIP_TRY(tileSum.alloc(ptiles)); HIP_TRY(totalExtra.alloc(1));
+      LAUNCH(presplit_priority, dim3(ptiles), dim3(256), 0, st, bufA.p, n, dGeoms.p, grid, prio.p, partial.p);
+      LAUNCH(presplit_sum, dim3(1), dim3(1024), 0, st, partial.p, ptiles, psum.p);
+      float budget = (float)splitBudget; uint32_t extra = 0; bool fits = false;
+      for (int attempt = 0; attempt < 6 && !fits; attempt++, budget *= 0.5f) {
+        LAUNCH(presplit_count, dim3(ptiles), dim3(256), 0, st, bufA.p, n, dGeoms.p, grid, prio.p, psum.p, budget, cnt.p, tileSum.p);
+        LAUNCH(presplit_scan, dim3(1), dim3(1024), 0, st, tileSum.p, ptiles, totalExtra.p);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(&extra, totalExtra.p, 4, hipMemcpyDeviceToHost, st)); HIP_TRY(hipStreamSynchronize(st)); syncs++;
+        fits = extra <= splitBudget;
+      }
+      if (fits && extra > 0u) {
+        LAUNCH(presplit_emit, dim3(ptiles), dim3(256), 0, st, bufA.p, n, dGeoms.p, grid, cnt.p, tileSum.p);
+        n += extra;
+        Counters hb = h; for (int k = 6; k < 12; k++) hb.bounds[k] = (k < 9) ? ENC_POS_INF : ENC_NEG_INF;
+        HIP_TRY(hipMemcpyAsync(ctr.p, &hb, sizeof(hb), hipMemcpyHostToDevice, st));
+        const uint32_t cb = (n + 255u) / 256u < 1024u ? (n + 255u) / 256u : 1024u;
+        LAUNCH(centroid_bounds, dim3(cb), dim3(256), 0, st, bufA.p, n, ctr.p);
+        Counters hb2; SYNC_READ(hb2);
+        for (int d = 0; d < 3; d++) { clo[d] = decf(hb2.bounds[6 + d]); chi[d] = decf(hb2.bounds[9 + d]); }
+        h.numPrims = n;
+      }
+      info.num_presplit = extra <= splitBudget ? extra : 0u;
+    }
+    // root binary node + first work item
+    BNode rootB{}; for (int d = 0; d < 3; d++) { rootB.lo[d] = glo[d]; rootB.hi[d] = ghi[d]; } rootB.begin = 0; rootB.end = n; rootB.left = rootB.right = NIL; rootB.splitSah = INFINITY;
+    HIP_TRY(hipMemcpyAsync(bnodes.p, &rootB, sizeof(rootB), hipMemcpyHostToDevice, st));
+    h.numBLeaves = 0; h.numSegsNext = 0; h.numChunks = 0; h.numSmall = 0; h.numSegs = n > prm.small ? 1u : 0u; h.topLevels = 0;
+    h.rootArea = fmaf(ghi[0] - glo[0], (ghi[1] - glo[1]) + (ghi[2] - glo[2]), (ghi[1] - glo[1]) * (ghi[2] - glo[2]));
+    if (n > prm.small) {
+      Seg s0{}; s0.begin = 0; s0.end = n; s0.bnode = 0; for (int d = 0; d < 3; d++) { s0.cmin[d] = clo[d]; s0.cmax[d] = chi[d]; }
+      HIP_TRY(hipMemcpyAsync(segs0.p, &s0, sizeof(s0), hipMemcpyHostToDevice, st)); numSegs = 1;
+    } else {
+      SmallEntry se{}; se.begin = 0; se.end = n; se.bnode = 0; se.buf = 0; for (int d = 0; d < 3; d++) { se.cmin[d] = clo[d]; se.cmax[d] = chi[d]; }
+      HIP_TRY(hipMemcpyAsync(small.p, &se, sizeof(se), hipMemcpyHostToDevice, st)); h.numSmall = 1;
+    }
+    HIP_TRY(hipMemcpyAsync(ctr.p, &h, sizeof(h), hipMemcpyHostToDevice, st));
   }
-  HIP_TRY(hipMemcpyAsync(ctr.p, &h, sizeof(h), hipMemcpyHostToDevice, st));
 
   if (prm.quality == 1u) {                                     // RTC_BUILD_QUALITY_LOW: Morton codes -> sort -> hierarchy -> boxes
     DevBuf<unsigned long long> keys, keysSorted; DevBuf<uint32_t> vals, valsSorted, parent, flags; DevBuf<char> tmp;
@@ -256,58 +276,65 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
     float3 cmin = make_float3(clo[0], clo[1], clo[2]), cscale;
     { const float e[3] = {chi[0] - clo[0], chi[1] - clo[1], chi[2] - clo[2]}; float s3[3]; for (int d = 0; d < 3; d++) s3[d] = e[d] > 0.0f ? 2097152.0f / e[d] : 0.0f; cscale = make_float3(s3[0], s3[1], s3[2]); }
     const uint32_t g = (n + 255u) / 256u;
-    hipLaunchKernelGGL(morton_keys, dim3(g), dim3(256), 0, st, bufA.p, n, cmin, cscale, keys.p, vals.p);
-    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.p, tmpBytes, keys.p, keysSorted.p, vals.p, valsSorted.p, (int)n, 0, 63, st));
-    hipLaunchKernelGGL(morton_gather, dim3(g), dim3(256), 0, st, bufA.p, valsSorted.p, n, bufB.p, finalIds.p);
+    LAUNCH(morton_keys, dim3(g), dim3(256), 0, st, bufA.p, n, cmin, cscale, keys.p, vals.p);
+    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.p, tmpBytes, keys.p, keysSorted.p, vals.p, valsSorted.p, (int)n, 0, 63, st)); launches += 8;
+    LAUNCH(morton_gather, dim3(g), dim3(256), 0, st, bufA.p, valsSorted.p, n, bufB.p, finalIds.p);
     HIP_TRY(hipMemsetAsync(flags.p, 0, (size_t)n * 4, st));
-    if (n > 1u) hipLaunchKernelGGL(lbvh_hierarchy, dim3((n + 254u) / 256u), dim3(256), 0, st, keysSorted.p, n, bnodes.p, parent.p);
-    hipLaunchKernelGGL(lbvh_bounds, dim3(g), dim3(256), 0, st, bufB.p, n, bnodes.p, parent.p, flags.p, ctr.p);
+    if (n > 1u) LAUNCH(lbvh_hierarchy, dim3((n + 254u) / 256u), dim3(256), 0, st, keysSorted.p, n, bnodes.p, parent.p);
+    LAUNCH(lbvh_bounds, dim3(g), dim3(256), 0, st, bufB.p, n, bnodes.p, parent.p, flags.p, ctr.p);
     HIP_TRY(hipGetLastError());
     numSegs = 0; numSmall = 0;
   }
   const bool sahBuild = prm.quality != 1u;
   // ---- top phase: one pass over the data per binary level.  Work-list sizes stay on the device: every kernel is launched with
   //      an upper bound of its grid (<= 2^level segments, <= N/CHUNK + #segments chunks) and surplus blocks exit at once, so
-  //      the levels are enqueued back to back; the host looks at the counters only where the level count is not implied by N.
+  //      the levels are enqueued back to back.
   uint32_t level = 0;
   Seg* cur = segs0.p; Seg* nxt = segs1.p;
   auto enqueue_top_level = [&]() {
     PrimRef* src = (level & 1u) ? bufB.p : bufA.p; PrimRef* dst = (level & 1u) ? bufA.p : bufB.p;
     const uint32_t segBound = level < 31u && (1u << level) < maxSegs ? (1u << level) : maxSegs;
     const uint32_t chunkBound = n / CHUNK + segBound + 1u;
-    hipLaunchKernelGGL(top_setup, dim3(segBound), dim3(256), 0, st, cur, bins.p, chunks.p, ctr.p);
-    hipLaunchKernelGGL(top_bin, dim3(chunkBound), dim3(256), 0, st, cur, chunks.p, src, bins.p, ctr.p);
-    hipLaunchKernelGGL(top_split, dim3(segBound), dim3(64), 0, st, cur, bins.p, bnodes.p, ctr.p, prm, level >= 96u ? 1u : 0u);
-    hipLaunchKernelGGL(top_partition, dim3(chunkBound), dim3(256), 0, st, cur, chunks.p, src, dst, ctr.p);
-    hipLaunchKernelGGL(top_emit, dim3((segBound + 255u) / 256u), dim3(256), 0, st, cur, bnodes.p, nxt, small.p, ctr.p, prm,
-                       (level & 1u) ? 0u : 1u, maxSegs, maxSmall);
-    hipLaunchKernelGGL(top_advance, dim3(1), dim3(1), 0, st, ctr.p, maxSegs);
+    LAUNCH(top_setup, dim3(segBound), dim3(256), 0, st, cur, bins.p, chunks.p, ctr.p);
+    LAUNCH(top_bin, dim3(chunkBound), dim3(256), 0, st, cur, chunks.p, src, bins.p, ctr.p);
+    LAUNCH(top_split, dim3(segBound), dim3(64), 0, st, cur, bins.p, bnodes.p, ctr.p, prm, level >= 96u ? 1u : 0u);
+    LAUNCH(top_partition, dim3(chunkBound), dim3(256), 0, st, cur, chunks.p, src, dst, ctr.p);
+    LAUNCH(top_emit, dim3((segBound + 255u) / 256u), dim3(256), 0, st, cur, bnodes.p, nxt, small.p, ctr.p, prm,
+           (level & 1u) ? 0u : 1u, maxSegs, maxSmall);
+    LAUNCH(top_advance, dim3(1), dim3(1), 0, st, ctr.p, maxSegs);
     Seg* t = cur; cur = nxt; nxt = t; level++;
   };
   if (numSegs && sahBuild) {
     uint32_t sure = 1; while (sure < 40u && ((uint64_t)prm.small << sure) < n) sure++;   // the largest segment halves at best: that many levels exist
-    for (uint32_t i = 0; i < sure; i++) enqueue_top_level();
-    for (;;) {
-      HIP_TRY(hipGetLastError());
-      HIP_TRY(hipMemcpyAsync(&h, ctr.p, sizeof(h), hipMemcpyDeviceToHost, st)); HIP_TRY(hipStreamSynchronize(st));
-      if (h.overflow) return set_error(hipErrorOutOfMemory, "top-phase work list overflow (pathological input)");
-      if (h.numSegs == 0) break;
-      enqueue_top_level(); enqueue_top_level();
+    if (fast) { for (uint32_t i = 0; i < sure + 8u; i++) enqueue_top_level(); }              // + margin: SAH splits are uneven (crown: 17 levels where 13 are implied)
+    else {
+      for (uint32_t i = 0; i < sure; i++) enqueue_top_level();
+      for (;;) {
+        SYNC_READ(h);
+        if (h.overflow) return set_error(hipErrorOutOfMemory, "top-phase work list overflow (pathological input)");
+        if (h.numSegs == 0) break;
+        enqueue_top_level(); enqueue_top_level();
+      }
     }
-  } else { HIP_TRY(hipMemcpyAsync(&h, ctr.p, sizeof(h), hipMemcpyDeviceToHost, st)); HIP_TRY(hipStreamSynchronize(st)); }
-  info.top_levels = h.topLevels;
-  numSmall = sahBuild ? h.numSmall : 0u;
-  if (numSmall > maxSmall) return set_error(hipErrorOutOfMemory, "small list overflow");
+  } else if (!fast) { SYNC_READ(h); }
 
   // ---- small phase
   const uint32_t microW = prm.minLeaf >= 2u ? 32u : 48u;       // LDS words per triangle of the micro mode (see micro_subtree)
   const size_t smallLds = sizeof(uint32_t) * (64u * microW > (uint32_t)BINS_WORDS ? 64u * microW : (uint32_t)BINS_WORDS);
-  if (numSmall) hipLaunchKernelGGL(small_build, dim3(numSmall), dim3(64), smallLds, st, small.p, bufA.p, bufB.p, bnodes.p, finalIds.p, ctr.p, prm, microW);
+  if (fast) {
+    // every small entry covers > small / 2^k ... triangles: at most one entry per top-phase leaf; the list cannot be longer than maxSmall (top_emit raises overflow)
+    const uint32_t bound = N > prm.small ? maxSmall : 1u;
+    LAUNCH(small_build, dim3(bound), dim3(64), smallLds, st, small.p, bufA.p, bufB.p, bnodes.p, finalIds.p, ctr.p, prm, microW);
+  } else {
+    info.top_levels = h.topLevels;
+    numSmall = sahBuild ? h.numSmall : 0u;
+    if (numSmall > maxSmall) return set_error(hipErrorOutOfMemory, "small list overflow");
+    if (numSmall) LAUNCH(small_build, dim3(numSmall), dim3(64), smallLds, st, small.p, bufA.p, bufB.p, bnodes.p, finalIds.p, ctr.p, prm, microW);
+  }
   HIP_TRY(hipGetLastError());
 
   // ---- wide collapse, level by level
-  const float rootArea = fmaf(ghi[0] - glo[0], (ghi[1] - glo[1]) + (ghi[2] - glo[2]), (ghi[1] - glo[1]) * (ghi[2] - glo[2]));
-  hipLaunchKernelGGL(wide_root, dim3(1), dim3(1), 0, st, w0.p, ctr.p);
+  LAUNCH(wide_root, dim3(1), dim3(1), 0, st, w0.p, ctr.p);
   WideItem* wc = w0.p; WideItem* wn = w1.p;
   uint32_t wlevel = 0;
   auto enqueue_wide_level = [&]() {
@@ -315,29 +342,54 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
     if (bound > maxLevelItems) bound = maxLevelItems;
     const uint32_t blocks = (uint32_t)((bound + 7u) / 8u) < 8192u ? (uint32_t)((bound + 7u) / 8u) : 8192u;   // = the waves resident at once
     const uint32_t parity = wlevel & 1u;
-    hipLaunchKernelGGL(wide_plan, dim3(blocks), dim3(64), 0, st, wc, bnodes.p, plans.p, itemCnt.p, groupSum.p, ctr.p, prm, parity, rootArea);
-    hipLaunchKernelGGL(wide_scan, dim3(1), dim3(1024), 0, st, groupSum.p, ctr.p, parity, maxWide);
-    hipLaunchKernelGGL(wide_emit, dim3(blocks), dim3(64), 0, st, wc, bnodes.p, plans.p, itemCnt.p, groupSum.p, wnodes.p, finalIds.p, outIds.p, wn, ctr.p, parity);
+    LAUNCH(wide_plan, dim3(blocks), dim3(64), 0, st, wc, bnodes.p, plans.p, itemCnt.p, groupSum.p, ctr.p, prm, parity);
+    LAUNCH(wide_scan, dim3(1), dim3(1024), 0, st, groupSum.p, ctr.p, parity, maxWide);
+    LAUNCH(wide_emit, dim3(blocks), dim3(64), 0, st, wc, bnodes.p, plans.p, itemCnt.p, groupSum.p, wnodes.p, finalIds.p, outIds.p, wn, ctr.p, parity);
     WideItem* t = wc; wc = wn; wn = t; wlevel++;
   };
-  for (uint32_t i = 0; i < 8u; i++) enqueue_wide_level();
-  for (;;) {
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(&h, ctr.p, sizeof(h), hipMemcpyDeviceToHost, st)); HIP_TRY(hipStreamSynchronize(st));
-    if (h.overflow) return set_error(hipErrorOutOfMemory, "wide node pool overflow");
-    if (h.wideCount[wlevel & 1u] == 0) break;
-    for (uint32_t i = 0; i < 4u; i++) enqueue_wide_level();
+  if (fast) {
+    // the depth of the wide tree is unknown here: 24 levels cover every scene measured so far (crown 12, powerplant 14); a deeper tree is finished below
+    for (uint32_t i = 0; i < 24u; i++) enqueue_wide_level();
+    // the leaf records can be written as soon as the leaf order is known; their array is sized by the upper bound N
+    HIP_TRY(hipMalloc(&bvh->d_tris, (size_t)N * sizeof(TriRec) + 128));
+    LAUNCH(tri_records, dim3((N + 255u) / 256u), dim3(256), 0, st, outIds.p, N, dGeoms.p, (TriRec*)bvh->d_tris, bp->robust ? 1u : 0u, (const Counters*)ctr.p);
+    SYNC_READ(h);                                                // the ONE round trip of the commit
+    if (h.overflow) return set_error(hipErrorOutOfMemory, "work list overflow (pathological input)");
+    if (h.numSegs != 0u) {                                       // the top phase needed more levels than N implies + 8: what came after it worked on an unfinished tree
+      return -1000;                                              // (the guard frees the half-built tree) the caller repeats the commit on the stepwise path
+    }
+    n = h.numPrims;
+    if (n == 0) { hipFree(bvh->d_tris); bvh->d_tris = nullptr; info.num_launches = launches; info.num_host_syncs = syncs; guard.ok = true; *out = bvh; return 0; }
+    for (int d = 0; d < 3; d++) { info.bounds_lower[d] = decf(h.bounds[d]); info.bounds_upper[d] = decf(h.bounds[3 + d]); }
+    info.top_levels = h.topLevels;
+    bool redoLeaves = false;
+    while (h.wideCount[wlevel & 1u] != 0u) {                     // deeper than 24 levels: go on level by level, then write the leaf records again
+      for (uint32_t i = 0; i < 4u; i++) enqueue_wide_level();
+      SYNC_READ(h);
+      if (h.overflow) return set_error(hipErrorOutOfMemory, "wide node pool overflow");
+      redoLeaves = true;
+    }
+    if (redoLeaves) LAUNCH(tri_records, dim3((N + 255u) / 256u), dim3(256), 0, st, outIds.p, N, dGeoms.p, (TriRec*)bvh->d_tris, bp->robust ? 1u : 0u, (const Counters*)ctr.p);
+  } else {
+    for (uint32_t i = 0; i < 8u; i++) enqueue_wide_level();
+    for (;;) {
+      SYNC_READ(h);
+      if (h.overflow) return set_error(hipErrorOutOfMemory, "wide node pool overflow");
+      if (h.wideCount[wlevel & 1u] == 0) break;
+      for (uint32_t i = 0; i < 4u; i++) enqueue_wide_level();
+    }
+    HIP_TRY(hipMalloc(&bvh->d_tris, (size_t)n * sizeof(TriRec) + 128));
+    LAUNCH(tri_records, dim3((n + 255u) / 256u), dim3(256), 0, st, outIds.p, n, dGeoms.p, (TriRec*)bvh->d_tris, bp->robust ? 1u : 0u, (const Counters*)nullptr);
   }
+  info.num_triangles = n;
   const uint32_t depth = h.wideDepth;
 
-  // ---- final arrays (exact size) + triangle records
+  // ---- final node array (exact size)
   const uint32_t numNodes = h.numWide;
-  HIP_TRY(hipMalloc(&bvh->d_tris, (size_t)n * sizeof(TriRec) + 128));
   if (numNodes) {
     HIP_TRY(hipMalloc(&bvh->d_nodes, (size_t)numNodes * sizeof(CNode)));
     HIP_TRY(hipMemcpyAsync(bvh->d_nodes, wnodes.p, (size_t)numNodes * sizeof(CNode), hipMemcpyDeviceToDevice, st));
   }
-  hipLaunchKernelGGL(tri_records, dim3((n + 255u) / 256u), dim3(256), 0, st, outIds.p, n, dGeoms.p, (TriRec*)bvh->d_tris, bp->robust ? 1u : 0u);
   bvh->robust = bp->robust != 0;
   if (bp->refit && h.numInvalid == 0u && depth < 64u && !presplit) {        // keep the leaf order and the level table for mi355_bvh_refit
     HIP_TRY(hipMalloc(&bvh->d_ids, (size_t)n * sizeof(uint2)));
@@ -347,14 +399,17 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
     info.bytes_refit = (uint64_t)n * sizeof(uint2);
   }
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipEventRecord(ev1, st)); HIP_TRY(hipEventSynchronize(ev1));
+  HIP_TRY(hipEventRecord(ev1, st)); HIP_TRY(hipEventSynchronize(ev1)); syncs++;
   float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
   bvh->root = h.rootRef;
   info.root_ref = h.rootRef; info.num_nodes = numNodes; info.num_leaves = h.numLeaves; info.num_binary_nodes = 2ull * h.numBLeaves - 1ull;
   info.bytes_nodes = (uint64_t)numNodes * sizeof(CNode); info.bytes_triangles = (uint64_t)n * sizeof(TriRec);
   info.sah = (float)((double)h.sahFixed / 16777216.0) + (numNodes ? prm.travCost : 0.0f); info.build_ms = ms; info.depth = depth;
+  info.num_launches = launches; info.num_host_syncs = syncs;
   guard.ok = true; *out = bvh;
   return 0;
+#undef LAUNCH
+#undef SYNC_READ
 }
 
 static int refit_impl(Bvh* bvh, const mi355_mesh* meshes, uint32_t numMeshes, hipStream_t st) {
@@ -385,7 +440,7 @@ static int refit_impl(Bvh* bvh, const mi355_mesh* meshes, uint32_t numMeshes, hi
   HIP_TRY(hipEventRecord(ev0, st));
   HIP_TRY(hipMemcpyAsync(dGeoms.p, gd.data(), gd.size() * sizeof(GeomDesc), hipMemcpyHostToDevice, st));
   HIP_TRY(hipMemsetAsync(flag.p, 0, 4, st));
-  hipLaunchKernelGGL(tri_records, dim3((n + 255u) / 256u), dim3(256), 0, st, (const uint2*)bvh->d_ids, n, dGeoms.p, (TriRec*)bvh->d_tris, bvh->robust ? 1u : 0u);
+  hipLaunchKernelGGL(tri_records, dim3((n + 255u) / 256u), dim3(256), 0, st, (const uint2*)bvh->d_ids, n, dGeoms.p, (TriRec*)bvh->d_tris, bvh->robust ? 1u : 0u, (const Counters*)nullptr);
   for (size_t l = bvh->lvlStart.size() - 1; l-- > 0;) {        // deepest level first
     const uint32_t first = bvh->lvlStart[l], count = bvh->lvlStart[l + 1] - first;
     if (!count) continue;
@@ -486,7 +541,7 @@ static int build_instanced_impl(int device, Bvh* own, const mi355_instance* inst
   mi355_mesh fake{}; fake.d_vertices = dfv; fake.vertex_stride = 12; fake.num_vertices = 3 * R; fake.d_indices = dfi; fake.index_stride = 12; fake.num_triangles = R; fake.geom_id = 0; fake.mask = 0xFFFFFFFFu;
   mi355_build_params tp = *bp; tp.refit = 0; tp.quality = 0;
   Bvh* top = nullptr;
-  { const int rc = build_impl(device, &fake, 1, &tp, st, &top); if (rc) return rc; }
+  { int rc = build_impl(device, &fake, 1, &tp, st, &top); if (rc == -1000) rc = build_impl(device, &fake, 1, &tp, st, &top, false); if (rc) return rc; }
   struct TopGuard { Bvh* t; ~TopGuard() { delete t; } } topGuard{top};
   if (top->info.num_triangles != R) return set_error(hipErrorInvalidValue, "top-level build dropped an instance");
   bvh->numCUs = top->numCUs;
@@ -540,7 +595,8 @@ int mi355_device_name(int device, char* out, size_t n) {
 int mi355_bvh_build(int device, const mi355_mesh* meshes, uint32_t num_meshes, const mi355_build_params* params, void* stream, mi355_bvh_t* out) {
   mi355_build_params def; if (!params) { mi355_default_build_params(&def); params = &def; }
   mi355::Bvh* b = nullptr;
-  const int rc = mi355::build_impl(device, meshes, num_meshes, params, (hipStream_t)stream, &b);
+  int rc = mi355::build_impl(device, meshes, num_meshes, params, (hipStream_t)stream, &b);
+  if (rc == -1000) rc = mi355::build_impl(device, meshes, num_meshes, params, (hipStream_t)stream, &b, false);   // margins of the one-round-trip path exceeded: stepwise path
   *out = (mi355_bvh_t)b; return rc;
 }
 void mi355_bvh_destroy(mi355_bvh_t bvh) { delete (mi355::Bvh*)bvh; }

@@ -46,6 +46,8 @@ struct Counters {
   uint32_t overflow, rootRef, numTrisOut, numInvalid;
   uint32_t numSegs, topLevels, wideDepth, lvlNodeBase, lvlTriBase, wideCount[2];      // level loops are driven from the device: no host readback per level
   unsigned long long sahFixed;                    // SAH statistics, 2^-24 fixed point (order-independent sum)
+  float rootArea;                                 // half area of the scene bounds (SAH statistics are relative to it); written by root_setup
+  uint32_t pad0;
   uint32_t lvlStart[64];                          // first node of every level of the wide tree (numbering is breadth first): what a refit walks bottom-up
 };
 struct Params { uint32_t shift, minLeaf, maxLeaf, small; float travCost, intCost; uint32_t quality; };

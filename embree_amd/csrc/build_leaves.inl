@@ -1,9 +1,9 @@
 // build_leaves.inl -- K5: leaf records; refit; node rebasing for instanced scenes.
 // Part of build.hip (included inside its anonymous namespace); see the header of build.hip for the pipeline.
 // --------------------------------------------------------------------------------- K5 tri_records
-__global__ __launch_bounds__(256) void tri_records(const uint2* finalIds, uint32_t n, const GeomDesc* geoms, TriRec* out, uint32_t robust) {
+__global__ __launch_bounds__(256) void tri_records(const uint2* finalIds, uint32_t n, const GeomDesc* geoms, TriRec* out, uint32_t robust, const Counters* ctr) {
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-  if (i >= n) return;
+  if (i >= (ctr ? ctr->numPrims : n)) return;                    // ctr: the grid is an upper bound, the number of valid triangles is on the device
   uint2 id = finalIds[i];
   const GeomDesc g = geoms[id.x];
   uint32_t i0, i1, i2, pid;

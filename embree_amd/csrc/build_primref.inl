@@ -58,15 +58,28 @@ __global__ __launch_bounds__(256) void primref_gen(const GeomDesc* geoms, uint32
   if (tid < 12) { if (tid % 6 < 3) atomicMin(&ctr->bounds[tid], s_acc[tid]); else atomicMax(&ctr->bounds[tid], s_acc[tid]); }
 }
 
-// rare path: stable compaction of the valid PrimRefs (tile = 256 consecutive entries)
-__global__ __launch_bounds__(256) void compact_count(const PrimRef* in, uint32_t n, uint32_t* tileCount) {
+// first kernel of a commit: the counters' initial state (what the host used to upload)
+__global__ void build_begin(Counters* ctr) {
+  const uint32_t t = threadIdx.x;
+  uint32_t* w = (uint32_t*)ctr;
+  for (uint32_t i = t; i < sizeof(Counters) / 4u; i += blockDim.x) w[i] = 0u;
+  __syncthreads();
+  if (t < 12u) ctr->bounds[t] = (t % 6u < 3u) ? ENC_POS_INF : ENC_NEG_INF;
+  if (t == 0u) ctr->rootRef = MI355_EMPTY_REF;
+}
+
+// rare path: stable compaction of the valid PrimRefs (tile = 256 consecutive entries).  `ctr` != nullptr: the commit runs without a host round trip
+// after primref_gen, so the kernels are always enqueued and return at once when there is nothing to squeeze out.
+__global__ __launch_bounds__(256) void compact_count(const PrimRef* in, uint32_t n, uint32_t* tileCount, const Counters* ctr) {
+  if (ctr && ctr->numInvalid == 0u) return;
   const uint32_t p = blockIdx.x * 256u + threadIdx.x;
   const bool ok = p < n && in[p].geom != NIL;
   const int c = __syncthreads_count(ok);
   if (threadIdx.x == 0) tileCount[blockIdx.x] = (uint32_t)c;
 }
-__global__ __launch_bounds__(1024) void compact_scan(uint32_t* tileCount, uint32_t numTiles, Counters* ctr) {
+__global__ __launch_bounds__(1024) void compact_scan(uint32_t* tileCount, uint32_t numTiles, Counters* ctr, uint32_t guarded) {
   __shared__ uint32_t s_part[1024];
+  if (guarded && ctr->numInvalid == 0u) return;
   const uint32_t tid = threadIdx.x, per = (numTiles + 1023u) / 1024u, b = tid * per, e = min(b + per, numTiles);
   uint32_t sum = 0; for (uint32_t i = b; i < e; i++) sum += tileCount[i];
   s_part[tid] = sum; __syncthreads();
@@ -74,8 +87,9 @@ __global__ __launch_bounds__(1024) void compact_scan(uint32_t* tileCount, uint32
   __syncthreads();
   uint32_t run = s_part[tid]; for (uint32_t i = b; i < e; i++) { const uint32_t t = tileCount[i]; tileCount[i] = run; run += t; }
 }
-__global__ __launch_bounds__(256) void compact_scatter(const PrimRef* in, uint32_t n, const uint32_t* tileOfs, PrimRef* out) {
+__global__ __launch_bounds__(256) void compact_scatter(const PrimRef* in, uint32_t n, const uint32_t* tileOfs, PrimRef* out, const Counters* ctr) {
   __shared__ uint32_t s_w[4];
+  if (ctr && ctr->numInvalid == 0u) return;
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, p = blockIdx.x * 256u + tid;
   PrimRef r{}; bool ok = false;
   if (p < n) { r = load_prim(in + p); ok = r.geom != NIL; }
@@ -84,4 +98,33 @@ __global__ __launch_bounds__(256) void compact_scatter(const PrimRef* in, uint32
   __syncthreads();
   uint32_t off = tileOfs[blockIdx.x]; for (uint32_t w = 0; w < wave; w++) off += s_w[w];
   if (ok) store_prim(out + off + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)), r);
+}
+
+__global__ __launch_bounds__(256) void compact_copyback(const PrimRef* in, PrimRef* out, const Counters* ctr) {   // the squeezed array goes back to where the build expects it
+  if (ctr->numInvalid == 0u) return;
+  const uint32_t n = ctr->numPrims;
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) store_prim(out + i, load_prim(in + i));
+}
+
+// Root of the binary tree and the first work item, made on the device from what primref_gen (and the compaction) left in the counters: the commit
+// needs no host round trip to learn the scene bounds or the number of valid triangles (the reference: PrimInfo pinfo = createPrimRefArray(...),
+// bvh_builder_sah.cpp:136, then BVHBuilderBinnedSAH::build(pinfo) -- one address space, no round trip there either).
+__global__ void root_setup(Counters* ctr, BNode* bnodes, Seg* segs0, SmallEntry* small, uint32_t totalPrims, uint32_t smallThreshold) {
+  if (threadIdx.x != 0u || blockIdx.x != 0u) return;
+  const uint32_t n = ctr->numInvalid ? ctr->numPrims : totalPrims;
+  ctr->numPrims = n;
+  float glo[3], ghi[3], clo[3], chi[3];
+  for (int d = 0; d < 3; d++) { glo[d] = dec(ctr->bounds[d]); ghi[d] = dec(ctr->bounds[3 + d]); clo[d] = dec(ctr->bounds[6 + d]); chi[d] = dec(ctr->bounds[9 + d]); }
+  ctr->rootArea = n ? fmaf(ghi[0] - glo[0], (ghi[1] - glo[1]) + (ghi[2] - glo[2]), (ghi[1] - glo[1]) * (ghi[2] - glo[2])) : 0.0f;
+  ctr->numBLeaves = 0; ctr->numSegsNext = 0; ctr->numChunks = 0; ctr->numSmall = 0; ctr->numSegs = 0; ctr->topLevels = 0;
+  if (n == 0u) return;
+  BNode rootB{}; for (int d = 0; d < 3; d++) { rootB.lo[d] = glo[d]; rootB.hi[d] = ghi[d]; } rootB.begin = 0; rootB.end = n; rootB.left = rootB.right = NIL; rootB.splitSah = __builtin_inff();
+  bnodes[0] = rootB;
+  if (n > smallThreshold) {
+    Seg s0{}; s0.begin = 0; s0.end = n; s0.bnode = 0; for (int d = 0; d < 3; d++) { s0.cmin[d] = clo[d]; s0.cmax[d] = chi[d]; }
+    segs0[0] = s0; ctr->numSegs = 1;
+  } else {
+    SmallEntry se{}; se.begin = 0; se.end = n; se.bnode = 0; se.buf = 0; for (int d = 0; d < 3; d++) { se.cmin[d] = clo[d]; se.cmax[d] = chi[d]; }
+    small[0] = se; ctr->numSmall = 1;
+  }
 }

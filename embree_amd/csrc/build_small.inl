@@ -212,6 +212,7 @@ __global__ __launch_bounds__(64) void small_build(const SmallEntry* entries, Pri
   __shared__ unsigned long long s_key[64];
   uint32_t* const s_bins = s_R;
   const uint32_t lane = threadIdx.x;
+  if (blockIdx.x >= ctr->numSmall) return;                       // the grid is an upper bound (the host does not read the list's length back)
   const SmallEntry e0 = entries[blockIdx.x];
   StackEntry cur; cur.begin = e0.begin; cur.end = e0.end; cur.bnode = e0.bnode; cur.buf = e0.buf;
   for (int d = 0; d < 3; d++) { cur.cmin[d] = e0.cmin[d]; cur.cmax[d] = e0.cmax[d]; }

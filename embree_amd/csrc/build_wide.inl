@@ -39,7 +39,8 @@ struct WidePlan { uint32_t ch[8]; uint32_t imask, leafMask, nch, pad; };   // by
 
 __global__ void wide_root(WideItem* items, Counters* ctr) {
   items[0].bnode = 0; items[0].node = 0;                       // the root is always CNode 0
-  ctr->rootRef = 0; ctr->numWide = 1; ctr->wideCount[0] = 1; ctr->wideCount[1] = 0; ctr->wideDepth = 0; ctr->lvlStart[0] = 0; ctr->numLeaves = 0; ctr->numTrisOut = 0; ctr->sahFixed = 0ull;
+  const bool any = ctr->numPrims != 0u;                        // (a scene whose triangles are all invalid has no tree)
+  ctr->rootRef = any ? 0u : MI355_EMPTY_REF; ctr->numWide = any ? 1u : 0u; ctr->wideCount[0] = any ? 1u : 0u; ctr->wideCount[1] = 0; ctr->wideDepth = 0; ctr->lvlStart[0] = 0; ctr->numLeaves = 0; ctr->numTrisOut = 0; ctr->sahFixed = 0ull;
 }
 
 template <typename T> __device__ __forceinline__ T grp_get(T v, uint32_t lane, uint32_t idx) { return __shfl(v, (int)((lane & ~7u) | idx), 64); }
@@ -60,8 +61,9 @@ __device__ __forceinline__ BNode load_bnode(const BNode* p) {
 }
 
 __global__ __launch_bounds__(64) void wide_plan(const WideItem* items, const BNode* bnodes, WidePlan* plans, uint2* itemCnt, uint2* groupSum,
-                                                Counters* ctr, Params prm, uint32_t parity, float rootArea) {
+                                                Counters* ctr, Params prm, uint32_t parity) {
   const uint32_t numItems = ctr->wideCount[parity];
+  const float rootArea = ctr->rootArea;
   const uint32_t lane = threadIdx.x, c = lane & 7u, g = lane >> 3;
   unsigned long long sahAcc = 0ull; uint32_t leafAcc = 0u;      // per-wave partial sums: one atomic per wave at the end (a same-address atomic costs ~2 ns)
   for (uint32_t base = blockIdx.x * 8u; base < numItems; base += gridDim.x * 8u) {

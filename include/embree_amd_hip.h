@@ -74,6 +74,8 @@ typedef struct mi355_bvh_info {
   uint64_t bytes_refit;      /* extra device memory kept for mi355_bvh_refit (0 unless built with params.refit) */
   uint32_t num_refits;       /* refits since the build; build_ms is the GPU time of the last build OR refit */
   uint32_t num_presplit;     /* quality 2: references added by pre-splitting (num_triangles counts references = leaf records) */
+  uint32_t num_launches;     /* kernel launches of the last build */
+  uint32_t num_host_syncs;   /* host round trips (stream synchronisations) of the last build: 2 on the default path (counters, final copy) */
 } mi355_bvh_info;
 
 MI355_API void mi355_default_build_params(mi355_build_params* p);

@@ -93,7 +93,9 @@ def compare_closest_arbitrated(got, want_fast, want_robust, rays_in, tri_t, max_
         bad = idx[~(is_tie | as_robust)]
     assert len(bad) == 0, f"{label}: {len(bad)}/{n} rays differ from the fast AND the robust reference (first {bad[:8]})"
     r_hit = want_robust["geomID"] != INVALID_ID
-    lost = r_hit & ((got["geomID"] == INVALID_ID) | (got["tfar"] > want_robust["tfar"] * np.float32(1 + RTOL)))
+    # nothing may be lost against the robust reference -- except where the fast reference gives the very same answer (the Moeller-Trumbore test is not
+    # watertight: a ray through an edge can slip between two triangles in the reference's fast mode as well, and bit-identical arithmetic slips with it)
+    lost = r_hit & ((got["geomID"] == INVALID_ID) | (got["tfar"] > want_robust["tfar"] * np.float32(1 + RTOL))) & ~same
     assert not lost.any(), f"{label}: {int(lost.sum())} rays end farther than the robust reference's hit (first {np.nonzero(lost)[0][:8]})"
     assert ties <= max(2, max_tie_frac * n), f"{label}: too many ties {ties}/{n}"
     assert ref_missed <= max_ref_miss_frac * n, f"{label}: {ref_missed} hits missing in the fast reference"
