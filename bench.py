@@ -172,6 +172,9 @@ class Events:
             self.L.mi355_event_destroy(e)
 
 
+STUCK = []            # helper threads that never came back from a collective
+
+
 def run_guarded(fn, timeout_s):
     """Runs fn() on a helper thread and gives up waiting after timeout_s (a collective that never completes must not take the result line down)."""
     box = {}
@@ -185,6 +188,7 @@ def run_guarded(fn, timeout_s):
     th.start()
     th.join(timeout_s)
     if th.is_alive():
+        STUCK.append(th)
         return dict(error="timed out after %d s" % timeout_s)
     return box.get("value") if "value" in box else dict(error=box.get("error", "unknown"))
 
@@ -476,7 +480,10 @@ def main():
                 "algorithmic_bytes_per_launch": int(alg_bytes),
                 "per_ray": {"nodes": round(st["nodes"] / M, 2), "node_step_simd_util": round(st["nodes"] / max(1, 64 * st["node_blocks"]), 3),
                             "tri_step_simd_util": round(st["tris"] / max(1, 64 * st["tri_blocks"]), 3),
-                            "triangles": round(st["tris"] / M, 2), "empty_node_visits": round(st["empty_nodes"] / M, 2), "bytes": round(alg_bytes / M, 1)},
+                            "triangles": round(st["tris"] / M, 2), "empty_node_visits": round(st["empty_nodes"] / M, 2), "bytes": round(alg_bytes / M, 1),
+                            "wave_iterations": int(st["wave_iters"]), "node_step_blocks": int(st["node_blocks"]), "tri_step_blocks": int(st["tri_blocks"]),
+                            "handout_events": int(st["refill_events"]), "handout_clock_share": round(st["refill_clocks"] / max(1, st["loop_clocks"]), 4),
+                            "node_step_clock_share": round(st["node_step_clocks"] / max(1, st["loop_clocks"]), 4)},
                 "note": "achieved = algorithmic bytes (SURVEY 8d) per launch / average duration of the timed launches (HIP events on the launch stream). Most of these bytes are "
                         "served by L1 / L2 / Infinity Cache: hbm_counter is what reaches the memory side, valu is the roof that binds."}
         if len(tstreams) > 1:
@@ -556,7 +563,8 @@ def main():
     if dist:
         dist[0].destroy_process_group()
     sys.stdout.flush()
-    os._exit(0)                                              # (a helper thread stuck in a collective must not keep the process alive)
+    if STUCK:
+        os._exit(0)                                          # a helper thread stuck in a collective must not keep the process alive (normal exit otherwise: profilers flush at exit)
 
 
 if __name__ == "__main__":

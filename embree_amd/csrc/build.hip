@@ -59,6 +59,11 @@ struct Arena {
   struct Block { char* p; size_t cap, used; };
   std::mutex mtx;
   std::vector<Block> blocks;
+  // The launch sequence of a default-quality commit, captured once as a HIP graph and replayed while its kernel arguments stay what they were (same
+  // triangle count, same parameters, same arena addresses): a dynamic scene that is re-committed every frame pays ONE host call for its ~200 launches.
+  hipStream_t stream = nullptr;                              // commits enqueue here when the caller gives no stream (a capture needs a real stream)
+  std::vector<uint64_t> graphKey; hipGraphExec_t graphExec = nullptr; bool graphBroken = false;   // graphBroken: capture / instantiate failed once on this device: plain launches from then on
+  void drop_graph() { if (graphExec) { hipGraphExecDestroy(graphExec); graphExec = nullptr; } graphKey.clear(); }
   void reset() { for (auto& b : blocks) b.used = 0; }
   hipError_t take(size_t bytes, void** out) {
     bytes = (bytes + 255) & ~(size_t)255;
@@ -68,7 +73,7 @@ struct Arena {
     if (e != hipSuccess) return e;
     blocks.push_back(nb); *out = nb.p; return hipSuccess;
   }
-  void release() { for (auto& b : blocks) hipFree(b.p); blocks.clear(); }
+  void release() { drop_graph(); for (auto& b : blocks) hipFree(b.p); blocks.clear(); }
 };
 static std::mutex g_arenaMtx;
 static std::map<int, Arena*> g_arenas;
@@ -102,7 +107,7 @@ TraceScratch* Bvh::scratch_for(hipStream_t s) {
   TraceScratch sc;
   if (hipMalloc((void**)&sc.counter, 4096) != hipSuccess) return nullptr;
   if (hipMalloc(&sc.spill, trace_spill_bytes(numCUs, info.depth)) != hipSuccess) return nullptr;
-  if (hipMalloc((void**)&sc.stats, 128) != hipSuccess) return nullptr;
+  if (hipMalloc((void**)&sc.stats, 256) != hipSuccess) return nullptr;
   { void* h = nullptr; void* d = nullptr;
     if (hipHostMalloc(&h, 64, hipHostMallocMapped) != hipSuccess) return nullptr;
     memset(h, 0, 64);
@@ -162,8 +167,15 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
   const uint32_t N = (uint32_t)total;
   static const bool envSync = getenv("MI355_BUILD_STEPWISE") != nullptr;         // A/B: force the stepwise path
   const bool fast = allowFast && !envSync && prm.quality == 0u;
+  static const bool envGraph = !(getenv("MI355_BUILD_GRAPH") && atoi(getenv("MI355_BUILD_GRAPH")) == 0);
+  if (fast && envGraph && !st && !arena->graphBroken) {        // the graph needs a stream of its own
+    if (!arena->stream && hipStreamCreateWithFlags(&arena->stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); arena->stream = nullptr; }
+    st = arena->stream;
+  }
+  const bool useGraph = fast && envGraph && st != nullptr && !arena->graphBroken;
   uint32_t launches = 0, syncs = 0;
-#define LAUNCH(...) do { hipLaunchKernelGGL(__VA_ARGS__); launches++; } while (0)
+  bool replay = false, capturing = false;                       // fast path: the launches below are replayed from the cached graph / are being captured into one
+#define LAUNCH(...) do { if (!replay) hipLaunchKernelGGL(__VA_ARGS__); launches++; } while (0)
 #define SYNC_READ(h) do { HIP_TRY(hipGetLastError()); HIP_TRY(hipMemcpyAsync(&(h), ctr.p, sizeof(h), hipMemcpyDeviceToHost, st)); HIP_TRY(hipStreamSynchronize(st)); syncs++; } while (0)
 
   DevBuf<GeomDesc> dGeoms; HIP_TRY(dGeoms.alloc(gd.size()));
@@ -189,7 +201,20 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
 
   hipEvent_t ev0, ev1; HIP_TRY(hipEventCreate(&ev0)); HIP_TRY(hipEventCreate(&ev1));
   struct EvGuard { hipEvent_t a, b; ~EvGuard() { hipEventDestroy(a); hipEventDestroy(b); } } evg{ev0, ev1};
-  HIP_TRY(hipEventRecord(ev0, st));
+  if (useGraph) {
+    HIP_TRY(hipStreamSynchronize(st));                         // (the geometry table above is in place before anything is captured)
+    const void* ptrs[] = {dGeoms.p, bufA.p, bufB.p, finalIds.p, bnodes.p, segs0.p, segs1.p, bins.p, chunks.p, small.p, ctr.p, w0.p, w1.p, wnodes.p, outIds.p, plans.p, itemCnt.p, groupSum.p, tileCount.p, (const void*)st};
+    std::vector<uint64_t> key; for (const void* q : ptrs) key.push_back((uint64_t)(uintptr_t)q);
+    uint32_t pw[sizeof(Params) / 4]; memcpy(pw, &prm, sizeof(prm)); for (uint32_t w : pw) key.push_back(w);
+    key.push_back(N); key.push_back(gd.size()); key.push_back(bp->robust);
+    if (arena->graphExec && arena->graphKey == key) replay = true;
+    else {
+      arena->drop_graph(); arena->graphKey = key;
+      if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) capturing = true; else (void)hipGetLastError();
+    }
+  }
+  struct CapGuard { hipStream_t s; bool& on; ~CapGuard() { if (on) { hipGraph_t g = nullptr; hipStreamEndCapture(s, &g); if (g) hipGraphDestroy(g); (void)hipGetLastError(); } } } capGuard{st, capturing};
+  if (!capturing && !replay) HIP_TRY(hipEventRecord(ev0, st));
 
   Counters h{};
   LAUNCH(build_begin, dim3(1), dim3(256), 0, st, ctr.p);
@@ -350,6 +375,17 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
   if (fast) {
     // the depth of the wide tree is unknown here: 24 levels cover every scene measured so far (crown 12, powerplant 14); a deeper tree is finished below
     for (uint32_t i = 0; i < 24u; i++) enqueue_wide_level();
+    if (capturing) {                                             // end of the captured sequence: instantiate, keep, run
+      hipGraph_t graph = nullptr;
+      const hipError_t e = hipStreamEndCapture(st, &graph);
+      capturing = false;
+      if (e != hipSuccess || !graph) { (void)hipGetLastError(); arena->drop_graph(); arena->graphBroken = true; return -1000; }   // the caller repeats the commit with plain launches
+      const hipError_t e2 = hipGraphInstantiate(&arena->graphExec, graph, nullptr, nullptr, 0);
+      hipGraphDestroy(graph);
+      if (e2 != hipSuccess) { (void)hipGetLastError(); arena->graphExec = nullptr; arena->drop_graph(); arena->graphBroken = true; return -1000; }
+      replay = true;
+    }
+    if (replay) { HIP_TRY(hipEventRecord(ev0, st)); HIP_TRY(hipGraphLaunch(arena->graphExec, st)); replay = false; }
     // the leaf records can be written as soon as the leaf order is known; their array is sized by the upper bound N
     HIP_TRY(hipMalloc(&bvh->d_tris, (size_t)N * sizeof(TriRec) + 128));
     LAUNCH(tri_records, dim3((N + 255u) / 256u), dim3(256), 0, st, outIds.p, N, dGeoms.p, (TriRec*)bvh->d_tris, bp->robust ? 1u : 0u, (const Counters*)ctr.p);

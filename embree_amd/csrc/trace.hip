@@ -48,7 +48,7 @@ constexpr uint32_t ITER_CAP = 1u << 24;    // safety net only: a corrupt tree mu
 // Neither safety net may fail silently: a wave that runs into the iteration cap, or a lane whose stack would outgrow its spill area, raises a word
 // in host-visible memory (TraceScratch::status); the blocking entry points turn it into RTC_ERROR_UNKNOWN, mi355_trace_status() reads it for device-pointer callers.
 constexpr uint32_t STATUS_ITER_CAP = 0, STATUS_SPILL = 1;
-constexpr uint32_t REFILL_MIN_DEFAULT = 32;  // rays are handed out in blocks of this many, once that many lanes are free (env MI355_REFILL_MIN)
+constexpr uint32_t REFILL_MIN_DEFAULT = 16;  // rays are handed out in blocks of this many, once that many lanes are free (env MI355_REFILL_MIN); 32 before finished rays went to the done queue
 
 __device__ __forceinline__ float rcp_nr(float a) {  // v_rcp_f32 + one Newton step (reference: RCPPS + Newton, vfloat4_sse2.h:304)
   float r = __builtin_amdgcn_rcpf(a);
@@ -237,6 +237,9 @@ constexpr uint32_t CURSOR_STRIDE = 64;     // words between cursors: each one in
 #ifndef MI355_TRACE_ATTR
 #define MI355_TRACE_ATTR
 #endif
+#ifndef MI355_TRI_PREFETCH
+#define MI355_TRI_PREFETCH 1
+#endif
 constexpr uint32_t NO_INST = 0xFFFFFFFFu;
 // InstanceIntersector1 (kernels/geometry/instance_intersector.cpp:26-31): org' = xfmPoint(world2local, org), dir' = xfmVector(world2local, dir),
 // nested FMAs exactly like common/math/affinespace.h:102 and linearspace3.h:159; tnear / tfar (and so every t) are unchanged.
@@ -277,6 +280,8 @@ __global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceAr
   __shared__ uint2 s_queue[BLOCK / 64][QCAP];
   __shared__ unsigned long long s_best[BLOCK / 64][64];
   __shared__ uint32_t s_pend[BLOCK / 64][64], s_lastT[BLOCK / 64][64];   // per ray slot: helper sub-trees in flight, last ring ticket pushed by helpers
+  __shared__ uint2 s_done[BLOCK / 64][INST ? 96 : 64];                    // finished closest-hit rays {ray index, winning triangle}: their hit records are written 64 at a time (flush_done);
+                                                                          // INST: + 64 words, the instance the winning triangle lies in (no separate array: 8192 B per wave is the budget of 5 waves / SIMD)
 
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = tid & 63u;
@@ -285,6 +290,40 @@ __global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceAr
   unsigned long long* const best = &s_best[tid >> 6][0];
   uint32_t* const pend = &s_pend[tid >> 6][0];
   uint32_t* const lastT = &s_lastT[tid >> 6][0];
+  uint2* const done = &s_done[tid >> 6][0];
+  uint32_t* const doneInst = (uint32_t*)&s_done[tid >> 6][INST ? 64 : 0];   // (only touched by INST kernels)
+  uint32_t dCount = 0;                                                    // wave-uniform: entries in the done queue
+  // Writes the hit records of the queued rays, one ray per lane: t, u, v, Ng are recomputed from the ray (re-read from the ray array: its lane has moved on)
+  // and the winning triangle with the arithmetic of the test in step 4 (Intersect1EpilogM, intersector_epilog.h:235-300).  A finished ray costs its lane two LDS
+  // words at retire time; this block runs with >= 75 % of the lanes instead of the 10-50 % that are retiring in any one iteration.
+  auto flush_done = [&]() {
+    if (lane < dCount) {
+      const uint2 e = done[lane];
+      char* rp = a.rays + (size_t)e.x * a.stride;
+      const float4 r0 = ((const float4*)rp)[0], r1 = ((const float4*)rp)[1];
+      const float4* tp = a.tris + (size_t)e.y * 3u;
+      const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
+      float hx = r0.x, hy = r0.y, hz = r0.z, gx = r1.x, gy = r1.y, gz = r1.z;
+      uint32_t hitInst = MI355_EMPTY_REF, hitInstPrim = MI355_EMPTY_REF;
+      if (INST) {
+        const uint32_t bi = doneInst[lane];
+        if (bi != NO_INST) {
+          const float4* ip = a.insts + (size_t)bi * 4u;
+          const float4 i0 = ip[0], i1 = ip[1], i2 = ip[2], i3 = ip[3];
+          if ((__float_as_uint(i3.w) & 1u) == 0u) { xfm_ray(i0, i1, i2, hx, hy, hz, gx, gy, gz); hitInst = __float_as_uint(i3.y); hitInstPrim = 0u; }   // the hit lies in an instance: its space, its id (instPrimID 0: instance_stack.h:19-50)
+        }
+      }
+      TriOut w;
+      const uint32_t pid = __float_as_uint(q2.y);            // bit 31: second triangle of a quad (tri_records, build.hip)
+      if (ROBUST) tri_pluecker<true>(q0, q1, q2, hx, hy, hz, gx, gy, gz, 0.0f, 0.0f, w, (pid >> 31) != 0u);
+      else tri_moeller<true>(q0, q1, q2, hx, hy, hz, gx, gy, gz, 0.0f, 0.0f, w, (pid >> 31) != 0u);
+      *(float*)(rp + 32) = w.t;
+      *(float4*)(rp + 48) = make_float4(w.Ngx, w.Ngy, w.Ngz, w.u);
+      *(uint4*)(rp + 64) = make_uint4(__float_as_uint(w.v), pid & 0x7FFFFFFFu, __float_as_uint(q2.z), hitInst);
+      *(uint32_t*)(rp + 80) = hitInstPrim;
+    }
+    dCount = 0;
+  };
   uint2* const spill = a.spill + (size_t)(blockIdx.x * BLOCK + tid) * a.spillPerLane;
 
   bool active = false, travDone = false, exhausted = false;
@@ -299,9 +338,21 @@ __global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceAr
   uint32_t inst = NO_INST, topSp = 0, bestInst = NO_INST, entryLo = 0, entryHi = 0;   // INST: instance the lane is in, stack depth at entry, instance of the best hit, best[] key at entry
   uint32_t stNodes = 0, stTris = 0, stRays = 0, stSpill = 0, stDepth = 0, stIter = 0, stNodeBlk = 0, stTriBlk = 0;
   uint32_t stIdle = 0, stWaitBatch = 0, stWaitDrain = 0, stBlocked = 0, stEmpty = 0, stCulled = 0;
+  unsigned long long stRefillClk = 0, stLoopClk = 0, stNodeClk = 0; uint32_t stRefillEv = 0;      // STATS: shader clocks (s_memtime) inside the hand-out block / the whole loop / the node step, hand-out events
+  const unsigned long long stClk0 = STATS ? __builtin_readcyclecounter() : 0ull;
 
   uint32_t iter = 0;
   for (; iter < a.iterCap; iter++) {
+    // ------------------------------------------------------------------ 0. a full batch of queued pairs is waiting: issue the loads of its triangle records now, so that
+    // their round trip overlaps steps 1 - 3a instead of being waited for in step 4 (the node loads of 3a already overlap step 4)
+    const bool pre = MI355_TRI_PREFETCH && (qTail - qHead) >= 64u;          // wave-uniform
+    uint2 pe; float4 pq0, pq1, pq2;
+    asm volatile("" : "=v"(pe.x), "=v"(pe.y)); MI355_UNDEF4(pq0); MI355_UNDEF4(pq1); MI355_UNDEF4(pq2);
+    if (pre) {
+      pe = queue[(qHead + lane) & (QCAP - 1u)];
+      const float4* tp = a.tris + (size_t)pe.x * 3u;
+      pq0 = tp[0]; pq1 = tp[1]; pq2 = tp[2];
+    }
     // ------------------------------------------------------------------ 1. retire finished rays, hand out new ones
     // Ray indices are handed out in blocks of G = refillMin consecutive rays.  Block B belongs to cursor B % numCursors, so
     // neighbouring blocks go to different cursors = different XCDs (a wave pulls from cursor blockIdx % 8 = its XCD): one
@@ -318,20 +369,33 @@ __global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceAr
       const bool anyBusy = __ballot(active && !retirable) != 0ull;
       if ((uint32_t)__popcll(freeMask) >= a.refillMin || !anyBusy) {
         const uint32_t G = a.refillMin;
-        // (a) retiring rays: read the winner, issue the loads of its triangle record
-        uint32_t htri = MI355_EMPTY_REF;
-        float4 q0 = make_float4(0, 0, 0, 0), q1 = q0, q2 = q0, i0 = q0, i1 = q0, i2 = q0, i3 = q0;
-        if (retirable) {
-          htri = (uint32_t)best[lane];
-          if (!ANY && htri != MI355_EMPTY_REF) { const float4* tp = a.tris + (size_t)htri * 3u; q0 = tp[0]; q1 = tp[1]; q2 = tp[2]; }
-          if (INST && !ANY && htri != MI355_EMPTY_REF && bestInst != NO_INST) { const float4* ip = a.insts + (size_t)bestInst * 4u; i0 = ip[0]; i1 = ip[1]; i2 = ip[2]; i3 = ip[3]; }
+        const unsigned long long stT0 = STATS ? __builtin_readcyclecounter() : 0ull;
+        if (STATS && lane == 0u) stRefillEv++;
+        // (a) retiring rays: an occluded ray gets its tfar = -inf right away, a closest hit goes to the done queue {ray, winning triangle}
+        {
+          uint32_t htri = MI355_EMPTY_REF;
+          if (retirable) htri = (uint32_t)best[lane];
+          const bool hasHit = retirable && htri != MI355_EMPTY_REF;
+          if (ANY) { if (hasHit) *(float*)(a.rays + (size_t)rayIdx * a.stride + 32) = -__builtin_inff(); }   // Occluded1EpilogM: tfar = -inf
+          else {
+            const unsigned long long hm = __ballot(hasHit);
+            const uint32_t k = (uint32_t)__popcll(hm);
+            if (dCount + k > 64u) flush_done();                  // room for this batch (wave-uniform)
+            if (hasHit) {
+              const uint32_t pos = dCount + (uint32_t)__popcll(hm & ((1ull << lane) - 1ull));
+              done[pos] = make_uint2(rayIdx, htri);
+              if (INST) doneInst[pos] = bestInst;
+            }
+            dCount += k;
+          }
+          if (retirable) active = false;
         }
-        bool retiredDone = false, more = true;
+        bool more = true;
         while (more) {
-          // (b) claim the reserved block for free lanes: the first round overlaps its ray loads with the triangle loads of (a)
-          const unsigned long long freeLanes = retiredDone ? __ballot(!active) : freeMask;
+          // (b) claim the reserved block for free lanes
+          const unsigned long long freeLanes = __ballot(!active);
           const bool canGrab = !exhausted && (uint32_t)__popcll(freeLanes) >= G;
-          bool got = false; uint32_t newIdx = 0; float4 r0 = q0, r1 = q0, r2 = q0;
+          bool got = false; uint32_t newIdx = 0; float4 r0 = make_float4(0, 0, 0, 0), r1 = r0, r2 = r0;
           if (canGrab) {
             while (!exhausted) {
               if (!resValid) { if (lane == 0u) resV = atomicAdd(a.counter + cursor * CURSOR_STRIDE, 1u); resValid = true; }
@@ -355,33 +419,6 @@ __global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceAr
               break;
             }
           }
-          // (c) write the retiring rays' results (uses the OLD ray registers)
-          if (!retiredDone) {
-            retiredDone = true;
-            if (retirable) {
-              if (htri != MI355_EMPTY_REF) {
-                char* rp = a.rays + (size_t)rayIdx * a.stride;
-                if (ANY) *(float*)(rp + 32) = -__builtin_inff();        // Occluded1EpilogM: tfar = -inf
-                else {
-                  // recompute the winner's t, u, v, Ng (same arithmetic as the test in step 4; Intersect1EpilogM, intersector_epilog.h:235-300)
-                  TriOut w;
-                  const uint32_t pid = __float_as_uint(q2.y);            // bit 31: second triangle of a quad (tri_records, build.hip)
-                  float hx = ox, hy = oy, hz = oz, gx = dx, gy = dy, gz = dz;
-                  uint32_t hitInst = MI355_EMPTY_REF, hitInstPrim = MI355_EMPTY_REF;
-                  if (INST && bestInst != NO_INST && (__float_as_uint(i3.w) & 1u) == 0u) {   // the hit lies in an instance: its space, its id (instPrimID 0: instance_stack.h:19-50)
-                    xfm_ray(i0, i1, i2, hx, hy, hz, gx, gy, gz); hitInst = __float_as_uint(i3.y); hitInstPrim = 0u;
-                  }
-                  if (ROBUST) tri_pluecker<true>(q0, q1, q2, hx, hy, hz, gx, gy, gz, tnear, tfar, w, (pid >> 31) != 0u);
-                  else tri_moeller<true>(q0, q1, q2, hx, hy, hz, gx, gy, gz, tnear, tfar, w, (pid >> 31) != 0u);
-                  *(float*)(rp + 32) = w.t;
-                  *(float4*)(rp + 48) = make_float4(w.Ngx, w.Ngy, w.Ngz, w.u);
-                  *(uint4*)(rp + 64) = make_uint4(__float_as_uint(w.v), pid & 0x7FFFFFFFu, __float_as_uint(q2.z), hitInst);
-                  *(uint32_t*)(rp + 80) = hitInstPrim;
-                }
-              }
-              active = false;
-            }
-          }
           // (d) start the new rays
           if (got) {
             rayIdx = newIdx;
@@ -400,6 +437,7 @@ __global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceAr
           }
           more = canGrab && !exhausted;                                   // more free lanes than one block (launch start, small G)
         }
+        if (STATS) stRefillClk += __builtin_readcyclecounter() - stT0;
       }
       if (__ballot(active) == 0ull) { if (exhausted) break; else continue; }
     }
@@ -545,13 +583,15 @@ __global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceAr
 
     // ------------------------------------------------------------------ 4. test queued pairs (queued in earlier iterations), 64 at a time (fewer only when nothing else can run)
     const bool anyTraversing = __ballot(active && !travDone && !waitDrain) != 0ull;
+    bool usePre = pre;
     for (;;) {
       const uint32_t count = qTail - qHead;
       if (count == 0u) break;
       if (count < 64u && anyTraversing && (!INST || (uint32_t)__popcll(__ballot(waitDrain)) < a.drainWaiters)) break;   // INST: lanes that wait to leave an instance force a partial batch
       const uint32_t n = min(count, 64u);
       const bool mine = lane < n;
-      const uint2 e = queue[(qHead + (mine ? lane : 0u)) & (QCAP - 1u)];
+      uint2 e;
+      if (usePre) e = pe; else e = queue[(qHead + (mine ? lane : 0u)) & (QCAP - 1u)];
       const int owner = (int)e.y;
       // the owner's ray (all 64 lanes execute the permutes; lanes without a pair read pair 0's owner and drop the result)
       const float gox = __shfl(ox, owner, 64), goy = __shfl(oy, owner, 64), goz = __shfl(oz, owner, 64);
@@ -561,8 +601,9 @@ __global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceAr
       if (STATS && lane == 0u) stTriBlk++;
       if (mine) {
         const float gtfar = __uint_as_float((uint32_t)(best[owner] >> 32));
-        const float4* tp = a.tris + (size_t)e.x * 3u;
-        const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
+        float4 q0, q1, q2;
+        if (usePre) { q0 = pq0; q1 = pq1; q2 = pq2; }
+        else { const float4* tp = a.tris + (size_t)e.x * 3u; q0 = tp[0]; q1 = tp[1]; q2 = tp[2]; }
         if (STATS) stTris++;
         const uint32_t tmask = __float_as_uint(q2.w);
         TriOut w;
@@ -571,10 +612,11 @@ __global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceAr
         ok = ok && ((tmask & grmask) != 0u);                           // EMBREE_RAY_MASK, intersector_epilog.h:256-262
         if (ok) atomicMin(&best[owner], ((unsigned long long)__float_as_uint(w.t + 0.0f) << 32) | e.x);   // + 0: a hit at -0 must not sort as a huge key
       }
-      qHead += n;
+      qHead += n; usePre = false;
     }
 
     // ------------------------------------------------------------------ 3b. node step, second half: 8 slab tests
+    const unsigned long long stN0 = STATS ? __builtin_readcyclecounter() : 0ull;
     if (doNode) {
       if (STATS) stNodes++;
       const float adx = __uint_as_float((n0.w & 0xFFu) << 23) * rdx;
@@ -606,6 +648,7 @@ __global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceAr
       if (STATS && hits == 0u) stEmpty++;
     }
     if (STATS) {
+      stNodeClk += __builtin_readcyclecounter() - stN0;
       const bool anyNode = __ballot(doNode) != 0ull;
       if (lane == 0u && anyNode) stNodeBlk++;
       // lane-iteration census: where do the lanes that are NOT opening a node spend this iteration?
@@ -630,6 +673,7 @@ __global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceAr
     }
   }
 
+  if (!ANY && dCount != 0u) flush_done();                        // the last finished rays
   if (iter >= a.iterCap) a.status[STATUS_ITER_CAP] = 1u;        // left the loop through the cap, not through "no rays left": results are incomplete
   if (STATS) {
     atomicAdd(&a.stats[0], (unsigned long long)stNodes);
@@ -646,6 +690,10 @@ __global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceAr
     atomicAdd(&a.stats[11], (unsigned long long)stBlocked);
     atomicAdd(&a.stats[12], (unsigned long long)stEmpty);
     atomicAdd(&a.stats[13], (unsigned long long)stCulled);
+    if (lane == 0u) {
+      atomicAdd(&a.stats[14], stRefillClk); atomicAdd(&a.stats[15], (unsigned long long)stRefillEv);
+      atomicAdd(&a.stats[16], __builtin_readcyclecounter() - stClk0); atomicAdd(&a.stats[17], stNodeClk);
+    }
   }
 }
 
@@ -740,11 +788,11 @@ static int launch_trace(Bvh* b, void* d_rays, uint32_t count, size_t stride, boo
   a.status = sc->statusDev;
   { const char* e = getenv("MI355_TRACE_HELPERS"); a.helpers = e && atoi(e) == 0 ? 0u : 1u; }   // tail helpers (step 1b) on unless MI355_TRACE_HELPERS=0
   if (statsOut) {
-    HIP_TRY(hipMemsetAsync(sc->stats, 0, 16 * sizeof(uint64_t), s));
+    HIP_TRY(hipMemsetAsync(sc->stats, 0, 32 * sizeof(uint64_t), s));
     a.stats = (unsigned long long*)sc->stats;
     hipLaunchKernelGGL(fn, dim3(blocks), dim3(BLOCK), 0, s, a);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(statsOut, sc->stats, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(statsOut, sc->stats, 32 * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     return 0;
   }
@@ -806,8 +854,8 @@ int mi355_trace_any(mi355_bvh_t bvh, void* d, uint32_t n, size_t stride, void* s
 int mi355_trace_timed(mi355_bvh_t bvh, void* d, uint32_t n, size_t stride, int any_hit, void* stream, void* ev_start, void* ev_stop) {
   return mi355::launch_trace((mi355::Bvh*)bvh, d, n, stride, any_hit != 0, (hipStream_t)stream, nullptr, (hipEvent_t)ev_start, (hipEvent_t)ev_stop);
 }
-int mi355_trace_stats(mi355_bvh_t bvh, void* d, uint32_t n, size_t stride, int any_hit, uint64_t out[16]) {
-  for (int i = 0; i < 16; i++) out[i] = 0;
+int mi355_trace_stats(mi355_bvh_t bvh, void* d, uint32_t n, size_t stride, int any_hit, uint64_t out[32]) {
+  for (int i = 0; i < 32; i++) out[i] = 0;
   return mi355::launch_trace((mi355::Bvh*)bvh, d, n, stride, any_hit != 0, nullptr, out);
 }
 int mi355_trace_closest_packet(mi355_bvh_t bvh, const int* v, void* d, uint32_t K, uint32_t n, size_t ps, void* stream) {

@@ -341,4 +341,5 @@ def shadow_rays(bounce_traced, meshes, samples=16, seed=3, first=0):
     dist = np.sqrt((v * v).sum(-1)).astype(np.float32)
     dirn = (v / np.maximum(dist, np.float32(1e-20))[:, None]).astype(np.float32)
     rh = make_rayhits(Pr, dirn, tnear=np.float32(1e-4) * s * np.float32(1e-3), tfar=dist * np.float32(1 - 1e-4))
+    rh["id"] = np.arange(first, first + n, dtype=np.uint32)          # RTCRay.id = the ray's index in the whole job, not in the shard
     return rays_of(rh)

@@ -144,9 +144,11 @@ MI355_API int mi355_trace_any_packet(mi355_bvh_t bvh, const int* d_valid, void* 
    out[5]=wave loop iterations, out[6]=node-step blocks executed (per wave), out[7]=triangle-step blocks executed
    (per wave); out[0] / (64 * out[6]) is the SIMD utilisation of the node step; out[8..11] = lane-iterations spent
    without a ray / waiting for the retire batch / waiting for the triangle queue to drain / blocked on unqueued
-   triangle bits.  any_hit != 0 selects the occlusion kernel.  The rays ARE traced (results written). */
+   triangle bits; out[12] = node visits that found no child, out[14] = shader clocks (summed over the waves) spent in the ray hand-out block,
+   out[15] = hand-out events, out[16] = shader clocks of the whole loop, out[17] = of the node step.  any_hit != 0 selects the occlusion kernel.
+   The rays ARE traced (results written). */
 MI355_API int mi355_trace_stats(mi355_bvh_t bvh, void* d_rays, uint32_t count, size_t byte_stride, int any_hit,
-                                uint64_t out[16]);
+                                uint64_t out[32]);
 
 /* ---- multi-GPU: sharded ray batches, results gathered over RCCL / xGMI (the reference has no multi-process code, so there is no
    reference function these replace: they implement BASELINE.json's north_star, "ray batches shard embarrassingly across the 8 GPUs of one node with the

@@ -218,14 +218,21 @@ def test_fast_mode_far_from_the_origin(api, dev, ref, offset):
     want, got = rays.copy(), rays.copy()
     R.intersect1(want, ref.hw_threads())
     s.intersect1M(got)
-    lost = (want["geomID"] != INVALID_ID) & (got["geomID"] == INVALID_ID)
-    assert not lost.any(), "%d hits of the reference are misses on the GPU" % int(lost.sum())
-    st = compare_closest(got, want, rays, tri_t_of(meshes), label="crown at %g" % offset)
+    RR = ref_scene(ref, meshes, flags=4)                             # the robust reference as arbiter: at 1e5 one ulp of a coordinate is 0.008, the
+    robust = rays.copy()                                             # reference's own fast mode starts to lose hits there (its node test has no margin)
+    RR.intersect1(robust, ref.hw_threads())
+    RR.close()
+    lost = (robust["geomID"] != INVALID_ID) & (got["geomID"] == INVALID_ID) & (want["geomID"] != INVALID_ID)
+    assert not lost.any(), "%d hits of both references are misses on the GPU" % int(lost.sum())
+    st = compare_closest_arbitrated(got, want, robust, rays, tri_t_of(meshes), max_ref_miss_frac=0.01, label="crown at %g" % offset)
+    print("crown at %g:" % offset, st)
     assert st["hits"] > 0.9 * st["rays"]
     wr, gr = rays_of(rays), rays_of(rays)
     R.occluded1(wr, ref.hw_threads())
     s.occluded1M(gr)
-    compare_occluded(gr["tfar"], wr["tfar"], rays_of(rays)["tfar"], label="crown at %g, occlusion" % offset)
+    g, w = np.isneginf(gr["tfar"]), np.isneginf(wr["tfar"])      # occlusion: the GPU may only see MORE than the fast reference (hits the reference lost)
+    assert not (w & ~g).any() and (g & ~w).sum() <= 0.01 * g.size
+    assert (gr["tfar"][~g] == rays_of(rays)["tfar"][~g]).all()
     s.release(); R.close()
 
 
@@ -292,3 +299,28 @@ def test_iteration_cap_is_reported_not_silent(api, dev):
     s.intersect1M(again)
     assert again.tobytes() == ok.tobytes()
     s.release()
+
+
+# ------------------------------------------------------------------------------------------------- sharded rays, gathered results
+def _run_ranks(world, transport):
+    import subprocess, sys
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + os.getpid() % 300), WORLD_SIZE=str(world))
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "gpu_dist2.py"), transport], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE) for r in range(world)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1].decode()[-1500:] for o in outs]
+    line = [l for l in outs[0][0].decode().splitlines() if l.startswith("DIST OK")]
+    assert line, outs[0][0].decode()[-500:]
+    return line[0]
+
+
+def test_rccl_gather_one_rank(api):
+    """mi355_comm_* (RCCL through the C ABI, librccl loaded on first use): a one-rank communicator on this GPU, ncclAllGather of the packed results."""
+    print(_run_ranks(1, "rccl"))
+
+
+def test_two_ranks_shard_and_gather(api):
+    """configs[3] in miniature with TWO ranks (sharing this box's GPU): contiguous shards, per-rank rtcOccluded1MDevice, packed results gathered in rank
+    order == the single-rank answer, bit for bit.  RCCL refuses two ranks on one device, so the gather goes through the host (gloo) here; with one
+    GPU per rank the same worker uses RCCL (tests/gpu_dist2.py)."""
+    print(_run_ranks(2, "gloo"))

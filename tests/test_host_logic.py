@@ -97,6 +97,11 @@ rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", rank=rank, world_size=world)
 lo, hi = shard.shard_range(16777216, rank, world)             # config 4: 16M shadow rays sharded over the ranks
 counts = shard.gather_counts(hi - lo, dist)
+import numpy as np
+mine = (np.arange(lo, lo + 1000, dtype=np.uint32) * 2654435761 %% 4294967291).astype(np.uint32)   # stand-in for a rank's packed results
+allr = shard.gather_host(mine, dist)                           # what the RCCL all-gather does on the GPUs: rank order, every rank gets everything
+want = np.concatenate([(np.arange(shard.shard_range(16777216, r, world)[0], shard.shard_range(16777216, r, world)[0] + 1000, dtype=np.uint32) * 2654435761 %% 4294967291).astype(np.uint32) for r in range(world)])
+assert allr.dtype == np.uint32 and (allr == want).all()
 elapsed = shard.max_over_ranks(0.5 + rank, dist)               # slowest rank defines the step time
 dist.barrier()
 if rank == 0:
@@ -116,3 +121,23 @@ def test_world_size_2_gloo(tmp_path):
     assert all(p.returncode == 0 for p in procs), [o[1].decode()[-800:] for o in outs]
     line = [l for l in outs[0][0].decode().splitlines() if l.startswith("RESULT")][0].split()
     assert int(line[1]) == 16777216 and float(line[2]) == 1.5 and abs(float(line[3]) - 16777216 / 1.5) < 1e-3
+
+
+def test_shadow_ray_shards_are_slices_of_the_single_rank_set():
+    """configs[3]: a rank generates only its contiguous shard of the 16 x hit-points shadow rays; the shards of N ranks must be exactly the rays one
+    rank would generate (same RandomSampler indices), or the gathered result would not be the single-rank answer."""
+    meshes = W.synthetic_crown(num_phi=8)
+    rng = np.random.default_rng(3)
+    n = 96
+    b = make_rayhits(rng.random((n, 3), dtype=np.float32) * 3 + 1, rng.random((n, 3), dtype=np.float32) - 0.5)
+    b["tfar"] = rng.random(n, dtype=np.float32) * 2
+    b["geomID"] = np.where(rng.random(n) < 0.8, 0, INVALID_ID).astype(np.uint32)
+    full = W.shadow_rays(b, meshes, samples=16)
+    assert full.shape[0] == 16 * n
+    for world in (2, 3, 8):
+        parts = []
+        for r in range(world):
+            lo, hi = shard.shard_range(16 * n, r, world)
+            assert lo % 16 == 0 and hi % 16 == 0
+            parts.append(W.shadow_rays(b[lo // 16: hi // 16], meshes, samples=16, first=lo))
+        assert np.concatenate(parts).tobytes() == full.tobytes()
