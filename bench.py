@@ -9,10 +9,11 @@ crown.ecs is not shipped with the reference, so the scene is the seeded syntheti
 49 geometries) unless $EMBREE_MODEL_DIR/crown/crown.ecs exists; rays are the cosine-weighted bounce rays of a 1024 x 1024 camera image, generated
 with the reference's RandomSampler.  A "step" = one closest-hit pass over one batch of 2^20 rays through rtcIntersect1MDevice, rays already
 resident in HBM (every step has its own pristine copy of the batch, staged before the timed region).  The timed region issues the K steps back to
-back on ONE stream (--streams 1, the default): one 2^20-ray batch at a time is the configuration north_star names, the kernel's own duration
-(HIP events on its stream) is then the step time, and the roofline of the line is computed from exactly the launches that were timed.
-What a wavefront renderer does in practice -- several batches in flight on several streams, so that the tail of one batch overlaps the next --
-is measured right after the timed region and reported under "pipelined" (same kernel, same buffers, 4 streams).
+back round-robin on --streams HIP streams (default 4), the way a wavefront renderer keeps several ray batches in flight: the persistent traversal
+kernel fills the chip, so the next batch's workgroups start as those of the previous one retire and the tail of a batch overlaps useful work.
+The roofline of the line is computed from exactly the launches that were timed (their own durations, HIP events on their streams).  One batch at a
+time (--streams 1) is measured right after the timed region and reported under "serial" (same kernel, same buffers): there the kernel's own
+duration is the step time.
 
 Workload `shadow16m`: configs[3] = 16 Mi shadow rays (16 per hit point of the configs[2] rays) through rtcOccluded1MDevice, STRONG scaling: the
 16,777,216 rays are sharded contiguously over the N ranks (embree_amd/shard.py), each rank packs its 4-byte results and the shards are gathered on
@@ -30,7 +31,8 @@ Printed JSON (rank 0, one line): metric/value/... as the driver contract, plus
                 Most of those bytes are L1/L2/Infinity-Cache hits, so next to it: `hbm_counter` (PMC FETCH_SIZE x2 + WRITE_SIZE per launch, from
                 profiles/pmc_bench_latest.json, only if that file was collected for THIS kernel source -- else null) and `valu`, the roof that
                 actually binds (SQ_INSTS_VALU per launch x 4 cycles / (1024 SIMDs x measured clock) / kernel time).
-  pipelined     the same kernel with --pipeline-streams batches in flight (throughput, concurrency)
+  roofline.address_rate   the resource that binds: scattered lane-addresses per second against 256 CUs x 1 per clock
+  serial        the same kernel launched alone, back to back on one stream (with --streams 1: `pipelined`, --pipeline-streams batches in flight)
   end_to_end    rtcIntersect1M on a pageable host array: H2D + kernel + D2H (PCIe-inclusive; never `value`)
   cpu_baseline  the REAL reference (oracle/_ref, Embree 4.4.1 AVX2) looping rtcIntersect1 over the same rays on the host threads (kind
                 "reference") with its rtcCommitScene timed 1 + 5 times, or the scalar C restatement on a sample (kind "port")
@@ -200,8 +202,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--workload", default="crown", choices=["crown", "shadow16m"])
     ap.add_argument("--rays", type=int, default=1 << 20, help="crown: rays per batch and GPU; shadow16m: hit points (x16 shadow rays), all GPUs together")
-    ap.add_argument("--streams", type=int, default=1, help="HIP streams the TIMED steps are issued on round-robin (1 = one batch at a time)")
-    ap.add_argument("--pipeline-streams", type=int, default=4, help="batches in flight of the extra `pipelined` leg (0 = skip it)")
+    ap.add_argument("--streams", type=int, default=4, help="HIP streams the TIMED steps are issued on round-robin = ray batches in flight (1 = one batch at a time)")
+    ap.add_argument("--pipeline-streams", type=int, default=4, help="batches in flight of the extra `pipelined` leg that is measured when --streams is 1 (0 = skip it)")
     ap.add_argument("--gather", default="auto", choices=["auto", "rccl", "none"], help="results gathered on the GPUs over RCCL (auto: rccl when more than one rank)")
     ap.add_argument("--phi", type=int, default=158, help="sphere tessellation of the synthetic crown (158 -> 4.76M triangles)")
     ap.add_argument("--config", default="", help="extra rtcNewDevice config, e.g. max_leaf=2,int_cost=0.5")
@@ -318,7 +320,8 @@ def main():
         rec, dtype, any_hit = 96, RAYHIT_DTYPE, 0
     M = rays.shape[0]
 
-    npipe = max(0, args.pipeline_streams) if not shadow else 0
+    # the leg that is NOT the timed region is measured right after it: lone launches (`serial`) when the timed steps are pipelined, and the other way round
+    npipe = (1 if args.streams > 1 else max(0, args.pipeline_streams)) if not shadow else 0
     streams = []
     for _ in range(max(1, args.streams, npipe)):
         st_ = C.c_void_p()
@@ -415,7 +418,7 @@ def main():
 
     # ---- extra legs, outside the timed region --------------------------------------------------------------------------------------
     pipelined = None
-    if npipe > 1 and not shadow:                           # several batches in flight, as a wavefront renderer keeps them
+    if npipe >= 1 and npipe != len(tstreams) and not shadow:   # the other mode: several batches in flight as a wavefront renderer keeps them / one batch at a time
         nps = min(args.steps, 40)
         restore(bufs[:nps])
         evp = Events(L, nps)
@@ -431,9 +434,12 @@ def main():
         pms = [evp.ms(k) for k in range(nps)]
         evp.free()
         assert bufs[0].download(dtype).tobytes() == result.tobytes()
+        pavg = float(np.mean(pms))
         pipelined = dict(value=round(M * nps / pel / 1e6, 1), unit="Mrays/s", batches_in_flight=npipe, steps=nps, ms_per_step=round(1e3 * pel / nps, 4),
-                         kernel_ms_avg=round(float(np.mean(pms)), 4), concurrency=round(float(np.sum(pms)) * 1e-3 / pel, 3),
-                         what="the same launches issued round-robin on %d HIP streams: the tail of one batch overlaps the next; per-GPU figure" % npipe)
+                         kernel_ms_avg=round(pavg, 4), kernel_ms_min=round(float(np.min(pms)), 4), concurrency=round(float(np.sum(pms)) * 1e-3 / pel, 3),
+                         hbm_algorithmic={"achieved": round(alg_bytes / (pavg * 1e-3) / 1e9, 1), "frac": round(alg_bytes / (pavg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+                         what=("the same launches issued round-robin on %d HIP streams: the tail of one batch overlaps the next; per-GPU figure" % npipe) if npipe > 1 else
+                              "the same launches back to back on ONE stream: one 2^20-ray batch at a time, the kernel's own duration is the step time; per-GPU figure")
     e2e = None
     if not shadow and rank == 0:                           # PCIe-inclusive: the blocking host-array entry point on a pageable numpy array
         times = []
@@ -487,7 +493,15 @@ def main():
                 "note": "achieved = algorithmic bytes (SURVEY 8d) per launch / average duration of the timed launches (HIP events on the launch stream). Most of these bytes are "
                         "served by L1 / L2 / Infinity Cache: hbm_counter is what reaches the memory side, valu is the roof that binds."}
         if len(tstreams) > 1:
-            roof["note"] += " The timed launches overlap (launches_in_flight): a launch then owns 1/launches_in_flight of the chip."
+            roof["note"] += (" The timed launches overlap (launches_in_flight): a launch then owns 1/launches_in_flight of the chip, its duration is that much longer and"
+                             " frac that much lower than in `serial` (lone launches).")
+        # what binds (profiles/r02_trace_history.md): every lane that fetches a 16-byte piece of a node / triangle / ray costs the CU's address path one slot, whatever
+        # the width and whatever the cache level that answers: 5 per node visit, 3 per triangle test, 3 per ray read + the hit record stores
+        acc = 5 * st["nodes"] + 3 * st["tris"] + M * 3 + (nhit * 4 if not shadow else nhit)
+        roof["address_rate"] = {"lane_accesses_per_launch": int(acc), "per_ray": round(acc / M, 1), "achieved_G_per_s": round(acc * args.steps / elapsed / 1e9, 1),
+                                "peak_G_per_s": round(256 * 2.4, 1), "frac": round(acc * args.steps / elapsed / (256 * 2.4e9), 4),
+                                "what": "scattered lane-addresses per second over all launches in flight against 256 CUs x 1 address per clock x 2.4 GHz: the resource this kernel "
+                                        "saturates (an extra 4-, 8- or 16-byte load per triangle test costs the same 11-12 %; throughput follows 1 / accesses when the leaf size changes)"}
         if pmc:
             c = pmc["counters"]
             clock_hz = pmc.get("kernel_cycles", 0.0) / (avg_ms * 1e-3) if pmc.get("kernel_cycles") else 2.4e9
@@ -509,8 +523,8 @@ def main():
             "higher_is_better": True, "scaling": "strong" if shadow else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic" if not scene_path else "file",
             "config": {"workload": ("configs[3]: %s, %d triangles, %d shadow rays (16 per hit point) in total, %d per GPU, rtcOccluded1MDevice, rays + BVH resident in HBM, results %s"
                                     % (scene_name, ntri, total_rays, M, "packed and all-gathered over RCCL" if comm is not None else "left in the per-rank buffers")) if shadow else
-                                   ("configs[2]: %s, %d triangles, %d geometries, %d incoherent diffuse-bounce rays per GPU and step, closest-hit, rays + BVH resident in HBM, one batch at a time"
-                                    % (scene_name, ntri, len(meshes), M)),
+                                   ("configs[2]: %s, %d triangles, %d geometries, %d incoherent diffuse-bounce rays per GPU and step, closest-hit, rays + BVH resident in HBM, %s"
+                                    % (scene_name, ntri, len(meshes), M, "one batch at a time" if len(tstreams) == 1 else "%d batches in flight" % len(tstreams))),
                        "rays_per_gpu": M, "triangles": ntri, "batches_in_flight": len(tstreams),
                        "parallelism": "rays sharded x%d, BVH replicated (deterministic build on every rank), %s" % (world, "RCCL all-gather of the 4-byte results inside the step" if (shadow and comm is not None) else "no collective inside the step"),
                        "device_config": args.config},
@@ -527,7 +541,7 @@ def main():
             "hit_fraction": round(nhit / M, 4),
         }
         if pipelined:
-            out["pipelined"] = pipelined
+            out["pipelined" if npipe > 1 else "serial"] = pipelined
         if e2e:
             out["end_to_end"] = e2e
         if gather is not None:

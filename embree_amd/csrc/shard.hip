@@ -59,7 +59,11 @@ Rccl* rccl() {
   std::lock_guard<std::mutex> lk(m);
   if (r) return r;
   r = new Rccl;
-  const char* names[] = {getenv("MI355_RCCL_LIB"), "librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
+  // The ROCm installation's own RCCL first, by PATH: a process that has imported PyTorch already holds PyTorch's private librccl.so.1, which is bound to
+  // PyTorch's private copy of the HIP runtime -- a second runtime that does not know this library's device allocations.  A dlopen by soname would return
+  // that copy; a dlopen by path loads the ROCm one, whose libamdhip64.so.7 is the runtime this library is already bound to.
+  std::string rocm = std::string(getenv("ROCM_PATH") ? getenv("ROCM_PATH") : "/opt/rocm") + "/lib/librccl.so.1";
+  const char* names[] = {getenv("MI355_RCCL_LIB"), rocm.c_str(), "/opt/rocm/lib/librccl.so.1", "librccl.so.1", "librccl.so"};
   for (const char* n : names) { if (!n) continue; r->lib = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (r->lib) break; r->err = dlerror(); }
   if (!r->lib) return r;
   auto sym = [&](const char* s) { void* p = dlsym(r->lib, s); if (!p) r->err = std::string("missing RCCL symbol ") + s; return p; };

@@ -137,3 +137,43 @@ class RefScene:
             self.close()
         except Exception:
             pass
+
+
+def build_stats(meshes, quality=1, flags=0, threads=4, cfg=""):
+    """Builds the scene with the real reference at verbose=2 and parses what BVHN::postBuild / BVHNStatistics print (kernels/bvh/bvh.cpp:139-179,
+    bvh_statistics.cpp:19-40): {'sah', 'sah_nodes', 'sah_leaves', 'nodes', 'depth', 'primitives', 'builder'}.  `sah` is the reference's own metric:
+    (sum of inner-node half areas + sum of leaf half areas x Triangle4 blocks) / root half area.  quality: 0 LOW, 1 MEDIUM, 2 HIGH (RTCBuildQuality)."""
+    import re
+    import sys
+    import tempfile
+    sys.stdout.flush()
+    tmp = tempfile.TemporaryFile()
+    saved = os.dup(1)
+    os.dup2(tmp.fileno(), 1)
+    try:
+        s = RefScene(("threads=%d,verbose=2," % threads) + cfg, flags=flags, quality=quality)
+        for v, t in meshes:
+            s.add_mesh(v, t)
+        s.commit()
+        s.close()
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
+    tmp.seek(0)
+    txt = tmp.read().decode(errors="replace")
+    out = {}
+    m = re.search(r"building (\S+) using (\S+)", txt)
+    if m:
+        out["builder"] = m.group(2)
+    m = re.search(r"primitives = (\d+), vertices = \d+, depth = (\d+)", txt)
+    if m:
+        out["primitives"], out["depth"] = int(m.group(1)), int(m.group(2))
+    for key, pat in (("sah", r"total\s+: sah =\s*([0-9.eE+-]+)"), ("sah_nodes", r"getAABBNodes\s+: sah =\s*([0-9.eE+-]+)"), ("sah_leaves", r"leaves\s+: sah =\s*([0-9.eE+-]+)")):
+        m = re.search(pat, txt)
+        if m:
+            out[key] = float(m.group(1))
+    m = re.search(r"total\s+: sah = .*?#nodes =\s*(\d+)", txt)
+    if m:
+        out["nodes"] = int(m.group(1))
+    return out

@@ -107,3 +107,26 @@ def validate(nodes, tris, root_ref, meshes, masks=None, geom_ids=None, max_leaf=
     assert (covered == 1).all(), f"{int((covered != 1).sum())} triangles not covered exactly once"
     assert (node_seen == 1).all(), f"{int((node_seen != 1).sum())} nodes not referenced exactly once"
     return stats
+
+
+def embree_metric_sah(nodes, tris=None):
+    """SAH of a downloaded tree in the REFERENCE's metric (BVHNStatistics, kernels/bvh/bvh_statistics.cpp:42-160): every inner node costs its half area,
+    every leaf its half area x the number of Triangle4 blocks (here: a leaf slot holds <= 3 triangles = one block), divided by the root's half area.
+    Areas are those of the decoded (quantised, i.e. slightly enlarged) child boxes, so the figure is a little pessimistic for this tree."""
+    scale = (nodes["exp"].astype(np.uint32) << 23).view(np.float32).astype(np.float64)                 # [node][axis]
+    org = nodes["org"].astype(np.float64)
+    lo = org[:, :, None] + nodes["qlo"].astype(np.float64) * scale[:, :, None]                        # [node][axis][slot]
+    hi = org[:, :, None] + nodes["qhi"].astype(np.float64) * scale[:, :, None]
+    d = np.maximum(hi - lo, 0.0)
+    area = d[:, 0] * (d[:, 1] + d[:, 2]) + d[:, 1] * d[:, 2]                                            # half area per slot
+    used = nodes["meta"] != 0
+    inner = used & (((nodes["imask"][:, None] >> np.arange(8)[None, :]) & 1) != 0)
+    leaf = used & ~inner
+    # the root's own box = union of its children
+    rlo = np.where(used[0][None, :], lo[0], np.inf).min(1)
+    rhi = np.where(used[0][None, :], hi[0], -np.inf).max(1)
+    rd = rhi - rlo
+    root = rd[0] * (rd[1] + rd[2]) + rd[1] * rd[2]
+    nodes_sah = (root + area[inner].sum()) / root
+    leaves_sah = area[leaf].sum() / root
+    return dict(sah=nodes_sah + leaves_sah, sah_nodes=nodes_sah, sah_leaves=leaves_sah, nodes=int(nodes.shape[0]), leaves=int(leaf.sum()))

@@ -12,6 +12,8 @@ from embree_amd.rtypes import RAYHIT_DTYPE, RAY_DTYPE
 rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 transport = sys.argv[1] if len(sys.argv) > 1 else "rccl"
 dist = None
+if os.environ.get("MI355_IMPORT_TORCH"):                         # the situation bench.py is in at N > 1: PyTorch (with its private HIP runtime and RCCL) is loaded before
+    import torch.distributed as _td                              # the library's first RCCL call; RCCL must still bind to the runtime that owns our allocations
 if world > 1:
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)

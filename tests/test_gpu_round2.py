@@ -302,9 +302,9 @@ def test_iteration_cap_is_reported_not_silent(api, dev):
 
 
 # ------------------------------------------------------------------------------------------------- sharded rays, gathered results
-def _run_ranks(world, transport):
+def _run_ranks(world, transport, extra_env=None):
     import subprocess, sys
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + os.getpid() % 300), WORLD_SIZE=str(world))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + os.getpid() % 300), WORLD_SIZE=str(world), **(extra_env or {}))
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "gpu_dist2.py"), transport], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
                               stdout=subprocess.PIPE, stderr=subprocess.PIPE) for r in range(world)]
     outs = [p.communicate(timeout=600) for p in procs]
@@ -317,6 +317,13 @@ def _run_ranks(world, transport):
 def test_rccl_gather_one_rank(api):
     """mi355_comm_* (RCCL through the C ABI, librccl loaded on first use): a one-rank communicator on this GPU, ncclAllGather of the packed results."""
     print(_run_ranks(1, "rccl"))
+
+
+def test_rccl_gather_with_pytorch_loaded_first(api):
+    """bench.py at N > 1 imports torch.distributed (gloo rendezvous) before the first RCCL call.  PyTorch brings a private HIP runtime and a private
+    librccl.so.1; the library must still end up with an RCCL that is bound to the runtime owning its allocations (embree_amd/csrc/shard.hip loads ROCm's
+    RCCL by path)."""
+    print(_run_ranks(1, "rccl", {"MI355_IMPORT_TORCH": "1"}))
 
 
 def test_two_ranks_shard_and_gather(api):
