@@ -54,13 +54,22 @@ struct Device : RefCounted {
   std::string name;
   static size_t threadToken() { static thread_local char t; return (size_t)&t; }
   ErrState& err() { std::lock_guard<std::mutex> lk(errMutex); return errors[threadToken()]; }
-  ~Device() override { mi355_release_build_scratch(gpu); }
+  // the build arena of a GPU is shared by all devices on it (a commit takes it for its duration) and goes back to the driver with the LAST of them
+  static std::mutex& countMutex() { static std::mutex m; return m; }
+  static std::map<int, int>& liveOnGpu() { static std::map<int, int> c; return c; }
+  bool counted = false;
+  void countIn() { std::lock_guard<std::mutex> lk(countMutex()); liveOnGpu()[gpu]++; counted = true; }
+  ~Device() override {
+    if (!counted) return;
+    bool last; { std::lock_guard<std::mutex> lk(countMutex()); last = --liveOnGpu()[gpu] == 0; }
+    if (last) mi355_release_build_scratch(gpu);
+  }
   // Device::memoryMonitor (kernels/common/device.cpp:332-345): every allocation the library keeps on the caller's behalf (buffers it owns, their
   // device copies, the committed BVH) is announced with +bytes before and -bytes after; a callback answering false fails the request with
   // RTC_ERROR_OUT_OF_MEMORY.  Build scratch is transient and not announced.
   void memoryMonitor(ssize_t bytes, bool post) {
     if (memFn && bytes != 0 && !memFn(memFnPtr, bytes, post) && bytes > 0) THROW(RTC_ERROR_OUT_OF_MEMORY, "memory monitor forced termination");
-  }   // the build arena of this GPU goes back to the driver with the last user
+  }
 };
 
 void process_error(Device* dev, RTCError code, const char* str) {     // Device::process_error, device.cpp:312-330
@@ -406,6 +415,15 @@ static bool pipelined_query(Scene* s, mi355_bvh_t b, char* data, char* d, unsign
   return true;
 }
 
+// bytes a buffer view really touches: offset + stride * (n - 1) + element size (TriangleMesh::setBuffer, scene_triangle_mesh.cpp:35-80; the reference reads
+// exactly that plus its documented 16-byte vertex padding) -- NOT n * stride: with an interleaved layout the last element ends before the last stride does
+static size_t format_bytes(RTCFormat fmt) {
+  if (fmt >= RTC_FORMAT_FLOAT && fmt <= RTC_FORMAT_FLOAT16) return 4u * (size_t)(fmt - RTC_FORMAT_FLOAT + 1);
+  if (fmt >= RTC_FORMAT_UINT && fmt <= RTC_FORMAT_UINT4) return 4u * (size_t)(fmt - RTC_FORMAT_UINT + 1);
+  return 16;
+}
+static size_t view_bytes(RTCFormat fmt, size_t stride, size_t n) { return n ? (n - 1) * stride + format_bytes(fmt) : 0; }
+
 // host-pointer AoS query: upload, trace, download the mutable parts
 void host_query(Scene* s, void* data, unsigned M, size_t stride, bool any) {
   if (M == 0) return;
@@ -461,6 +479,7 @@ RTC_API RTCDevice rtcNewDevice(const char* config) {
   if (n <= 0) THROW(RTC_ERROR_UNSUPPORTED_CPU, "no HIP device found: this library has no CPU fallback");
   if (d->gpu < 0 || d->gpu >= n) THROW(RTC_ERROR_INVALID_ARGUMENT, "gpu ordinal out of range");
   char nm[256]; if (mi355_device_name(d->gpu, nm, sizeof(nm)) == 0) d->name = nm;
+  d->countIn();
   if (d->verbose >= 1) printf("Embree(MI355X) %s on %s\n", RTC_VERSION_STRING, d->name.c_str());
   return (RTCDevice)d;
   CATCH_END(nullptr)
@@ -580,7 +599,7 @@ RTC_API void rtcSetSharedGeometryBuffer(RTCGeometry h, enum RTCBufferType type, 
                                         size_t byteOffset, size_t byteStride, size_t itemCount) {
   CATCH_BEGIN
   Geometry* g = geom_of(h);
-  Buffer* b = new Buffer(g->device, itemCount * byteStride, (char*)ptr + byteOffset);
+  Buffer* b = new Buffer(g->device, view_bytes(fmt, byteStride, itemCount), (char*)ptr + byteOffset);
   try { g->setBuffer(type, slot, fmt, b, 0, byteStride, itemCount); } catch (...) { b->release(); throw; }
   b->release();
   CATCH_END(GEOM_DEV(h))
@@ -592,7 +611,7 @@ RTC_API void rtcSetSharedGeometryBufferHostDevice(RTCGeometry h, enum RTCBufferT
   CATCH_BEGIN
   Geometry* g = geom_of(h);
   if (!dptr) THROW(RTC_ERROR_INVALID_ARGUMENT, "device pointer may not be NULL");
-  Buffer* b = new Buffer(g->device, itemCount * byteStride, ptr ? (char*)ptr + byteOffset : (char*)16, (char*)dptr + byteOffset);
+  Buffer* b = new Buffer(g->device, view_bytes(fmt, byteStride, itemCount), ptr ? (char*)ptr + byteOffset : (char*)16, (char*)dptr + byteOffset);
   try { g->setBuffer(type, slot, fmt, b, 0, byteStride, itemCount); } catch (...) { b->release(); throw; }
   b->release();
   CATCH_END(GEOM_DEV(h))

@@ -20,9 +20,19 @@ from kernel_hash import trace_kernel_hash   # noqa: E402
 src, pattern, out = sys.argv[1], sys.argv[2], sys.argv[3]
 agg = collections.defaultdict(list)
 meta = {}
+# Only the full-size launches count (the persistent grid = every resident workgroup slot); smaller grids are the chunks of the host-array leg.  The
+# first full-size launch of a bench.py run traces the coherent primary rays that the bounce rays are made from: not the workload either.
 for p in sorted(glob.glob(os.path.join(src, "p*", "*counter_collection.csv"))):
-    for r in csv.DictReader(open(p)):
-        if pattern not in r["Kernel_Name"]:
+    rows = [r for r in csv.DictReader(open(p)) if pattern in r["Kernel_Name"]]
+    if not rows:
+        continue
+    full = max(int(r["Grid_Size"]) for r in rows)
+    seen_first = {}
+    for r in rows:
+        if int(r["Grid_Size"]) != full:
+            continue
+        if not seen_first.get(r["Counter_Name"]):
+            seen_first[r["Counter_Name"]] = True           # skip the primary-ray launch
             continue
         agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
         meta = dict(kernel=r["Kernel_Name"], grid=int(r["Grid_Size"]), workgroup=int(r["Workgroup_Size"]), lds=int(r["LDS_Block_Size"]),
