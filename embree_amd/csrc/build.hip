@@ -46,6 +46,7 @@ namespace {
 #include "build_presplit.inl"    // RTC_BUILD_QUALITY_HIGH: pre-splitting of large triangles
 #include "build_binning.inl"     // bin mapping, binning helpers (rows / runs), SAH sweep of one wavefront
 #include "build_top.inl"         // K2: level-synchronous top phase
+#include "build_spatial.inl"     // RTC_BUILD_QUALITY_HIGH: spatial splits inside the top phase
 #include "build_small.inl"       // K3: sub-trees finished by one wavefront in LDS
 #include "build_morton.inl"      // RTC_BUILD_QUALITY_LOW: Morton-code build
 #include "build_wide.inl"        // K4: collapse of the binary tree into 8-wide quantised nodes
@@ -149,6 +150,10 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
   prm.maxLeaf = bp->max_leaf > MI355_MAX_LEAF ? MI355_MAX_LEAF : bp->max_leaf; if (prm.maxLeaf < prm.minLeaf) prm.maxLeaf = prm.minLeaf;
   if (prm.minLeaf > MI355_MAX_LEAF) prm.minLeaf = prm.maxLeaf = MI355_MAX_LEAF;
   prm.small = bp->small_threshold < 64u ? 64u : (bp->small_threshold > 65536u ? 65536u : bp->small_threshold); prm.travCost = bp->trav_cost; prm.intCost = bp->int_cost; prm.quality = bp->quality;
+  // RTC_BUILD_QUALITY_HIGH: spatial splits inside the recursion (the reference's default, bvh_builder_sah_spatial.cpp:93-160); "presplits=1" selects the
+  // reference's other form, splitting big triangles up front (state.cpp:88 useSpatialPreSplits).  The spatial splits live in the top phase: lower its end.
+  prm.spatial = (bp->quality == 2u && !bp->presplits && numMeshes < (1u << 27)) ? 1u : 0u;
+  if (prm.spatial && prm.small > 256u) prm.small = 256u;
 
   std::vector<GeomDesc> gd; uint64_t total = 0;
   for (uint32_t i = 0; i < numMeshes; i++) {
@@ -180,8 +185,9 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
 
   DevBuf<GeomDesc> dGeoms; HIP_TRY(dGeoms.alloc(gd.size()));
   HIP_TRY(hipMemcpyAsync(dGeoms.p, gd.data(), gd.size() * sizeof(GeomDesc), hipMemcpyHostToDevice, st));
-  const bool presplit = prm.quality == 2u;                     // RTC_BUILD_QUALITY_HIGH: up to 20 % more references than triangles
-  const uint32_t splitBudget = presplit ? (uint32_t)((double)N * (bp->split_factor > 1.0f ? (double)bp->split_factor - 1.0 : 0.2)) : 0u;
+  const bool spatial = prm.spatial != 0u;
+  const bool presplit = prm.quality == 2u && !spatial;         // up to 20 % more references than triangles, either way
+  const uint32_t splitBudget = prm.quality == 2u ? (uint32_t)((double)N * (bp->split_factor > 1.0f ? (double)bp->split_factor - 1.0 : 0.2)) : 0u;
   const uint64_t cap64 = (uint64_t)N + splitBudget;
   if (cap64 >= (1ull << 31)) return set_error(hipErrorInvalidValue, "more than 2^31 references are not supported by the 32-bit triangle index");
   const uint32_t NC = (uint32_t)cap64;                        // capacity of every per-reference array
@@ -198,6 +204,8 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
   HIP_TRY(plans.alloc(maxLevelItems)); HIP_TRY(itemCnt.alloc(maxLevelItems)); HIP_TRY(groupSum.alloc(maxLevelItems / 8u + 16u));
   const uint32_t tiles = (N + 255u) / 256u;
   HIP_TRY(tileCount.alloc(tiles));
+  DevBuf<SegX> segx0, segx1; DevBuf<uint32_t> sbins;            // spatial-split builds: extended ranges of the top phase's sets, their spatial bins
+  if (spatial) { HIP_TRY(segx0.alloc(maxSegs)); HIP_TRY(segx1.alloc(maxSegs)); HIP_TRY(sbins.alloc((size_t)maxSegs * SBINS_WORDS)); }
 
   hipEvent_t ev0, ev1; HIP_TRY(hipEventCreate(&ev0)); HIP_TRY(hipEventCreate(&ev1));
   struct EvGuard { hipEvent_t a, b; ~EvGuard() { hipEventDestroy(a); hipEventDestroy(b); } } evg{ev0, ev1};
@@ -282,6 +290,7 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
     HIP_TRY(hipMemcpyAsync(bnodes.p, &rootB, sizeof(rootB), hipMemcpyHostToDevice, st));
     h.numBLeaves = 0; h.numSegsNext = 0; h.numChunks = 0; h.numSmall = 0; h.numSegs = n > prm.small ? 1u : 0u; h.topLevels = 0;
     h.rootArea = fmaf(ghi[0] - glo[0], (ghi[1] - glo[1]) + (ghi[2] - glo[2]), (ghi[1] - glo[1]) * (ghi[2] - glo[2]));
+    h.areaFixed = 0ull;
     if (n > prm.small) {
       Seg s0{}; s0.begin = 0; s0.end = n; s0.bnode = 0; for (int d = 0; d < 3; d++) { s0.cmin[d] = clo[d]; s0.cmax[d] = chi[d]; }
       HIP_TRY(hipMemcpyAsync(segs0.p, &s0, sizeof(s0), hipMemcpyHostToDevice, st)); numSegs = 1;
@@ -290,6 +299,13 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
       HIP_TRY(hipMemcpyAsync(small.p, &se, sizeof(se), hipMemcpyHostToDevice, st)); h.numSmall = 1;
     }
     HIP_TRY(hipMemcpyAsync(ctr.p, &h, sizeof(h), hipMemcpyHostToDevice, st));
+    if (spatial && n > prm.small) {                              // split budgets of the references; the root set owns everything behind them
+      const uint32_t ab = (n + 255u) / 256u < 2048u ? (n + 255u) / 256u : 2048u;
+      LAUNCH(spatial_area_sum, dim3(ab), dim3(256), 0, st, bufA.p, n, ctr.p);
+      LAUNCH(spatial_budgets, dim3((n + 255u) / 256u), dim3(256), 0, st, bufA.p, n, ctr.p);
+      SegX x0{}; x0.extEnd = NC;
+      HIP_TRY(hipMemcpyAsync(segx0.p, &x0, sizeof(x0), hipMemcpyHostToDevice, st));
+    }
   }
 
   if (prm.quality == 1u) {                                     // RTC_BUILD_QUALITY_LOW: Morton codes -> sort -> hierarchy -> boxes
@@ -315,19 +331,25 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
   //      an upper bound of its grid (<= 2^level segments, <= N/CHUNK + #segments chunks) and surplus blocks exit at once, so
   //      the levels are enqueued back to back.
   uint32_t level = 0;
-  Seg* cur = segs0.p; Seg* nxt = segs1.p;
+  Seg* cur = segs0.p; Seg* nxt = segs1.p; SegX* xcur = segx0.p; SegX* xnxt = segx1.p;     // (the SegX arrays: nullptr unless spatial)
   auto enqueue_top_level = [&]() {
     PrimRef* src = (level & 1u) ? bufB.p : bufA.p; PrimRef* dst = (level & 1u) ? bufA.p : bufB.p;
     const uint32_t segBound = level < 31u && (1u << level) < maxSegs ? (1u << level) : maxSegs;
-    const uint32_t chunkBound = n / CHUNK + segBound + 1u;
+    const uint32_t chunkBound = (spatial ? NC : n) / CHUNK + segBound + 1u;
     LAUNCH(top_setup, dim3(segBound), dim3(256), 0, st, cur, bins.p, chunks.p, ctr.p);
     LAUNCH(top_bin, dim3(chunkBound), dim3(256), 0, st, cur, chunks.p, src, bins.p, ctr.p);
-    LAUNCH(top_split, dim3(segBound), dim3(64), 0, st, cur, bins.p, bnodes.p, ctr.p, prm, level >= 96u ? 1u : 0u);
+    LAUNCH(top_split, dim3(segBound), dim3(64), 0, st, cur, bins.p, bnodes.p, ctr.p, prm, level >= 96u ? 1u : 0u, xcur);
+    if (spatial) {                                               // sets whose object split leaves overlapping children try a spatial split
+      LAUNCH(spatial_decide, dim3(segBound), dim3(128), 0, st, cur, xcur, bnodes.p, sbins.p, ctr.p);
+      LAUNCH(spatial_bin, dim3(chunkBound), dim3(256), 0, st, cur, xcur, chunks.p, src, dGeoms.p, sbins.p, ctr.p);
+      LAUNCH(spatial_best, dim3(segBound), dim3(64), 0, st, cur, xcur, sbins.p, bnodes.p, ctr.p, prm);
+    }
     LAUNCH(top_partition, dim3(chunkBound), dim3(256), 0, st, cur, chunks.p, src, dst, ctr.p);
+    if (spatial) LAUNCH(spatial_partition, dim3(chunkBound), dim3(256), 0, st, cur, xcur, chunks.p, src, dst, dGeoms.p, ctr.p);
     LAUNCH(top_emit, dim3((segBound + 255u) / 256u), dim3(256), 0, st, cur, bnodes.p, nxt, small.p, ctr.p, prm,
-           (level & 1u) ? 0u : 1u, maxSegs, maxSmall);
+           (level & 1u) ? 0u : 1u, maxSegs, maxSmall, (const SegX*)xcur, xnxt);
     LAUNCH(top_advance, dim3(1), dim3(1), 0, st, ctr.p, maxSegs);
-    Seg* t = cur; cur = nxt; nxt = t; level++;
+    Seg* t = cur; cur = nxt; nxt = t; SegX* tx = xcur; xcur = xnxt; xnxt = tx; level++;
   };
   if (numSegs && sahBuild) {
     uint32_t sure = 1; while (sure < 40u && ((uint64_t)prm.small << sure) < n) sure++;   // the largest segment halves at best: that many levels exist
@@ -336,7 +358,7 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
       for (uint32_t i = 0; i < sure; i++) enqueue_top_level();
       for (;;) {
         SYNC_READ(h);
-        if (h.overflow) return set_error(hipErrorOutOfMemory, "top-phase work list overflow (pathological input)");
+        if (h.overflow) return set_error(hipErrorOutOfMemory, h.overflow == 2u ? "spatial split ran out of its extended range" : "top-phase work list overflow (pathological input)");
         if (h.numSegs == 0) break;
         enqueue_top_level(); enqueue_top_level();
       }
@@ -414,6 +436,7 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
       if (h.wideCount[wlevel & 1u] == 0) break;
       for (uint32_t i = 0; i < 4u; i++) enqueue_wide_level();
     }
+    if (spatial) { info.num_presplit = h.numTrisOut > n ? h.numTrisOut - n : 0u; n = h.numTrisOut; }   // the references the splits created are leaf entries like any other
     HIP_TRY(hipMalloc(&bvh->d_tris, (size_t)n * sizeof(TriRec) + 128));
     LAUNCH(tri_records, dim3((n + 255u) / 256u), dim3(256), 0, st, outIds.p, n, dGeoms.p, (TriRec*)bvh->d_tris, bp->robust ? 1u : 0u, (const Counters*)nullptr);
   }
@@ -427,7 +450,7 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
     HIP_TRY(hipMemcpyAsync(bvh->d_nodes, wnodes.p, (size_t)numNodes * sizeof(CNode), hipMemcpyDeviceToDevice, st));
   }
   bvh->robust = bp->robust != 0;
-  if (bp->refit && h.numInvalid == 0u && depth < 64u && !presplit) {        // keep the leaf order and the level table for mi355_bvh_refit
+  if (bp->refit && h.numInvalid == 0u && depth < 64u && prm.quality != 2u) {        // keep the leaf order and the level table for mi355_bvh_refit
     HIP_TRY(hipMalloc(&bvh->d_ids, (size_t)n * sizeof(uint2)));
     HIP_TRY(hipMemcpyAsync(bvh->d_ids, outIds.p, (size_t)n * sizeof(uint2), hipMemcpyDeviceToDevice, st));
     bvh->lvlStart.assign(h.lvlStart, h.lvlStart + depth); bvh->lvlStart.push_back(numNodes);
@@ -620,7 +643,7 @@ extern "C" {
 
 void mi355_default_build_params(mi355_build_params* p) {
   memset(p, 0, sizeof(*p));
-  p->sah_block_shift = 0; p->min_leaf = 2; p->max_leaf = 3; p->small_threshold = 1024; p->trav_cost = 1.0f; p->int_cost = 1.0f; p->split_factor = 1.2f;
+  p->sah_block_shift = 0; p->min_leaf = 2; p->max_leaf = 3; p->small_threshold = 1024; p->trav_cost = 1.0f; p->int_cost = 1.0f; p->split_factor = 1.2f; p->presplits = 0;
 }
 const char* mi355_last_error(void) { return mi355::g_err.c_str(); }
 int mi355_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }

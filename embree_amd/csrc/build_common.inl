@@ -48,9 +48,10 @@ struct Counters {
   unsigned long long sahFixed;                    // SAH statistics, 2^-24 fixed point (order-independent sum)
   float rootArea;                                 // half area of the scene bounds (SAH statistics are relative to it); written by root_setup
   uint32_t pad0;
+  unsigned long long areaFixed;                   // spatial-split builds: sum of the references' box areas / scene area, 2^-32 fixed point (build_spatial.inl)
   uint32_t lvlStart[64];                          // first node of every level of the wide tree (numbering is breadth first): what a refit walks bottom-up
 };
-struct Params { uint32_t shift, minLeaf, maxLeaf, small; float travCost, intCost; uint32_t quality; };
+struct Params { uint32_t shift, minLeaf, maxLeaf, small; float travCost, intCost; uint32_t quality, spatial; };
 
 // order-preserving float <-> uint so that integer atomicMin/Max reduce floats exactly
 __device__ __forceinline__ uint32_t enc(float f) { uint32_t u = __float_as_uint(f); return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u); }

@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256) void morton_gather(const PrimRef* src, const u
   if (i >= n) return;
   const PrimRef p = load_prim(src + order[i]);
   store_prim(dst + i, p);
-  finalIds[i] = make_uint2(p.geom, p.prim);
+  finalIds[i] = make_uint2(p.geom & 0x07FFFFFFu, p.prim);
 }
 // length of the common prefix of the (code, index) pairs i and j; -1 outside the array
 __device__ __forceinline__ int lbvh_delta(const unsigned long long* keys, int n, int i, int j) {

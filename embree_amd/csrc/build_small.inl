@@ -194,7 +194,7 @@ __device__ void micro_subtree(uint32_t* R, uint32_t W, uint32_t (*s_cb)[64][6], 
   }
   // every remaining segment is a binary leaf (the reference never splits sets of <= minLeafSize, bvh_builder_sah.h:253)
   if (lane < n0) {
-    finalIds[gbegin + lane] = make_uint2(p.geom, p.prim);
+    finalIds[gbegin + lane] = make_uint2(p.geom & 0x07FFFFFFu, p.prim);   // (top 5 bits: split budget of spatial-split builds, build_spatial.inl)
     if (lane == segB) ((uint4*)(bnodes + node))[2] = make_uint4(NIL, NIL, __float_as_uint(__builtin_inff()), 0u);
   }
   const unsigned long long leaves = __ballot(lane < n0 && lane == segB);

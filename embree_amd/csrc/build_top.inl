@@ -48,7 +48,12 @@ __global__ __launch_bounds__(256) void top_bin(const Seg* segs, const Chunk* chu
   }
 }
 
-__global__ __launch_bounds__(64) void top_split(Seg* segs, const uint32_t* bins, BNode* bnodes, Counters* ctr, Params prm, uint32_t forceFallback) {
+struct SegX;                                                    // build_spatial.inl: extended ranges of spatial-split builds (nullptr otherwise)
+__device__ __forceinline__ uint32_t segx_ext_end(const SegX* sx, uint32_t s);
+__device__ __forceinline__ void segx_object_split(SegX* sx, uint32_t s, uint32_t capL, float sah);
+__device__ __forceinline__ uint32_t segx_cap_left(const SegX* sx, uint32_t s);
+__device__ __forceinline__ void segx_child(SegX* nx, uint32_t k, uint32_t extEnd);
+__global__ __launch_bounds__(64) void top_split(Seg* segs, const uint32_t* bins, BNode* bnodes, Counters* ctr, Params prm, uint32_t forceFallback, SegX* sx) {
   __shared__ SplitResult s_res;
   const uint32_t s = blockIdx.x, lane = threadIdx.x;
   if (s >= ctr->numSegs) return;
@@ -61,16 +66,20 @@ __global__ __launch_bounds__(64) void top_split(Seg* segs, const uint32_t* bins,
     SplitResult r = s_res;
     const bool fallback = (r.dim < 0) || forceFallback;        // split invalid -> median split (split_template :144-147)
     const uint32_t nL = fallback ? ((begin + end) / 2u - begin) : r.nL;
-    const uint32_t idL = sg->bnode + 1u, idR = sg->bnode + 2u * nL;   // implicit pre-order numbering (see K3)
+    // spatial-split builds: the set's extended range [end, extEnd) is shared between the children by their size, the right child starts behind the left
+    // child's CAPACITY and binary nodes are numbered by capacity as well (setExtentedRanges / moveExtentedRange, heuristic_spatial_array.h:115-170)
+    uint32_t capL = nL;
+    if (sx) { const uint32_t ext = segx_ext_end(sx, s) - end; capL = nL + (uint32_t)floorf((float)nL / (float)n * (float)ext); segx_object_split(sx, s, capL, r.sah); }
+    const uint32_t idL = sg->bnode + 1u, idR = sg->bnode + 2u * capL;   // implicit pre-order numbering (see K3)
     BNode* par = bnodes + sg->bnode;
     par->left = idL; par->right = idR; par->splitSah = r.sah;
     BNode L{}, R{};
-    L.begin = begin; L.end = begin + nL; R.begin = begin + nL; R.end = end;
+    L.begin = begin; L.end = begin + nL; R.begin = begin + capL; R.end = begin + capL + (n - nL);
     L.left = L.right = R.left = R.right = NIL; L.splitSah = R.splitSah = __builtin_inff();
     for (int d = 0; d < 3; d++) { L.lo[d] = r.llo[d]; L.hi[d] = r.lhi[d]; R.lo[d] = r.rlo[d]; R.hi[d] = r.rhi[d]; }
     bnodes[idL] = L; bnodes[idR] = R;
     sg->flags = fallback ? 1u : 0u; sg->dim = fallback ? 0u : (uint32_t)r.dim; sg->pos = (uint32_t)r.pos; sg->nL = nL;
-    sg->childL = idL; sg->childR = idR; sg->curL = begin; sg->curR = begin + nL;
+    sg->childL = idL; sg->childR = idR; sg->curL = begin; sg->curR = begin + capL;
     for (int side = 0; side < 2; side++) for (int k = 0; k < 12; k++) sg->acc[side][k] = (k % 6 < 3) ? ENC_POS_INF : ENC_NEG_INF;
     (void)n;
   }
@@ -82,6 +91,7 @@ __global__ __launch_bounds__(256) void top_partition(Seg* segs, const Chunk* chu
   if (blockIdx.x >= ctr->numChunks) return;
   const Chunk ck = chunks[blockIdx.x];
   Seg* sg = segs + ck.seg;
+  if (sg->flags & 2u) return;                                    // this set splits spatially: spatial_partition (build_spatial.inl) moves it
   const bool fallback = (sg->flags & 1u) != 0u;
   const uint32_t dim = sg->dim, pos = sg->pos, mid = sg->begin + sg->nL;
   const float ofs = sg->ofs[dim], scale = sg->scale[dim];
@@ -137,16 +147,22 @@ __global__ __launch_bounds__(256) void top_partition(Seg* segs, const Chunk* chu
 }
 
 __global__ void top_emit(const Seg* segs, BNode* bnodes, Seg* next, SmallEntry* small, Counters* ctr,
-                         Params prm, uint32_t dstBuf, uint32_t maxNext, uint32_t maxSmall) {
+                         Params prm, uint32_t dstBuf, uint32_t maxNext, uint32_t maxSmall, const SegX* sx, SegX* nx) {
   const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= ctr->numSegs) return;
   const Seg* sg = segs + s;
+  const uint32_t capL = sx ? segx_cap_left(sx, s) : sg->nL;
   for (int side = 0; side < 2; side++) {
-    const uint32_t b = side ? sg->begin + sg->nL : sg->begin, e = side ? sg->end : sg->begin + sg->nL;
+    // spatial-split builds: the partition's cursors say how many references each side received (a spatial split creates some); a child's capacity ends
+    // where its share of the extended range ends
+    const uint32_t b = side ? sg->begin + capL : sg->begin;
+    const uint32_t e = sx ? (side ? sg->curR : sg->curL) : (side ? sg->end : sg->begin + sg->nL);
+    const uint32_t childExtEnd = sx ? (side ? segx_ext_end(sx, s) : sg->begin + capL) : e;
     const uint32_t child = side ? sg->childR : sg->childL;
     float cmin[3], cmax[3];
     for (int d = 0; d < 3; d++) { cmin[d] = dec(sg->acc[side][d]); cmax[d] = dec(sg->acc[side][3 + d]); }
-    if (sg->flags & 1u) for (int d = 0; d < 3; d++) { bnodes[child].lo[d] = dec(sg->acc[side][6 + d]); bnodes[child].hi[d] = dec(sg->acc[side][9 + d]); }
+    if (sg->flags & 3u) for (int d = 0; d < 3; d++) { bnodes[child].lo[d] = dec(sg->acc[side][6 + d]); bnodes[child].hi[d] = dec(sg->acc[side][9 + d]); }
+    if (sg->flags & 2u) { bnodes[child].begin = b; bnodes[child].end = e; }
     if (e - b <= prm.small) {
       const uint32_t k = atomicAdd(&ctr->numSmall, 1u);
       if (k >= maxSmall) { ctr->overflow = 1u; continue; }
@@ -159,6 +175,7 @@ __global__ void top_emit(const Seg* segs, BNode* bnodes, Seg* next, SmallEntry* 
       Seg ns{}; ns.begin = b; ns.end = e; ns.bnode = child;
       for (int d = 0; d < 3; d++) { ns.cmin[d] = cmin[d]; ns.cmax[d] = cmax[d]; }
       next[k] = ns;
+      if (nx) segx_child(nx, k, childExtEnd);
     }
   }
 }

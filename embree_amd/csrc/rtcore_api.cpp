@@ -364,6 +364,7 @@ void parse_config(Device* d, const char* cfg) {
     else if (k == "leaf_block_shift") d->build.sah_block_shift = (uint32_t)atoi(v.c_str());
     else if (k == "small_threshold") d->build.small_threshold = (uint32_t)atoi(v.c_str());
     else if (k == "quality") d->build.quality = (v == "low" || v == "1") ? 1u : (v == "high" || v == "2") ? 2u : 0u;
+    else if (k == "presplits") d->build.presplits = atoi(v.c_str()) != 0 ? 1u : 0u;                    // state.cpp:443
     else if (k == "max_spatial_split_replications") d->build.split_factor = (float)atof(v.c_str());   // state.cpp:437
     else if (k == "host_pipeline_min") d->pipelineMin = (unsigned)atol(v.c_str());
     else if (k == "host_pipeline_chunk") d->pipelineChunk = atol(v.c_str()) >= 1024 ? (unsigned)atol(v.c_str()) : 1024u;

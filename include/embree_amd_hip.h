@@ -55,10 +55,13 @@ typedef struct mi355_build_params {
                                 (triangle_intersector_pluecker.h:68-118).  default 0 */
   uint32_t quality;          /* 0 = RTC_BUILD_QUALITY_MEDIUM (binned SAH, the default); 1 = RTC_BUILD_QUALITY_LOW: Morton-code build like the
                                 reference's fast builder (kernels/builders/bvh_builder_morton.h), same node and leaf layout;
-                                2 = RTC_BUILD_QUALITY_HIGH: large triangles are pre-split into several references with clipped boxes before the SAH
-                                build (the reference's presplit builder, kernels/builders/primrefgen_presplit.h); no refit data is kept */
+                                2 = RTC_BUILD_QUALITY_HIGH: SAH build with spatial splits inside the recursion (the reference's default high-quality
+                                builder, kernels/builders/heuristic_spatial_array.h), or, with presplits = 1, large triangles pre-split into several
+                                references with clipped boxes before a plain SAH build (kernels/builders/primrefgen_presplit.h); no refit data is kept */
   float    split_factor;     /* quality 2 only: references may grow to split_factor * triangles (reference: max_spatial_split_replications = 1.2).  default 1.2 */
   uint32_t refit;            /* 1: keep what mi355_bvh_refit needs (8 B per triangle: the leaf order, and the level table).  default 0 */
+  uint32_t presplits;        /* quality 2 only: 1 = pre-split instead of splitting inside the recursion (reference: device config "presplits=1",
+                                kernels/common/state.cpp:88,443).  default 0 */
 } mi355_build_params;
 
 typedef struct mi355_bvh_info {

@@ -496,10 +496,15 @@ def _sticks(n, seed):
 
 
 @pytest.mark.parametrize("flags", [0, 4])
-def test_high_quality_presplit(api, dev, flags):
-    """rtcSetSceneBuildQuality(HIGH) = the reference's presplit builder (kernels/builders/primrefgen_presplit.h + the binned SAH build): big triangles enter
-    the build as several references with clipped boxes.  Hits do not depend on the tree: they must equal the MEDIUM scene's bit for bit (closest hit, any hit,
-    masks); the reference count stays within max_spatial_split_replications; the SAH cost drops; rebuilds are bit-identical; refit data is not kept."""
+@pytest.mark.parametrize("form", ["spatial", "presplits"])
+def test_high_quality_presplit(api, dev, flags, form):
+    """rtcSetSceneBuildQuality(HIGH), both forms of the reference: spatial splits inside the recursion (the default: kernels/builders/heuristic_spatial_array.h
+    under BVHBuilderBinnedFastSpatialSAH) and, with the device config "presplits=1" (state.cpp:443), the presplit builder (kernels/builders/
+    primrefgen_presplit.h + the binned SAH build): big triangles enter the tree as several references with clipped boxes.  Hits do not depend on the tree:
+    they must equal the MEDIUM scene's bit for bit (closest hit, any hit, masks); the reference count stays within max_spatial_split_replications; the SAH
+    cost drops; rebuilds are bit-identical; refit data is not kept."""
+    own = api.Device("gpu=0,presplits=1") if form == "presplits" else None
+    if own is not None: dev = own
     # few big triangles among many small ones: the budget (20 % of all references) goes to the big ones (a scene of ONLY big triangles gets no
     # splits at all: every relative priority is below 1, primrefgen_presplit.h:301-305)
     meshes = [_sticks(300, 5), W.triangle_sphere(np.array([0.5, 0.5, 0.5], np.float32), 0.25, 80, noise=0.1, seed=2)]
@@ -531,7 +536,7 @@ def test_high_quality_presplit(api, dev, flags):
             ra, rb = rays_of(rays), rays_of(rays)
             high.occluded1M(ra); med.occluded1M(rb)
             assert (np.isneginf(ra["tfar"]) == np.isneginf(rb["tfar"])).all()
-            print("presplit flags=%d: %d + %d references, SAH %.2f -> %.2f, nodes/ray %.2f -> %.2f, tris/ray %.2f -> %.2f" % (flags, ntri, ih["num_presplit"], im["sah"], ih["sah"], sm["nodes"] / 8e4, sh["nodes"] / 8e4, sm["tris"] / 8e4, sh["tris"] / 8e4))
+            print("HIGH (%s) flags=%d: %d + %d references, SAH %.2f -> %.2f, nodes/ray %.2f -> %.2f, tris/ray %.2f -> %.2f" % (form, flags, ntri, ih["num_presplit"], im["sah"], ih["sah"], sm["nodes"] / 8e4, sh["nodes"] / 8e4, sm["tris"] / 8e4, sh["tris"] / 8e4))
         high.release()
     assert blobs[0] == blobs[1]
     med.release()
@@ -544,6 +549,7 @@ def test_high_quality_presplit(api, dev, flags):
     same = (got["geomID"] == g["hits"]["geomID"]) & (got["primID"] == g["hits"]["primID"])
     assert same.mean() > 0.995 and np.allclose(got["tfar"][same], g["hits"]["tfar"][same], rtol=1e-4)
     s.release()
+    if own is not None: own.release()
 
 
 def test_interpolate(api, dev):
