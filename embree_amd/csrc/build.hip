@@ -186,6 +186,10 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
   DevBuf<GeomDesc> dGeoms; HIP_TRY(dGeoms.alloc(gd.size()));
   HIP_TRY(hipMemcpyAsync(dGeoms.p, gd.data(), gd.size() * sizeof(GeomDesc), hipMemcpyHostToDevice, st));
   const bool spatial = prm.spatial != 0u;
+  // sets of fewer references than this split by object only (the reference tries a spatial split wherever a set has an extended range): measured, the SAH
+  // of the long-triangle scene is 12.53 instead of 12.52 and the crown stand-in's tree does not change, for 1.2 ms less (spatial_bin clips a small set's
+  // references through most of its 16 bins per axis); 2048 would cost 2 % of the SAH gain, 65536 all of it on small scenes (profiles/r02_sah_vs_reference.md)
+  static const uint32_t spatialMin = getenv("MI355_SPATIAL_MIN") ? (uint32_t)atol(getenv("MI355_SPATIAL_MIN")) : 512u;
   const bool presplit = prm.quality == 2u && !spatial;         // up to 20 % more references than triangles, either way
   const uint32_t splitBudget = prm.quality == 2u ? (uint32_t)((double)N * (bp->split_factor > 1.0f ? (double)bp->split_factor - 1.0 : 0.2)) : 0u;
   const uint64_t cap64 = (uint64_t)N + splitBudget;
@@ -340,7 +344,7 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
     LAUNCH(top_bin, dim3(chunkBound), dim3(256), 0, st, cur, chunks.p, src, bins.p, ctr.p);
     LAUNCH(top_split, dim3(segBound), dim3(64), 0, st, cur, bins.p, bnodes.p, ctr.p, prm, level >= 96u ? 1u : 0u, xcur);
     if (spatial) {                                               // sets whose object split leaves overlapping children try a spatial split
-      LAUNCH(spatial_decide, dim3(segBound), dim3(128), 0, st, cur, xcur, bnodes.p, sbins.p, ctr.p);
+      LAUNCH(spatial_decide, dim3(segBound), dim3(128), 0, st, cur, xcur, bnodes.p, sbins.p, ctr.p, spatialMin);
       LAUNCH(spatial_bin, dim3(chunkBound), dim3(256), 0, st, cur, xcur, chunks.p, src, dGeoms.p, sbins.p, ctr.p);
       LAUNCH(spatial_best, dim3(segBound), dim3(64), 0, st, cur, xcur, sbins.p, bnodes.p, ctr.p, prm);
     }

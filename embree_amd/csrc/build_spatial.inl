@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void spatial_budgets(PrimRef* prims, uint32_t 
 }
 
 // ---- per level, after top_split: does the object split leave overlapping children?  (HeuristicArraySpatialSAH::find, heuristic_spatial_array.h:171-186)
-__global__ void spatial_decide(const Seg* segs, SegX* sx, const BNode* bnodes, uint32_t* sbins, const Counters* ctr) {
+__global__ void spatial_decide(const Seg* segs, SegX* sx, const BNode* bnodes, uint32_t* sbins, const Counters* ctr, uint32_t minSize) {
   const uint32_t s = blockIdx.x, tid = threadIdx.x;
   if (s >= ctr->numSegs) return;
   const Seg* sg = segs + s; SegX* x = sx + s;
@@ -109,7 +109,7 @@ __global__ void spatial_decide(const Seg* segs, SegX* sx, const BNode* bnodes, u
   if (tid == 0u) {
     uint32_t t = 0u;
     const uint32_t ext = x->extEnd - sg->end;
-    if (ext > 0u && !(sg->flags & 1u)) {
+    if (ext > 0u && !(sg->flags & 1u) && sg->end - sg->begin >= minSize) {
       const BNode& P = bnodes[sg->bnode]; const BNode& L = bnodes[sg->childL]; const BNode& R = bnodes[sg->childR];
       float olo[3], ohi[3];
       for (int d = 0; d < 3; d++) { olo[d] = fmaxf(L.lo[d], R.lo[d]); ohi[d] = fminf(L.hi[d], R.hi[d]); }
@@ -141,11 +141,13 @@ __device__ __forceinline__ void sbin_extend(uint32_t* bins, int dim, int bin, co
 // l = the bin it is counted to begin in (numBegin), rr = the bin it is counted to end in (numEnd) -- a plane p then sees it on the left iff l < p and on the
 // right iff rr >= p.  EXTEND: the pieces also extend the bins' boxes (binning); without it only (l, rr) come back, which is how spatial_partition decides
 // the sides: by construction neither side can receive more references than spatial_best predicted from the counts.
+// The triangle's vertices are only fetched (once, `have`) when the reference spans more than one bin on some axis: most do not.
 template <bool EXTEND>
-__device__ __forceinline__ void spatial_chain(const float (&v)[3][3], const PrimRef& r, int d, float ofs, float scale, float inv, uint32_t* bins, int& l, int& rr) {
+__device__ __forceinline__ void spatial_chain(float (&v)[3][3], bool& have, const GeomDesc* geoms, const PrimRef& r, int d, float ofs, float scale, float inv, uint32_t* bins, int& l, int& rr) {
   const float rlo = sel3((uint32_t)d, r.lo[0], r.lo[1], r.lo[2]), rhi = sel3((uint32_t)d, r.hi[0], r.hi[1], r.hi[2]);
   l = sbin(rlo, ofs, scale); rr = sbin(rhi, ofs, scale);
   if (l == rr) { if (EXTEND) sbin_extend(bins, d, l, r.lo, r.hi); return; }
+  if (!have) { load_tri_masked(geoms, r, v); have = true; }
   int bs = l, be = rr;
   float restLo[3] = {r.lo[0], r.lo[1], r.lo[2]}, restHi[3] = {r.hi[0], r.hi[1], r.hi[2]};
   while (bs < be && sbin_pos(bs + 1, ofs, inv) <= rlo) bs++;                       // "assure that split position always overlaps the primitive bounds"
@@ -162,38 +164,94 @@ __device__ __forceinline__ void spatial_chain(const float (&v)[3][3], const Prim
   if (EXTEND) sbin_extend(bins, d, bin, restLo, restHi);
   rr = rr < 0 ? 0 : rr; l = l > rr ? rr : l;                                       // degenerate pieces: still counted on one side of every plane
 }
+// References that lie in ONE bin of an axis (nearly all) are not sent to the LDS bins one by one: like top_bin (bins_add_rows), the 16 lanes of a DPP row
+// hold 16 consecutive references, which sit in one bin or straddle one boundary; the row's lowest and highest bin are reduced with row_shr steps and lane 15
+// issues the atomics of the two groups (same-word LDS atomics of a wave are executed one lane after the other: they are what binning waits for).
+__device__ __forceinline__ void sbins_add_rows(uint32_t* bins, int d, uint32_t b, bool simple, const uint32_t (&c)[6], uint32_t lane) {
+  const unsigned long long sm = __ballot(simple);
+  const uint32_t rowBase = lane & 48u;
+  const bool rowFull = ((sm >> rowBase) & 0xFFFFull) == 0xFFFFull;
+  const uint32_t bb = simple ? b : 0u;
+  const uint32_t bmin = (uint32_t)__shfl((int)row_umin15(bb), (int)(lane | 15u), 64), bmax = (uint32_t)__shfl((int)row_umax15(bb), (int)(lane | 15u), 64);
+  const bool inLo = rowFull && bb == bmin, inHi = rowFull && bb == bmax && bmax != bmin;
+  uint32_t lo[6], hi[6];
+  for (int k = 0; k < 3; k++) {
+    lo[k] = row_umin15(inLo ? c[k] : 0xFFFFFFFFu); lo[3 + k] = row_umax15(inLo ? c[3 + k] : 0u);
+    hi[k] = row_umin15(inHi ? c[k] : 0xFFFFFFFFu); hi[3 + k] = row_umax15(inHi ? c[3 + k] : 0u);
+  }
+  const uint32_t nLo = (uint32_t)__popcll((__ballot(inLo) >> rowBase) & 0xFFFFull), nHi = (uint32_t)__popcll((__ballot(inHi) >> rowBase) & 0xFFFFull);
+  if ((lane & 15u) == 15u && rowFull) {
+    uint32_t* e = bins + (d * SBINS + bmin) * SBINW;
+    atomicMin(&e[0], lo[0]); atomicMin(&e[1], lo[1]); atomicMin(&e[2], lo[2]);
+    atomicMax(&e[3], lo[3]); atomicMax(&e[4], lo[4]); atomicMax(&e[5], lo[5]);
+    atomicAdd(&e[6], nLo); atomicAdd(&e[7], nLo);
+    if (nHi) {
+      uint32_t* f = bins + (d * SBINS + bmax) * SBINW;
+      atomicMin(&f[0], hi[0]); atomicMin(&f[1], hi[1]); atomicMin(&f[2], hi[2]);
+      atomicMax(&f[3], hi[3]); atomicMax(&f[4], hi[4]); atomicMax(&f[5], hi[5]);
+      atomicAdd(&f[6], nHi); atomicAdd(&f[7], nHi);
+    }
+  }
+  if (simple && !inLo && !inHi) {
+    uint32_t* e = bins + (d * SBINS + b) * SBINW;
+    atomicMin(&e[0], c[0]); atomicMin(&e[1], c[1]); atomicMin(&e[2], c[2]);
+    atomicMax(&e[3], c[3]); atomicMax(&e[4], c[4]); atomicMax(&e[5], c[5]);
+    atomicAdd(&e[6], 1u); atomicAdd(&e[7], 1u);
+  }
+}
 __global__ __launch_bounds__(256) void spatial_bin(const Seg* segs, const SegX* sx, const Chunk* chunks, const PrimRef* src, const GeomDesc* geoms, uint32_t* sbins, const Counters* ctr) {
   __shared__ uint32_t s_b[SBINS_WORDS];
-  const uint32_t tid = threadIdx.x;
-  if (blockIdx.x >= ctr->numChunks) return;
-  const Chunk ck = chunks[blockIdx.x];
+  const uint32_t tid = threadIdx.x, lane = tid & 63u;
+  const uint32_t numChunks = ctr->numChunks, c0 = blockIdx.x;
+  if (c0 >= numChunks) return;
+  Chunk ck = chunks[c0];
   const SegX* x = sx + ck.seg;
   if (!x->trySpatial) return;
+  const uint32_t c1 = c0 + 1u;                                   // (one chunk per workgroup: doing several in a row left the top levels with too few workgroups)
   for (uint32_t w = tid; w < (uint32_t)SBINS_WORDS; w += 256u) { const uint32_t k = w % SBINW; s_b[w] = k < 3 ? ENC_POS_INF : (k < 6 ? ENC_NEG_INF : 0u); }
   __syncthreads();
   float ofs[3], scale[3], inv[3];
   for (int d = 0; d < 3; d++) { ofs[d] = x->sofs[d]; scale[d] = x->sscale[d]; inv[d] = x->sinv[d]; }
-  for (uint32_t i = ck.begin + tid; i < ck.end; i += 256u) {
-    const PrimRef r = load_prim(src + i);
-    const uint32_t budget = r.geom >> SPLIT_SHIFT;
-    if (budget <= 1u) {                                                             // cannot be split: whole into the bin of its centre (:170-178)
+  const uint32_t first = ck.begin; uint32_t last = ck.end;
+  for (uint32_t c = c0;;) {
+    // each wave owns a contiguous quarter of the chunk (as in top_bin): a row of 16 lanes sees 16 consecutive references
+    const uint32_t span = ck.begin + (tid >> 6) * (CHUNK / 4u), spanEnd = min(span + CHUNK / 4u, ck.end);
+    for (uint32_t i0 = span; i0 < spanEnd; i0 += 64u) {           // wave-uniform trip count
+      const uint32_t i = i0 + lane; const bool v = i < spanEnd;
+      PrimRef r{}; if (v) r = load_prim(src + i);
+      const uint32_t budget = r.geom >> SPLIT_SHIFT;
+      uint32_t c6[6];
+      for (int k = 0; k < 3; k++) { c6[k] = enc(r.lo[k]); c6[3 + k] = enc(r.hi[k]); }
+      float tv[3][3]; bool have = false;
+#pragma unroll
       for (int d = 0; d < 3; d++) {
-        const int b = sbin(0.5f * (r.lo[d] + r.hi[d]), ofs[d], scale[d]);
-        sbin_extend(s_b, d, b, r.lo, r.hi);
-        atomicAdd(&s_b[(d * SBINS + b) * SBINW + 6], 1u); atomicAdd(&s_b[(d * SBINS + b) * SBINW + 7], 1u);
+        // a reference without budget goes whole into the bin of its centre on every axis (:170-178); one with budget into the bin its box lies in, if that
+        // is ONE bin; otherwise it is clipped bin by bin (spatial_chain) -- on axes the mapping is valid for (mapping.invalid(dim))
+        bool simple = false; uint32_t b = 0u;
+        if (v) {
+          if (budget <= 1u) { simple = true; b = (uint32_t)sbin(0.5f * (r.lo[d] + r.hi[d]), ofs[d], scale[d]); }
+          else if (scale[d] != 0.0f) {
+            const int l = sbin(r.lo[d], ofs[d], scale[d]), rr = sbin(r.hi[d], ofs[d], scale[d]);
+            if (l == rr) { simple = true; b = (uint32_t)l; }
+            else {
+              int l2, r2; spatial_chain<true>(tv, have, geoms, r, d, ofs[d], scale[d], inv[d], s_b, l2, r2);
+              atomicAdd(&s_b[(d * SBINS + l2) * SBINW + 6], 1u); atomicAdd(&s_b[(d * SBINS + r2) * SBINW + 7], 1u);
+            }
+          }
+        }
+        sbins_add_rows(s_b, d, b, simple, c6, lane);
       }
-      continue;
     }
-    float v[3][3]; load_tri_masked(geoms, r, v);
-    for (int d = 0; d < 3; d++) {
-      if (scale[d] == 0.0f) continue;                                              // mapping.invalid(dim)
-      int l, rr;
-      spatial_chain<true>(v, r, d, ofs[d], scale[d], inv[d], s_b, l, rr);
-      atomicAdd(&s_b[(d * SBINS + l) * SBINW + 6], 1u); atomicAdd(&s_b[(d * SBINS + rr) * SBINW + 7], 1u);
-    }
+    last = ck.end;
+    if (++c >= c1) break;
+    const Chunk nk = chunks[c];
+    if (nk.seg != ck.seg) break;
+    ck = nk;
   }
   __syncthreads();
+  const Seg* sg = segs + ck.seg;
   uint32_t* g = sbins + (size_t)ck.seg * SBINS_WORDS;
+  if (first == sg->begin && last == sg->end) { for (uint32_t w = tid; w < (uint32_t)SBINS_WORDS; w += 256u) g[w] = s_b[w]; return; }   // the whole set: these ARE its bins
   for (uint32_t w = tid; w < (uint32_t)SBINS_WORDS; w += 256u) {
     const uint32_t k = w % SBINW, v = s_b[w];
     if (k < 3) { if (v != ENC_POS_INF) atomicMin(&g[w], v); } else if (k < 6) { if (v != ENC_NEG_INF) atomicMax(&g[w], v); } else if (v) atomicAdd(&g[w], v);
@@ -260,9 +318,26 @@ __global__ __launch_bounds__(64) void spatial_best(Seg* segs, SegX* sx, const ui
   }
 }
 
-// ---- create_spatial_splits + the partition by centre (heuristic_spatial_array.h:266-330, :395-420) for the chunks of the sets that split spatially
+// ---- create_spatial_splits + the partition by centre (heuristic_spatial_array.h:266-330, :395-420) for the chunks of the sets that split spatially.
+// Two passes over the chunk: the first decides the side(s) of every reference and counts, ONE pair of atomics then reserves the chunk's places behind the
+// set's two cursors (a reservation per round of 256 made the big sets of the top levels wait for 37,000 same-address atomics: 1.5 ms a level), the second
+// reads the references again (L2), cuts the straddling ones and writes.
+__device__ __forceinline__ void spatial_sides(const PrimRef& r, uint32_t dim, int pos, float ofs, float scale, float inv, const GeomDesc* geoms, float (&tv)[3][3], bool& toL, bool& toR) {
+  const uint32_t budget = r.geom >> SPLIT_SHIFT;
+  const float rlo = sel3(dim, r.lo[0], r.lo[1], r.lo[2]), rhi = sel3(dim, r.hi[0], r.hi[1], r.hi[2]);
+  if (budget > 1u) {                                             // the sides binning counted it on (spatial_chain)
+    bool have = false; int l, rr;
+    spatial_chain<false>(tv, have, geoms, r, (int)dim, ofs, scale, inv, nullptr, l, rr);
+    toL = l < pos; toR = rr >= pos;
+    if (toL && toR) {                                            // straddles the plane (so l != rr: the vertices are there): cut it, unless a piece would be empty
+      float Llo[3], Lhi[3], Rlo[3], Rhi[3];
+      split_triangle(tv, dim, sbin_pos(pos, ofs, inv), r.lo, r.hi, Llo, Lhi, Rlo, Rhi);
+      if (box_empty(Llo, Lhi)) toL = false; else if (box_empty(Rlo, Rhi)) toR = false;
+    }
+  } else { toL = sbin(0.5f * (rlo + rhi), ofs, scale) < pos; toR = !toL; }   // whole, to the side its centre lies on
+}
 __global__ __launch_bounds__(256) void spatial_partition(Seg* segs, const SegX* sx, const Chunk* chunks, const PrimRef* src, PrimRef* dst, const GeomDesc* geoms, Counters* ctr) {
-  __shared__ uint32_t s_cnt[4][2], s_acc[2][12], s_baseL, s_baseR;
+  __shared__ uint32_t s_cnt[CHUNK_ROUNDS][4][2], s_off[CHUNK_ROUNDS][4][2], s_baseL, s_baseR;
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   if (blockIdx.x >= ctr->numChunks) return;
   const Chunk ck = chunks[blockIdx.x];
@@ -271,63 +346,76 @@ __global__ __launch_bounds__(256) void spatial_partition(Seg* segs, const SegX* 
   const uint32_t dim = sg->dim; const int pos = (int)sg->pos;
   const float ofs = sel3(dim, x->sofs[0], x->sofs[1], x->sofs[2]), scale = sel3(dim, x->sscale[0], x->sscale[1], x->sscale[2]), inv = sel3(dim, x->sinv[0], x->sinv[1], x->sinv[2]);
   const float fpos = sbin_pos(pos, ofs, inv);
-  for (uint32_t round = 0; round < (uint32_t)CHUNK_ROUNDS; round++) {
-    if (tid < 24u) s_acc[tid / 12u][tid % 12u] = (tid % 6u < 3u) ? ENC_POS_INF : ENC_NEG_INF;
-    __syncthreads();
-    const uint32_t i = ck.begin + round * 256u + tid;
-    const bool v = i < ck.end;
-    PrimRef L{}, R{}; bool toL = false, toR = false;
-    if (v) {
-      const PrimRef r = load_prim(src + i);
+  uint32_t bitsL = 0u, bitsR = 0u;                               // this thread's decisions, one bit per round
+  unsigned long long lm[CHUNK_ROUNDS], rm[CHUNK_ROUNDS];
+#pragma unroll
+  for (int round = 0; round < CHUNK_ROUNDS; round++) {
+    const uint32_t i = ck.begin + (uint32_t)round * 256u + tid;
+    bool toL = false, toR = false;
+    if (i < ck.end) { const PrimRef r = load_prim(src + i); float tv[3][3]; spatial_sides(r, dim, pos, ofs, scale, inv, geoms, tv, toL, toR); }
+    lm[round] = __ballot(toL); rm[round] = __ballot(toR);
+    if (lane == 0u) { s_cnt[round][wave][0] = (uint32_t)__popcll(lm[round]); s_cnt[round][wave][1] = (uint32_t)__popcll(rm[round]); }
+    if (toL) bitsL |= 1u << round;
+    if (toR) bitsR |= 1u << round;
+  }
+  __syncthreads();
+  if (tid == 0u) {
+    uint32_t l = 0, rr = 0;
+    for (int r = 0; r < CHUNK_ROUNDS; r++) for (int w = 0; w < 4; w++) { s_off[r][w][0] = l; s_off[r][w][1] = rr; l += s_cnt[r][w][0]; rr += s_cnt[r][w][1]; }
+    s_baseL = l ? atomicAdd(&sg->curL, l) : 0u; s_baseR = rr ? atomicAdd(&sg->curR, rr) : 0u;
+  }
+  __syncthreads();
+  uint32_t acc[2][12];                                           // this thread's share of the children's centroid / geometry bounds (ordered uint), folded across the wave at the end
+  for (int side = 0; side < 2; side++) for (int k = 0; k < 12; k++) acc[side][k] = (k % 6 < 3) ? ENC_POS_INF : ENC_NEG_INF;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  const uint32_t limL = sg->begin + x->capL, limR = x->extEnd;
+#pragma unroll
+  for (int round = 0; round < CHUNK_ROUNDS; round++) {
+    const bool toL = (bitsL >> round) & 1u, toR = (bitsR >> round) & 1u;
+    if (!toL && !toR) continue;
+    const uint32_t i = ck.begin + (uint32_t)round * 256u + tid;
+    const PrimRef r = load_prim(src + i);
+    PrimRef L = r, R = r;
+    if (toL && toR) {                                            // the cut of pass one, now for its boxes
+      float tv[3][3]; load_tri_masked(geoms, r, tv);
+      float Llo[3], Lhi[3], Rlo[3], Rhi[3];
+      split_triangle(tv, dim, fpos, r.lo, r.hi, Llo, Lhi, Rlo, Rhi);
+      for (int d = 0; d < 3; d++) { L.lo[d] = Llo[d]; L.hi[d] = Lhi[d]; R.lo[d] = Rlo[d]; R.hi[d] = Rhi[d]; }
       const uint32_t budget = r.geom >> SPLIT_SHIFT;
-      const float rlo = sel3(dim, r.lo[0], r.lo[1], r.lo[2]), rhi = sel3(dim, r.hi[0], r.hi[1], r.hi[2]);
-      if (budget > 1u) {                                                              // the sides binning counted it on (spatial_chain)
-        float tv[3][3]; load_tri_masked(geoms, r, tv);
-        int l, rr; spatial_chain<false>(tv, r, (int)dim, ofs, scale, inv, nullptr, l, rr);
-        toL = l < pos; toR = rr >= pos;
-        if (toL && toR) {                                                             // straddles the plane: cut it, unless a piece would be empty
-          float Llo[3], Lhi[3], Rlo[3], Rhi[3];
-          split_triangle(tv, dim, fpos, r.lo, r.hi, Llo, Lhi, Rlo, Rhi);
-          const bool eL = box_empty(Llo, Lhi), eR = box_empty(Rlo, Rhi);
-          if (!eL && !eR) {
-            L = r; R = r;
-            for (int d = 0; d < 3; d++) { L.lo[d] = Llo[d]; L.hi[d] = Lhi[d]; R.lo[d] = Rlo[d]; R.hi[d] = Rhi[d]; }
-            L.geom = (r.geom & GEOM_MASK) | ((budget - 1u) << SPLIT_SHIFT); R.geom = L.geom;
-          } else if (eL) { toL = false; R = r; } else { toR = false; L = r; }
-        } else if (toL) L = r; else R = r;
-      } else {                                                                        // whole, to the side its centre lies on
-        toL = sbin(0.5f * (rlo + rhi), ofs, scale) < pos; toR = !toL;
-        if (toL) L = r; else R = r;
-      }
-      for (int side = 0; side < 2; side++) {
-        if (!(side ? toR : toL)) continue;
-        const PrimRef& q = side ? R : L;
-        for (int d = 0; d < 3; d++) {
-          const uint32_t cc = enc(q.lo[d] + q.hi[d]);
-          atomicMin(&s_acc[side][d], cc); atomicMax(&s_acc[side][3 + d], cc);
-          atomicMin(&s_acc[side][6 + d], enc(q.lo[d])); atomicMax(&s_acc[side][9 + d], enc(q.hi[d]));
-        }
+      L.geom = (r.geom & GEOM_MASK) | ((budget - 1u) << SPLIT_SHIFT); R.geom = L.geom;
+    }
+#pragma unroll
+    for (int side = 0; side < 2; side++) {
+      if (!(side ? toR : toL)) continue;
+      const PrimRef& q = side ? R : L;
+#pragma unroll
+      for (int d = 0; d < 3; d++) {
+        const uint32_t cc = enc(q.lo[d] + q.hi[d]), el = enc(q.lo[d]), eh = enc(q.hi[d]);
+        acc[side][d] = min(acc[side][d], cc); acc[side][3 + d] = max(acc[side][3 + d], cc);
+        acc[side][6 + d] = min(acc[side][6 + d], el); acc[side][9 + d] = max(acc[side][9 + d], eh);
       }
     }
-    const unsigned long long lm = __ballot(toL), rm = __ballot(toR);
-    if (lane == 0u) { s_cnt[wave][0] = (uint32_t)__popcll(lm); s_cnt[wave][1] = (uint32_t)__popcll(rm); }
-    __syncthreads();
-    if (tid == 0u) {
-      const uint32_t l = s_cnt[0][0] + s_cnt[1][0] + s_cnt[2][0] + s_cnt[3][0], rr = s_cnt[0][1] + s_cnt[1][1] + s_cnt[2][1] + s_cnt[3][1];
-      s_baseL = l ? atomicAdd(&sg->curL, l) : 0u; s_baseR = rr ? atomicAdd(&sg->curR, rr) : 0u;
-    }
-    __syncthreads();
-    uint32_t offL = s_baseL, offR = s_baseR;
-    for (uint32_t w = 0; w < wave; w++) { offL += s_cnt[w][0]; offR += s_cnt[w][1]; }
-    const unsigned long long lt = (1ull << lane) - 1ull;
     // (the limits cannot be reached -- the counts of spatial_best are upper bounds -- but a store past a set's capacity would corrupt a sibling: guarded)
-    const uint32_t oL = offL + (uint32_t)__popcll(lm & lt), oR = offR + (uint32_t)__popcll(rm & lt);
-    if (toL) { if (oL < sg->begin + x->capL) store_prim(dst + oL, L); else ctr->overflow = 2u; }
-    if (toR) { if (oR < x->extEnd) store_prim(dst + oR, R); else ctr->overflow = 2u; }
-    if (tid < 24u) {
-      const uint32_t side = tid / 12u, k = tid % 12u, val = s_acc[side][k];
-      if (k % 6u < 3u) { if (val != ENC_POS_INF) atomicMin(&sg->acc[side][k], val); } else { if (val != ENC_NEG_INF) atomicMax(&sg->acc[side][k], val); }
+    const uint32_t oL = s_baseL + s_off[round][wave][0] + (uint32_t)__popcll(lm[round] & lt), oR = s_baseR + s_off[round][wave][1] + (uint32_t)__popcll(rm[round] & lt);
+    if (toL) { if (oL < limL) store_prim(dst + oL, L); else ctr->overflow = 2u; }
+    if (toR) { if (oR < limR) store_prim(dst + oR, R); else ctr->overflow = 2u; }
+  }
+  // fold the bounds: lanes of a wave (DPP), the four waves of the workgroup (LDS), then 24 atomics per chunk -- atomics of many chunks on the one cache line
+  // of a big set's record are what this kernel waited for (one per wave: 0.95 of the 1.14 ms of the root's level)
+  __shared__ uint32_t s_acc[2][12];
+  if (tid < 24u) s_acc[tid / 12u][tid % 12u] = (tid % 6u < 3u) ? ENC_POS_INF : ENC_NEG_INF;
+  __syncthreads();
+#pragma unroll
+  for (int side = 0; side < 2; side++)
+#pragma unroll
+    for (int k = 0; k < 12; k++) {
+      const bool lo = (k % 6) < 3;
+      const uint32_t val = lo ? wave_umin63(acc[side][k]) : wave_umax63(acc[side][k]);
+      if (lane == 63u) { if (lo) atomicMin(&s_acc[side][k], val); else atomicMax(&s_acc[side][k], val); }
     }
-    __syncthreads();
+  __syncthreads();
+  if (tid < 24u) {
+    const uint32_t side = tid / 12u, k = tid % 12u, val = s_acc[side][k];
+    if (k % 6u < 3u) { if (val != ENC_POS_INF) atomicMin(&sg->acc[side][k], val); } else { if (val != ENC_NEG_INF) atomicMax(&sg->acc[side][k], val); }
   }
 }

@@ -41,6 +41,10 @@ __global__ __launch_bounds__(256) void top_bin(const Seg* segs, const Chunk* chu
   }
   __syncthreads();
   uint32_t* g = bins + (size_t)ck.seg * BINS_WORDS;
+  if (ck.begin == sg->begin && ck.end == sg->end) {             // the set's only chunk (every set of the lower levels): its bins ARE the set's bins, no atomics
+    for (uint32_t w = tid; w < (uint32_t)BINS_WORDS; w += 256u) g[w] = s_bins[w];
+    return;
+  }
   for (uint32_t w = tid; w < (uint32_t)BINS_WORDS; w += 256u) {      // BinInfoT::merge :312-321
     const uint32_t k = w % BINW, cnt = s_bins[w - k + 6];
     if (cnt == 0u) continue;
@@ -78,7 +82,7 @@ __global__ __launch_bounds__(64) void top_split(Seg* segs, const uint32_t* bins,
     L.left = L.right = R.left = R.right = NIL; L.splitSah = R.splitSah = __builtin_inff();
     for (int d = 0; d < 3; d++) { L.lo[d] = r.llo[d]; L.hi[d] = r.lhi[d]; R.lo[d] = r.rlo[d]; R.hi[d] = r.rhi[d]; }
     bnodes[idL] = L; bnodes[idR] = R;
-    sg->flags = fallback ? 1u : 0u; sg->dim = fallback ? 0u : (uint32_t)r.dim; sg->pos = (uint32_t)r.pos; sg->nL = nL;
+    sg->flags = fallback ? 1u : 0u; sg->dim = fallback ? 0u : (uint32_t)r.dim; sg->pos = fallback ? capL : (uint32_t)r.pos; sg->nL = nL;   // (median split: pos = where the right child starts, see top_partition)
     sg->childL = idL; sg->childR = idR; sg->curL = begin; sg->curR = begin + capL;
     for (int side = 0; side < 2; side++) for (int k = 0; k < 12; k++) sg->acc[side][k] = (k % 6 < 3) ? ENC_POS_INF : ENC_NEG_INF;
     (void)n;
@@ -136,8 +140,11 @@ __global__ __launch_bounds__(256) void top_partition(Seg* segs, const Chunk* chu
   for (int r = 0; r < CHUNK_ROUNDS; r++) {
     if (!(validBits & (1u << r))) continue;
     const bool left = (sideBits >> r) & 1u;
-    const uint32_t o = left ? s_baseL + s_off[r][wave][0] + (uint32_t)__popcll(lm[r] & lt)
-                            : s_baseR + s_off[r][wave][1] + (uint32_t)__popcll(rm[r] & lt);
+    uint32_t o = left ? s_baseL + s_off[r][wave][0] + (uint32_t)__popcll(lm[r] & lt)
+                      : s_baseR + s_off[r][wave][1] + (uint32_t)__popcll(rm[r] & lt);
+    // a median split keeps the order (left = the first half as it lies, right = the rest): its positions do not depend on which chunk got to the
+    // cursors first -- what the NEXT median split of the same triangles cuts off must be the same on every run (scenes of coincident triangles)
+    if (fallback) { const uint32_t i = ck.begin + (uint32_t)r * 256u + tid; o = left ? i : sg->begin + pos + (i - mid); }
     store_prim(dst + o, pr[r]);
   }
   if (tid < 24) {

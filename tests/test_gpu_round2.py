@@ -406,7 +406,8 @@ def test_spatial_split_build_scenes(api, dev, name):
         both = (a["geomID"] != INVALID_ID) & (b["geomID"] != INVALID_ID)
         return ((a["geomID"] != b["geomID"]) | (a["primID"] != b["primID"])) & both & (np.abs(a["tfar"] - b["tfar"]) <= 1e-4 * np.abs(b["tfar"]))
     tie = near_ties(a, b)
-    assert tie.mean() <= 1e-4, (name, int(tie.sum()))
+    tie_limit = 1.0 if name.startswith("coincident") else 1e-4    # 3000 coincident triangles: every hit on them is an exact tie, any of them is the right answer
+    assert tie.mean() <= tie_limit, (name, int(tie.sum()))
     for f in ("geomID", "primID", "tfar", "u", "v", "Ng_x", "Ng_y", "Ng_z"):
         d = (a[f].view(np.uint32) != b[f].view(np.uint32)) & ~tie
         assert not d.any(), (name, f, int(d.sum()))
@@ -420,7 +421,7 @@ def test_spatial_split_build_scenes(api, dev, name):
     a, b = rays.copy(), rays.copy()
     hr.intersect1M(a); mr.intersect1M(b)
     tie = near_ties(a, b)
-    assert tie.mean() <= 1e-4, (name, "robust", int(tie.sum()))
+    assert tie.mean() <= tie_limit, (name, "robust", int(tie.sum()))
     for f in ("geomID", "primID", "tfar"):
         assert not ((a[f].view(np.uint32) != b[f].view(np.uint32)) & ~tie).any(), (name, "robust", f)
     sh, sm = high.trace_stats(api.DeviceArray.from_numpy(rays).ptr, rays.shape[0], 96), med.trace_stats(api.DeviceArray.from_numpy(rays).ptr, rays.shape[0], 96)
