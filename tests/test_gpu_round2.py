@@ -428,3 +428,75 @@ def test_spatial_split_build_scenes(api, dev, name):
     print("%s: %d + %d references, SAH %.2f -> %.2f, nodes/ray %.2f -> %.2f, tris/ray %.2f -> %.2f, build %.2f -> %.2f ms"
           % (name, im["num_triangles"], ih["num_presplit"], im["sah"], ih["sah"], sm["nodes"] / rays.shape[0], sh["nodes"] / rays.shape[0], sm["tris"] / rays.shape[0], sh["tris"] / rays.shape[0], im["build_ms"], ih["build_ms"]))
     for s in (med, high, high2, hr, mr): s.release()
+
+
+# ------------------------------------------------------------------------------------------- many small random scenes, every build quality
+def _random_scene(rng):
+    """1..400 triangles in 1..3 geometries: indexed strips / fans with shared vertices, soups, slivers, exact duplicates, a few invalid indices"""
+    meshes = []
+    for _ in range(int(rng.integers(1, 4))):
+        kind = int(rng.integers(0, 4))
+        if kind == 0:                                            # grid patch (shared vertices, consistent winding)
+            k = int(rng.integers(1, 10))
+            gy, gx = np.meshgrid(np.arange(k + 1, dtype=np.float32), np.arange(k + 1, dtype=np.float32), indexing="ij")
+            v = np.stack([gx / k, gy / k, 0.3 * rng.random((k + 1, k + 1), dtype=np.float32)], -1).reshape(-1, 3) + rng.random(3, dtype=np.float32)
+            ii = (np.arange(k)[:, None] * (k + 1) + np.arange(k)[None, :]).ravel()
+            t = np.concatenate([np.stack([ii, ii + 1, ii + k + 2], -1), np.stack([ii, ii + k + 2, ii + k + 1], -1)])
+        elif kind == 1:                                          # soup of big overlapping triangles
+            n = int(rng.integers(1, 120))
+            v = (rng.random((n, 1, 3), dtype=np.float32) * 1.5 + (rng.random((n, 3, 3), dtype=np.float32) - 0.5) * float(rng.choice([0.05, 0.5, 2.0]))).reshape(-1, 3)
+            t = np.arange(3 * n).reshape(-1, 3)
+        elif kind == 2:                                          # slivers and exact duplicates
+            n = int(rng.integers(1, 60))
+            a = rng.random((n, 3), dtype=np.float32) * 1.5
+            d = np.zeros((n, 3), np.float32); d[np.arange(n), rng.integers(0, 3, n)] = 1.0
+            v = np.stack([a, a + d, a + d * 0.5 + (rng.random((n, 3), dtype=np.float32) - 0.5) * 1e-3], 1).reshape(-1, 3)
+            t = np.arange(3 * n).reshape(-1, 3)
+            t = np.concatenate([t, t[: max(1, n // 4)]])         # some triangles twice
+        else:                                                    # a fan around one vertex
+            n = int(rng.integers(3, 40))
+            ang = np.linspace(0, 2 * np.pi, n, endpoint=False, dtype=np.float32)
+            v = np.concatenate([rng.random((1, 3), dtype=np.float32), np.stack([np.cos(ang), np.sin(ang), 0.2 * rng.random(n, dtype=np.float32)], -1) * 0.7 + 0.7]).astype(np.float32)
+            t = np.stack([np.zeros(n, np.int64), 1 + np.arange(n), 1 + (np.arange(n) + 1) % n], -1)
+        t = t.astype(np.uint32)
+        if rng.random() < 0.2: t[int(rng.integers(0, t.shape[0]))][int(rng.integers(0, 3))] = 10**6     # an index out of range: the triangle is skipped
+        meshes.append((v.astype(np.float32), t))
+    return meshes
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flags", [0, 4])
+def test_fuzz_small_scenes(api, dev, flags):
+    """250 random small scenes (shared-vertex patches, soups, slivers, duplicates, fans, invalid indices) x the three build qualities, fast and robust:
+    closest hit and occlusion against the C restatement of the reference (bit-exact ids, ties classified, t / u / v / Ng to 1e-4) -- the oracle does
+    not depend on the tree, so every builder path (Morton, binned SAH with its median fallbacks, spatial splits) has to give the reference's answers."""
+    from oracle import restate as R
+    assert R.available()
+    rng = np.random.default_rng(20260922 + flags)
+    for it in range(250):
+        meshes = _random_scene(rng)
+        o = R.OracleScene(robust=bool(flags))
+        orob = o if flags else R.OracleScene(robust=True)        # fast mode: the reference's own fast node test may lose a hit on thin geometry; its robust mode arbitrates
+        for v, t in meshes:
+            o.add_mesh(v, t, 1)
+            if orob is not o: orob.add_mesh(v, t, 1)
+        o.commit()
+        if orob is not o: orob.commit()
+        lo = np.min([v.min(0) for v, _ in meshes], 0); hi = np.max([v.max(0) for v, _ in meshes], 0)
+        n = 3000
+        org = (rng.random((n, 3), dtype=np.float32) * 1.6 - 0.3) * (hi - lo + 0.1) + lo
+        tgt = rng.random((n, 3), dtype=np.float32) * (hi - lo) + lo
+        rays = make_rayhits(org, tgt - org)
+        rays["tnear"][::7] = 0.25; rays["tfar"][::5] = 0.9
+        want = rays.copy(); o.intersect1(want)
+        wrob = want
+        if orob is not o: wrob = rays.copy(); orob.intersect1(wrob)
+        wr = rays_of(rays); o.occluded1(wr)
+        for q in (None, api.RTC_BUILD_QUALITY_LOW, api.RTC_BUILD_QUALITY_HIGH):
+            s = api.make_scene(dev, meshes, flags=flags, quality=q)
+            got = rays.copy(); s.intersect1M(got)
+            if flags: compare_closest(got, want, rays, o.triangle_t, max_tie_frac=0.2, label=f"fuzz{it} q={q} robust")
+            else: compare_closest_arbitrated(got, want, wrob, rays, o.triangle_t, max_tie_frac=0.2, max_ref_miss_frac=0.02, label=f"fuzz{it} q={q} fast")
+            gr = rays_of(rays); s.occluded1M(gr)
+            compare_occluded(gr["tfar"], wr["tfar"], rays_of(rays)["tfar"], max_flip_frac=0.02, label=f"fuzz{it} q={q}")
+            s.release()
