@@ -10,8 +10,12 @@ meshes = W.synthetic_powerplant() if os.environ.get("PP") else W.synthetic_crown
 s = api.Scene(dev, 0, q)
 for v, t in meshes:
     s.add_triangle_mesh(v, t, device_resident=True)
-ms = []
+import time
+ms = []; wall = []; ls = []
 for i in range(reps):
-    s.touch(); s.commit(); ms.append(s.info()["build_ms"])
+    s.touch(); t0 = time.perf_counter(); s.commit(); wall.append((time.perf_counter() - t0) * 1e3)
+    ii = s.info(); ms.append(ii["build_ms"]); ls.append("%d/%d" % (ii["num_launches"], ii["num_host_syncs"]))
+    if os.environ.get("SLEEP"): time.sleep(float(os.environ["SLEEP"]))
+print("WALL", " ".join("%.2f" % w for w in wall), "| launches/syncs", " ".join(ls))
 i = s.info()
 print("BUILD cfg=%r q=%s: %s ms | nodes %d sah %.2f launches %d syncs %d" % (cfg, q, " ".join("%.2f" % m for m in ms), i["num_nodes"], i["sah"], i["num_launches"], i["num_host_syncs"]))
