@@ -45,7 +45,6 @@ struct Device : RefCounted {
   int gpu = 0;
   int verbose = 0;
   bool benchmark = false;
-  unsigned pipelineStreams = 4;                            // config key host_pipeline_streams (2..4)
   unsigned pipelineMin = 262144, pipelineChunk = 65536;   // host-array queries of at least pipelineMin rays are cut into chunks of pipelineChunk rays (config keys host_pipeline_min / host_pipeline_chunk)
   mi355_build_params build;
   RTCErrorFunction errorFn = nullptr; void* errorFnPtr = nullptr;
@@ -203,7 +202,8 @@ struct Scene : RefCounted {
   RTCProgressMonitorFunction progress = nullptr; void* progressPtr = nullptr;
   // host-pointer query staging (device memory), one per calling thread
   static constexpr int PIPE = 4;
-  hipStream_t pipe[PIPE] = {nullptr, nullptr, nullptr, nullptr};   // large host-array queries: streams that take the chunks in turn (pipelined_query)
+  hipStream_t pipe[PIPE] = {nullptr, nullptr, nullptr, nullptr};   // large host-array queries: upload, download, two compute streams (pipelined_query)
+  std::vector<hipEvent_t> pipeEvents;                       // ... and two events per chunk
   struct Staging { char* d = nullptr; size_t cap = 0; };
   std::map<size_t, Staging> staging;
   Scene(Device* d) : device(d) { d->retain(); setEmptyBounds(); }
@@ -218,6 +218,7 @@ struct Scene : RefCounted {
     if (flat) { mi355_bvh_destroy(flat); device->memoryMonitor(-flatBytes, true); }
     for (auto& kv : staging) if (kv.second.d) hipFree(kv.second.d);
     for (int k = 0; k < PIPE; k++) if (pipe[k]) hipStreamDestroy(pipe[k]);
+    for (hipEvent_t e : pipeEvents) hipEventDestroy(e);
     device->release();
   }
   char* stage(size_t bytes) {
@@ -368,7 +369,6 @@ void parse_config(Device* d, const char* cfg) {
     else if (k == "quality") d->build.quality = (v == "low" || v == "1") ? 1u : (v == "high" || v == "2") ? 2u : 0u;
     else if (k == "presplits") d->build.presplits = atoi(v.c_str()) != 0 ? 1u : 0u;                    // state.cpp:443
     else if (k == "max_spatial_split_replications") d->build.split_factor = (float)atof(v.c_str());   // state.cpp:437
-    else if (k == "host_pipeline_streams") d->pipelineStreams = (unsigned)atol(v.c_str());
     else if (k == "host_pipeline_min") d->pipelineMin = (unsigned)atol(v.c_str());
     else if (k == "host_pipeline_chunk") d->pipelineChunk = atol(v.c_str()) >= 1024 ? (unsigned)atol(v.c_str()) : 1024u;
     else if (k == "int_cost") d->build.int_cost = (float)atof(v.c_str());
@@ -393,31 +393,35 @@ static void check_trace_status(mi355_bvh_t b, hipStream_t q) {
   if (flags & MI355_TRACE_STACK_OVERFLOW) THROW(RTC_ERROR_UNKNOWN, "traversal stack overflow: results are incomplete");
 }
 
-// Large host arrays: the caller's array is pinned for the duration of the call and cut into chunks that go round a few streams, so that the upload of one
-// chunk, the traversal of another and the download of a third overlap.  A chunk is three stages in ITS stream (H2D, kernel, D2H), so two streams keep at
-// most two of the three resources busy: 4.0-4.15 ms per 2^20 rays, about the two copy directions one after the other (1.77 ms each at 54 GB/s); four
-// streams and chunks of 2^16 rays: 3.3 ms (tests/gpu_e2e.py; 2^17: 3.8, 2^15: 3.7, 2^18: 4.3; both directions at once would allow ~2.1, tests/gpu_pcie.py).
+// Large host arrays: the caller's array is pinned for the duration of the call and cut into chunks; ONE stream uploads them one after the other, ONE
+// downloads them, the traversal of chunk k runs on one of two compute streams between "chunk k is up" and "chunk k may go down" (an event each).  Both
+// directions of the link are busy all the time that way (tests/gpu_pcie.py: upload + download streams alone 2.4 ms for 96 MB each way; chunks that go round
+// k streams, each doing its own H2D - kernel - D2H: 3.3 ms and up, the copy engines then serve one direction at a time for long stretches).
 // Returns false when the array cannot be pinned (the plain path takes over).
 static bool pipelined_query(Scene* s, mi355_bvh_t b, char* data, char* d, unsigned M, size_t stride, bool any, size_t bytes) {
   if (hipHostRegister(data, bytes, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); return false; }
   struct Unpin { void* p; ~Unpin() { hipHostUnregister(p); } } unpin{data};
-  const int ns = (int)(s->device->pipelineStreams < 2u ? 2u : (s->device->pipelineStreams > (unsigned)Scene::PIPE ? (unsigned)Scene::PIPE : s->device->pipelineStreams));
-  hipStream_t st[Scene::PIPE];
-  { std::lock_guard<std::mutex> lk(s->mtx);
-    for (int k = 0; k < ns; k++) { if (!s->pipe[k]) hip_check(hipStreamCreateWithFlags(&s->pipe[k], hipStreamNonBlocking), "hipStreamCreate"); st[k] = s->pipe[k]; } }
   const size_t rec = any ? 48 : 96;
-  const unsigned chunk = s->device->pipelineChunk;
+  const unsigned chunk = s->device->pipelineChunk, nchunks = (M + chunk - 1u) / chunk;
+  hipStream_t up, down, comp[2];
+  std::vector<hipEvent_t> ev;
+  { std::lock_guard<std::mutex> lk(s->mtx);
+    for (int k = 0; k < Scene::PIPE; k++) if (!s->pipe[k]) hip_check(hipStreamCreateWithFlags(&s->pipe[k], hipStreamNonBlocking), "hipStreamCreate");
+    while (s->pipeEvents.size() < 2u * (size_t)nchunks) { hipEvent_t e; hip_check(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate"); s->pipeEvents.push_back(e); }
+    up = s->pipe[0]; down = s->pipe[1]; comp[0] = s->pipe[2]; comp[1] = s->pipe[3]; ev = s->pipeEvents; }
   unsigned c = 0;
   for (unsigned first = 0; first < M; first += chunk, c++) {
     const unsigned n = M - first < chunk ? M - first : chunk;
     const size_t ofs = (size_t)first * stride, nb = (size_t)(n - 1) * stride + rec;
-    hipStream_t q = st[c % (unsigned)ns];
-    hip_check(hipMemcpyAsync(d + ofs, data + ofs, nb, hipMemcpyHostToDevice, q), "hipMemcpyAsync(rays H2D)");
+    hipStream_t q = comp[c & 1u];
+    hip_check(hipMemcpyAsync(d + ofs, data + ofs, nb, hipMemcpyHostToDevice, up), "hipMemcpyAsync(rays H2D)");
+    hip_check(hipEventRecord(ev[2u * c], up), "hipEventRecord"); hip_check(hipStreamWaitEvent(q, ev[2u * c], 0), "hipStreamWaitEvent");
     core_check(any ? mi355_trace_any(b, d + ofs, n, stride, q) : mi355_trace_closest(b, d + ofs, n, stride, q), "trace");
-    hip_check(hipMemcpyAsync(data + ofs, d + ofs, nb, hipMemcpyDeviceToHost, q), "hipMemcpyAsync(rays D2H)");
+    hip_check(hipEventRecord(ev[2u * c + 1u], q), "hipEventRecord"); hip_check(hipStreamWaitEvent(down, ev[2u * c + 1u], 0), "hipStreamWaitEvent");
+    hip_check(hipMemcpyAsync(data + ofs, d + ofs, nb, hipMemcpyDeviceToHost, down), "hipMemcpyAsync(rays D2H)");
   }
-  for (int k = 0; k < ns; k++) hip_check(hipStreamSynchronize(st[k]), "hipStreamSynchronize");
-  for (int k = 0; k < ns && (unsigned)k < c; k++) check_trace_status(b, st[k]);
+  hip_check(hipStreamSynchronize(down), "hipStreamSynchronize");   // (everything else was waited for by the downloads)
+  check_trace_status(b, comp[0]); if (c > 1) check_trace_status(b, comp[1]);
   return true;
 }
 

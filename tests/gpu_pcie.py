@@ -28,3 +28,36 @@ for trial in range(2):
     def h2d2d(): hip.hipMemcpy2DAsync(d, 96, p, 96, 48, N, 1, s1); hip.hipStreamSynchronize(s1)
     print("pinned H2D 96 MB %.2f ms | D2H 96 MB %.2f ms | 48 MB each way at once %.2f ms | 2D D2H 64 of 96 B %.2f ms | 2D H2D 48 of 96 B %.2f ms" % (t(h2d), t(d2h), t(both), t(d2h2d), t(h2d2d)))
     hip.hipHostUnregister(p)
+# ---- the pipeline's copy pattern without kernels: chunks go round k streams, each chunk H2D then D2H in its stream
+a = np.zeros(B, np.uint8); a[:] = 1; p = a.ctypes.data
+assert hip.hipHostRegister(p, B, 0) == 0
+streams = []
+for _ in range(8):
+    s_ = vp(); hip.hipStreamCreate(C.byref(s_)); streams.append(s_)
+for k, chunk in ((2, 1 << 17), (4, 1 << 17), (4, 1 << 16), (8, 1 << 16), (4, 1 << 18), (1, 1 << 20)):
+    def pipe():
+        c = 0
+        for first in range(0, N, chunk):
+            q = streams[c % k]; o = first * 96; nb = chunk * 96
+            hip.hipMemcpyAsync(vp(d.value + o), vp(p + o), nb, 1, q)
+            hip.hipMemcpyAsync(vp(p + o), vp(d.value + o), nb, 2, q)
+            c += 1
+        for q in streams[:k]: hip.hipStreamSynchronize(q)
+    print("copy pipeline: %d streams, chunks of %d rays: %.2f ms" % (k, chunk, t(pipe)))
+# ---- dedicated upload / download streams, an event per chunk (upload k+1 overlaps download k)
+hip.hipEventCreateWithFlags.argtypes = [C.POINTER(vp), C.c_uint]; hip.hipEventRecord.argtypes = [vp, vp]; hip.hipStreamWaitEvent.argtypes = [vp, vp, C.c_uint]
+evs = []
+for _ in range(64):
+    e = vp(); assert hip.hipEventCreateWithFlags(C.byref(e), 2) == 0; evs.append(e)      # hipEventDisableTiming
+up, down = streams[0], streams[1]
+for chunk in (1 << 16, 1 << 17, 1 << 18):
+    def pipe2():
+        c = 0
+        for first in range(0, N, chunk):
+            o = first * 96; nb = chunk * 96
+            hip.hipMemcpyAsync(vp(d.value + o), vp(p + o), nb, 1, up)
+            hip.hipEventRecord(evs[c], up); hip.hipStreamWaitEvent(down, evs[c], 0)
+            hip.hipMemcpyAsync(vp(p + o), vp(d.value + o), nb, 2, down)
+            c += 1
+        hip.hipStreamSynchronize(up); hip.hipStreamSynchronize(down)
+    print("upload stream + download stream, chunks of %d rays: %.2f ms" % (chunk, t(pipe2)))
