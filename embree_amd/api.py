@@ -35,7 +35,7 @@ rtcSetGeometryTimeStepCount rtcSetGeometryVertexAttributeCount rtcSetGeometryMas
 rtcSetGeometryInstancedScene rtcSetGeometryTransform rtcGetGeometryTransform rtcInterpolate rtcInterpolateN
 rtcSetGeometryBuffer rtcSetSharedGeometryBuffer rtcSetSharedGeometryBufferHostDevice rtcSetNewGeometryBuffer
 rtcGetGeometryBufferData rtcUpdateGeometryBuffer rtcSetGeometryUserData rtcGetGeometryUserData
-rtcSetGeometryIntersectFilterFunction rtcSetGeometryOccludedFilterFunction
+rtcSetGeometryIntersectFilterFunction rtcSetGeometryOccludedFilterFunction rtcSetGeometryEnableFilterFunctionFromArguments
 rtcNewScene rtcGetSceneDevice rtcRetainScene rtcReleaseScene rtcGetSceneTraversable rtcAttachGeometry
 rtcAttachGeometryByID rtcDetachGeometry rtcGetGeometry rtcGetGeometryThreadSafe rtcCommitScene rtcJoinCommitScene
 rtcSetSceneProgressMonitorFunction rtcSetSceneBuildQuality rtcSetSceneFlags rtcGetSceneFlags rtcGetSceneBounds
@@ -49,6 +49,25 @@ mi355_trace_closest_packet mi355_trace_any_packet mi355_trace_stats mi355_trace_
 mi355_memcpy_d2h mi355_synchronize mi355_device_synchronize mi355_memcpy_d2d_async mi355_stream_create
 mi355_stream_destroy mi355_event_create mi355_event_record mi355_event_elapsed_ms mi355_event_destroy
 mi355_comm_unique_id mi355_comm_init mi355_comm_destroy mi355_comm_allgather mi355_comm_gather mi355_pack_hits mi355_pack_occluded mi355_stream_query""".split()
+
+
+class FilterArguments(C.Structure):            # RTCFilterFunctionNArguments
+    _fields_ = [("valid", C.POINTER(C.c_int)), ("geometryUserPtr", C.c_void_p), ("context", C.c_void_p), ("ray", C.POINTER(C.c_float)),
+                ("hit", C.POINTER(C.c_float)), ("N", C.c_uint)]
+
+
+FILTER_FN = C.CFUNCTYPE(None, C.POINTER(FilterArguments))
+RTC_RAY_QUERY_FLAG_INVOKE_ARGUMENT_FILTER = 2
+
+
+class QueryArguments(C.Structure):             # RTCIntersectArguments / RTCOccludedArguments (same layout)
+    _fields_ = [("flags", C.c_int), ("feature_mask", C.c_int), ("context", C.c_void_p), ("filter", C.c_void_p), ("callback", C.c_void_p)]
+
+    def __init__(self, filter_fn=None, flags=0):
+        super().__init__()
+        self.flags, self.feature_mask, self.context, self.callback = flags, -1, None, None
+        self._fn = filter_fn
+        self.filter = C.cast(filter_fn, C.c_void_p) if filter_fn else None
 
 
 class BuildParams(C.Structure):
@@ -165,6 +184,9 @@ def load():
     for k in (4, 8, 16):
         getattr(L, "rtcIntersect%d" % k).argtypes = [vp, vp, vp, vp]
         getattr(L, "rtcOccluded%d" % k).argtypes = [vp, vp, vp, vp]
+    for fn in (L.rtcSetGeometryIntersectFilterFunction, L.rtcSetGeometryOccludedFilterFunction):
+        fn.argtypes = [vp, vp]
+    L.rtcSetGeometryEnableFilterFunctionFromArguments.argtypes = [vp, C.c_bool]
     L.rtcIntersect1M.argtypes = [vp, vp, u32, sz, vp]
     L.rtcOccluded1M.argtypes = [vp, vp, u32, sz, vp]
     L.rtcIntersect1MDevice.argtypes = [vp, vp, u32, sz, vp, vp]
@@ -439,14 +461,25 @@ class Scene:
         self.L.rtcOccluded1(self.h, ray_record.ctypes.data, None)
         self.dev.check()
 
-    def intersect1M(self, rayhits):
+    def intersect1M(self, rayhits, args=None):
+        """args: a QueryArguments (flags, filter) or None"""
         assert rayhits.dtype == RAYHIT_DTYPE and rayhits.flags["C_CONTIGUOUS"]
-        self.L.rtcIntersect1M(self.h, rayhits.ctypes.data, rayhits.shape[0], 96, None)
+        self.L.rtcIntersect1M(self.h, rayhits.ctypes.data, rayhits.shape[0], 96, C.addressof(args) if args is not None else None)
         self.dev.check()
 
-    def occluded1M(self, rays):
+    def occluded1M(self, rays, args=None):
         assert rays.dtype == RAY_DTYPE and rays.flags["C_CONTIGUOUS"]
-        self.L.rtcOccluded1M(self.h, rays.ctypes.data, rays.shape[0], 48, None)
+        self.L.rtcOccluded1M(self.h, rays.ctypes.data, rays.shape[0], 48, C.addressof(args) if args is not None else None)
+        self.dev.check()
+
+    # -- filter callbacks (host functions: the host-array entry points run them between launches) --
+    def set_filters(self, gid, intersect=None, occluded=None, from_arguments=False):
+        """intersect / occluded: FILTER_FN instances (keep them alive) or None"""
+        g = self.L.rtcGetGeometry(self.h, gid)
+        self._keep += [intersect, occluded]
+        self.L.rtcSetGeometryIntersectFilterFunction(g, C.cast(intersect, C.c_void_p) if intersect else None)
+        self.L.rtcSetGeometryOccludedFilterFunction(g, C.cast(occluded, C.c_void_p) if occluded else None)
+        self.L.rtcSetGeometryEnableFilterFunctionFromArguments(g, bool(from_arguments))
         self.dev.check()
 
     # -- queries on device memory --

@@ -144,6 +144,8 @@ struct Geometry : RefCounted {
   float l2w[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0};
   unsigned topoCounter = 0, dataCounter = 0;                // bumped when buffers are (re)bound / the index data changes; when vertex data or the mask changes
   void* userPtr = nullptr;
+  RTCFilterFunctionN intersectFilter = nullptr, occludedFilter = nullptr;   // host callbacks: run between launches by the host-array entry points (filtered_query)
+  bool argFilter = false;                                   // rtcSetGeometryEnableFilterFunctionFromArguments
   std::atomic<int> attached{0};
   Geometry(Device* d, RTCGeometryType t) : device(d), type(t) { d->retain(); }
   ~Geometry() override;
@@ -377,8 +379,12 @@ void parse_config(Device* d, const char* cfg) {
   }
 }
 
-void check_query_args(const RTCFilterFunctionN filter, const void* callback) {
-  if (filter || callback) THROW(RTC_ERROR_INVALID_OPERATION, "filter / user-geometry callbacks cannot run on the GPU path");
+static std::atomic<bool> g_anyFilterEver{false};            // some geometry was given a filter callback at some point: host queries then look at their scene's geometries
+// user-geometry callbacks cannot exist here (no user geometries); filter callbacks are HOST functions: the host-array entry points run them between
+// launches (filtered_query), the device-pointer entry points cannot
+void check_query_args(const RTCFilterFunctionN filter, const void* callback, bool hostEntry = false) {
+  if (callback) THROW(RTC_ERROR_INVALID_OPERATION, "user-geometry callbacks are not supported (no user geometries on the GPU path)");
+  if (filter && !hostEntry) THROW(RTC_ERROR_INVALID_OPERATION, "a filter callback is a host function: use the host-array entry points (rtcIntersect1/4/8/16/1M), not the device-pointer ones");
 }
 mi355_bvh_t committed_bvh(Scene* s) {
   if (!s->committed || !s->bvh) THROW(RTC_ERROR_INVALID_OPERATION, "scene not committed");   // missing_rtcCommit, scene.cpp:66
@@ -434,15 +440,74 @@ static size_t format_bytes(RTCFormat fmt) {
 }
 static size_t view_bytes(RTCFormat fmt, size_t stride, size_t n) { return n ? (n - 1) * stride + format_bytes(fmt) : 0; }
 
+// ---- filter callbacks (rtcSetGeometryIntersectFilterFunction / OccludedFilterFunction, RTCIntersectArguments::filter).  The reference calls them inside the
+// traversal for every potential hit (runIntersectionFilter1 / runOcclusionFilter1, kernels/geometry/filter.h:14-80; Intersect1EpilogM, intersector_epilog.h:
+// 235-300) and goes on when one says no.  A host function cannot run in a HIP kernel, so here the traversal finds the CLOSEST candidate, the host asks the
+// callbacks (geometry filter first, then the argument filter if the geometry enabled it or RTC_RAY_QUERY_FLAG_INVOKE_ARGUMENT_FILTER is set; N = 1, ray.tfar =
+// the candidate's distance while they run), and a ray whose candidate was rejected is traced again from just behind it.  The closest ACCEPTED hit -- what
+// the reference returns -- comes out the same; differences: a callback sees candidates in distance order and only the closest ones (the reference: in
+// traversal order, possibly farther ones first), a second triangle at exactly a rejected distance is skipped with it, and occlusion queries with filters
+// cost a closest-hit search per round.  Instanced scenes are not covered (the hit's geometry lives in another scene object).
+static bool scene_has_filters(Scene* s, const RTCFilterFunctionN argFilter, unsigned flags, bool any) {
+  for (auto& kv : s->geoms) {
+    Geometry* g = kv.second;
+    if (any ? g->occludedFilter != nullptr : g->intersectFilter != nullptr) return true;
+    if (argFilter && (g->argFilter || (flags & RTC_RAY_QUERY_FLAG_INVOKE_ARGUMENT_FILTER))) return true;
+  }
+  return false;
+}
+static void plain_query(Scene* s, void* data, unsigned M, size_t stride, bool any);
+static void filtered_query(Scene* s, void* data, unsigned M, size_t stride, bool any, RTCFilterFunctionN argFilter, unsigned qflags, RTCRayQueryContext* uctx) {
+  for (auto& kv : s->geoms) if (kv.second->type == RTC_GEOMETRY_TYPE_INSTANCE && kv.second->enabled) THROW(RTC_ERROR_INVALID_OPERATION, "filter callbacks are not supported in scenes with instances");
+  RTCRayQueryContext defctx; rtcInitRayQueryContext(&defctx);
+  RTCRayQueryContext* ctx = uctx ? uctx : &defctx;
+  std::vector<RTCRayHit> work(M);                            // the rays still searching, as closest-hit records
+  std::vector<unsigned> who(M);                              // ... and whose they are
+  for (unsigned i = 0; i < M; i++) {
+    const char* src = (const char*)data + (size_t)i * stride;
+    memcpy(&work[i].ray, src, sizeof(RTCRay)); memset(&work[i].hit, 0, sizeof(RTCHit));
+    work[i].hit.geomID = RTC_INVALID_GEOMETRY_ID; work[i].hit.primID = RTC_INVALID_GEOMETRY_ID; work[i].hit.instID[0] = RTC_INVALID_GEOMETRY_ID;
+    who[i] = i;
+  }
+  unsigned n = M;
+  for (unsigned round = 0; n != 0u; round++) {
+    if (round >= 4096u) THROW(RTC_ERROR_UNKNOWN, "filter callbacks rejected 4096 candidates in a row along one ray");
+    plain_query(s, work.data(), n, sizeof(RTCRayHit), false);
+    unsigned m = 0;
+    for (unsigned k = 0; k < n; k++) {
+      RTCRayHit& w = work[k];
+      if (w.hit.geomID == RTC_INVALID_GEOMETRY_ID) continue;  // nothing (left) on this ray: the caller's record stays as it is
+      char* dst = (char*)data + (size_t)who[k] * stride;
+      auto it = s->geoms.find(w.hit.geomID);
+      Geometry* g = it == s->geoms.end() ? nullptr : it->second;
+      int valid = -1;
+      RTCRayHit cand = w;                                     // the callbacks may change the hit and shorten tfar
+      RTCFilterFunctionNArguments fa; fa.valid = &valid; fa.geometryUserPtr = g ? g->userPtr : nullptr; fa.context = ctx;
+      fa.ray = (RTCRayN*)&cand.ray; fa.hit = (RTCHitN*)&cand.hit; fa.N = 1;
+      const RTCFilterFunctionN gf = g ? (any ? g->occludedFilter : g->intersectFilter) : nullptr;
+      if (gf) gf(&fa);
+      if (valid != 0 && argFilter && g && (g->argFilter || (qflags & RTC_RAY_QUERY_FLAG_INVOKE_ARGUMENT_FILTER))) argFilter(&fa);
+      if (valid != 0) {                                       // accepted
+        if (any) ((RTCRay*)dst)->tfar = -INFINITY;
+        else { ((RTCRayHit*)dst)->ray.tfar = cand.ray.tfar; ((RTCRayHit*)dst)->hit = cand.hit; }
+        continue;
+      }
+      // rejected: search on behind it, up to the ray's own tfar
+      const float t = w.ray.tfar;
+      RTCRayHit nx; memcpy(&nx.ray, (const char*)data + (size_t)who[k] * stride, sizeof(RTCRay));
+      nx.ray.tnear = t > nx.ray.tnear ? t : nextafterf(nx.ray.tnear, INFINITY);    // the triangle test is strict at tnear: the rejected hit is out
+      if (w.ray.tnear >= nx.ray.tnear) nx.ray.tnear = nextafterf(w.ray.tnear, INFINITY);
+      memset(&nx.hit, 0, sizeof(RTCHit)); nx.hit.geomID = RTC_INVALID_GEOMETRY_ID; nx.hit.primID = RTC_INVALID_GEOMETRY_ID; nx.hit.instID[0] = RTC_INVALID_GEOMETRY_ID;
+      work[m] = nx; who[m] = who[k]; m++;
+    }
+    n = m;
+  }
+}
+
 // host-pointer AoS query: upload, trace, download the mutable parts
-void host_query(Scene* s, void* data, unsigned M, size_t stride, bool any) {
-  if (M == 0) return;
+static void plain_query(Scene* s, void* data, unsigned M, size_t stride, bool any) {
   mi355_bvh_t b = committed_bvh(s);
   const size_t rec = any ? 48 : 96;
-  if (stride < rec) THROW(RTC_ERROR_INVALID_ARGUMENT, "byteStride smaller than the ray record");
-  hip_check(hipSetDevice(s->device->gpu), "hipSetDevice");
-  const bool repack = (stride & 15) || ((size_t)data & 15);
-  if (repack) THROW(RTC_ERROR_INVALID_ARGUMENT, "ray records must be 16-byte aligned (include/embree4/rtcore.h)");
   const size_t bytes = (size_t)(M - 1) * stride + rec;
   char* d = s->stage(bytes);
   if (M >= s->device->pipelineMin && pipelined_query(s, b, (char*)data, d, M, stride, any, bytes)) return;
@@ -451,9 +516,20 @@ void host_query(Scene* s, void* data, unsigned M, size_t stride, bool any) {
   hip_check(hipMemcpy(data, d, bytes, hipMemcpyDeviceToHost), "hipMemcpy(rays D2H)");
   check_trace_status(b, nullptr);
 }
+void host_query(Scene* s, void* data, unsigned M, size_t stride, bool any, RTCFilterFunctionN argFilter = nullptr, unsigned qflags = 0, RTCRayQueryContext* uctx = nullptr) {
+  if (M == 0) return;
+  committed_bvh(s);
+  const size_t rec = any ? 48 : 96;
+  if (stride < rec) THROW(RTC_ERROR_INVALID_ARGUMENT, "byteStride smaller than the ray record");
+  hip_check(hipSetDevice(s->device->gpu), "hipSetDevice");
+  const bool repack = (stride & 15) || ((size_t)data & 15);
+  if (repack) THROW(RTC_ERROR_INVALID_ARGUMENT, "ray records must be 16-byte aligned (include/embree4/rtcore.h)");
+  if ((g_anyFilterEver.load(std::memory_order_relaxed) || argFilter) && scene_has_filters(s, argFilter, qflags, any)) { filtered_query(s, data, M, stride, any, argFilter, qflags, uctx); return; }
+  plain_query(s, data, M, stride, any);
+}
 // rtcIntersect4/8/16, rtcOccluded4/8/16 on a host packet: the K lanes are turned into AoS records on the host (RayHitK::get / set, kernels/common/ray.h:283-376),
 // the active ones go through the batch path as one launch, and only active lanes are written back (InactiveRaysTest, verify.cpp:3553).
-void host_packet_query(Scene* s, const int* valid, void* packet, unsigned K, bool any) {
+void host_packet_query(Scene* s, const int* valid, void* packet, unsigned K, bool any, RTCFilterFunctionN argFilter = nullptr, unsigned qflags = 0, RTCRayQueryContext* uctx = nullptr) {
   if (!valid || !packet) THROW(RTC_ERROR_INVALID_ARGUMENT, "invalid argument");
   const unsigned nf = any ? 12u : 21u, recw = any ? 12u : 24u;
   alignas(16) uint32_t aos[16 * 24];
@@ -467,7 +543,7 @@ void host_packet_query(Scene* s, const int* valid, void* packet, unsigned K, boo
     lane[n++] = k;
   }
   if (n == 0) { committed_bvh(s); return; }
-  host_query(s, aos, n, recw * 4, any);
+  host_query(s, aos, n, recw * 4, any, argFilter, qflags, uctx);
   uint32_t* out = (uint32_t*)packet;
   for (unsigned j = 0; j < n; j++) {
     const uint32_t* r = aos + (size_t)j * recw; const unsigned k = lane[j];
@@ -694,12 +770,11 @@ RTC_API void rtcGetGeometryTransform(RTCGeometry h, float, enum RTCFormat fmt, v
 }
 RTC_API void rtcSetGeometryUserData(RTCGeometry h, void* p) { CATCH_BEGIN geom_of(h)->userPtr = p; CATCH_END(GEOM_DEV(h)) }
 RTC_API void* rtcGetGeometryUserData(RTCGeometry h) { CATCH_BEGIN return geom_of(h)->userPtr; CATCH_END(GEOM_DEV(h)) return nullptr; }
-RTC_API void rtcSetGeometryIntersectFilterFunction(RTCGeometry h, RTCFilterFunctionN f) {
-  CATCH_BEGIN geom_of(h); if (f) THROW(RTC_ERROR_INVALID_OPERATION, "filter functions cannot run on the GPU path"); CATCH_END(GEOM_DEV(h))
-}
-RTC_API void rtcSetGeometryOccludedFilterFunction(RTCGeometry h, RTCFilterFunctionN f) {
-  CATCH_BEGIN geom_of(h); if (f) THROW(RTC_ERROR_INVALID_OPERATION, "filter functions cannot run on the GPU path"); CATCH_END(GEOM_DEV(h))
-}
+// Filter callbacks are host functions; the host-array entry points run them between launches (filtered_query above).  A geometry tells the scenes it is
+// attached to lazily: the flag below is looked at by every host query.
+RTC_API void rtcSetGeometryIntersectFilterFunction(RTCGeometry h, RTCFilterFunctionN f) { CATCH_BEGIN geom_of(h)->intersectFilter = f; if (f) g_anyFilterEver = true; CATCH_END(GEOM_DEV(h)) }
+RTC_API void rtcSetGeometryOccludedFilterFunction(RTCGeometry h, RTCFilterFunctionN f) { CATCH_BEGIN geom_of(h)->occludedFilter = f; if (f) g_anyFilterEver = true; CATCH_END(GEOM_DEV(h)) }
+RTC_API void rtcSetGeometryEnableFilterFunctionFromArguments(RTCGeometry h, bool enable) { CATCH_BEGIN geom_of(h)->argFilter = enable; CATCH_END(GEOM_DEV(h)) }
 
 // ============================================================================================= scene
 #define SCENE_DEV(h) ((h) ? ((Scene*)(h))->device : nullptr)
@@ -767,18 +842,18 @@ RTC_API void rtcGetSceneBounds(RTCScene h, struct RTCBounds* o) {
 
 // ============================================================================================ queries
 RTC_API void rtcIntersect1(RTCScene h, struct RTCRayHit* rh, struct RTCIntersectArguments* a) {
-  CATCH_BEGIN Scene* s = scene_of(h); if (a) check_query_args(a->filter, (const void*)a->intersect); host_query(s, rh, 1, sizeof(RTCRayHit), false); CATCH_END(SCENE_DEV(h))
+  CATCH_BEGIN Scene* s = scene_of(h); if (a) check_query_args(a->filter, (const void*)a->intersect, true); host_query(s, rh, 1, sizeof(RTCRayHit), false, a ? a->filter : nullptr, a ? (unsigned)a->flags : 0u, a ? a->context : nullptr); CATCH_END(SCENE_DEV(h))
 }
 RTC_API void rtcOccluded1(RTCScene h, struct RTCRay* r, struct RTCOccludedArguments* a) {
-  CATCH_BEGIN Scene* s = scene_of(h); if (a) check_query_args(a->filter, (const void*)a->occluded); host_query(s, r, 1, sizeof(RTCRay), true); CATCH_END(SCENE_DEV(h))
+  CATCH_BEGIN Scene* s = scene_of(h); if (a) check_query_args(a->filter, (const void*)a->occluded, true); host_query(s, r, 1, sizeof(RTCRay), true, a ? a->filter : nullptr, a ? (unsigned)a->flags : 0u, a ? a->context : nullptr); CATCH_END(SCENE_DEV(h))
 }
 #define PACKET_ENTRY(K)                                                                                                     \
   RTC_API void rtcIntersect##K(const int* valid, RTCScene h, struct RTCRayHit##K* rh, struct RTCIntersectArguments* a) {    \
-    CATCH_BEGIN Scene* s = scene_of(h); if (a) check_query_args(a->filter, (const void*)a->intersect);                      \
-    host_packet_query(s, valid, rh, K, false); CATCH_END(SCENE_DEV(h)) }                                                    \
+    CATCH_BEGIN Scene* s = scene_of(h); if (a) check_query_args(a->filter, (const void*)a->intersect, true);                \
+    host_packet_query(s, valid, rh, K, false, a ? a->filter : nullptr, a ? (unsigned)a->flags : 0u, a ? a->context : nullptr); CATCH_END(SCENE_DEV(h)) }                                                    \
   RTC_API void rtcOccluded##K(const int* valid, RTCScene h, struct RTCRay##K* r, struct RTCOccludedArguments* a) {          \
-    CATCH_BEGIN Scene* s = scene_of(h); if (a) check_query_args(a->filter, (const void*)a->occluded);                       \
-    host_packet_query(s, valid, r, K, true); CATCH_END(SCENE_DEV(h)) }                                                      \
+    CATCH_BEGIN Scene* s = scene_of(h); if (a) check_query_args(a->filter, (const void*)a->occluded, true);                 \
+    host_packet_query(s, valid, r, K, true, a ? a->filter : nullptr, a ? (unsigned)a->flags : 0u, a ? a->context : nullptr); CATCH_END(SCENE_DEV(h)) }                                                      \
   RTC_API void rtcTraversableIntersect##K(const int* valid, RTCTraversable t, struct RTCRayHit##K* rh, struct RTCIntersectArguments* a) { rtcIntersect##K(valid, (RTCScene)t, rh, a); } \
   RTC_API void rtcTraversableOccluded##K(const int* valid, RTCTraversable t, struct RTCRay##K* r, struct RTCOccludedArguments* a) { rtcOccluded##K(valid, (RTCScene)t, r, a); }
 PACKET_ENTRY(4)
@@ -788,10 +863,10 @@ RTC_API void rtcTraversableIntersect1(RTCTraversable t, struct RTCRayHit* rh, st
 RTC_API void rtcTraversableOccluded1(RTCTraversable t, struct RTCRay* r, struct RTCOccludedArguments* a) { rtcOccluded1((RTCScene)t, r, a); }
 
 RTC_API void rtcIntersect1M(RTCScene h, struct RTCRayHit* rh, unsigned M, size_t stride, struct RTCIntersectArguments* a) {
-  CATCH_BEGIN Scene* s = scene_of(h); if (a) check_query_args(a->filter, (const void*)a->intersect); host_query(s, rh, M, stride, false); CATCH_END(SCENE_DEV(h))
+  CATCH_BEGIN Scene* s = scene_of(h); if (a) check_query_args(a->filter, (const void*)a->intersect, true); host_query(s, rh, M, stride, false, a ? a->filter : nullptr, a ? (unsigned)a->flags : 0u, a ? a->context : nullptr); CATCH_END(SCENE_DEV(h))
 }
 RTC_API void rtcOccluded1M(RTCScene h, struct RTCRay* r, unsigned M, size_t stride, struct RTCOccludedArguments* a) {
-  CATCH_BEGIN Scene* s = scene_of(h); if (a) check_query_args(a->filter, (const void*)a->occluded); host_query(s, r, M, stride, true); CATCH_END(SCENE_DEV(h))
+  CATCH_BEGIN Scene* s = scene_of(h); if (a) check_query_args(a->filter, (const void*)a->occluded, true); host_query(s, r, M, stride, true, a ? a->filter : nullptr, a ? (unsigned)a->flags : 0u, a ? a->context : nullptr); CATCH_END(SCENE_DEV(h))
 }
 RTC_API void rtcIntersect1MDevice(RTCScene h, void* d_rh, unsigned M, size_t stride, struct RTCIntersectArguments* a, void* stream) {
   CATCH_BEGIN Scene* s = scene_of(h); if (a) check_query_args(a->filter, (const void*)a->intersect);
@@ -809,7 +884,6 @@ extern "C" __attribute__((visibility("default"))) mi355_bvh_t rtcGetSceneBVH_mi3
 #define UNSUPPORTED_GEOM(name, ...) RTC_API void name(RTCGeometry h, ##__VA_ARGS__) { process_error(GEOM_DEV(h), RTC_ERROR_INVALID_OPERATION, #name " is not supported by the MI355X triangle core"); }
 UNSUPPORTED_GEOM(rtcSetGeometryTimeRange, float, float)
 UNSUPPORTED_GEOM(rtcSetGeometryMaxRadiusScale, float)
-UNSUPPORTED_GEOM(rtcSetGeometryEnableFilterFunctionFromArguments, bool)
 UNSUPPORTED_GEOM(rtcSetGeometryPointQueryFunction, void*)
 UNSUPPORTED_GEOM(rtcSetGeometryUserPrimitiveCount, unsigned)
 UNSUPPORTED_GEOM(rtcSetGeometryBoundsFunction, void*, void*)

@@ -251,15 +251,36 @@ RTC_FORCEINLINE void rtcInitRayQueryContext(struct RTCRayQueryContext* c) {
   c->instID[0] = RTC_INVALID_GEOMETRY_ID; c->instPrimID[0] = RTC_INVALID_GEOMETRY_ID;
 }
 
-/* callbacks exist in the argument structs for layout compatibility only; a
-   host function cannot run inside a HIP kernel, so a non-NULL filter/intersect
-   makes the call record RTC_ERROR_INVALID_OPERATION. */
-struct RTCFilterFunctionNArguments;
+/* Filter callbacks [ref: rtcore_common.h:308-324, rtcore_ray.h:221-261, kernels/geometry/filter.h:14-80] are HOST functions.  The host-array entry points
+   (rtcIntersect1/4/8/16/1M, rtcOccluded...) run them between launches: the traversal finds the closest candidate, the callbacks (N = 1) accept or reject it,
+   a rejected ray is traced on from behind the candidate -- the closest ACCEPTED hit is what the reference returns too.  The device-pointer entry points
+   record RTC_ERROR_INVALID_OPERATION for a non-NULL filter; user-geometry callbacks (intersect / occluded) always do. */
+struct RTCRayN; struct RTCHitN;
+struct RTCFilterFunctionNArguments {
+  int* valid;
+  void* geometryUserPtr;
+  struct RTCRayQueryContext* context;
+  struct RTCRayN* ray;
+  struct RTCHitN* hit;
+  unsigned int N;
+};
 struct RTCIntersectFunctionNArguments;
 struct RTCOccludedFunctionNArguments;
 typedef void (*RTCFilterFunctionN)(const struct RTCFilterFunctionNArguments*);
 typedef void (*RTCIntersectFunctionN)(const struct RTCIntersectFunctionNArguments*);
 typedef void (*RTCOccludedFunctionN)(const struct RTCOccludedFunctionNArguments*);
+/* structure-of-arrays accessors of a ray / hit packet of size N, lane i (the reference's helpers of the same names) */
+#define RTC_RAYN_FIELD(name, type, k) RTC_FORCEINLINE type* RTCRayN_##name##_ptr(struct RTCRayN* r, unsigned int N, unsigned int i) { return (type*)r + (k) * N + i; } \
+  RTC_FORCEINLINE type RTCRayN_get_##name(const struct RTCRayN* r, unsigned int N, unsigned int i) { return ((const type*)r)[(k) * N + i]; }
+RTC_RAYN_FIELD(org_x, float, 0) RTC_RAYN_FIELD(org_y, float, 1) RTC_RAYN_FIELD(org_z, float, 2) RTC_RAYN_FIELD(tnear, float, 3)
+RTC_RAYN_FIELD(dir_x, float, 4) RTC_RAYN_FIELD(dir_y, float, 5) RTC_RAYN_FIELD(dir_z, float, 6) RTC_RAYN_FIELD(time, float, 7)
+RTC_RAYN_FIELD(tfar, float, 8) RTC_RAYN_FIELD(mask, unsigned int, 9) RTC_RAYN_FIELD(id, unsigned int, 10) RTC_RAYN_FIELD(flags, unsigned int, 11)
+#undef RTC_RAYN_FIELD
+#define RTC_HITN_FIELD(name, type, k) RTC_FORCEINLINE type* RTCHitN_##name##_ptr(struct RTCHitN* h, unsigned int N, unsigned int i) { return (type*)h + (k) * N + i; } \
+  RTC_FORCEINLINE type RTCHitN_get_##name(const struct RTCHitN* h, unsigned int N, unsigned int i) { return ((const type*)h)[(k) * N + i]; }
+RTC_HITN_FIELD(Ng_x, float, 0) RTC_HITN_FIELD(Ng_y, float, 1) RTC_HITN_FIELD(Ng_z, float, 2) RTC_HITN_FIELD(u, float, 3) RTC_HITN_FIELD(v, float, 4)
+RTC_HITN_FIELD(primID, unsigned int, 5) RTC_HITN_FIELD(geomID, unsigned int, 6) RTC_HITN_FIELD(instID0, unsigned int, 7)
+#undef RTC_HITN_FIELD
 
 /* [ref: rtcore_scene.h:34-58] */
 struct RTCIntersectArguments {
@@ -360,6 +381,7 @@ RTC_API void* rtcGetGeometryUserData(RTCGeometry geometry);
 /* recorded as RTC_ERROR_INVALID_OPERATION when the function is non-NULL */
 RTC_API void rtcSetGeometryIntersectFilterFunction(RTCGeometry geometry, RTCFilterFunctionN filter);
 RTC_API void rtcSetGeometryOccludedFilterFunction(RTCGeometry geometry, RTCFilterFunctionN filter);
+RTC_API void rtcSetGeometryEnableFilterFunctionFromArguments(RTCGeometry geometry, bool enable);
 
 /* -------------------------------------------------------------------- scene */
 /* [ref: rtcore_scene.h:89-150] */

@@ -254,6 +254,53 @@ __attribute__((visibility("default"))) double refd_packet(void* h, int K, int an
   return -1.0;
 }
 
+// ---- filter callbacks: two fixed rules, installed on the REAL library, so that the GPU path's host-side filter loop (rtcore_api.cpp: filtered_query) can be
+// compared with the reference's in-traversal filters (kernels/geometry/filter.h).  tests/test_gpu_round2.py installs the same rules through its own callbacks.
+//   geometry rule : reject a hit whose primID is a multiple of 3, or whose u is above 0.7
+//   argument rule : reject a hit with (primID + 2 * geomID) % 5 == 1
+static void refd_rule_geometry(const RTCFilterFunctionNArguments* a) {
+  for (unsigned i = 0; i < a->N; i++) {
+    if (a->valid[i] != -1) continue;
+    if (RTCHitN_primID(a->hit, a->N, i) % 3u == 0u || RTCHitN_u(a->hit, a->N, i) > 0.7f) a->valid[i] = 0;
+  }
+}
+static void refd_rule_argument(const RTCFilterFunctionNArguments* a) {
+  for (unsigned i = 0; i < a->N; i++) {
+    if (a->valid[i] != -1) continue;
+    if ((RTCHitN_primID(a->hit, a->N, i) + 2u * RTCHitN_geomID(a->hit, a->N, i)) % 5u == 1u) a->valid[i] = 0;
+  }
+}
+// mode bit 0: geometry rule as intersect filter, bit 1: as occluded filter, bit 2: the geometries accept the argument filter; on geometries 0 .. ngeom-1
+__attribute__((visibility("default"))) void refd_set_filters(void* h, unsigned ngeom, unsigned mode) {
+  RefScene* s = (RefScene*)h;
+  for (unsigned id = 0; id < ngeom; id++) {
+    RTCGeometry g = rtcGetGeometry(s->scene, id);
+    if (!g) continue;
+    rtcSetGeometryIntersectFilterFunction(g, (mode & 1u) ? refd_rule_geometry : nullptr);
+    rtcSetGeometryOccludedFilterFunction(g, (mode & 2u) ? refd_rule_geometry : nullptr);
+    rtcSetGeometryEnableFilterFunctionFromArguments(g, (mode & 4u) != 0u);
+    rtcCommitGeometry(g);
+  }
+  rtcCommitScene(s->scene);
+}
+// rtcIntersect1 / rtcOccluded1 with RTCIntersectArguments: argRule != 0 passes the argument rule as args.filter, flags as given (e.g. INVOKE_ARGUMENT_FILTER)
+__attribute__((visibility("default"))) double refd_intersect1_args(void* h, RTCRayHit* rh, unsigned M, int threads, int argRule, unsigned flags) {
+  RefScene* s = (RefScene*)h;
+  return run_blocks(M, threads, [&](unsigned lo, unsigned hi) {
+    RTCIntersectArguments a; rtcInitIntersectArguments(&a);
+    a.flags = (RTCRayQueryFlags)flags; a.filter = argRule ? refd_rule_argument : nullptr;
+    for (unsigned i = lo; i < hi; i++) rtcIntersect1(s->scene, &rh[i], &a);
+  });
+}
+__attribute__((visibility("default"))) double refd_occluded1_args(void* h, RTCRay* r, unsigned M, int threads, int argRule, unsigned flags) {
+  RefScene* s = (RefScene*)h;
+  return run_blocks(M, threads, [&](unsigned lo, unsigned hi) {
+    RTCOccludedArguments a; rtcInitOccludedArguments(&a);
+    a.flags = (RTCRayQueryFlags)flags; a.filter = argRule ? refd_rule_argument : nullptr;
+    for (unsigned i = lo; i < hi; i++) rtcOccluded1(s->scene, &r[i], &a);
+  });
+}
+
 __attribute__((visibility("default"))) void refd_free(void* h) {
   RefScene* s = (RefScene*)h;
   if (!s) return;

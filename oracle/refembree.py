@@ -47,6 +47,10 @@ def _load():
         L.refd_packet.restype = ctypes.c_double
         L.refd_packet.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_uint, ctypes.c_void_p, ctypes.c_int]
         L.refd_free.argtypes = [ctypes.c_void_p]
+        L.refd_set_filters.argtypes = [ctypes.c_void_p, ctypes.c_uint, ctypes.c_uint]
+        for f in (L.refd_intersect1_args, L.refd_occluded1_args):
+            f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint, ctypes.c_int, ctypes.c_int, ctypes.c_uint]
+            f.restype = ctypes.c_double
         L.refd_hw_threads.restype = ctypes.c_uint
         _lib = L
     return _lib
@@ -123,6 +127,16 @@ class RefScene:
 
     def occluded1(self, rays, threads=1):
         return self._run("refd_occluded1", rays, threads)
+
+    def set_filters(self, ngeom, mode):
+        """the fixed filter rules of ref_driver.cpp on geometries 0..ngeom-1: bit 0 intersect filter, bit 1 occluded filter, bit 2 accept the argument filter"""
+        _load().refd_set_filters(self._h, ngeom, mode)
+
+    def intersect1_args(self, rayhits, arg_rule=False, flags=0, threads=1):
+        return _load().refd_intersect1_args(self._h, rayhits.ctypes.data, rayhits.shape[0], threads, 1 if arg_rule else 0, flags)
+
+    def occluded1_args(self, rays, arg_rule=False, flags=0, threads=1):
+        return _load().refd_occluded1_args(self._h, rays.ctypes.data, rays.shape[0], threads, 1 if arg_rule else 0, flags)
 
     def error(self):
         return _load().refd_error(self._h)

@@ -500,3 +500,84 @@ def test_fuzz_small_scenes(api, dev, flags):
             gr = rays_of(rays); s.occluded1M(gr)
             compare_occluded(gr["tfar"], wr["tfar"], rays_of(rays)["tfar"], max_flip_frac=0.02, label=f"fuzz{it} q={q}")
             s.release()
+
+
+# ------------------------------------------------------------------------------------------- filter callbacks (host functions, run between launches)
+@pytest.mark.gpu
+@pytest.mark.parametrize("flags", [0, 4])
+def test_filter_callbacks_vs_reference(api, dev, ref, flags):
+    """rtcSetGeometryIntersectFilterFunction / OccludedFilterFunction, RTCIntersectArguments::filter with rtcSetGeometryEnableFilterFunctionFromArguments or
+    RTC_RAY_QUERY_FLAG_INVOKE_ARGUMENT_FILTER (IntersectionFilterTest, tutorials/verify/verify.cpp; kernels/geometry/filter.h:14-80).  The same two rules are
+    installed in the REAL reference (oracle/ref_driver.cpp: in-traversal callbacks) and here (host callbacks between launches, rtcore_api.cpp filtered_query):
+    the closest ACCEPTED hit and the occlusion answer must be the reference's; rays none of whose hits is accepted stay untouched; the single-ray
+    entry point goes through the same loop; the device-pointer entry point refuses a filter."""
+    from tests.test_gpu_reference_suite import _sticks
+    meshes = [_sticks(400, 3), W.triangle_sphere(np.array([0.5, 0.5, 0.5], np.float32), 0.3, 40, noise=0.1, seed=5),
+              W.triangle_sphere(np.array([0.5, 0.5, 0.5], np.float32), 0.55, 30, noise=0.05, seed=6)]
+    rng = np.random.default_rng(77)
+    n = 12000
+    org = rng.random((n, 3), dtype=np.float32) * 1.8 - 0.4
+    tgt = rng.random((n, 3), dtype=np.float32)
+    rays = make_rayhits(org, (tgt - org) * np.float32(2.0))
+
+    calls = {"geom": 0, "arg": 0}
+    def rule_geometry(a):
+        a = a.contents; calls["geom"] += 1
+        for i in range(a.N):
+            if a.valid[i] != -1: continue
+            prim = C.cast(a.hit, C.POINTER(C.c_uint32))[5 * a.N + i]; u = a.hit[3 * a.N + i]
+            if prim % 3 == 0 or u > 0.7: a.valid[i] = 0
+    def rule_argument(a):
+        a = a.contents; calls["arg"] += 1
+        for i in range(a.N):
+            if a.valid[i] != -1: continue
+            hp = C.cast(a.hit, C.POINTER(C.c_uint32))
+            if (hp[5 * a.N + i] + 2 * hp[6 * a.N + i]) % 5 == 1: a.valid[i] = 0
+    f_geom, f_arg = api.FILTER_FN(rule_geometry), api.FILTER_FN(rule_argument)
+
+    r = ref.RefScene(flags=flags)
+    for v, t in meshes: r.add_mesh(v, t)
+    r.commit()
+    s = api.make_scene(dev, meshes, flags=flags)
+    plain = rays.copy(); s.intersect1M(plain)
+    for mode, use_arg, qflags in ((1, False, 0), (1 | 4, True, 0), (0, True, api.RTC_RAY_QUERY_FLAG_INVOKE_ARGUMENT_FILTER), (0, True, 0)):
+        r.set_filters(len(meshes), mode)
+        for g in range(len(meshes)): s.set_filters(g, intersect=f_geom if mode & 1 else None, occluded=None, from_arguments=bool(mode & 4))
+        want = rays.copy(); r.intersect1_args(want, arg_rule=use_arg, flags=qflags)
+        got = rays.copy(); s.intersect1M(got, api.QueryArguments(f_arg if use_arg else None, qflags))
+        # exact ties aside, ids and distances are the reference's; a rejected-everywhere ray is untouched (compare_closest checks misses byte for byte)
+        def tri_t(rr, geom, prim):
+            out = np.zeros(rr.shape[0], np.float32)
+            for k in range(rr.shape[0]):
+                v, t = meshes[int(geom[k])]; a, b, c = v[t[int(prim[k])]].astype(np.float64)
+                o = np.array([rr["org_x"][k], rr["org_y"][k], rr["org_z"][k]], np.float64); d = np.array([rr["dir_x"][k], rr["dir_y"][k], rr["dir_z"][k]], np.float64)
+                nrm = np.cross(b - a, c - a); out[k] = np.dot(nrm, a - o) / np.dot(nrm, d)
+            return out
+        st = compare_closest(got, want, rays, tri_t, max_tie_frac=2e-3, label=f"filter mode={mode} arg={use_arg} qflags={qflags}")
+        changed = int(((got["primID"] != plain["primID"]) | (got["geomID"] != plain["geomID"])).sum())
+        if mode or (use_arg and qflags): assert changed > 1000, "the filters did not change anything: the test would prove nothing"
+        else: assert changed == 0                               # an argument filter nobody enabled is not called (filter.h:25-29)
+        print("filter mode=%d arg=%s flags=%d: %d hits, %d rays changed by the filters, %d ties; callbacks so far %s" % (mode, use_arg, qflags, st["hits"], changed, st["ties"], calls))
+    # occlusion with filters
+    for mode, use_arg in ((2, False), (2 | 4, True)):
+        r.set_filters(len(meshes), mode)
+        for g in range(len(meshes)): s.set_filters(g, intersect=None, occluded=f_geom, from_arguments=bool(mode & 4))
+        wr = rays_of(rays); r.occluded1_args(wr, arg_rule=use_arg)
+        gr = rays_of(rays); s.occluded1M(gr, api.QueryArguments(f_arg if use_arg else None, 0))
+        compare_occluded(gr["tfar"], wr["tfar"], rays_of(rays)["tfar"], max_flip_frac=2e-3, label=f"occluded filter mode={mode}")
+        noflt = rays_of(rays); s2 = api.make_scene(dev, meshes, flags=flags); s2.occluded1M(noflt); s2.release()
+        assert (np.isneginf(noflt["tfar"]).sum() - np.isneginf(gr["tfar"]).sum()) > 200      # the filters let rays through that were occluded
+    # the single-ray entry point goes through the same loop
+    r.set_filters(len(meshes), 1)
+    for g in range(len(meshes)): s.set_filters(g, intersect=f_geom, occluded=None)
+    want = rays[:64].copy(); r.intersect1_args(want)
+    one = rays[:64].copy()
+    for i in range(64): s.intersect1(one[i:i + 1])
+    compare_closest(one, want, rays[:64], None, label="filter through rtcIntersect1")
+    # the device-pointer entry point cannot run a host callback
+    L = api.load()
+    d = api.DeviceArray.from_numpy(rays[:64])
+    qa = api.QueryArguments(f_arg, api.RTC_RAY_QUERY_FLAG_INVOKE_ARGUMENT_FILTER)
+    L.rtcIntersect1MDevice(s.h, d.ptr, 64, 96, C.addressof(qa), None)
+    assert L.rtcGetDeviceError(dev.h) == 3                       # RTC_ERROR_INVALID_OPERATION
+    d.free(); s.release(); r.close()
