@@ -269,18 +269,24 @@ struct RTCOccludedFunctionNArguments;
 typedef void (*RTCFilterFunctionN)(const struct RTCFilterFunctionNArguments*);
 typedef void (*RTCIntersectFunctionN)(const struct RTCIntersectFunctionNArguments*);
 typedef void (*RTCOccludedFunctionN)(const struct RTCOccludedFunctionNArguments*);
-/* structure-of-arrays accessors of a ray / hit packet of size N, lane i (the reference's helpers of the same names) */
-#define RTC_RAYN_FIELD(name, type, k) RTC_FORCEINLINE type* RTCRayN_##name##_ptr(struct RTCRayN* r, unsigned int N, unsigned int i) { return (type*)r + (k) * N + i; } \
-  RTC_FORCEINLINE type RTCRayN_get_##name(const struct RTCRayN* r, unsigned int N, unsigned int i) { return ((const type*)r)[(k) * N + i]; }
-RTC_RAYN_FIELD(org_x, float, 0) RTC_RAYN_FIELD(org_y, float, 1) RTC_RAYN_FIELD(org_z, float, 2) RTC_RAYN_FIELD(tnear, float, 3)
-RTC_RAYN_FIELD(dir_x, float, 4) RTC_RAYN_FIELD(dir_y, float, 5) RTC_RAYN_FIELD(dir_z, float, 6) RTC_RAYN_FIELD(time, float, 7)
-RTC_RAYN_FIELD(tfar, float, 8) RTC_RAYN_FIELD(mask, unsigned int, 9) RTC_RAYN_FIELD(id, unsigned int, 10) RTC_RAYN_FIELD(flags, unsigned int, 11)
-#undef RTC_RAYN_FIELD
-#define RTC_HITN_FIELD(name, type, k) RTC_FORCEINLINE type* RTCHitN_##name##_ptr(struct RTCHitN* h, unsigned int N, unsigned int i) { return (type*)h + (k) * N + i; } \
-  RTC_FORCEINLINE type RTCHitN_get_##name(const struct RTCHitN* h, unsigned int N, unsigned int i) { return ((const type*)h)[(k) * N + i]; }
-RTC_HITN_FIELD(Ng_x, float, 0) RTC_HITN_FIELD(Ng_y, float, 1) RTC_HITN_FIELD(Ng_z, float, 2) RTC_HITN_FIELD(u, float, 3) RTC_HITN_FIELD(v, float, 4)
-RTC_HITN_FIELD(primID, unsigned int, 5) RTC_HITN_FIELD(geomID, unsigned int, 6) RTC_HITN_FIELD(instID0, unsigned int, 7)
-#undef RTC_HITN_FIELD
+/* structure-of-arrays accessors of a ray / hit packet of size N, lane i [ref: rtcore_ray.h:221-261]: in C++ the reference's names returning references
+   (RTCRayN_tfar(ray, N, i) = ...), in C pointer forms (*RTCRayN_tfar_ptr(ray, N, i) = ...) */
+#if defined(__cplusplus)
+#define RTC_SOA_FIELD(S, name, type, k) RTC_FORCEINLINE type& S##_##name(S* p, unsigned int N, unsigned int i) { return ((type*)p)[(k) * N + i]; }
+#else
+#define RTC_SOA_FIELD(S, name, type, k) RTC_FORCEINLINE type* S##_##name##_ptr(struct S* p, unsigned int N, unsigned int i) { return (type*)p + (k) * N + i; }
+#endif
+RTC_SOA_FIELD(RTCRayN, org_x, float, 0) RTC_SOA_FIELD(RTCRayN, org_y, float, 1) RTC_SOA_FIELD(RTCRayN, org_z, float, 2) RTC_SOA_FIELD(RTCRayN, tnear, float, 3)
+RTC_SOA_FIELD(RTCRayN, dir_x, float, 4) RTC_SOA_FIELD(RTCRayN, dir_y, float, 5) RTC_SOA_FIELD(RTCRayN, dir_z, float, 6) RTC_SOA_FIELD(RTCRayN, time, float, 7)
+RTC_SOA_FIELD(RTCRayN, tfar, float, 8) RTC_SOA_FIELD(RTCRayN, mask, unsigned int, 9) RTC_SOA_FIELD(RTCRayN, id, unsigned int, 10) RTC_SOA_FIELD(RTCRayN, flags, unsigned int, 11)
+RTC_SOA_FIELD(RTCHitN, Ng_x, float, 0) RTC_SOA_FIELD(RTCHitN, Ng_y, float, 1) RTC_SOA_FIELD(RTCHitN, Ng_z, float, 2) RTC_SOA_FIELD(RTCHitN, u, float, 3) RTC_SOA_FIELD(RTCHitN, v, float, 4)
+RTC_SOA_FIELD(RTCHitN, primID, unsigned int, 5) RTC_SOA_FIELD(RTCHitN, geomID, unsigned int, 6)
+#if defined(__cplusplus)
+RTC_FORCEINLINE unsigned int& RTCHitN_instID(RTCHitN* p, unsigned int N, unsigned int i, unsigned int level) { return ((unsigned int*)p)[(7 + level) * N + i]; }
+#else
+RTC_FORCEINLINE unsigned int* RTCHitN_instID_ptr(struct RTCHitN* p, unsigned int N, unsigned int i, unsigned int level) { return (unsigned int*)p + (7 + level) * N + i; }
+#endif
+#undef RTC_SOA_FIELD
 
 /* [ref: rtcore_scene.h:34-58] */
 struct RTCIntersectArguments {
