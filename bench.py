@@ -503,17 +503,21 @@ def main():
                                 "what": "scattered lane-addresses per second over all launches in flight against 256 CUs x 1 address per clock x 2.4 GHz: the resource this kernel "
                                         "saturates (an extra 4-, 8- or 16-byte load per triangle test costs the same 11-12 %; throughput follows 1 / accesses when the leaf size changes)"}
         if pmc:
+            # PMC counters are per LAUNCH (lone launches of the PMC run); the rates below are for the whole chip over the timed region, like address_rate:
+            # counter x launches timed / elapsed -- with several launches in flight a single launch's duration says nothing about what the chip sustains
             c = pmc["counters"]
-            clock_hz = pmc.get("kernel_cycles", 0.0) / (avg_ms * 1e-3) if pmc.get("kernel_cycles") else 2.4e9
+            lone_ms = (pipelined or {}).get("kernel_ms_avg") if (len(tstreams) > 1 and pipelined) else avg_ms      # a lone launch's duration (the `serial` leg), for the clock
+            clock_hz = pmc.get("kernel_cycles", 0.0) / (lone_ms * 1e-3) if (pmc.get("kernel_cycles") and lone_ms) else 2.4e9
             clock_hz = min(max(clock_hz, 1.0e9), 2.4e9)
-            roof["hbm_counter"] = {"bytes_per_launch": int(pmc["hbm_traffic_bytes_per_launch"]), "achieved": round(pmc["hbm_traffic_bytes_per_launch"] / (avg_ms * 1e-3) / 1e9, 1),
-                                   "frac": round(pmc["hbm_traffic_bytes_per_launch"] / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                   "what": "rocprofv3 --pmc FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE per launch of this kernel source (profiles/pmc_bench_latest.json, hash %s); includes Infinity-Cache hits" % pmc["source_hash"]}
+            hbm_rate = pmc["hbm_traffic_bytes_per_launch"] * args.steps / elapsed / 1e9
+            roof["hbm_counter"] = {"bytes_per_launch": int(pmc["hbm_traffic_bytes_per_launch"]), "achieved": round(hbm_rate, 1), "frac": round(hbm_rate / HBM_PEAK_GBS, 4),
+                                   "what": "rocprofv3 --pmc FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE per launch of this kernel source (profiles/pmc_bench_latest.json, hash %s) x launches timed / elapsed; includes Infinity-Cache hits" % pmc["source_hash"]}
             if "SQ_INSTS_VALU" in c:
                 valu_s = c["SQ_INSTS_VALU"] * 4.0 / (NUM_SIMDS * clock_hz)
                 roof["valu"] = {"wave_instructions_per_launch": int(c["SQ_INSTS_VALU"]), "cycles_per_instruction": 4, "clock_ghz": round(clock_hz / 1e9, 3),
-                                "issue_ms": round(valu_s * 1e3, 4), "frac": round(valu_s / (avg_ms * 1e-3), 4),
-                                "what": "SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x clock) / kernel time: the share of the launch in which the VALU pipes issue (clock = GRBM_GUI_ACTIVE / 8 / kernel time of the PMC run, capped at 2.4 GHz)"}
+                                "issue_ms": round(valu_s * 1e3, 4), "frac": round(valu_s * args.steps / elapsed, 4),
+                                "what": "SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x clock) per launch x launches timed / elapsed: the share of the timed region in which the VALU pipes issue "
+                                        "(~4 cycles per wave instruction: tools/valu_bench.hip; clock = kernel cycles of the PMC run / duration of a lone launch, capped at 2.4 GHz)"}
         else:
             roof["pmc_note"] = pmc_note
         out = {
