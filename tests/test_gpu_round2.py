@@ -453,6 +453,13 @@ def _random_scene(rng):
             v = np.stack([a, a + d, a + d * 0.5 + (rng.random((n, 3), dtype=np.float32) - 0.5) * 1e-3], 1).reshape(-1, 3)
             t = np.arange(3 * n).reshape(-1, 3)
             t = np.concatenate([t, t[: max(1, n // 4)]])         # some triangles twice
+        elif kind == 3 and rng.random() < 0.5:                   # a quad patch (RTC_GEOMETRY_TYPE_QUAD: uint4 indices)
+            k = int(rng.integers(1, 8))
+            gy, gx = np.meshgrid(np.arange(k + 1, dtype=np.float32), np.arange(k + 1, dtype=np.float32), indexing="ij")
+            v = np.stack([gx / k, 0.3 * rng.random((k + 1, k + 1), dtype=np.float32), gy / k], -1).reshape(-1, 3) + rng.random(3, dtype=np.float32)
+            ii = (np.arange(k)[:, None] * (k + 1) + np.arange(k)[None, :]).ravel()
+            meshes.append((v.astype(np.float32), np.stack([ii, ii + 1, ii + k + 2, ii + k + 1], -1).astype(np.uint32)))
+            continue
         else:                                                    # a fan around one vertex
             n = int(rng.integers(3, 40))
             ang = np.linspace(0, 2 * np.pi, n, endpoint=False, dtype=np.float32)
@@ -478,8 +485,8 @@ def test_fuzz_small_scenes(api, dev, flags):
         o = R.OracleScene(robust=bool(flags))
         orob = o if flags else R.OracleScene(robust=True)        # fast mode: the reference's own fast node test may lose a hit on thin geometry; its robust mode arbitrates
         for v, t in meshes:
-            o.add_mesh(v, t, 1)
-            if orob is not o: orob.add_mesh(v, t, 1)
+            for oo in ((o,) if orob is o else (o, orob)):
+                (oo.add_quads if t.shape[1] == 4 else oo.add_mesh)(v, t, 1)
         o.commit()
         if orob is not o: orob.commit()
         lo = np.min([v.min(0) for v, _ in meshes], 0); hi = np.max([v.max(0) for v, _ in meshes], 0)
@@ -493,7 +500,9 @@ def test_fuzz_small_scenes(api, dev, flags):
         if orob is not o: wrob = rays.copy(); orob.intersect1(wrob)
         wr = rays_of(rays); o.occluded1(wr)
         for q in (None, api.RTC_BUILD_QUALITY_LOW, api.RTC_BUILD_QUALITY_HIGH):
-            s = api.make_scene(dev, meshes, flags=flags, quality=q)
+            s = api.Scene(dev, flags, q)
+            for v, t in meshes: (s.add_quad_mesh if t.shape[1] == 4 else s.add_triangle_mesh)(v, t)
+            s.commit()
             got = rays.copy(); s.intersect1M(got)
             if flags: compare_closest(got, want, rays, o.triangle_t, max_tie_frac=0.2, label=f"fuzz{it} q={q} robust")
             else: compare_closest_arbitrated(got, want, wrob, rays, o.triangle_t, max_tie_frac=0.2, max_ref_miss_frac=0.02, label=f"fuzz{it} q={q} fast")
