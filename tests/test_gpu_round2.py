@@ -590,3 +590,19 @@ def test_filter_callbacks_vs_reference(api, dev, ref, flags):
     L.rtcIntersect1MDevice(s.h, d.ptr, 64, 96, C.addressof(qa), None)
     assert L.rtcGetDeviceError(dev.h) == 3                       # RTC_ERROR_INVALID_OPERATION
     d.free(); s.release(); r.close()
+
+
+# ------------------------------------------------------------------------------------------- a C application against the header and the library
+@pytest.mark.gpu
+def test_c_example_builds_and_runs(tmp_path):
+    """examples/minimal.c: plain C, include/embree4/rtcore.h, linked against libembree4_mi355.so like an Embree application would be; the answers are the
+    known answers of the reference's tutorials/minimal (hit at t = 1 on geometry 0 / primitive 0, u = v = 0.33; the second ray misses)."""
+    import subprocess
+    exe = str(tmp_path / "minimal")
+    lib = os.path.join(ROOT, "embree_amd", "lib")
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "minimal.c"),
+                           "-L", lib, "-lembree4_mi355", "-Wl,-rpath," + lib, "-lm", "-o", exe])
+    out = subprocess.check_output([exe]).decode().splitlines()
+    assert out[0].startswith("ray 0: hit geomID 0 primID 0 tfar 1 u 0.33 v 0.33"), out
+    assert out[1] == "ray 1: no hit" and out[2] == "batch: hit miss" and out[3] == "occluded: yes no", out
+    assert out[4] == "bounds: 0 0 0 .. 1 1 0" and out[5] == "errors: 0", out
