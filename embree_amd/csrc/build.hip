@@ -208,6 +208,8 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
   HIP_TRY(plans.alloc(maxLevelItems)); HIP_TRY(itemCnt.alloc(maxLevelItems)); HIP_TRY(groupSum.alloc(maxLevelItems / 8u + 16u));
   const uint32_t tiles = (N + 255u) / 256u;
   HIP_TRY(tileCount.alloc(tiles));
+  DevBuf<uint32_t> chunkCnt; DevBuf<uint2> chunkBase;          // per chunk of a level: its bin counts, then its places in the two children (top_bin -> top_split -> top_partition)
+  HIP_TRY(chunkCnt.alloc((size_t)maxChunks * 3u * NBINS)); HIP_TRY(chunkBase.alloc(maxChunks));
   DevBuf<SegX> segx0, segx1; DevBuf<uint32_t> sbins;            // spatial-split builds: extended ranges of the top phase's sets, their spatial bins
   if (spatial) { HIP_TRY(segx0.alloc(maxSegs)); HIP_TRY(segx1.alloc(maxSegs)); HIP_TRY(sbins.alloc((size_t)maxSegs * SBINS_WORDS)); }
 
@@ -215,7 +217,7 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
   struct EvGuard { hipEvent_t a, b; ~EvGuard() { hipEventDestroy(a); hipEventDestroy(b); } } evg{ev0, ev1};
   if (useGraph) {
     HIP_TRY(hipStreamSynchronize(st));                         // (the geometry table above is in place before anything is captured)
-    const void* ptrs[] = {dGeoms.p, bufA.p, bufB.p, finalIds.p, bnodes.p, segs0.p, segs1.p, bins.p, chunks.p, small.p, ctr.p, w0.p, w1.p, wnodes.p, outIds.p, plans.p, itemCnt.p, groupSum.p, tileCount.p, (const void*)st};
+    const void* ptrs[] = {dGeoms.p, bufA.p, bufB.p, finalIds.p, bnodes.p, segs0.p, segs1.p, bins.p, chunks.p, small.p, ctr.p, w0.p, w1.p, wnodes.p, outIds.p, plans.p, itemCnt.p, groupSum.p, tileCount.p, chunkCnt.p, chunkBase.p, (const void*)st};
     std::vector<uint64_t> key; for (const void* q : ptrs) key.push_back((uint64_t)(uintptr_t)q);
     uint32_t pw[sizeof(Params) / 4]; memcpy(pw, &prm, sizeof(prm)); for (uint32_t w : pw) key.push_back(w);
     key.push_back(N); key.push_back(gd.size()); key.push_back(bp->robust);
@@ -341,14 +343,14 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
     const uint32_t segBound = level < 31u && (1u << level) < maxSegs ? (1u << level) : maxSegs;
     const uint32_t chunkBound = (spatial ? NC : n) / CHUNK + segBound + 1u;
     LAUNCH(top_setup, dim3(segBound), dim3(256), 0, st, cur, bins.p, chunks.p, ctr.p);
-    LAUNCH(top_bin, dim3(chunkBound), dim3(256), 0, st, cur, chunks.p, src, bins.p, ctr.p);
-    LAUNCH(top_split, dim3(segBound), dim3(64), 0, st, cur, bins.p, bnodes.p, ctr.p, prm, level >= 96u ? 1u : 0u, xcur);
+    LAUNCH(top_bin, dim3(chunkBound), dim3(256), 0, st, cur, chunks.p, src, bins.p, ctr.p, chunkCnt.p);
+    LAUNCH(top_split, dim3(segBound), dim3(64), 0, st, cur, bins.p, bnodes.p, ctr.p, prm, level >= 96u ? 1u : 0u, xcur, (const uint32_t*)chunkCnt.p, chunkBase.p);
     if (spatial) {                                               // sets whose object split leaves overlapping children try a spatial split
       LAUNCH(spatial_decide, dim3(segBound), dim3(128), 0, st, cur, xcur, bnodes.p, sbins.p, ctr.p, spatialMin);
       LAUNCH(spatial_bin, dim3(chunkBound), dim3(256), 0, st, cur, xcur, chunks.p, src, dGeoms.p, sbins.p, ctr.p);
       LAUNCH(spatial_best, dim3(segBound), dim3(64), 0, st, cur, xcur, sbins.p, bnodes.p, ctr.p, prm);
     }
-    LAUNCH(top_partition, dim3(chunkBound), dim3(256), 0, st, cur, chunks.p, src, dst, ctr.p);
+    LAUNCH(top_partition, dim3(chunkBound), dim3(256), 0, st, cur, chunks.p, src, dst, ctr.p, (const uint2*)chunkBase.p);
     if (spatial) LAUNCH(spatial_partition, dim3(chunkBound), dim3(256), 0, st, cur, xcur, chunks.p, src, dst, dGeoms.p, ctr.p);
     LAUNCH(top_emit, dim3((segBound + 255u) / 256u), dim3(256), 0, st, cur, bnodes.p, nxt, small.p, ctr.p, prm,
            (level & 1u) ? 0u : 1u, maxSegs, maxSmall, (const SegX*)xcur, xnxt);

@@ -36,6 +36,7 @@ struct Seg {
   float scale[3]; uint32_t nL;
   uint32_t childL, childR, curL, curR;
   uint32_t acc[2][12];                          // per side: centroid lo/hi (6) + geometry lo/hi (6), ordered uint
+  uint32_t chunk0, pad0, pad1, pad2;            // first of the set's chunks in this level's chunk list (they are consecutive)
 };
 struct SmallEntry { uint32_t begin, end, bnode, buf; float cmin[3], cmax[3]; };
 struct Chunk { uint32_t seg, begin, end; };

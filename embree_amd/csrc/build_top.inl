@@ -14,6 +14,7 @@ __global__ __launch_bounds__(256) void top_setup(Seg* segs, uint32_t* bins, Chun
     for (int d = 0; d < 3; d++) { sg->ofs[d] = m.ofs[d]; sg->scale[d] = m.scale[d]; }
     sg->nb = m.nb;
     s_base = atomicAdd(&ctr->numChunks, nch);
+    sg->chunk0 = s_base;
   }
   __syncthreads();
   for (uint32_t c = tid; c < nch; c += 256u) {
@@ -22,7 +23,9 @@ __global__ __launch_bounds__(256) void top_setup(Seg* segs, uint32_t* bins, Chun
   }
 }
 
-__global__ __launch_bounds__(256) void top_bin(const Seg* segs, const Chunk* chunks, const PrimRef* src, uint32_t* bins, const Counters* ctr) {
+// chunkCnt: per chunk, how many of its references fell into every bin (3 x NBINS words): top_split turns them into the chunk's places in the two children,
+// so that where a reference lands does not depend on which chunk reached a cursor first (top_partition)
+__global__ __launch_bounds__(256) void top_bin(const Seg* segs, const Chunk* chunks, const PrimRef* src, uint32_t* bins, const Counters* ctr, uint32_t* chunkCnt) {
   __shared__ uint32_t s_bins[BINS_WORDS];
   const uint32_t tid = threadIdx.x;
   if (blockIdx.x >= ctr->numChunks) return;
@@ -40,6 +43,7 @@ __global__ __launch_bounds__(256) void top_bin(const Seg* segs, const Chunk* chu
     }
   }
   __syncthreads();
+  if (tid < 3u * (uint32_t)NBINS) chunkCnt[(size_t)blockIdx.x * (3u * NBINS) + tid] = s_bins[tid * BINW + 6];
   uint32_t* g = bins + (size_t)ck.seg * BINS_WORDS;
   if (ck.begin == sg->begin && ck.end == sg->end) {             // the set's only chunk (every set of the lower levels): its bins ARE the set's bins, no atomics
     for (uint32_t w = tid; w < (uint32_t)BINS_WORDS; w += 256u) g[w] = s_bins[w];
@@ -57,8 +61,10 @@ __device__ __forceinline__ uint32_t segx_ext_end(const SegX* sx, uint32_t s);
 __device__ __forceinline__ void segx_object_split(SegX* sx, uint32_t s, uint32_t capL, float sah);
 __device__ __forceinline__ uint32_t segx_cap_left(const SegX* sx, uint32_t s);
 __device__ __forceinline__ void segx_child(SegX* nx, uint32_t k, uint32_t extEnd);
-__global__ __launch_bounds__(64) void top_split(Seg* segs, const uint32_t* bins, BNode* bnodes, Counters* ctr, Params prm, uint32_t forceFallback, SegX* sx) {
+__global__ __launch_bounds__(64) void top_split(Seg* segs, const uint32_t* bins, BNode* bnodes, Counters* ctr, Params prm, uint32_t forceFallback, SegX* sx,
+                                                const uint32_t* chunkCnt, uint2* chunkBase) {
   __shared__ SplitResult s_res;
+  __shared__ uint32_t s_plan[4];                                // fallback, dim, pos, capacity of the left child
   const uint32_t s = blockIdx.x, lane = threadIdx.x;
   if (s >= ctr->numSegs) return;
   Seg* sg = segs + s;
@@ -85,11 +91,29 @@ __global__ __launch_bounds__(64) void top_split(Seg* segs, const uint32_t* bins,
     sg->flags = fallback ? 1u : 0u; sg->dim = fallback ? 0u : (uint32_t)r.dim; sg->pos = fallback ? capL : (uint32_t)r.pos; sg->nL = nL;   // (median split: pos = where the right child starts, see top_partition)
     sg->childL = idL; sg->childR = idR; sg->curL = begin; sg->curR = begin + capL;
     for (int side = 0; side < 2; side++) for (int k = 0; k < 12; k++) sg->acc[side][k] = (k % 6 < 3) ? ENC_POS_INF : ENC_NEG_INF;
-    (void)n;
+    s_plan[0] = fallback ? 1u : 0u; s_plan[1] = fallback ? 0u : (uint32_t)r.dim; s_plan[2] = (uint32_t)r.pos; s_plan[3] = capL;
+  }
+  __syncthreads();
+  // Where every chunk of the set writes its left and its right references: an exclusive scan, in chunk order, of the per-chunk bin counts of top_bin.
+  // (A cursor advanced with atomics hands the places out in the order the chunks ARRIVE: the sets come out the same, their order does not -- and a later
+  // median split of coincident centroids cuts by order.)
+  if (s_plan[0] == 0u) {
+    const uint32_t begin = sg->begin, n = sg->end - begin, nch = (n + CHUNK - 1u) / CHUNK, c0 = sg->chunk0, dim = s_plan[1], pos = s_plan[2], capL = s_plan[3];
+    uint32_t carry = 0u;
+    for (uint32_t cb = 0; cb < nch; cb += 64u) {                 // wave-uniform trip count
+      const uint32_t c = cb + lane;
+      uint32_t cntL = 0u;
+      if (c < nch) { const uint32_t* h = chunkCnt + (size_t)(c0 + c) * (3u * NBINS) + dim * NBINS; for (uint32_t b = 0; b < pos; b++) cntL += h[b]; }
+      uint32_t incl = cntL;
+      for (int o = 1; o < 64; o <<= 1) { const uint32_t u = (uint32_t)__shfl_up((int)incl, o, 64); if (lane >= (uint32_t)o) incl += u; }
+      const uint32_t exclL = carry + incl - cntL;
+      if (c < nch) chunkBase[c0 + c] = make_uint2(begin + exclL, begin + capL + (c * CHUNK - exclL));
+      carry += (uint32_t)__shfl((int)incl, 63, 64);
+    }
   }
 }
 
-__global__ __launch_bounds__(256) void top_partition(Seg* segs, const Chunk* chunks, const PrimRef* src, PrimRef* dst, const Counters* ctr) {
+__global__ __launch_bounds__(256) void top_partition(Seg* segs, const Chunk* chunks, const PrimRef* src, PrimRef* dst, const Counters* ctr, const uint2* chunkBase) {
   __shared__ uint32_t s_cnt[CHUNK_ROUNDS][4][2], s_off[CHUNK_ROUNDS][4][2], s_acc[2][12], s_baseL, s_baseR;
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   if (blockIdx.x >= ctr->numChunks) return;
@@ -132,7 +156,10 @@ __global__ __launch_bounds__(256) void top_partition(Seg* segs, const Chunk* chu
   if (tid == 0) {
     uint32_t l = 0, rr = 0;
     for (int r = 0; r < CHUNK_ROUNDS; r++) for (int w = 0; w < 4; w++) { s_off[r][w][0] = l; s_off[r][w][1] = rr; l += s_cnt[r][w][0]; rr += s_cnt[r][w][1]; }
-    s_baseL = l ? atomicAdd(&sg->curL, l) : 0u; s_baseR = rr ? atomicAdd(&sg->curR, rr) : 0u;
+    if (l) atomicAdd(&sg->curL, l);                              // (the cursors only COUNT here: top_emit of spatial-split builds reads them)
+    if (rr) atomicAdd(&sg->curR, rr);
+    const uint2 base = chunkBase[blockIdx.x];                    // this chunk's places, in chunk order (top_split)
+    s_baseL = base.x; s_baseR = base.y;
   }
   __syncthreads();
   const unsigned long long lt = (1ull << lane) - 1ull;

@@ -606,3 +606,22 @@ def test_c_example_builds_and_runs(tmp_path):
     assert out[0].startswith("ray 0: hit geomID 0 primID 0 tfar 1 u 0.33 v 0.33"), out
     assert out[1] == "ray 1: no hit" and out[2] == "batch: hit miss" and out[3] == "occluded: yes no", out
     assert out[4] == "bounds: 0 0 0 .. 1 1 0" and out[5] == "errors: 0", out
+
+
+@pytest.mark.gpu
+def test_rebuilds_identical_with_coincident_centroids(api, dev):
+    """A set of references with ONE centroid has no SAH split: the builder cuts it in the middle of its current order (the reference's fallback split,
+    heuristic_binning_array_aligned.h:50-65).  That order must not depend on which workgroup of an earlier partition got to a cursor first -- the places of
+    every chunk come from a scan of the chunks' bin counts (top_split), so eight builds of 7001 triangles (7000 of them coincident, more than three chunks
+    of the top phase) give byte-identical trees, MEDIUM and HIGH."""
+    base = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32)
+    dup = (np.tile(base, (7000, 1)), np.arange(21000, dtype=np.uint32).reshape(-1, 3))
+    other = (base + np.float32(5), np.array([[0, 1, 2]], np.uint32))
+    for q in (None, api.RTC_BUILD_QUALITY_HIGH):
+        blobs = set()
+        for rep in range(8):
+            s = api.make_scene(dev, [dup, other], quality=q)
+            nodes, tris = s.download_bvh()
+            blobs.add(nodes.tobytes() + tris.tobytes())
+            s.release()
+        assert len(blobs) == 1, (q, len(blobs))
