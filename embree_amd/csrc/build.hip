@@ -64,6 +64,7 @@ struct Arena {
   // triangle count, same parameters, same arena addresses): a dynamic scene that is re-committed every frame pays ONE host call for its ~200 launches.
   hipStream_t stream = nullptr;                              // commits enqueue here when the caller gives no stream (a capture needs a real stream)
   std::vector<uint64_t> graphKey; hipGraphExec_t graphExec = nullptr; bool graphBroken = false;   // graphBroken: capture / instantiate failed once on this device: plain launches from then on
+  uint32_t marginFailedN = 0;                                // a commit of this many triangles outgrew the level margins of the one-round-trip path: the next one goes stepwise at once
   void drop_graph() { if (graphExec) { hipGraphExecDestroy(graphExec); graphExec = nullptr; } graphKey.clear(); }
   void reset() { for (auto& b : blocks) b.used = 0; }
   hipError_t take(size_t bytes, void** out) {
@@ -74,7 +75,7 @@ struct Arena {
     if (e != hipSuccess) return e;
     blocks.push_back(nb); *out = nb.p; return hipSuccess;
   }
-  void release() { drop_graph(); for (auto& b : blocks) hipFree(b.p); blocks.clear(); }
+  void release() { drop_graph(); if (stream) { hipStreamDestroy(stream); stream = nullptr; } for (auto& b : blocks) hipFree(b.p); blocks.clear(); }
 };
 static std::mutex g_arenaMtx;
 static std::map<int, Arena*> g_arenas;
@@ -171,10 +172,12 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
   if (total == 0) { guard.ok = true; *out = bvh; return 0; }
   const uint32_t N = (uint32_t)total;
   static const bool envSync = getenv("MI355_BUILD_STEPWISE") != nullptr;         // A/B: force the stepwise path
-  const bool fast = allowFast && !envSync && prm.quality == 0u;
+  const bool fast = allowFast && !envSync && prm.quality == 0u && !(arena->marginFailedN != 0u && arena->marginFailedN == N);
   static const bool envGraph = !(getenv("MI355_BUILD_GRAPH") && atoi(getenv("MI355_BUILD_GRAPH")) == 0);
   if (fast && envGraph && !st && !arena->graphBroken) {        // the graph needs a stream of its own
-    if (!arena->stream && hipStreamCreateWithFlags(&arena->stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); arena->stream = nullptr; }
+    // a BLOCKING stream (default flags): it keeps the implicit ordering with the legacy null stream that a commit on the null stream had -- work the application
+    // queued there to fill device-resident shared buffers (rtcSetSharedGeometryBufferHostDevice) is finished before the build reads them
+    if (!arena->stream && hipStreamCreateWithFlags(&arena->stream, hipStreamDefault) != hipSuccess) { (void)hipGetLastError(); arena->stream = nullptr; }
     st = arena->stream;
   }
   const bool useGraph = fast && envGraph && st != nullptr && !arena->graphBroken;
@@ -420,6 +423,7 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
     SYNC_READ(h);                                                // the ONE round trip of the commit
     if (h.overflow) return set_error(hipErrorOutOfMemory, "work list overflow (pathological input)");
     if (h.numSegs != 0u) {                                       // the top phase needed more levels than N implies + 8: what came after it worked on an unfinished tree
+      arena->marginFailedN = N;
       return -1000;                                              // (the guard frees the half-built tree) the caller repeats the commit on the stepwise path
     }
     n = h.numPrims;

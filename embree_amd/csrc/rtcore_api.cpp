@@ -132,8 +132,10 @@ struct BufferView { Buffer* buf = nullptr; size_t offset = 0, stride = 0; unsign
 
 struct Scene;
 static std::atomic<unsigned long long> g_commitSerial{0};
+static std::atomic<unsigned long long> g_geomSerial{0};
 struct Geometry : RefCounted {
   Device* device; RTCGeometryType type;
+  const unsigned long long serial = ++g_geomSerial;          // process-unique: what a tree was built from is remembered by serial, never by address (a freed geometry's address comes back)
   BufferView vertices, indices;
   std::map<unsigned, Buffer*> attribs;                     // vertex attributes: kept alive for the caller, unused by the kernels (rtcInterpolate reads them on the host)
   std::map<unsigned, BufferView> attribViews;
@@ -194,10 +196,11 @@ struct Scene : RefCounted {
   RTCSceneFlags flags = RTC_SCENE_FLAG_NONE; RTCBuildQuality quality = RTC_BUILD_QUALITY_MEDIUM;
   mi355_bvh_t bvh = nullptr; ssize_t bvhBytes = 0; bool committed = false, modified = true;
   ssize_t flatBytes = 0;
+  const unsigned long long serial = ++g_geomSerial;        // (instances remember the scene they were built over by this, not by address)
   mi355_bvh_t flat = nullptr;                               // the tree of this scene's own triangles / quads: what an instance of this scene refers to (== bvh unless the scene has instances)
-  struct BuiltFrom { unsigned id; Geometry* g; unsigned topo, data; };   // what the current tree was built from: decides rebuild vs refit vs nothing to do
+  struct BuiltFrom { unsigned id; unsigned long long g; RTCBuildQuality q; unsigned topo, data; };   // g = Geometry::serial   // what the current tree was built from: decides rebuild vs refit vs nothing to do
   std::vector<BuiltFrom> builtFrom; unsigned builtFlags = 0;
-  struct InstFrom { unsigned id; Geometry* g; Scene* object; unsigned topo, data; unsigned long long objSerial; };
+  struct InstFrom { unsigned id; unsigned long long g; unsigned long long object; unsigned topo, data; unsigned long long objSerial; };   // g = Geometry::serial, object = Scene::serial
   std::vector<InstFrom> builtInst;
   unsigned long long commitSerial = 0;                       // changes with every commit that built or refitted something (instances of this scene notice)
   RTCBounds bounds;
@@ -206,6 +209,7 @@ struct Scene : RefCounted {
   static constexpr int PIPE = 4;
   hipStream_t pipe[PIPE] = {nullptr, nullptr, nullptr, nullptr};   // large host-array queries: upload, download, two compute streams (pipelined_query)
   std::vector<hipEvent_t> pipeEvents;                       // ... and two events per chunk
+  std::mutex pipeMtx;                                       // one pipelined query per scene at a time: the four streams, the events and the streams' status words are shared
   struct Staging { char* d = nullptr; size_t cap = 0; };
   std::map<size_t, Staging> staging;
   Scene(Device* d) : device(d) { d->retain(); setEmptyBounds(); }
@@ -258,7 +262,7 @@ struct Scene : RefCounted {
     for (auto& kv : geoms) {
       Geometry* g = kv.second;
       if (!g->enabled || !g->vertices.buf || !g->indices.buf) continue;
-      from.push_back({kv.first, g, g->topoCounter, g->dataCounter});
+      from.push_back({kv.first, g->serial, g->quality, g->topoCounter, g->dataCounter});
       wantRefit = wantRefit || g->quality == RTC_BUILD_QUALITY_REFIT;
     }
     bp.refit = wantRefit ? 1u : 0u;
@@ -270,9 +274,9 @@ struct Scene : RefCounted {
     for (auto& kv : geoms) {
       Geometry* g = kv.second;
       if (g->type != RTC_GEOMETRY_TYPE_INSTANCE || !g->enabled || !g->object) continue;
-      instFrom.push_back({kv.first, g, g->object, g->topoCounter, g->dataCounter, g->object->commitSerial});
+      instFrom.push_back({kv.first, g->serial, g->object->serial, g->topoCounter, g->dataCounter, g->object->commitSerial});
     }
-    if (committed && bvh && nowFlags == builtFlags && from.size() == builtFrom.size() && instFrom.size() == builtInst.size()) {
+    if (committed && !modified && bvh && nowFlags == builtFlags && from.size() == builtFrom.size() && instFrom.size() == builtInst.size()) {   // (attach / detach set `modified`)
       bool same = true;
       for (size_t i = 0; same && i < from.size(); i++) { const BuiltFrom &a = from[i], &b = builtFrom[i]; same = a.id == b.id && a.g == b.g && a.topo == b.topo && a.data == b.data; }
       for (size_t i = 0; same && i < instFrom.size(); i++) { const InstFrom &a = instFrom[i], &b = builtInst[i]; same = a.id == b.id && a.g == b.g && a.object == b.object && a.topo == b.topo && a.data == b.data && a.objSerial == b.objSerial; }
@@ -283,7 +287,7 @@ struct Scene : RefCounted {
     bool refit = flat && committed && from.size() == builtFrom.size() && nowFlags == builtFlags && !from.empty();
     for (size_t i = 0; refit && i < from.size(); i++) {
       const BuiltFrom &a = from[i], &b = builtFrom[i];
-      refit = a.id == b.id && a.g == b.g && a.topo == b.topo && (a.data == b.data || a.g->quality == RTC_BUILD_QUALITY_REFIT);
+      refit = a.id == b.id && a.g == b.g && a.topo == b.topo && (a.data == b.data || a.q == RTC_BUILD_QUALITY_REFIT);
     }
     mi355_bvh_info info;
     bool done = false;
@@ -407,6 +411,7 @@ static void check_trace_status(mi355_bvh_t b, hipStream_t q) {
 static bool pipelined_query(Scene* s, mi355_bvh_t b, char* data, char* d, unsigned M, size_t stride, bool any, size_t bytes) {
   if (hipHostRegister(data, bytes, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); return false; }
   struct Unpin { void* p; ~Unpin() { hipHostUnregister(p); } } unpin{data};
+  std::lock_guard<std::mutex> pipeLock(s->pipeMtx);         // (another thread's pipelined query would wait on my events and could read my status words)
   const size_t rec = any ? 48 : 96;
   const unsigned chunk = s->device->pipelineChunk, nchunks = (M + chunk - 1u) / chunk;
   hipStream_t up, down, comp[2];
@@ -495,7 +500,10 @@ static void filtered_query(Scene* s, void* data, unsigned M, size_t stride, bool
       // rejected: search on behind it, up to the ray's own tfar
       const float t = w.ray.tfar;
       RTCRayHit nx; memcpy(&nx.ray, (const char*)data + (size_t)who[k] * stride, sizeof(RTCRay));
-      nx.ray.tnear = t > nx.ray.tnear ? t : nextafterf(nx.ray.tnear, INFINITY);    // the triangle test is strict at tnear: the rejected hit is out
+      // fast scenes: Moeller-Trumbore is strict at tnear, so restarting AT t leaves the rejected hit out; robust scenes: the Pluecker test is inclusive
+      // at both ends (triangle_intersector_pluecker.h:104), the same triangle would come back and the callback would see it twice: restart one ulp behind
+      const bool robust = (s->flags & RTC_SCENE_FLAG_ROBUST) != 0;
+      nx.ray.tnear = t > nx.ray.tnear ? (robust ? nextafterf(t, INFINITY) : t) : nextafterf(nx.ray.tnear, INFINITY);
       if (w.ray.tnear >= nx.ray.tnear) nx.ray.tnear = nextafterf(w.ray.tnear, INFINITY);
       memset(&nx.hit, 0, sizeof(RTCHit)); nx.hit.geomID = RTC_INVALID_GEOMETRY_ID; nx.hit.primID = RTC_INVALID_GEOMETRY_ID; nx.hit.instID[0] = RTC_INVALID_GEOMETRY_ID;
       work[m] = nx; who[m] = who[k]; m++;

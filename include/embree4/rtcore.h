@@ -10,12 +10,14 @@
  * interface it replaces as  [ref: file:line]  (paths relative to the
  * reference's include/embree4/).
  *
- * Entry points of the reference that are outside the triangle path (curves,
- * subdivision, instancing, user geometry, filters, point queries, collision,
- * interpolation) are not declared here; the shared library still exports the
- * most common of them as stubs that record RTC_ERROR_INVALID_OPERATION, which
- * is what a reference build with those features compiled out does
- * (kernels/common/rtcore.cpp:1553-1555).
+ * Declared and built beyond plain triangle meshes: quad meshes, one level of
+ * instancing, filter callbacks (host-array entry points) and device-side filter
+ * rules, rtcInterpolate.  Entry points of the reference outside that path
+ * (curves, subdivision, user geometry, point queries, collision, motion blur)
+ * are not declared here; the shared library still exports every one of the
+ * reference's 154 rtc* symbols, the undeclared ones as stubs that record
+ * RTC_ERROR_INVALID_OPERATION -- what a reference build with those features
+ * compiled out does (kernels/common/rtcore.cpp:1553-1555).
  *
  * Extension (required for a GPU: one host call per ray cannot feed 256 CUs):
  * the batched calls rtcIntersect1M / rtcOccluded1M (modelled on the Embree-3
@@ -173,8 +175,8 @@ enum RTCBufferType {
   RTC_BUFFER_TYPE_HOLE = 22, RTC_BUFFER_TYPE_TRANSFORM = 23, RTC_BUFFER_TYPE_FLAGS = 32
 };
 
-/* [ref: rtcore_geometry.h:18-53] TRIANGLE is the only type this library builds;
-   every other value makes rtcNewGeometry record RTC_ERROR_INVALID_OPERATION. */
+/* [ref: rtcore_geometry.h:18-53] TRIANGLE, QUAD and INSTANCE are the types this library
+   builds; every other value makes rtcNewGeometry record RTC_ERROR_INVALID_OPERATION. */
 enum RTCGeometryType {
   RTC_GEOMETRY_TYPE_TRIANGLE = 0, RTC_GEOMETRY_TYPE_QUAD = 1, RTC_GEOMETRY_TYPE_GRID = 2,
   RTC_GEOMETRY_TYPE_SUBDIVISION = 8,
@@ -283,8 +285,10 @@ RTC_SOA_FIELD(RTCHitN, Ng_x, float, 0) RTC_SOA_FIELD(RTCHitN, Ng_y, float, 1) RT
 RTC_SOA_FIELD(RTCHitN, primID, unsigned int, 5) RTC_SOA_FIELD(RTCHitN, geomID, unsigned int, 6)
 #if defined(__cplusplus)
 RTC_FORCEINLINE unsigned int& RTCHitN_instID(RTCHitN* p, unsigned int N, unsigned int i, unsigned int level) { return ((unsigned int*)p)[(7 + level) * N + i]; }
+RTC_FORCEINLINE unsigned int& RTCHitN_instPrimID(RTCHitN* p, unsigned int N, unsigned int i, unsigned int level) { return ((unsigned int*)p)[(7 + RTC_MAX_INSTANCE_LEVEL_COUNT + level) * N + i]; }   /* [ref: rtcore_ray.h:220] */
 #else
 RTC_FORCEINLINE unsigned int* RTCHitN_instID_ptr(struct RTCHitN* p, unsigned int N, unsigned int i, unsigned int level) { return (unsigned int*)p + (7 + level) * N + i; }
+RTC_FORCEINLINE unsigned int* RTCHitN_instPrimID_ptr(struct RTCHitN* p, unsigned int N, unsigned int i, unsigned int level) { return (unsigned int*)p + (7 + RTC_MAX_INSTANCE_LEVEL_COUNT + level) * N + i; }
 #endif
 #undef RTC_SOA_FIELD
 
@@ -384,7 +388,10 @@ RTC_API void* rtcGetGeometryBufferData(RTCGeometry geometry, enum RTCBufferType 
 RTC_API void rtcUpdateGeometryBuffer(RTCGeometry geometry, enum RTCBufferType type, unsigned int slot);
 RTC_API void rtcSetGeometryUserData(RTCGeometry geometry, void* ptr);
 RTC_API void* rtcGetGeometryUserData(RTCGeometry geometry);
-/* recorded as RTC_ERROR_INVALID_OPERATION when the function is non-NULL */
+/* host callbacks: run by the host-array entry points between launches (the closest candidate of every ray is
+   offered, rejected rays are traced on); the device-pointer entry points record RTC_ERROR_INVALID_OPERATION when
+   a callback would have to run (a host function cannot run in a HIP kernel) -- see rtcSetGeometryFilterRule_mi355
+   below for rules that run inside the kernel.  [ref: rtcore_geometry.h:150-165] */
 RTC_API void rtcSetGeometryIntersectFilterFunction(RTCGeometry geometry, RTCFilterFunctionN filter);
 RTC_API void rtcSetGeometryOccludedFilterFunction(RTCGeometry geometry, RTCFilterFunctionN filter);
 RTC_API void rtcSetGeometryEnableFilterFunctionFromArguments(RTCGeometry geometry, bool enable);
