@@ -143,6 +143,30 @@ def cpu_baseline(meshes, rays, any_hit=False, budget_s=25.0):
                 sample="first %d rays of the step, scalar C restatement (oracle/restate.c)" % n), None
 
 
+def reference_visits(meshes, rays, sample=1 << 16):
+    """Visit counters of the REFERENCE-STRUCTURE tree (oracle/restate.c: the reference's BVH8 of Triangle4 blocks, ordered descent; the counters of
+    kernels/common/stat.h:9-19) on a sample of the timed rays, to stand beside roofline.per_ray.  CPU, test infrastructure."""
+    from oracle import restate
+    if not restate.available():
+        return None
+    o = restate.OracleScene()
+    for v, t in meshes:
+        o.add_mesh(v, t)
+    o.commit()
+    n = min(sample, rays.shape[0])
+    idx = np.linspace(0, rays.shape[0] - 1, n).astype(np.int64)          # spread over the whole batch
+    r = np.ascontiguousarray(rays[idx])
+    o.visit_stats(reset=True)
+    o.intersect1(r)
+    vs = o.visit_stats()
+    c = o.counts()
+    o.close()
+    return dict(rays_sampled=int(n), nodes_per_ray=round(vs["nodes"] / n, 2), leaves_per_ray=round(vs["leaves"] / n, 2), triangle4_blocks_per_ray=round(vs["blocks"] / n, 2),
+                tree=dict(nodes=c["nodes"], triangle4_blocks=c["blocks"]),
+                what="oracle/restate.c: the reference's tree (BVH8 AABB nodes, leaves of <= 7 Triangle4 blocks, bvh_builder_sah.h:214-308) and its ordered single-ray descent "
+                     "(bvh_traverser1.h:311-433) on an evenly spaced sample of the timed rays; a block is four triangles tested by one SIMD instruction")
+
+
 def classify_parity(got, want, rays_in, meshes):
     """IDs bit-exact except classified exact-t ties, t within 1e-4: the same check the GPU tests use; raises AssertionError on a real difference."""
     from oracle import restate
@@ -195,6 +219,42 @@ def run_guarded(fn, timeout_s):
     return box.get("value") if "value" in box else dict(error=box.get("error", "unknown"))
 
 
+def spawn_ranks(n, script=None, script_args=None):
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks ourselves (one process per GPU, rendezvous on 127.0.0.1) and pass rank 0's
+    line through.  Under `python -m torch.distributed.run` (WORLD_SIZE set) this is not used: the launcher has started the ranks already."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   MI355_BENCH_SELF_SPAWNED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + (sys.argv[1:] if script_args is None else list(script_args)), env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    alive = list(procs)
+    while alive:                                            # a rank that dies must not leave the others waiting at a barrier for ever
+        time.sleep(0.2)
+        for p_ in list(alive):
+            r_ = p_.poll()
+            if r_ is None:
+                continue
+            alive.remove(p_)
+            if r_ != 0:
+                rc = rc or r_
+                deadline = time.time() + 20
+                for q in alive:
+                    while q.poll() is None and time.time() < deadline:
+                        time.sleep(0.2)
+                    if q.poll() is None:
+                        q.kill()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -208,6 +268,8 @@ def main():
     ap.add_argument("--phi", type=int, default=158, help="sphere tessellation of the synthetic crown (158 -> 4.76M triangles)")
     ap.add_argument("--config", default="", help="extra rtcNewDevice config, e.g. max_leaf=2,int_cost=0.5")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--inprocess-gpus", type=int, default=0, help="extra leg at N = 1: rtcIntersect1M through ONE RTCDevice over this many GPUs (0 = all GPUs of the node, 1 = skip; "
+                                                                    "more than the node has = replicas share GPUs)")
     ap.add_argument("--scene", default="", help=".ecs / .xml / .obj scene file; default: $EMBREE_MODEL_DIR/crown/crown.ecs if it exists, "
                                                  "else the synthetic crown stand-in")
     args = ap.parse_args()
@@ -217,11 +279,13 @@ def main():
     if args.warmup is None:
         args.warmup = 2 if shadow else 12
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:       # no launcher: this process becomes the launcher of N ranks (SCALE runs must never measure N = 1 N times)
+        sys.exit(spawn_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
-        log("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world))
+    if args.gpus != world:
+        raise SystemExit("bench.py: --gpus %d but %d ranks were started (WORLD_SIZE): refusing to print a line whose n_gpus is not what ran" % (args.gpus, world))
     use_rccl = args.gather == "rccl" or (args.gather == "auto" and world > 1)
     L = api.load()
     ngpu = L.mi355_device_count()
@@ -437,7 +501,8 @@ def main():
         pavg = float(np.mean(pms))
         pipelined = dict(value=round(M * nps / pel / 1e6, 1), unit="Mrays/s", batches_in_flight=npipe, steps=nps, ms_per_step=round(1e3 * pel / nps, 4),
                          kernel_ms_avg=round(pavg, 4), kernel_ms_min=round(float(np.min(pms)), 4), concurrency=round(float(np.sum(pms)) * 1e-3 / pel, 3),
-                         hbm_algorithmic={"achieved": round(alg_bytes / (pavg * 1e-3) / 1e9, 1), "frac": round(alg_bytes / (pavg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+                         hbm_algorithmic=({"achieved": round(alg_bytes / (pavg * 1e-3) / 1e9, 1), "frac": round(alg_bytes / (pavg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "how": "algorithmic bytes per launch / average duration of the lone launches"} if npipe == 1 else
+                                          {"achieved": round(alg_bytes * nps / pel / 1e9, 1), "frac": round(alg_bytes * nps / pel / 1e9 / HBM_PEAK_GBS, 4), "how": "algorithmic bytes x launches / elapsed"}),
                          what=("the same launches issued round-robin on %d HIP streams: the tail of one batch overlaps the next; per-GPU figure" % npipe) if npipe > 1 else
                               "the same launches back to back on ONE stream: one 2^20-ray batch at a time, the kernel's own duration is the step time; per-GPU figure")
     e2e = None
@@ -451,6 +516,48 @@ def main():
         assert h.tobytes() == result.tobytes()
         e2e = dict(value=round(M / min(times) / 1e6, 1), unit="Mrays/s", ms=round(1e3 * min(times), 3),
                    what="rtcIntersect1M on a pageable host array of %d RTCRayHit: pin + H2D (96 MB) + kernel + D2H (96 MB), pipelined in chunks; best of 3" % M)
+    latency = None
+    if not shadow and rank == 0:                           # the per-ray entry points are "not the measured path and the report must say so": what one call costs
+        one = rays[:1].copy()
+        for _ in range(20):
+            scene.intersect1(one.copy())
+        ts = []
+        for i in range(200):
+            r1 = rays[i:i + 1].copy()
+            t1 = time.perf_counter()
+            scene.intersect1(r1)
+            ts.append(time.perf_counter() - t1)
+        latency = dict(rtcIntersect1_us_median=round(1e6 * float(np.median(ts)), 1), rtcIntersect1_us_min=round(1e6 * float(np.min(ts)), 1),
+                       calls=200, what="one blocking rtcIntersect1 call on a host RTCRayHit (H2D copy + one-wave launch + D2H copy + status read), "
+                                       "ctypes call overhead included: the Embree 4 per-ray API works but is not how a GPU is fed -- the batched calls are the measured path")
+    multi = None
+    if not shadow and rank == 0 and world == 1 and args.inprocess_gpus != 1:
+        # ONE process, one RTCDevice over K GPUs (rtcNewDevice("gpus=K")): the BVH committed on every GPU, the host ray array sharded over them by rtcIntersect1M
+        k_gpus = args.inprocess_gpus if args.inprocess_gpus > 0 else ngpu
+        if k_gpus > 1:
+            try:
+                mdev = api.Device(("gpu=%d,gpus=%d,%s" % (gpu, k_gpus, "gpu_oversubscribe=1," if k_gpus > ngpu else "")) + args.config)
+                msc = api.Scene(mdev)
+                for v, t in meshes:
+                    msc.add_triangle_mesh(v, t)
+                t1 = time.perf_counter()
+                msc.commit()
+                commit_s = time.perf_counter() - t1
+                times = []
+                for _ in range(3):
+                    h = rays.copy()
+                    t1 = time.perf_counter()
+                    msc.intersect1M(h)
+                    times.append(time.perf_counter() - t1)
+                assert h.tobytes() == result.tobytes(), "the sharded in-process query disagrees with the single-GPU answer"
+                multi = dict(gpus=k_gpus, distinct_gpus=min(k_gpus, ngpu), value=round(M / min(times) / 1e6, 1), unit="Mrays/s", ms=round(1e3 * min(times), 3),
+                             commit_all_replicas_ms=round(1e3 * commit_s, 2),
+                             what="rtcNewDevice(\"gpus=%d\"): one process, the tree committed on every GPU, rtcIntersect1M on a pageable host array of %d RTCRayHit split contiguously over the "
+                                  "replicas (one host thread per GPU, results copied straight into the caller's array); PCIe-inclusive; result identical to the single-GPU answer" % (k_gpus, M))
+                msc.release()
+                mdev.release()
+            except Exception as e:                            # noqa: BLE001
+                multi = dict(error=repr(e))
     gather = None
     if not shadow and comm is not None:                    # crown: the north-star gather of the packed hit records, exercised and timed outside the headline
         def do_gather():
@@ -477,12 +584,22 @@ def main():
         avg_ms = float(np.mean(kernel_ms))
         conc = float(np.sum(kernel_ms)) * 1e-3 / elapsed
         value = total_rays * args.steps / elapsed / 1e6 if shadow else world * M * args.steps / elapsed / 1e6
-        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+        # achieved = algorithmic bytes / kernel time.  With several launches in flight the launches OVERLAP, so "kernel time" is the timed
+        # region itself: bytes of all timed launches / elapsed (chip level, this rank's GPU).  Dividing by the per-launch duration of overlapping launches
+        # would count every moment of the region launches_in_flight times; the lone-launch figure (duration = kernel time) stands beside it under `serial`.
+        achieved = alg_bytes * args.steps / elapsed / 1e9
+        bw = (C.c_double * 2)()
+        bw_ok = L.mi355_measure_bandwidth(gpu, 2 << 30, 5, bw) == 0          # what a streaming copy / read kernel reaches on THIS box ("also measure")
         pmc, pmc_note = load_pmc() if not shadow else (None, "PMC passes are collected for the closest-hit kernel only")
         roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": int(pmc["hbm_traffic_bytes_per_launch"]) if pmc and "hbm_traffic_bytes_per_launch" in pmc else None,
-                "kernel": "trace_kernel_q<%s>" % ("any" if shadow else "closest"), "kernel_ms_avg": round(avg_ms, 4), "kernel_ms_min": round(float(np.min(kernel_ms)), 4),
+                "traffic_source": "profiles/pmc_bench_latest.json (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE per lone launch of this kernel source)" if pmc else None,
+                "peak_measured": {"copy_GBs": round(bw[0], 1), "read_GBs": round(bw[1], 1), "frac_of_copy": round(achieved / bw[0], 4) if bw_ok and bw[0] > 0 else None,
+                                  "what": "mi355_measure_bandwidth on this GPU: device-to-device copy (bytes read + written) and read-only streaming kernels over 2 GiB, best of 5"} if bw_ok else None,
+                "kernel": "trace_kernel_q<%s>" % ("any" if shadow else "closest"),
+                "how": "algorithmic bytes per launch x launches timed / elapsed of the timed region / peak (launches overlap: %.2f in flight); lone launches: see `serial`" % conc,
                 "launches_timed": args.steps, "launches_in_flight": round(conc, 3),
+                "kernel_ms_avg_overlapping": round(avg_ms, 4), "kernel_ms_min": round(float(np.min(kernel_ms)), 4),
                 "algorithmic_bytes_per_launch": int(alg_bytes),
                 "per_ray": {"nodes": round(st["nodes"] / M, 2), "node_step_simd_util": round(st["nodes"] / max(1, 64 * st["node_blocks"]), 3),
                             "tri_step_simd_util": round(st["tris"] / max(1, 64 * st["tri_blocks"]), 3),
@@ -490,11 +607,8 @@ def main():
                             "wave_iterations": int(st["wave_iters"]), "node_step_blocks": int(st["node_blocks"]), "tri_step_blocks": int(st["tri_blocks"]),
                             "handout_events": int(st["refill_events"]), "handout_clock_share": round(st["refill_clocks"] / max(1, st["loop_clocks"]), 4),
                             "node_step_clock_share": round(st["node_step_clocks"] / max(1, st["loop_clocks"]), 4)},
-                "note": "achieved = algorithmic bytes (SURVEY 8d) per launch / average duration of the timed launches (HIP events on the launch stream). Most of these bytes are "
-                        "served by L1 / L2 / Infinity Cache: hbm_counter is what reaches the memory side, valu is the roof that binds."}
-        if len(tstreams) > 1:
-            roof["note"] += (" The timed launches overlap (launches_in_flight): a launch then owns 1/launches_in_flight of the chip, its duration is that much longer and"
-                             " frac that much lower than in `serial` (lone launches).")
+                "note": "algorithmic bytes (SURVEY 8d) = rays x (48 read + 52 written on a hit) + node visits x 80 + triangle records x 48, visit counts from the counting build of the same "
+                        "kernel on the same rays. Most of these bytes are served by L1 / L2 / Infinity Cache: hbm_counter_from_profile is what reaches the memory side."}
         # what binds (profiles/r02_trace_history.md): every lane that fetches a 16-byte piece of a node / triangle / ray costs the CU's address path one slot, whatever
         # the width and whatever the cache level that answers: 5 per node visit, 3 per triangle test, 3 per ray read + the hit record stores
         acc = 5 * st["nodes"] + 3 * st["tris"] + M * 3 + (nhit * 4 if not shadow else nhit)
@@ -503,27 +617,29 @@ def main():
                                 "what": "scattered lane-addresses per second over all launches in flight against 256 CUs x 1 address per clock x 2.4 GHz: the resource this kernel "
                                         "saturates (an extra 4-, 8- or 16-byte load per triangle test costs the same 11-12 %; throughput follows 1 / accesses when the leaf size changes)"}
         if pmc:
-            # PMC counters are per LAUNCH (lone launches of the PMC run); the rates below are for the whole chip over the timed region, like address_rate:
-            # counter x launches timed / elapsed -- with several launches in flight a single launch's duration says nothing about what the chip sustains
+            # PMC counters are per LAUNCH (lone launches of the PMC run, from profiles/); the rates below are for the whole chip over the timed region:
+            # counter x launches timed / elapsed
             c = pmc["counters"]
             lone_ms = (pipelined or {}).get("kernel_ms_avg") if (len(tstreams) > 1 and pipelined) else avg_ms      # a lone launch's duration (the `serial` leg), for the clock
             clock_hz = pmc.get("kernel_cycles", 0.0) / (lone_ms * 1e-3) if (pmc.get("kernel_cycles") and lone_ms) else 2.4e9
             clock_hz = min(max(clock_hz, 1.0e9), 2.4e9)
             hbm_rate = pmc["hbm_traffic_bytes_per_launch"] * args.steps / elapsed / 1e9
-            roof["hbm_counter"] = {"bytes_per_launch": int(pmc["hbm_traffic_bytes_per_launch"]), "achieved": round(hbm_rate, 1), "frac": round(hbm_rate / HBM_PEAK_GBS, 4),
-                                   "what": "rocprofv3 --pmc FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE per launch of this kernel source (profiles/pmc_bench_latest.json, hash %s) x launches timed / elapsed; includes Infinity-Cache hits" % pmc["source_hash"]}
+            roof["hbm_counter_from_profile"] = {"bytes_per_launch": int(pmc["hbm_traffic_bytes_per_launch"]), "achieved": round(hbm_rate, 1), "frac": round(hbm_rate / HBM_PEAK_GBS, 4),
+                                                "frac_of_copy": round(hbm_rate / bw[0], 4) if bw_ok and bw[0] > 0 else None,
+                                                "what": "rocprofv3 --pmc FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE per launch of this kernel source (profiles/pmc_bench_latest.json, hash %s) x launches timed / elapsed; includes Infinity-Cache hits" % pmc["source_hash"]}
             if "SQ_INSTS_VALU" in c:
                 valu_s = c["SQ_INSTS_VALU"] * 4.0 / (NUM_SIMDS * clock_hz)
-                roof["valu"] = {"wave_instructions_per_launch": int(c["SQ_INSTS_VALU"]), "cycles_per_instruction": 4, "clock_ghz": round(clock_hz / 1e9, 3),
-                                "issue_ms": round(valu_s * 1e3, 4), "frac": round(valu_s * args.steps / elapsed, 4),
-                                "what": "SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x clock) per launch x launches timed / elapsed: the share of the timed region in which the VALU pipes issue "
-                                        "(~4 cycles per wave instruction: tools/valu_bench.hip; clock = kernel cycles of the PMC run / duration of a lone launch, capped at 2.4 GHz)"}
+                roof["valu_from_profile"] = {"wave_instructions_per_launch": int(c["SQ_INSTS_VALU"]), "cycles_per_instruction": 4, "clock_ghz": round(clock_hz / 1e9, 3),
+                                             "issue_ms": round(valu_s * 1e3, 4), "frac": round(valu_s * args.steps / elapsed, 4),
+                                             "what": "SQ_INSTS_VALU (profiles/pmc_bench_latest.json) x 4 cycles / (1024 SIMDs x clock) per launch x launches timed / elapsed: the share of the timed region in which the VALU pipes issue "
+                                                     "(~4 cycles per wave instruction: tools/valu_bench.hip; clock = kernel cycles of the PMC run / duration of a lone launch, capped at 2.4 GHz)"}
         else:
             roof["pmc_note"] = pmc_note
         out = {
-            "metric": ("Mrays/s (shadow rays, any-hit) on crown, 16 Mi rays sharded" if shadow else "Mrays/s (incoherent diffuse, closest-hit) on crown"),
+            "metric": ("Mrays/s (shadow rays, any-hit) on crown, 16 Mi rays sharded" if shadow else
+                       "Mrays/s (incoherent diffuse, closest-hit) on crown" + (", %d batches of 2^20 rays in flight (one batch at a time: serial.value)" % len(tstreams) if len(tstreams) > 1 else "")),
             "value": round(value, 2), "unit": "Mrays/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "n_gpus": world, "ranks": world, "distinct_gpus": min(world, ngpu), "rccl_ranks": (world if comm is not None else 0), "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
             "higher_is_better": True, "scaling": "strong" if shadow else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic" if not scene_path else "file",
             "config": {"workload": ("configs[3]: %s, %d triangles, %d shadow rays (16 per hit point) in total, %d per GPU, rtcOccluded1MDevice, rays + BVH resident in HBM, results %s"
                                     % (scene_name, ntri, total_rays, M, "packed and all-gathered over RCCL" if comm is not None else "left in the per-rank buffers")) if shadow else
@@ -548,6 +664,10 @@ def main():
             out["pipelined" if npipe > 1 else "serial"] = pipelined
         if e2e:
             out["end_to_end"] = e2e
+        if latency:
+            out["per_call_latency"] = latency
+        if multi:
+            out["in_process_multi_gpu"] = multi
         if gather is not None:
             out["gather"] = gather
         if gather_check is not None:
@@ -560,6 +680,11 @@ def main():
                 cb, ref_traced = cpu_baseline(meshes, rays, any_hit=shadow)
                 if cb:
                     out["cpu_baseline"] = cb
+                if not shadow:
+                    try:
+                        out["reference_visits"] = reference_visits(meshes, rays)
+                    except Exception as e:                    # noqa: BLE001
+                        out["reference_visits"] = {"error": repr(e)}
                 if ref_traced is not None and not shadow:        # parity at full size against the real reference, ties classified
                     try:
                         out["parity_vs_reference"] = classify_parity(result, ref_traced, rays, meshes)

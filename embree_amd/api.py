@@ -45,10 +45,10 @@ rtcTraversableOccluded1 rtcTraversableOccluded4 rtcTraversableOccluded8 rtcTrave
 rtcIntersect1M rtcOccluded1M rtcIntersect1MDevice rtcOccluded1MDevice""".split()
 MI355_SYMBOLS = """mi355_default_build_params mi355_last_error mi355_device_count mi355_device_name mi355_bvh_build
 mi355_bvh_destroy mi355_bvh_build_instanced mi355_bvh_refit mi355_release_build_scratch mi355_bvh_get_info mi355_bvh_download mi355_trace_prepare mi355_trace_closest mi355_trace_any
-mi355_trace_closest_packet mi355_trace_any_packet mi355_trace_stats mi355_trace_timed mi355_trace_status mi355_malloc mi355_free mi355_memcpy_h2d
+mi355_trace_query mi355_trace_closest_packet mi355_trace_any_packet mi355_trace_stats mi355_trace_timed mi355_trace_status mi355_malloc mi355_free mi355_memcpy_h2d
 mi355_memcpy_d2h mi355_synchronize mi355_device_synchronize mi355_memcpy_d2d_async mi355_stream_create
 mi355_stream_destroy mi355_event_create mi355_event_record mi355_event_elapsed_ms mi355_event_destroy
-mi355_comm_unique_id mi355_comm_init mi355_comm_destroy mi355_comm_allgather mi355_comm_gather mi355_pack_hits mi355_pack_occluded mi355_stream_query""".split()
+mi355_comm_unique_id mi355_comm_init mi355_comm_destroy mi355_comm_allgather mi355_comm_gather mi355_pack_hits mi355_pack_occluded mi355_stream_query mi355_measure_bandwidth""".split()
 
 
 class FilterArguments(C.Structure):            # RTCFilterFunctionNArguments
@@ -58,6 +58,8 @@ class FilterArguments(C.Structure):            # RTCFilterFunctionNArguments
 
 FILTER_FN = C.CFUNCTYPE(None, C.POINTER(FilterArguments))
 RTC_RAY_QUERY_FLAG_INVOKE_ARGUMENT_FILTER = 2
+RTC_RAY_QUERY_FLAG_COHERENT = 1 << 16
+RTC_DEVICE_PROPERTY_GPU_COUNT = 143
 
 
 class QueryArguments(C.Structure):             # RTCIntersectArguments / RTCOccludedArguments (same layout)
@@ -202,6 +204,9 @@ def load():
     L.mi355_trace_prepare.argtypes = [vp, vp]
     L.mi355_trace_closest.argtypes = [vp, vp, u32, sz, vp]
     L.mi355_trace_any.argtypes = [vp, vp, u32, sz, vp]
+    L.mi355_trace_query.argtypes = [vp, vp, u32, sz, C.c_int, u32, vp]
+    L.rtcGetSceneReplicaBVH_mi355.restype = vp
+    L.rtcGetSceneReplicaBVH_mi355.argtypes = [vp, u32]
     L.mi355_trace_timed.argtypes = [vp, vp, u32, sz, C.c_int, vp, vp, vp]
     L.mi355_trace_stats.argtypes = [vp, vp, u32, sz, C.c_int, C.POINTER(C.c_uint64)]
     L.mi355_trace_status.argtypes = [vp, vp, C.POINTER(u32)]
@@ -229,6 +234,7 @@ def load():
     L.mi355_pack_hits.argtypes = [vp, u32, sz, vp, vp]
     L.mi355_pack_occluded.argtypes = [vp, u32, sz, vp, vp]
     L.mi355_stream_query.argtypes = [vp]
+    L.mi355_measure_bandwidth.argtypes = [C.c_int, sz, C.c_int, C.POINTER(C.c_double)]
     _lib = L
     return L
 
@@ -263,6 +269,9 @@ class Device:
         e = self.get_error()
         if e != RTC_ERROR_NONE:
             raise RTCErrorException(e, self.last_message())
+
+    def gpu_count(self):
+        return int(self.L.rtcGetDeviceProperty(self.h, RTC_DEVICE_PROPERTY_GPU_COUNT))
 
     def name(self):
         buf = C.create_string_buffer(256)
@@ -483,13 +492,17 @@ class Scene:
         self.dev.check()
 
     # -- queries on device memory --
-    def intersect1M_device(self, dptr, count, stride=96, stream=None):
-        self.L.rtcIntersect1MDevice(self.h, dptr, count, stride, None, stream)
+    def intersect1M_device(self, dptr, count, stride=96, stream=None, args=None):
+        self.L.rtcIntersect1MDevice(self.h, dptr, count, stride, C.addressof(args) if args is not None else None, stream)
         self.dev.check()
 
-    def occluded1M_device(self, dptr, count, stride=48, stream=None):
-        self.L.rtcOccluded1MDevice(self.h, dptr, count, stride, None, stream)
+    def occluded1M_device(self, dptr, count, stride=48, stream=None, args=None):
+        self.L.rtcOccluded1MDevice(self.h, dptr, count, stride, C.addressof(args) if args is not None else None, stream)
         self.dev.check()
+
+    def replica_bvh(self, k):
+        """the tree on replica k of a device over several GPUs (rtcNewDevice("gpus=N")); None beyond the last"""
+        return self.L.rtcGetSceneReplicaBVH_mi355(self.h, k)
 
     def trace_status(self, stream=None):
         """mi355_trace_status: synchronises `stream`, returns (and clears) the flags the traversal kernels raised on it (0 = no work was dropped)."""

@@ -18,7 +18,10 @@
 #include <map>
 #include <mutex>
 #include <set>
+#include <exception>
+#include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 #include "../../include/embree4/rtcore.h"
 #include "../../include/embree_amd_hip.h"
@@ -42,7 +45,16 @@ struct RefCounted {
 };
 
 struct Device : RefCounted {
-  int gpu = 0;
+  int gpu = 0;                                               // first GPU (config key gpu=)
+  // "gpus=N": ONE RTCDevice over N GPUs of the node (the north star's "ray batches shard embarrassingly across the 8 GPUs of one node with the BVH
+  // replicated"; the reference shows a GPU device sitting behind the same RTCDevice in Scene::commit_task, kernels/common/scene.cpp:866-872).  Every
+  // geometry buffer and every committed tree exists once per GPU (the build is deterministic: bit-identical replicas, nothing to broadcast); the batched
+  // queries split their ray range contiguously over the replicas, one host thread per GPU, and every shard's results go straight into the caller's
+  // array (no collective when the consumer is the host).  gpus[k] = HIP ordinal of replica k; "gpu_oversubscribe=1" lets replicas share a
+  // GPU when the box has fewer than N (how the sharded path is tested on a 1-GPU box).
+  std::vector<int> gpus{0};
+  int wantGpus = 1; bool oversubscribe = false;
+  unsigned shardMin = 16384;                                 // host-array / device-array batches of fewer rays than this per replica stay on replica 0 (config key shard_min)
   int verbose = 0;
   bool benchmark = false;
   unsigned pipelineMin = 262144, pipelineChunk = 65536;   // host-array queries of at least pipelineMin rays are cut into chunks of pipelineChunk rays (config keys host_pipeline_min / host_pipeline_chunk)
@@ -58,12 +70,15 @@ struct Device : RefCounted {
   static std::mutex& countMutex() { static std::mutex m; return m; }
   static std::map<int, int>& liveOnGpu() { static std::map<int, int> c; return c; }
   bool counted = false;
-  void countIn() { std::lock_guard<std::mutex> lk(countMutex()); liveOnGpu()[gpu]++; counted = true; }
+  void countIn() { std::lock_guard<std::mutex> lk(countMutex()); for (int g : gpus) liveOnGpu()[g]++; counted = true; }
   ~Device() override {
     if (!counted) return;
-    bool last; { std::lock_guard<std::mutex> lk(countMutex()); last = --liveOnGpu()[gpu] == 0; }
-    if (last) mi355_release_build_scratch(gpu);
+    for (int g : gpus) {
+      bool last; { std::lock_guard<std::mutex> lk(countMutex()); last = --liveOnGpu()[g] == 0; }
+      if (last) mi355_release_build_scratch(g);
+    }
   }
+  size_t numReplicas() const { return gpus.size(); }
   // Device::memoryMonitor (kernels/common/device.cpp:332-345): every allocation the library keeps on the caller's behalf (buffers it owns, their
   // device copies, the committed BVH) is announced with +bytes before and -bytes after; a callback answering false fails the request with
   // RTC_ERROR_OUT_OF_MEMORY.  Build scratch is transient and not announced.
@@ -100,7 +115,9 @@ void core_check(int rc, const char* what) {
 
 struct Buffer : RefCounted {
   Device* device; size_t bytes; char* host = nullptr; bool ownsHost = false;
-  char* dev = nullptr; bool ownsDev = false; bool devDirty = true;
+  char* dev = nullptr; bool ownsDev = false; bool devDirty = true;   // the copy on the device's first GPU (or the application's own device memory there)
+  std::vector<char*> peers;                                  // "gpus=N": the copies on replicas 1 .. N-1 (always owned)
+  char* devAt(size_t k) const { return k == 0 ? dev : (k - 1 < peers.size() ? peers[k - 1] : nullptr); }
   Buffer(Device* d, size_t n, void* shared, void* sharedDev = nullptr) : device(d), bytes(n) {
     d->retain();
     if (shared) host = (char*)shared;
@@ -113,17 +130,34 @@ struct Buffer : RefCounted {
   ~Buffer() override {
     if (ownsHost) { free(host); device->memoryMonitor(-(ssize_t)bytes, true); }
     if (ownsDev && dev) { hipSetDevice(device->gpu); hipFree(dev); device->memoryMonitor(-(ssize_t)bytes, true); }
+    for (size_t k = 0; k < peers.size(); k++) if (peers[k]) { hipSetDevice(device->gpus[k + 1]); hipFree(peers[k]); device->memoryMonitor(-(ssize_t)bytes, true); }
     device->release();
   }
   void upload() {                                           // the reference's SYCL path copies in rtcCommitBuffer/rtcCommitGeometry too
-    if (!devDirty && dev) return;
-    hip_check(hipSetDevice(device->gpu), "hipSetDevice");
-    if (!dev) {
-      device->memoryMonitor((ssize_t)bytes, false);
-      if (hipMalloc((void**)&dev, bytes + 16) != hipSuccess) { dev = nullptr; device->memoryMonitor(-(ssize_t)bytes, true); THROW(RTC_ERROR_OUT_OF_MEMORY, "hipMalloc(geometry buffer)"); }
-      ownsDev = true;
+    const bool sharedDevMem = dev && !ownsDev;               // the application's own device memory on the first GPU: its contents are the application's business
+    if (devDirty || !dev) {
+      hip_check(hipSetDevice(device->gpu), "hipSetDevice");
+      if (!dev) {
+        device->memoryMonitor((ssize_t)bytes, false);
+        if (hipMalloc((void**)&dev, bytes + 16) != hipSuccess) { dev = nullptr; device->memoryMonitor(-(ssize_t)bytes, true); THROW(RTC_ERROR_OUT_OF_MEMORY, "hipMalloc(geometry buffer)"); }
+        ownsDev = true;
+      }
+      if (bytes) hip_check(hipMemcpy(dev, host, bytes, hipMemcpyHostToDevice), "hipMemcpy(geometry buffer)");
+    } else if (!sharedDevMem && peers.size() + 1 == device->numReplicas()) return;
+    // replicas: from the host copy, or -- memory the application shared as device memory -- from the first GPU, peer to peer (xGMI)
+    if (peers.size() + 1 < device->numReplicas()) peers.resize(device->numReplicas() - 1, nullptr);
+    for (size_t k = 0; k < peers.size(); k++) {
+      const int g = device->gpus[k + 1];
+      hip_check(hipSetDevice(g), "hipSetDevice");
+      if (!peers[k]) {
+        device->memoryMonitor((ssize_t)bytes, false);
+        if (hipMalloc((void**)&peers[k], bytes + 16) != hipSuccess) { peers[k] = nullptr; device->memoryMonitor(-(ssize_t)bytes, true); THROW(RTC_ERROR_OUT_OF_MEMORY, "hipMalloc(geometry buffer replica)"); }
+      }
+      if (!bytes) continue;
+      if (sharedDevMem) hip_check(hipMemcpyPeer(peers[k], g, dev, device->gpu, bytes), "hipMemcpyPeer(geometry buffer)");
+      else hip_check(hipMemcpy(peers[k], host, bytes, hipMemcpyHostToDevice), "hipMemcpy(geometry buffer replica)");
     }
-    if (bytes) hip_check(hipMemcpy(dev, host, bytes, hipMemcpyHostToDevice), "hipMemcpy(geometry buffer)");
+    hip_check(hipSetDevice(device->gpu), "hipSetDevice");
     devDirty = false;
   }
 };
@@ -189,49 +223,25 @@ struct Geometry : RefCounted {
   }
 };
 
-struct Scene : RefCounted {
-  Device* device;
-  std::mutex mtx;
-  std::map<unsigned, Geometry*> geoms;
-  RTCSceneFlags flags = RTC_SCENE_FLAG_NONE; RTCBuildQuality quality = RTC_BUILD_QUALITY_MEDIUM;
-  mi355_bvh_t bvh = nullptr; ssize_t bvhBytes = 0; bool committed = false, modified = true;
-  ssize_t flatBytes = 0;
-  const unsigned long long serial = ++g_geomSerial;        // (instances remember the scene they were built over by this, not by address)
-  mi355_bvh_t flat = nullptr;                               // the tree of this scene's own triangles / quads: what an instance of this scene refers to (== bvh unless the scene has instances)
-  struct BuiltFrom { unsigned id; unsigned long long g; RTCBuildQuality q; unsigned topo, data; };   // g = Geometry::serial   // what the current tree was built from: decides rebuild vs refit vs nothing to do
-  std::vector<BuiltFrom> builtFrom; unsigned builtFlags = 0;
-  struct InstFrom { unsigned id; unsigned long long g; unsigned long long object; unsigned topo, data; unsigned long long objSerial; };   // g = Geometry::serial, object = Scene::serial
-  std::vector<InstFrom> builtInst;
-  unsigned long long commitSerial = 0;                       // changes with every commit that built or refitted something (instances of this scene notice)
-  RTCBounds bounds;
-  RTCProgressMonitorFunction progress = nullptr; void* progressPtr = nullptr;
+// What a scene keeps on ONE GPU.  A device over N GPUs ("gpus=N") commits N bit-identical replicas (the build is deterministic) and shards ray batches over them.
+struct Replica {
+  int gpu = 0;
+  mi355_bvh_t bvh = nullptr; ssize_t bvhBytes = 0;          // what queries traverse (== flat unless the scene has instances)
+  mi355_bvh_t flat = nullptr; ssize_t flatBytes = 0;        // the tree of this scene's own triangles / quads: what an instance of this scene refers to
   // host-pointer query staging (device memory), one per calling thread
   static constexpr int PIPE = 4;
+  std::mutex mtx;
   hipStream_t pipe[PIPE] = {nullptr, nullptr, nullptr, nullptr};   // large host-array queries: upload, download, two compute streams (pipelined_query)
   std::vector<hipEvent_t> pipeEvents;                       // ... and two events per chunk
-  std::mutex pipeMtx;                                       // one pipelined query per scene at a time: the four streams, the events and the streams' status words are shared
+  std::mutex pipeMtx;                                       // one pipelined query per replica at a time: the four streams, the events and the streams' status words are shared
   struct Staging { char* d = nullptr; size_t cap = 0; };
   std::map<size_t, Staging> staging;
-  Scene(Device* d) : device(d) { d->retain(); setEmptyBounds(); }
-  void setEmptyBounds() {
-    bounds.lower_x = bounds.lower_y = bounds.lower_z = INFINITY; bounds.upper_x = bounds.upper_y = bounds.upper_z = -INFINITY;
-    bounds.align0 = bounds.align1 = 0;
-  }
-  ~Scene() override {
-    for (auto& kv : geoms) { kv.second->attached--; kv.second->release(); }
-    hipSetDevice(device->gpu);
-    if (bvh && bvh != flat) { mi355_bvh_destroy(bvh); device->memoryMonitor(-bvhBytes, true); }
-    if (flat) { mi355_bvh_destroy(flat); device->memoryMonitor(-flatBytes, true); }
-    for (auto& kv : staging) if (kv.second.d) hipFree(kv.second.d);
-    for (int k = 0; k < PIPE; k++) if (pipe[k]) hipStreamDestroy(pipe[k]);
-    for (hipEvent_t e : pipeEvents) hipEventDestroy(e);
-    device->release();
-  }
+  hipStream_t shardStream = nullptr; hipEvent_t shardIn = nullptr, shardOut = nullptr;   // device-array queries sharded over the replicas (sharded_device_query)
   char* stage(size_t bytes) {
     std::lock_guard<std::mutex> lk(mtx);
     Staging& s = staging[Device::threadToken()];
     if (s.cap < bytes) {
-      hip_check(hipSetDevice(device->gpu), "hipSetDevice");
+      hip_check(hipSetDevice(gpu), "hipSetDevice");
       if (s.d) hipFree(s.d);
       s.cap = bytes < 4096 ? 4096 : bytes + bytes / 4;
       s.d = nullptr;
@@ -239,20 +249,83 @@ struct Scene : RefCounted {
     }
     return s.d;
   }
+  void release_all(Device* device) {
+    hipSetDevice(gpu);
+    if (bvh && bvh != flat) { mi355_bvh_destroy(bvh); device->memoryMonitor(-bvhBytes, true); }
+    if (flat) { mi355_bvh_destroy(flat); device->memoryMonitor(-flatBytes, true); }
+    bvh = flat = nullptr;
+    for (auto& kv : staging) if (kv.second.d) hipFree(kv.second.d);
+    for (int k = 0; k < PIPE; k++) if (pipe[k]) hipStreamDestroy(pipe[k]);
+    for (hipEvent_t e : pipeEvents) hipEventDestroy(e);
+    if (shardStream) hipStreamDestroy(shardStream);
+    if (shardIn) hipEventDestroy(shardIn);
+    if (shardOut) hipEventDestroy(shardOut);
+  }
+};
+
+// runs fn(k) for every replica, one host thread per GPU (replica 0 on the calling thread); the first exception is rethrown on the caller
+template <typename F> static void for_each_replica(size_t n, F fn) {
+  if (n == 1) { fn((size_t)0); return; }
+  std::vector<std::exception_ptr> err(n);
+  std::vector<std::thread> th;
+  for (size_t k = 1; k < n; k++) th.emplace_back([&, k]() { try { fn(k); } catch (...) { err[k] = std::current_exception(); } });
+  try { fn((size_t)0); } catch (...) { err[0] = std::current_exception(); }
+  for (auto& t : th) t.join();
+  for (size_t k = 0; k < n; k++) if (err[k]) std::rethrow_exception(err[k]);
+}
+
+struct Scene : RefCounted {
+  Device* device;
+  std::mutex mtx;
+  std::map<unsigned, Geometry*> geoms;
+  RTCSceneFlags flags = RTC_SCENE_FLAG_NONE; RTCBuildQuality quality = RTC_BUILD_QUALITY_MEDIUM;
+  bool committed = false, modified = true;
+  const unsigned long long serial = ++g_geomSerial;        // (instances remember the scene they were built over by this, not by address)
+  std::vector<std::unique_ptr<Replica>> reps;               // one per GPU of the device
+  struct BuiltFrom { unsigned id; unsigned long long g; RTCBuildQuality q; unsigned topo, data; };   // what the current tree was built from: decides rebuild vs refit vs nothing to do; g = Geometry::serial
+  std::vector<BuiltFrom> builtFrom; unsigned builtFlags = 0;
+  struct InstFrom { unsigned id; unsigned long long g; unsigned long long object; unsigned topo, data; unsigned long long objSerial; };   // g = Geometry::serial, object = Scene::serial
+  std::vector<InstFrom> builtInst;
+  unsigned long long commitSerial = 0;                       // changes with every commit that built or refitted something (instances of this scene notice)
+  RTCBounds bounds;
+  RTCProgressMonitorFunction progress = nullptr; void* progressPtr = nullptr;
+  Scene(Device* d) : device(d) {
+    d->retain(); setEmptyBounds();
+    for (int g : d->gpus) { reps.emplace_back(new Replica); reps.back()->gpu = g; }
+  }
+  void setEmptyBounds() {
+    bounds.lower_x = bounds.lower_y = bounds.lower_z = INFINITY; bounds.upper_x = bounds.upper_y = bounds.upper_z = -INFINITY;
+    bounds.align0 = bounds.align1 = 0;
+  }
+  ~Scene() override {
+    for (auto& kv : geoms) { kv.second->attached--; kv.second->release(); }
+    for (auto& r : reps) r->release_all(device);
+    hipSetDevice(device->gpu);
+    device->release();
+  }
+  mi355_bvh_t bvh0() const { return reps[0]->bvh; }
+  mi355_bvh_t flat0() const { return reps[0]->flat; }
   void commit() {
     std::lock_guard<std::mutex> lk(mtx);
-    std::vector<mi355_mesh> meshes;
     for (auto& kv : geoms) {                                 // std::map => ascending geomID
       Geometry* g = kv.second;
       if (!g->enabled) continue;
       if (!g->vertices.buf || !g->indices.buf) continue;     // a mesh without buffers has no primitives
       if (!g->committed) THROW(RTC_ERROR_INVALID_OPERATION, "geometry attached to the scene was modified but not committed");
-      mi355_mesh m;
-      m.d_vertices = g->vertices.buf->dev + g->vertices.offset; m.vertex_stride = g->vertices.stride; m.num_vertices = g->vertices.num;
-      m.d_indices = g->indices.buf->dev + g->indices.offset; m.index_stride = g->indices.stride; m.num_triangles = g->indices.num;
-      m.geom_id = kv.first; m.mask = g->mask; m.quads = g->type == RTC_GEOMETRY_TYPE_QUAD ? 1u : 0u; m.reserved = 0;
-      meshes.push_back(m);
     }
+    auto meshes_of = [&](size_t k) {                         // the mesh table as replica k sees it (its own copies of the buffers)
+      std::vector<mi355_mesh> meshes;
+      for (auto& kv : geoms) {
+        Geometry* g = kv.second;
+        if (!g->enabled || !g->vertices.buf || !g->indices.buf) continue;
+        mi355_mesh m;
+        m.d_vertices = g->vertices.buf->devAt(k) + g->vertices.offset; m.vertex_stride = g->vertices.stride; m.num_vertices = g->vertices.num;
+        m.d_indices = g->indices.buf->devAt(k) + g->indices.offset; m.index_stride = g->indices.stride; m.num_triangles = g->indices.num;
+        m.geom_id = kv.first; m.mask = g->mask; m.quads = g->type == RTC_GEOMETRY_TYPE_QUAD ? 1u : 0u; m.reserved = 0;
+        meshes.push_back(m);
+      }
+      return meshes;
+    };
     if (progress && !progress(progressPtr, 0.0)) THROW(RTC_ERROR_CANCELLED, "progress monitor forced termination");
     mi355_build_params bp = device->build;
     bp.robust = (flags & RTC_SCENE_FLAG_ROBUST) ? 1u : 0u;   // scene.cpp:180-188: robust scenes get Triangle4v leaves + the Pluecker intersector
@@ -276,7 +349,8 @@ struct Scene : RefCounted {
       if (g->type != RTC_GEOMETRY_TYPE_INSTANCE || !g->enabled || !g->object) continue;
       instFrom.push_back({kv.first, g->serial, g->object->serial, g->topoCounter, g->dataCounter, g->object->commitSerial});
     }
-    if (committed && !modified && bvh && nowFlags == builtFlags && from.size() == builtFrom.size() && instFrom.size() == builtInst.size()) {   // (attach / detach set `modified`)
+    const bool haveTree = committed && reps[0]->bvh != nullptr, haveFlat = committed && reps[0]->flat != nullptr;
+    if (haveTree && !modified && nowFlags == builtFlags && from.size() == builtFrom.size() && instFrom.size() == builtInst.size()) {   // (attach / detach set `modified`)
       bool same = true;
       for (size_t i = 0; same && i < from.size(); i++) { const BuiltFrom &a = from[i], &b = builtFrom[i]; same = a.id == b.id && a.g == b.g && a.topo == b.topo && a.data == b.data; }
       for (size_t i = 0; same && i < instFrom.size(); i++) { const InstFrom &a = instFrom[i], &b = builtInst[i]; same = a.id == b.id && a.g == b.g && a.object == b.object && a.topo == b.topo && a.data == b.data && a.objSerial == b.objSerial; }
@@ -284,64 +358,80 @@ struct Scene : RefCounted {
     }
     // Refit instead of rebuild (the reference: BVHNRefitT for RTC_BUILD_QUALITY_REFIT meshes of a dynamic scene, kernels/bvh/bvh_refit.cpp):
     // same geometries with the same buffer bindings and index data, and every geometry whose vertices / mask changed asks for REFIT.
-    bool refit = flat && committed && from.size() == builtFrom.size() && nowFlags == builtFlags && !from.empty();
+    bool refit = haveFlat && from.size() == builtFrom.size() && nowFlags == builtFlags && !from.empty();
     for (size_t i = 0; refit && i < from.size(); i++) {
       const BuiltFrom &a = from[i], &b = builtFrom[i];
       refit = a.id == b.id && a.g == b.g && a.topo == b.topo && (a.data == b.data || a.q == RTC_BUILD_QUALITY_REFIT);
     }
-    mi355_bvh_info info;
-    bool done = false;
+    bool keepFlat = false;
     {                                                        // the scene's own triangles / quads are what they were: only instances moved, keep the flat tree
-      bool flatSame = flat && committed && from.size() == builtFrom.size() && nowFlags == builtFlags;
+      bool flatSame = haveFlat && from.size() == builtFrom.size() && nowFlags == builtFlags;
       for (size_t i = 0; flatSame && i < from.size(); i++) { const BuiltFrom &a = from[i], &b = builtFrom[i]; flatSame = a.id == b.id && a.g == b.g && a.topo == b.topo && a.data == b.data; }
-      if (flatSame) { done = true; refit = false; }
+      if (flatSame) { keepFlat = true; refit = false; }
     }
-    if (refit) { mi355_bvh_get_info(flat, &info); refit = info.bytes_refit != 0; }   // the tree was built to be refitted
-    if (refit) {
-      const int rc = mi355_bvh_refit(flat, meshes.data(), (uint32_t)meshes.size(), nullptr);
-      if (rc == 0) done = true;
-      else if (rc != MI355_REFIT_IMPOSSIBLE) { committed = false; if (rc != MI355_REFIT_BROKEN) core_check(rc, "BVH refit"); }   // a refit that stopped half way leaves no usable tree
-    }
-    if (!done) {
-      mi355_bvh_t nb = nullptr;
-      core_check(mi355_bvh_build(device->gpu, meshes.data(), (uint32_t)meshes.size(), &bp, nullptr, &nb), "BVH build");
-      mi355_bvh_get_info(nb, &info);
-      const ssize_t newBytes = (ssize_t)(info.bytes_nodes + info.bytes_triangles + info.bytes_refit);
-      try { device->memoryMonitor(newBytes, false); } catch (...) { mi355_bvh_destroy(nb); throw; }   // the old tree stays in place
-      if (flat) { mi355_bvh_destroy(flat); device->memoryMonitor(-flatBytes, true); if (bvh == flat) bvh = nullptr; }
-      flat = nb; flatBytes = newBytes;
-    }
-    builtFrom = from; builtFlags = nowFlags;
+    if (refit) { mi355_bvh_info fi; mi355_bvh_get_info(reps[0]->flat, &fi); refit = fi.bytes_refit != 0; }   // the tree was built to be refitted
     // ---- instances (RTC_GEOMETRY_TYPE_INSTANCE, one level): top tree over their world boxes + copies of the instanced scenes' flat trees
-    std::vector<mi355_instance> insts;
+    struct InstGeom { Geometry* g; unsigned id; };
+    std::vector<InstGeom> instGeoms;
     for (auto& kv : geoms) {
       Geometry* g = kv.second;
       if (g->type != RTC_GEOMETRY_TYPE_INSTANCE || !g->enabled || !g->object) continue;
       if (!g->committed) THROW(RTC_ERROR_INVALID_OPERATION, "geometry attached to the scene was modified but not committed");
       if (g->object == this) THROW(RTC_ERROR_INVALID_OPERATION, "a scene cannot instance itself");
-      if (!g->object->committed || !g->object->flat) THROW(RTC_ERROR_INVALID_OPERATION, "the instanced scene has to be committed before the scene that instances it");
-      mi355_instance in; in.object = g->object->flat;           // a second level inside the object is dropped, like the reference does at RTC_MAX_INSTANCE_LEVEL_COUNT = 1 (instance_stack.h:36-47)
-      memcpy(in.local2world, g->l2w, sizeof(in.local2world)); in.inst_id = kv.first; in.mask = g->mask;
-      insts.push_back(in);
+      if (!g->object->committed || !g->object->flat0()) THROW(RTC_ERROR_INVALID_OPERATION, "the instanced scene has to be committed before the scene that instances it");
+      instGeoms.push_back({g, kv.first});
     }
-    if (bvh && bvh != flat) { mi355_bvh_destroy(bvh); device->memoryMonitor(-bvhBytes, true); bvhBytes = 0; }
-    bvh = flat;
-    if (!insts.empty()) {
-      mi355_bvh_t nb = nullptr;
-      core_check(mi355_bvh_build_instanced(device->gpu, flat, insts.data(), (uint32_t)insts.size(), &bp, nullptr, &nb), "instanced BVH build");
-      mi355_bvh_get_info(nb, &info);
-      const ssize_t newBytes = (ssize_t)(info.bytes_nodes + info.bytes_triangles);
-      try { device->memoryMonitor(newBytes, false); } catch (...) { mi355_bvh_destroy(nb); committed = false; throw; }
-      bvh = nb; bvhBytes = newBytes;
-    }
-    mi355_bvh_get_info(bvh, &info);
+    // ---- every replica does the same thing on its own GPU, side by side (one host thread per GPU; the build is deterministic, so the replicas come out bit-identical)
+    std::vector<int> didRefit(reps.size(), 0);
+    std::atomic<bool> refitBroken{false};
+    try {
+    for_each_replica(reps.size(), [&](size_t k) {
+      Replica& r = *reps[k];
+      hip_check(hipSetDevice(r.gpu), "hipSetDevice");
+      const std::vector<mi355_mesh> meshes = meshes_of(k);
+      mi355_bvh_info info;
+      bool done = keepFlat;
+      if (refit) {
+        const int rc = mi355_bvh_refit(r.flat, meshes.data(), (uint32_t)meshes.size(), nullptr);
+        if (rc == 0) { done = true; didRefit[k] = 1; }
+        else if (rc != MI355_REFIT_IMPOSSIBLE) { refitBroken = true; if (rc != MI355_REFIT_BROKEN) core_check(rc, "BVH refit"); }   // a refit that stopped half way leaves no usable tree
+      }
+      if (!done) {
+        mi355_bvh_t nb = nullptr;
+        core_check(mi355_bvh_build(r.gpu, meshes.data(), (uint32_t)meshes.size(), &bp, nullptr, &nb), "BVH build");
+        mi355_bvh_get_info(nb, &info);
+        const ssize_t newBytes = (ssize_t)(info.bytes_nodes + info.bytes_triangles + info.bytes_refit);
+        try { device->memoryMonitor(newBytes, false); } catch (...) { mi355_bvh_destroy(nb); throw; }   // the old tree stays in place
+        if (r.flat) { mi355_bvh_destroy(r.flat); device->memoryMonitor(-r.flatBytes, true); if (r.bvh == r.flat) r.bvh = nullptr; }
+        r.flat = nb; r.flatBytes = newBytes;
+      }
+      if (r.bvh && r.bvh != r.flat) { mi355_bvh_destroy(r.bvh); device->memoryMonitor(-r.bvhBytes, true); r.bvhBytes = 0; }
+      r.bvh = r.flat;
+      if (!instGeoms.empty()) {
+        std::vector<mi355_instance> insts;
+        for (const InstGeom& ig : instGeoms) {
+          mi355_instance in; in.object = ig.g->object->reps[k]->flat;   // a second level inside the object is dropped, like the reference does at RTC_MAX_INSTANCE_LEVEL_COUNT = 1 (instance_stack.h:36-47)
+          memcpy(in.local2world, ig.g->l2w, sizeof(in.local2world)); in.inst_id = ig.id; in.mask = ig.g->mask;
+          insts.push_back(in);
+        }
+        mi355_bvh_t nb = nullptr;
+        core_check(mi355_bvh_build_instanced(r.gpu, r.flat, insts.data(), (uint32_t)insts.size(), &bp, nullptr, &nb), "instanced BVH build");
+        mi355_bvh_get_info(nb, &info);
+        const ssize_t newBytes = (ssize_t)(info.bytes_nodes + info.bytes_triangles);
+        try { device->memoryMonitor(newBytes, false); } catch (...) { mi355_bvh_destroy(nb); throw; }
+        r.bvh = nb; r.bvhBytes = newBytes;
+      }
+    });
+    } catch (...) { if (refitBroken) committed = false; throw; }   // (a refit that stopped half way and a rebuild that failed: no usable tree)
+    builtFrom = from; builtFlags = nowFlags;
+    mi355_bvh_info info; mi355_bvh_get_info(reps[0]->bvh, &info);
     setEmptyBounds();
     if (info.num_triangles) {
       bounds.lower_x = info.bounds_lower[0]; bounds.lower_y = info.bounds_lower[1]; bounds.lower_z = info.bounds_lower[2];
       bounds.upper_x = info.bounds_upper[0]; bounds.upper_y = info.bounds_upper[1]; bounds.upper_z = info.bounds_upper[2];
     }
     if (device->verbose >= 2 || device->benchmark)           // BVHN::postBuild prints BENCHMARK_BUILD, bvh.cpp:175-179
-      printf("%s %.3f ms %.3f Mprims/s sah %.4f nodes %llu tris %llu bytes %llu\n", done ? "BENCHMARK_REFIT" : "BENCHMARK_BUILD", info.build_ms,
+      printf("%s %.3f ms %.3f Mprims/s sah %.4f nodes %llu tris %llu bytes %llu\n", (keepFlat || didRefit[0]) ? "BENCHMARK_REFIT" : "BENCHMARK_BUILD", info.build_ms,
              info.build_ms > 0 ? info.num_triangles / (info.build_ms * 1e3) : 0.0, info.sah, (unsigned long long)info.num_nodes,
              (unsigned long long)info.num_triangles, (unsigned long long)(info.bytes_nodes + info.bytes_triangles));
     if (progress) progress(progressPtr, 1.0);
@@ -368,6 +458,9 @@ void parse_config(Device* d, const char* cfg) {
     if (k == "verbose") d->verbose = atoi(v.c_str());
     else if (k == "benchmark") d->benchmark = atoi(v.c_str()) != 0;
     else if (k == "gpu") d->gpu = atoi(v.c_str());
+    else if (k == "gpus") d->wantGpus = atoi(v.c_str());                                              // one RTCDevice over N GPUs: replicated BVH, sharded ray batches
+    else if (k == "gpu_oversubscribe") d->oversubscribe = atoi(v.c_str()) != 0;
+    else if (k == "shard_min") d->shardMin = atol(v.c_str()) >= 1 ? (unsigned)atol(v.c_str()) : 1u;
     else if (k == "max_leaf" || k == "max_triangles_per_leaf") d->build.max_leaf = (uint32_t)atoi(v.c_str());
     else if (k == "min_leaf") d->build.min_leaf = (uint32_t)atoi(v.c_str());
     else if (k == "leaf_block_shift") d->build.sah_block_shift = (uint32_t)atoi(v.c_str());
@@ -390,9 +483,9 @@ void check_query_args(const RTCFilterFunctionN filter, const void* callback, boo
   if (callback) THROW(RTC_ERROR_INVALID_OPERATION, "user-geometry callbacks are not supported (no user geometries on the GPU path)");
   if (filter && !hostEntry) THROW(RTC_ERROR_INVALID_OPERATION, "a filter callback is a host function: use the host-array entry points (rtcIntersect1/4/8/16/1M), not the device-pointer ones");
 }
-mi355_bvh_t committed_bvh(Scene* s) {
-  if (!s->committed || !s->bvh) THROW(RTC_ERROR_INVALID_OPERATION, "scene not committed");   // missing_rtcCommit, scene.cpp:66
-  return s->bvh;
+mi355_bvh_t committed_bvh(Scene* s, size_t k = 0) {
+  if (!s->committed || !s->reps[k]->bvh) THROW(RTC_ERROR_INVALID_OPERATION, "scene not committed");   // missing_rtcCommit, scene.cpp:66
+  return s->reps[k]->bvh;
 }
 
 // the kernels' safety nets (iteration cap, stack bound) drop work rather than hang; a blocking query that ran into one reports it instead of returning a wrong answer
@@ -402,24 +495,28 @@ static void check_trace_status(mi355_bvh_t b, hipStream_t q) {
   if (flags & MI355_TRACE_ITER_CAP_HIT) THROW(RTC_ERROR_UNKNOWN, "traversal stopped at its iteration cap: results are incomplete");
   if (flags & MI355_TRACE_STACK_OVERFLOW) THROW(RTC_ERROR_UNKNOWN, "traversal stack overflow: results are incomplete");
 }
+static int trace_launch(mi355_bvh_t b, void* d, unsigned n, size_t stride, bool any, unsigned qflags, hipStream_t q) {
+  return mi355_trace_query(b, d, n, stride, any ? 1 : 0, qflags, q);
+}
 
 // Large host arrays: the caller's array is pinned for the duration of the call and cut into chunks; ONE stream uploads them one after the other, ONE
 // downloads them, the traversal of chunk k runs on one of two compute streams between "chunk k is up" and "chunk k may go down" (an event each).  Both
 // directions of the link are busy all the time that way (tests/gpu_pcie.py: upload + download streams alone 2.4 ms for 96 MB each way; chunks that go round
 // k streams, each doing its own H2D - kernel - D2H: 3.3 ms and up, the copy engines then serve one direction at a time for long stretches).
-// Returns false when the array cannot be pinned (the plain path takes over).
-static bool pipelined_query(Scene* s, mi355_bvh_t b, char* data, char* d, unsigned M, size_t stride, bool any, size_t bytes) {
-  if (hipHostRegister(data, bytes, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); return false; }
-  struct Unpin { void* p; ~Unpin() { hipHostUnregister(p); } } unpin{data};
-  std::lock_guard<std::mutex> pipeLock(s->pipeMtx);         // (another thread's pipelined query would wait on my events and could read my status words)
+// Returns false when the array cannot be pinned (the plain path takes over).  `pinned`: the caller has pinned the whole array already (sharded queries).
+static bool pipelined_query(Scene* s, Replica& r, char* data, char* d, unsigned M, size_t stride, bool any, unsigned qflags, size_t bytes, bool pinned) {
+  if (!pinned && hipHostRegister(data, bytes, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); return false; }
+  struct Unpin { void* p; ~Unpin() { if (p) hipHostUnregister(p); } } unpin{pinned ? nullptr : data};
+  std::lock_guard<std::mutex> pipeLock(r.pipeMtx);          // (another thread's pipelined query would wait on my events and could read my status words)
+  mi355_bvh_t b = r.bvh;
   const size_t rec = any ? 48 : 96;
   const unsigned chunk = s->device->pipelineChunk, nchunks = (M + chunk - 1u) / chunk;
   hipStream_t up, down, comp[2];
   std::vector<hipEvent_t> ev;
-  { std::lock_guard<std::mutex> lk(s->mtx);
-    for (int k = 0; k < Scene::PIPE; k++) if (!s->pipe[k]) hip_check(hipStreamCreateWithFlags(&s->pipe[k], hipStreamNonBlocking), "hipStreamCreate");
-    while (s->pipeEvents.size() < 2u * (size_t)nchunks) { hipEvent_t e; hip_check(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate"); s->pipeEvents.push_back(e); }
-    up = s->pipe[0]; down = s->pipe[1]; comp[0] = s->pipe[2]; comp[1] = s->pipe[3]; ev = s->pipeEvents; }
+  { std::lock_guard<std::mutex> lk(r.mtx);
+    for (int k = 0; k < Replica::PIPE; k++) if (!r.pipe[k]) hip_check(hipStreamCreateWithFlags(&r.pipe[k], hipStreamNonBlocking), "hipStreamCreate");
+    while (r.pipeEvents.size() < 2u * (size_t)nchunks) { hipEvent_t e; hip_check(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate"); r.pipeEvents.push_back(e); }
+    up = r.pipe[0]; down = r.pipe[1]; comp[0] = r.pipe[2]; comp[1] = r.pipe[3]; ev = r.pipeEvents; }
   unsigned c = 0;
   for (unsigned first = 0; first < M; first += chunk, c++) {
     const unsigned n = M - first < chunk ? M - first : chunk;
@@ -427,7 +524,7 @@ static bool pipelined_query(Scene* s, mi355_bvh_t b, char* data, char* d, unsign
     hipStream_t q = comp[c & 1u];
     hip_check(hipMemcpyAsync(d + ofs, data + ofs, nb, hipMemcpyHostToDevice, up), "hipMemcpyAsync(rays H2D)");
     hip_check(hipEventRecord(ev[2u * c], up), "hipEventRecord"); hip_check(hipStreamWaitEvent(q, ev[2u * c], 0), "hipStreamWaitEvent");
-    core_check(any ? mi355_trace_any(b, d + ofs, n, stride, q) : mi355_trace_closest(b, d + ofs, n, stride, q), "trace");
+    core_check(trace_launch(b, d + ofs, n, stride, any, qflags, q), "trace");
     hip_check(hipEventRecord(ev[2u * c + 1u], q), "hipEventRecord"); hip_check(hipStreamWaitEvent(down, ev[2u * c + 1u], 0), "hipStreamWaitEvent");
     hip_check(hipMemcpyAsync(data + ofs, d + ofs, nb, hipMemcpyDeviceToHost, down), "hipMemcpyAsync(rays D2H)");
   }
@@ -461,7 +558,7 @@ static bool scene_has_filters(Scene* s, const RTCFilterFunctionN argFilter, unsi
   }
   return false;
 }
-static void plain_query(Scene* s, void* data, unsigned M, size_t stride, bool any);
+static void plain_query(Scene* s, void* data, unsigned M, size_t stride, bool any, unsigned qflags);
 static void filtered_query(Scene* s, void* data, unsigned M, size_t stride, bool any, RTCFilterFunctionN argFilter, unsigned qflags, RTCRayQueryContext* uctx) {
   for (auto& kv : s->geoms) if (kv.second->type == RTC_GEOMETRY_TYPE_INSTANCE && kv.second->enabled) THROW(RTC_ERROR_INVALID_OPERATION, "filter callbacks are not supported in scenes with instances");
   RTCRayQueryContext defctx; rtcInitRayQueryContext(&defctx);
@@ -477,7 +574,7 @@ static void filtered_query(Scene* s, void* data, unsigned M, size_t stride, bool
   unsigned n = M;
   for (unsigned round = 0; n != 0u; round++) {
     if (round >= 4096u) THROW(RTC_ERROR_UNKNOWN, "filter callbacks rejected 4096 candidates in a row along one ray");
-    plain_query(s, work.data(), n, sizeof(RTCRayHit), false);
+    plain_query(s, work.data(), n, sizeof(RTCRayHit), false, 0u);
     unsigned m = 0;
     for (unsigned k = 0; k < n; k++) {
       RTCRayHit& w = work[k];
@@ -512,17 +609,72 @@ static void filtered_query(Scene* s, void* data, unsigned M, size_t stride, bool
   }
 }
 
-// host-pointer AoS query: upload, trace, download the mutable parts
-static void plain_query(Scene* s, void* data, unsigned M, size_t stride, bool any) {
-  mi355_bvh_t b = committed_bvh(s);
+// host-pointer AoS query on ONE replica: upload, trace, download
+static void replica_query(Scene* s, size_t k, char* data, unsigned M, size_t stride, bool any, unsigned qflags, bool pinned) {
+  Replica& r = *s->reps[k];
+  mi355_bvh_t b = committed_bvh(s, k);
+  hip_check(hipSetDevice(r.gpu), "hipSetDevice");
   const size_t rec = any ? 48 : 96;
   const size_t bytes = (size_t)(M - 1) * stride + rec;
-  char* d = s->stage(bytes);
-  if (M >= s->device->pipelineMin && pipelined_query(s, b, (char*)data, d, M, stride, any, bytes)) return;
+  char* d = r.stage(bytes);
+  if (M >= s->device->pipelineMin && pipelined_query(s, r, data, d, M, stride, any, qflags, bytes, pinned)) return;
   hip_check(hipMemcpy(d, data, bytes, hipMemcpyHostToDevice), "hipMemcpy(rays H2D)");
-  core_check(any ? mi355_trace_any(b, d, M, stride, nullptr) : mi355_trace_closest(b, d, M, stride, nullptr), "trace");
+  core_check(trace_launch(b, d, M, stride, any, qflags, nullptr), "trace");
   hip_check(hipMemcpy(data, d, bytes, hipMemcpyDeviceToHost), "hipMemcpy(rays D2H)");
   check_trace_status(b, nullptr);
+}
+// contiguous ray range of replica k out of n ([k M / n, (k + 1) M / n); embree_amd/shard.py shard_range is the same formula)
+static inline unsigned shard_begin(unsigned M, size_t k, size_t n) { return (unsigned)(((unsigned long long)M * k) / n); }
+// host-pointer AoS query: on one GPU, or -- device over N GPUs, batch large enough -- the ray range split contiguously over the replicas, one host thread per GPU,
+// every shard uploaded to / traced on / downloaded from its own GPU straight into the caller's array (no collective: the consumer is the host)
+static void plain_query(Scene* s, void* data, unsigned M, size_t stride, bool any, unsigned qflags = 0) {
+  const size_t n = s->reps.size();
+  if (n == 1 || M < s->device->shardMin * n) { replica_query(s, 0, (char*)data, M, stride, any, qflags, false); return; }
+  const size_t rec = any ? 48 : 96, bytes = (size_t)(M - 1) * stride + rec;
+  const bool pinned = hipHostRegister(data, bytes, hipHostRegisterPortable) == hipSuccess;    // once, for all GPUs (portable: every device's copies may use it)
+  if (!pinned) (void)hipGetLastError();
+  struct Unpin { void* p; ~Unpin() { if (p) hipHostUnregister(p); } } unpin{pinned ? data : nullptr};
+  for_each_replica(n, [&](size_t k) {
+    const unsigned lo = shard_begin(M, k, n), hi = shard_begin(M, k + 1, n);
+    if (hi > lo) replica_query(s, k, (char*)data + (size_t)lo * stride, hi - lo, stride, any, qflags, pinned);
+  });
+  hip_check(hipSetDevice(s->device->gpu), "hipSetDevice");
+}
+// device-array query on a device over N GPUs: the array lives on the first GPU; shards 1 .. N-1 travel peer to peer (xGMI) to their replicas' staging
+// areas and back, each on its replica's own stream, fenced against the caller's stream by events: asynchronous like the single-GPU form.
+static void sharded_device_query(Scene* s, char* d, unsigned M, size_t stride, bool any, unsigned qflags, hipStream_t stream) {
+  const size_t n = s->reps.size(), rec = any ? 48 : 96;
+  Replica& r0 = *s->reps[0];
+  std::lock_guard<std::mutex> enqueueLock(r0.pipeMtx);      // the fence events are per replica: one thread enqueues a sharded query at a time
+  hip_check(hipSetDevice(r0.gpu), "hipSetDevice");
+  { std::lock_guard<std::mutex> lk(r0.mtx); if (!r0.shardIn) hip_check(hipEventCreateWithFlags(&r0.shardIn, hipEventDisableTiming), "hipEventCreate"); }
+  hip_check(hipEventRecord(r0.shardIn, stream), "hipEventRecord");          // the rays are ready on the caller's stream from here on
+  for (size_t k = 1; k < n; k++) {
+    Replica& r = *s->reps[k];
+    const unsigned lo = shard_begin(M, k, n), hi = shard_begin(M, k + 1, n);
+    if (hi <= lo) continue;
+    const size_t nb = (size_t)(hi - lo - 1) * stride + rec;
+    hip_check(hipSetDevice(r.gpu), "hipSetDevice");
+    { std::lock_guard<std::mutex> lk(r.mtx);
+      if (!r.shardStream) hip_check(hipStreamCreateWithFlags(&r.shardStream, hipStreamNonBlocking), "hipStreamCreate");
+      if (!r.shardOut) hip_check(hipEventCreateWithFlags(&r.shardOut, hipEventDisableTiming), "hipEventCreate"); }
+    char* st = r.stage(nb);
+    hip_check(hipStreamWaitEvent(r.shardStream, r0.shardIn, 0), "hipStreamWaitEvent");
+    hip_check(hipMemcpyPeerAsync(st, r.gpu, d + (size_t)lo * stride, r0.gpu, nb, r.shardStream), "hipMemcpyPeerAsync(shard out)");
+    core_check(trace_launch(committed_bvh(s, k), st, hi - lo, stride, any, qflags, r.shardStream), "trace");
+    hip_check(hipMemcpyPeerAsync(d + (size_t)lo * stride, r0.gpu, st, r.gpu, nb, r.shardStream), "hipMemcpyPeerAsync(shard back)");
+    hip_check(hipEventRecord(r.shardOut, r.shardStream), "hipEventRecord");
+  }
+  hip_check(hipSetDevice(r0.gpu), "hipSetDevice");
+  const unsigned hi0 = shard_begin(M, 1, n);
+  if (hi0) core_check(trace_launch(committed_bvh(s, 0), d, hi0, stride, any, qflags, stream), "trace");
+  for (size_t k = 1; k < n; k++) if (s->reps[k]->shardOut && shard_begin(M, k + 1, n) > shard_begin(M, k, n)) hip_check(hipStreamWaitEvent(stream, s->reps[k]->shardOut, 0), "hipStreamWaitEvent");
+}
+static void device_query(Scene* s, void* d, unsigned M, size_t stride, bool any, unsigned qflags, void* stream) {
+  if (M == 0) { committed_bvh(s); return; }
+  const size_t n = s->reps.size();
+  if (n > 1 && M >= s->device->shardMin * n) { sharded_device_query(s, (char*)d, M, stride, any, qflags, (hipStream_t)stream); return; }
+  core_check(trace_launch(committed_bvh(s), d, M, stride, any, qflags, (hipStream_t)stream), "trace");
 }
 void host_query(Scene* s, void* data, unsigned M, size_t stride, bool any, RTCFilterFunctionN argFilter = nullptr, unsigned qflags = 0, RTCRayQueryContext* uctx = nullptr) {
   if (M == 0) return;
@@ -533,7 +685,7 @@ void host_query(Scene* s, void* data, unsigned M, size_t stride, bool any, RTCFi
   const bool repack = (stride & 15) || ((size_t)data & 15);
   if (repack) THROW(RTC_ERROR_INVALID_ARGUMENT, "ray records must be 16-byte aligned (include/embree4/rtcore.h)");
   if ((g_anyFilterEver.load(std::memory_order_relaxed) || argFilter) && scene_has_filters(s, argFilter, qflags, any)) { filtered_query(s, data, M, stride, any, argFilter, qflags, uctx); return; }
-  plain_query(s, data, M, stride, any);
+  plain_query(s, data, M, stride, any, qflags);
 }
 // rtcIntersect4/8/16, rtcOccluded4/8/16 on a host packet: the K lanes are turned into AoS records on the host (RayHitK::get / set, kernels/common/ray.h:283-376),
 // the active ones go through the batch path as one launch, and only active lanes are written back (InactiveRaysTest, verify.cpp:3553).
@@ -572,6 +724,16 @@ RTC_API RTCDevice rtcNewDevice(const char* config) {
   const int n = mi355_device_count();
   if (n <= 0) THROW(RTC_ERROR_UNSUPPORTED_CPU, "no HIP device found: this library has no CPU fallback");
   if (d->gpu < 0 || d->gpu >= n) THROW(RTC_ERROR_INVALID_ARGUMENT, "gpu ordinal out of range");
+  if (d->wantGpus < 1 || d->wantGpus > 64) THROW(RTC_ERROR_INVALID_ARGUMENT, "gpus= out of range");
+  if (d->wantGpus > n && !d->oversubscribe) THROW(RTC_ERROR_INVALID_ARGUMENT, "gpus= asks for more GPUs than this node has (gpu_oversubscribe=1 lets replicas share a GPU)");
+  d->gpus.clear();
+  for (int k = 0; k < d->wantGpus; k++) d->gpus.push_back((d->gpu + k) % n);                          // replica k lives on GPU (gpu + k) mod #GPUs
+  for (size_t k = 1; k < d->gpus.size(); k++) {                                                        // shards of device-array queries travel peer to peer
+    if (d->gpus[k] == d->gpu) continue;
+    int can = 0; if (hipDeviceCanAccessPeer(&can, d->gpu, d->gpus[k]) == hipSuccess && can) { hipSetDevice(d->gpu); if (hipDeviceEnablePeerAccess(d->gpus[k], 0) != hipSuccess) (void)hipGetLastError(); }
+    can = 0; if (hipDeviceCanAccessPeer(&can, d->gpus[k], d->gpu) == hipSuccess && can) { hipSetDevice(d->gpus[k]); if (hipDeviceEnablePeerAccess(d->gpu, 0) != hipSuccess) (void)hipGetLastError(); }
+  }
+  hipSetDevice(d->gpu);
   char nm[256]; if (mi355_device_name(d->gpu, nm, sizeof(nm)) == 0) d->name = nm;
   d->countIn();
   if (d->verbose >= 1) printf("Embree(MI355X) %s on %s\n", RTC_VERSION_STRING, d->name.c_str());
@@ -595,6 +757,7 @@ RTC_API ssize_t rtcGetDeviceProperty(RTCDevice h, enum RTCDeviceProperty prop) {
     case RTC_DEVICE_PROPERTY_RAY_MASK_SUPPORTED: return 1;
     case RTC_DEVICE_PROPERTY_TRIANGLE_GEOMETRY_SUPPORTED: case RTC_DEVICE_PROPERTY_QUAD_GEOMETRY_SUPPORTED: return 1;
     case RTC_DEVICE_PROPERTY_HIP_DEVICE: return 1;
+    case RTC_DEVICE_PROPERTY_GPU_COUNT: return (ssize_t)((Device*)h)->gpus.size();
     case RTC_DEVICE_PROPERTY_BACKFACE_CULLING_ENABLED: case RTC_DEVICE_PROPERTY_BACKFACE_CULLING_CURVES_ENABLED:
     case RTC_DEVICE_PROPERTY_BACKFACE_CULLING_SPHERES_ENABLED: case RTC_DEVICE_PROPERTY_FILTER_FUNCTION_SUPPORTED:
     case RTC_DEVICE_PROPERTY_IGNORE_INVALID_RAYS_ENABLED: case RTC_DEVICE_PROPERTY_COMPACT_POLYS_ENABLED:
@@ -878,14 +1041,16 @@ RTC_API void rtcOccluded1M(RTCScene h, struct RTCRay* r, unsigned M, size_t stri
 }
 RTC_API void rtcIntersect1MDevice(RTCScene h, void* d_rh, unsigned M, size_t stride, struct RTCIntersectArguments* a, void* stream) {
   CATCH_BEGIN Scene* s = scene_of(h); if (a) check_query_args(a->filter, (const void*)a->intersect);
-  core_check(mi355_trace_closest(committed_bvh(s), d_rh, M, stride, stream), "trace"); CATCH_END(SCENE_DEV(h))
+  device_query(s, d_rh, M, stride, false, a ? (unsigned)a->flags : 0u, stream); CATCH_END(SCENE_DEV(h))
 }
 RTC_API void rtcOccluded1MDevice(RTCScene h, void* d_r, unsigned M, size_t stride, struct RTCOccludedArguments* a, void* stream) {
   CATCH_BEGIN Scene* s = scene_of(h); if (a) check_query_args(a->filter, (const void*)a->occluded);
-  core_check(mi355_trace_any(committed_bvh(s), d_r, M, stride, stream), "trace"); CATCH_END(SCENE_DEV(h))
+  device_query(s, d_r, M, stride, true, a ? (unsigned)a->flags : 0u, stream); CATCH_END(SCENE_DEV(h))
 }
 // extension used by tests/bench: the core BVH handle behind a committed scene (NULL if not committed)
-extern "C" __attribute__((visibility("default"))) mi355_bvh_t rtcGetSceneBVH_mi355(RTCScene h) { return h ? ((Scene*)h)->bvh : nullptr; }
+extern "C" __attribute__((visibility("default"))) mi355_bvh_t rtcGetSceneBVH_mi355(RTCScene h) { return h ? ((Scene*)h)->bvh0() : nullptr; }
+// ... and of replica k of a device over several GPUs (NULL beyond the last)
+extern "C" __attribute__((visibility("default"))) mi355_bvh_t rtcGetSceneReplicaBVH_mi355(RTCScene h, unsigned k) { return h && k < ((Scene*)h)->reps.size() ? ((Scene*)h)->reps[k]->bvh : nullptr; }
 
 // ================================================================= entry points outside the triangle path
 // exported so that applications linking the full Embree API resolve; each records RTC_ERROR_INVALID_OPERATION

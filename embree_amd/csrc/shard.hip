@@ -41,6 +41,35 @@ __global__ void pack_occluded_kernel(const char* rays, uint32_t count, uint32_t 
     out[i] = *(const uint32_t*)(rays + (size_t)i * stride + 32);
 }
 
+// ---- achievable HBM bandwidth of THIS box ("also measure an on-device copy/read kernel and report the fraction against both").  Grid-stride
+// 16-byte accesses, 8 independent loads in flight per lane, far more workgroups than CUs; the buffers are larger than the 256 MB Infinity Cache.
+__global__ __launch_bounds__(256) void bw_copy_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i + 7 * stride < n16; i += 8 * stride) {
+    uint4 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) v[k] = __builtin_nontemporal_load(src + i + k * stride);
+#pragma unroll
+    for (int k = 0; k < 8; k++) __builtin_nontemporal_store(v[k], dst + i + k * stride);
+  }
+  for (; i < n16; i += stride) dst[i] = src[i];
+}
+__global__ __launch_bounds__(256) void bw_read_kernel(const uint4* __restrict__ src, size_t n16, uint32_t* sink) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t acc = 0;
+  for (; i + 7 * stride < n16; i += 8 * stride) {
+    uint4 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) v[k] = __builtin_nontemporal_load(src + i + k * stride);
+#pragma unroll
+    for (int k = 0; k < 8; k++) acc ^= v[k].x ^ v[k].y ^ v[k].z ^ v[k].w;
+  }
+  for (; i < n16; i += stride) acc ^= src[i].x;
+  if (acc == 0x9E3779B9u) *sink = acc;                        // (keeps the loads alive; practically never taken)
+}
+
 // ---- RCCL, bound at run time ------------------------------------------------------------------------------------------------------------
 typedef struct { char internal[128]; } rcclUniqueId;        // ncclUniqueId, rccl.h: NCCL_UNIQUE_ID_BYTES = 128
 typedef void* rcclComm;
@@ -145,6 +174,35 @@ int mi355_comm_gather(mi355_comm_t c, const void* d_send, void* d_recv, size_t b
   HIP_TRY(hipSetDevice(c->device));
   const int rc = rccl()->Gather(d_send, d_recv, bytes_per_rank, RCCL_INT8, root, c->comm, (hipStream_t)stream);
   return rc ? rccl_fail("ncclGather", rc) : 0;
+}
+// Measures what a streaming kernel reaches on this GPU: out[0] = copy (bytes read + bytes written per second), out[1] = read only, GB/s, best of `reps`.
+int mi355_measure_bandwidth(int device, size_t bytes, int reps, double out[2]) {
+  HIP_TRY(hipSetDevice(device));
+  if (bytes < (1u << 20)) bytes = 1u << 20;
+  bytes &= ~(size_t)4095;
+  char *a = nullptr, *b = nullptr; uint32_t* sink = nullptr;
+  HIP_TRY(hipMalloc((void**)&a, bytes)); 
+  if (hipMalloc((void**)&b, bytes) != hipSuccess) { hipFree(a); return mi355::set_error(hipErrorOutOfMemory, "mi355_measure_bandwidth"); }
+  if (hipMalloc((void**)&sink, 64) != hipSuccess) { hipFree(a); hipFree(b); return mi355::set_error(hipErrorOutOfMemory, "mi355_measure_bandwidth"); }
+  hipMemset(a, 1, bytes); hipMemset(b, 2, bytes);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  const size_t n16 = bytes / 16;
+  const uint32_t blocks = 256u * 16u;
+  double bestCopy = 0.0, bestRead = 0.0;
+  for (int r = 0; r < reps + 1; r++) {
+    float ms = 0;
+    hipEventRecord(e0, nullptr); hipLaunchKernelGGL(bw_copy_kernel, dim3(blocks), dim3(256), 0, nullptr, (const uint4*)a, (uint4*)b, n16); hipEventRecord(e1, nullptr);
+    hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
+    if (r && ms > 0) { const double g = 2.0 * (double)bytes / (ms * 1e-3) / 1e9; if (g > bestCopy) bestCopy = g; }
+    hipEventRecord(e0, nullptr); hipLaunchKernelGGL(bw_read_kernel, dim3(blocks), dim3(256), 0, nullptr, (const uint4*)a, n16, sink); hipEventRecord(e1, nullptr);
+    hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
+    if (r && ms > 0) { const double g = (double)bytes / (ms * 1e-3) / 1e9; if (g > bestRead) bestRead = g; }
+  }
+  const hipError_t le = hipGetLastError();
+  hipEventDestroy(e0); hipEventDestroy(e1); hipFree(a); hipFree(b); hipFree(sink);
+  if (le != hipSuccess) return mi355::set_error(le, "mi355_measure_bandwidth");
+  out[0] = bestCopy; out[1] = bestRead;
+  return 0;
 }
 int mi355_stream_query(void* stream) {                           // 0 = everything enqueued on the stream has finished, 1 = still running, < 0 = error
   const hipError_t e = hipStreamQuery((hipStream_t)stream);

@@ -851,6 +851,10 @@ int mi355_trace_closest(mi355_bvh_t bvh, void* d, uint32_t n, size_t stride, voi
 int mi355_trace_any(mi355_bvh_t bvh, void* d, uint32_t n, size_t stride, void* stream) {
   return mi355::launch_trace((mi355::Bvh*)bvh, d, n, stride, true, (hipStream_t)stream, nullptr);
 }
+int mi355_trace_query(mi355_bvh_t bvh, void* d, uint32_t n, size_t stride, int any_hit, uint32_t query_flags, void* stream) {
+  (void)query_flags;
+  return mi355::launch_trace((mi355::Bvh*)bvh, d, n, stride, any_hit != 0, (hipStream_t)stream, nullptr);
+}
 int mi355_trace_timed(mi355_bvh_t bvh, void* d, uint32_t n, size_t stride, int any_hit, void* stream, void* ev_start, void* ev_stop) {
   return mi355::launch_trace((mi355::Bvh*)bvh, d, n, stride, any_hit != 0, (hipStream_t)stream, nullptr, (hipEvent_t)ev_start, (hipEvent_t)ev_stop);
 }

@@ -153,7 +153,8 @@ enum RTCDeviceProperty {
   RTC_DEVICE_PROPERTY_CPU_DEVICE = 140,
   RTC_DEVICE_PROPERTY_SYCL_DEVICE = 141,
   /* extension: 1 on this library (HIP device behind the API) */
-  RTC_DEVICE_PROPERTY_HIP_DEVICE = 142
+  RTC_DEVICE_PROPERTY_HIP_DEVICE = 142,
+  RTC_DEVICE_PROPERTY_GPU_COUNT = 143              /* extension: GPUs behind this device (rtcNewDevice("gpus=N")) */
 };
 
 /* [ref: rtcore_device.h:90-100] */

@@ -124,6 +124,12 @@ MI355_API int mi355_bvh_download(mi355_bvh_t bvh, void* nodes, size_t nodes_byte
 MI355_API int mi355_trace_prepare(mi355_bvh_t bvh, void* stream);
 MI355_API int mi355_trace_closest(mi355_bvh_t bvh, void* d_rayhit, uint32_t count, size_t byte_stride, void* stream);
 MI355_API int mi355_trace_any(mi355_bvh_t bvh, void* d_ray, uint32_t count, size_t byte_stride, void* stream);
+/* The same two launches with the query flags of RTCIntersectArguments / RTCOccludedArguments (include/embree4/rtcore.h RTCRayQueryFlags).
+   MI355_QUERY_COHERENT (= RTC_RAY_QUERY_FLAG_COHERENT, the reference: BVHNIntersectorKHybrid::intersectCoherent, kernels/bvh/
+   bvh_intersector_hybrid.cpp:374-533): consecutive rays are expected to take similar paths; the launch then uses the wave-packet kernel, in which
+   the 64 rays of a wavefront walk the tree TOGETHER (one node fetch for all of them).  Results are those of the incoherent kernels. */
+#define MI355_QUERY_COHERENT 0x10000u
+MI355_API int mi355_trace_query(mi355_bvh_t bvh, void* d_rays, uint32_t count, size_t byte_stride, int any_hit, uint32_t query_flags, void* stream);
 /* Same launch with a HIP event recorded on `stream` immediately before and after the traversal kernel
    (after the 4-byte cursor reset), so that the interval is the kernel alone.  any_hit selects the kernel. */
 MI355_API int mi355_trace_timed(mi355_bvh_t bvh, void* d_rays, uint32_t count, size_t byte_stride, int any_hit,
@@ -171,7 +177,10 @@ MI355_API int  mi355_comm_gather(mi355_comm_t comm, const void* d_send, void* d_
    closest hit: 32 B per ray = { tfar, u, v, primID | geomID, Ng_x, Ng_y, Ng_z } (two 16-byte halves); occlusion: 4 B per ray = tfar (-inf = occluded). */
 MI355_API int  mi355_pack_hits(const void* d_rayhit, uint32_t count, size_t byte_stride, void* d_out, void* stream);
 MI355_API int  mi355_pack_occluded(const void* d_ray, uint32_t count, size_t byte_stride, void* d_out, void* stream);
-MI355_API int  mi355_stream_query(void* stream);             /* hipStreamQuery: 0 = idle, 1 = work pending, < 0 = error */
+MI355_API int  mi355_stream_query(void* stream);
+/* What a streaming kernel reaches on this GPU (the achievable figure beside the 8 TB/s vendor peak): out[0] = device-to-device copy,
+   bytes read + written per second; out[1] = read only; GB/s, best of `reps` passes over `bytes` (use >= 1 GiB: the Infinity Cache holds 256 MB). Blocking. */
+MI355_API int  mi355_measure_bandwidth(int device, size_t bytes, int reps, double out[2]);             /* hipStreamQuery: 0 = idle, 1 = work pending, < 0 = error */
 
 /* raw device memory helpers for hosts without a HIP binding (ctypes tests / bench) */
 MI355_API int mi355_malloc(int device, size_t bytes, void** d_ptr);

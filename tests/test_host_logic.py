@@ -141,3 +141,32 @@ def test_shadow_ray_shards_are_slices_of_the_single_rank_set():
             assert lo % 16 == 0 and hi % 16 == 0
             parts.append(W.shadow_rays(b[lo // 16: hi // 16], meshes, samples=16, first=lo))
         assert np.concatenate(parts).tobytes() == full.tobytes()
+
+
+_LAUNCHED = r'''
+import os, sys
+import torch.distributed as dist
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+assert os.environ["MASTER_ADDR"] == "127.0.0.1" and int(os.environ["LOCAL_RANK"]) == rank
+if len(sys.argv) > 2 and sys.argv[2] == "die" and rank == 1:
+    sys.exit(3)                                               # a rank that fails before the rendezvous
+dist.init_process_group("gloo", rank=rank, world_size=world)
+dist.barrier()
+open(os.path.join(sys.argv[1], "rank%d.txt" % rank), "w").write("%d %d" % (rank, world))
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_bench_launcher_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus N` without a launcher around it must start N ranks itself (bench.spawn_ranks): rendezvous on 127.0.0.1, RANK / LOCAL_RANK /
+    WORLD_SIZE set, exit code 0 only if every rank succeeded -- and a rank that dies must not leave the others waiting for ever."""
+    sys.path.insert(0, ROOT)
+    import bench
+    script = tmp_path / "launched.py"
+    script.write_text(_LAUNCHED)
+    assert bench.spawn_ranks(2, script=str(script), script_args=[str(tmp_path)]) == 0
+    assert (tmp_path / "rank0.txt").read_text() == "0 2" and (tmp_path / "rank1.txt").read_text() == "1 2"
+    t0 = __import__("time").time()
+    assert bench.spawn_ranks(2, script=str(script), script_args=[str(tmp_path), "die"]) != 0
+    assert __import__("time").time() - t0 < 120
