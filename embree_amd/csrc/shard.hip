@@ -43,11 +43,12 @@ __global__ void pack_occluded_kernel(const char* rays, uint32_t count, uint32_t 
 
 // ---- achievable HBM bandwidth of THIS box ("also measure an on-device copy/read kernel and report the fraction against both").  Grid-stride
 // 16-byte accesses, 8 independent loads in flight per lane, far more workgroups than CUs; the buffers are larger than the 256 MB Infinity Cache.
-__global__ __launch_bounds__(256) void bw_copy_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16) {
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void bw_copy_kernel(const u32x4* __restrict__ src, u32x4* __restrict__ dst, size_t n16) {
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   for (; i + 7 * stride < n16; i += 8 * stride) {
-    uint4 v[8];
+    u32x4 v[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) v[k] = __builtin_nontemporal_load(src + i + k * stride);
 #pragma unroll
@@ -55,12 +56,12 @@ __global__ __launch_bounds__(256) void bw_copy_kernel(const uint4* __restrict__ 
   }
   for (; i < n16; i += stride) dst[i] = src[i];
 }
-__global__ __launch_bounds__(256) void bw_read_kernel(const uint4* __restrict__ src, size_t n16, uint32_t* sink) {
+__global__ __launch_bounds__(256) void bw_read_kernel(const u32x4* __restrict__ src, size_t n16, uint32_t* sink) {
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   uint32_t acc = 0;
   for (; i + 7 * stride < n16; i += 8 * stride) {
-    uint4 v[8];
+    u32x4 v[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) v[k] = __builtin_nontemporal_load(src + i + k * stride);
 #pragma unroll
@@ -191,10 +192,10 @@ int mi355_measure_bandwidth(int device, size_t bytes, int reps, double out[2]) {
   double bestCopy = 0.0, bestRead = 0.0;
   for (int r = 0; r < reps + 1; r++) {
     float ms = 0;
-    hipEventRecord(e0, nullptr); hipLaunchKernelGGL(bw_copy_kernel, dim3(blocks), dim3(256), 0, nullptr, (const uint4*)a, (uint4*)b, n16); hipEventRecord(e1, nullptr);
+    hipEventRecord(e0, nullptr); hipLaunchKernelGGL(bw_copy_kernel, dim3(blocks), dim3(256), 0, nullptr, (const u32x4*)a, (u32x4*)b, n16); hipEventRecord(e1, nullptr);
     hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
     if (r && ms > 0) { const double g = 2.0 * (double)bytes / (ms * 1e-3) / 1e9; if (g > bestCopy) bestCopy = g; }
-    hipEventRecord(e0, nullptr); hipLaunchKernelGGL(bw_read_kernel, dim3(blocks), dim3(256), 0, nullptr, (const uint4*)a, n16, sink); hipEventRecord(e1, nullptr);
+    hipEventRecord(e0, nullptr); hipLaunchKernelGGL(bw_read_kernel, dim3(blocks), dim3(256), 0, nullptr, (const u32x4*)a, n16, sink); hipEventRecord(e1, nullptr);
     hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
     if (r && ms > 0) { const double g = (double)bytes / (ms * 1e-3) / 1e9; if (g > bestRead) bestRead = g; }
   }
