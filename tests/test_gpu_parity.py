@@ -563,7 +563,7 @@ def test_low_quality_crown_duplicates_and_determinism(api, dev, restate):
             want, got = rays.copy(), rays.copy()
             o.intersect1(want)
             s.intersect1M(got)
-            compare_closest(got, want, rays, o.triangle_t, max_tie_frac=0.05, label="morton crown")
+            compare_closest(got, want, rays, o.triangle_t, label="morton crown")
         s.release()
     assert blobs[0] == blobs[1]
     med = api.make_scene(dev, meshes)
@@ -578,7 +578,7 @@ def test_low_quality_crown_duplicates_and_determinism(api, dev, restate):
     want, got = rays.copy(), rays.copy()
     orb.intersect1(want)
     r.intersect1M(got)
-    compare_closest(got, want, rays, orb.triangle_t, max_tie_frac=0.05, label="morton + robust")
+    compare_closest(got, want, rays, orb.triangle_t, label="morton + robust")
     r.release()
 
 
@@ -840,7 +840,8 @@ def test_full_size_vs_real_reference(api, dev, crown_full):
     o = restate.OracleScene()                                 # only for triangle_t (no tree needed for that)
     for v, t in meshes:
         o.add_mesh(v, t)
-    st = compare_closest(got, want, rays, o.triangle_t, max_tie_frac=1e-3, label="crown full vs reference")
+    st = compare_closest(got, want, rays, o.triangle_t, label="crown full vs reference")
+    assert st["ties"] <= 16, st                               # measured: 2 of 2^20
     assert st["hits"] > 0.99 * st["rays"]
     sh = W.shadow_rays(want[: 1 << 16], meshes, samples=16)   # 2^20 shadow rays (config 4 per-GPU shard size is 2^21)
     ws, gs = sh.copy(), sh.copy()

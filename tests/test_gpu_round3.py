@@ -1,0 +1,267 @@
+"""GPU tests added in round 3 (pytest -m gpu), all through the C ABI:
+
+  * one RTCDevice over several GPUs (rtcNewDevice("gpus=N")): replicas bit-identical, the sharded host-array and device-array queries give the
+    single-GPU answer bit for bit (on a 1-GPU box the replicas share the GPU: gpu_oversubscribe=1 -- same code, same threads, same peer copies);
+  * the cost-optimal collapse (embree_amd/csrc/build_collapse.inl) against the reference's greedy rule: both trees valid, same answers, fewer nodes,
+    bit-identical rebuilds;
+  * rtcCommitScene after detach + a NEW geometry that reuses the freed one's address and counters (the advisor's stale-tree scenario);
+  * filter callbacks in a ROBUST scene see every rejected candidate exactly once;
+  * configs[3] as a whole job at N = 1 through bench.py's own code (pack + gather) against the real reference on a 2^22-ray prefix;
+  * RTC_RAY_QUERY_FLAG_COHERENT: the wave-packet kernel gives the incoherent kernel's answers;
+  * device-side filter rules against the same rule run as a host callback in the real reference.
+"""
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from embree_amd import workloads as W
+from embree_amd.rtypes import rays_of, make_rayhits, INVALID_ID, RAYHIT_DTYPE, RAY_DTYPE
+from tests import bvh_check
+from tests.helpers import compare_closest, compare_occluded
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def api():
+    from embree_amd import api as A
+    A.load()
+    assert A.load().mi355_device_count() > 0, "no HIP device: the product has no CPU fallback"
+    return A
+
+
+@pytest.fixture(scope="module")
+def dev(api):
+    d = api.Device("gpu=0")
+    yield d
+    d.release()
+
+
+@pytest.fixture(scope="module")
+def ref():
+    from oracle import refembree
+    if not refembree.available():
+        pytest.skip("oracle/_ref not present on this box (make -f oracle/ref.mk in the build container)")
+    return refembree
+
+
+def tri_t_of(meshes):
+    from oracle import restate
+    o = restate.OracleScene()
+    for v, t in meshes:
+        o.add_mesh(v, t)
+    return o.triangle_t
+
+
+# ------------------------------------------------------------------------------------------- one RTCDevice over N GPUs
+@pytest.mark.parametrize("gpus", [1, 2, 3])
+def test_one_device_over_several_gpus(api, dev, gpus):
+    """rtcNewDevice("gpus=N") (the reference's shape: a GPU device behind the same RTCDevice, kernels/common/scene.cpp:866-872; the ray count of its own
+    benchmark, tutorials/verify/verify.cpp:5933, is what gets sharded).  gpus=1 drives the very same code with one replica."""
+    L = api.load()
+    ngpu = L.mi355_device_count()
+    cfg = "gpu=0,gpus=%d,shard_min=1024%s" % (gpus, ",gpu_oversubscribe=1" if gpus > ngpu else "")
+    md = api.Device(cfg)
+    assert md.gpu_count() == gpus
+    meshes = W.synthetic_crown(num_phi=24)
+    single = api.make_scene(dev, meshes)
+    ms = api.make_scene(md, meshes)
+    n0, t0 = single.download_bvh()
+    for k in range(gpus):                                      # every replica is the single-GPU tree, bit for bit
+        b = ms.replica_bvh(k)
+        assert b
+        i = api.BvhInfo()
+        L.mi355_bvh_get_info(b, C.byref(i))
+        nodes = np.zeros(i.num_nodes, api.NODE_DTYPE)
+        tris = np.zeros(i.num_triangles, api.TRI_DTYPE)
+        assert L.mi355_bvh_download(b, nodes.ctypes.data, nodes.nbytes, tris.ctypes.data, tris.nbytes) == 0
+        assert nodes.tobytes() == n0.tobytes() and tris.tobytes() == t0.tobytes(), "replica %d differs from the single-GPU tree" % k
+    assert ms.replica_bvh(gpus) is None
+    prim = W.crown_camera_rays(meshes, 256, 256)
+    a = prim.copy()
+    single.intersect1M(a)
+    rays = W.diffuse_bounce_rays(a, meshes)
+    for M in (rays.shape[0], 40001, 3000):                     # sharded, sharded with ragged shards, below shard_min * N (one replica)
+        want, got = rays[:M].copy(), rays[:M].copy()
+        single.intersect1M(want)
+        ms.intersect1M(got)
+        assert got.tobytes() == want.tobytes(), "sharded rtcIntersect1M differs from the single-GPU answer (M = %d)" % M
+        wr, gr = rays_of(rays[:M]), rays_of(rays[:M])
+        single.occluded1M(wr)
+        ms.occluded1M(gr)
+        assert gr.tobytes() == wr.tobytes()
+    # device-array form: the array lives on the first GPU, shards travel peer to peer
+    want = rays.copy()
+    single.intersect1M(want)
+    d = api.DeviceArray.from_numpy(rays, 0)
+    st = C.c_void_p()
+    L.mi355_stream_create(0, C.byref(st))
+    ms.intersect1M_device(d.ptr, rays.shape[0], stream=st)
+    L.mi355_synchronize(st)
+    assert d.download(RAYHIT_DTYPE).tobytes() == want.tobytes(), "sharded rtcIntersect1MDevice differs from the single-GPU answer"
+    r48 = rays_of(rays)
+    wr = r48.copy()
+    single.occluded1M(wr)
+    d2 = api.DeviceArray.from_numpy(r48, 0)
+    ms.occluded1M_device(d2.ptr, r48.shape[0], stream=st)
+    L.mi355_synchronize(st)
+    assert d2.download(RAY_DTYPE).tobytes() == wr.tobytes()
+    # a refit and an instanced scene on every replica
+    if gpus > 1:
+        obj = api.make_scene(md, [meshes[0]])
+        top = api.Scene(md)
+        top.add_instance(obj, [1, 0, 0, 0, 1, 0, 0, 0, 1, 0.25, 0, 0])
+        top.add_triangle_mesh(*meshes[1])
+        top.commit()
+        obj1 = api.make_scene(dev, [meshes[0]])
+        top1 = api.Scene(dev)
+        top1.add_instance(obj1, [1, 0, 0, 0, 1, 0, 0, 0, 1, 0.25, 0, 0])
+        top1.add_triangle_mesh(*meshes[1])
+        top1.commit()
+        w, g = rays.copy(), rays.copy()
+        top1.intersect1M(w)
+        top.intersect1M(g)
+        assert g.tobytes() == w.tobytes(), "instanced scene on replicas differs"
+        for s_ in (top, obj, top1, obj1):
+            s_.release()
+    L.mi355_stream_destroy(st)
+    d.free(); d2.free()
+    ms.release(); single.release(); md.release()
+
+
+def test_more_gpus_than_the_node_has_is_an_error(api):
+    L = api.load()
+    n = L.mi355_device_count()
+    with pytest.raises(api.RTCErrorException) as e:
+        api.Device("gpus=%d" % (n + 1))
+    assert e.value.code == api.RTC_ERROR_INVALID_ARGUMENT
+    L.rtcGetDeviceError(None)
+
+
+# ------------------------------------------------------------------------------------------- cost-optimal collapse vs the reference's greedy rule
+def test_collapse_cost_optimal_vs_greedy(api):
+    """The children of a wide node come from a dynamic programme over the binary tree (build_collapse.inl) instead of the reference's greedy
+    "largest half-area first" (bvh_builder_sah.h:247-272).  Both trees must be valid, give identical answers (the hit does not depend on the tree),
+    the cost-optimal one has fewer, fuller nodes; rebuilds are bit-identical (the tables are filled by a race-free climb)."""
+    meshes = W.synthetic_crown(num_phi=48)
+    rays = W.incoherent_rays(100000, [2, 2, 1.5], seed=5)
+    out = {}
+    for name, cfg in (("dp", "gpu=0"), ("greedy", "gpu=0,collapse=greedy"), ("dp_low", "gpu=0,quality=low"), ("dp_high", "gpu=0,quality=high")):
+        d = api.Device(cfg)
+        blobs = []
+        for rep in range(2):
+            s = api.make_scene(d, meshes)
+            nodes, tris = s.download_bvh()
+            blobs.append((nodes.tobytes(), tris.tobytes()))
+            if rep == 0:
+                info = s.info()
+                if name != "dp_high":                              # (a spatial-split tree holds some triangles several times: its own tests check it)
+                    bvh_check.validate(nodes, tris, info["root_ref"], meshes, max_leaf=info["max_leaf"])
+                got = rays.copy()
+                s.intersect1M(got)
+                dd = api.DeviceArray.from_numpy(rays)
+                stt = s.trace_stats(dd.ptr, rays.shape[0], 96)
+                dd.free()
+                fill = (info["num_leaves"] + info["num_nodes"] - 1) / max(1, info["num_nodes"])
+                out[name] = dict(got=got, nodes=info["num_nodes"], leaves=info["num_leaves"], fill=fill, npr=stt["nodes"] / rays.shape[0], tpr=stt["tris"] / rays.shape[0], ms=info["build_ms"])
+            s.release()
+        assert blobs[0] == blobs[1], "%s: two commits of the same scene differ" % name
+        d.release()
+    for k, v in out.items():
+        print("collapse %-8s nodes %7d leaf slots %7d children/node %.2f | nodes/ray %.2f tris/ray %.2f | build %.2f ms" % (k, v["nodes"], v["leaves"], v["fill"], v["npr"], v["tpr"], v["ms"]))
+    tt = tri_t_of(meshes)
+    compare_closest(out["dp"]["got"], out["greedy"]["got"], rays, tt, label="cost-optimal vs greedy collapse")
+    compare_closest(out["dp_low"]["got"], out["greedy"]["got"], rays, tt, label="cost-optimal collapse of the Morton tree")
+    compare_closest(out["dp_high"]["got"], out["greedy"]["got"], rays, tt, label="cost-optimal collapse of the spatial-split tree")
+    assert out["dp"]["nodes"] < 0.9 * out["greedy"]["nodes"], (out["dp"]["nodes"], out["greedy"]["nodes"])
+    assert out["dp"]["fill"] > out["greedy"]["fill"] + 0.5
+    assert out["dp"]["npr"] < out["greedy"]["npr"]
+
+
+# ------------------------------------------------------------------------------------------- advisor: stale tree after detach + new geometry
+def test_commit_after_detach_and_a_new_geometry_at_the_same_address(api, dev):
+    """rtcDetachGeometry frees the old geometry (the scene held the last reference); rtcNewGeometry very likely returns the same address; the same buffer-set
+    sequence gives the same counters and rtcAttachGeometry the same id.  rtcCommitScene must build the NEW geometry's tree (Scene::commit compares
+    process-unique serials, not addresses)."""
+    L = api.load()
+    v0 = np.array([[0, 0, 1], [1, 0, 1], [0, 1, 1]], np.float32)
+    t = np.array([[0, 1, 2]], np.uint32)
+    ray = make_rayhits([[0.2, 0.2, 0]], [[0, 0, 1]])
+    for trial in range(8):
+        s = api.Scene(dev)
+        s.add_triangle_mesh(v0, t, shared=False)
+        s.commit()
+        r = ray.copy(); s.intersect1M(r)
+        assert r["geomID"][0] == 0 and abs(r["tfar"][0] - 1.0) < 1e-6
+        L.rtcDetachGeometry(s.h, 0)
+        dev.check()
+        gid = s.add_triangle_mesh(v0 + np.float32([0, 0, 2.0 + trial]), t, shared=False)      # same sequence of calls, other vertices
+        assert gid == 0
+        s.commit()
+        r = ray.copy(); s.intersect1M(r)
+        assert r["geomID"][0] == 0 and abs(r["tfar"][0] - (3.0 + trial)) < 1e-5, "the scene still answers with the detached geometry's tree (t = %g)" % r["tfar"][0]
+        s.release()
+
+
+# ------------------------------------------------------------------------------------------- advisor: robust scenes, a rejected candidate is offered once
+@pytest.mark.parametrize("flags", [0, 4])
+def test_filter_sees_every_rejected_candidate_once(api, dev, flags):
+    """A stack of 6 parallel triangles, a filter that rejects everything and counts: the callback must see each triangle exactly once per ray, fast
+    (strict at tnear) and robust (Pluecker, inclusive at tnear) alike -- a transparency accumulation would otherwise count layers twice."""
+    vs, ts = [], []
+    for k in range(6):
+        vs += [[-1, -1, 1 + k], [3, -1, 1 + k], [-1, 3, 1 + k]]
+        ts.append([3 * k, 3 * k + 1, 3 * k + 2])
+    s = api.make_scene(dev, [(np.array(vs, np.float32), np.array(ts, np.uint32))], flags=flags)
+    seen = []
+
+    def reject_all(a):
+        a = a.contents
+        for i in range(a.N):
+            if a.valid[i] != -1:
+                continue
+            seen.append(int(C.cast(a.hit, C.POINTER(C.c_uint32))[5 * a.N + i]))
+            a.valid[i] = 0
+    f = api.FILTER_FN(reject_all)
+    s.set_filters(0, intersect=f, occluded=f)
+    r = make_rayhits([[0.1, 0.1, 0]], [[0, 0, 1]])
+    s.intersect1M(r)
+    assert r["geomID"][0] == INVALID_ID and sorted(seen) == [0, 1, 2, 3, 4, 5], seen
+    seen.clear()
+    o = rays_of(make_rayhits([[0.1, 0.1, 0]], [[0, 0, 1]]))
+    s.occluded1M(o)
+    assert not np.isneginf(o["tfar"][0]) and sorted(seen) == [0, 1, 2, 3, 4, 5], seen
+    s.release()
+
+
+# ------------------------------------------------------------------------------------------- configs[3]: the whole job through bench.py's code
+def test_shadow16m_whole_job_vs_reference_prefix(api, ref, tmp_path):
+    """configs[3] at N = 1 exactly as the driver would run it: bench.py --workload shadow16m (16 Mi shadow rays through rtcOccluded1MDevice, results packed on the GPU
+    and gathered with RCCL -- one rank: the all-gather is a copy), the gathered words dumped, and a 2^22-ray prefix checked against the REAL reference's rtcOccluded1."""
+    dump = str(tmp_path / "shadow.npz")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "shadow16m", "--gather", "rccl", "--steps", "2", "--warmup", "1", "--no-cpu", "--dump", dump],
+                       capture_output=True, text=True, timeout=1500, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["config"]["rays_per_gpu"] == 16 * (1 << 20) and line["scaling"] == "strong"
+    assert "error" not in line.get("gather", {}), line.get("gather")
+    z = np.load(dump)
+    rays, words = z["rays"], z["gathered"]
+    assert rays.shape[0] == 1 << 22 and words.shape[0] == 1 << 22
+    meshes = W.synthetic_crown(num_phi=158)
+    R = ref.RefScene("threads=%d" % ref.hw_threads())
+    for v, t in meshes:
+        R.add_mesh(v, t)
+    R.commit()
+    want = rays.copy()
+    R.occluded1(want, ref.hw_threads())
+    st = compare_occluded(words.view(np.float32), want["tfar"], rays["tfar"], max_flip_frac=1e-5, label="shadow16m prefix vs reference")
+    print("shadow16m whole job: %.1f Mrays/s; prefix of %d rays vs reference: %s" % (line["value"], rays.shape[0], st))
+    R.close()
