@@ -50,7 +50,6 @@ namespace {
 #include "build_small.inl"       // K3: sub-trees finished by one wavefront in LDS
 #include "build_morton.inl"      // RTC_BUILD_QUALITY_LOW: Morton-code build
 #include "build_wide.inl"        // K4: collapse of the binary tree into 8-wide quantised nodes
-#include "build_collapse.inl"    // which binary nodes become the children of a wide node: cost-optimal cut (dynamic programme over the binary tree)
 #include "build_leaves.inl"      // K5: leaf records; refit; node rebasing for instanced scenes
 
 // Build scratch comes from a per-device arena that survives the commit: rtcCommitScene is timed on the wall clock
@@ -155,8 +154,6 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
   // RTC_BUILD_QUALITY_HIGH: spatial splits inside the recursion (the reference's default, bvh_builder_sah_spatial.cpp:93-160); "presplits=1" selects the
   // reference's other form, splitting big triangles up front (state.cpp:88 useSpatialPreSplits).  The spatial splits live in the top phase: lower its end.
   prm.spatial = (bp->quality == 2u && !bp->presplits && numMeshes < (1u << 27)) ? 1u : 0u;
-  prm.collapse = bp->collapse == 1u ? 0u : 1u;                  // default: cost-optimal cut (build_collapse.inl); collapse = 1: the reference's greedy rule
-  prm.dpNode = bp->dp_node_cost > 0.0f ? bp->dp_node_cost : 1.0f; prm.dpTri = bp->dp_tri_cost > 0.0f ? bp->dp_tri_cost : 0.5f;
   if (prm.spatial && prm.small > 256u) prm.small = 256u;
 
   std::vector<GeomDesc> gd; uint64_t total = 0;
@@ -187,7 +184,6 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
   uint32_t launches = 0, syncs = 0;
   bool replay = false, capturing = false;                       // fast path: the launches below are replayed from the cached graph / are being captured into one
 #define LAUNCH(...) do { if (!replay) hipLaunchKernelGGL(__VA_ARGS__); launches++; } while (0)
-#define MEMSET(p, v, bytes) do { if (!replay) HIP_TRY(hipMemsetAsync(p, v, bytes, st)); } while (0)   // (part of the captured sequence like the launches)
 #define SYNC_READ(h) do { HIP_TRY(hipGetLastError()); HIP_TRY(hipMemcpyAsync(&(h), ctr.p, sizeof(h), hipMemcpyDeviceToHost, st)); HIP_TRY(hipStreamSynchronize(st)); syncs++; } while (0)
 
   DevBuf<GeomDesc> dGeoms; HIP_TRY(dGeoms.alloc(gd.size()));
@@ -217,10 +213,6 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
   HIP_TRY(tileCount.alloc(tiles));
   DevBuf<uint32_t> chunkCnt; DevBuf<uint2> chunkBase;          // per chunk of a level: its bin counts, then its places in the two children (top_bin -> top_split -> top_partition)
   HIP_TRY(chunkCnt.alloc((size_t)maxChunks * 3u * NBINS)); HIP_TRY(chunkBase.alloc(maxChunks));
-  const bool dpCollapse = prm.collapse != 0u;
-  const uint32_t maxB = 2u * NC + 2u;                           // binary node slots
-  DevBuf<uint32_t> dpParent, dpFlags, leafNode; DevBuf<float> dpTab;   // cost-optimal collapse: parent links, arrival counters, the leaf that begins at every position, 8 floats per binary node
-  if (dpCollapse) { HIP_TRY(dpParent.alloc(maxB)); HIP_TRY(dpFlags.alloc(maxB)); HIP_TRY(leafNode.alloc(NC)); HIP_TRY(dpTab.alloc(8ull * maxB)); }
   DevBuf<SegX> segx0, segx1; DevBuf<uint32_t> sbins;            // spatial-split builds: extended ranges of the top phase's sets, their spatial bins
   if (spatial) { HIP_TRY(segx0.alloc(maxSegs)); HIP_TRY(segx1.alloc(maxSegs)); HIP_TRY(sbins.alloc((size_t)maxSegs * SBINS_WORDS)); }
 
@@ -228,7 +220,7 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
   struct EvGuard { hipEvent_t a, b; ~EvGuard() { hipEventDestroy(a); hipEventDestroy(b); } } evg{ev0, ev1};
   if (useGraph) {
     HIP_TRY(hipStreamSynchronize(st));                         // (the geometry table above is in place before anything is captured)
-    const void* ptrs[] = {dGeoms.p, bufA.p, bufB.p, finalIds.p, bnodes.p, segs0.p, segs1.p, bins.p, chunks.p, small.p, ctr.p, w0.p, w1.p, wnodes.p, outIds.p, plans.p, itemCnt.p, groupSum.p, tileCount.p, chunkCnt.p, chunkBase.p, dpParent.p, dpFlags.p, leafNode.p, dpTab.p, (const void*)st};
+    const void* ptrs[] = {dGeoms.p, bufA.p, bufB.p, finalIds.p, bnodes.p, segs0.p, segs1.p, bins.p, chunks.p, small.p, ctr.p, w0.p, w1.p, wnodes.p, outIds.p, plans.p, itemCnt.p, groupSum.p, tileCount.p, chunkCnt.p, chunkBase.p, (const void*)st};
     std::vector<uint64_t> key; for (const void* q : ptrs) key.push_back((uint64_t)(uintptr_t)q);
     uint32_t pw[sizeof(Params) / 4]; memcpy(pw, &prm, sizeof(prm)); for (uint32_t w : pw) key.push_back(w);
     key.push_back(N); key.push_back(gd.size()); key.push_back(bp->robust);
@@ -325,11 +317,9 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
     }
   }
 
-  uint32_t lbvhN = 0;
-  if (dpCollapse && prm.quality != 1u) MEMSET(leafNode.p, 0xFF, (size_t)NC * 4u);   // NIL: no binary leaf begins here
   if (prm.quality == 1u) {                                     // RTC_BUILD_QUALITY_LOW: Morton codes -> sort -> hierarchy -> boxes
-    DevBuf<unsigned long long> keys, keysSorted; DevBuf<uint32_t> vals, valsSorted, flags; DevBuf<char> tmp; DevBuf<uint32_t> parentLocal; DevBuf<uint32_t>& parent = dpCollapse ? dpParent : parentLocal;
-    HIP_TRY(keys.alloc(n)); HIP_TRY(keysSorted.alloc(n)); HIP_TRY(vals.alloc(n)); HIP_TRY(valsSorted.alloc(n)); if (!dpCollapse) HIP_TRY(parentLocal.alloc(2ull * n)); HIP_TRY(flags.alloc(n));
+    DevBuf<unsigned long long> keys, keysSorted; DevBuf<uint32_t> vals, valsSorted, parent, flags; DevBuf<char> tmp;
+    HIP_TRY(keys.alloc(n)); HIP_TRY(keysSorted.alloc(n)); HIP_TRY(vals.alloc(n)); HIP_TRY(valsSorted.alloc(n)); HIP_TRY(parent.alloc(2ull * n)); HIP_TRY(flags.alloc(n));
     size_t tmpBytes = 0;
     HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmpBytes, keys.p, keysSorted.p, vals.p, valsSorted.p, (int)n, 0, 63, st));
     HIP_TRY(tmp.alloc(tmpBytes));
@@ -343,7 +333,7 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
     if (n > 1u) LAUNCH(lbvh_hierarchy, dim3((n + 254u) / 256u), dim3(256), 0, st, keysSorted.p, n, bnodes.p, parent.p);
     LAUNCH(lbvh_bounds, dim3(g), dim3(256), 0, st, bufB.p, n, bnodes.p, parent.p, flags.p, ctr.p);
     HIP_TRY(hipGetLastError());
-    numSegs = 0; numSmall = 0; lbvhN = n;
+    numSegs = 0; numSmall = 0;
   }
   const bool sahBuild = prm.quality != 1u;
   // ---- top phase: one pass over the data per binary level.  Work-list sizes stay on the device: every kernel is launched with
@@ -357,7 +347,7 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
     const uint32_t chunkBound = (spatial ? NC : n) / CHUNK + segBound + 1u;
     LAUNCH(top_setup, dim3(segBound), dim3(256), 0, st, cur, bins.p, chunks.p, ctr.p);
     LAUNCH(top_bin, dim3(chunkBound), dim3(256), 0, st, cur, chunks.p, src, bins.p, ctr.p, chunkCnt.p);
-    LAUNCH(top_split, dim3(segBound), dim3(64), 0, st, cur, bins.p, bnodes.p, ctr.p, prm, level >= 96u ? 1u : 0u, xcur, (const uint32_t*)chunkCnt.p, chunkBase.p, dpParent.p);
+    LAUNCH(top_split, dim3(segBound), dim3(64), 0, st, cur, bins.p, bnodes.p, ctr.p, prm, level >= 96u ? 1u : 0u, xcur, (const uint32_t*)chunkCnt.p, chunkBase.p);
     if (spatial) {                                               // sets whose object split leaves overlapping children try a spatial split
       LAUNCH(spatial_decide, dim3(segBound), dim3(128), 0, st, cur, xcur, bnodes.p, sbins.p, ctr.p, spatialMin);
       LAUNCH(spatial_bin, dim3(chunkBound), dim3(256), 0, st, cur, xcur, chunks.p, src, dGeoms.p, sbins.p, ctr.p);
@@ -390,22 +380,15 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
   if (fast) {
     // every small entry covers > small / 2^k ... triangles: at most one entry per top-phase leaf; the list cannot be longer than maxSmall (top_emit raises overflow)
     const uint32_t bound = N > prm.small ? maxSmall : 1u;
-    LAUNCH(small_build, dim3(bound), dim3(64), smallLds, st, small.p, bufA.p, bufB.p, bnodes.p, finalIds.p, ctr.p, prm, microW, dpParent.p, leafNode.p);
+    LAUNCH(small_build, dim3(bound), dim3(64), smallLds, st, small.p, bufA.p, bufB.p, bnodes.p, finalIds.p, ctr.p, prm, microW);
   } else {
     info.top_levels = h.topLevels;
     numSmall = sahBuild ? h.numSmall : 0u;
     if (numSmall > maxSmall) return set_error(hipErrorOutOfMemory, "small list overflow");
-    if (numSmall) LAUNCH(small_build, dim3(numSmall), dim3(64), smallLds, st, small.p, bufA.p, bufB.p, bnodes.p, finalIds.p, ctr.p, prm, microW, dpParent.p, leafNode.p);
+    if (numSmall) LAUNCH(small_build, dim3(numSmall), dim3(64), smallLds, st, small.p, bufA.p, bufB.p, bnodes.p, finalIds.p, ctr.p, prm, microW);
   }
   HIP_TRY(hipGetLastError());
 
-  // ---- cost-optimal cut of the binary tree (build_collapse.inl): the tables are filled from the binary leaves up in one launch
-  if (dpCollapse) {
-    MEMSET(dpFlags.p, 0, (size_t)maxB * 4u);
-    const uint32_t limit = prm.quality == 1u ? lbvhN : NC;
-    LAUNCH(collapse_dp, dim3((limit + 255u) / 256u), dim3(256), 0, st, prm.quality == 1u ? (const uint32_t*)nullptr : (const uint32_t*)leafNode.p, lbvhN, (const BNode*)bnodes.p,
-           (const uint32_t*)dpParent.p, dpFlags.p, dpTab.p, prm, maxB, limit);
-  }
   // ---- wide collapse, level by level
   LAUNCH(wide_root, dim3(1), dim3(1), 0, st, w0.p, ctr.p);
   WideItem* wc = w0.p; WideItem* wn = w1.p;
@@ -415,7 +398,7 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
     if (bound > maxLevelItems) bound = maxLevelItems;
     const uint32_t blocks = (uint32_t)((bound + 7u) / 8u) < 8192u ? (uint32_t)((bound + 7u) / 8u) : 8192u;   // = the waves resident at once
     const uint32_t parity = wlevel & 1u;
-    LAUNCH(wide_plan, dim3(blocks), dim3(64), 0, st, wc, bnodes.p, plans.p, itemCnt.p, groupSum.p, ctr.p, prm, parity, dpCollapse ? (const float*)dpTab.p : (const float*)nullptr);
+    LAUNCH(wide_plan, dim3(blocks), dim3(64), 0, st, wc, bnodes.p, plans.p, itemCnt.p, groupSum.p, ctr.p, prm, parity);
     LAUNCH(wide_scan, dim3(1), dim3(1024), 0, st, groupSum.p, ctr.p, parity, maxWide);
     LAUNCH(wide_emit, dim3(blocks), dim3(64), 0, st, wc, bnodes.p, plans.p, itemCnt.p, groupSum.p, wnodes.p, finalIds.p, outIds.p, wn, ctr.p, parity);
     WideItem* t = wc; wc = wn; wn = t; wlevel++;
@@ -495,7 +478,6 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
   guard.ok = true; *out = bvh;
   return 0;
 #undef LAUNCH
-#undef MEMSET
 #undef SYNC_READ
 }
 
@@ -671,7 +653,7 @@ extern "C" {
 
 void mi355_default_build_params(mi355_build_params* p) {
   memset(p, 0, sizeof(*p));
-  p->sah_block_shift = 0; p->min_leaf = 2; p->max_leaf = 3; p->small_threshold = 1024; p->trav_cost = 1.0f; p->int_cost = 1.0f; p->split_factor = 1.2f; p->presplits = 0; p->collapse = 0; p->dp_node_cost = 1.0f; p->dp_tri_cost = 0.5f;
+  p->sah_block_shift = 0; p->min_leaf = 2; p->max_leaf = 3; p->small_threshold = 1024; p->trav_cost = 1.0f; p->int_cost = 1.0f; p->split_factor = 1.2f; p->presplits = 0;
 }
 const char* mi355_last_error(void) { return mi355::g_err.c_str(); }
 int mi355_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }

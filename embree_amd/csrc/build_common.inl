@@ -52,7 +52,7 @@ struct Counters {
   unsigned long long areaFixed;                   // spatial-split builds: sum of the references' box areas / scene area, 2^-32 fixed point (build_spatial.inl)
   uint32_t lvlStart[64];                          // first node of every level of the wide tree (numbering is breadth first): what a refit walks bottom-up
 };
-struct Params { uint32_t shift, minLeaf, maxLeaf, small; float travCost, intCost; uint32_t quality, spatial; uint32_t collapse; float dpNode, dpTri; };   // collapse: 1 = cost-optimal (build_collapse.inl), 0 = the reference's greedy rule
+struct Params { uint32_t shift, minLeaf, maxLeaf, small; float travCost, intCost; uint32_t quality, spatial; };
 
 // order-preserving float <-> uint so that integer atomicMin/Max reduce floats exactly
 __device__ __forceinline__ uint32_t enc(float f) { uint32_t u = __float_as_uint(f); return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u); }

@@ -27,7 +27,7 @@ __device__ __forceinline__ float unzhi(uint32_t u) { return dec(u); }
 //   R + b * 16) and the exchange buffer the partition moves the triangles through (10 x 64 words at R + 1024).
 __device__ void micro_subtree(uint32_t* R, uint32_t W, uint32_t (*s_cb)[64][6], unsigned long long* s_key, const PrimRef* src,
                               uint32_t gbegin, uint32_t n0, uint32_t rootNode, const float* cmin0, const float* cmax0,
-                              BNode* bnodes, uint2* finalIds, Counters* ctr, const Params& prm, uint32_t lane, uint32_t* parent, uint32_t* leafNode) {
+                              BNode* bnodes, uint2* finalIds, Counters* ctr, const Params& prm, uint32_t lane) {
   PrimRef p{};
   if (lane < n0) p = load_prim(src + gbegin + lane);
   uint32_t segB = 0, segE = n0, node = rootNode;
@@ -179,7 +179,6 @@ __device__ void micro_subtree(uint32_t* R, uint32_t W, uint32_t (*s_cb)[64][6], 
         ((float4*)(bnodes + L))[1] = make_float4(cb[3], cb[4], cb[5], __uint_as_float(gbegin + segB + nL));
         ((float4*)(bnodes + Rr))[0] = make_float4(cb[6], cb[7], cb[8], __uint_as_float(gbegin + segB + nL));
         ((float4*)(bnodes + Rr))[1] = make_float4(cb[9], cb[10], cb[11], __uint_as_float(gbegin + segE));
-        if (parent) { parent[L] = node; parent[Rr] = node; }
       }
     }
     __syncthreads();
@@ -197,7 +196,6 @@ __device__ void micro_subtree(uint32_t* R, uint32_t W, uint32_t (*s_cb)[64][6], 
   if (lane < n0) {
     finalIds[gbegin + lane] = make_uint2(p.geom & 0x07FFFFFFu, p.prim);   // (top 5 bits: split budget of spatial-split builds, build_spatial.inl)
     if (lane == segB) ((uint4*)(bnodes + node))[2] = make_uint4(NIL, NIL, __float_as_uint(__builtin_inff()), 0u);
-    if (leafNode) leafNode[gbegin + lane] = lane == segB ? node : NIL;      // the binary leaf that begins at this position: where collapse_dp starts climbing
   }
   const unsigned long long leaves = __ballot(lane < n0 && lane == segB);
   if (lane == 0u) atomicAdd(&ctr->numBLeaves, (uint32_t)__popcll(leaves));
@@ -205,7 +203,7 @@ __device__ void micro_subtree(uint32_t* R, uint32_t W, uint32_t (*s_cb)[64][6], 
 }
 
 __global__ __launch_bounds__(64) void small_build(const SmallEntry* entries, PrimRef* bufA, PrimRef* bufB, BNode* bnodes,
-                                                  uint2* finalIds, Counters* ctr, Params prm, uint32_t W, uint32_t* parent, uint32_t* leafNode) {
+                                                  uint2* finalIds, Counters* ctr, Params prm, uint32_t W) {
   extern __shared__ __attribute__((aligned(16))) uint32_t s_R[];   // max(BINS_WORDS, 64 * W) words: bins / micro scratch
   __shared__ SplitResult s_res;
   __shared__ uint32_t s_acc[2][12];
@@ -224,7 +222,7 @@ __global__ __launch_bounds__(64) void small_build(const SmallEntry* entries, Pri
     PrimRef* src = cur.buf ? bufB : bufA;
     PrimRef* dst = cur.buf ? bufA : bufB;
     if (n <= MICRO) {
-      micro_subtree(s_R, W, s_cb, s_key, src, cur.begin, n, cur.bnode, cur.cmin, cur.cmax, bnodes, finalIds, ctr, prm, lane, parent, leafNode);
+      micro_subtree(s_R, W, s_cb, s_key, src, cur.begin, n, cur.bnode, cur.cmin, cur.cmax, bnodes, finalIds, ctr, prm, lane);
       if (sp == 0) break;
       cur = s_stack[--sp];
       __syncthreads();
@@ -295,7 +293,6 @@ __global__ __launch_bounds__(64) void small_build(const SmallEntry* entries, Pri
         br.lo[d] = fallback ? dec(s_acc[1][6 + d]) : r.rlo[d]; br.hi[d] = fallback ? dec(s_acc[1][9 + d]) : r.rhi[d];
       }
       bnodes[idL] = bl; bnodes[idR] = br;
-      if (parent) { parent[idL] = cur.bnode; parent[idR] = cur.bnode; }
     }
     // continue with the smaller child, push the larger: the stack stays <= log2(small_threshold) deep
     const bool leftSmaller = (L.end - L.begin) <= (R.end - R.begin);

@@ -62,7 +62,7 @@ __device__ __forceinline__ void segx_object_split(SegX* sx, uint32_t s, uint32_t
 __device__ __forceinline__ uint32_t segx_cap_left(const SegX* sx, uint32_t s);
 __device__ __forceinline__ void segx_child(SegX* nx, uint32_t k, uint32_t extEnd);
 __global__ __launch_bounds__(64) void top_split(Seg* segs, const uint32_t* bins, BNode* bnodes, Counters* ctr, Params prm, uint32_t forceFallback, SegX* sx,
-                                                const uint32_t* chunkCnt, uint2* chunkBase, uint32_t* parent) {
+                                                const uint32_t* chunkCnt, uint2* chunkBase) {
   __shared__ SplitResult s_res;
   __shared__ uint32_t s_plan[4];                                // fallback, dim, pos, capacity of the left child
   const uint32_t s = blockIdx.x, lane = threadIdx.x;
@@ -88,7 +88,6 @@ __global__ __launch_bounds__(64) void top_split(Seg* segs, const uint32_t* bins,
     L.left = L.right = R.left = R.right = NIL; L.splitSah = R.splitSah = __builtin_inff();
     for (int d = 0; d < 3; d++) { L.lo[d] = r.llo[d]; L.hi[d] = r.lhi[d]; R.lo[d] = r.rlo[d]; R.hi[d] = r.rhi[d]; }
     bnodes[idL] = L; bnodes[idR] = R;
-    if (parent) { parent[idL] = sg->bnode; parent[idR] = sg->bnode; }   // (what the cost-optimal collapse climbs, build_collapse.inl)
     sg->flags = fallback ? 1u : 0u; sg->dim = fallback ? 0u : (uint32_t)r.dim; sg->pos = fallback ? capL : (uint32_t)r.pos; sg->nL = nL;   // (median split: pos = where the right child starts, see top_partition)
     sg->childL = idL; sg->childR = idR; sg->curL = begin; sg->curR = begin + capL;
     for (int side = 0; side < 2; side++) for (int k = 0; k < 12; k++) sg->acc[side][k] = (k % 6 < 3) ? ENC_POS_INF : ENC_NEG_INF;

@@ -35,9 +35,6 @@ __device__ void sort_leaf(uint2* ids, uint32_t b, uint32_t e) {
 //   wide_emit   quantises the child boxes (8 bits, verified conservative in fp32), writes the 80-byte node, the next level's
 //               work items, and the leaf triangles' ids in (primID, geomID) order
 // The first version used one thread per node (206 VGPRs, 2 waves/SIMD, atomics for the numbering: 1.6 ms of a 9.4 ms commit).
-// cost-optimal cut of the binary tree (build_collapse.inl): table look-ups used by wide_plan
-__device__ __forceinline__ bool dp_is_leaf(const float* dp, uint32_t node);
-__device__ __forceinline__ uint32_t dp_distribute(const float* dp, uint32_t l, uint32_t r, uint32_t budget, float& D);
 struct WidePlan { uint32_t ch[8]; uint32_t imask, leafMask, nch, pad; };   // by slot; NIL = empty slot
 
 __global__ void wide_root(WideItem* items, Counters* ctr) {
@@ -64,7 +61,7 @@ __device__ __forceinline__ BNode load_bnode(const BNode* p) {
 }
 
 __global__ __launch_bounds__(64) void wide_plan(const WideItem* items, const BNode* bnodes, WidePlan* plans, uint2* itemCnt, uint2* groupSum,
-                                                Counters* ctr, Params prm, uint32_t parity, const float* dp) {
+                                                Counters* ctr, Params prm, uint32_t parity) {
   const uint32_t numItems = ctr->wideCount[parity];
   const float rootArea = ctr->rootArea;
   const uint32_t lane = threadIdx.x, c = lane & 7u, g = lane >> 3;
@@ -75,39 +72,6 @@ __global__ __launch_bounds__(64) void wide_plan(const WideItem* items, const BNo
     const BNode root = load_bnode(bnodes + it.bnode);
     // ---- children: lane c holds child c
     uint32_t nch, my = NIL; BNode mb = root;
-    if (dp) {
-      // cost-optimal cut (build_collapse.inl): every lane holds (binary node, roots it may still become); a lane with more than one root either gives one up
-      // (C(n, i) = C(n, i - 1)) or hands them to its two children the way D(n, i) says -- all lanes at once, a new lane per split
-      uint32_t bud = 0u;
-      if (!valid || root.left == NIL || dp_is_leaf(dp, it.bnode)) { nch = 1; if (c == 0u) my = it.bnode; }      // only the tree root can be a leaf itself
-      else {
-        float D; const uint32_t k = dp_distribute(dp, root.left, root.right, 8u, D);
-        nch = 2;
-        if (c < 2u) { my = c == 0u ? root.left : root.right; bud = c == 0u ? k : 8u - k; mb = load_bnode(bnodes + my); }
-      }
-      for (uint32_t round = 0; round < 24u; round++) {
-        const bool open = valid && c < nch && bud > 1u;
-        if (__ballot(open) == 0ull) break;
-        bool split = false; uint32_t k = 0u;
-        if (open) {
-          if (mb.left == NIL) bud = 1u;                            // a binary leaf: nothing to distribute
-          else {
-            float D; k = dp_distribute(dp, mb.left, mb.right, bud, D);
-            if (dp[8ull * my + (bud - 2u)] <= D) bud--;            // C(n, bud - 1) is as cheap: one root fewer
-            else split = true;
-          }
-        }
-        const uint32_t sm = (uint32_t)((__ballot(split) >> (lane & ~7u)) & 0xFFull);    // (group-uniform)
-        // lane nch + r takes the right child of the r-th splitting lane
-        uint32_t srcLane = c;
-        if (c >= nch) { uint32_t w = sm; for (uint32_t r = c - nch; r != 0u && w != 0u; r--) w &= w - 1u; srcLane = w ? (uint32_t)__builtin_ctz(w) : c; }
-        const uint32_t gr = grp_get(mb.right, lane, srcLane), gb = grp_get(bud, lane, srcLane), gk = grp_get(k, lane, srcLane);
-        const uint32_t ns = (uint32_t)__popc(sm);
-        if (split) { my = mb.left; bud = k; mb = load_bnode(bnodes + my); }
-        else if (valid && c >= nch && c < nch + ns) { my = gr; bud = gb - gk; mb = load_bnode(bnodes + my); }
-        nch += ns;
-      }
-    } else {
     if (root.left == NIL || make_leaf(root, prm)) { nch = 1; if (c == 0u) my = it.bnode; }        // only the tree root can be a leaf itself
     else { nch = 2; if (c < 2u) { my = c == 0u ? root.left : root.right; mb = load_bnode(bnodes + my); } }
     bool done = !valid || nch == 1u;
@@ -124,9 +88,8 @@ __global__ __launch_bounds__(64) void wide_plan(const WideItem* items, const BNo
         if (nch == 8u) done = true;
       }
     }
-    }
     const bool has = valid && c < nch;
-    const bool leaf = has && (dp ? (mb.left == NIL || dp_is_leaf(dp, my)) : make_leaf(mb, prm));
+    const bool leaf = has && make_leaf(mb, prm);
     const uint32_t cnt = has ? mb.end - mb.begin : 0u;
     float lo[3], hi[3], olo[3], ohi[3];
     for (int d = 0; d < 3; d++) { lo[d] = has ? mb.lo[d] : __builtin_inff(); hi[d] = has ? mb.hi[d] : -__builtin_inff(); olo[d] = grp_min(lo[d]); ohi[d] = grp_max(hi[d]); }

@@ -471,9 +471,6 @@ void parse_config(Device* d, const char* cfg) {
     else if (k == "host_pipeline_min") d->pipelineMin = (unsigned)atol(v.c_str());
     else if (k == "host_pipeline_chunk") d->pipelineChunk = atol(v.c_str()) >= 1024 ? (unsigned)atol(v.c_str()) : 1024u;
     else if (k == "int_cost") d->build.int_cost = (float)atof(v.c_str());
-    else if (k == "collapse") d->build.collapse = (v == "greedy" || v == "1") ? 1u : 0u;            // wide-node children: cost-optimal cut (default) or the reference's greedy rule
-    else if (k == "dp_node_cost") d->build.dp_node_cost = (float)atof(v.c_str());
-    else if (k == "dp_tri_cost") d->build.dp_tri_cost = (float)atof(v.c_str());
     else if (k == "trav_cost") d->build.trav_cost = (float)atof(v.c_str());
     // CPU-only keys of the reference (threads, isa, tri_accel, hugepages, ...) are accepted and ignored
   }

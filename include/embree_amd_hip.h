@@ -62,12 +62,6 @@ typedef struct mi355_build_params {
   uint32_t refit;            /* 1: keep what mi355_bvh_refit needs (8 B per triangle: the leaf order, and the level table).  default 0 */
   uint32_t presplits;        /* quality 2 only: 1 = pre-split instead of splitting inside the recursion (reference: device config "presplits=1",
                                 kernels/common/state.cpp:88,443).  default 0 */
-  uint32_t collapse;         /* which binary nodes become the children of an 8-wide node.  0 (default) = the cost-optimal cut: a dynamic programme over the
-                                binary tree that prices a wide node the same whether 2 or 8 of its slots are used (embree_amd/csrc/build_collapse.inl);
-                                1 = the reference's greedy rule, "split the child with the largest half-area until there are 8" + leaf-vs-split SAH test
-                                (BuilderT::recurse, kernels/builders/bvh_builder_sah.h:229-272) */
-  float    dp_node_cost;     /* collapse = 0: cost of a wide node per unit of half-area.  default 1 */
-  float    dp_tri_cost;      /* collapse = 0: cost of a leaf triangle per unit of half-area.  default 0.5 */
 } mi355_build_params;
 
 typedef struct mi355_bvh_info {

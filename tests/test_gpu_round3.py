@@ -2,8 +2,6 @@
 
   * one RTCDevice over several GPUs (rtcNewDevice("gpus=N")): replicas bit-identical, the sharded host-array and device-array queries give the
     single-GPU answer bit for bit (on a 1-GPU box the replicas share the GPU: gpu_oversubscribe=1 -- same code, same threads, same peer copies);
-  * the cost-optimal collapse (embree_amd/csrc/build_collapse.inl) against the reference's greedy rule: both trees valid, same answers, fewer nodes,
-    bit-identical rebuilds;
   * rtcCommitScene after detach + a NEW geometry that reuses the freed one's address and counters (the advisor's stale-tree scenario);
   * filter callbacks in a ROBUST scene see every rejected candidate exactly once;
   * configs[3] as a whole job at N = 1 through bench.py's own code (pack + gather) against the real reference on a 2^22-ray prefix;
@@ -142,46 +140,6 @@ def test_more_gpus_than_the_node_has_is_an_error(api):
         api.Device("gpus=%d" % (n + 1))
     assert e.value.code == api.RTC_ERROR_INVALID_ARGUMENT
     L.rtcGetDeviceError(None)
-
-
-# ------------------------------------------------------------------------------------------- cost-optimal collapse vs the reference's greedy rule
-def test_collapse_cost_optimal_vs_greedy(api):
-    """The children of a wide node come from a dynamic programme over the binary tree (build_collapse.inl) instead of the reference's greedy
-    "largest half-area first" (bvh_builder_sah.h:247-272).  Both trees must be valid, give identical answers (the hit does not depend on the tree),
-    the cost-optimal one has fewer, fuller nodes; rebuilds are bit-identical (the tables are filled by a race-free climb)."""
-    meshes = W.synthetic_crown(num_phi=48)
-    rays = W.incoherent_rays(100000, [2, 2, 1.5], seed=5)
-    out = {}
-    for name, cfg in (("dp", "gpu=0"), ("greedy", "gpu=0,collapse=greedy"), ("dp_low", "gpu=0,quality=low"), ("dp_high", "gpu=0,quality=high")):
-        d = api.Device(cfg)
-        blobs = []
-        for rep in range(2):
-            s = api.make_scene(d, meshes)
-            nodes, tris = s.download_bvh()
-            blobs.append((nodes.tobytes(), tris.tobytes()))
-            if rep == 0:
-                info = s.info()
-                if name != "dp_high":                              # (a spatial-split tree holds some triangles several times: its own tests check it)
-                    bvh_check.validate(nodes, tris, info["root_ref"], meshes, max_leaf=info["max_leaf"])
-                got = rays.copy()
-                s.intersect1M(got)
-                dd = api.DeviceArray.from_numpy(rays)
-                stt = s.trace_stats(dd.ptr, rays.shape[0], 96)
-                dd.free()
-                fill = (info["num_leaves"] + info["num_nodes"] - 1) / max(1, info["num_nodes"])
-                out[name] = dict(got=got, nodes=info["num_nodes"], leaves=info["num_leaves"], fill=fill, npr=stt["nodes"] / rays.shape[0], tpr=stt["tris"] / rays.shape[0], ms=info["build_ms"])
-            s.release()
-        assert blobs[0] == blobs[1], "%s: two commits of the same scene differ" % name
-        d.release()
-    for k, v in out.items():
-        print("collapse %-8s nodes %7d leaf slots %7d children/node %.2f | nodes/ray %.2f tris/ray %.2f | build %.2f ms" % (k, v["nodes"], v["leaves"], v["fill"], v["npr"], v["tpr"], v["ms"]))
-    tt = tri_t_of(meshes)
-    compare_closest(out["dp"]["got"], out["greedy"]["got"], rays, tt, label="cost-optimal vs greedy collapse")
-    compare_closest(out["dp_low"]["got"], out["greedy"]["got"], rays, tt, label="cost-optimal collapse of the Morton tree")
-    compare_closest(out["dp_high"]["got"], out["greedy"]["got"], rays, tt, label="cost-optimal collapse of the spatial-split tree")
-    assert out["dp"]["nodes"] < 0.9 * out["greedy"]["nodes"], (out["dp"]["nodes"], out["greedy"]["nodes"])
-    assert out["dp"]["fill"] > out["greedy"]["fill"] + 0.5
-    assert out["dp"]["npr"] < out["greedy"]["npr"]
 
 
 # ------------------------------------------------------------------------------------------- advisor: stale tree after detach + new geometry
