@@ -134,7 +134,7 @@ Bvh::~Bvh() {
 // looks at the counters between groups of levels like the first generations of this builder did.  Why: a host round trip costs 20-40 us on an idle
 // box but was measured at ~0.8 ms each on the round-end driver's box (commit 13.9 ms there, 7.0 ms here, same code), and there were nine of them.
 // LOW (Morton: the sort needs n on the host) and HIGH (presplit: the budget loop) keep one round trip after primref_gen.
-static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, const mi355_build_params* bp, hipStream_t st, Bvh** out, bool allowFast = true) {
+static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, const mi355_build_params* bp, hipStream_t st, Bvh** out, bool allowFast = true, bool allowTopSplits = true) {
   HIP_TRY(hipSetDevice(device));
   Arena* arena = arena_of(device);
   std::lock_guard<std::mutex> arenaLock(arena->mtx);
@@ -155,6 +155,14 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
   // reference's other form, splitting big triangles up front (state.cpp:88 useSpatialPreSplits).  The spatial splits live in the top phase: lower its end.
   prm.spatial = (bp->quality == 2u && !bp->presplits && numMeshes < (1u << 27)) ? 1u : 0u;
   if (prm.spatial && prm.small > 256u) prm.small = 256u;
+  // RTC_BUILD_QUALITY_MEDIUM (the default): the SAME spatial splits, but only in the sets of the first levels (>= top_split_min references, default 65536)
+  // and without leaving the one-round-trip path.  Measured on the crown stand-in (profiles/r03_collapse.md): what the HIGH tree gains on the bench's rays
+  // (36.6 -> 32.7 node visits, 51.0 -> 46.6 triangle tests per ray, +11 % rays per second) comes from the few room-sized triangles cut near the root;
+  // restricted to big sets the splits keep that gain for a fraction of HIGH's build time.  The reference's MEDIUM builder never splits
+  // (BVHBuilderBinnedSAH, kernels/builders/bvh_builder_sah.h:446); answers do not depend on it, "top_splits=0" switches it off.  Not with refit data
+  // (a refit walks one leaf record per triangle).
+  const bool topSplits = allowTopSplits && bp->quality == 0u && bp->top_splits != 0u && !bp->refit && numMeshes < (1u << 27);
+  if (topSplits) prm.spatial = 1u;
 
   std::vector<GeomDesc> gd; uint64_t total = 0;
   for (uint32_t i = 0; i < numMeshes; i++) {
@@ -192,9 +200,10 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
   // sets of fewer references than this split by object only (the reference tries a spatial split wherever a set has an extended range): measured, the SAH
   // of the long-triangle scene is 12.53 instead of 12.52 and the crown stand-in's tree does not change, for 1.2 ms less (spatial_bin clips a small set's
   // references through most of its 16 bins per axis); 2048 would cost 2 % of the SAH gain, 65536 all of it on small scenes (profiles/r02_sah_vs_reference.md)
-  static const uint32_t spatialMin = getenv("MI355_SPATIAL_MIN") ? (uint32_t)atol(getenv("MI355_SPATIAL_MIN")) : 512u;
+  static const uint32_t spatialMinHigh = getenv("MI355_SPATIAL_MIN") ? (uint32_t)atol(getenv("MI355_SPATIAL_MIN")) : 512u;
+  const uint32_t spatialMin = topSplits ? (bp->top_split_min ? bp->top_split_min : 65536u) : spatialMinHigh;
   const bool presplit = prm.quality == 2u && !spatial;         // up to 20 % more references than triangles, either way
-  const uint32_t splitBudget = prm.quality == 2u ? (uint32_t)((double)N * (bp->split_factor > 1.0f ? (double)bp->split_factor - 1.0 : 0.2)) : 0u;
+  const uint32_t splitBudget = (prm.quality == 2u || topSplits) ? (uint32_t)((double)N * (bp->split_factor > 1.0f ? (double)bp->split_factor - 1.0 : 0.2)) : 0u;
   const uint64_t cap64 = (uint64_t)N + splitBudget;
   if (cap64 >= (1ull << 31)) return set_error(hipErrorInvalidValue, "more than 2^31 references are not supported by the 32-bit triangle index");
   const uint32_t NC = (uint32_t)cap64;                        // capacity of every per-reference array
@@ -220,10 +229,10 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
   struct EvGuard { hipEvent_t a, b; ~EvGuard() { hipEventDestroy(a); hipEventDestroy(b); } } evg{ev0, ev1};
   if (useGraph) {
     HIP_TRY(hipStreamSynchronize(st));                         // (the geometry table above is in place before anything is captured)
-    const void* ptrs[] = {dGeoms.p, bufA.p, bufB.p, finalIds.p, bnodes.p, segs0.p, segs1.p, bins.p, chunks.p, small.p, ctr.p, w0.p, w1.p, wnodes.p, outIds.p, plans.p, itemCnt.p, groupSum.p, tileCount.p, chunkCnt.p, chunkBase.p, (const void*)st};
+    const void* ptrs[] = {dGeoms.p, bufA.p, bufB.p, finalIds.p, bnodes.p, segs0.p, segs1.p, bins.p, chunks.p, small.p, ctr.p, w0.p, w1.p, wnodes.p, outIds.p, plans.p, itemCnt.p, groupSum.p, tileCount.p, chunkCnt.p, chunkBase.p, segx0.p, segx1.p, sbins.p, (const void*)st};
     std::vector<uint64_t> key; for (const void* q : ptrs) key.push_back((uint64_t)(uintptr_t)q);
     uint32_t pw[sizeof(Params) / 4]; memcpy(pw, &prm, sizeof(prm)); for (uint32_t w : pw) key.push_back(w);
-    key.push_back(N); key.push_back(gd.size()); key.push_back(bp->robust);
+    key.push_back(N); key.push_back(gd.size()); key.push_back(bp->robust); key.push_back(spatialMin); key.push_back(NC);
     if (arena->graphExec && arena->graphKey == key) replay = true;
     else {
       arena->drop_graph(); arena->graphKey = key;
@@ -249,6 +258,12 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
     LAUNCH(compact_copyback, dim3(tiles < 2048u ? tiles : 2048u), dim3(256), 0, st, bufB.p, bufA.p, ctr.p);
     LAUNCH(root_setup, dim3(1), dim3(1), 0, st, ctr.p, bnodes.p, segs0.p, small.p, N, prm.small);
     numSegs = N > prm.small ? 1u : 0u;
+    if (spatial && N > prm.small) {                              // split budgets of the references (the number of valid ones is on the device); the root set owns everything behind them
+      const uint32_t ab = (N + 255u) / 256u < 2048u ? (N + 255u) / 256u : 2048u;
+      LAUNCH(spatial_area_sum, dim3(ab), dim3(256), 0, st, bufA.p, N, ctr.p);
+      LAUNCH(spatial_budgets, dim3((N + 255u) / 256u), dim3(256), 0, st, bufA.p, N, ctr.p);
+      LAUNCH(segx_root, dim3(1), dim3(1), 0, st, segx0.p, NC);
+    }
   } else {
     SYNC_READ(h);
     h.numPrims = N - h.numInvalid;
@@ -340,6 +355,10 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
   //      an upper bound of its grid (<= 2^level segments, <= N/CHUNK + #segments chunks) and surplus blocks exit at once, so
   //      the levels are enqueued back to back.
   uint32_t level = 0;
+  // top splits of a MEDIUM build: a set of >= spatialMin references cannot exist below level log2(N / spatialMin) + a margin for uneven splits (a set that is
+  // still that big further down simply splits by object, like every small set does): the spatial kernels are not even launched there
+  uint32_t spatialLevels = 0xFFFFFFFFu;
+  if (topSplits) { spatialLevels = 6u; while (spatialLevels < 40u && ((uint64_t)spatialMin << (spatialLevels - 6u)) < N) spatialLevels++; }
   Seg* cur = segs0.p; Seg* nxt = segs1.p; SegX* xcur = segx0.p; SegX* xnxt = segx1.p;     // (the SegX arrays: nullptr unless spatial)
   auto enqueue_top_level = [&]() {
     PrimRef* src = (level & 1u) ? bufB.p : bufA.p; PrimRef* dst = (level & 1u) ? bufA.p : bufB.p;
@@ -348,13 +367,14 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
     LAUNCH(top_setup, dim3(segBound), dim3(256), 0, st, cur, bins.p, chunks.p, ctr.p);
     LAUNCH(top_bin, dim3(chunkBound), dim3(256), 0, st, cur, chunks.p, src, bins.p, ctr.p, chunkCnt.p);
     LAUNCH(top_split, dim3(segBound), dim3(64), 0, st, cur, bins.p, bnodes.p, ctr.p, prm, level >= 96u ? 1u : 0u, xcur, (const uint32_t*)chunkCnt.p, chunkBase.p);
-    if (spatial) {                                               // sets whose object split leaves overlapping children try a spatial split
+    const bool spatialLevel = spatial && level < spatialLevels;
+    if (spatialLevel) {                                          // sets whose object split leaves overlapping children try a spatial split
       LAUNCH(spatial_decide, dim3(segBound), dim3(128), 0, st, cur, xcur, bnodes.p, sbins.p, ctr.p, spatialMin);
       LAUNCH(spatial_bin, dim3(chunkBound), dim3(256), 0, st, cur, xcur, chunks.p, src, dGeoms.p, sbins.p, ctr.p);
       LAUNCH(spatial_best, dim3(segBound), dim3(64), 0, st, cur, xcur, sbins.p, bnodes.p, ctr.p, prm);
     }
     LAUNCH(top_partition, dim3(chunkBound), dim3(256), 0, st, cur, chunks.p, src, dst, ctr.p, (const uint2*)chunkBase.p);
-    if (spatial) LAUNCH(spatial_partition, dim3(chunkBound), dim3(256), 0, st, cur, xcur, chunks.p, src, dst, dGeoms.p, ctr.p);
+    if (spatialLevel) LAUNCH(spatial_partition, dim3(chunkBound), dim3(256), 0, st, cur, xcur, chunks.p, src, dst, dGeoms.p, ctr.p);
     LAUNCH(top_emit, dim3((segBound + 255u) / 256u), dim3(256), 0, st, cur, bnodes.p, nxt, small.p, ctr.p, prm,
            (level & 1u) ? 0u : 1u, maxSegs, maxSmall, (const SegX*)xcur, xnxt);
     LAUNCH(top_advance, dim3(1), dim3(1), 0, st, ctr.p, maxSegs);
@@ -418,15 +438,17 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
     }
     if (replay) { HIP_TRY(hipEventRecord(ev0, st)); HIP_TRY(hipGraphLaunch(arena->graphExec, st)); replay = false; }
     // the leaf records can be written as soon as the leaf order is known; their array is sized by the upper bound N
-    HIP_TRY(hipMalloc(&bvh->d_tris, (size_t)N * sizeof(TriRec) + 128));
-    LAUNCH(tri_records, dim3((N + 255u) / 256u), dim3(256), 0, st, outIds.p, N, dGeoms.p, (TriRec*)bvh->d_tris, bp->robust ? 1u : 0u, (const Counters*)ctr.p);
+    HIP_TRY(hipMalloc(&bvh->d_tris, (size_t)NC * sizeof(TriRec) + 128));
+    LAUNCH(tri_records, dim3((NC + 255u) / 256u), dim3(256), 0, st, outIds.p, NC, dGeoms.p, (TriRec*)bvh->d_tris, bp->robust ? 1u : 0u, (const Counters*)ctr.p);
     SYNC_READ(h);                                                // the ONE round trip of the commit
+    if (h.overflow == 2u && topSplits) return -1001;             // a top split ran out of its extended range (guarded stores, nothing was corrupted): the caller repeats the commit without top splits
     if (h.overflow) return set_error(hipErrorOutOfMemory, "work list overflow (pathological input)");
     if (h.numSegs != 0u) {                                       // the top phase needed more levels than N implies + 8: what came after it worked on an unfinished tree
       arena->marginFailedN = N;
       return -1000;                                              // (the guard frees the half-built tree) the caller repeats the commit on the stepwise path
     }
     n = h.numPrims;
+    if (spatial && n != 0u) { info.num_presplit = h.numTrisOut > n ? h.numTrisOut - n : 0u; n = h.numTrisOut; }   // the references the splits created are leaf entries like any other
     if (n == 0) { hipFree(bvh->d_tris); bvh->d_tris = nullptr; info.num_launches = launches; info.num_host_syncs = syncs; guard.ok = true; *out = bvh; return 0; }
     for (int d = 0; d < 3; d++) { info.bounds_lower[d] = decf(h.bounds[d]); info.bounds_upper[d] = decf(h.bounds[3 + d]); }
     info.top_levels = h.topLevels;
@@ -437,7 +459,7 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
       if (h.overflow) return set_error(hipErrorOutOfMemory, "wide node pool overflow");
       redoLeaves = true;
     }
-    if (redoLeaves) LAUNCH(tri_records, dim3((N + 255u) / 256u), dim3(256), 0, st, outIds.p, N, dGeoms.p, (TriRec*)bvh->d_tris, bp->robust ? 1u : 0u, (const Counters*)ctr.p);
+    if (redoLeaves) LAUNCH(tri_records, dim3((NC + 255u) / 256u), dim3(256), 0, st, outIds.p, NC, dGeoms.p, (TriRec*)bvh->d_tris, bp->robust ? 1u : 0u, (const Counters*)ctr.p);
   } else {
     for (uint32_t i = 0; i < 8u; i++) enqueue_wide_level();
     for (;;) {
@@ -460,7 +482,7 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
     HIP_TRY(hipMemcpyAsync(bvh->d_nodes, wnodes.p, (size_t)numNodes * sizeof(CNode), hipMemcpyDeviceToDevice, st));
   }
   bvh->robust = bp->robust != 0;
-  if (bp->refit && h.numInvalid == 0u && depth < 64u && prm.quality != 2u) {        // keep the leaf order and the level table for mi355_bvh_refit
+  if (bp->refit && h.numInvalid == 0u && depth < 64u && prm.quality != 2u && !spatial) {        // keep the leaf order and the level table for mi355_bvh_refit
     HIP_TRY(hipMalloc(&bvh->d_ids, (size_t)n * sizeof(uint2)));
     HIP_TRY(hipMemcpyAsync(bvh->d_ids, outIds.p, (size_t)n * sizeof(uint2), hipMemcpyDeviceToDevice, st));
     bvh->lvlStart.assign(h.lvlStart, h.lvlStart + depth); bvh->lvlStart.push_back(numNodes);
@@ -479,6 +501,15 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
   return 0;
 #undef LAUNCH
 #undef SYNC_READ
+}
+
+// the one-round-trip path can ask for the commit to be repeated: -1000 = level margins exceeded (stepwise path), -1001 = a top split of a MEDIUM build
+// ran out of its extended range (same path, no top splits)
+static int build_retry(int device, const mi355_mesh* meshes, uint32_t numMeshes, const mi355_build_params* bp, hipStream_t st, Bvh** out) {
+  int rc = build_impl(device, meshes, numMeshes, bp, st, out);
+  if (rc == -1001) rc = build_impl(device, meshes, numMeshes, bp, st, out, true, false);
+  if (rc == -1000) rc = build_impl(device, meshes, numMeshes, bp, st, out, false, false);
+  return rc;
 }
 
 static int refit_impl(Bvh* bvh, const mi355_mesh* meshes, uint32_t numMeshes, hipStream_t st) {
@@ -610,7 +641,8 @@ static int build_instanced_impl(int device, Bvh* own, const mi355_instance* inst
   mi355_mesh fake{}; fake.d_vertices = dfv; fake.vertex_stride = 12; fake.num_vertices = 3 * R; fake.d_indices = dfi; fake.index_stride = 12; fake.num_triangles = R; fake.geom_id = 0; fake.mask = 0xFFFFFFFFu;
   mi355_build_params tp = *bp; tp.refit = 0; tp.quality = 0;
   Bvh* top = nullptr;
-  { int rc = build_impl(device, &fake, 1, &tp, st, &top); if (rc == -1000) rc = build_impl(device, &fake, 1, &tp, st, &top, false); if (rc) return rc; }
+  tp.top_splits = 0;                                            // (the "triangles" of this build are the instances' boxes: one leaf record each)
+  { const int rc = build_retry(device, &fake, 1, &tp, st, &top); if (rc) return rc; }
   struct TopGuard { Bvh* t; ~TopGuard() { delete t; } } topGuard{top};
   if (top->info.num_triangles != R) return set_error(hipErrorInvalidValue, "top-level build dropped an instance");
   bvh->numCUs = top->numCUs;
@@ -653,7 +685,7 @@ extern "C" {
 
 void mi355_default_build_params(mi355_build_params* p) {
   memset(p, 0, sizeof(*p));
-  p->sah_block_shift = 0; p->min_leaf = 2; p->max_leaf = 3; p->small_threshold = 1024; p->trav_cost = 1.0f; p->int_cost = 1.0f; p->split_factor = 1.2f; p->presplits = 0;
+  p->sah_block_shift = 0; p->min_leaf = 2; p->max_leaf = 3; p->small_threshold = 1024; p->trav_cost = 1.0f; p->int_cost = 1.0f; p->split_factor = 1.2f; p->presplits = 0; p->top_splits = 1; p->top_split_min = 65536;
 }
 const char* mi355_last_error(void) { return mi355::g_err.c_str(); }
 int mi355_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
@@ -664,8 +696,7 @@ int mi355_device_name(int device, char* out, size_t n) {
 int mi355_bvh_build(int device, const mi355_mesh* meshes, uint32_t num_meshes, const mi355_build_params* params, void* stream, mi355_bvh_t* out) {
   mi355_build_params def; if (!params) { mi355_default_build_params(&def); params = &def; }
   mi355::Bvh* b = nullptr;
-  int rc = mi355::build_impl(device, meshes, num_meshes, params, (hipStream_t)stream, &b);
-  if (rc == -1000) rc = mi355::build_impl(device, meshes, num_meshes, params, (hipStream_t)stream, &b, false);   // margins of the one-round-trip path exceeded: stepwise path
+  const int rc = mi355::build_retry(device, meshes, num_meshes, params, (hipStream_t)stream, &b);
   *out = (mi355_bvh_t)b; return rc;
 }
 void mi355_bvh_destroy(mi355_bvh_t bvh) { delete (mi355::Bvh*)bvh; }

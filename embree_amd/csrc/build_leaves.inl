@@ -3,7 +3,7 @@
 // --------------------------------------------------------------------------------- K5 tri_records
 __global__ __launch_bounds__(256) void tri_records(const uint2* finalIds, uint32_t n, const GeomDesc* geoms, TriRec* out, uint32_t robust, const Counters* ctr) {
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-  if (i >= (ctr ? ctr->numPrims : n)) return;                    // ctr: the grid is an upper bound, the number of valid triangles is on the device
+  if (i >= (ctr ? max(ctr->numPrims, ctr->numTrisOut) : n)) return;   // ctr: the grid is an upper bound, the number of leaf records is on the device (numTrisOut: what the wide collapse numbered; > numPrims after spatial splits)
   uint2 id = finalIds[i];
   const GeomDesc g = geoms[id.x];
   uint32_t i0, i1, i2, pid;

@@ -66,6 +66,11 @@ __device__ uint32_t presplit_walk(const PrimRef& ref, uint32_t want, const float
       }
     }
     bool okL = true, okR = true;
+    for (int d = 0; d < 3; d++) {                                  // interpolated cut points: 4 ulp of slack before the clamp (see split_triangle, build_spatial.inl)
+      const float eL = 4.76837158e-7f * fmaxf(fabsf(L.lo[d]), fabsf(L.hi[d])), eR = 4.76837158e-7f * fmaxf(fabsf(R.lo[d]), fabsf(R.hi[d]));
+      if (L.lo[d] <= L.hi[d]) { L.lo[d] -= eL; L.hi[d] += eL; }
+      if (R.lo[d] <= R.hi[d]) { R.lo[d] -= eR; R.hi[d] += eR; }
+    }
     for (int d = 0; d < 3; d++) {                                  // intersect with the piece that is being split
       L.lo[d] = fmaxf(L.lo[d], cur.lo[d]); L.hi[d] = fminf(L.hi[d], cur.hi[d]); R.lo[d] = fmaxf(R.lo[d], cur.lo[d]); R.hi[d] = fminf(R.hi[d], cur.hi[d]);
       okL = okL && L.lo[d] <= L.hi[d]; okR = okR && R.lo[d] <= R.hi[d];

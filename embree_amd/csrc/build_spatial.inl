@@ -64,6 +64,15 @@ __device__ __forceinline__ void split_triangle(const float (&v)[3][3], uint32_t 
       for (int d = 0; d < 3; d++) { const float c = fmaf(t, v[e1][d] - v[e][d], v[e][d]); Llo[d] = fminf(Llo[d], c); Lhi[d] = fmaxf(Lhi[d], c); Rlo[d] = fminf(Rlo[d], c); Rhi[d] = fmaxf(Rhi[d], c); }
     }
   }
+  // The cut points are interpolated (t = (pos - a0) / (a1 - a0), c = v + t (v' - v)): each coordinate carries a rounding error of a few ulp OF ITS MAGNITUDE, so
+  // far from the origin the two pieces' boxes could leave a sliver of the triangle along the cut uncovered (crown stand-in at 1e5: 7 of 16384 rays slipped
+  // through, tests/test_gpu_round2.py::test_fast_mode_far_from_the_origin).  Both boxes are therefore widened by 4 ulp of their largest coordinate before they
+  // are clamped to the piece that is being cut (whose box is conservative by induction: the first one is the triangle's exact box).
+  for (int d = 0; d < 3; d++) {
+    const float eL = 4.76837158e-7f * fmaxf(fabsf(Llo[d]), fabsf(Lhi[d])), eR = 4.76837158e-7f * fmaxf(fabsf(Rlo[d]), fabsf(Rhi[d]));
+    if (Llo[d] <= Lhi[d]) { Llo[d] -= eL; Lhi[d] += eL; }
+    if (Rlo[d] <= Rhi[d]) { Rlo[d] -= eR; Rhi[d] += eR; }
+  }
   for (int d = 0; d < 3; d++) { Llo[d] = fmaxf(Llo[d], curLo[d]); Lhi[d] = fminf(Lhi[d], curHi[d]); Rlo[d] = fmaxf(Rlo[d], curLo[d]); Rhi[d] = fminf(Rhi[d], curHi[d]); }
 }
 __device__ __forceinline__ bool box_empty(const float* lo, const float* hi) { return lo[0] > hi[0] || lo[1] > hi[1] || lo[2] > hi[2]; }
@@ -72,8 +81,10 @@ __device__ __forceinline__ void load_tri_masked(const GeomDesc* geoms, const Pri
 }
 
 // ---- split budgets (bvh_builder_sah.h:574-601): two passes over the references, the sum in fixed point relative to the scene's area
-__global__ __launch_bounds__(256) void spatial_area_sum(const PrimRef* prims, uint32_t n, Counters* ctr) {
+__global__ void segx_root(SegX* sx, uint32_t cap) { if (threadIdx.x == 0u && blockIdx.x == 0u) { SegX x{}; x.extEnd = cap; sx[0] = x; } }   // the root set owns the whole extended range
+__global__ __launch_bounds__(256) void spatial_area_sum(const PrimRef* prims, uint32_t nUpper, Counters* ctr) {
   __shared__ unsigned long long s_w[4];
+  const uint32_t n = min(nUpper, ctr->numPrims);                // (one-round-trip commits: the number of valid references is on the device)
   const float rootArea2 = 2.0f * ctr->rootArea;
   unsigned long long acc = 0ull;
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
@@ -86,8 +97,8 @@ __global__ __launch_bounds__(256) void spatial_area_sum(const PrimRef* prims, ui
   __syncthreads();
   if (threadIdx.x == 0u) atomicAdd(&ctr->areaFixed, s_w[0] + s_w[1] + s_w[2] + s_w[3]);
 }
-__global__ __launch_bounds__(256) void spatial_budgets(PrimRef* prims, uint32_t n, const Counters* ctr) {
-  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+__global__ __launch_bounds__(256) void spatial_budgets(PrimRef* prims, uint32_t nUpper, const Counters* ctr) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x, n = min(nUpper, ctr->numPrims);
   if (i >= n) return;
   const float rootArea2 = 2.0f * ctr->rootArea;
   const double sumRel = (double)ctr->areaFixed / 4294967296.0;                     // sum of the boxes' areas / scene area

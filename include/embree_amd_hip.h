@@ -62,6 +62,11 @@ typedef struct mi355_build_params {
   uint32_t refit;            /* 1: keep what mi355_bvh_refit needs (8 B per triangle: the leaf order, and the level table).  default 0 */
   uint32_t presplits;        /* quality 2 only: 1 = pre-split instead of splitting inside the recursion (reference: device config "presplits=1",
                                 kernels/common/state.cpp:88,443).  default 0 */
+  uint32_t top_splits;       /* quality 0 (MEDIUM) only: 1 = sets of >= top_split_min references may split spatially like a quality-2 build (same kernels,
+                                same thresholds, embree_amd/csrc/build_spatial.inl); the rest of the tree splits by object only.  The reference's MEDIUM builder
+                                never splits spatially; hits do not depend on it; leaf records of a cut triangle exist more than once
+                                (mi355_bvh_info.num_presplit).  Off whenever params.refit is set.  default 1 */
+  uint32_t top_split_min;    /* default 65536 */
 } mi355_build_params;
 
 typedef struct mi355_bvh_info {

@@ -23,7 +23,9 @@ def decode_child_boxes(node):
     return lo, hi
 
 
-def validate(nodes, tris, root_ref, meshes, masks=None, geom_ids=None, max_leaf=3):
+def validate(nodes, tris, root_ref, meshes, masks=None, geom_ids=None, max_leaf=3, allow_splits=False):
+    """allow_splits: the tree may hold a triangle several times (spatial splits: every record of a cut triangle bounds only its piece, so the containment
+    check is made for the triangles that appear once; every triangle must still be there at least once)"""
     n_tris = tris.shape[0]
     # --- triangle records against the input meshes
     expect = {}
@@ -36,17 +38,19 @@ def validate(nodes, tris, root_ref, meshes, masks=None, geom_ids=None, max_leaf=
         ok &= np.isfinite(tv).all((1, 2)) & (np.abs(tv) < 1.844e18).all((1, 2))
         for p in np.nonzero(ok)[0]:
             expect[(gid, int(p))] = tv[p]
-    assert n_tris == len(expect), f"tree holds {n_tris} triangles, input has {len(expect)} valid ones"
-    seen = set()
+    assert n_tris == len(expect) or (allow_splits and n_tris >= len(expect)), f"tree holds {n_tris} triangles, input has {len(expect)} valid ones"
+    seen = {}
     for i in range(n_tris):
         key = (int(tris["geomID"][i]), int(tris["primID"][i]))
-        assert key in expect and key not in seen, f"triangle record {i} {key} unexpected or duplicated"
-        seen.add(key)
+        assert key in expect and (allow_splits or key not in seen), f"triangle record {i} {key} unexpected or duplicated"
+        seen[key] = seen.get(key, 0) + 1
         a, b, c = expect[key]
         assert (tris["v0"][i] == a).all() and (tris["e1"][i] == a - b).all() and (tris["e2"][i] == c - a).all(), f"record {i} geometry"
         if masks is not None:
             gi = key[0] if geom_ids is None else geom_ids.index(key[0])
             assert tris["mask"][i] == masks[gi]
+    assert len(seen) == len(expect), "a triangle is missing from the tree"
+    whole = np.array([seen[(int(tris["geomID"][i]), int(tris["primID"][i]))] == 1 for i in range(n_tris)], bool) if n_tris else np.zeros(0, bool)
     if n_tris == 0:
         assert root_ref == EMPTY
         return dict(nodes=0, leaves=0, depth=0)
@@ -93,9 +97,12 @@ def validate(nodes, tris, root_ref, meshes, masks=None, geom_ids=None, max_leaf=
                 assert first + cnt <= n_tris
                 covered[first:first + cnt] += 1
                 ids = (tris["primID"][first:first + cnt].astype(np.uint64) << 32) | tris["geomID"][first:first + cnt]
-                assert cnt == 1 or (np.diff(ids.astype(np.int64)) > 0).all(), "leaf not sorted by (primID, geomID)"
+                assert cnt == 1 or (np.diff(ids.astype(np.int64)) >= (0 if allow_splits else 1)).all(), "leaf not sorted by (primID, geomID)"
                 stats["leaves"] += 1
-                clo, chi = tlo[first:first + cnt].min(0), thi[first:first + cnt].max(0)
+                w = whole[first:first + cnt]
+                if not w.any():                                   # only pieces of cut triangles: nothing this validator can bound
+                    continue
+                clo, chi = tlo[first:first + cnt][w].min(0), thi[first:first + cnt][w].max(0)
             assert (lo[s] <= clo + slack).all() and (hi[s] >= chi - slack).all(), \
                 f"node {idx} slot {s}: decoded box {lo[s]}..{hi[s]} does not contain {clo}..{chi}"
             blo, bhi = np.minimum(blo, clo), np.maximum(bhi, chi)

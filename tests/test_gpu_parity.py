@@ -165,7 +165,7 @@ def test_crown_small_bounce_and_shadow(api, dev, restate):
     s = api.make_scene(dev, meshes)
     info = s.info()
     nodes, tris = s.download_bvh()
-    bvh_check.validate(nodes, tris, info["root_ref"], meshes, max_leaf=info["max_leaf"])
+    bvh_check.validate(nodes, tris, info["root_ref"], meshes, max_leaf=info["max_leaf"], allow_splits=True)   # 72,972 triangles: the first levels may cut some (top splits)
     o = oracle_scene(restate, meshes)
     prim = W.crown_camera_rays(meshes, 160, 160)
     want, got = prim.copy(), prim.copy()
@@ -746,7 +746,7 @@ def check_properties(s, meshes, rays, min_hit=0.0):
 def test_full_size_properties(api, dev, crown_full):
     """configs[2] at full size (2^20 incoherent rays, 4.76M triangles): properties that need no oracle."""
     meshes, s, rays = crown_full
-    assert s.info()["num_triangles"] == W.num_triangles(meshes)
+    assert s.info()["num_triangles"] - s.info()["num_presplit"] == W.num_triangles(meshes)    # (a MEDIUM build may cut triangles of its first levels: num_presplit extra leaf records)
     check_properties(s, meshes, rays, min_hit=0.99)        # closed room: (almost) every bounce ray hits something
 
 
@@ -813,7 +813,7 @@ def test_powerplant_full_size(api, dev):
     m = W.synthetic_powerplant()
     s = api.make_scene(dev, m, device_resident=True)
     info = s.info()
-    assert info["num_triangles"] == W.num_triangles(m) == 12699996
+    assert info["num_triangles"] - info["num_presplit"] == W.num_triangles(m) == 12699996
     assert info["bytes_nodes"] == 80 * info["num_nodes"] and info["depth"] < 64
     lo, hi = W.scene_bounds(m)
     blo, bhi = s.bounds()

@@ -165,7 +165,7 @@ def test_powerplant_full_size_vs_real_reference(api, dev, ref):
     on this geometry the reference's fast mode loses ~50 of 2^20 hits its robust mode finds (measured), the GPU's fast mode must lose none."""
     m = W.synthetic_powerplant()
     s = api.make_scene(dev, m, device_resident=True)
-    assert s.info()["num_triangles"] == W.num_triangles(m) == 12699996
+    assert s.info()["num_triangles"] - s.info()["num_presplit"] == W.num_triangles(m) == 12699996
     R = ref_scene(ref, m)
     rlo, rhi = R.bounds()
     blo, bhi = s.bounds()
@@ -212,9 +212,12 @@ def test_fast_mode_far_from_the_origin(api, dev, ref, offset):
     R, rays = small_crown_rays(ref, meshes, n_side=128, seed=7)
     s = api.make_scene(dev, meshes)
     from tests import bvh_check
-    nodes, tris = s.download_bvh()
-    info = s.info()
+    dv = api.Device("gpu=0,top_splits=0")                      # (the validator wants every triangle once and whole: no cut references)
+    sv = api.make_scene(dv, meshes)
+    nodes, tris = sv.download_bvh()
+    info = sv.info()
     bvh_check.validate(nodes, tris, info["root_ref"], meshes, max_leaf=info["max_leaf"])      # EXACT decoded planes contain the geometry
+    sv.release(); dv.release()
     want, got = rays.copy(), rays.copy()
     R.intersect1(want, ref.hw_threads())
     s.intersect1M(got)
@@ -390,7 +393,8 @@ def test_spatial_split_build_scenes(api, dev, name):
         s.commit(); return s
     med, high = mk(None), mk(api.RTC_BUILD_QUALITY_HIGH)
     im, ih = med.info(), high.info()
-    assert ih["num_triangles"] == im["num_triangles"] + ih["num_presplit"] and ih["num_presplit"] <= int(0.2 * im["num_triangles"]) + 1
+    nm0 = im["num_triangles"] - im["num_presplit"]                       # (MEDIUM builds of >= 65536 triangles cut some triangles of their first levels as well)
+    assert ih["num_triangles"] == nm0 + ih["num_presplit"] and ih["num_presplit"] <= int(0.2 * nm0) + 1
     nodes, tris = high.download_bvh()
     nm, tm = med.download_bvh()
     key = lambda t: np.unique(t["geomID"].astype(np.uint64) << 32 | (t["primID"] & 0x7FFFFFFF))
