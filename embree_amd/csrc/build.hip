@@ -120,7 +120,7 @@ TraceScratch* Bvh::scratch_for(hipStream_t s) {
 }
 Bvh::~Bvh() {
   hipSetDevice(device);
-  for (auto& kv : scratch) { hipFree(kv.second.counter); hipFree(kv.second.spill); hipFree(kv.second.stats); if (kv.second.pkt) hipFree(kv.second.pkt); hipHostFree((void*)kv.second.statusHost); delete kv.second.enqueue; }
+  for (auto& kv : scratch) { hipFree(kv.second.counter); hipFree(kv.second.spill); hipFree(kv.second.stats); if (kv.second.pkt) hipFree(kv.second.pkt); if (kv.second.defer) hipFree(kv.second.defer); hipHostFree((void*)kv.second.statusHost); delete kv.second.enqueue; }
   if (d_nodes) hipFree(d_nodes);
   if (d_tris) hipFree(d_tris);
   if (d_ids) hipFree(d_ids);
@@ -162,7 +162,11 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
   // (BVHBuilderBinnedSAH, kernels/builders/bvh_builder_sah.h:446); answers do not depend on it, "top_splits=0" switches it off.  Not with refit data
   // (a refit walks one leaf record per triangle).
   const bool topSplits = allowTopSplits && bp->quality == 0u && bp->top_splits != 0u && !bp->refit && numMeshes < (1u << 27);
+  // ... and only when such references are FEW (at most N / 2048 + 64 boxes of >= top_split_rel x the mean box area): a dozen room-sized triangles are what a
+  // handful of planes near the root can fix (crown stand-in +9 % rays per second); thousands of long pipe triangles are not (powerplant stand-in: +0.6 % for
+  // +3 ms), and there the spatial kernels see the count on the device and return at once.
   if (topSplits) prm.spatial = 1u;
+  const float topSplitRel = bp->top_split_rel > 0.0f ? bp->top_split_rel : 32.0f;   // only references this many times larger than the mean box may be cut by a top split
 
   std::vector<GeomDesc> gd; uint64_t total = 0;
   for (uint32_t i = 0; i < numMeshes; i++) {
@@ -232,7 +236,7 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
     const void* ptrs[] = {dGeoms.p, bufA.p, bufB.p, finalIds.p, bnodes.p, segs0.p, segs1.p, bins.p, chunks.p, small.p, ctr.p, w0.p, w1.p, wnodes.p, outIds.p, plans.p, itemCnt.p, groupSum.p, tileCount.p, chunkCnt.p, chunkBase.p, segx0.p, segx1.p, sbins.p, (const void*)st};
     std::vector<uint64_t> key; for (const void* q : ptrs) key.push_back((uint64_t)(uintptr_t)q);
     uint32_t pw[sizeof(Params) / 4]; memcpy(pw, &prm, sizeof(prm)); for (uint32_t w : pw) key.push_back(w);
-    key.push_back(N); key.push_back(gd.size()); key.push_back(bp->robust); key.push_back(spatialMin); key.push_back(NC);
+    key.push_back(N); key.push_back(gd.size()); key.push_back(bp->robust); key.push_back(spatialMin); key.push_back(NC); { uint32_t w; memcpy(&w, &topSplitRel, 4); key.push_back(w); }
     if (arena->graphExec && arena->graphKey == key) replay = true;
     else {
       arena->drop_graph(); arena->graphKey = key;
@@ -261,7 +265,7 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
     if (spatial && N > prm.small) {                              // split budgets of the references (the number of valid ones is on the device); the root set owns everything behind them
       const uint32_t ab = (N + 255u) / 256u < 2048u ? (N + 255u) / 256u : 2048u;
       LAUNCH(spatial_area_sum, dim3(ab), dim3(256), 0, st, bufA.p, N, ctr.p);
-      LAUNCH(spatial_budgets, dim3((N + 255u) / 256u), dim3(256), 0, st, bufA.p, N, ctr.p);
+      LAUNCH(spatial_budgets, dim3((N + 255u) / 256u), dim3(256), 0, st, bufA.p, N, ctr.p, topSplits ? topSplitRel : 0.0f);
       LAUNCH(segx_root, dim3(1), dim3(1), 0, st, segx0.p, NC);
     }
   } else {
@@ -326,7 +330,7 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
     if (spatial && n > prm.small) {                              // split budgets of the references; the root set owns everything behind them
       const uint32_t ab = (n + 255u) / 256u < 2048u ? (n + 255u) / 256u : 2048u;
       LAUNCH(spatial_area_sum, dim3(ab), dim3(256), 0, st, bufA.p, n, ctr.p);
-      LAUNCH(spatial_budgets, dim3((n + 255u) / 256u), dim3(256), 0, st, bufA.p, n, ctr.p);
+      LAUNCH(spatial_budgets, dim3((n + 255u) / 256u), dim3(256), 0, st, bufA.p, n, ctr.p, topSplits ? topSplitRel : 0.0f);
       SegX x0{}; x0.extEnd = NC;
       HIP_TRY(hipMemcpyAsync(segx0.p, &x0, sizeof(x0), hipMemcpyHostToDevice, st));
     }
@@ -369,7 +373,7 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
     LAUNCH(top_split, dim3(segBound), dim3(64), 0, st, cur, bins.p, bnodes.p, ctr.p, prm, level >= 96u ? 1u : 0u, xcur, (const uint32_t*)chunkCnt.p, chunkBase.p);
     const bool spatialLevel = spatial && level < spatialLevels;
     if (spatialLevel) {                                          // sets whose object split leaves overlapping children try a spatial split
-      LAUNCH(spatial_decide, dim3(segBound), dim3(128), 0, st, cur, xcur, bnodes.p, sbins.p, ctr.p, spatialMin);
+      LAUNCH(spatial_decide, dim3(segBound), dim3(128), 0, st, cur, xcur, bnodes.p, sbins.p, ctr.p, spatialMin, topSplits ? N / 2048u + 64u : 0xFFFFFFFFu);
       LAUNCH(spatial_bin, dim3(chunkBound), dim3(256), 0, st, cur, xcur, chunks.p, src, dGeoms.p, sbins.p, ctr.p);
       LAUNCH(spatial_best, dim3(segBound), dim3(64), 0, st, cur, xcur, sbins.p, bnodes.p, ctr.p, prm);
     }
@@ -685,7 +689,7 @@ extern "C" {
 
 void mi355_default_build_params(mi355_build_params* p) {
   memset(p, 0, sizeof(*p));
-  p->sah_block_shift = 0; p->min_leaf = 2; p->max_leaf = 3; p->small_threshold = 1024; p->trav_cost = 1.0f; p->int_cost = 1.0f; p->split_factor = 1.2f; p->presplits = 0; p->top_splits = 1; p->top_split_min = 65536;
+  p->sah_block_shift = 0; p->min_leaf = 2; p->max_leaf = 3; p->small_threshold = 1024; p->trav_cost = 1.0f; p->int_cost = 1.0f; p->split_factor = 1.2f; p->presplits = 0; p->top_splits = 1; p->top_split_min = 65536; p->top_split_rel = 32.0f;
 }
 const char* mi355_last_error(void) { return mi355::g_err.c_str(); }
 int mi355_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }

@@ -48,7 +48,7 @@ struct Counters {
   uint32_t numSegs, topLevels, wideDepth, lvlNodeBase, lvlTriBase, wideCount[2];      // level loops are driven from the device: no host readback per level
   unsigned long long sahFixed;                    // SAH statistics, 2^-24 fixed point (order-independent sum)
   float rootArea;                                 // half area of the scene bounds (SAH statistics are relative to it); written by root_setup
-  uint32_t pad0;
+  uint32_t numOutliers;                           // MEDIUM builds with top splits: references whose box is >= top_split_rel x the mean box (spatial_budgets counts them)
   unsigned long long areaFixed;                   // spatial-split builds: sum of the references' box areas / scene area, 2^-32 fixed point (build_spatial.inl)
   uint32_t lvlStart[64];                          // first node of every level of the wide tree (numbering is breadth first): what a refit walks bottom-up
 };

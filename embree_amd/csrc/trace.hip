@@ -73,6 +73,7 @@ struct TraceArgs {
   volatile uint32_t* status;  // host-mapped: [STATUS_ITER_CAP], [STATUS_SPILL] set to 1 when a safety net dropped work
   unsigned long long* stats;  // optional counters
   const float4* insts;   // INST kernels: InstRec[] as 4 x float4 (world2local vx,vy,vz,p | root node, instID, mask, flags)
+  const uint32_t* deferList; const uint32_t* deferCount;   // second pass of a RTC_RAY_QUERY_FLAG_COHERENT query: the packets (64 consecutive rays each) the packet kernel gave up on; nullptr otherwise
 };
 
 // slab test of the 4 children whose quantised planes sit in one dword per plane; returns their contribution to the hit word.
@@ -341,6 +342,8 @@ __global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceAr
   unsigned long long stRefillClk = 0, stLoopClk = 0, stNodeClk = 0; uint32_t stRefillEv = 0;      // STATS: shader clocks (s_memtime) inside the hand-out block / the whole loop / the node step, hand-out events
   const unsigned long long stClk0 = STATS ? __builtin_readcyclecounter() : 0ull;
 
+  const uint32_t rayCount = a.deferCount ? *a.deferCount * 64u : a.count;   // (wave-uniform) rays to hand out: all of them, or those of the deferred packets
+  if (rayCount == 0u) return;                                               // (the pass behind a packet launch none of whose packets gave up)
   uint32_t iter = 0;
   for (; iter < a.iterCap; iter++) {
     // ------------------------------------------------------------------ 0. a full batch of queued pairs is waiting: issue the loads of its triangle records now, so that
@@ -402,15 +405,16 @@ __global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceAr
               const uint32_t base = __builtin_amdgcn_readfirstlane(resV);
               const unsigned long long firstRay = ((unsigned long long)base * a.numCursors + cursor) * G;
               resValid = false;
-              if (firstRay >= a.count) {                                 // this cursor is dry: try the next one
+              if (firstRay >= rayCount) {                                 // this cursor is dry: try the next one
                 cursor = (cursor + 1u) % a.numCursors;
                 if (++dryCursors >= a.numCursors) exhausted = true;
                 continue;
               }
               const uint32_t rank = (uint32_t)__popcll(freeLanes & ((1ull << lane) - 1ull));
-              got = ((freeLanes >> lane) & 1ull) != 0ull && rank < G && firstRay + rank < a.count;
+              got = ((freeLanes >> lane) & 1ull) != 0ull && rank < G && firstRay + rank < rayCount;
+              if (got && a.deferList) { const uint32_t q = (uint32_t)firstRay + rank; newIdx = a.deferList[q >> 6] * 64u + (q & 63u); got = newIdx < a.count; }   // (the last packet of a batch may be ragged)
+              else if (got) newIdx = (uint32_t)firstRay + rank;
               if (got) {
-                newIdx = (uint32_t)firstRay + rank;
                 const float4* rp = (const float4*)(a.rays + (size_t)newIdx * a.stride);
                 r0 = rp[0]; r1 = rp[1]; r2 = rp[2];
               }
@@ -697,6 +701,184 @@ __global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceAr
   }
 }
 
+// =============================================================================================
+// RTC_RAY_QUERY_FLAG_COHERENT: the 64 rays of a wavefront walk the tree TOGETHER.
+//   The reference's coherent path (BVHNIntersectorKHybrid::intersectCoherent, kernels/bvh/bvh_intersector_hybrid.cpp:374-533) traverses a packet with a
+//   shared stack and tests every node against all rays of the packet at once.  Here a packet is one wavefront = 64 CONSECUTIVE rays of the batch: the
+//   stack lives per wave in LDS ({node, mask of the lanes that entered its box}), a node is fetched ONCE per packet through the scalar cache (the node index
+//   is wave-uniform) instead of once per lane, every lane of the mask runs the 8 slab tests on it, the triangles of the leaf slots some lane entered are
+//   fetched once and tested by all those lanes, and each lane keeps its own best hit in registers (no ring, no LDS atomics).  Children are visited in the
+//   front-to-back order of the packet's first ray.  What a lane reports is the minimum of (t, triangle index) over all accepted candidates exactly as in
+//   trace_kernel_q, so the two kernels give bit-identical answers; which one is faster depends on the rays: a packet pays ~200 VALU instructions per node
+//   ANY of its rays visits, so it wins when neighbouring rays share most of their path (primary rays of a moderately tessellated scene, shadow rays towards
+//   one light) and loses on incoherent batches -- the flag is the application's promise, as in the reference.
+constexpr int PSTACK = 128;                 // stack entries per packet: <= 7 siblings left behind per level
+struct PacketTraceArgs { const uint4* nodes; const float4* tris; uint32_t hasRoot; char* rays; uint32_t count, stride; uint32_t* deferList; uint32_t* deferCount; volatile uint32_t* status; uint32_t minServed; };
+
+template <bool ANY, bool ROBUST>
+__global__ __launch_bounds__(64) void trace_packet_kernel(PacketTraceArgs a) {
+  __shared__ uint4 s_stk[PSTACK];                               // {node, lane mask lo, lane mask hi, -}
+  const uint32_t lane = threadIdx.x;
+  const uint4* __restrict__ nodes = a.nodes;
+  const float4* __restrict__ tris = a.tris;
+  // packets are dealt round-robin to the resident waves (no cursor: a single atomic word hands out ~88 packets per microsecond, which alone would take 0.19 ms
+  // for the 16384 packets of a 2^20-ray batch -- more than the whole Cornell-box launch)
+  for (uint32_t pk = blockIdx.x;; pk += gridDim.x) {
+    const unsigned long long first = (unsigned long long)pk * 64ull;
+    if (first >= a.count) break;
+    const uint32_t idx = (uint32_t)first + lane;
+    const bool valid = idx < a.count;
+    char* const rp = a.rays + (size_t)(valid ? idx : (uint32_t)first) * a.stride;
+    const float4 r0 = ((const float4*)rp)[0], r1 = ((const float4*)rp)[1], r2 = ((const float4*)rp)[2];
+    const float ox = r0.x, oy = r0.y, oz = r0.z, tnear = r0.w, dx = r1.x, dy = r1.y, dz = r1.z;
+    const uint32_t rmask = __float_as_uint(r2.y);
+    float rdx, rdy, rdz, rfx = 0, rfy = 0, rfz = 0; uint32_t octinv4;
+    setup_rdir<ROBUST>(dx, dy, dz, rdx, rdy, rdz, rfx, rfy, rfz, octinv4);
+    const float tnearTrav = fmaxf(tnear, 0.0f);
+    float bestT = r2.x; uint32_t bestTri = MI355_EMPTY_REF;
+    bool alive = valid && a.hasRoot != 0u && !(ANY && bestT < 0.0f);
+    unsigned long long am = __ballot(alive);
+    if (am == 0ull) continue;
+    const uint32_t pOct = (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl((int)(octinv4 & 7u), __builtin_ctzll(am), 64));   // the packet's order: its first ray's
+    uint32_t sp = 0u;
+    uint32_t cur = 0u; unsigned long long curMask = am;
+    bool haveCur = true;
+    // A packet whose rays do not stay together is not worth finishing: every node ANY ray visits costs the whole wave its 200 instructions.  Every 4 node
+    // visits the packet looks at how many lanes those 4 visits served; fewer than 48 of 64 on average (env MI355_PACKET_MIN_LANES; a visit of the per-lane
+    // kernel serves ~47 lanes for about the same instructions) and it gives up, leaves its rays untouched and puts
+    // itself on the deferred list, which the per-lane kernel (trace_kernel_q) traces right behind this launch.  The reference's hybrid traversal switches to
+    // single-ray traversal the same way when few rays of a packet are active (BVHNIntersectorKHybrid, bvh_intersector_hybrid.h:33-37: switchThreshold).
+    uint32_t visits = 0u, served = 0u; bool gaveUp = false;
+    for (uint32_t guard = 0; guard < (1u << 22); guard++) {
+      if (!haveCur) {
+        if (sp == 0u) break;
+        sp--;
+        const uint4 e = s_stk[sp];
+        cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.x);
+        curMask = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)e.z) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)e.y);
+        if (ANY) curMask &= __ballot(alive);
+        if (curMask == 0ull) continue;
+      }
+      haveCur = false;
+      visits++; served += (uint32_t)__popcll(curMask);
+      if ((visits & 3u) == 0u) {
+        if (served < a.minServed) { gaveUp = true; break; }
+        served = 0u;
+      }
+      // ---- the node, once per packet
+      const uint4* np = nodes + (size_t)cur * 5u;
+      const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
+      const bool in = ((curMask >> lane) & 1ull) != 0ull && (!ANY || alive);
+      uint32_t hitBits = 0u;
+      if (in) {
+        const float scx = __uint_as_float((n0.w & 0xFFu) << 23), scy = __uint_as_float(((n0.w >> 8) & 0xFFu) << 23), scz = __uint_as_float(((n0.w >> 16) & 0xFFu) << 23);
+        const float nox = __uint_as_float(n0.x), noy = __uint_as_float(n0.y), noz = __uint_as_float(n0.z);
+        const bool sx = rdx < 0.0f, sy = rdy < 0.0f, sz = rdz < 0.0f;
+        const float tmax0 = fmaxf(bestT, 0.0f);
+        // fast mode: plane distance = q * (scale * rdir) + (org_node - org_ray) * rdir with the per-axis error bound of test4; robust mode: test4_robust's arithmetic
+        const float adx = scx * rdx, ady = scy * rdy, adz = scz * rdz;
+        const float bx = (nox - ox) * rdx, by = (noy - oy) * rdy, bz = (noz - oz) * rdz;
+        const float ex = fmaf(fabsf(adx), 255.0f, fabsf(bx)) * 0x1p-21f, ey = fmaf(fabsf(ady), 255.0f, fabsf(by)) * 0x1p-21f, ez = fmaf(fabsf(adz), 255.0f, fabsf(bz)) * 0x1p-21f;
+#define MI355_PCHILD(J, QLX, QLY, QLZ, QHX, QHY, QHZ)                                                          \
+        {                                                                                                      \
+          const float lx = ubyte<(J) & 3>(QLX), ly = ubyte<(J) & 3>(QLY), lz = ubyte<(J) & 3>(QLZ);              \
+          const float hx = ubyte<(J) & 3>(QHX), hy = ubyte<(J) & 3>(QHY), hz = ubyte<(J) & 3>(QHZ);              \
+          float tN, tF;                                                                                        \
+          if (ROBUST) {                                                                                        \
+            const float nxq = sx ? hx : lx, fxq = sx ? lx : hx, nyq = sy ? hy : ly, fyq = sy ? ly : hy, nzq = sz ? hz : lz, fzq = sz ? lz : hz; \
+            const float tnx = (fmaf(nxq, scx, nox) - ox) * rdx, tny = (fmaf(nyq, scy, noy) - oy) * rdy, tnz = (fmaf(nzq, scz, noz) - oz) * rdz; \
+            const float tfx = (fmaf(fxq, scx, nox) - ox) * rfx, tfy = (fmaf(fyq, scy, noy) - oy) * rfy, tfz = (fmaf(fzq, scz, noz) - oz) * rfz; \
+            tN = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, tnearTrav)); tF = fminf(fminf(tfx, tfy), fminf(tfz, tmax0)); \
+          } else {                                                                                             \
+            const float ax = fmaf(lx, adx, bx), cx = fmaf(hx, adx, bx), ay = fmaf(ly, ady, by), cy = fmaf(hy, ady, by), az = fmaf(lz, adz, bz), cz = fmaf(hz, adz, bz); \
+            const float tnx = fminf(ax, cx) - ex, tfx = fmaxf(ax, cx) + ex, tny = fminf(ay, cy) - ey, tfy = fmaxf(ay, cy) + ey, tnz = fminf(az, cz) - ez, tfz = fmaxf(az, cz) + ez; \
+            tN = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, tnearTrav)); tF = fminf(fminf(tfx, tfy), fminf(tfz, tmax0)); \
+          }                                                                                                    \
+          hitBits |= (tN <= tF) ? (1u << (J)) : 0u;                                                            \
+        }
+        MI355_PCHILD(0, n2.x, n2.z, n3.x, n3.z, n4.x, n4.z) MI355_PCHILD(1, n2.x, n2.z, n3.x, n3.z, n4.x, n4.z)
+        MI355_PCHILD(2, n2.x, n2.z, n3.x, n3.z, n4.x, n4.z) MI355_PCHILD(3, n2.x, n2.z, n3.x, n3.z, n4.x, n4.z)
+        MI355_PCHILD(4, n2.y, n2.w, n3.y, n3.w, n4.y, n4.w) MI355_PCHILD(5, n2.y, n2.w, n3.y, n3.w, n4.y, n4.w)
+        MI355_PCHILD(6, n2.y, n2.w, n3.y, n3.w, n4.y, n4.w) MI355_PCHILD(7, n2.y, n2.w, n3.y, n3.w, n4.y, n4.w)
+#undef MI355_PCHILD
+      }
+      const uint32_t imask = n0.w >> 24;
+      const unsigned long long metaAll = ((unsigned long long)n1.w << 32) | n1.z;   // meta byte of slot s = bits 8s .. 8s+7
+      // ---- leaf slots some lane entered: ALL their triangles (<= 24) are fetched in one round trip, lane j loading the j-th of them (nearest slot first:
+      // far limits shrink early), then handed to the lanes that entered the slot one after the other with v_readlane (the triangle index is wave-uniform).
+      // (One scalar load per triangle inside the loop exposed a memory round trip per triangle: 3.6 instead of 5.5 Grays/s on the Cornell box.)
+      uint32_t T = 0u, myTri = 0u, mySlot = 0u;
+      for (int k = 7; k >= 0; k--) {
+        const uint32_t s_ = ((uint32_t)k ^ pOct) & 7u;
+        if ((imask >> s_) & 1u) continue;
+        const uint32_t meta = (uint32_t)(metaAll >> (8u * s_)) & 0xFFu;
+        if (meta == 0u) continue;
+        if (__ballot(((hitBits >> s_) & 1u) != 0u) == 0ull) continue;
+        const uint32_t cnt = (uint32_t)__popc(meta >> 5), firstTri = n1.y + (meta & 31u);
+        if (lane >= T && lane < T + cnt) { myTri = firstTri + (lane - T); mySlot = s_; }
+        T += cnt;
+      }
+      if (T != 0u) {
+        float4 q0 = make_float4(0, 0, 0, 0), q1 = q0, q2 = q0;
+        if (lane < T) { const float4* tp = tris + (size_t)myTri * 3u; q0 = tp[0]; q1 = tp[1]; q2 = tp[2]; }
+        for (uint32_t t = 0; t < T; t++) {
+#define MI355_BCAST(x) __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(x), (int)t))
+          const float4 u0 = make_float4(MI355_BCAST(q0.x), MI355_BCAST(q0.y), MI355_BCAST(q0.z), MI355_BCAST(q0.w));
+          const float4 u1 = make_float4(MI355_BCAST(q1.x), MI355_BCAST(q1.y), MI355_BCAST(q1.z), MI355_BCAST(q1.w));
+          const float4 u2 = make_float4(MI355_BCAST(q2.x), MI355_BCAST(q2.y), MI355_BCAST(q2.z), MI355_BCAST(q2.w));
+#undef MI355_BCAST
+          const uint32_t ti = (uint32_t)__builtin_amdgcn_readlane((int)myTri, (int)t), sl = (uint32_t)__builtin_amdgcn_readlane((int)mySlot, (int)t);
+          if (((hitBits >> sl) & 1u) != 0u && (!ANY || alive)) {
+            TriOut w;
+            bool ok = ROBUST ? tri_pluecker<false>(u0, u1, u2, ox, oy, oz, dx, dy, dz, tnear, bestT, w)
+                             : tri_moeller<false>(u0, u1, u2, ox, oy, oz, dx, dy, dz, tnear, bestT, w);
+            ok = ok && ((__float_as_uint(u2.w) & rmask) != 0u);
+            if (ok) {
+              const float tt = w.t + 0.0f;
+              if (ANY) { bestTri = ti; alive = false; }
+              else if (tt < bestT || (tt == bestT && ti < bestTri)) { bestT = tt; bestTri = ti; }   // minimum of (t, triangle index): trace_kernel_q's atomicMin key
+            }
+          }
+        }
+      }
+      if (ANY && __ballot(alive) == 0ull) break;
+      // ---- inner children some lane entered: far ones first onto the stack, the nearest is opened next
+      for (int k = 0; k < 8; k++) {
+        const uint32_t s_ = ((uint32_t)k ^ pOct) & 7u;
+        if (!((imask >> s_) & 1u)) continue;
+        const unsigned long long m = __ballot(((hitBits >> s_) & 1u) != 0u && (!ANY || alive));
+        if (m == 0ull) continue;
+        const uint32_t child = n1.x + (uint32_t)__popc(imask & ((1u << s_) - 1u));
+        if (haveCur) {                                            // what was "next" so far is farther than this one: it goes onto the stack
+          if (sp < (uint32_t)PSTACK) { if (lane == 0u) s_stk[sp] = make_uint4(cur, (uint32_t)curMask, (uint32_t)(curMask >> 32), 0u); sp++; }
+          else a.status[STATUS_SPILL] = 1u;
+        }
+        cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)child); curMask = m; haveCur = true;
+      }
+    }
+    if (gaveUp) {                                                // nothing has been written: the rays are as they came
+      if (lane == 0u) a.deferList[atomicAdd(a.deferCount, 1u)] = pk;
+      continue;
+    }
+    // ---- results
+    if (valid && bestTri != MI355_EMPTY_REF) {
+      if (ANY) *(float*)(rp + 32) = -__builtin_inff();           // Occluded1EpilogM: tfar = -inf
+      else {
+        const float4* tp = tris + (size_t)bestTri * 3u;
+        const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
+        TriOut w;
+        const uint32_t pid = __float_as_uint(q2.y);
+        if (ROBUST) tri_pluecker<true>(q0, q1, q2, ox, oy, oz, dx, dy, dz, 0.0f, 0.0f, w, (pid >> 31) != 0u);
+        else tri_moeller<true>(q0, q1, q2, ox, oy, oz, dx, dy, dz, 0.0f, 0.0f, w, (pid >> 31) != 0u);
+        *(float*)(rp + 32) = w.t;
+        *(float4*)(rp + 48) = make_float4(w.Ngx, w.Ngy, w.Ngz, w.u);
+        *(uint4*)(rp + 64) = make_uint4(__float_as_uint(w.v), pid & 0x7FFFFFFFu, __float_as_uint(q2.z), MI355_EMPTY_REF);
+        *(uint32_t*)(rp + 80) = MI355_EMPTY_REF;
+      }
+    }
+  }
+}
+
 // ---- packet adaptor: SoA RTCRayHitK / RTCRayK <-> the AoS records the trace kernels consume ----
 // (RayHitK::get/set kernels/common/ray.h:283-376; packet calls never touch lanes whose valid[i] != -1, InactiveRaysTest verify.cpp:3553)
 // Lane i of the packet array becomes AoS record i, active or not: an inactive lane is copied with tnear = +inf, tfar = -inf (it cannot enter the root's
@@ -763,7 +945,7 @@ size_t trace_spill_bytes(int numCUs, uint32_t depth) {
 }
 
 static int launch_trace(Bvh* b, void* d_rays, uint32_t count, size_t stride, bool any, hipStream_t s, uint64_t* statsOut,
-                        hipEvent_t evStart = nullptr, hipEvent_t evStop = nullptr) {
+                        hipEvent_t evStart = nullptr, hipEvent_t evStop = nullptr, const uint32_t* deferList = nullptr, const uint32_t* deferCount = nullptr) {
   if (count == 0) return 0;
   if (stride < (any ? 48u : 96u) || (stride & 15u) || ((uintptr_t)d_rays & 15u)) return set_error(hipErrorInvalidValue, "ray array must be 16-byte aligned with a 16-byte-multiple stride");
   HIP_TRY(hipSetDevice(b->device));
@@ -777,7 +959,7 @@ static int launch_trace(Bvh* b, void* d_rays, uint32_t count, size_t stride, boo
   HIP_TRY(hipMemsetAsync(sc->counter, 0, NUM_CURSORS * CURSOR_STRIDE * sizeof(uint32_t), s));
   TraceArgs a;
   a.nodes = (const uint4*)b->d_nodes; a.tris = (const float4*)b->d_tris; a.hasRoot = b->root != MI355_EMPTY_REF ? 1u : 0u;
-  a.rays = (char*)d_rays; a.count = count; a.stride = (uint32_t)stride; a.insts = (const float4*)b->d_insts;
+  a.rays = (char*)d_rays; a.count = count; a.stride = (uint32_t)stride; a.insts = (const float4*)b->d_insts; a.deferList = deferList; a.deferCount = deferCount;
   a.counter = sc->counter; a.spill = (uint2*)sc->spill; a.spillPerLane = trace_spill_per_lane(b->info.depth); a.stats = nullptr;
   static const uint32_t refillMin = env_u32("MI355_REFILL_MIN", REFILL_MIN_DEFAULT, 1, 64);
   static const uint32_t pushRounds = env_u32("MI355_PUSH_ROUNDS", PUSH_ROUNDS_DEFAULT, 1, 24);
@@ -801,6 +983,48 @@ static int launch_trace(Bvh* b, void* d_rays, uint32_t count, size_t stride, boo
   if (evStop) HIP_TRY(hipEventRecord(evStop, s));
   HIP_TRY(hipGetLastError());
   return 0;
+}
+
+typedef void (*PacketFn)(PacketTraceArgs);
+static int launch_trace_coherent(Bvh* b, void* d_rays, uint32_t count, size_t stride, bool any, hipStream_t s) {
+  if (count == 0) return 0;
+  if (stride < (any ? 48u : 96u) || (stride & 15u) || ((uintptr_t)d_rays & 15u)) return set_error(hipErrorInvalidValue, "ray array must be 16-byte aligned with a 16-byte-multiple stride");
+  HIP_TRY(hipSetDevice(b->device));
+  const PacketFn fn = b->robust ? (any ? trace_packet_kernel<true, true> : trace_packet_kernel<false, true>) : (any ? trace_packet_kernel<true, false> : trace_packet_kernel<false, false>);
+  static std::mutex m; static std::map<std::pair<int, PacketFn>, uint32_t> cache;
+  uint32_t maxBlocks;
+  { std::lock_guard<std::mutex> lk(m);
+    auto key = std::make_pair(b->device, fn); auto it = cache.find(key);
+    if (it == cache.end()) {
+      int perCU = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, (const void*)fn, 64, 0) != hipSuccess || perCU < 1) perCU = 8;
+      if (perCU > 32) perCU = 32;
+      it = cache.emplace(key, (uint32_t)b->numCUs * (uint32_t)perCU).first;
+    }
+    maxBlocks = it->second; }
+  uint32_t blocks = (count + 63u) / 64u;
+  if (blocks > maxBlocks) blocks = maxBlocks;
+  TraceScratch* sc = b->scratch_for(s);
+  if (!sc) return set_error(hipErrorOutOfMemory, "trace scratch allocation failed");
+  const size_t packets = ((size_t)count + 63u) / 64u, need = (64u + packets) * sizeof(uint32_t);
+  uint32_t* defer = nullptr;
+  { std::lock_guard<std::mutex> enqueueLock(*sc->enqueue);
+    if (sc->deferCap < need) {                                  // (stream order keeps earlier launches' use of the old list apart: wait for them before it goes)
+      if (sc->defer) { HIP_TRY(hipStreamSynchronize(s)); HIP_TRY(hipFree(sc->defer)); sc->defer = nullptr; sc->deferCap = 0; }
+      const size_t cap = need < 65536 ? 65536 : need + need / 4;
+      HIP_TRY(hipMalloc((void**)&sc->defer, cap)); sc->deferCap = cap;
+    }
+    defer = sc->defer;
+    HIP_TRY(hipMemsetAsync(defer, 0, sizeof(uint32_t), s));
+    PacketTraceArgs a;
+    a.nodes = (const uint4*)b->d_nodes; a.tris = (const float4*)b->d_tris; a.hasRoot = b->root != MI355_EMPTY_REF ? 1u : 0u;
+    a.rays = (char*)d_rays; a.count = count; a.stride = (uint32_t)stride; a.deferCount = defer; a.deferList = defer + 64; a.status = sc->statusDev;
+    static const uint32_t minLanes = env_u32("MI355_PACKET_MIN_LANES", 48, 0, 64);
+    a.minServed = 4u * minLanes;
+    hipLaunchKernelGGL(fn, dim3(blocks), dim3(64), 0, s, a);
+    HIP_TRY(hipGetLastError()); }
+  // the packets that gave up (their rays untouched), traced per lane right behind: the count stays on the device, a launch that finds none ends at once
+  return launch_trace(b, d_rays, count, stride, any, s, nullptr, nullptr, nullptr, defer + 64, defer);
 }
 
 static int launch_packets(Bvh* b, const int* d_valid, void* d_pk, uint32_t K, uint32_t n, size_t pstride, bool any, hipStream_t s) {
@@ -852,8 +1076,10 @@ int mi355_trace_any(mi355_bvh_t bvh, void* d, uint32_t n, size_t stride, void* s
   return mi355::launch_trace((mi355::Bvh*)bvh, d, n, stride, true, (hipStream_t)stream, nullptr);
 }
 int mi355_trace_query(mi355_bvh_t bvh, void* d, uint32_t n, size_t stride, int any_hit, uint32_t query_flags, void* stream) {
-  (void)query_flags;
-  return mi355::launch_trace((mi355::Bvh*)bvh, d, n, stride, any_hit != 0, (hipStream_t)stream, nullptr);
+  mi355::Bvh* b = (mi355::Bvh*)bvh;
+  // RTC_RAY_QUERY_FLAG_COHERENT: the wave-packet kernel (not for scenes with instances: a packet cannot change space lane by lane)
+  if ((query_flags & MI355_QUERY_COHERENT) && !b->d_insts) return mi355::launch_trace_coherent(b, d, n, stride, any_hit != 0, (hipStream_t)stream);
+  return mi355::launch_trace(b, d, n, stride, any_hit != 0, (hipStream_t)stream, nullptr);
 }
 int mi355_trace_timed(mi355_bvh_t bvh, void* d, uint32_t n, size_t stride, int any_hit, void* stream, void* ev_start, void* ev_stop) {
   return mi355::launch_trace((mi355::Bvh*)bvh, d, n, stride, any_hit != 0, (hipStream_t)stream, nullptr, (hipEvent_t)ev_start, (hipEvent_t)ev_stop);

@@ -67,6 +67,8 @@ typedef struct mi355_build_params {
                                 never splits spatially; hits do not depend on it; leaf records of a cut triangle exist more than once
                                 (mi355_bvh_info.num_presplit).  Off whenever params.refit is set.  default 1 */
   uint32_t top_split_min;    /* default 65536 */
+  float    top_split_rel;    /* a top split may only cut references whose box area is at least this many times the mean box area (the others go whole to the
+                                side their centre lies on).  default 32 */
 } mi355_build_params;
 
 typedef struct mi355_bvh_info {

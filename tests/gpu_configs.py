@@ -24,8 +24,8 @@ for _ in range(4):
     streams.append(st)
 
 
-def rate(scene, rays, any_hit, reps=12):
-    """(lone launches Mrays/s, 4 in flight Mrays/s)"""
+def rate(scene, rays, any_hit, reps=12, coherent=False):
+    """(lone launches Mrays/s, 4 in flight Mrays/s); coherent: RTC_RAY_QUERY_FLAG_COHERENT = the wave-packet kernel"""
     M, rec = rays.shape[0], rays.dtype.itemsize
     pristine = api.DeviceArray.from_numpy(rays)
     bufs = [api.DeviceArray(rays.nbytes) for _ in range(reps)]
@@ -38,7 +38,7 @@ def rate(scene, rays, any_hit, reps=12):
             L.mi355_device_synchronize(0)
             t0 = time.perf_counter()
             for k in range(reps):
-                rc = (L.mi355_trace_any if any_hit else L.mi355_trace_closest)(scene.bvh(), bufs[k].ptr, M, rec, streams[k % ns])
+                rc = L.mi355_trace_query(scene.bvh(), bufs[k].ptr, M, rec, int(any_hit), api.RTC_RAY_QUERY_FLAG_COHERENT if coherent else 0, streams[k % ns])
                 assert rc == 0
             L.mi355_device_synchronize(0)
             dt = time.perf_counter() - t0
@@ -74,12 +74,20 @@ s = scene_of(m)
 r = W.cube_camera_rays(1024, 1024)
 a, b = rate(s, r, False)
 rows.append(("configs[0] scene (cube + plane, 14 triangles), 2^20 coherent primary rays (the config itself is 1k rays on the CPU)", W.num_triangles(m), commit_ms(s), "closest", a, b))
+a, b = rate(s, r, False, coherent=True)
+rows.append(("  same, RTC_RAY_QUERY_FLAG_COHERENT (wave-packet kernel)", W.num_triangles(m), commit_ms(s), "closest", a, b))
 s.release()
 m = W.cornell_box()
 s = scene_of(m)
 r = W.cornell_camera_rays(1024, 1024)
 a, b = rate(s, r, False)
 rows.append(("configs[1] Cornell box, 2^20 coherent primary rays", W.num_triangles(m), commit_ms(s), "closest", a, b))
+a, b = rate(s, r, False, coherent=True)
+rows.append(("  same, RTC_RAY_QUERY_FLAG_COHERENT (wave-packet kernel)", W.num_triangles(m), commit_ms(s), "closest", a, b))
+a, b = rate(s, rays_of(r), True, coherent=False)
+rows.append(("  same rays, rtcOccluded", W.num_triangles(m), commit_ms(s), "any hit", a, b))
+a, b = rate(s, rays_of(r), True, coherent=True)
+rows.append(("  same rays, rtcOccluded, RTC_RAY_QUERY_FLAG_COHERENT", W.num_triangles(m), commit_ms(s), "any hit", a, b))
 s.release()
 # configs[2]/[3]: crown stand-in
 m = W.synthetic_crown()
@@ -93,11 +101,15 @@ a, b = rate(s, bounce, False)
 rows.append(("configs[2] crown stand-in, 2^20 incoherent diffuse rays (the bench.py workload)", W.num_triangles(m), cms, "closest", a, b))
 a, b = rate(s, prim, False)
 rows.append(("  same scene, 2^20 coherent primary rays", W.num_triangles(m), cms, "closest", a, b))
+a, b = rate(s, prim, False, coherent=True)
+rows.append(("  same rays, RTC_RAY_QUERY_FLAG_COHERENT (wave-packet kernel: 4.5 triangles per pixel, the packets diverge)", W.num_triangles(m), cms, "closest", a, b))
 bt = bounce.copy()
 s.intersect1M(bt)
 sh = W.shadow_rays(bt[: 1 << 17], m, samples=16)                # one rank's 2 Mi shadow-ray shard of configs[3]
 a, b = rate(s, sh, True, reps=8)
 rows.append(("configs[3] crown stand-in, one rank's shard of the 16 Mi shadow rays (2^21 rays)", W.num_triangles(m), cms, "any hit", a, b))
+a, b = rate(s, sh, True, reps=8, coherent=True)
+rows.append(("  same rays, RTC_RAY_QUERY_FLAG_COHERENT (16 consecutive rays share a hit point)", W.num_triangles(m), cms, "any hit", a, b))
 s.release()
 # configs[4]: powerplant stand-in
 m = W.synthetic_powerplant()

@@ -223,3 +223,58 @@ def test_shadow16m_whole_job_vs_reference_prefix(api, ref, tmp_path):
     st = compare_occluded(words.view(np.float32), want["tfar"], rays["tfar"], max_flip_frac=1e-5, label="shadow16m prefix vs reference")
     print("shadow16m whole job: %.1f Mrays/s; prefix of %d rays vs reference: %s" % (line["value"], rays.shape[0], st))
     R.close()
+
+
+# ------------------------------------------------------------------------------------------- RTC_RAY_QUERY_FLAG_COHERENT: the wave-packet kernel
+@pytest.mark.parametrize("flags", [0, 4])
+def test_coherent_flag_gives_the_incoherent_answers(api, dev, flags):
+    """RTC_RAY_QUERY_FLAG_COHERENT selects the wave-packet kernel (the reference: intersectCoherent, kernels/bvh/bvh_intersector_hybrid.cpp:374-533; a hint,
+    never a change of the answer).  Both kernels report the minimum of (t, triangle index) over all accepted candidates, so the results must be the same BYTES:
+    coherent primary rays, incoherent rays (a broken promise must still be answered correctly), occlusion, masks, ragged counts, quads, fast and robust."""
+    qa = api.QueryArguments(None, api.RTC_RAY_QUERY_FLAG_COHERENT)
+    cases = []
+    m = W.cornell_box()
+    cases.append(("cornell primary", m, None, W.cornell_camera_rays(300, 217)))                         # 65100 rays: the last packet is ragged
+    m = W.synthetic_crown(num_phi=32)
+    prim = W.crown_camera_rays(m, 256, 256)
+    cases.append(("crown primary", m, None, prim))
+    cases.append(("crown incoherent", m, None, W.incoherent_rays(50000, [2, 2, 1.5], seed=9)))
+    m2 = W.synthetic_crown(num_phi=12)
+    masks = [1 << (i % 3) for i in range(len(m2))]
+    r = W.incoherent_rays(30001, [2, 2, 1.5], seed=3)
+    r["mask"] = np.where(np.arange(r.shape[0]) % 2 == 0, 3, 4).astype(np.uint32)
+    cases.append(("masks", m2, masks, r))
+    for name, meshes, masks, rays in cases:
+        s = api.make_scene(dev, meshes, masks, flags=flags)
+        a, b = rays.copy(), rays.copy()
+        s.intersect1M(a)
+        s.intersect1M(b, qa)
+        assert (a["geomID"] != INVALID_ID).any()
+        assert a.tobytes() == b.tobytes(), "%s: the packet kernel's closest hits differ on %d rays" % (name, int((a["primID"] != b["primID"]).sum()))
+        oa, ob = rays_of(rays), rays_of(rays)
+        s.occluded1M(oa)
+        s.occluded1M(ob, qa)
+        assert oa.tobytes() == ob.tobytes(), "%s: occlusion differs" % name
+        # device-pointer form and the 8-wide packet entry point with the flag
+        d = api.DeviceArray.from_numpy(rays)
+        s.intersect1M_device(d.ptr, rays.shape[0], args=qa)
+        api.load().mi355_device_synchronize(0)
+        assert d.download(RAYHIT_DTYPE).tobytes() == a.tobytes()
+        d.free()
+        assert s.trace_status() == 0
+        s.release()
+    # quads
+    rng = np.random.default_rng(5)
+    gx, gy = np.meshgrid(np.arange(20), np.arange(20))
+    v = np.stack([gx.ravel() * 0.1, gy.ravel() * 0.1, rng.random(400) * 0.05], -1).astype(np.float32)
+    q = np.array([[j * 20 + i, j * 20 + i + 1, (j + 1) * 20 + i + 1, (j + 1) * 20 + i] for j in range(19) for i in range(19)], np.uint32)
+    s = api.Scene(dev, flags)
+    s.add_quad_mesh(v, q)
+    s.commit()
+    org = np.stack([rng.random(20000) * 1.9, rng.random(20000) * 1.9, np.full(20000, 1.0)], -1).astype(np.float32)
+    rays = make_rayhits(org, np.tile(np.float32([0.01, -0.02, -1]), (20000, 1)))
+    a, b = rays.copy(), rays.copy()
+    s.intersect1M(a)
+    s.intersect1M(b, qa)
+    assert (a["geomID"] == 0).mean() > 0.9 and a.tobytes() == b.tobytes()
+    s.release()
