@@ -35,7 +35,7 @@ rtcSetGeometryTimeStepCount rtcSetGeometryVertexAttributeCount rtcSetGeometryMas
 rtcSetGeometryInstancedScene rtcSetGeometryTransform rtcGetGeometryTransform rtcInterpolate rtcInterpolateN
 rtcSetGeometryBuffer rtcSetSharedGeometryBuffer rtcSetSharedGeometryBufferHostDevice rtcSetNewGeometryBuffer
 rtcGetGeometryBufferData rtcUpdateGeometryBuffer rtcSetGeometryUserData rtcGetGeometryUserData
-rtcSetGeometryIntersectFilterFunction rtcSetGeometryOccludedFilterFunction rtcSetGeometryEnableFilterFunctionFromArguments
+rtcSetGeometryIntersectFilterFunction rtcSetGeometryOccludedFilterFunction rtcSetGeometryEnableFilterFunctionFromArguments rtcSetGeometryFilterRule
 rtcNewScene rtcGetSceneDevice rtcRetainScene rtcReleaseScene rtcGetSceneTraversable rtcAttachGeometry
 rtcAttachGeometryByID rtcDetachGeometry rtcGetGeometry rtcGetGeometryThreadSafe rtcCommitScene rtcJoinCommitScene
 rtcSetSceneProgressMonitorFunction rtcSetSceneBuildQuality rtcSetSceneFlags rtcGetSceneFlags rtcGetSceneBounds
@@ -44,7 +44,7 @@ rtcTraversableIntersect1 rtcTraversableIntersect4 rtcTraversableIntersect8 rtcTr
 rtcTraversableOccluded1 rtcTraversableOccluded4 rtcTraversableOccluded8 rtcTraversableOccluded16
 rtcIntersect1M rtcOccluded1M rtcIntersect1MDevice rtcOccluded1MDevice""".split()
 MI355_SYMBOLS = """mi355_default_build_params mi355_last_error mi355_device_count mi355_device_name mi355_bvh_build
-mi355_bvh_destroy mi355_bvh_build_instanced mi355_bvh_refit mi355_release_build_scratch mi355_bvh_get_info mi355_bvh_download mi355_trace_prepare mi355_trace_closest mi355_trace_any
+mi355_bvh_destroy mi355_bvh_build_instanced mi355_bvh_refit mi355_release_build_scratch mi355_bvh_get_info mi355_bvh_set_filter_rules mi355_bvh_download mi355_trace_prepare mi355_trace_closest mi355_trace_any
 mi355_trace_query mi355_trace_closest_packet mi355_trace_any_packet mi355_trace_stats mi355_trace_timed mi355_trace_status mi355_malloc mi355_free mi355_memcpy_h2d
 mi355_memcpy_d2h mi355_synchronize mi355_device_synchronize mi355_memcpy_d2d_async mi355_stream_create
 mi355_stream_destroy mi355_event_create mi355_event_record mi355_event_elapsed_ms mi355_event_destroy
@@ -70,6 +70,15 @@ class QueryArguments(C.Structure):             # RTCIntersectArguments / RTCOccl
         self.flags, self.feature_mask, self.context, self.callback = flags, -1, None, None
         self._fn = filter_fn
         self.filter = C.cast(filter_fn, C.c_void_p) if filter_fn else None
+
+
+class FilterRule(C.Structure):                  # struct RTCFilterRule (include/embree4/rtcore.h)
+    _fields_ = [("kinds", C.c_uint), ("apply", C.c_uint), ("modulus", C.c_uint), ("remainder", C.c_uint), ("primFactor", C.c_uint), ("geomFactor", C.c_uint),
+                ("tmin", C.c_float), ("tmax", C.c_float), ("umax", C.c_float), ("vmax", C.c_float), ("bits", C.c_void_p), ("numBits", C.c_uint)]
+
+
+RTC_FILTER_RULE_MODULO, RTC_FILTER_RULE_PRIMITIVE_BITS, RTC_FILTER_RULE_DISTANCE_WINDOW, RTC_FILTER_RULE_UV_CUTOFF = 1, 2, 4, 8
+RTC_FILTER_RULE_APPLY_INTERSECT, RTC_FILTER_RULE_APPLY_OCCLUDED = 1, 2
 
 
 class BuildParams(C.Structure):
@@ -189,6 +198,7 @@ def load():
     for fn in (L.rtcSetGeometryIntersectFilterFunction, L.rtcSetGeometryOccludedFilterFunction):
         fn.argtypes = [vp, vp]
     L.rtcSetGeometryEnableFilterFunctionFromArguments.argtypes = [vp, C.c_bool]
+    L.rtcSetGeometryFilterRule.argtypes = [vp, C.POINTER(FilterRule)]
     L.rtcIntersect1M.argtypes = [vp, vp, u32, sz, vp]
     L.rtcOccluded1M.argtypes = [vp, vp, u32, sz, vp]
     L.rtcIntersect1MDevice.argtypes = [vp, vp, u32, sz, vp, vp]
@@ -489,6 +499,12 @@ class Scene:
         self.L.rtcSetGeometryIntersectFilterFunction(g, C.cast(intersect, C.c_void_p) if intersect else None)
         self.L.rtcSetGeometryOccludedFilterFunction(g, C.cast(occluded, C.c_void_p) if occluded else None)
         self.L.rtcSetGeometryEnableFilterFunctionFromArguments(g, bool(from_arguments))
+        self.dev.check()
+
+    def set_filter_rule(self, gid, rule):
+        """rtcSetGeometryFilterRule on geometry `gid` (a FilterRule or None); takes effect with the next commit()"""
+        g = self.L.rtcGetGeometry(self.h, gid)
+        self.L.rtcSetGeometryFilterRule(g, C.byref(rule) if rule is not None else None)
         self.dev.check()
 
     # -- queries on device memory --

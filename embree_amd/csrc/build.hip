@@ -125,6 +125,7 @@ Bvh::~Bvh() {
   if (d_tris) hipFree(d_tris);
   if (d_ids) hipFree(d_ids);
   if (d_insts) hipFree(d_insts);
+  if (d_rules) hipFree(d_rules);
 }
 
 // A commit is enqueued as ONE sequence of launches with no host round trip inside (MEDIUM quality, the default): the number of valid triangles, the
@@ -669,7 +670,29 @@ static int build_instanced_impl(int device, Bvh* own, const mi355_instance* inst
     if (n) hipLaunchKernelGGL(rebase_nodes, dim3((n + 255u) / 256u), dim3(256), 0, st, (const uint4*)objs[k]->d_nodes, (uint4*)bvh->d_nodes + 5ull * nodeOfs[k], n, nodeOfs[k], triOfs[k]);
     HIP_TRY(hipMemcpyAsync((char*)bvh->d_tris + (size_t)triOfs[k] * sizeof(TriRec), objs[k]->d_tris, (size_t)objs[k]->info.num_triangles * sizeof(TriRec), hipMemcpyDeviceToDevice, st));
   }
-  for (uint32_t k = 0; k < R; k++) recs[k].root = nodeOfs[objIndex[recObj[k]]];
+  // device-side filter rules: one table for the combined tree -- every distinct object's entries behind a base of its own (InstRec.flags >> 8), bit arrays at the end
+  std::vector<uint32_t> ruleBase(objs.size(), 0u);
+  { bool any = false; uint32_t entries = 0;
+    for (size_t k = 0; k < objs.size(); k++) { ruleBase[k] = entries; entries += objs[k]->numRuleGeoms; any = any || !objs[k]->h_rules.empty(); }
+    if (any && entries < (1u << 24)) {
+      std::vector<uint32_t> tab((size_t)entries * 12u, 0u);
+      for (size_t k = 0; k < objs.size(); k++) {
+        const std::vector<uint32_t>& h = objs[k]->h_rules; const uint32_t ng = objs[k]->numRuleGeoms;
+        if (h.size() < (size_t)ng * 12u) continue;                  // (an object without rules: its entries stay zero = no rule)
+        const uint32_t bitsAt = (uint32_t)tab.size(), oldBitsAt = ng * 12u;
+        for (uint32_t g = 0; g < ng; g++) {
+          uint32_t* e = &tab[((size_t)ruleBase[k] + g) * 12u];
+          memcpy(e, &h[(size_t)g * 12u], 48);
+          if (e[0] & 2u) e[8] = bitsAt + (e[8] - oldBitsAt);        // RULE_BITS: where this object's bit arrays land
+        }
+        tab.insert(tab.end(), h.begin() + oldBitsAt, h.end());
+      }
+      HIP_TRY(hipMalloc(&bvh->d_rules, tab.size() * 4u));
+      HIP_TRY(hipMemcpyAsync(bvh->d_rules, tab.data(), tab.size() * 4u, hipMemcpyHostToDevice, st));
+      HIP_TRY(hipStreamSynchronize(st));                            // (tab is a local)
+    }
+  }
+  for (uint32_t k = 0; k < R; k++) { const uint32_t oi = objIndex[recObj[k]]; recs[k].root = nodeOfs[oi]; if (bvh->d_rules) recs[k].flags |= ruleBase[oi] << 8; }
   HIP_TRY(hipMalloc((void**)&dRecs, (size_t)R * sizeof(InstRec))); bvh->d_insts = dRecs;
   HIP_TRY(hipMemcpyAsync(dRecs, recs.data(), (size_t)R * sizeof(InstRec), hipMemcpyHostToDevice, st));
   HIP_TRY(hipGetLastError());
@@ -718,6 +741,19 @@ void mi355_release_build_scratch(int device) {
   Arena* a = arena_of(device);
   std::lock_guard<std::mutex> lk(a->mtx);
   hipSetDevice(device); a->release();
+}
+int mi355_bvh_set_filter_rules(mi355_bvh_t bvh, const uint32_t* words, size_t num_words, uint32_t num_geoms) {
+  mi355::Bvh* b = (mi355::Bvh*)bvh; if (!b) return mi355::set_error(hipErrorInvalidValue, "mi355_bvh_set_filter_rules: no tree");
+  HIP_TRY(hipSetDevice(b->device));
+  if (b->d_rules) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(b->d_rules)); b->d_rules = nullptr; }   // (queries in flight may still read the old table)
+  b->h_rules.clear(); b->numRuleGeoms = num_geoms;
+  if (!words || num_words == 0) return 0;
+  if (num_words < (size_t)num_geoms * 12u) return mi355::set_error(hipErrorInvalidValue, "mi355_bvh_set_filter_rules: table shorter than 12 words per geometry");
+  b->h_rules.assign(words, words + num_words);
+  if (b->d_insts) return 0;                                      // (an instanced tree carries the combined table it was built with)
+  HIP_TRY(hipMalloc(&b->d_rules, num_words * 4u));
+  HIP_TRY(hipMemcpy(b->d_rules, words, num_words * 4u, hipMemcpyHostToDevice));
+  return 0;
 }
 int mi355_bvh_get_info(mi355_bvh_t bvh, mi355_bvh_info* info) { *info = ((mi355::Bvh*)bvh)->info; return 0; }
 int mi355_bvh_download(mi355_bvh_t bvh, void* nodes, size_t nb, void* tris, size_t tb) {

@@ -35,6 +35,8 @@ struct Bvh {
   void* d_tris = nullptr;        // TriRec[numTris]
   uint32_t root = 0xFFFFFFFFu;
   void* d_insts = nullptr;       // scenes with instances: InstRec[] (64 B: world2local | root node, instID, mask, flags); d_nodes / d_tris = top tree + the objects' trees
+  void* d_rules = nullptr;       // device-side filter rules: 48 B per geometry id (instanced scenes: the own geometries', then every object's behind its base) + bit arrays
+  std::vector<uint32_t> h_rules; uint32_t numRuleGeoms = 0;   // ... and the host copy of a FLAT tree's table (what an instanced build concatenates)
   bool robust = false;           // TriRec holds v0,v1,v2 (instead of v0,e1,e2); traversal = conservative node test + Pluecker
   mi355_bvh_info info{};
   // refit data (params.refit): leaf order (geometry table index, internal triangle) per TriRec, first node of every level, the mesh list it was built from

@@ -182,6 +182,7 @@ struct Geometry : RefCounted {
   void* userPtr = nullptr;
   RTCFilterFunctionN intersectFilter = nullptr, occludedFilter = nullptr;   // host callbacks: run between launches by the host-array entry points (filtered_query)
   bool argFilter = false;                                   // rtcSetGeometryEnableFilterFunctionFromArguments
+  bool hasRule = false; RTCFilterRule rule{}; std::vector<unsigned> ruleBits; unsigned ruleCounter = 0;   // device-side filter rule (rtcSetGeometryFilterRule): goes to the GPU with the next rtcCommitScene
   std::atomic<int> attached{0};
   Geometry(Device* d, RTCGeometryType t) : device(d), type(t) { d->retain(); }
   ~Geometry() override;
@@ -282,7 +283,7 @@ struct Scene : RefCounted {
   bool committed = false, modified = true;
   const unsigned long long serial = ++g_geomSerial;        // (instances remember the scene they were built over by this, not by address)
   std::vector<std::unique_ptr<Replica>> reps;               // one per GPU of the device
-  struct BuiltFrom { unsigned id; unsigned long long g; RTCBuildQuality q; unsigned topo, data; };   // what the current tree was built from: decides rebuild vs refit vs nothing to do; g = Geometry::serial
+  struct BuiltFrom { unsigned id; unsigned long long g; RTCBuildQuality q; unsigned topo, data, rule; };   // what the current tree was built from: decides rebuild vs refit vs nothing to do; g = Geometry::serial
   std::vector<BuiltFrom> builtFrom; unsigned builtFlags = 0;
   struct InstFrom { unsigned id; unsigned long long g; unsigned long long object; unsigned topo, data; unsigned long long objSerial; };   // g = Geometry::serial, object = Scene::serial
   std::vector<InstFrom> builtInst;
@@ -335,7 +336,7 @@ struct Scene : RefCounted {
     for (auto& kv : geoms) {
       Geometry* g = kv.second;
       if (!g->enabled || !g->vertices.buf || !g->indices.buf) continue;
-      from.push_back({kv.first, g->serial, g->quality, g->topoCounter, g->dataCounter});
+      from.push_back({kv.first, g->serial, g->quality, g->topoCounter, g->dataCounter, g->ruleCounter});
       wantRefit = wantRefit || g->quality == RTC_BUILD_QUALITY_REFIT;
     }
     bp.refit = wantRefit ? 1u : 0u;
@@ -352,7 +353,7 @@ struct Scene : RefCounted {
     const bool haveTree = committed && reps[0]->bvh != nullptr, haveFlat = committed && reps[0]->flat != nullptr;
     if (haveTree && !modified && nowFlags == builtFlags && from.size() == builtFrom.size() && instFrom.size() == builtInst.size()) {   // (attach / detach set `modified`)
       bool same = true;
-      for (size_t i = 0; same && i < from.size(); i++) { const BuiltFrom &a = from[i], &b = builtFrom[i]; same = a.id == b.id && a.g == b.g && a.topo == b.topo && a.data == b.data; }
+      for (size_t i = 0; same && i < from.size(); i++) { const BuiltFrom &a = from[i], &b = builtFrom[i]; same = a.id == b.id && a.g == b.g && a.topo == b.topo && a.data == b.data && a.rule == b.rule; }
       for (size_t i = 0; same && i < instFrom.size(); i++) { const InstFrom &a = instFrom[i], &b = builtInst[i]; same = a.id == b.id && a.g == b.g && a.object == b.object && a.topo == b.topo && a.data == b.data && a.objSerial == b.objSerial; }
       if (same) { if (progress) progress(progressPtr, 1.0); return; }
     }
@@ -381,6 +382,25 @@ struct Scene : RefCounted {
       if (!g->object->committed || !g->object->flat0()) THROW(RTC_ERROR_INVALID_OPERATION, "the instanced scene has to be committed before the scene that instances it");
       instGeoms.push_back({g, kv.first});
     }
+    // ---- device-side filter rules (rtcSetGeometryFilterRule): the table every replica uploads
+    std::vector<uint32_t> ruleTable; uint32_t ruleGeoms = geoms.empty() ? 0u : geoms.rbegin()->first + 1u;
+    { bool any = false;
+      for (auto& kv : geoms) any = any || (kv.second->enabled && kv.second->hasRule && kv.second->rule.kinds != 0u);
+      if (any) {
+        ruleTable.assign((size_t)ruleGeoms * 12u, 0u);
+        for (auto& kv : geoms) {
+          Geometry* g = kv.second;
+          if (!g->enabled || !g->hasRule || g->rule.kinds == 0u) continue;
+          const RTCFilterRule& q = g->rule;
+          uint32_t e[12] = {0}; float f[4] = {q.tmin, q.tmax, q.umax, q.vmax};
+          e[0] = (q.kinds & 0xFFu) | ((q.apply & 3u) << 8); e[1] = q.modulus; e[2] = q.remainder; e[3] = (q.primFactor & 0xFFFFu) | ((q.geomFactor & 0xFFFFu) << 16);
+          memcpy(&e[4], f, 16);
+          if ((q.kinds & RTC_FILTER_RULE_PRIMITIVE_BITS) && !g->ruleBits.empty()) { e[8] = (uint32_t)ruleTable.size(); e[9] = q.numBits; ruleTable.insert(ruleTable.end(), g->ruleBits.begin(), g->ruleBits.end()); }
+          else e[0] &= ~(uint32_t)RTC_FILTER_RULE_PRIMITIVE_BITS;
+          memcpy(&ruleTable[(size_t)kv.first * 12u], e, 48);
+        }
+      }
+    }
     // ---- every replica does the same thing on its own GPU, side by side (one host thread per GPU; the build is deterministic, so the replicas come out bit-identical)
     std::vector<int> didRefit(reps.size(), 0);
     std::atomic<bool> refitBroken{false};
@@ -405,6 +425,8 @@ struct Scene : RefCounted {
         if (r.flat) { mi355_bvh_destroy(r.flat); device->memoryMonitor(-r.flatBytes, true); if (r.bvh == r.flat) r.bvh = nullptr; }
         r.flat = nb; r.flatBytes = newBytes;
       }
+      // device-side filter rules of this scene's geometries: one 12-word entry per geometry id + the bit arrays (mi355_bvh_set_filter_rules)
+      core_check(mi355_bvh_set_filter_rules(r.flat, ruleTable.empty() ? nullptr : ruleTable.data(), ruleTable.size(), ruleGeoms), "filter rules");
       if (r.bvh && r.bvh != r.flat) { mi355_bvh_destroy(r.bvh); device->memoryMonitor(-r.bvhBytes, true); r.bvhBytes = 0; }
       r.bvh = r.flat;
       if (!instGeoms.empty()) {
@@ -948,6 +970,19 @@ RTC_API void* rtcGetGeometryUserData(RTCGeometry h) { CATCH_BEGIN return geom_of
 // attached to lazily: the flag below is looked at by every host query.
 RTC_API void rtcSetGeometryIntersectFilterFunction(RTCGeometry h, RTCFilterFunctionN f) { CATCH_BEGIN geom_of(h)->intersectFilter = f; if (f) g_anyFilterEver = true; CATCH_END(GEOM_DEV(h)) }
 RTC_API void rtcSetGeometryOccludedFilterFunction(RTCGeometry h, RTCFilterFunctionN f) { CATCH_BEGIN geom_of(h)->occludedFilter = f; if (f) g_anyFilterEver = true; CATCH_END(GEOM_DEV(h)) }
+RTC_API void rtcSetGeometryFilterRule(RTCGeometry h, const struct RTCFilterRule* rule) {
+  CATCH_BEGIN Geometry* g = geom_of(h);
+  if (rule) {
+    if (rule->primFactor > 0xFFFFu || rule->geomFactor > 0xFFFFu) THROW(RTC_ERROR_INVALID_ARGUMENT, "filter rule factors must be below 65536");
+    if ((rule->kinds & RTC_FILTER_RULE_PRIMITIVE_BITS) && rule->numBits && !rule->bits) THROW(RTC_ERROR_INVALID_ARGUMENT, "filter rule without its bit array");
+    g->rule = *rule; g->hasRule = true;
+    g->ruleBits.clear();
+    if ((rule->kinds & RTC_FILTER_RULE_PRIMITIVE_BITS) && rule->numBits) g->ruleBits.assign(rule->bits, rule->bits + (rule->numBits + 31u) / 32u);   // copied: the caller's array may go
+    g->rule.bits = nullptr;
+  } else { g->hasRule = false; g->rule = RTCFilterRule{}; g->ruleBits.clear(); }
+  g->ruleCounter++;
+  CATCH_END(GEOM_DEV(h))
+}
 RTC_API void rtcSetGeometryEnableFilterFunctionFromArguments(RTCGeometry h, bool enable) { CATCH_BEGIN geom_of(h)->argFilter = enable; CATCH_END(GEOM_DEV(h)) }
 
 // ============================================================================================= scene

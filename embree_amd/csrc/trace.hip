@@ -73,6 +73,7 @@ struct TraceArgs {
   volatile uint32_t* status;  // host-mapped: [STATUS_ITER_CAP], [STATUS_SPILL] set to 1 when a safety net dropped work
   unsigned long long* stats;  // optional counters
   const float4* insts;   // INST kernels: InstRec[] as 4 x float4 (world2local vx,vy,vz,p | root node, instID, mask, flags)
+  const uint4* rules;    // device-side filter rules, 48 B per geometry (+ bit arrays behind them), or nullptr
   const uint32_t* deferList; const uint32_t* deferCount;   // second pass of a RTC_RAY_QUERY_FLAG_COHERENT query: the packets (64 consecutive rays each) the packet kernel gave up on; nullptr otherwise
 };
 
@@ -211,6 +212,33 @@ __device__ __forceinline__ bool tri_pluecker(const float4 q0, const float4 q1, c
     o.u = quad2 ? 1.0f - v : u; o.v = quad2 ? 1.0f - u : v; o.Ngx = sg * Ngx; o.Ngy = sg * Ngy; o.Ngz = sg * Ngz;
   }
   return ok;
+}
+
+// ---- device-side filter rules (include/embree4/rtcore.h rtcSetGeometryFilterRule_mi355).  The reference runs filter CALLBACKS inside the traversal for every
+// potential hit and goes on when one says no (runIntersectionFilter1 / runOcclusionFilter1, kernels/geometry/filter.h:14-80, called from Intersect1EpilogM /
+// Occluded1EpilogM, intersector_epilog.h:235-368).  A host function cannot run in a HIP kernel; what can is a small fixed set of RULES per geometry, evaluated
+// where the reference calls the callback: after the triangle test and the mask test accepted a candidate, before it is published.  A rule is a pure function
+// of (primID, geomID, t, u, v), so "closest accepted hit" / "any accepted hit" do not depend on the order candidates are met in.  48 bytes per geometry:
+//   w0 kinds | apply << 8   w1 modulus   w2 remainder   w3 primID factor | geomID factor << 16     w4-7 tmin tmax umax vmax     w8 bit array offset (words)  w9 bits
+constexpr uint32_t RULE_MODULO = 1u, RULE_BITS = 2u, RULE_TWINDOW = 4u, RULE_UV = 8u, RULE_APPLY_INTERSECT = 1u << 8, RULE_APPLY_OCCLUDED = 2u << 8;
+template <bool ANY, bool ROBUST>
+__device__ __forceinline__ bool rule_accepts(const uint4* rules, uint32_t ruleIdx, const float4 q0, const float4 q1, const float4 q2, float t,
+                                             float ox, float oy, float oz, float dx, float dy, float dz) {
+  const uint4 r0 = rules[(size_t)ruleIdx * 3u];
+  if ((r0.x & 0xFFu) == 0u || !(r0.x & (ANY ? RULE_APPLY_OCCLUDED : RULE_APPLY_INTERSECT))) return true;
+  const uint4 r1 = rules[(size_t)ruleIdx * 3u + 1u], r2 = rules[(size_t)ruleIdx * 3u + 2u];
+  const uint32_t pidRaw = __float_as_uint(q2.y), pid = pidRaw & 0x7FFFFFFFu, gid = __float_as_uint(q2.z);
+  bool reject = false;
+  if ((r0.x & RULE_MODULO) && r0.y != 0u) reject = ((pid * (r0.w & 0xFFFFu) + gid * (r0.w >> 16)) % r0.y) == r0.z;
+  if ((r0.x & RULE_BITS) && pid < r2.y) reject = reject || ((((const uint32_t*)rules)[r2.x + (pid >> 5)] >> (pid & 31u)) & 1u) != 0u;
+  if (r0.x & RULE_TWINDOW) reject = reject || !(t >= __uint_as_float(r1.x) && t <= __uint_as_float(r1.y));
+  if (r0.x & RULE_UV) {                                         // u, v as the hit record would carry them (second half of a quad included)
+    TriOut w;
+    if (ROBUST) tri_pluecker<true>(q0, q1, q2, ox, oy, oz, dx, dy, dz, 0.0f, 0.0f, w, (pidRaw >> 31) != 0u);
+    else tri_moeller<true>(q0, q1, q2, ox, oy, oz, dx, dy, dz, 0.0f, 0.0f, w, (pidRaw >> 31) != 0u);
+    reject = reject || w.u > __uint_as_float(r1.z) || w.v > __uint_as_float(r1.w);
+  }
+  return !reject;
 }
 
 // =============================================================================================
@@ -602,6 +630,7 @@ __global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceAr
       const float gdx = __shfl(dx, owner, 64), gdy = __shfl(dy, owner, 64), gdz = __shfl(dz, owner, 64);
       const float gtnear = __shfl(tnear, owner, 64);
       const uint32_t grmask = (uint32_t)__shfl((int)rmask, owner, 64);
+      const uint32_t ginst = (INST && a.rules) ? (uint32_t)__shfl((int)inst, owner, 64) : NO_INST;   // (rules of an instanced scene's geometries sit behind that instance's base)
       if (STATS && lane == 0u) stTriBlk++;
       if (mine) {
         const float gtfar = __uint_as_float((uint32_t)(best[owner] >> 32));
@@ -614,6 +643,11 @@ __global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceAr
         bool ok = ROBUST ? tri_pluecker<false>(q0, q1, q2, gox, goy, goz, gdx, gdy, gdz, gtnear, gtfar, w)
                          : tri_moeller<false>(q0, q1, q2, gox, goy, goz, gdx, gdy, gdz, gtnear, gtfar, w);
         ok = ok && ((tmask & grmask) != 0u);                           // EMBREE_RAY_MASK, intersector_epilog.h:256-262
+        if (ok && a.rules) {                                           // device-side filter rule of the candidate's geometry: where the reference calls the filter callback
+          uint32_t ri = __float_as_uint(q2.z);
+          if (INST && ginst != NO_INST) ri += __float_as_uint(a.insts[(size_t)ginst * 4u + 3u].w) >> 8;
+          ok = rule_accepts<ANY, ROBUST>(a.rules, ri, q0, q1, q2, w.t, gox, goy, goz, gdx, gdy, gdz);
+        }
         if (ok) atomicMin(&best[owner], ((unsigned long long)__float_as_uint(w.t + 0.0f) << 32) | e.x);   // + 0: a hit at -0 must not sort as a huge key
       }
       qHead += n; usePre = false;
@@ -713,7 +747,7 @@ __global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceAr
 //   ANY of its rays visits, so it wins when neighbouring rays share most of their path (primary rays of a moderately tessellated scene, shadow rays towards
 //   one light) and loses on incoherent batches -- the flag is the application's promise, as in the reference.
 constexpr int PSTACK = 128;                 // stack entries per packet: <= 7 siblings left behind per level
-struct PacketTraceArgs { const uint4* nodes; const float4* tris; uint32_t hasRoot; char* rays; uint32_t count, stride; uint32_t* deferList; uint32_t* deferCount; volatile uint32_t* status; uint32_t minServed; };
+struct PacketTraceArgs { const uint4* nodes; const float4* tris; uint32_t hasRoot; char* rays; uint32_t count, stride; uint32_t* deferList; uint32_t* deferCount; volatile uint32_t* status; uint32_t minServed; const uint4* rules; };
 
 template <bool ANY, bool ROBUST>
 __global__ __launch_bounds__(64) void trace_packet_kernel(PacketTraceArgs a) {
@@ -833,6 +867,7 @@ __global__ __launch_bounds__(64) void trace_packet_kernel(PacketTraceArgs a) {
             bool ok = ROBUST ? tri_pluecker<false>(u0, u1, u2, ox, oy, oz, dx, dy, dz, tnear, bestT, w)
                              : tri_moeller<false>(u0, u1, u2, ox, oy, oz, dx, dy, dz, tnear, bestT, w);
             ok = ok && ((__float_as_uint(u2.w) & rmask) != 0u);
+            if (ok && a.rules) ok = rule_accepts<ANY, ROBUST>(a.rules, __float_as_uint(u2.z), u0, u1, u2, w.t, ox, oy, oz, dx, dy, dz);
             if (ok) {
               const float tt = w.t + 0.0f;
               if (ANY) { bestTri = ti; alive = false; }
@@ -959,7 +994,7 @@ static int launch_trace(Bvh* b, void* d_rays, uint32_t count, size_t stride, boo
   HIP_TRY(hipMemsetAsync(sc->counter, 0, NUM_CURSORS * CURSOR_STRIDE * sizeof(uint32_t), s));
   TraceArgs a;
   a.nodes = (const uint4*)b->d_nodes; a.tris = (const float4*)b->d_tris; a.hasRoot = b->root != MI355_EMPTY_REF ? 1u : 0u;
-  a.rays = (char*)d_rays; a.count = count; a.stride = (uint32_t)stride; a.insts = (const float4*)b->d_insts; a.deferList = deferList; a.deferCount = deferCount;
+  a.rays = (char*)d_rays; a.count = count; a.stride = (uint32_t)stride; a.insts = (const float4*)b->d_insts; a.deferList = deferList; a.deferCount = deferCount; a.rules = (const uint4*)b->d_rules;
   a.counter = sc->counter; a.spill = (uint2*)sc->spill; a.spillPerLane = trace_spill_per_lane(b->info.depth); a.stats = nullptr;
   static const uint32_t refillMin = env_u32("MI355_REFILL_MIN", REFILL_MIN_DEFAULT, 1, 64);
   static const uint32_t pushRounds = env_u32("MI355_PUSH_ROUNDS", PUSH_ROUNDS_DEFAULT, 1, 24);
@@ -1018,7 +1053,7 @@ static int launch_trace_coherent(Bvh* b, void* d_rays, uint32_t count, size_t st
     HIP_TRY(hipMemsetAsync(defer, 0, sizeof(uint32_t), s));
     PacketTraceArgs a;
     a.nodes = (const uint4*)b->d_nodes; a.tris = (const float4*)b->d_tris; a.hasRoot = b->root != MI355_EMPTY_REF ? 1u : 0u;
-    a.rays = (char*)d_rays; a.count = count; a.stride = (uint32_t)stride; a.deferCount = defer; a.deferList = defer + 64; a.status = sc->statusDev;
+    a.rays = (char*)d_rays; a.count = count; a.stride = (uint32_t)stride; a.deferCount = defer; a.deferList = defer + 64; a.status = sc->statusDev; a.rules = (const uint4*)b->d_rules;
     static const uint32_t minLanes = env_u32("MI355_PACKET_MIN_LANES", 48, 0, 64);
     a.minServed = 4u * minLanes;
     hipLaunchKernelGGL(fn, dim3(blocks), dim3(64), 0, s, a);

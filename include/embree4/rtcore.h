@@ -396,6 +396,24 @@ RTC_API void* rtcGetGeometryUserData(RTCGeometry geometry);
 RTC_API void rtcSetGeometryIntersectFilterFunction(RTCGeometry geometry, RTCFilterFunctionN filter);
 RTC_API void rtcSetGeometryOccludedFilterFunction(RTCGeometry geometry, RTCFilterFunctionN filter);
 RTC_API void rtcSetGeometryEnableFilterFunctionFromArguments(RTCGeometry geometry, bool enable);
+/* Extension: a filter RULE that runs inside the traversal kernels, where the reference calls the filter callbacks [ref: kernels/geometry/filter.h:14-80,
+   intersector_epilog.h:235-368].  A candidate hit of this geometry is rejected (the ray goes on) if ANY enabled part of the rule says so:
+     RTC_FILTER_RULE_MODULO           (primID * primFactor + geomID * geomFactor) % modulus == remainder
+     RTC_FILTER_RULE_PRIMITIVE_BITS   bit primID of `bits` (numBits bits, copied at rtcCommitScene) is set -- a per-primitive alpha mask
+     RTC_FILTER_RULE_DISTANCE_WINDOW  t outside [tmin, tmax]
+     RTC_FILTER_RULE_UV_CUTOFF        u > umax or v > vmax
+   `apply` says which queries run it.  Works for every entry point (the device-pointer ones included) and inside instanced scenes; takes effect with the next
+   rtcCommitScene of the scene(s) the geometry is attached to.  rule = NULL removes it.  Host callbacks, where set, run after it on the host-array entry points. */
+enum RTCFilterRuleKind { RTC_FILTER_RULE_MODULO = 1, RTC_FILTER_RULE_PRIMITIVE_BITS = 2, RTC_FILTER_RULE_DISTANCE_WINDOW = 4, RTC_FILTER_RULE_UV_CUTOFF = 8 };
+enum RTCFilterRuleApply { RTC_FILTER_RULE_APPLY_INTERSECT = 1, RTC_FILTER_RULE_APPLY_OCCLUDED = 2 };
+struct RTCFilterRule {
+  unsigned int kinds;                      /* OR of RTCFilterRuleKind */
+  unsigned int apply;                      /* OR of RTCFilterRuleApply */
+  unsigned int modulus, remainder, primFactor, geomFactor;   /* factors < 65536 */
+  float tmin, tmax, umax, vmax;
+  const unsigned int* bits; unsigned int numBits;
+};
+RTC_API void rtcSetGeometryFilterRule(RTCGeometry geometry, const struct RTCFilterRule* rule);
 
 /* -------------------------------------------------------------------- scene */
 /* [ref: rtcore_scene.h:89-150] */

@@ -122,6 +122,15 @@ MI355_API int mi355_bvh_refit(mi355_bvh_t bvh, const mi355_mesh* meshes, uint32_
 /* Build scratch (prim refs, binary tree, work lists) is kept per device between commits; this returns it to the driver. */
 MI355_API void mi355_release_build_scratch(int device);
 MI355_API int mi355_bvh_get_info(mi355_bvh_t bvh, mi355_bvh_info* info);
+/* Device-side filter rules of a FLAT tree (the reference: filter callbacks run inside the traversal, kernels/geometry/filter.h:14-80, intersector_epilog.h:
+   235-368; a host function cannot run in a HIP kernel, a rule can).  `words` = num_geoms entries of 12 words, indexed by geometry id --
+     w0 kinds (1 modulo, 2 bit array, 4 distance window, 8 u/v cut-off) | apply << 8 (1 rtcIntersect*, 2 rtcOccluded*)
+     w1 modulus m, w2 remainder r, w3 a | b << 16:  reject if (primID * a + geomID * b) % m == r
+     w4 tmin, w5 tmax (floats): reject unless tmin <= t <= tmax          w6 umax, w7 vmax: reject if u > umax or v > vmax
+     w8 offset (in words from the start of `words`) and w9 length (bits) of a bit array: reject if bit primID is set          w10, w11 reserved
+   -- followed by the bit arrays.  num_words = 0 removes the rules.  An instanced tree (mi355_bvh_build_instanced) takes the rules its object trees carry at
+   the time it is built.  Blocking; must not overlap queries on the tree. */
+MI355_API int mi355_bvh_set_filter_rules(mi355_bvh_t bvh, const uint32_t* words, size_t num_words, uint32_t num_geoms);
 /* Copies the tree to host memory for validation (tests): nodes = num_nodes*80 B, tris = num_triangles*48 B. */
 MI355_API int mi355_bvh_download(mi355_bvh_t bvh, void* nodes, size_t nodes_bytes, void* tris, size_t tris_bytes);
 

@@ -278,3 +278,161 @@ def test_coherent_flag_gives_the_incoherent_answers(api, dev, flags):
     s.intersect1M(b, qa)
     assert (a["geomID"] == 0).mean() > 0.9 and a.tobytes() == b.tobytes()
     s.release()
+
+
+# ------------------------------------------------------------------------------------------- device-side filter rules
+def _rule_scene_meshes():
+    from tests.test_gpu_reference_suite import _sticks
+    return [_sticks(400, 3), W.triangle_sphere(np.array([0.5, 0.5, 0.5], np.float32), 0.3, 40, noise=0.1, seed=5),
+            W.triangle_sphere(np.array([0.5, 0.5, 0.5], np.float32), 0.55, 30, noise=0.05, seed=6)]
+
+
+def _rule_rays(n=12000, seed=77):
+    rng = np.random.default_rng(seed)
+    org = rng.random((n, 3), dtype=np.float32) * 1.8 - 0.4
+    tgt = rng.random((n, 3), dtype=np.float32)
+    return make_rayhits(org, (tgt - org) * np.float32(2.0))
+
+
+def _tri_t64(meshes):
+    def tri_t(rr, geom, prim):
+        out = np.zeros(rr.shape[0], np.float32)
+        for k in range(rr.shape[0]):
+            v, t = meshes[int(geom[k])]
+            a, b, c = v[t[int(prim[k])]].astype(np.float64)
+            o = np.array([rr["org_x"][k], rr["org_y"][k], rr["org_z"][k]], np.float64)
+            d = np.array([rr["dir_x"][k], rr["dir_y"][k], rr["dir_z"][k]], np.float64)
+            nrm = np.cross(b - a, c - a)
+            out[k] = np.dot(nrm, a - o) / np.dot(nrm, d)
+        return out
+    return tri_t
+
+
+@pytest.mark.parametrize("flags", [0, 4])
+def test_device_filter_rules_vs_reference_callbacks(api, dev, ref, flags):
+    """rtcSetGeometryFilterRule: the reference's geometry rule of oracle/ref_driver.cpp ("reject primID % 3 == 0 or u > 0.7") installed as a RULE that runs
+    inside the traversal kernels, against the real reference running it as a filter CALLBACK inside its traversal (kernels/geometry/filter.h:14-80,
+    intersector_epilog.h:235-368): closest accepted hit and occlusion must be the reference's, through the host-array AND the device-pointer entry points
+    (which cannot run callbacks), with the packet kernel, fast and robust; and the same rule as a host callback here gives the same bytes."""
+    meshes = _rule_scene_meshes()
+    rays = _rule_rays()
+    r = ref.RefScene(flags=flags)
+    for v, t in meshes:
+        r.add_mesh(v, t)
+    r.commit()
+    s = api.make_scene(dev, meshes, flags=flags)
+    plain = rays.copy()
+    s.intersect1M(plain)
+    rule = api.FilterRule(kinds=api.RTC_FILTER_RULE_MODULO | api.RTC_FILTER_RULE_UV_CUTOFF, apply=api.RTC_FILTER_RULE_APPLY_INTERSECT | api.RTC_FILTER_RULE_APPLY_OCCLUDED,
+                          modulus=3, remainder=0, primFactor=1, geomFactor=0, tmin=0, tmax=0, umax=0.7, vmax=np.inf, bits=None, numBits=0)
+    for g in range(len(meshes)):
+        s.set_filter_rule(g, rule)
+    s.commit()
+    r.set_filters(len(meshes), 1 | 2)
+    want = rays.copy()
+    r.intersect1_args(want)
+    got = rays.copy()
+    s.intersect1M(got)
+    st = compare_closest(got, want, rays, _tri_t64(meshes), max_tie_frac=2e-3, label="device rule vs reference callback")
+    changed = int(((got["primID"] != plain["primID"]) | (got["geomID"] != plain["geomID"])).sum())
+    assert changed > 1000
+    d = api.DeviceArray.from_numpy(rays)                       # the device-pointer entry point filters as well
+    s.intersect1M_device(d.ptr, rays.shape[0])
+    api.load().mi355_device_synchronize(0)
+    assert d.download(RAYHIT_DTYPE).tobytes() == got.tobytes()
+    d.free()
+    coh = rays.copy()                                          # ... and so does the packet kernel
+    s.intersect1M(coh, api.QueryArguments(None, api.RTC_RAY_QUERY_FLAG_COHERENT))
+    assert coh.tobytes() == got.tobytes()
+    wr, gr = rays_of(rays), rays_of(rays)
+    r.occluded1_args(wr)
+    s.occluded1M(gr)
+    compare_occluded(gr["tfar"], wr["tfar"], rays_of(rays)["tfar"], max_flip_frac=2e-3, label="device rule, occlusion")
+    # the same rule as a HOST callback on a second scene: same bytes
+    def rule_geometry(a):
+        a = a.contents
+        for i in range(a.N):
+            if a.valid[i] != -1:
+                continue
+            prim = C.cast(a.hit, C.POINTER(C.c_uint32))[5 * a.N + i]
+            if prim % 3 == 0 or a.hit[3 * a.N + i] > 0.7:
+                a.valid[i] = 0
+    f = api.FILTER_FN(rule_geometry)
+    s2 = api.make_scene(dev, meshes, flags=flags)
+    for g in range(len(meshes)):
+        s2.set_filters(g, intersect=f, occluded=f)
+    host = rays.copy()
+    s2.intersect1M(host)
+    assert host.tobytes() == got.tobytes(), "device rule and host callback disagree on %d rays" % int((host["primID"] != got["primID"]).sum())
+    # rule removed again: the plain answers come back, without a rebuild
+    n0 = s.info()["num_nodes"]
+    for g in range(len(meshes)):
+        s.set_filter_rule(g, None)
+    s.commit()
+    back = rays.copy()
+    s.intersect1M(back)
+    assert back.tobytes() == plain.tobytes() and s.info()["num_nodes"] == n0
+    print("device rule: %d hits, %d rays changed, %d ties" % (st["hits"], changed, st["ties"]))
+    s.release(); s2.release(); r.close()
+
+
+def test_device_filter_rule_kinds_and_instances(api, dev):
+    """The other rule kinds (per-primitive bit array = alpha mask, distance window) against the same predicate as a host callback, and a rule on a geometry
+    INSIDE an instanced scene (host callbacks cannot run there: rtcore_api.cpp filtered_query refuses instances)."""
+    meshes = _rule_scene_meshes()
+    rays = _rule_rays(8000, seed=5)
+    rng = np.random.default_rng(1)
+    nb = meshes[1][1].shape[0]
+    bits = (rng.random(nb) < 0.4)
+    words = np.zeros((nb + 31) // 32, np.uint32)
+    for i in np.nonzero(bits)[0]:
+        words[i >> 5] |= np.uint32(1 << (int(i) & 31))
+    s = api.make_scene(dev, meshes)
+    s.set_filter_rule(1, api.FilterRule(kinds=api.RTC_FILTER_RULE_PRIMITIVE_BITS, apply=3, bits=words.ctypes.data, numBits=nb))
+    s.set_filter_rule(2, api.FilterRule(kinds=api.RTC_FILTER_RULE_DISTANCE_WINDOW, apply=3, tmin=0.2, tmax=0.45))
+    s.commit()
+    got = rays.copy()
+    s.intersect1M(got)
+
+    def cb(a):
+        a = a.contents
+        for i in range(a.N):
+            if a.valid[i] != -1:
+                continue
+            hp = C.cast(a.hit, C.POINTER(C.c_uint32))
+            prim, geom, t = hp[5 * a.N + i], hp[6 * a.N + i], a.ray[8 * a.N + i]
+            if (geom == 1 and bits[prim]) or (geom == 2 and not (np.float32(0.2) <= np.float32(t) <= np.float32(0.45))):
+                a.valid[i] = 0
+    f = api.FILTER_FN(cb)
+    s2 = api.make_scene(dev, meshes)
+    for g in range(len(meshes)):
+        s2.set_filters(g, intersect=f, occluded=f)
+    host = rays.copy()
+    s2.intersect1M(host)
+    assert host.tobytes() == got.tobytes(), "bit-array / window rules differ from the host callback on %d rays" % int((host["primID"] != got["primID"]).sum())
+    assert (got["geomID"] == 1).any() and not bits[got["primID"][got["geomID"] == 1]].any()
+    og, oh = rays_of(rays), rays_of(rays)
+    s.occluded1M(og); s2.occluded1M(oh)
+    assert og.tobytes() == oh.tobytes()
+    # ---- a rule inside an instanced scene: the instance of a filtered object answers like the filtered object itself, moved
+    obj = api.make_scene(dev, [meshes[1]])
+    obj.set_filter_rule(0, api.FilterRule(kinds=api.RTC_FILTER_RULE_PRIMITIVE_BITS, apply=3, bits=words.ctypes.data, numBits=nb))
+    obj.commit()
+    top = api.Scene(dev)
+    shift = np.float32([0.25, -0.1, 0.05])
+    top.add_instance(obj, [1, 0, 0, 0, 1, 0, 0, 0, 1, shift[0], shift[1], shift[2]])
+    top.add_triangle_mesh(*meshes[0])
+    top.commit()
+    a = rays.copy()
+    top.intersect1M(a)
+    inst = a["instID"][:, 0] if a["instID"].ndim > 1 else a["instID"]
+    hit_inst = (a["geomID"] != INVALID_ID) & (inst == 0)
+    assert hit_inst.sum() > 100 and not bits[a["primID"][hit_inst]].any(), "a masked primitive of the instanced object was reported"
+    moved = rays.copy()                                        # the same rays in the object's space against the object alone
+    moved["org_x"] -= shift[0]; moved["org_y"] -= shift[1]; moved["org_z"] -= shift[2]
+    b = moved.copy()
+    obj.intersect1M(b)
+    closer = hit_inst & (b["geomID"] != INVALID_ID)
+    assert closer.sum() > 100 and (np.abs(a["tfar"][closer] - b["tfar"][closer]) <= 1e-4 * np.abs(b["tfar"][closer]) + 1e-6).mean() > 0.95
+    for x in (top, obj, s, s2):
+        x.release()
