@@ -283,6 +283,11 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:       # no launcher: this process becomes the launcher of N ranks (SCALE runs must never measure N = 1 N times)
         sys.exit(spawn_ranks(args.gpus))
+    # stdout carries ONE JSON line and nothing else: native libraries print there too (RCCL's version banner, Gloo's connection messages), so fd 1 points at
+    # stderr for the whole run and the line goes to the saved descriptor at the end
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -703,7 +708,7 @@ def main():
                         failed = "%d occlusion results differ from the reference" % flips
             except Exception as e:                            # the baseline leg must never take the GPU number down
                 out["cpu_baseline"] = {"error": repr(e)}
-        print(json.dumps(out), flush=True)
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
         if failed:
             log("PARITY FAILURE: " + failed)
             os._exit(1)

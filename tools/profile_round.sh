@@ -4,7 +4,7 @@
 # 1. rocprofv3 --kernel-trace --stats of the default bench command (kernel durations: must agree with roofline.kernel_ms_avg)
 # 2. the PMC passes of tools/pmc_run.sh (counters in their own runs, never mixed with tracing), summarised for the closest-hit kernel together with
 #    the hash of the kernel source they were collected for
-T=${1:-r02}
+T=${1:-r03}
 R=$PWD
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${T}_prof -o ${T} -- python $R/bench.py --no-cpu > $R/gpurun_out/${T}_prof_bench.json 2> $R/gpurun_out/${T}_prof_bench.err )
 python tools/kstats.py gpurun_out/${T}_prof > gpurun_out/${T}_kstats.md 2>&1
