@@ -85,7 +85,7 @@ class BuildParams(C.Structure):
     _fields_ = [("sah_block_shift", C.c_uint32), ("min_leaf", C.c_uint32), ("max_leaf", C.c_uint32),
                 ("small_threshold", C.c_uint32), ("trav_cost", C.c_float), ("int_cost", C.c_float),
                 ("robust", C.c_uint32), ("quality", C.c_uint32), ("split_factor", C.c_float), ("refit", C.c_uint32),
-                ("presplits", C.c_uint32), ("top_splits", C.c_uint32), ("top_split_min", C.c_uint32), ("top_split_rel", C.c_float)]
+                ("presplits", C.c_uint32), ("top_splits", C.c_uint32), ("top_split_min", C.c_uint32), ("top_split_rel", C.c_float), ("top_split_cell", C.c_float)]
 
 
 class BvhInfo(C.Structure):

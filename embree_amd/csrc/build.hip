@@ -156,18 +156,12 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
   // reference's other form, splitting big triangles up front (state.cpp:88 useSpatialPreSplits).  The spatial splits live in the top phase: lower its end.
   prm.spatial = (bp->quality == 2u && !bp->presplits && numMeshes < (1u << 27)) ? 1u : 0u;
   if (prm.spatial && prm.small > 256u) prm.small = 256u;
-  // RTC_BUILD_QUALITY_MEDIUM (the default): the SAME spatial splits, but only in the sets of the first levels (>= top_split_min references, default 65536)
-  // and without leaving the one-round-trip path.  Measured on the crown stand-in (profiles/r03_collapse.md): what the HIGH tree gains on the bench's rays
-  // (36.6 -> 32.7 node visits, 51.0 -> 46.6 triangle tests per ray, +11 % rays per second) comes from the few room-sized triangles cut near the root;
-  // restricted to big sets the splits keep that gain for a fraction of HIGH's build time.  The reference's MEDIUM builder never splits
-  // (BVHBuilderBinnedSAH, kernels/builders/bvh_builder_sah.h:446); answers do not depend on it, "top_splits=0" switches it off.  Not with refit data
-  // (a refit walks one leaf record per triangle).
+  // RTC_BUILD_QUALITY_MEDIUM (the default): the few references that dwarf all others are cut into grid pieces before the build (build_presplit.inl,
+  // outlier_*; "top_splits=0" switches it off, and so does refit data: a refit walks one leaf record per triangle).  The reference's MEDIUM builder never
+  // cuts a triangle (BVHBuilderBinnedSAH, kernels/builders/bvh_builder_sah.h:446); answers do not depend on it.
   const bool topSplits = allowTopSplits && bp->quality == 0u && bp->top_splits != 0u && !bp->refit && numMeshes < (1u << 27);
-  // ... and only when such references are FEW (at most N / 2048 + 64 boxes of >= top_split_rel x the mean box area): a dozen room-sized triangles are what a
-  // handful of planes near the root can fix (crown stand-in +9 % rays per second); thousands of long pipe triangles are not (powerplant stand-in: +0.6 % for
-  // +3 ms), and there the spatial kernels see the count on the device and return at once.
-  if (topSplits) prm.spatial = 1u;
-  const float topSplitRel = bp->top_split_rel > 0.0f ? bp->top_split_rel : 32.0f;   // only references this many times larger than the mean box may be cut by a top split
+  const float topSplitRel = bp->top_split_rel > 0.0f ? bp->top_split_rel : 32.0f;   // an outlier: box area >= this many times the mean box area ...
+  const float topSplitCell = bp->top_split_cell > 0.0f ? bp->top_split_cell : 1.0f / 8.0f;   // ... and longer than this fraction of the scene's largest extent (= the grid its pieces are cut on)
 
   std::vector<GeomDesc> gd; uint64_t total = 0;
   for (uint32_t i = 0; i < numMeshes; i++) {
@@ -206,9 +200,10 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
   // of the long-triangle scene is 12.53 instead of 12.52 and the crown stand-in's tree does not change, for 1.2 ms less (spatial_bin clips a small set's
   // references through most of its 16 bins per axis); 2048 would cost 2 % of the SAH gain, 65536 all of it on small scenes (profiles/r02_sah_vs_reference.md)
   static const uint32_t spatialMinHigh = getenv("MI355_SPATIAL_MIN") ? (uint32_t)atol(getenv("MI355_SPATIAL_MIN")) : 512u;
-  const uint32_t spatialMin = topSplits ? (bp->top_split_min ? bp->top_split_min : 65536u) : spatialMinHigh;
+  const uint32_t spatialMin = spatialMinHigh;
   const bool presplit = prm.quality == 2u && !spatial;         // up to 20 % more references than triangles, either way
-  const uint32_t splitBudget = (prm.quality == 2u || topSplits) ? (uint32_t)((double)N * (bp->split_factor > 1.0f ? (double)bp->split_factor - 1.0 : 0.2)) : 0u;
+  const uint32_t splitBudget = prm.quality == 2u ? (uint32_t)((double)N * (bp->split_factor > 1.0f ? (double)bp->split_factor - 1.0 : 0.2))
+                             : (topSplits ? N / 16u + 65536u : 0u);   // MEDIUM: the reserve for the pieces of outlier references
   const uint64_t cap64 = (uint64_t)N + splitBudget;
   if (cap64 >= (1ull << 31)) return set_error(hipErrorInvalidValue, "more than 2^31 references are not supported by the 32-bit triangle index");
   const uint32_t NC = (uint32_t)cap64;                        // capacity of every per-reference array
@@ -224,7 +219,9 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
   DevBuf<WidePlan> plans; DevBuf<uint2> itemCnt, groupSum; DevBuf<uint32_t> tileCount;
   HIP_TRY(plans.alloc(maxLevelItems)); HIP_TRY(itemCnt.alloc(maxLevelItems)); HIP_TRY(groupSum.alloc(maxLevelItems / 8u + 16u));
   const uint32_t tiles = (N + 255u) / 256u;
-  HIP_TRY(tileCount.alloc(tiles));
+  HIP_TRY(tileCount.alloc((NC + 255u) / 256u));
+  DevBuf<uint32_t> outlierCnt, outlierTile, outlierTotal;      // MEDIUM: grid cells every reference asks for (0 unless it is an outlier), their tile sums / offsets, the total
+  if (topSplits) { HIP_TRY(outlierCnt.alloc(N)); HIP_TRY(outlierTile.alloc(tiles)); HIP_TRY(outlierTotal.alloc(1)); }
   DevBuf<uint32_t> chunkCnt; DevBuf<uint2> chunkBase;          // per chunk of a level: its bin counts, then its places in the two children (top_bin -> top_split -> top_partition)
   HIP_TRY(chunkCnt.alloc((size_t)maxChunks * 3u * NBINS)); HIP_TRY(chunkBase.alloc(maxChunks));
   DevBuf<SegX> segx0, segx1; DevBuf<uint32_t> sbins;            // spatial-split builds: extended ranges of the top phase's sets, their spatial bins
@@ -234,10 +231,10 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
   struct EvGuard { hipEvent_t a, b; ~EvGuard() { hipEventDestroy(a); hipEventDestroy(b); } } evg{ev0, ev1};
   if (useGraph) {
     HIP_TRY(hipStreamSynchronize(st));                         // (the geometry table above is in place before anything is captured)
-    const void* ptrs[] = {dGeoms.p, bufA.p, bufB.p, finalIds.p, bnodes.p, segs0.p, segs1.p, bins.p, chunks.p, small.p, ctr.p, w0.p, w1.p, wnodes.p, outIds.p, plans.p, itemCnt.p, groupSum.p, tileCount.p, chunkCnt.p, chunkBase.p, segx0.p, segx1.p, sbins.p, (const void*)st};
+    const void* ptrs[] = {dGeoms.p, bufA.p, bufB.p, finalIds.p, bnodes.p, segs0.p, segs1.p, bins.p, chunks.p, small.p, ctr.p, w0.p, w1.p, wnodes.p, outIds.p, plans.p, itemCnt.p, groupSum.p, tileCount.p, chunkCnt.p, chunkBase.p, segx0.p, segx1.p, sbins.p, outlierCnt.p, outlierTile.p, outlierTotal.p, (const void*)st};
     std::vector<uint64_t> key; for (const void* q : ptrs) key.push_back((uint64_t)(uintptr_t)q);
     uint32_t pw[sizeof(Params) / 4]; memcpy(pw, &prm, sizeof(prm)); for (uint32_t w : pw) key.push_back(w);
-    key.push_back(N); key.push_back(gd.size()); key.push_back(bp->robust); key.push_back(spatialMin); key.push_back(NC); { uint32_t w; memcpy(&w, &topSplitRel, 4); key.push_back(w); }
+    key.push_back(N); key.push_back(gd.size()); key.push_back(bp->robust); key.push_back(spatialMin); key.push_back(NC); { uint32_t w; memcpy(&w, &topSplitRel, 4); key.push_back(w); memcpy(&w, &topSplitCell, 4); key.push_back(w); } key.push_back(topSplits ? 1u : 0u);
     if (arena->graphExec && arena->graphKey == key) replay = true;
     else {
       arena->drop_graph(); arena->graphKey = key;
@@ -256,26 +253,32 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
   float glo[3], ghi[3], clo[3], chi[3];
   uint32_t numSegs = 0, numSmall = 0;
   if (fast) {
-    // invalid triangles are squeezed out on the device, if there are any; then the root
-    LAUNCH(compact_count, dim3(tiles), dim3(256), 0, st, bufA.p, N, tileCount.p, ctr.p);
-    LAUNCH(compact_scan, dim3(1), dim3(1024), 0, st, tileCount.p, tiles, ctr.p, 1u);
-    LAUNCH(compact_scatter, dim3(tiles), dim3(256), 0, st, bufA.p, N, tileCount.p, bufB.p, ctr.p);
-    LAUNCH(compact_copyback, dim3(tiles < 2048u ? tiles : 2048u), dim3(256), 0, st, bufB.p, bufA.p, ctr.p);
+    const uint32_t ctiles = (NC + 255u) / 256u;                  // tiles of the compaction: the references and, behind them, the reserve for outlier pieces
+    if (topSplits) {                                             // references that dwarf all others are cut into grid pieces (build_presplit.inl): holes and originals become "invalid"
+      const uint32_t ab = tiles < 2048u ? tiles : 2048u;
+      LAUNCH(outlier_area, dim3(ab), dim3(256), 0, st, bufA.p, N, ctr.p);
+      LAUNCH(outlier_mark, dim3(tiles), dim3(256), 0, st, bufA.p, N, ctr.p, topSplitRel, topSplitCell, outlierCnt.p, outlierTile.p);
+      LAUNCH(presplit_scan, dim3(1), dim3(1024), 0, st, outlierTile.p, tiles, outlierTotal.p);
+      LAUNCH(outlier_emit, dim3(tiles), dim3(256), 0, st, bufA.p, N, NC - N, dGeoms.p, outlierCnt.p, outlierTile.p, outlierTotal.p, ctr.p, topSplitRel, topSplitCell);
+    }
+    // invalid triangles (and the holes of the outlier grid) are squeezed out on the device, if there are any; then the root
+    LAUNCH(compact_count, dim3(ctiles), dim3(256), 0, st, bufA.p, NC, tileCount.p, ctr.p, N);
+    LAUNCH(compact_scan, dim3(1), dim3(1024), 0, st, tileCount.p, ctiles, ctr.p, 1u);
+    LAUNCH(compact_scatter, dim3(ctiles), dim3(256), 0, st, bufA.p, NC, tileCount.p, bufB.p, ctr.p, N);
+    LAUNCH(compact_copyback, dim3(ctiles < 2048u ? ctiles : 2048u), dim3(256), 0, st, bufB.p, bufA.p, ctr.p);
+    if (topSplits) {                                             // pieces have other centres than their triangles: the centroid box is measured again (only if something was cut)
+      LAUNCH(centroid_reset, dim3(1), dim3(64), 0, st, ctr.p);
+      LAUNCH(centroid_bounds_guarded, dim3(tiles < 1024u ? tiles : 1024u), dim3(256), 0, st, bufA.p, ctr.p);
+    }
     LAUNCH(root_setup, dim3(1), dim3(1), 0, st, ctr.p, bnodes.p, segs0.p, small.p, N, prm.small);
     numSegs = N > prm.small ? 1u : 0u;
-    if (spatial && N > prm.small) {                              // split budgets of the references (the number of valid ones is on the device); the root set owns everything behind them
-      const uint32_t ab = (N + 255u) / 256u < 2048u ? (N + 255u) / 256u : 2048u;
-      LAUNCH(spatial_area_sum, dim3(ab), dim3(256), 0, st, bufA.p, N, ctr.p);
-      LAUNCH(spatial_budgets, dim3((N + 255u) / 256u), dim3(256), 0, st, bufA.p, N, ctr.p, topSplits ? topSplitRel : 0.0f);
-      LAUNCH(segx_root, dim3(1), dim3(1), 0, st, segx0.p, NC);
-    }
   } else {
     SYNC_READ(h);
     h.numPrims = N - h.numInvalid;
     if (h.numInvalid) {                                          // rare: squeeze the invalid triangles out (stable)
-      LAUNCH(compact_count, dim3(tiles), dim3(256), 0, st, bufA.p, N, tileCount.p, (const Counters*)nullptr);
+      LAUNCH(compact_count, dim3(tiles), dim3(256), 0, st, bufA.p, N, tileCount.p, (const Counters*)nullptr, N);
       LAUNCH(compact_scan, dim3(1), dim3(1024), 0, st, tileCount.p, tiles, ctr.p, 0u);
-      LAUNCH(compact_scatter, dim3(tiles), dim3(256), 0, st, bufA.p, N, tileCount.p, bufB.p, (const Counters*)nullptr);
+      LAUNCH(compact_scatter, dim3(tiles), dim3(256), 0, st, bufA.p, N, tileCount.p, bufB.p, (const Counters*)nullptr, N);
       HIP_TRY(hipGetLastError());
       HIP_TRY(hipMemcpyAsync(bufA.p, bufB.p, (size_t)h.numPrims * sizeof(PrimRef), hipMemcpyDeviceToDevice, st));
       HIP_TRY(hipStreamSynchronize(st)); syncs++;
@@ -331,7 +334,7 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
     if (spatial && n > prm.small) {                              // split budgets of the references; the root set owns everything behind them
       const uint32_t ab = (n + 255u) / 256u < 2048u ? (n + 255u) / 256u : 2048u;
       LAUNCH(spatial_area_sum, dim3(ab), dim3(256), 0, st, bufA.p, n, ctr.p);
-      LAUNCH(spatial_budgets, dim3((n + 255u) / 256u), dim3(256), 0, st, bufA.p, n, ctr.p, topSplits ? topSplitRel : 0.0f);
+      LAUNCH(spatial_budgets, dim3((n + 255u) / 256u), dim3(256), 0, st, bufA.p, n, ctr.p);
       SegX x0{}; x0.extEnd = NC;
       HIP_TRY(hipMemcpyAsync(segx0.p, &x0, sizeof(x0), hipMemcpyHostToDevice, st));
     }
@@ -360,10 +363,6 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
   //      an upper bound of its grid (<= 2^level segments, <= N/CHUNK + #segments chunks) and surplus blocks exit at once, so
   //      the levels are enqueued back to back.
   uint32_t level = 0;
-  // top splits of a MEDIUM build: a set of >= spatialMin references cannot exist below level log2(N / spatialMin) + a margin for uneven splits (a set that is
-  // still that big further down simply splits by object, like every small set does): the spatial kernels are not even launched there
-  uint32_t spatialLevels = 0xFFFFFFFFu;
-  if (topSplits) { spatialLevels = 6u; while (spatialLevels < 40u && ((uint64_t)spatialMin << (spatialLevels - 6u)) < N) spatialLevels++; }
   Seg* cur = segs0.p; Seg* nxt = segs1.p; SegX* xcur = segx0.p; SegX* xnxt = segx1.p;     // (the SegX arrays: nullptr unless spatial)
   auto enqueue_top_level = [&]() {
     PrimRef* src = (level & 1u) ? bufB.p : bufA.p; PrimRef* dst = (level & 1u) ? bufA.p : bufB.p;
@@ -372,14 +371,13 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
     LAUNCH(top_setup, dim3(segBound), dim3(256), 0, st, cur, bins.p, chunks.p, ctr.p);
     LAUNCH(top_bin, dim3(chunkBound), dim3(256), 0, st, cur, chunks.p, src, bins.p, ctr.p, chunkCnt.p);
     LAUNCH(top_split, dim3(segBound), dim3(64), 0, st, cur, bins.p, bnodes.p, ctr.p, prm, level >= 96u ? 1u : 0u, xcur, (const uint32_t*)chunkCnt.p, chunkBase.p);
-    const bool spatialLevel = spatial && level < spatialLevels;
-    if (spatialLevel) {                                          // sets whose object split leaves overlapping children try a spatial split
-      LAUNCH(spatial_decide, dim3(segBound), dim3(128), 0, st, cur, xcur, bnodes.p, sbins.p, ctr.p, spatialMin, topSplits ? N / 2048u + 64u : 0xFFFFFFFFu);
+    if (spatial) {                                          // sets whose object split leaves overlapping children try a spatial split
+      LAUNCH(spatial_decide, dim3(segBound), dim3(128), 0, st, cur, xcur, bnodes.p, sbins.p, ctr.p, spatialMin);
       LAUNCH(spatial_bin, dim3(chunkBound), dim3(256), 0, st, cur, xcur, chunks.p, src, dGeoms.p, sbins.p, ctr.p);
       LAUNCH(spatial_best, dim3(segBound), dim3(64), 0, st, cur, xcur, sbins.p, bnodes.p, ctr.p, prm);
     }
     LAUNCH(top_partition, dim3(chunkBound), dim3(256), 0, st, cur, chunks.p, src, dst, ctr.p, (const uint2*)chunkBase.p);
-    if (spatialLevel) LAUNCH(spatial_partition, dim3(chunkBound), dim3(256), 0, st, cur, xcur, chunks.p, src, dst, dGeoms.p, ctr.p);
+    if (spatial) LAUNCH(spatial_partition, dim3(chunkBound), dim3(256), 0, st, cur, xcur, chunks.p, src, dst, dGeoms.p, ctr.p);
     LAUNCH(top_emit, dim3((segBound + 255u) / 256u), dim3(256), 0, st, cur, bnodes.p, nxt, small.p, ctr.p, prm,
            (level & 1u) ? 0u : 1u, maxSegs, maxSmall, (const SegX*)xcur, xnxt);
     LAUNCH(top_advance, dim3(1), dim3(1), 0, st, ctr.p, maxSegs);
@@ -446,14 +444,13 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
     HIP_TRY(hipMalloc(&bvh->d_tris, (size_t)NC * sizeof(TriRec) + 128));
     LAUNCH(tri_records, dim3((NC + 255u) / 256u), dim3(256), 0, st, outIds.p, NC, dGeoms.p, (TriRec*)bvh->d_tris, bp->robust ? 1u : 0u, (const Counters*)ctr.p);
     SYNC_READ(h);                                                // the ONE round trip of the commit
-    if (h.overflow == 2u && topSplits) return -1001;             // a top split ran out of its extended range (guarded stores, nothing was corrupted): the caller repeats the commit without top splits
     if (h.overflow) return set_error(hipErrorOutOfMemory, "work list overflow (pathological input)");
     if (h.numSegs != 0u) {                                       // the top phase needed more levels than N implies + 8: what came after it worked on an unfinished tree
       arena->marginFailedN = N;
       return -1000;                                              // (the guard frees the half-built tree) the caller repeats the commit on the stepwise path
     }
     n = h.numPrims;
-    if (spatial && n != 0u) { info.num_presplit = h.numTrisOut > n ? h.numTrisOut - n : 0u; n = h.numTrisOut; }   // the references the splits created are leaf entries like any other
+    info.num_presplit = h.outlierPieces > h.numOutliers ? h.outlierPieces - h.numOutliers : 0u;   // leaf records beyond one per triangle: the pieces of the cut outliers
     if (n == 0) { hipFree(bvh->d_tris); bvh->d_tris = nullptr; info.num_launches = launches; info.num_host_syncs = syncs; guard.ok = true; *out = bvh; return 0; }
     for (int d = 0; d < 3; d++) { info.bounds_lower[d] = decf(h.bounds[d]); info.bounds_upper[d] = decf(h.bounds[3 + d]); }
     info.top_levels = h.topLevels;
@@ -508,11 +505,9 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
 #undef SYNC_READ
 }
 
-// the one-round-trip path can ask for the commit to be repeated: -1000 = level margins exceeded (stepwise path), -1001 = a top split of a MEDIUM build
-// ran out of its extended range (same path, no top splits)
+// the one-round-trip path can ask for the commit to be repeated on the stepwise path (-1000: level margins exceeded); that path does not cut outliers
 static int build_retry(int device, const mi355_mesh* meshes, uint32_t numMeshes, const mi355_build_params* bp, hipStream_t st, Bvh** out) {
   int rc = build_impl(device, meshes, numMeshes, bp, st, out);
-  if (rc == -1001) rc = build_impl(device, meshes, numMeshes, bp, st, out, true, false);
   if (rc == -1000) rc = build_impl(device, meshes, numMeshes, bp, st, out, false, false);
   return rc;
 }
@@ -712,7 +707,7 @@ extern "C" {
 
 void mi355_default_build_params(mi355_build_params* p) {
   memset(p, 0, sizeof(*p));
-  p->sah_block_shift = 0; p->min_leaf = 2; p->max_leaf = 3; p->small_threshold = 1024; p->trav_cost = 1.0f; p->int_cost = 1.0f; p->split_factor = 1.2f; p->presplits = 0; p->top_splits = 1; p->top_split_min = 65536; p->top_split_rel = 32.0f;
+  p->sah_block_shift = 0; p->min_leaf = 2; p->max_leaf = 3; p->small_threshold = 1024; p->trav_cost = 1.0f; p->int_cost = 1.0f; p->split_factor = 1.2f; p->presplits = 0; p->top_splits = 1; p->top_split_min = 0; p->top_split_rel = 32.0f; p->top_split_cell = 1.0f / 8.0f;
 }
 const char* mi355_last_error(void) { return mi355::g_err.c_str(); }
 int mi355_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }

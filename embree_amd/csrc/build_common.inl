@@ -48,8 +48,9 @@ struct Counters {
   uint32_t numSegs, topLevels, wideDepth, lvlNodeBase, lvlTriBase, wideCount[2];      // level loops are driven from the device: no host readback per level
   unsigned long long sahFixed;                    // SAH statistics, 2^-24 fixed point (order-independent sum)
   float rootArea;                                 // half area of the scene bounds (SAH statistics are relative to it); written by root_setup
-  uint32_t numOutliers;                           // MEDIUM builds with top splits: references whose box is >= top_split_rel x the mean box (spatial_budgets counts them)
+  uint32_t numOutliers;                           // MEDIUM builds: references cut up front because their box dwarfs the average one (build_presplit.inl, outlier_*)
   unsigned long long areaFixed;                   // spatial-split builds: sum of the references' box areas / scene area, 2^-32 fixed point (build_spatial.inl)
+  uint32_t outlierCells, outlierPieces, outlierValid, outlierSkip;   // ... the places reserved for their pieces behind the references, the pieces that exist, the valid references counted, 1 = too many
   uint32_t lvlStart[64];                          // first node of every level of the wide tree (numbering is breadth first): what a refit walks bottom-up
 };
 struct Params { uint32_t shift, minLeaf, maxLeaf, small; float travCost, intCost; uint32_t quality, spatial; };

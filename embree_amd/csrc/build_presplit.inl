@@ -182,3 +182,168 @@ __global__ __launch_bounds__(256) void centroid_bounds(const PrimRef* prims, uin
   __syncthreads();
   if (threadIdx.x < 6u) { if (threadIdx.x < 3u) atomicMin(&ctr->bounds[6 + threadIdx.x], s_acc[threadIdx.x]); else atomicMax(&ctr->bounds[6 + threadIdx.x], s_acc[threadIdx.x]); }
 }
+
+// --------------------------------------------------------------------------------- RTC_BUILD_QUALITY_MEDIUM: the few references that dwarf all others are cut up front
+// A handful of triangles that span the scene (the walls of a room, a ground plane) sit in every node of the first levels and make every box above them as
+// large as they are.  The reference's answer is RTC_BUILD_QUALITY_HIGH (spatial splits, above and in build_spatial.inl), at 2.5 x the build time.  Measured on
+// the crown stand-in (profiles/r03_collapse.md): ALL of what the HIGH tree gains on the bench's rays (36.6 -> 32.7 node visits, 51.0 -> 46.9 triangle tests per
+// ray, +11 % rays per second) comes from the twelve room-sized triangles -- and a tree built by object splits alone over the same room cut into a grid of
+// pieces gains the same (tests/gpu_perf.py --tess-room: 32.5 / 47.2 with 16 pieces per wall triangle, 32.0 / 44.9 with 1024).  So a MEDIUM commit cuts such
+// references before the build, on the device, inside the one-round-trip commit:
+//   outlier_area   sum of the valid references' box areas (fixed point, order independent) and their number
+//   outlier_mark   a reference is an OUTLIER if its box area is >= top_split_rel (32) x the mean box area and longer than one cell of a uniform grid of
+//                  top_split_cell (1/8) of the scene's largest extent; it asks for one place per grid cell its box covers (<= 32 cells per axis)
+//   presplit_scan  places behind the references, in reference order (no atomic decides an index: rebuilds are bit-identical)
+//   outlier_emit   the triangle is clipped against every cell (Sutherland-Hodgman, 6 planes); a cell it really crosses gets a reference of the SAME triangle
+//                  with the clipped polygon's box (widened by 4 ulp, clamped to cell and box), an empty cell leaves a hole; the original is dropped
+//   the stable compaction that squeezes out invalid triangles (compact_*) squeezes out the holes; centroid_bounds recomputes the centroid box.
+// Everything after that is the ordinary binned-SAH build over a few more references (crown stand-in: 12 triangles -> 3,3 k pieces, +0.07 %).  If the
+// outliers' cells do not fit the reserve (N / 16 + 65536 places) nothing is cut: thousands of long pipe triangles are not what this is for.
+constexpr int OUTLIER_MAX_AXIS = 32;
+__device__ __forceinline__ float ctr_root_area2(const Counters* ctr, float (&ext)[3]) {
+  for (int d = 0; d < 3; d++) ext[d] = dec(ctr->bounds[3 + d]) - dec(ctr->bounds[d]);
+  return 2.0f * half_area3(ext[0], ext[1], ext[2]);
+}
+__global__ __launch_bounds__(256) void outlier_area(const PrimRef* prims, uint32_t n, Counters* ctr) {
+  __shared__ unsigned long long s_w[4]; __shared__ uint32_t s_c[4];
+  float ext[3]; const float rootArea2 = ctr_root_area2(ctr, ext);
+  unsigned long long acc = 0ull; uint32_t cnt = 0u;
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+    const PrimRef r = load_prim(prims + i);
+    if (r.geom == NIL) continue;
+    const float a = 2.0f * half_area3(r.hi[0] - r.lo[0], r.hi[1] - r.lo[1], r.hi[2] - r.lo[2]);
+    if (rootArea2 > 0.0f) acc += (unsigned long long)((double)(a / rootArea2) * 4294967296.0);
+    cnt++;
+  }
+  for (int o = 32; o > 0; o >>= 1) { acc += __shfl_down(acc, o, 64); cnt += (uint32_t)__shfl_down((int)cnt, o, 64); }
+  if ((threadIdx.x & 63u) == 0u) { s_w[threadIdx.x >> 6] = acc; s_c[threadIdx.x >> 6] = cnt; }
+  __syncthreads();
+  if (threadIdx.x == 0u) { atomicAdd(&ctr->areaFixed, s_w[0] + s_w[1] + s_w[2] + s_w[3]); atomicAdd(&ctr->outlierValid, s_c[0] + s_c[1] + s_c[2] + s_c[3]); }
+}
+// grid cells of one reference (1 = not an outlier)
+__device__ __forceinline__ uint32_t outlier_cells(const PrimRef& r, const Counters* ctr, float minRel, float cellFrac, uint32_t (&nc)[3], float (&cell)[3]) {
+  nc[0] = nc[1] = nc[2] = 1u; cell[0] = cell[1] = cell[2] = 0.0f;
+  if (r.geom == NIL) return 1u;
+  float ext[3]; const float rootArea2 = ctr_root_area2(ctr, ext);
+  const double sumRel = (double)ctr->areaFixed / 4294967296.0;
+  const uint32_t valid = ctr->outlierValid;
+  if (!(rootArea2 > 0.0f) || !(sumRel > 0.0) || valid < 1024u) return 1u;           // (small scenes have no "average" worth the name)
+  const float a = 2.0f * half_area3(r.hi[0] - r.lo[0], r.hi[1] - r.lo[1], r.hi[2] - r.lo[2]);
+  const float rel = (float)((double)valid * ((double)(a / rootArea2) / sumRel));     // this box's area / the mean box area
+  if (!(rel >= minRel)) return 1u;
+  const float L = fmaxf(ext[0], fmaxf(ext[1], ext[2])) * cellFrac;
+  if (!(L > 0.0f)) return 1u;
+  uint32_t total = 1u;
+  for (int d = 0; d < 3; d++) {
+    const float e = r.hi[d] - r.lo[d];
+    float k = ceilf(e / L); k = k < 1.0f ? 1.0f : (k > (float)OUTLIER_MAX_AXIS ? (float)OUTLIER_MAX_AXIS : k);
+    nc[d] = (uint32_t)k; cell[d] = e / k; total *= nc[d];
+  }
+  return total;
+}
+__global__ __launch_bounds__(256) void outlier_mark(const PrimRef* prims, uint32_t n, const Counters* ctr, float minRel, float cellFrac, uint32_t* cnt, uint32_t* tileSum) {
+  __shared__ uint32_t s_w[4];
+  const uint32_t tid = threadIdx.x, i = blockIdx.x * 256u + tid;
+  uint32_t c = 0u;
+  if (i < n) {
+    const PrimRef r = load_prim(prims + i);
+    uint32_t nc[3]; float cell[3];
+    const uint32_t cells = outlier_cells(r, ctr, minRel, cellFrac, nc, cell);
+    c = cells > 1u ? cells : 0u;
+    cnt[i] = c;
+  }
+  uint32_t x = c; for (int o = 32; o > 0; o >>= 1) x += (uint32_t)__shfl_down((int)x, o, 64);
+  if ((tid & 63u) == 0u) s_w[tid >> 6] = x;
+  __syncthreads();
+  if (tid == 0u) tileSum[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+// Sutherland-Hodgman: the polygon in `p` (n vertices) against the half space x[axis] <= pos (keepLess) or >= pos; returns the new vertex count (<= n + 1)
+__device__ int clip_halfspace(float (*p)[3], int n, int axis, float pos, bool keepLess) {
+  float q[10][3]; int m = 0;
+  for (int i = 0; i < n; i++) {
+    const float* a = p[i]; const float* b = p[i + 1 == n ? 0 : i + 1];
+    const float da = keepLess ? pos - a[axis] : a[axis] - pos, db = keepLess ? pos - b[axis] : b[axis] - pos;   // >= 0: inside
+    if (da >= 0.0f) { for (int d = 0; d < 3; d++) q[m][d] = a[d]; m++; }
+    if ((da > 0.0f && db < 0.0f) || (da < 0.0f && db > 0.0f)) {
+      const float t = da / (da - db);
+      for (int d = 0; d < 3; d++) q[m][d] = fmaf(t, b[d] - a[d], a[d]);
+      q[m][axis] = pos; m++;
+    }
+  }
+  for (int i = 0; i < m; i++) for (int d = 0; d < 3; d++) p[i][d] = q[i][d];
+  return m;
+}
+__global__ __launch_bounds__(256) void outlier_emit(PrimRef* prims, uint32_t n, uint32_t cap, const GeomDesc* geoms, const uint32_t* cnt, const uint32_t* tileOfs, const uint32_t* total,
+                                                    Counters* ctr, float minRel, float cellFrac) {
+  __shared__ uint32_t s_cnt[256], s_scan[256], s_pieces, s_holes, s_cut;
+  const uint32_t tid = threadIdx.x, i = blockIdx.x * 256u + tid;
+  const uint32_t tot = total[0];
+  if (tot == 0u) return;
+  if (tot > cap) { if (blockIdx.x == 0u && tid == 0u) ctr->outlierSkip = 1u; return; }          // too many / too large outliers for the reserve: nothing is cut
+  if (blockIdx.x == 0u && tid == 0u) ctr->outlierCells = tot;
+  const uint32_t c = i < n ? cnt[i] : 0u;
+  s_cnt[tid] = c; s_scan[tid] = c;
+  if (tid == 0u) { s_pieces = 0u; s_holes = 0u; s_cut = 0u; }
+  __syncthreads();
+  for (uint32_t o = 1; o < 256u; o <<= 1) { uint32_t x = 0; if (tid >= o) x = s_scan[tid - o]; __syncthreads(); s_scan[tid] += x; __syncthreads(); }
+  if (s_scan[255] == 0u) return;                                                                 // no outlier in this tile
+  uint32_t pieces = 0u, holes = 0u;
+  for (uint32_t r_ = 0; r_ < 256u; r_++) {
+    const uint32_t cells = s_cnt[r_];
+    if (cells == 0u) continue;                                                                   // (block-uniform)
+    const uint32_t src = blockIdx.x * 256u + r_, base = n + tileOfs[blockIdx.x] + s_scan[r_] - cells;
+    const PrimRef ref = load_prim(prims + src);
+    uint32_t nc[3]; float cell[3];
+    outlier_cells(ref, ctr, minRel, cellFrac, nc, cell);
+    float v[3][3]; load_tri(geoms, ref, v);
+    __syncthreads();                                                                             // (everybody has read the reference before thread 0 retires it below)
+    for (uint32_t k = tid; k < cells; k += 256u) {
+      const uint32_t cx = k % nc[0], cy = (k / nc[0]) % nc[1], cz = k / (nc[0] * nc[1]);
+      float lo[3], hi[3];
+      const uint32_t ci[3] = {cx, cy, cz};
+      for (int d = 0; d < 3; d++) {                                                              // the cell (the outermost ones end exactly at the box)
+        lo[d] = ci[d] == 0u ? ref.lo[d] : fmaf((float)ci[d], cell[d], ref.lo[d]);
+        hi[d] = ci[d] + 1u == nc[d] ? ref.hi[d] : fmaf((float)(ci[d] + 1u), cell[d], ref.lo[d]);
+      }
+      float p[10][3]; int m = 3;
+      for (int a = 0; a < 3; a++) for (int d = 0; d < 3; d++) p[a][d] = v[a][d];
+      for (int d = 0; d < 3 && m > 0; d++) { m = clip_halfspace(p, m, d, lo[d], false); if (m > 0) m = clip_halfspace(p, m, d, hi[d], true); }
+      PrimRef o = ref;
+      if (m > 0) {
+        float blo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, bhi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+        for (int a = 0; a < m; a++) for (int d = 0; d < 3; d++) { blo[d] = fminf(blo[d], p[a][d]); bhi[d] = fmaxf(bhi[d], p[a][d]); }
+        for (int d = 0; d < 3; d++) {                                                            // interpolated points: 4 ulp of their magnitude, then the cell and the triangle's own box
+          const float e = 4.76837158e-7f * fmaxf(fabsf(blo[d]), fabsf(bhi[d]));
+          o.lo[d] = fmaxf(fmaxf(blo[d] - e, lo[d] - e), ref.lo[d]); o.hi[d] = fminf(fminf(bhi[d] + e, hi[d] + e), ref.hi[d]);
+        }
+        pieces++;
+      } else { o.geom = NIL; holes++; }                                                          // the triangle does not cross this cell: a hole, squeezed out by the compaction
+      store_prim(prims + base + k, o);
+    }
+    if (tid == 0u) { PrimRef dead = ref; dead.geom = NIL; store_prim(prims + src, dead); atomicAdd(&s_cut, 1u); }   // the original goes: its pieces stand for it
+  }
+  atomicAdd(&s_pieces, pieces); atomicAdd(&s_holes, holes);
+  __syncthreads();
+  if (tid == 0u) { atomicAdd(&ctr->outlierPieces, s_pieces); atomicAdd(&ctr->numOutliers, s_cut); atomicAdd(&ctr->numInvalid, s_holes + s_cut); }
+}
+__global__ void centroid_reset(Counters* ctr) {                 // the pieces' centres are not the triangles': the centroid box is measured again (centroid_bounds)
+  if (threadIdx.x == 0u && blockIdx.x == 0u && ctr->outlierPieces != 0u) for (int k = 6; k < 12; k++) ctr->bounds[k] = k < 9 ? ENC_POS_INF : ENC_NEG_INF;
+}
+__global__ __launch_bounds__(256) void centroid_bounds_guarded(const PrimRef* prims, Counters* ctr) {
+  if (ctr->outlierPieces == 0u) return;
+  __shared__ uint32_t s_acc[6];
+  if (threadIdx.x < 6u) s_acc[threadIdx.x] = threadIdx.x < 3u ? 0xFFFFFFFFu : 0u;
+  __syncthreads();
+  const uint32_t n = ctr->numPrims;
+  uint32_t acc[6]; for (int k = 0; k < 6; k++) acc[k] = k < 3 ? 0xFFFFFFFFu : 0u;
+  for (uint32_t p = blockIdx.x * 256u + threadIdx.x; p < n; p += gridDim.x * 256u) {
+    const PrimRef r = load_prim(prims + p);
+    for (int d = 0; d < 3; d++) { const uint32_t c2 = enc(r.lo[d] + r.hi[d]); acc[d] = min(acc[d], c2); acc[3 + d] = max(acc[3 + d], c2); }
+  }
+  for (int k = 0; k < 6; k++) {
+    const uint32_t x = k < 3 ? wave_umin63(acc[k]) : wave_umax63(acc[k]);
+    if ((threadIdx.x & 63u) == 63u) { if (k < 3) atomicMin(&s_acc[k], x); else atomicMax(&s_acc[k], x); }
+  }
+  __syncthreads();
+  if (threadIdx.x < 6u) { if (threadIdx.x < 3u) atomicMin(&ctr->bounds[6 + threadIdx.x], s_acc[threadIdx.x]); else atomicMax(&ctr->bounds[6 + threadIdx.x], s_acc[threadIdx.x]); }
+}

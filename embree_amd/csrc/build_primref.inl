@@ -70,8 +70,10 @@ __global__ void build_begin(Counters* ctr) {
 
 // rare path: stable compaction of the valid PrimRefs (tile = 256 consecutive entries).  `ctr` != nullptr: the commit runs without a host round trip
 // after primref_gen, so the kernels are always enqueued and return at once when there is nothing to squeeze out.
-__global__ __launch_bounds__(256) void compact_count(const PrimRef* in, uint32_t n, uint32_t* tileCount, const Counters* ctr) {
+// (one-round-trip commits with outlier pieces behind the references: `n` is the capacity, what is really there ends at base + ctr->outlierCells)
+__global__ __launch_bounds__(256) void compact_count(const PrimRef* in, uint32_t n, uint32_t* tileCount, const Counters* ctr, uint32_t base) {
   if (ctr && ctr->numInvalid == 0u) return;
+  if (ctr) n = min(n, base + ctr->outlierCells);
   const uint32_t p = blockIdx.x * 256u + threadIdx.x;
   const bool ok = p < n && in[p].geom != NIL;
   const int c = __syncthreads_count(ok);
@@ -87,9 +89,10 @@ __global__ __launch_bounds__(1024) void compact_scan(uint32_t* tileCount, uint32
   __syncthreads();
   uint32_t run = s_part[tid]; for (uint32_t i = b; i < e; i++) { const uint32_t t = tileCount[i]; tileCount[i] = run; run += t; }
 }
-__global__ __launch_bounds__(256) void compact_scatter(const PrimRef* in, uint32_t n, const uint32_t* tileOfs, PrimRef* out, const Counters* ctr) {
+__global__ __launch_bounds__(256) void compact_scatter(const PrimRef* in, uint32_t n, const uint32_t* tileOfs, PrimRef* out, const Counters* ctr, uint32_t base) {
   __shared__ uint32_t s_w[4];
   if (ctr && ctr->numInvalid == 0u) return;
+  if (ctr) n = min(n, base + ctr->outlierCells);
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, p = blockIdx.x * 256u + tid;
   PrimRef r{}; bool ok = false;
   if (p < n) { r = load_prim(in + p); ok = r.geom != NIL; }

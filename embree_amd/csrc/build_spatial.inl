@@ -81,10 +81,8 @@ __device__ __forceinline__ void load_tri_masked(const GeomDesc* geoms, const Pri
 }
 
 // ---- split budgets (bvh_builder_sah.h:574-601): two passes over the references, the sum in fixed point relative to the scene's area
-__global__ void segx_root(SegX* sx, uint32_t cap) { if (threadIdx.x == 0u && blockIdx.x == 0u) { SegX x{}; x.extEnd = cap; sx[0] = x; } }   // the root set owns the whole extended range
-__global__ __launch_bounds__(256) void spatial_area_sum(const PrimRef* prims, uint32_t nUpper, Counters* ctr) {
+__global__ __launch_bounds__(256) void spatial_area_sum(const PrimRef* prims, uint32_t n, Counters* ctr) {
   __shared__ unsigned long long s_w[4];
-  const uint32_t n = min(nUpper, ctr->numPrims);                // (one-round-trip commits: the number of valid references is on the device)
   const float rootArea2 = 2.0f * ctr->rootArea;
   unsigned long long acc = 0ull;
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
@@ -97,28 +95,22 @@ __global__ __launch_bounds__(256) void spatial_area_sum(const PrimRef* prims, ui
   __syncthreads();
   if (threadIdx.x == 0u) atomicAdd(&ctr->areaFixed, s_w[0] + s_w[1] + s_w[2] + s_w[3]);
 }
-__global__ __launch_bounds__(256) void spatial_budgets(PrimRef* prims, uint32_t nUpper, Counters* ctr, float minRel) {
-  const uint32_t i = blockIdx.x * 256u + threadIdx.x, n = min(nUpper, ctr->numPrims);
-  if (blockIdx.x * 256u >= n) return;
-  if (i >= n) { if (minRel > 0.0f) (void)__syncthreads_count(0); return; }   // (the block votes below)
+__global__ __launch_bounds__(256) void spatial_budgets(PrimRef* prims, uint32_t n, const Counters* ctr) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
   const float rootArea2 = 2.0f * ctr->rootArea;
   const double sumRel = (double)ctr->areaFixed / 4294967296.0;                     // sum of the boxes' areas / scene area
   PrimRef r = load_prim(prims + i);
   const float a = 2.0f * half_area3(r.hi[0] - r.lo[0], r.hi[1] - r.lo[1], r.hi[2] - r.lo[2]);
-  int k = 1; float rel = 0.0f;                                                      // rel = this box's area / the mean box area
-  if (rootArea2 > 0.0f && sumRel > 0.0) { rel = (float)((double)n * ((double)(a / rootArea2) / sumRel)); const float nf = ceilf(10.0f * rel); k = nf > 27.0f ? 27 : (nf < 1.0f ? 1 : (int)nf); }
-  uint32_t budget = 4u + (uint32_t)(k > 27 ? 27 : k);                               // 4 + min(maxSplits - 4, max(1, nf)), maxSplits = 31
-  // MEDIUM builds (top splits): only references much larger than the average may be cut (minRel x the mean box area); every other reference goes whole
-  // into the bin of its centre (budget <= 1: SpatialBinInfo::bin2's branch for references without budget, heuristic_spatial.h:170-178).  The splits are
-  // there for the few triangles that span a set; clipping every small triangle that straddles a bin plane cost 2.4 ms of a 10.6 ms commit.
-  if (minRel > 0.0f && rel < minRel) budget = 0u;
+  int k = 1;
+  if (rootArea2 > 0.0f && sumRel > 0.0) { const float nf = ceilf((float)(10.0 * (double)n * ((double)(a / rootArea2) / sumRel))); k = nf > 27.0f ? 27 : (nf < 1.0f ? 1 : (int)nf); }
+  const uint32_t budget = 4u + (uint32_t)(k > 27 ? 27 : k);                         // 4 + min(maxSplits - 4, max(1, nf)), maxSplits = 31
   r.geom = (r.geom & GEOM_MASK) | (budget << SPLIT_SHIFT);
   store_prim(prims + i, r);
-  if (minRel > 0.0f) { const int c = __syncthreads_count(budget != 0u); if (threadIdx.x == 0u && c) atomicAdd(&ctr->numOutliers, (uint32_t)c); }
 }
 
 // ---- per level, after top_split: does the object split leave overlapping children?  (HeuristicArraySpatialSAH::find, heuristic_spatial_array.h:171-186)
-__global__ void spatial_decide(const Seg* segs, SegX* sx, const BNode* bnodes, uint32_t* sbins, const Counters* ctr, uint32_t minSize, uint32_t maxOutliers) {
+__global__ void spatial_decide(const Seg* segs, SegX* sx, const BNode* bnodes, uint32_t* sbins, const Counters* ctr, uint32_t minSize) {
   const uint32_t s = blockIdx.x, tid = threadIdx.x;
   if (s >= ctr->numSegs) return;
   const Seg* sg = segs + s; SegX* x = sx + s;
@@ -126,7 +118,7 @@ __global__ void spatial_decide(const Seg* segs, SegX* sx, const BNode* bnodes, u
   if (tid == 0u) {
     uint32_t t = 0u;
     const uint32_t ext = x->extEnd - sg->end;
-    if (ext > 0u && !(sg->flags & 1u) && sg->end - sg->begin >= minSize && ctr->numOutliers <= maxOutliers) {
+    if (ext > 0u && !(sg->flags & 1u) && sg->end - sg->begin >= minSize) {
       const BNode& P = bnodes[sg->bnode]; const BNode& L = bnodes[sg->childL]; const BNode& R = bnodes[sg->childR];
       float olo[3], ohi[3];
       for (int d = 0; d < 3; d++) { olo[d] = fmaxf(L.lo[d], R.lo[d]); ohi[d] = fminf(L.hi[d], R.hi[d]); }

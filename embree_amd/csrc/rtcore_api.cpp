@@ -493,9 +493,10 @@ void parse_config(Device* d, const char* cfg) {
     else if (k == "host_pipeline_min") d->pipelineMin = (unsigned)atol(v.c_str());
     else if (k == "host_pipeline_chunk") d->pipelineChunk = atol(v.c_str()) >= 1024 ? (unsigned)atol(v.c_str()) : 1024u;
     else if (k == "int_cost") d->build.int_cost = (float)atof(v.c_str());
-    else if (k == "top_splits") d->build.top_splits = atoi(v.c_str()) != 0 ? 1u : 0u;                 // MEDIUM builds: spatial splits in the sets of the first levels
+    else if (k == "top_splits") d->build.top_splits = atoi(v.c_str()) != 0 ? 1u : 0u;                 // MEDIUM builds: references that dwarf all others are cut into grid pieces first
     else if (k == "top_split_min") d->build.top_split_min = (uint32_t)atol(v.c_str());
     else if (k == "top_split_rel") d->build.top_split_rel = (float)atof(v.c_str());
+    else if (k == "top_split_cell") d->build.top_split_cell = (float)atof(v.c_str());
     else if (k == "trav_cost") d->build.trav_cost = (float)atof(v.c_str());
     // CPU-only keys of the reference (threads, isa, tri_accel, hugepages, ...) are accepted and ignored
   }

@@ -303,7 +303,9 @@ __device__ __forceinline__ void setup_rdir(float dx, float dy, float dz, float& 
 // the object's tree with the same loop; ring pairs are tested with the owner's CURRENT ray, so a lane changes space only after the ring has
 // passed its last pair.  The winning triangle's instance is remembered per lane (the key in best[] changed while inside) and the hit is
 // recomputed in that instance's space when the ray retires.  Tail helpers (1b) only take sub-trees that lie inside an instance.
-template <bool ANY, bool STATS, bool ROBUST, bool INST>
+// FILT: the scene has device-side filter rules (rule_accepts above).  A template parameter, not a run-time test: the rule code (a second, finishing triangle
+// test for the u/v cut-off) costs 6 - 12 VGPRs, which takes the robust kernels from 128 to 134 = from four to three waves per SIMD for every scene.
+template <bool ANY, bool STATS, bool ROBUST, bool INST, bool FILT>
 __global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceArgs a) {
   __shared__ uint2 s_stack[BLOCK / 64][QSTACK_LDS][64];
   __shared__ uint2 s_queue[BLOCK / 64][QCAP];
@@ -630,7 +632,7 @@ __global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceAr
       const float gdx = __shfl(dx, owner, 64), gdy = __shfl(dy, owner, 64), gdz = __shfl(dz, owner, 64);
       const float gtnear = __shfl(tnear, owner, 64);
       const uint32_t grmask = (uint32_t)__shfl((int)rmask, owner, 64);
-      const uint32_t ginst = (INST && a.rules) ? (uint32_t)__shfl((int)inst, owner, 64) : NO_INST;   // (rules of an instanced scene's geometries sit behind that instance's base)
+      const uint32_t ginst = (INST && FILT) ? (uint32_t)__shfl((int)inst, owner, 64) : NO_INST;   // (rules of an instanced scene's geometries sit behind that instance's base)
       if (STATS && lane == 0u) stTriBlk++;
       if (mine) {
         const float gtfar = __uint_as_float((uint32_t)(best[owner] >> 32));
@@ -643,7 +645,7 @@ __global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceAr
         bool ok = ROBUST ? tri_pluecker<false>(q0, q1, q2, gox, goy, goz, gdx, gdy, gdz, gtnear, gtfar, w)
                          : tri_moeller<false>(q0, q1, q2, gox, goy, goz, gdx, gdy, gdz, gtnear, gtfar, w);
         ok = ok && ((tmask & grmask) != 0u);                           // EMBREE_RAY_MASK, intersector_epilog.h:256-262
-        if (ok && a.rules) {                                           // device-side filter rule of the candidate's geometry: where the reference calls the filter callback
+        if (FILT && ok && a.rules) {                                   // device-side filter rule of the candidate's geometry: where the reference calls the filter callback
           uint32_t ri = __float_as_uint(q2.z);
           if (INST && ginst != NO_INST) ri += __float_as_uint(a.insts[(size_t)ginst * 4u + 3u].w) >> 8;
           ok = rule_accepts<ANY, ROBUST>(a.rules, ri, q0, q1, q2, w.t, gox, goy, goz, gdx, gdy, gdz);
@@ -954,11 +956,19 @@ static uint32_t env_u32(const char* name, uint32_t def, uint32_t lo, uint32_t hi
   const char* e = getenv(name); if (!e) return def;
   const long v = atol(e); return v < (long)lo || v > (long)hi ? def : (uint32_t)v;
 }
-template <bool INST> static TraceFn pick_kernel_i(bool any, bool stats, bool robust) {
-  if (robust) return any ? (stats ? trace_kernel_q<true, true, true, INST> : trace_kernel_q<true, false, true, INST>) : (stats ? trace_kernel_q<false, true, true, INST> : trace_kernel_q<false, false, true, INST>);
-  return any ? (stats ? trace_kernel_q<true, true, false, INST> : trace_kernel_q<true, false, false, INST>) : (stats ? trace_kernel_q<false, true, false, INST> : trace_kernel_q<false, false, false, INST>);
+template <bool INST, bool FILT> static TraceFn pick_kernel_if(bool any, bool robust) {
+  if (robust) return any ? trace_kernel_q<true, false, true, INST, FILT> : trace_kernel_q<false, false, true, INST, FILT>;
+  return any ? trace_kernel_q<true, false, false, INST, FILT> : trace_kernel_q<false, false, false, INST, FILT>;
 }
-static TraceFn pick_kernel(bool any, bool stats, bool robust, bool inst) { return inst ? pick_kernel_i<true>(any, stats, robust) : pick_kernel_i<false>(any, stats, robust); }
+template <bool INST> static TraceFn pick_stats_i(bool any, bool robust) {            // the counting build always knows the rules (it is not the measured path)
+  if (robust) return any ? trace_kernel_q<true, true, true, INST, true> : trace_kernel_q<false, true, true, INST, true>;
+  return any ? trace_kernel_q<true, true, false, INST, true> : trace_kernel_q<false, true, false, INST, true>;
+}
+static TraceFn pick_kernel(bool any, bool stats, bool robust, bool inst, bool filt) {
+  if (stats) return inst ? pick_stats_i<true>(any, robust) : pick_stats_i<false>(any, robust);
+  if (inst) return filt ? pick_kernel_if<true, true>(any, robust) : pick_kernel_if<true, false>(any, robust);
+  return filt ? pick_kernel_if<false, true>(any, robust) : pick_kernel_if<false, false>(any, robust);
+}
 // persistent grid = exactly the blocks that are resident at once (a larger grid would run a second, ragged round)
 static uint32_t resident_blocks(Bvh* b, TraceFn fn) {
   static std::mutex m; static std::map<std::pair<int, TraceFn>, uint32_t> cache;
@@ -984,7 +994,7 @@ static int launch_trace(Bvh* b, void* d_rays, uint32_t count, size_t stride, boo
   if (count == 0) return 0;
   if (stride < (any ? 48u : 96u) || (stride & 15u) || ((uintptr_t)d_rays & 15u)) return set_error(hipErrorInvalidValue, "ray array must be 16-byte aligned with a 16-byte-multiple stride");
   HIP_TRY(hipSetDevice(b->device));
-  const TraceFn fn = pick_kernel(any, statsOut != nullptr, b->robust, b->d_insts != nullptr);
+  const TraceFn fn = pick_kernel(any, statsOut != nullptr, b->robust, b->d_insts != nullptr, b->d_rules != nullptr);
   const uint32_t maxBlocks = resident_blocks(b, fn);
   uint32_t blocks = (count + BLOCK - 1) / BLOCK;
   if (blocks > maxBlocks) blocks = maxBlocks;

@@ -62,13 +62,14 @@ typedef struct mi355_build_params {
   uint32_t refit;            /* 1: keep what mi355_bvh_refit needs (8 B per triangle: the leaf order, and the level table).  default 0 */
   uint32_t presplits;        /* quality 2 only: 1 = pre-split instead of splitting inside the recursion (reference: device config "presplits=1",
                                 kernels/common/state.cpp:88,443).  default 0 */
-  uint32_t top_splits;       /* quality 0 (MEDIUM) only: 1 = sets of >= top_split_min references may split spatially like a quality-2 build (same kernels,
-                                same thresholds, embree_amd/csrc/build_spatial.inl); the rest of the tree splits by object only.  The reference's MEDIUM builder
-                                never splits spatially; hits do not depend on it; leaf records of a cut triangle exist more than once
-                                (mi355_bvh_info.num_presplit).  Off whenever params.refit is set.  default 1 */
-  uint32_t top_split_min;    /* default 65536 */
-  float    top_split_rel;    /* a top split may only cut references whose box area is at least this many times the mean box area (the others go whole to the
-                                side their centre lies on).  default 32 */
+  uint32_t top_splits;       /* quality 0 (MEDIUM) only: 1 = the few references that dwarf all others (walls, a ground plane) are cut into grid pieces before the
+                                build, on the device (embree_amd/csrc/build_presplit.inl, outlier_*): the tree is then built by object splits over a few more
+                                references.  The reference's MEDIUM builder never cuts a triangle; hits do not depend on it; leaf records of a cut triangle
+                                exist more than once (mi355_bvh_info.num_presplit).  Off whenever params.refit is set.  default 1 */
+  uint32_t top_split_min;    /* reserved */
+  float    top_split_rel;    /* an outlier's box area is at least this many times the mean box area ...  default 32 */
+  float    top_split_cell;   /* ... and it is longer than this fraction of the scene's largest extent, which is also the grid its pieces are cut on
+                                (at most 32 cells per axis; nothing is cut if the cells of all outliers exceed N / 16 + 65536).  default 1/8 */
 } mi355_build_params;
 
 typedef struct mi355_bvh_info {

@@ -27,11 +27,29 @@ ap.add_argument("--sort", default="", help="experiment: reorder the rays on the 
 ap.add_argument("--powerplant", action="store_true", help="configs[4]: the 12.7 M triangle powerplant stand-in instead of the crown stand-in")
 ap.add_argument("--primary", action="store_true")
 ap.add_argument("--tag", default="")
+ap.add_argument("--tess-room", type=int, default=0, help="experiment: the 12 room triangles of the crown stand-in replaced by K x K quads per wall (what cutting them into sphere-sized pieces would give)")
 ap.add_argument("--retrace", action="store_true", help="trace once, then time the same rays with tfar preset to the hit distance (perfect-culling bound)")
 a = ap.parse_args()
 L = api.load()
 dev = api.Device(a.config)
 meshes = W.synthetic_powerplant() if a.powerplant else W.synthetic_crown(num_phi=a.phi)
+if a.tess_room and not a.powerplant:
+    v, t = meshes[-1]
+    K = a.tess_room
+    nv, nt = [], []
+    for q in range(6):                                           # every wall = two triangles (a, b, c), (a, c, d)
+        pa, pb, pc = v[t[2 * q]]
+        pd = v[t[2 * q + 1][2]]
+        base = len(nv)
+        for j in range(K + 1):
+            for i in range(K + 1):
+                fu, fv = i / K, j / K
+                nv.append((1 - fu) * (1 - fv) * pa + fu * (1 - fv) * pb + fu * fv * pc + (1 - fu) * fv * pd)
+        for j in range(K):
+            for i in range(K):
+                p0 = base + j * (K + 1) + i
+                nt += [(p0, p0 + 1, p0 + K + 2), (p0, p0 + K + 2, p0 + K + 1)]
+    meshes = meshes[:-1] + [(np.array(nv, np.float32), np.array(nt, np.uint32))]
 s = api.Scene(dev, api.RTC_SCENE_FLAG_ROBUST if a.robust else 0, api.RTC_BUILD_QUALITY_LOW if a.low else (api.RTC_BUILD_QUALITY_HIGH if a.high else None))
 for v, t in meshes:
     s.add_triangle_mesh(v, t, device_resident=True)

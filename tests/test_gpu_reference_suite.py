@@ -509,7 +509,8 @@ def test_high_quality_presplit(api, dev, flags, form):
     # splits at all: every relative priority is below 1, primrefgen_presplit.h:301-305)
     meshes = [_sticks(300, 5), W.triangle_sphere(np.array([0.5, 0.5, 0.5], np.float32), 0.25, 80, noise=0.1, seed=2)]
     ntri = sum(t.shape[0] for _, t in meshes)
-    med = api.make_scene(dev, meshes, masks=[1, 2], flags=flags)
+    plain = api.Device("gpu=0,top_splits=0")                  # the yardstick: a MEDIUM tree that cuts nothing (by default MEDIUM cuts outlier references itself)
+    med = api.make_scene(plain, meshes, masks=[1, 2], flags=flags)
     blobs = []
     for rep in range(2):
         high = api.make_scene(dev, meshes, masks=[1, 2], flags=flags, quality=api.RTC_BUILD_QUALITY_HIGH)
@@ -539,7 +540,7 @@ def test_high_quality_presplit(api, dev, flags, form):
             print("HIGH (%s) flags=%d: %d + %d references, SAH %.2f -> %.2f, nodes/ray %.2f -> %.2f, tris/ray %.2f -> %.2f" % (form, flags, ntri, ih["num_presplit"], im["sah"], ih["sah"], sm["nodes"] / 8e4, sh["nodes"] / 8e4, sm["tris"] / 8e4, sh["tris"] / 8e4))
         high.release()
     assert blobs[0] == blobs[1]
-    med.release()
+    med.release(); plain.release()
     # the golden scenes answer the same through a HIGH-quality tree
     import os
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_cornell_4k.npz"))

@@ -10,5 +10,5 @@ R=$PWD
 python tools/kstats.py gpurun_out/${T}_prof > gpurun_out/${T}_kstats.md 2>&1
 tools/pmc_run.sh gpurun_out/${T}_pmc python $R/bench.py --steps 8 --warmup 2 --no-cpu --streams 1 --pipeline-streams 0 > gpurun_out/${T}_pmc.log 2>&1
 rm -f gpurun_out/${T}_pmc_trace.md
-python tools/pmc_summary.py gpurun_out/${T}_pmc "trace_kernel_q<false, false, false, false>" gpurun_out/${T}_pmc_trace > gpurun_out/${T}_pmc_summary.log 2>&1
+python tools/pmc_summary.py gpurun_out/${T}_pmc "trace_kernel_q<false, false, false, false, false>" gpurun_out/${T}_pmc_trace > gpurun_out/${T}_pmc_summary.log 2>&1
 tail -5 gpurun_out/${T}_pmc_summary.log
