@@ -50,7 +50,9 @@ struct Counters {
   float rootArea;                                 // half area of the scene bounds (SAH statistics are relative to it); written by root_setup
   uint32_t numOutliers;                           // MEDIUM builds: references cut up front because their box dwarfs the average one (build_presplit.inl, outlier_*)
   unsigned long long areaFixed;                   // spatial-split builds: sum of the references' box areas / scene area, 2^-32 fixed point (build_spatial.inl)
+  uint32_t compactFrom;                           // stable compaction: first position that moves (everything before the first hole stays where it is)
   uint32_t outlierCells, outlierPieces, outlierValid, outlierSkip;   // ... the places reserved for their pieces behind the references, the pieces that exist, the valid references counted, 1 = too many
+  uint32_t padC[3];
   uint32_t lvlStart[64];                          // first node of every level of the wide tree (numbering is breadth first): what a refit walks bottom-up
 };
 struct Params { uint32_t shift, minLeaf, maxLeaf, small; float travCost, intCost; uint32_t quality, spatial; };

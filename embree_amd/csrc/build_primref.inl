@@ -80,18 +80,24 @@ __global__ __launch_bounds__(256) void compact_count(const PrimRef* in, uint32_t
   if (threadIdx.x == 0) tileCount[blockIdx.x] = (uint32_t)c;
 }
 __global__ __launch_bounds__(1024) void compact_scan(uint32_t* tileCount, uint32_t numTiles, Counters* ctr, uint32_t guarded) {
-  __shared__ uint32_t s_part[1024];
+  __shared__ uint32_t s_part[1024], s_first[1024];
   if (guarded && ctr->numInvalid == 0u) return;
   const uint32_t tid = threadIdx.x, per = (numTiles + 1023u) / 1024u, b = tid * per, e = min(b + per, numTiles);
-  uint32_t sum = 0; for (uint32_t i = b; i < e; i++) sum += tileCount[i];
-  s_part[tid] = sum; __syncthreads();
-  if (tid == 0) { uint32_t run = 0; for (int i = 0; i < 1024; i++) { const uint32_t t = s_part[i]; s_part[i] = run; run += t; } ctr->numPrims = run; }
+  uint32_t sum = 0, first = 0xFFFFFFFFu;                       // first tile that is not completely valid: nothing in front of it moves
+  for (uint32_t i = b; i < e; i++) { const uint32_t c = tileCount[i]; sum += c; if (c != 256u && first == 0xFFFFFFFFu) first = i; }
+  s_part[tid] = sum; s_first[tid] = first; __syncthreads();
+  if (tid == 0) {
+    uint32_t run = 0, f = 0xFFFFFFFFu;
+    for (int i = 0; i < 1024; i++) { const uint32_t t = s_part[i]; s_part[i] = run; run += t; if (s_first[i] < f) f = s_first[i]; }
+    ctr->numPrims = run; ctr->compactFrom = f == 0xFFFFFFFFu ? run : f * 256u;
+  }
   __syncthreads();
   uint32_t run = s_part[tid]; for (uint32_t i = b; i < e; i++) { const uint32_t t = tileCount[i]; tileCount[i] = run; run += t; }
 }
 __global__ __launch_bounds__(256) void compact_scatter(const PrimRef* in, uint32_t n, const uint32_t* tileOfs, PrimRef* out, const Counters* ctr, uint32_t base) {
   __shared__ uint32_t s_w[4];
   if (ctr && ctr->numInvalid == 0u) return;
+  if (ctr && blockIdx.x * 256u < ctr->compactFrom) return;     // (tiles in front of the first hole: their references stay where they are)
   if (ctr) n = min(n, base + ctr->outlierCells);
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, p = blockIdx.x * 256u + tid;
   PrimRef r{}; bool ok = false;
@@ -106,7 +112,7 @@ __global__ __launch_bounds__(256) void compact_scatter(const PrimRef* in, uint32
 __global__ __launch_bounds__(256) void compact_copyback(const PrimRef* in, PrimRef* out, const Counters* ctr) {   // the squeezed array goes back to where the build expects it
   if (ctr->numInvalid == 0u) return;
   const uint32_t n = ctr->numPrims;
-  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) store_prim(out + i, load_prim(in + i));
+  for (uint32_t i = ctr->compactFrom + blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) store_prim(out + i, load_prim(in + i));
 }
 
 // Root of the binary tree and the first work item, made on the device from what primref_gen (and the compaction) left in the counters: the commit
