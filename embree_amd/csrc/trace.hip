@@ -365,6 +365,7 @@ __global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceAr
   uint32_t cursor = blockIdx.x % a.numCursors, dryCursors = 0;            // wave-uniform: which ray cursor this wave pulls from
   uint32_t resV = 0; bool resValid = false;                              // the block reserved ahead (lane 0 holds the atomic's result)
   float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0, rdx = 0, rdy = 0, rdz = 0, tnear = 0, tnearTrav = 0, tfar = 0;
+  float tfar0 = 0;                                                       // the ray's OWN tfar (tfar follows the best hit): what a triangle candidate is tested against, see step 4
   float rfx = 0, rfy = 0, rfz = 0;                                       // ROBUST: rdir_far (rdx.. hold rdir_near)
   uint32_t inst = NO_INST, topSp = 0, bestInst = NO_INST, entryLo = 0, entryHi = 0;   // INST: instance the lane is in, stack depth at entry, instance of the best hit, best[] key at entry
   uint32_t stNodes = 0, stTris = 0, stRays = 0, stSpill = 0, stDepth = 0, stIter = 0, stNodeBlk = 0, stTriBlk = 0;
@@ -458,7 +459,7 @@ __global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceAr
             rayIdx = newIdx;
             ox = r0.x; oy = r0.y; oz = r0.z; tnear = r0.w;
             dx = r1.x; dy = r1.y; dz = r1.z;
-            tfar = r2.x; rmask = __float_as_uint(r2.y);
+            tfar = r2.x; tfar0 = r2.x; rmask = __float_as_uint(r2.y);
             setup_rdir<ROBUST>(dx, dy, dz, rdx, rdy, rdz, rfx, rfy, rfz, octinv4);
             tnearTrav = fmaxf(tnear, 0.0f);                               // tnear/tfar clamped to >= 0 for traversal (bvh_intersector1.cpp:65)
             if (INST) { inst = NO_INST; bestInst = NO_INST; }
@@ -632,18 +633,22 @@ __global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceAr
       const float gdx = __shfl(dx, owner, 64), gdy = __shfl(dy, owner, 64), gdz = __shfl(dz, owner, 64);
       const float gtnear = __shfl(tnear, owner, 64);
       const uint32_t grmask = (uint32_t)__shfl((int)rmask, owner, 64);
+      // A candidate is tested against the ray's OWN far limit, not against the best hit so far: the reference's form of the test, T <= absDen * tfar, is not
+      // monotone in the rounded t = T * rcp(absDen), so with the current best as tfar a second triangle at exactly the same t (a shared edge hit exactly) was
+      // accepted or not depending on which of the two was tested first -- one ray in 2^20 changed its primID between launches.  Every candidate in front of
+      // the ray's own limit now reaches the atomic-min, which takes the minimum of (t bits, triangle index): the answer no longer depends on the order.
+      const float gtfar0 = __shfl(tfar0, owner, 64);
       const uint32_t ginst = (INST && FILT) ? (uint32_t)__shfl((int)inst, owner, 64) : NO_INST;   // (rules of an instanced scene's geometries sit behind that instance's base)
       if (STATS && lane == 0u) stTriBlk++;
       if (mine) {
-        const float gtfar = __uint_as_float((uint32_t)(best[owner] >> 32));
         float4 q0, q1, q2;
         if (usePre) { q0 = pq0; q1 = pq1; q2 = pq2; }
         else { const float4* tp = a.tris + (size_t)e.x * 3u; q0 = tp[0]; q1 = tp[1]; q2 = tp[2]; }
         if (STATS) stTris++;
         const uint32_t tmask = __float_as_uint(q2.w);
         TriOut w;
-        bool ok = ROBUST ? tri_pluecker<false>(q0, q1, q2, gox, goy, goz, gdx, gdy, gdz, gtnear, gtfar, w)
-                         : tri_moeller<false>(q0, q1, q2, gox, goy, goz, gdx, gdy, gdz, gtnear, gtfar, w);
+        bool ok = ROBUST ? tri_pluecker<false>(q0, q1, q2, gox, goy, goz, gdx, gdy, gdz, gtnear, gtfar0, w)
+                         : tri_moeller<false>(q0, q1, q2, gox, goy, goz, gdx, gdy, gdz, gtnear, gtfar0, w);
         ok = ok && ((tmask & grmask) != 0u);                           // EMBREE_RAY_MASK, intersector_epilog.h:256-262
         if (FILT && ok && a.rules) {                                   // device-side filter rule of the candidate's geometry: where the reference calls the filter callback
           uint32_t ri = __float_as_uint(q2.z);
@@ -772,6 +777,7 @@ __global__ __launch_bounds__(64) void trace_packet_kernel(PacketTraceArgs a) {
     setup_rdir<ROBUST>(dx, dy, dz, rdx, rdy, rdz, rfx, rfy, rfz, octinv4);
     const float tnearTrav = fmaxf(tnear, 0.0f);
     float bestT = r2.x; uint32_t bestTri = MI355_EMPTY_REF;
+    const float tfar0 = r2.x;                                    // candidates are tested against the ray's own limit (see trace_kernel_q, step 4)
     bool alive = valid && a.hasRoot != 0u && !(ANY && bestT < 0.0f);
     unsigned long long am = __ballot(alive);
     if (am == 0ull) continue;
@@ -866,8 +872,8 @@ __global__ __launch_bounds__(64) void trace_packet_kernel(PacketTraceArgs a) {
           const uint32_t ti = (uint32_t)__builtin_amdgcn_readlane((int)myTri, (int)t), sl = (uint32_t)__builtin_amdgcn_readlane((int)mySlot, (int)t);
           if (((hitBits >> sl) & 1u) != 0u && (!ANY || alive)) {
             TriOut w;
-            bool ok = ROBUST ? tri_pluecker<false>(u0, u1, u2, ox, oy, oz, dx, dy, dz, tnear, bestT, w)
-                             : tri_moeller<false>(u0, u1, u2, ox, oy, oz, dx, dy, dz, tnear, bestT, w);
+            bool ok = ROBUST ? tri_pluecker<false>(u0, u1, u2, ox, oy, oz, dx, dy, dz, tnear, tfar0, w)
+                             : tri_moeller<false>(u0, u1, u2, ox, oy, oz, dx, dy, dz, tnear, tfar0, w);
             ok = ok && ((__float_as_uint(u2.w) & rmask) != 0u);
             if (ok && a.rules) ok = rule_accepts<ANY, ROBUST>(a.rules, __float_as_uint(u2.z), u0, u1, u2, w.t, ox, oy, oz, dx, dy, dz);
             if (ok) {
