@@ -427,8 +427,9 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
     WideItem* t = wc; wc = wn; wn = t; wlevel++;
   };
   if (fast) {
-    // the depth of the wide tree is unknown here: 24 levels cover every scene measured so far (crown 12, powerplant 14); a deeper tree is finished below
-    for (uint32_t i = 0; i < 24u; i++) enqueue_wide_level();
+    // the depth of the wide tree is unknown here: 18 levels cover every scene measured so far (crown 12, powerplant 14); a deeper tree is finished below
+    // (every level enqueued beyond the last one costs three empty launches, ~13 us)
+    for (uint32_t i = 0; i < 18u; i++) enqueue_wide_level();
     if (capturing) {                                             // end of the captured sequence: instantiate, keep, run
       hipGraph_t graph = nullptr;
       const hipError_t e = hipStreamEndCapture(st, &graph);

@@ -432,7 +432,11 @@ __global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceAr
           bool got = false; uint32_t newIdx = 0; float4 r0 = make_float4(0, 0, 0, 0), r1 = r0, r2 = r0;
           if (canGrab) {
             while (!exhausted) {
-              if (!resValid) { if (lane == 0u) resV = atomicAdd(a.counter + cursor * CURSOR_STRIDE, 1u); resValid = true; }
+              // A wave without a reserved block (launch start: all 64 lanes free) takes as many blocks as it has room for with ONE atomic: 4096 waves asking
+              // for four blocks one after the other is 16384 atomics on eight words, ~20 us in which nobody traverses.  Blocks v, v + 1, ... of a cursor are
+              // not neighbours in the ray array (cursors interleave), which is as good as any other order.
+              uint32_t take = 1u;
+              if (!resValid) { take = max(1u, (uint32_t)__popcll(freeLanes) / G); if (lane == 0u) resV = atomicAdd(a.counter + cursor * CURSOR_STRIDE, take); resValid = true; }
               const uint32_t base = __builtin_amdgcn_readfirstlane(resV);
               const unsigned long long firstRay = ((unsigned long long)base * a.numCursors + cursor) * G;
               resValid = false;
@@ -442,9 +446,10 @@ __global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceAr
                 continue;
               }
               const uint32_t rank = (uint32_t)__popcll(freeLanes & ((1ull << lane) - 1ull));
-              got = ((freeLanes >> lane) & 1ull) != 0ull && rank < G && firstRay + rank < rayCount;
-              if (got && a.deferList) { const uint32_t q = (uint32_t)firstRay + rank; newIdx = a.deferList[q >> 6] * 64u + (q & 63u); got = newIdx < a.count; }   // (the last packet of a batch may be ragged)
-              else if (got) newIdx = (uint32_t)firstRay + rank;
+              const unsigned long long myRay = (((unsigned long long)base + rank / G) * a.numCursors + cursor) * G + rank % G;   // block rank / G of this grab, ray rank % G of it
+              got = ((freeLanes >> lane) & 1ull) != 0ull && rank < take * G && myRay < rayCount;
+              if (got && a.deferList) { const uint32_t q = (uint32_t)myRay; newIdx = a.deferList[q >> 6] * 64u + (q & 63u); got = newIdx < a.count; }   // (the last packet of a batch may be ragged)
+              else if (got) newIdx = (uint32_t)myRay;
               if (got) {
                 const float4* rp = (const float4*)(a.rays + (size_t)newIdx * a.stride);
                 r0 = rp[0]; r1 = rp[1]; r2 = rp[2];

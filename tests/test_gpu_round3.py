@@ -42,6 +42,13 @@ def dev(api):
 
 
 @pytest.fixture(scope="module")
+def restate():
+    from oracle import restate as R
+    assert R.available(), "oracle/librestate.so missing (make -C oracle)"
+    return R
+
+
+@pytest.fixture(scope="module")
 def ref():
     from oracle import refembree
     if not refembree.available():
@@ -436,3 +443,31 @@ def test_device_filter_rule_kinds_and_instances(api, dev):
     assert closer.sum() > 100 and (np.abs(a["tfar"][closer] - b["tfar"][closer]) <= 1e-4 * np.abs(b["tfar"][closer]) + 1e-6).mean() > 0.95
     for x in (top, obj, s, s2):
         x.release()
+
+
+def test_deep_tree_beyond_the_enqueued_levels(api, dev, restate):
+    """The one-round-trip commit enqueues 18 levels of the wide collapse; a tree that is deeper is finished level by level afterwards and its leaf records are
+    written again.  Triangles whose size and position double from one to the next make every SAH split peel one triangle off: a tree as deep as it gets."""
+    n = 460                                                   # sizes up to 2^57.5: inside the reference's validity limit of 1.844e18
+    vs, ts = [], []
+    for i in range(n):
+        s_ = np.float32(2.0) ** np.float32(i * 0.125)
+        x = np.float32(3.0) * s_
+        y = np.float32(2 * (i % 8)) * s_                             # neighbours in x do not overlap: no coplanar ties
+        vs += [[x, y, 0], [x + s_, y, 0], [x, y + s_, 0]]
+        ts.append([3 * i, 3 * i + 1, 3 * i + 2])
+    meshes = [(np.array(vs, np.float32), np.array(ts, np.uint32))]
+    s = api.make_scene(dev, meshes)
+    info = s.info()
+    nodes, tris = s.download_bvh()
+    bvh_check.validate(nodes, tris, info["root_ref"], meshes, max_leaf=info["max_leaf"])
+    assert info["depth"] > 18, info["depth"]
+    o = restate.OracleScene()
+    o.add_mesh(*meshes[0]); o.commit()
+    c = np.array(vs, np.float32).reshape(n, 3, 3).mean(1)
+    rays = make_rayhits(c + np.float32([0, 0, 1]), np.tile(np.float32([0, 0, -1]), (n, 1)))
+    want, got = rays.copy(), rays.copy()
+    o.intersect1(want); s.intersect1M(got)
+    st = compare_closest(got, want, rays, o.triangle_t, label="deep tree")
+    assert st["hits"] > n // 2                               # (at coordinates of 1e17 some centre rays miss in fp32: the reference misses the same ones)
+    s.release()
