@@ -75,7 +75,23 @@ struct Arena {
     if (e != hipSuccess) return e;
     blocks.push_back(nb); *out = nb.p; return hipSuccess;
   }
+  // Tree buffers (CNode / TriRec arrays) of destroyed trees are kept for the next commit of a similar size: a scene that is re-committed every frame would
+  // otherwise pay a hipFree + hipMalloc of ~300 MB per commit, and every second or third of those takes the driver 8 ms (commit 7.6 -> 16 ms, measured).
+  struct Spare { void* p; size_t cap; };
+  std::vector<Spare> spares;                                 // at most 4
+  void* take_output(size_t bytes, size_t* cap) {
+    for (size_t i = 0; i < spares.size(); i++)
+      if (spares[i].cap >= bytes && spares[i].cap <= bytes + bytes / 2 + 4096) { void* p = spares[i].p; *cap = spares[i].cap; spares.erase(spares.begin() + i); return p; }
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); for (auto& sp : spares) hipFree(sp.p); spares.clear(); if (hipMalloc(&p, bytes) != hipSuccess) return nullptr; }
+    *cap = bytes; return p;
+  }
+  void give_output(void* p, size_t cap) {
+    if (spares.size() >= 4) { hipFree(spares.front().p); spares.erase(spares.begin()); }
+    spares.push_back({p, cap});
+  }
   void release() { drop_graph(); if (stream) { hipStreamDestroy(stream); stream = nullptr; } for (auto& b : blocks) hipFree(b.p); blocks.clear(); }
+  void release_spares() { for (auto& sp : spares) hipFree(sp.p); spares.clear(); }
 };
 static std::mutex g_arenaMtx;
 static std::map<int, Arena*> g_arenas;
@@ -86,6 +102,21 @@ static Arena* arena_of(int device) {
   return a;
 }
 static thread_local Arena* t_arena = nullptr;
+// tree buffers go through the arena's spare list (its own lock: trees are destroyed from any thread, also while a commit holds the arena)
+static std::mutex g_spareMtx;
+static void* output_alloc(int device, size_t bytes, size_t* cap) {
+  std::lock_guard<std::mutex> lk(g_spareMtx);
+  void* p = arena_of(device)->take_output(bytes, cap);
+  if (getenv("MI355_BUILD_DEBUG")) fprintf(stderr, "[mi355 build] output_alloc %zu -> %p cap %zu\n", bytes, p, *cap);
+  return p;
+}
+static void output_free(int device, void* p, size_t cap) {
+  if (!p) return;
+  hipDeviceSynchronize();                                    // (what hipFree would have waited for: nothing may still read the tree)
+  std::lock_guard<std::mutex> lk(g_spareMtx);
+  if (getenv("MI355_BUILD_DEBUG")) fprintf(stderr, "[mi355 build] output_free %p cap %zu\n", p, cap);
+  arena_of(device)->give_output(p, cap);
+}
 
 template <typename T> struct DevBuf {
   T* p = nullptr;
@@ -121,8 +152,8 @@ TraceScratch* Bvh::scratch_for(hipStream_t s) {
 Bvh::~Bvh() {
   hipSetDevice(device);
   for (auto& kv : scratch) { hipFree(kv.second.counter); hipFree(kv.second.spill); hipFree(kv.second.stats); if (kv.second.pkt) hipFree(kv.second.pkt); if (kv.second.defer) hipFree(kv.second.defer); hipHostFree((void*)kv.second.statusHost); delete kv.second.enqueue; }
-  if (d_nodes) hipFree(d_nodes);
-  if (d_tris) hipFree(d_tris);
+  if (d_nodes) { if (nodesCap) output_free(device, d_nodes, nodesCap); else hipFree(d_nodes); }
+  if (d_tris) { if (trisCap) output_free(device, d_tris, trisCap); else hipFree(d_tris); }
   if (d_ids) hipFree(d_ids);
   if (d_insts) hipFree(d_insts);
   if (d_rules) hipFree(d_rules);
@@ -190,7 +221,9 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
   const bool useGraph = fast && envGraph && st != nullptr && !arena->graphBroken;
   uint32_t launches = 0, syncs = 0;
   bool replay = false, capturing = false;                       // fast path: the launches below are replayed from the cached graph / are being captured into one
-#define LAUNCH(...) do { if (!replay) hipLaunchKernelGGL(__VA_ARGS__); launches++; } while (0)
+  // MI355_BUILD_DEBUG=1: every launch is named on stderr and waited for (finds the kernel behind a device fault; use with MI355_BUILD_GRAPH=0)
+  static const bool envDebug = getenv("MI355_BUILD_DEBUG") != nullptr;
+#define LAUNCH(...) do { if (!replay) { hipLaunchKernelGGL(__VA_ARGS__); if (envDebug && !capturing) { fprintf(stderr, "[mi355 build] %s\n", #__VA_ARGS__); const hipError_t de_ = hipStreamSynchronize(st); if (de_ != hipSuccess) fprintf(stderr, "[mi355 build]   -> %s\n", hipGetErrorString(de_)); } } launches++; } while (0)
 #define SYNC_READ(h) do { HIP_TRY(hipGetLastError()); HIP_TRY(hipMemcpyAsync(&(h), ctr.p, sizeof(h), hipMemcpyDeviceToHost, st)); HIP_TRY(hipStreamSynchronize(st)); syncs++; } while (0)
 
   DevBuf<GeomDesc> dGeoms; HIP_TRY(dGeoms.alloc(gd.size()));
@@ -442,7 +475,8 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
     }
     if (replay) { HIP_TRY(hipEventRecord(ev0, st)); HIP_TRY(hipGraphLaunch(arena->graphExec, st)); replay = false; }
     // the leaf records can be written as soon as the leaf order is known; their array is sized by the upper bound N
-    HIP_TRY(hipMalloc(&bvh->d_tris, (size_t)NC * sizeof(TriRec) + 128));
+    bvh->d_tris = output_alloc(device, (size_t)NC * sizeof(TriRec) + 128, &bvh->trisCap);
+    if (!bvh->d_tris) return set_error(hipErrorOutOfMemory, "leaf record array");
     LAUNCH(tri_records, dim3((NC + 255u) / 256u), dim3(256), 0, st, outIds.p, NC, dGeoms.p, (TriRec*)bvh->d_tris, bp->robust ? 1u : 0u, (const Counters*)ctr.p);
     SYNC_READ(h);                                                // the ONE round trip of the commit
     if (h.overflow) return set_error(hipErrorOutOfMemory, "work list overflow (pathological input)");
@@ -452,7 +486,7 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
     }
     n = h.numPrims;
     info.num_presplit = h.outlierPieces > h.numOutliers ? h.outlierPieces - h.numOutliers : 0u;   // leaf records beyond one per triangle: the pieces of the cut outliers
-    if (n == 0) { hipFree(bvh->d_tris); bvh->d_tris = nullptr; info.num_launches = launches; info.num_host_syncs = syncs; guard.ok = true; *out = bvh; return 0; }
+    if (n == 0) { output_free(device, bvh->d_tris, bvh->trisCap); bvh->d_tris = nullptr; bvh->trisCap = 0; info.num_launches = launches; info.num_host_syncs = syncs; guard.ok = true; *out = bvh; return 0; }
     for (int d = 0; d < 3; d++) { info.bounds_lower[d] = decf(h.bounds[d]); info.bounds_upper[d] = decf(h.bounds[3 + d]); }
     info.top_levels = h.topLevels;
     bool redoLeaves = false;
@@ -472,7 +506,8 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
       for (uint32_t i = 0; i < 4u; i++) enqueue_wide_level();
     }
     if (spatial) { info.num_presplit = h.numTrisOut > n ? h.numTrisOut - n : 0u; n = h.numTrisOut; }   // the references the splits created are leaf entries like any other
-    HIP_TRY(hipMalloc(&bvh->d_tris, (size_t)n * sizeof(TriRec) + 128));
+    bvh->d_tris = output_alloc(device, (size_t)n * sizeof(TriRec) + 128, &bvh->trisCap);
+    if (!bvh->d_tris) return set_error(hipErrorOutOfMemory, "leaf record array");
     LAUNCH(tri_records, dim3((n + 255u) / 256u), dim3(256), 0, st, outIds.p, n, dGeoms.p, (TriRec*)bvh->d_tris, bp->robust ? 1u : 0u, (const Counters*)nullptr);
   }
   info.num_triangles = n;
@@ -481,7 +516,8 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
   // ---- final node array (exact size)
   const uint32_t numNodes = h.numWide;
   if (numNodes) {
-    HIP_TRY(hipMalloc(&bvh->d_nodes, (size_t)numNodes * sizeof(CNode)));
+    bvh->d_nodes = output_alloc(device, (size_t)numNodes * sizeof(CNode), &bvh->nodesCap);
+    if (!bvh->d_nodes) return set_error(hipErrorOutOfMemory, "node array");
     HIP_TRY(hipMemcpyAsync(bvh->d_nodes, wnodes.p, (size_t)numNodes * sizeof(CNode), hipMemcpyDeviceToDevice, st));
   }
   bvh->robust = bp->robust != 0;
@@ -737,6 +773,7 @@ void mi355_release_build_scratch(int device) {
   Arena* a = arena_of(device);
   std::lock_guard<std::mutex> lk(a->mtx);
   hipSetDevice(device); a->release();
+  std::lock_guard<std::mutex> lk2(g_spareMtx); a->release_spares();
 }
 int mi355_bvh_set_filter_rules(mi355_bvh_t bvh, const uint32_t* words, size_t num_words, uint32_t num_geoms) {
   mi355::Bvh* b = (mi355::Bvh*)bvh; if (!b) return mi355::set_error(hipErrorInvalidValue, "mi355_bvh_set_filter_rules: no tree");

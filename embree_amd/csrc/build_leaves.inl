@@ -3,7 +3,10 @@
 // --------------------------------------------------------------------------------- K5 tri_records
 __global__ __launch_bounds__(256) void tri_records(const uint2* finalIds, uint32_t n, const GeomDesc* geoms, TriRec* out, uint32_t robust, const Counters* ctr) {
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-  if (i >= (ctr ? max(ctr->numPrims, ctr->numTrisOut) : n)) return;   // ctr: the grid is an upper bound, the number of leaf records is on the device (numTrisOut: what the wide collapse numbered; > numPrims after spatial splits)
+  // ctr: the grid is an upper bound, the number of leaf records is on the device: what the wide collapse has numbered so far.  Of a tree deeper than the levels
+  // enqueued with this launch that is a part only -- the ids behind it are whatever the arena held (a device fault, found when tree buffers began to be
+  // recycled); the host runs the remaining levels and launches this kernel again
+  if (i >= (ctr ? ctr->numTrisOut : n)) return;
   uint2 id = finalIds[i];
   const GeomDesc g = geoms[id.x];
   uint32_t i0, i1, i2, pid;

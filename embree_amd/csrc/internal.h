@@ -33,6 +33,7 @@ struct Bvh {
   int numCUs = 256;
   void* d_nodes = nullptr;       // CNode[numNodes]
   void* d_tris = nullptr;        // TriRec[numTris]
+  size_t nodesCap = 0, trisCap = 0;   // capacities of the two arrays when they came from the build arena's spare list (0: plain hipMalloc)
   uint32_t root = 0xFFFFFFFFu;
   void* d_insts = nullptr;       // scenes with instances: InstRec[] (64 B: world2local | root node, instID, mask, flags); d_nodes / d_tris = top tree + the objects' trees
   void* d_rules = nullptr;       // device-side filter rules: 48 B per geometry id (instanced scenes: the own geometries', then every object's behind its base) + bit arrays
