@@ -432,7 +432,8 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
 
   // ---- small phase
   const uint32_t microW = prm.minLeaf >= 2u ? 32u : 48u;       // LDS words per triangle of the micro mode (see micro_subtree)
-  const size_t smallLds = sizeof(uint32_t) * (64u * microW > (uint32_t)BINS_WORDS ? 64u * microW : (uint32_t)BINS_WORDS);
+  static const size_t smallLdsPad = getenv("MI355_SMALL_LDS_PAD") ? (size_t)atol(getenv("MI355_SMALL_LDS_PAD")) : 0u;   // A/B: fewer workgroups per CU
+  const size_t smallLds = sizeof(uint32_t) * (64u * microW > (uint32_t)BINS_WORDS ? 64u * microW : (uint32_t)BINS_WORDS) + smallLdsPad;
   if (fast) {
     // every small entry covers > small / 2^k ... triangles: at most one entry per top-phase leaf; the list cannot be longer than maxSmall (top_emit raises overflow)
     const uint32_t bound = N > prm.small ? maxSmall : 1u;
@@ -511,6 +512,9 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
     LAUNCH(tri_records, dim3((n + 255u) / 256u), dim3(256), 0, st, outIds.p, n, dGeoms.p, (TriRec*)bvh->d_tris, bp->robust ? 1u : 0u, (const Counters*)nullptr);
   }
   info.num_triangles = n;
+#ifdef SM_STATS
+  fprintf(stderr, "[mi355 build] micro level passes %u, lanes in use %.1f of 64, passes with a set of >= 20: %u\n", h.padC[0], h.padC[0] ? (double)h.padC[1] / h.padC[0] : 0.0, h.padC[2]);
+#endif
   const uint32_t depth = h.wideDepth;
 
   // ---- final node array (exact size)

@@ -194,6 +194,11 @@ __device__ __forceinline__ void bins_add_rows(uint32_t* bins, const Mapping& m, 
   }
 }
 
+// v_min_f32 / v_max_f32 as they are: fminf / fmaxf of values that come out of a bit cast are preceded by a canonicalising v_max x, x each (294 of the
+// kernel's 3100 VALU instructions); a quiet NaN operand loses against a number either way, which lets empty bins decode to NaN and drop out
+__device__ __forceinline__ float vmin(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float vmax(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
 struct SplitResult { float sah; int dim, pos; uint32_t nL; float llo[3], lhi[3], rlo[3], rhi[3]; };
 
 // BinInfoT::best (heuristic_binning.h:339-386) by ONE wavefront as two scans: lanes 0-31 hold the 32 bins of one axis, lanes
@@ -222,8 +227,8 @@ __device__ void sah_best_wave(const uint32_t* bins, const Mapping& m, uint32_t s
       const uint32_t un = (uint32_t)__shfl_up((int)pn, o, 32), dn = (uint32_t)__shfl_down((int)sn, o, 32);
       float ul[3], uh[3], dl[3], dh[3];
       for (int d = 0; d < 3; d++) { ul[d] = __shfl_up(plo[d], o, 32); uh[d] = __shfl_up(phi[d], o, 32); dl[d] = __shfl_down(slo[d], o, 32); dh[d] = __shfl_down(shi[d], o, 32); }
-      if (b >= (uint32_t)o) { pn += un; for (int d = 0; d < 3; d++) { plo[d] = fminf(plo[d], ul[d]); phi[d] = fmaxf(phi[d], uh[d]); } }
-      if (b + (uint32_t)o < 32u) { sn += dn; for (int d = 0; d < 3; d++) { slo[d] = fminf(slo[d], dl[d]); shi[d] = fmaxf(shi[d], dh[d]); } }
+      if (b >= (uint32_t)o) { pn += un; for (int d = 0; d < 3; d++) { plo[d] = vmin(plo[d], ul[d]); phi[d] = vmax(phi[d], uh[d]); } }
+      if (b + (uint32_t)o < 32u) { sn += dn; for (int d = 0; d < 3; d++) { slo[d] = vmin(slo[d], dl[d]); shi[d] = vmax(shi[d], dh[d]); } }
     }
     // candidate pos = b: left = prefix of lane b-1, right = my suffix
     const uint32_t lN = (uint32_t)__shfl_up((int)pn, 1, 32);

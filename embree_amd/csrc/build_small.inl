@@ -21,37 +21,69 @@ __device__ __forceinline__ float unzlo(uint32_t u) { return dec(~u); }
 __device__ __forceinline__ uint32_t zhi(float f) { return enc(f); }           // enc(x) > 0 for every float
 __device__ __forceinline__ float unzhi(uint32_t u) { return dec(u); }
 
+// A sub-tree root of <= MICRO triangles, parked by the large mode until the wave has finished its larger sets
+struct MicroRoot { uint32_t begin, nbuf, bnode; float cmin[3], cmax[3]; };   // nbuf = n | buf << 8
+constexpr uint32_t MICRO_ROOTS = 32;                              // (a set of <= 1024 triangles leaves at most 31 of them)
+
 // R: per-wave LDS scratch of 64 * W words (W = 32 words per triangle when min_leaf >= 2, 48 for min_leaf = 1):
 //   bins of the segment starting at lane b live at R + b * W as [axis][bin][8] (3 * nb * 8 <= n * W words for every
 //   splittable n); once the candidates are evaluated the same memory holds the split records (16 words per segment at
-//   R + b * 16) and the exchange buffer the partition moves the triangles through (10 x 64 words at R + 1024).
-__device__ void micro_subtree(uint32_t* R, uint32_t W, uint32_t (*s_cb)[64][6], unsigned long long* s_key, const PrimRef* src,
-                              uint32_t gbegin, uint32_t n0, uint32_t rootNode, const float* cmin0, const float* cmax0,
-                              BNode* bnodes, uint2* finalIds, Counters* ctr, const Params& prm, uint32_t lane) {
+//   R + b * 8: a segment that is split has two lanes at least), the exchange buffer the partition moves the triangles through
+//   (11 x 64 words at R + 512) and the centroid bounds of the NEXT level's segments (6 words per segment at CB + b * 6,
+//   CB = R + 1664: cleared once the bins are dead, filled by the partition, read at the top of the next level before the
+//   bins are cleared again).
+// The wave works on SEVERAL sub-trees at a time: the lanes [0, nAct) hold the triangles of all segments that still split,
+// segment after segment; a segment that has become a leaf writes its ids and leaves (the partition squeezes its lanes out),
+// and whenever a parked root fits into the free lanes it is taken in.  One sub-tree at a time left 58 % of the lanes of a
+// level pass idle (profiles/r01_build_history.md: 26.9 of 64 lanes on average over the 6.5 levels of a 43-triangle root).
+__device__ void micro_flush(uint32_t* R, uint32_t W, unsigned long long* s_key, const MicroRoot* roots, uint32_t numRoots,
+                            const PrimRef* bufA, const PrimRef* bufB, BNode* bnodes, uint2* finalIds, Counters* ctr, const Params& prm, uint32_t lane) {
   PrimRef p{};
-  if (lane < n0) p = load_prim(src + gbegin + lane);
-  uint32_t segB = 0, segE = n0, node = rootNode;
-  bool act = lane < n0 && n0 > prm.minLeaf;
-  if (lane == 0u) for (int d = 0; d < 3; d++) { s_cb[0][0][d] = zlo(cmin0[d]); s_cb[0][0][3 + d] = zhi(cmax0[d]); }
-  __syncthreads();
+  uint32_t segB = 0, segE = 0, node = 0, gsb = 0;                 // my segment: lanes [segB, segE), binary node, where it begins in the id array
+  uint32_t nAct = 0, leaves = 0;                                  // (uniform)
+  uint32_t pending = numRoots >= 32u ? 0xFFFFFFFFu : (1u << numRoots) - 1u;
+  const uint32_t myRootN = lane < numRoots ? (roots[lane].nbuf & 0xFFu) : 0xFFFFu;
+  uint32_t* const CB = R + 1664u;
   const uint32_t addBlk = (1u << prm.shift) - 1u;
-  uint32_t pp = 0;
-  for (uint32_t level = 0; level < 64u; level++) {
-    if (__ballot(act) == 0ull) break;
-    // ---- L0: bin mapping of my segment (BinMapping, heuristic_binning.h:46-55); clear bins, keys, next level's centroid bounds
+  for (;;) {
+    // ---- take in parked roots while one fits (first fit)
+    while (pending) {
+      const unsigned long long fm = __ballot(((pending >> (lane & 31u)) & 1u) != 0u && lane < 32u && myRootN <= 64u - nAct);
+      if (fm == 0ull) break;
+      const uint32_t k = (uint32_t)__builtin_amdgcn_readfirstlane((int)__builtin_ctzll(fm));
+      pending &= ~(1u << k);
+      const MicroRoot r = roots[k];
+      const uint32_t n = r.nbuf & 0xFFu;
+      const PrimRef* src = (r.nbuf >> 8) ? bufB : bufA;
+      if (n <= prm.minLeaf) {                                     // a leaf as it is (the reference never splits sets of <= minLeafSize, bvh_builder_sah.h:253)
+        if (lane < n) { const PrimRef q = load_prim(src + r.begin + lane); finalIds[r.begin + lane] = make_uint2(q.geom & 0x07FFFFFFu, q.prim); }
+        if (lane == 0u) ((uint4*)(bnodes + r.bnode))[2] = make_uint4(NIL, NIL, __float_as_uint(__builtin_inff()), 0u);
+        leaves++;
+        continue;
+      }
+      if (lane >= nAct && lane < nAct + n) { p = load_prim(src + r.begin + (lane - nAct)); segB = nAct; segE = nAct + n; node = r.bnode; gsb = r.begin; }
+      if (lane == nAct) for (int d = 0; d < 3; d++) { CB[nAct * 6u + d] = zlo(r.cmin[d]); CB[nAct * 6u + 3 + d] = zhi(r.cmax[d]); }
+      nAct += n;
+    }
+    if (nAct == 0u) break;
+    const bool act = lane < nAct;                                 // every lane below nAct sits in a segment that splits
+#ifdef SM_STATS
+    if (lane == 0u) { atomicAdd(&ctr->padC[0], 1u); atomicAdd(&ctr->padC[1], nAct); }
+#endif
+    __syncthreads();                                             // (the new roots' centroid bounds)
+    // ---- L0: bin mapping of my segment (BinMapping, heuristic_binning.h:46-55); clear bins and keys
     const uint32_t n = segE - segB;
     float ofs[3] = {0, 0, 0}, scale[3] = {0, 0, 0}; uint32_t nb = 4;
     if (act) {
       float cmin[3], cmax[3];
-      for (int d = 0; d < 3; d++) { cmin[d] = unzlo(s_cb[pp][segB][d]); cmax[d] = unzhi(s_cb[pp][segB][3 + d]); }
+      for (int d = 0; d < 3; d++) { cmin[d] = unzlo(CB[segB * 6u + d]); cmax[d] = unzhi(CB[segB * 6u + 3 + d]); }
       const Mapping m = make_mapping(n, cmin, cmax);
       for (int d = 0; d < 3; d++) { ofs[d] = m.ofs[d]; scale[d] = m.scale[d]; }
       nb = m.nb;
     }
-    __syncthreads();                                             // everybody has read s_cb[pp] and is done with the exchange buffer
+    __syncthreads();                                             // everybody has read the centroid bounds and is done with the exchange buffer
     for (uint32_t i = 0; i < W / 4u; i++) ((uint4*)R)[i * 64u + lane] = make_uint4(0u, 0u, 0u, 0u);
     s_key[lane] = ~0ull;
-    for (int k = 0; k < 6; k++) s_cb[pp ^ 1u][lane][k] = 0u;
     __syncthreads();
     // ---- L1: bin (BinInfoT::bin, heuristic_binning.h:210-257)
     uint32_t* const sb = R + segB * W;
@@ -75,19 +107,18 @@ __device__ void micro_subtree(uint32_t* R, uint32_t W, uint32_t (*s_cb)[64][6], 
       for (uint32_t axis = lane - segB; axis < 3u; axis += n) {
         if (sel3(axis, scale[0], scale[1], scale[2]) == 0.0f) continue;          // mapping.invalid(dim) :375
         const uint4* e = (const uint4*)(sb + axis * 32u);
-        float lo[4][3], hi[4][3]; uint32_t cn[4];
+        float lo[4][3], hi[4][3]; uint32_t cn[4];                             // (an empty bin holds zeros: they decode to quiet NaNs, which vmin / vmax drop)
 #pragma unroll
         for (int b = 0; b < 4; b++) {
           const uint4 x = e[2 * b], y = e[2 * b + 1];
           cn[b] = y.z;
-          const bool any = cn[b] != 0u;
-          lo[b][0] = any ? unzlo(x.x) : __builtin_inff(); lo[b][1] = any ? unzlo(x.y) : __builtin_inff(); lo[b][2] = any ? unzlo(x.z) : __builtin_inff();
-          hi[b][0] = any ? unzhi(x.w) : -__builtin_inff(); hi[b][1] = any ? unzhi(y.x) : -__builtin_inff(); hi[b][2] = any ? unzhi(y.y) : -__builtin_inff();
+          lo[b][0] = unzlo(x.x); lo[b][1] = unzlo(x.y); lo[b][2] = unzlo(x.z);
+          hi[b][0] = unzhi(x.w); hi[b][1] = unzhi(y.x); hi[b][2] = unzhi(y.y);
         }
         float slo[4][3], shi[4][3]; uint32_t sn[4];                            // suffix: bins pos..3
         for (int d = 0; d < 3; d++) { slo[3][d] = lo[3][d]; shi[3][d] = hi[3][d]; } sn[3] = cn[3];
 #pragma unroll
-        for (int b = 2; b >= 1; b--) { for (int d = 0; d < 3; d++) { slo[b][d] = fminf(lo[b][d], slo[b + 1][d]); shi[b][d] = fmaxf(hi[b][d], shi[b + 1][d]); } sn[b] = cn[b] + sn[b + 1]; }
+        for (int b = 2; b >= 1; b--) { for (int d = 0; d < 3; d++) { slo[b][d] = vmin(lo[b][d], slo[b + 1][d]); shi[b][d] = vmax(hi[b][d], shi[b + 1][d]); } sn[b] = cn[b] + sn[b + 1]; }
         float llo[3] = {lo[0][0], lo[0][1], lo[0][2]}, lhi[3] = {hi[0][0], hi[0][1], hi[0][2]}; uint32_t lN = cn[0];
 #pragma unroll
         for (int pos = 1; pos < 4; pos++) {
@@ -100,26 +131,32 @@ __device__ void micro_subtree(uint32_t* R, uint32_t W, uint32_t (*s_cb)[64][6], 
               for (int d = 0; d < 3; d++) { bl[d] = llo[d]; bh[d] = lhi[d]; rl[d] = slo[pos][d]; rh[d] = shi[pos][d]; }
             }
           }
-          for (int d = 0; d < 3; d++) { llo[d] = fminf(llo[d], lo[pos][d]); lhi[d] = fmaxf(lhi[d], hi[pos][d]); }
+          for (int d = 0; d < 3; d++) { llo[d] = vmin(llo[d], lo[pos][d]); lhi[d] = vmax(lhi[d], hi[pos][d]); }
           lN += cn[pos];
         }
       }
     } else if (act) {
+#ifdef SM_STATS
+      if (lane == (uint32_t)__builtin_ctzll(__ballot(act && nb != 4u))) atomicAdd(&ctr->padC[2], 1u);
+#endif
       const uint32_t nb1 = nb - 1u, ncand = 3u * nb1;
       for (uint32_t c = lane - segB; c < ncand; c += n) {
         const uint32_t axis = (c >= nb1 ? 1u : 0u) + (c >= 2u * nb1 ? 1u : 0u), pos = c - axis * nb1 + 1u;
         if (sel3(axis, scale[0], scale[1], scale[2]) == 0.0f) continue;          // mapping.invalid(dim) :375
-        float llo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, lhi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
-        float rlo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, rhi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+        // both sides are merged as they lie in the bins (atomicMax encodings, zero = nothing) and decoded once
+        uint32_t zl[6] = {0u, 0u, 0u, 0u, 0u, 0u}, zr[6] = {0u, 0u, 0u, 0u, 0u, 0u};
         uint32_t lN = 0, rN = 0;
+        const uint4* e = (const uint4*)(sb + axis * nb * 8u);
         for (uint32_t b = 0; b < nb; b++) {
-          const uint32_t* e = sb + (axis * nb + b) * 8u;
-          const uint32_t cnt = e[6];
-          if (cnt == 0u) continue;
-          if (b < pos) { lN += cnt; for (int d = 0; d < 3; d++) { llo[d] = fminf(llo[d], unzlo(e[d])); lhi[d] = fmaxf(lhi[d], unzhi(e[3 + d])); } }
-          else         { rN += cnt; for (int d = 0; d < 3; d++) { rlo[d] = fminf(rlo[d], unzlo(e[d])); rhi[d] = fmaxf(rhi[d], unzhi(e[3 + d])); } }
+          const uint4 x = e[2u * b], y = e[2u * b + 1u];
+          const bool isL = b < pos;
+          const uint32_t v[6] = {x.x, x.y, x.z, x.w, y.x, y.y};
+          for (int k = 0; k < 6; k++) { zl[k] = max(zl[k], isL ? v[k] : 0u); zr[k] = max(zr[k], isL ? 0u : v[k]); }
+          lN += isL ? y.z : 0u; rN += isL ? 0u : y.z;
         }
         if (lN == 0u || rN == 0u) continue;
+        float llo[3], lhi[3], rlo[3], rhi[3];
+        for (int d = 0; d < 3; d++) { llo[d] = unzlo(zl[d]); lhi[d] = unzhi(zl[3 + d]); rlo[d] = unzlo(zr[d]); rhi[d] = unzhi(zr[3 + d]); }
         const float lA = half_area3(lhi[0] - llo[0], lhi[1] - llo[1], lhi[2] - llo[2]);
         const float rA = half_area3(rhi[0] - rlo[0], rhi[1] - rlo[1], rhi[2] - rlo[2]);
         const float sah = fmaf(lA, (float)((lN + addBlk) >> prm.shift), rA * (float)((rN + addBlk) >> prm.shift));
@@ -131,17 +168,18 @@ __device__ void micro_subtree(uint32_t* R, uint32_t W, uint32_t (*s_cb)[64][6], 
     }
     const unsigned long long key = bestC == NIL ? ~0ull : (((unsigned long long)__float_as_uint(bestSah) << 32) | bestC);
     if (act && key != ~0ull) atomicMin(&s_key[segB], key);
-    __syncthreads();                                             // bins are dead from here on: R now holds split records + exchange buffer
+    __syncthreads();                                             // bins are dead from here on: R now holds split records + exchange buffer + next centroid bounds
     const unsigned long long win = act ? s_key[segB] : 0ull;
+    for (int k = 0; k < 6; k++) CB[lane * 6u + k] = 0u;          // (zero = the identity of the atomicMax encodings)
     const bool fb = act && win == ~0ull;                          // no valid candidate -> median split (split_template :144-147)
-    uint32_t* const rec = R + segB * 16u;
+    uint32_t* const rec = R + segB * 8u;
     if (act && !fb && key == win) {
       const uint32_t nb1 = nb - 1u, axis = (bestC >= nb1 ? 1u : 0u) + (bestC >= 2u * nb1 ? 1u : 0u), pos = bestC - axis * nb1 + 1u;
       rec[0] = axis | (pos << 8); rec[1] = bestNL; rec[2] = __float_as_uint(bestSah);
       for (int d = 0; d < 3; d++) { rec[4 + d] = __float_as_uint(bl[d]); rec[7 + d] = __float_as_uint(bh[d]); rec[10 + d] = __float_as_uint(rl[d]); rec[13 + d] = __float_as_uint(rh[d]); }
     }
     if (fb && lane == segB) {
-      rec[0] = 1u << 16; rec[1] = (gbegin + segB + gbegin + segE) / 2u - (gbegin + segB); rec[2] = __float_as_uint(__builtin_inff());
+      rec[0] = 1u << 16; rec[1] = n >> 1; rec[2] = __float_as_uint(__builtin_inff());      // (begin + end) / 2 - begin
       for (int k = 4; k < 16; k++) rec[k] = 0u;
     }
     __syncthreads();
@@ -152,53 +190,62 @@ __device__ void micro_subtree(uint32_t* R, uint32_t W, uint32_t (*s_cb)[64][6], 
       }
       __syncthreads();
     }
-    // ---- L4: partition (heuristic_binning_array_aligned.h:150-176): new lane of my triangle, child centroid bounds, node records
+    // ---- L4: partition (heuristic_binning_array_aligned.h:150-176): new lane of my triangle, child centroid bounds, node records.
+    //      A child of <= min_leaf triangles is a leaf: its triangles write their ids and leave; the others close ranks.
     bool left = false; uint32_t nL = 0;
     if (act) {
       const uint32_t w0 = rec[0], dim = w0 & 3u, pos = (w0 >> 8) & 0xFFu; nL = rec[1];
       const float c2 = sel3(dim, p.lo[0] + p.hi[0], p.lo[1] + p.hi[1], p.lo[2] + p.hi[2]);
       left = (w0 >> 16) ? (lane < segB + nL) : (bin_unsafe(c2, sel3(dim, ofs[0], ofs[1], ofs[2]), sel3(dim, scale[0], scale[1], scale[2])) < (int)pos);
     }
-    const unsigned long long segMask = act ? ((n >= 64u ? ~0ull : ((1ull << n) - 1ull)) << segB) : 0ull;
-    const unsigned long long lm = __ballot(act && left) & segMask, rm = __ballot(act && !left) & segMask, lt = (1ull << lane) - 1ull;
+    // the partition permutes inside a segment's lanes: as a PLACE, lane x belongs to the left child iff x < segB + nL
+    const unsigned long long gone = __ballot(act && (lane < segB + nL ? nL : n - nL) <= prm.minLeaf);
+    // my rank among the lefts / rights of my segment: lanes-below counts (v_mbcnt) of the wave's ballot, minus what the segment's first lane counts
+    const unsigned long long lb = __ballot(act && left);
+    const uint32_t mbL = __builtin_amdgcn_mbcnt_hi((uint32_t)(lb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lb, 0u));
+    const uint32_t mbG = __builtin_amdgcn_mbcnt_hi((uint32_t)(gone >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)gone, 0u));
+    const uint32_t rankL = mbL - (uint32_t)__shfl((int)mbL, (int)segB, 64), rankR = (lane - segB) - rankL;
+    bool leafHead = false;
+    const uint32_t below = (uint32_t)__shfl((int)mbG, (int)(left ? segB : segB + nL) & 63, 64);   // places below my child that were given up (whole segments)
     if (act) {
-      const uint32_t nSegB = left ? segB : segB + nL, nSegE = left ? segB + nL : segE, nNode = left ? node + 1u : node + 2u * nL;
-      const uint32_t npos = left ? segB + (uint32_t)__popcll(lm & lt) : segB + nL + (uint32_t)__popcll(rm & lt);
-      for (int d = 0; d < 3; d++) { const float cc = p.lo[d] + p.hi[d]; atomicMax(&s_cb[pp ^ 1u][nSegB][d], zlo(cc)); atomicMax(&s_cb[pp ^ 1u][nSegB][3 + d], zhi(cc)); }
-      uint32_t* X = R + 1024u + npos;
-      X[0] = __float_as_uint(p.lo[0]); X[64] = __float_as_uint(p.lo[1]); X[128] = __float_as_uint(p.lo[2]); X[192] = p.geom;
-      X[256] = __float_as_uint(p.hi[0]); X[320] = __float_as_uint(p.hi[1]); X[384] = __float_as_uint(p.hi[2]); X[448] = p.prim;
-      X[512] = nSegB | (nSegE << 8); X[576] = nNode;
+      const uint32_t nSegB = left ? segB : segB + nL, cs = left ? nL : n - nL, nNode = left ? node + 1u : node + 2u * nL, ngsb = left ? gsb : gsb + nL;
+      const uint32_t npos = left ? segB + rankL : segB + nL + rankR;
+      if (cs <= prm.minLeaf) {
+        finalIds[ngsb + (npos - nSegB)] = make_uint2(p.geom & 0x07FFFFFFu, p.prim);   // (top 5 bits: split budget of spatial-split builds, build_spatial.inl)
+        leafHead = npos == nSegB;
+        if (leafHead) ((uint4*)(bnodes + nNode))[2] = make_uint4(NIL, NIL, __float_as_uint(__builtin_inff()), 0u);
+      } else {
+        const uint32_t cB = nSegB - below, cpos = npos - below;
+        for (int d = 0; d < 3; d++) { const float cc = p.lo[d] + p.hi[d]; atomicMax(&CB[cB * 6u + d], zlo(cc)); atomicMax(&CB[cB * 6u + 3 + d], zhi(cc)); }
+        uint32_t* X = R + 512u + cpos;
+        X[0] = __float_as_uint(p.lo[0]); X[64] = __float_as_uint(p.lo[1]); X[128] = __float_as_uint(p.lo[2]); X[192] = p.geom;
+        X[256] = __float_as_uint(p.hi[0]); X[320] = __float_as_uint(p.hi[1]); X[384] = __float_as_uint(p.hi[2]); X[448] = p.prim;
+        X[512] = cB | ((cB + cs) << 8); X[576] = nNode; X[640] = ngsb;
+      }
       if (lane == segB) {                                        // one lane per segment: my links, my children's boxes and ranges
-        const bool isfb = (rec[0] >> 16) != 0u;
         float cb[12];
-        for (int k = 0; k < 12; k++) cb[k] = isfb ? ((k % 6) < 3 ? unzlo(rec[4 + k]) : unzhi(rec[4 + k])) : __uint_as_float(rec[4 + k]);
+        for (int k = 0; k < 12; k++) cb[k] = __uint_as_float(rec[4 + k]);
+        if ((rec[0] >> 16) != 0u) for (int k = 0; k < 12; k++) cb[k] = (k % 6) < 3 ? unzlo(rec[4 + k]) : unzhi(rec[4 + k]);   // (median split: reduced with the atomicMax encodings)
         const uint32_t L = node + 1u, Rr = node + 2u * nL;
         ((uint4*)(bnodes + node))[2] = make_uint4(L, Rr, rec[2], 0u);
-        ((float4*)(bnodes + L))[0] = make_float4(cb[0], cb[1], cb[2], __uint_as_float(gbegin + segB));
-        ((float4*)(bnodes + L))[1] = make_float4(cb[3], cb[4], cb[5], __uint_as_float(gbegin + segB + nL));
-        ((float4*)(bnodes + Rr))[0] = make_float4(cb[6], cb[7], cb[8], __uint_as_float(gbegin + segB + nL));
-        ((float4*)(bnodes + Rr))[1] = make_float4(cb[9], cb[10], cb[11], __uint_as_float(gbegin + segE));
+        ((float4*)(bnodes + L))[0] = make_float4(cb[0], cb[1], cb[2], __uint_as_float(gsb));
+        ((float4*)(bnodes + L))[1] = make_float4(cb[3], cb[4], cb[5], __uint_as_float(gsb + nL));
+        ((float4*)(bnodes + Rr))[0] = make_float4(cb[6], cb[7], cb[8], __uint_as_float(gsb + nL));
+        ((float4*)(bnodes + Rr))[1] = make_float4(cb[9], cb[10], cb[11], __uint_as_float(gsb + n));
       }
     }
+    leaves += (uint32_t)__popcll(__ballot(leafHead));
+    nAct -= (uint32_t)__popcll(gone);
     __syncthreads();
     // ---- L5: pick up the triangle that moved to my lane
-    if (act) {
-      const uint32_t* X = R + 1024u + lane;
+    if (lane < nAct) {
+      const uint32_t* X = R + 512u + lane;
       p.lo[0] = __uint_as_float(X[0]); p.lo[1] = __uint_as_float(X[64]); p.lo[2] = __uint_as_float(X[128]); p.geom = X[192];
       p.hi[0] = __uint_as_float(X[256]); p.hi[1] = __uint_as_float(X[320]); p.hi[2] = __uint_as_float(X[384]); p.prim = X[448];
-      segB = X[512] & 0xFFu; segE = X[512] >> 8; node = X[576];
-      act = segE - segB > prm.minLeaf;
+      segB = X[512] & 0xFFu; segE = X[512] >> 8; node = X[576]; gsb = X[640];
     }
-    pp ^= 1u;
   }
-  // every remaining segment is a binary leaf (the reference never splits sets of <= minLeafSize, bvh_builder_sah.h:253)
-  if (lane < n0) {
-    finalIds[gbegin + lane] = make_uint2(p.geom & 0x07FFFFFFu, p.prim);   // (top 5 bits: split budget of spatial-split builds, build_spatial.inl)
-    if (lane == segB) ((uint4*)(bnodes + node))[2] = make_uint4(NIL, NIL, __float_as_uint(__builtin_inff()), 0u);
-  }
-  const unsigned long long leaves = __ballot(lane < n0 && lane == segB);
-  if (lane == 0u) atomicAdd(&ctr->numBLeaves, (uint32_t)__popcll(leaves));
+  if (lane == 0u && leaves) atomicAdd(&ctr->numBLeaves, leaves);
   __syncthreads();
 }
 
@@ -208,8 +255,9 @@ __global__ __launch_bounds__(64) void small_build(const SmallEntry* entries, Pri
   __shared__ SplitResult s_res;
   __shared__ uint32_t s_acc[2][12];
   __shared__ StackEntry s_stack[24];
-  __shared__ uint32_t s_cb[2][64][6];
   __shared__ unsigned long long s_key[64];
+  __shared__ MicroRoot s_roots[MICRO_ROOTS];
+  uint32_t numRoots = 0;
   uint32_t* const s_bins = s_R;
   const uint32_t lane = threadIdx.x;
   if (blockIdx.x >= ctr->numSmall) return;                       // the grid is an upper bound (the host does not read the list's length back)
@@ -217,15 +265,24 @@ __global__ __launch_bounds__(64) void small_build(const SmallEntry* entries, Pri
   StackEntry cur; cur.begin = e0.begin; cur.end = e0.end; cur.bnode = e0.bnode; cur.buf = e0.buf;
   for (int d = 0; d < 3; d++) { cur.cmin[d] = e0.cmin[d]; cur.cmax[d] = e0.cmax[d]; }
   uint32_t sp = 0;
-  for (uint32_t iter = 0; iter < (1u << 20); iter++) {         // the cap is a safety net only: <= 2*small_threshold iterations are possible
+  bool done = false;
+  uint32_t iter = 0;
+  while (!done) {
+  for (; iter < (1u << 20); iter++) {         // the cap is a safety net only: <= 2*small_threshold iterations are possible
     const uint32_t n = cur.end - cur.begin;
     PrimRef* src = cur.buf ? bufB : bufA;
     PrimRef* dst = cur.buf ? bufA : bufB;
-    if (n <= MICRO) {
-      micro_subtree(s_R, W, s_cb, s_key, src, cur.begin, n, cur.bnode, cur.cmin, cur.cmax, bnodes, finalIds, ctr, prm, lane);
-      if (sp == 0) break;
+    if (n <= MICRO) {                                            // parked: the micro mode takes the roots of this sub-tree in together (micro_flush)
+      if (lane == 0) {
+        MicroRoot r; r.begin = cur.begin; r.nbuf = n | (cur.buf << 8); r.bnode = cur.bnode;
+        for (int d = 0; d < 3; d++) { r.cmin[d] = cur.cmin[d]; r.cmax[d] = cur.cmax[d]; }
+        s_roots[numRoots] = r;
+      }
+      numRoots++;
+      if (sp == 0) { done = true; break; }
       cur = s_stack[--sp];
       __syncthreads();
+      if (numRoots == MICRO_ROOTS) break;                        // (only with small_threshold > 1024)
       continue;
     }
     const Mapping m = make_mapping(n, cur.cmin, cur.cmax);
@@ -308,5 +365,10 @@ __global__ __launch_bounds__(64) void small_build(const SmallEntry* entries, Pri
     sp++;
     cur = keep;
     __syncthreads();
+  }
+  if (iter >= (1u << 20)) done = true;
+  __syncthreads();
+  micro_flush(s_R, W, s_key, s_roots, numRoots, bufA, bufB, bnodes, finalIds, ctr, prm, lane);
+  numRoots = 0;
   }
 }

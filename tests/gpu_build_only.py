@@ -18,4 +18,8 @@ for i in range(reps):
     if os.environ.get("SLEEP"): time.sleep(float(os.environ["SLEEP"]))
 print("WALL", " ".join("%.2f" % w for w in wall), "| launches/syncs", " ".join(ls))
 i = s.info()
+if os.environ.get("TREEHASH"):
+    import hashlib
+    nodes, tris = s.download_bvh()
+    print("TREEHASH nodes %s tris %s" % (hashlib.sha256(nodes.tobytes()).hexdigest()[:16], hashlib.sha256(tris.tobytes()).hexdigest()[:16]))
 print("BUILD cfg=%r q=%s: %s ms | nodes %d sah %.2f launches %d syncs %d" % (cfg, q, " ".join("%.2f" % m for m in ms), i["num_nodes"], i["sah"], i["num_launches"], i["num_host_syncs"]))
