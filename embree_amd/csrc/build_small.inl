@@ -36,6 +36,13 @@ constexpr uint32_t MICRO_ROOTS = 32;                              // (a set of <
 // segment after segment; a segment that has become a leaf writes its ids and leaves (the partition squeezes its lanes out),
 // and whenever a parked root fits into the free lanes it is taken in.  One sub-tree at a time left 58 % of the lanes of a
 // level pass idle (profiles/r01_build_history.md: 26.9 of 64 lanes on average over the 6.5 levels of a 43-triangle root).
+// (The workgroup is ONE wavefront: -DSM_LDS_SYNC makes the barriers of the micro mode wait for the LDS queue only, not for the global stores of node
+// records and ids -- measured: no difference, the kernel is bound by instruction issue, not by waiting.)
+#ifdef SM_LDS_SYNC
+#define MICRO_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#else
+#define MICRO_SYNC() __syncthreads()
+#endif
 __device__ void micro_flush(uint32_t* R, uint32_t W, unsigned long long* s_key, const MicroRoot* roots, uint32_t numRoots,
                             const PrimRef* bufA, const PrimRef* bufB, BNode* bnodes, uint2* finalIds, Counters* ctr, const Params& prm, uint32_t lane) {
   PrimRef p{};
@@ -70,7 +77,7 @@ __device__ void micro_flush(uint32_t* R, uint32_t W, unsigned long long* s_key, 
 #ifdef SM_STATS
     if (lane == 0u) { atomicAdd(&ctr->padC[0], 1u); atomicAdd(&ctr->padC[1], nAct); }
 #endif
-    __syncthreads();                                             // (the new roots' centroid bounds)
+    MICRO_SYNC();                                             // (the new roots' centroid bounds)
     // ---- L0: bin mapping of my segment (BinMapping, heuristic_binning.h:46-55); clear bins and keys
     const uint32_t n = segE - segB;
     float ofs[3] = {0, 0, 0}, scale[3] = {0, 0, 0}; uint32_t nb = 4;
@@ -81,10 +88,16 @@ __device__ void micro_flush(uint32_t* R, uint32_t W, unsigned long long* s_key, 
       for (int d = 0; d < 3; d++) { ofs[d] = m.ofs[d]; scale[d] = m.scale[d]; }
       nb = m.nb;
     }
-    __syncthreads();                                             // everybody has read the centroid bounds and is done with the exchange buffer
-    for (uint32_t i = 0; i < W / 4u; i++) ((uint4*)R)[i * 64u + lane] = make_uint4(0u, 0u, 0u, 0u);
+    MICRO_SYNC();                                             // everybody has read the centroid bounds and is done with the exchange buffer
+    if (W == 32u) {
+#pragma unroll
+      for (uint32_t i = 0; i < 8u; i++) ((uint4*)R)[i * 64u + lane] = make_uint4(0u, 0u, 0u, 0u);
+    } else {
+#pragma unroll
+      for (uint32_t i = 0; i < 12u; i++) ((uint4*)R)[i * 64u + lane] = make_uint4(0u, 0u, 0u, 0u);
+    }
     s_key[lane] = ~0ull;
-    __syncthreads();
+    MICRO_SYNC();
     // ---- L1: bin (BinInfoT::bin, heuristic_binning.h:210-257)
     uint32_t* const sb = R + segB * W;
     if (act) {
@@ -96,7 +109,7 @@ __device__ void micro_flush(uint32_t* R, uint32_t W, unsigned long long* s_key, 
         atomicAdd(&e[6], 1u);
       }
     }
-    __syncthreads();
+    MICRO_SYNC();
     // ---- L2: candidates (BinInfoT::best :339-386): lane j of a segment evaluates candidates j, j + n, ...;
     //      candidate c = axis * (nb - 1) + (pos - 1), so the minimum of (sah, c) is the reference's choice
     float bestSah = __builtin_inff(); uint32_t bestC = NIL, bestNL = 0;
@@ -168,7 +181,7 @@ __device__ void micro_flush(uint32_t* R, uint32_t W, unsigned long long* s_key, 
     }
     const unsigned long long key = bestC == NIL ? ~0ull : (((unsigned long long)__float_as_uint(bestSah) << 32) | bestC);
     if (act && key != ~0ull) atomicMin(&s_key[segB], key);
-    __syncthreads();                                             // bins are dead from here on: R now holds split records + exchange buffer + next centroid bounds
+    MICRO_SYNC();                                             // bins are dead from here on: R now holds split records + exchange buffer + next centroid bounds
     const unsigned long long win = act ? s_key[segB] : 0ull;
     for (int k = 0; k < 6; k++) CB[lane * 6u + k] = 0u;          // (zero = the identity of the atomicMax encodings)
     const bool fb = act && win == ~0ull;                          // no valid candidate -> median split (split_template :144-147)
@@ -182,13 +195,13 @@ __device__ void micro_flush(uint32_t* R, uint32_t W, unsigned long long* s_key, 
       rec[0] = 1u << 16; rec[1] = n >> 1; rec[2] = __float_as_uint(__builtin_inff());      // (begin + end) / 2 - begin
       for (int k = 4; k < 16; k++) rec[k] = 0u;
     }
-    __syncthreads();
+    MICRO_SYNC();
     if (__ballot(fb) != 0ull) {                                   // child geometry bounds of a median split: reduce over the triangles
       if (fb) {
         const uint32_t o = lane < segB + rec[1] ? 4u : 10u;
         for (int d = 0; d < 3; d++) { atomicMax(&rec[o + d], zlo(p.lo[d])); atomicMax(&rec[o + 3 + d], zhi(p.hi[d])); }
       }
-      __syncthreads();
+      MICRO_SYNC();
     }
     // ---- L4: partition (heuristic_binning_array_aligned.h:150-176): new lane of my triangle, child centroid bounds, node records.
     //      A child of <= min_leaf triangles is a leaf: its triangles write their ids and leave; the others close ranks.
@@ -236,7 +249,7 @@ __device__ void micro_flush(uint32_t* R, uint32_t W, unsigned long long* s_key, 
     }
     leaves += (uint32_t)__popcll(__ballot(leafHead));
     nAct -= (uint32_t)__popcll(gone);
-    __syncthreads();
+    MICRO_SYNC();
     // ---- L5: pick up the triangle that moved to my lane
     if (lane < nAct) {
       const uint32_t* X = R + 512u + lane;
@@ -246,7 +259,7 @@ __device__ void micro_flush(uint32_t* R, uint32_t W, unsigned long long* s_key, 
     }
   }
   if (lane == 0u && leaves) atomicAdd(&ctr->numBLeaves, leaves);
-  __syncthreads();
+  MICRO_SYNC();
 }
 
 __global__ __launch_bounds__(64) void small_build(const SmallEntry* entries, PrimRef* bufA, PrimRef* bufB, BNode* bnodes,

@@ -208,21 +208,29 @@ __device__ __forceinline__ void sbins_add_rows(uint32_t* bins, int d, uint32_t b
     atomicAdd(&e[6], 1u); atomicAdd(&e[7], 1u);
   }
 }
+// The clipping chains are not run where they are found: a reference that spans several bins of an axis is the exception in a batch of 64, its chain is
+// up to 15 dependent cuts long, and a wave that runs it on the spot waits for its longest chain -- three times per batch, once per axis (spatial_bin was 8.2
+// of the 17.5 ms of a HIGH commit; parked chains: 7.0 of 16.4.  At the lower levels, where a bin is about as wide as a triangle, nearly every pair is a
+// chain and the LDS atomics of the pieces -- six per piece -- are what is left).  The (reference, axis) pairs go to a list in LDS instead, and once the chunk's simple references are binned the workgroup's 256 lanes take
+// one chain each.  What a chain adds to the bins is min / max / add atomics, so the bins do not depend on the order the chains are run in.
+constexpr uint32_t CHAIN_CAP = 3u * CHUNK;                           // every (reference, axis) pair of a chunk fits
 __global__ __launch_bounds__(256) void spatial_bin(const Seg* segs, const SegX* sx, const Chunk* chunks, const PrimRef* src, const GeomDesc* geoms, uint32_t* sbins, const Counters* ctr) {
   __shared__ uint32_t s_b[SBINS_WORDS];
+  __shared__ uint32_t s_chain[CHAIN_CAP];                           // reference index | axis << 30
+  __shared__ uint32_t s_numChains;
   const uint32_t tid = threadIdx.x, lane = tid & 63u;
   const uint32_t numChunks = ctr->numChunks, c0 = blockIdx.x;
   if (c0 >= numChunks) return;
   Chunk ck = chunks[c0];
   const SegX* x = sx + ck.seg;
   if (!x->trySpatial) return;
-  const uint32_t c1 = c0 + 1u;                                   // (one chunk per workgroup: doing several in a row left the top levels with too few workgroups)
   for (uint32_t w = tid; w < (uint32_t)SBINS_WORDS; w += 256u) { const uint32_t k = w % SBINW; s_b[w] = k < 3 ? ENC_POS_INF : (k < 6 ? ENC_NEG_INF : 0u); }
+  if (tid == 0u) s_numChains = 0u;
   __syncthreads();
   float ofs[3], scale[3], inv[3];
   for (int d = 0; d < 3; d++) { ofs[d] = x->sofs[d]; scale[d] = x->sscale[d]; inv[d] = x->sinv[d]; }
-  const uint32_t first = ck.begin; uint32_t last = ck.end;
-  for (uint32_t c = c0;;) {
+  const uint32_t first = ck.begin, last = ck.end;                 // (one chunk per workgroup: doing several in a row left the top levels with too few workgroups)
+  {
     // each wave owns a contiguous quarter of the chunk (as in top_bin): a row of 16 lanes sees 16 consecutive references
     const uint32_t span = ck.begin + (tid >> 6) * (CHUNK / 4u), spanEnd = min(span + CHUNK / 4u, ck.end);
     for (uint32_t i0 = span; i0 < spanEnd; i0 += 64u) {           // wave-uniform trip count
@@ -231,11 +239,10 @@ __global__ __launch_bounds__(256) void spatial_bin(const Seg* segs, const SegX* 
       const uint32_t budget = r.geom >> SPLIT_SHIFT;
       uint32_t c6[6];
       for (int k = 0; k < 3; k++) { c6[k] = enc(r.lo[k]); c6[3 + k] = enc(r.hi[k]); }
-      float tv[3][3]; bool have = false;
 #pragma unroll
       for (int d = 0; d < 3; d++) {
         // a reference without budget goes whole into the bin of its centre on every axis (:170-178); one with budget into the bin its box lies in, if that
-        // is ONE bin; otherwise it is clipped bin by bin (spatial_chain) -- on axes the mapping is valid for (mapping.invalid(dim))
+        // is ONE bin; otherwise it is clipped bin by bin (spatial_chain, below) -- on axes the mapping is valid for (mapping.invalid(dim))
         bool simple = false; uint32_t b = 0u;
         if (v) {
           if (budget <= 1u) { simple = true; b = (uint32_t)sbin(0.5f * (r.lo[d] + r.hi[d]), ofs[d], scale[d]); }
@@ -243,19 +250,30 @@ __global__ __launch_bounds__(256) void spatial_bin(const Seg* segs, const SegX* 
             const int l = sbin(r.lo[d], ofs[d], scale[d]), rr = sbin(r.hi[d], ofs[d], scale[d]);
             if (l == rr) { simple = true; b = (uint32_t)l; }
             else {
-              int l2, r2; spatial_chain<true>(tv, have, geoms, r, d, ofs[d], scale[d], inv[d], s_b, l2, r2);
-              atomicAdd(&s_b[(d * SBINS + l2) * SBINW + 6], 1u); atomicAdd(&s_b[(d * SBINS + r2) * SBINW + 7], 1u);
+              const uint32_t slot = atomicAdd(&s_numChains, 1u);
+              if (slot < CHAIN_CAP) s_chain[slot] = (i - first) | ((uint32_t)d << 30);
+              else {                                              // (cannot happen with CHUNK = 2048; kept for other chunk sizes)
+                float tv[3][3]; bool have = false; int l2, r2;
+                spatial_chain<true>(tv, have, geoms, r, d, ofs[d], scale[d], inv[d], s_b, l2, r2);
+                atomicAdd(&s_b[(d * SBINS + l2) * SBINW + 6], 1u); atomicAdd(&s_b[(d * SBINS + r2) * SBINW + 7], 1u);
+              }
             }
           }
         }
         sbins_add_rows(s_b, d, b, simple, c6, lane);
       }
     }
-    last = ck.end;
-    if (++c >= c1) break;
-    const Chunk nk = chunks[c];
-    if (nk.seg != ck.seg) break;
-    ck = nk;
+  }
+  __syncthreads();
+  {
+    const uint32_t numChains = min(s_numChains, CHAIN_CAP);
+    for (uint32_t t = tid; t < numChains; t += 256u) {
+      const uint32_t task = s_chain[t], d = task >> 30;
+      const PrimRef r = load_prim(src + first + (task & 0x3FFFFFFFu));
+      float tv[3][3]; bool have = false; int l2, r2;
+      spatial_chain<true>(tv, have, geoms, r, (int)d, sel3(d, ofs[0], ofs[1], ofs[2]), sel3(d, scale[0], scale[1], scale[2]), sel3(d, inv[0], inv[1], inv[2]), s_b, l2, r2);
+      atomicAdd(&s_b[(d * SBINS + (uint32_t)l2) * SBINW + 6], 1u); atomicAdd(&s_b[(d * SBINS + (uint32_t)r2) * SBINW + 7], 1u);
+    }
   }
   __syncthreads();
   const Seg* sg = segs + ck.seg;

@@ -22,4 +22,4 @@ if os.environ.get("TREEHASH"):
     import hashlib
     nodes, tris = s.download_bvh()
     print("TREEHASH nodes %s tris %s" % (hashlib.sha256(nodes.tobytes()).hexdigest()[:16], hashlib.sha256(tris.tobytes()).hexdigest()[:16]))
-print("BUILD cfg=%r q=%s: %s ms | nodes %d sah %.2f launches %d syncs %d" % (cfg, q, " ".join("%.2f" % m for m in ms), i["num_nodes"], i["sah"], i["num_launches"], i["num_host_syncs"]))
+print("BUILD cfg=%r q=%s: %s ms | nodes %d sah %.2f launches %d syncs %d top_levels %d depth %d" % (cfg, q, " ".join("%.2f" % m for m in ms), i["num_nodes"], i["sah"], i["num_launches"], i["num_host_syncs"], i.get("top_levels", -1), i.get("depth", -1)))
