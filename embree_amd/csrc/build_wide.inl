@@ -44,13 +44,22 @@ __global__ void wide_root(WideItem* items, Counters* ctr) {
 }
 
 template <typename T> __device__ __forceinline__ T grp_get(T v, uint32_t lane, uint32_t idx) { return __shfl(v, (int)((lane & ~7u) | idx), 64); }
-__device__ __forceinline__ float grp_min(float v) { v = fminf(v, __shfl_xor(v, 1, 64)); v = fminf(v, __shfl_xor(v, 2, 64)); return fminf(v, __shfl_xor(v, 4, 64)); }
-__device__ __forceinline__ float grp_max(float v) { v = fmaxf(v, __shfl_xor(v, 1, 64)); v = fmaxf(v, __shfl_xor(v, 2, 64)); return fmaxf(v, __shfl_xor(v, 4, 64)); }
-__device__ __forceinline__ float grp_sum(float v) { v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); return v + __shfl_xor(v, 4, 64); }
+// Reductions over the 8 lanes of a group as three DPP butterflies -- quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror (lane i <-> i ^ 7: the other
+// quad of the group, whose four lanes agree after the first two steps) -- instead of three ds_bpermute round trips through the LDS pipe (~100 cycles each,
+// and the open loop of wide_plan is one dependent chain of them)
+__device__ __forceinline__ float grp_xf(float v, int step) {
+  const uint32_t u = __float_as_uint(v);
+  return __uint_as_float(step == 0 ? dpp_u<0xB1, 0xF>(u, u) : (step == 1 ? dpp_u<0x4E, 0xF>(u, u) : dpp_u<0x141, 0xF>(u, u)));
+}
+__device__ __forceinline__ uint32_t grp_xu(uint32_t u, int step) { return step == 0 ? dpp_u<0xB1, 0xF>(u, u) : (step == 1 ? dpp_u<0x4E, 0xF>(u, u) : dpp_u<0x141, 0xF>(u, u)); }
+__device__ __forceinline__ float grp_min(float v) { v = fminf(v, grp_xf(v, 0)); v = fminf(v, grp_xf(v, 1)); return fminf(v, grp_xf(v, 2)); }
+__device__ __forceinline__ float grp_max(float v) { v = fmaxf(v, grp_xf(v, 0)); v = fmaxf(v, grp_xf(v, 1)); return fmaxf(v, grp_xf(v, 2)); }
+__device__ __forceinline__ float grp_sum(float v) { v += grp_xf(v, 0); v += grp_xf(v, 1); return v + grp_xf(v, 2); }
 // argmax over the 8 lanes of a group; ties go to the lower index (the serial formulation keeps the first maximum)
 __device__ __forceinline__ void grp_argmax(float& v, uint32_t& idx) {
-  for (int o = 1; o < 8; o <<= 1) {
-    const float ov = __shfl_xor(v, o, 64); const uint32_t oi = (uint32_t)__shfl_xor((int)idx, o, 64);
+#pragma unroll
+  for (int st = 0; st < 3; st++) {
+    const float ov = grp_xf(v, st); const uint32_t oi = grp_xu(idx, st);
     if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
   }
 }
@@ -126,7 +135,7 @@ __global__ __launch_bounds__(64) void wide_plan(const WideItem* items, const BNo
     const uint32_t gshift = lane & ~7u;
     const uint32_t imask = (uint32_t)((__ballot(sHas && !sLeaf) >> gshift) & 0xFFull), leafMask = (uint32_t)((__ballot(sHas && sLeaf) >> gshift) & 0xFFull);
     uint32_t nTri = (sHas && sLeaf) ? sCnt : 0u;
-    nTri += (uint32_t)__shfl_xor((int)nTri, 1, 64); nTri += (uint32_t)__shfl_xor((int)nTri, 2, 64); nTri += (uint32_t)__shfl_xor((int)nTri, 4, 64);
+    nTri += grp_xu(nTri, 0); nTri += grp_xu(nTri, 1); nTri += grp_xu(nTri, 2);
     const uint32_t nInner = (uint32_t)__popc(imask);
     if (valid) {
       plans[t].ch[c] = sHas ? sCh : NIL;

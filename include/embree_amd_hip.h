@@ -120,7 +120,8 @@ MI355_API int mi355_bvh_build_instanced(int device, mi355_bvh_t own, const mi355
 #define MI355_REFIT_IMPOSSIBLE (-2)
 #define MI355_REFIT_BROKEN (-3)
 MI355_API int mi355_bvh_refit(mi355_bvh_t bvh, const mi355_mesh* meshes, uint32_t num_meshes, void* stream);
-/* Build scratch (prim refs, binary tree, work lists) is kept per device between commits; this returns it to the driver. */
+/* Build scratch (prim refs, binary tree, work lists) is kept per device between commits, and so are the node / triangle arrays of up to four destroyed
+   trees (the next commit of a similar size takes them over instead of paying hipFree + hipMalloc); this returns all of it to the driver. */
 MI355_API void mi355_release_build_scratch(int device);
 MI355_API int mi355_bvh_get_info(mi355_bvh_t bvh, mi355_bvh_info* info);
 /* Device-side filter rules of a FLAT tree (the reference: filter callbacks run inside the traversal, kernels/geometry/filter.h:14-80, intersector_epilog.h:

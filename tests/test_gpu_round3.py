@@ -471,3 +471,38 @@ def test_deep_tree_beyond_the_enqueued_levels(api, dev, restate):
     st = compare_closest(got, want, rays, o.triangle_t, label="deep tree")
     assert st["hits"] > n // 2                               # (at coordinates of 1e17 some centre rays miss in fp32: the reference misses the same ones)
     s.release()
+
+
+# ------------------------------------------------------------------------------------------- builder knobs
+@pytest.mark.parametrize("cfg", ["min_leaf=1", "min_leaf=1,max_leaf=1", "min_leaf=3,max_leaf=3", "small_threshold=128", "small_threshold=4096", "small_threshold=64"])
+def test_builder_knobs_keep_the_tree_valid(api, dev, cfg):
+    """The small phase has paths the default configuration never takes: 48 instead of 32 LDS words per triangle (min_leaf = 1: sets of two triangles are
+    split), a root list that fills up and is worked off before the sub-tree is finished (small_threshold = 4096: up to 127 roots of <= 64 triangles, 32
+    parked at a time), sub-trees that are ALL micro roots (small_threshold = 64).  Every configuration must give a valid tree (each triangle once, every box
+    contains what is below it) and the hits of the default tree (same t; an ID may differ where two triangles are hit at the same distance)."""
+    meshes = W.synthetic_crown(num_phi=24)                     # ~110 k triangles
+    rng = np.random.default_rng(5)
+    lo = np.min([v.min(0) for v, _ in meshes], 0); hi = np.max([v.max(0) for v, _ in meshes], 0)
+    org = (lo + (hi - lo) * rng.random((20000, 3))).astype(np.float32)
+    d = rng.normal(size=(20000, 3)).astype(np.float32)
+    rays = make_rayhits(org, d)
+    base = api.make_scene(dev, meshes)
+    want = rays.copy(); base.intersect1M(want)
+    d2 = api.Device("gpu=0," + cfg)
+    try:
+        s = api.make_scene(d2, meshes)
+        info = s.info()
+        nodes, tris = s.download_bvh()
+        bvh_check.validate(nodes, tris, info["root_ref"], meshes, max_leaf=info["max_leaf"], allow_splits=info["num_presplit"] > 0)
+        got = rays.copy(); s.intersect1M(got)
+        hit = want["geomID"] != INVALID_ID
+        assert ((got["geomID"] != INVALID_ID) == hit).all()
+        assert (got["tfar"][hit] == want["tfar"][hit]).all(), "a different tree over the same triangles changed a hit distance"
+        same = (got["geomID"] == want["geomID"]) & (got["primID"] == want["primID"])
+        assert (~same[hit]).mean() < 1e-3, "IDs differ on more rays than coincident triangles explain"
+        again = api.make_scene(d2, meshes)                     # and the same tree again
+        n2, t2 = again.download_bvh()
+        assert nodes.tobytes() == n2.tobytes() and tris.tobytes() == t2.tobytes(), "two commits of the same scene differ"
+        again.release(); s.release()
+    finally:
+        base.release(); d2.release()
