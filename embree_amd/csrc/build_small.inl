@@ -26,12 +26,14 @@ struct MicroRoot { uint32_t begin, nbuf, bnode; float cmin[3], cmax[3]; };   // 
 constexpr uint32_t MICRO_ROOTS = 32;                              // (a set of <= 1024 triangles leaves at most 31 of them)
 
 // R: per-wave LDS scratch of 64 * W words (W = 32 words per triangle when min_leaf >= 2, 48 for min_leaf = 1):
-//   bins of the segment starting at lane b live at R + b * W as [axis][bin][8] (3 * nb * 8 <= n * W words for every
-//   splittable n); once the candidates are evaluated the same memory holds the split records (16 words per segment at
-//   R + b * 8: a segment that is split has two lanes at least), the exchange buffer the partition moves the triangles through
-//   (11 x 64 words at R + 512) and the centroid bounds of the NEXT level's segments (6 words per segment at CB + b * 6,
-//   CB = R + 1664: cleared once the bins are dead, filled by the partition, read at the top of the next level before the
-//   bins are cleared again).
+//   the bins are seven PLANES of 64 * W / 8 words -- lo.x, lo.y, lo.z, hi.x, hi.y, hi.z, count -- and the segment that starts at lane b owns the slots
+//   [b * W / 8, ...) of every plane, one slot per (axis, bin): slot = b * W / 8 + axis * nb + bin (3 * nb <= n * W / 8 for every splittable n).  A lane's
+//   seven atomics go to seven planes, and within a plane the lanes of one instruction are spread over consecutive words: with the record layout this
+//   replaces ([axis][bin][8 words] at R + b * W) every atomic of an instruction fell on the same 4 of the 32 banks, 58 % of the kernel's LDS cycles were
+//   bank conflicts and the LDS pipe was busy half of the time (profiles/r03_pmc_small_build.md).  Once the candidates are evaluated the same memory holds -- all as planes of 64 words, word j of segment b at
+//   base + j * 64 + b -- the split records (15 planes at R), the exchange buffer the partition moves the triangles through (11 planes at R + 960) and
+//   the centroid bounds of the NEXT level's segments (6 planes at CB = R + 1664: cleared once the bins are dead, filled by the partition, read at the
+//   top of the next level before the bins are cleared again).
 // The wave works on SEVERAL sub-trees at a time: the lanes [0, nAct) hold the triangles of all segments that still split,
 // segment after segment; a segment that has become a leaf writes its ids and leaves (the partition squeezes its lanes out),
 // and whenever a parked root fits into the free lanes it is taken in.  One sub-tree at a time left 58 % of the lanes of a
@@ -43,7 +45,8 @@ constexpr uint32_t MICRO_ROOTS = 32;                              // (a set of <
 #else
 #define MICRO_SYNC() __syncthreads()
 #endif
-__device__ void micro_flush(uint32_t* R, uint32_t W, unsigned long long* s_key, const MicroRoot* roots, uint32_t numRoots,
+template <uint32_t W>
+__device__ void micro_flush(uint32_t* R, unsigned long long* s_key, const MicroRoot* roots, uint32_t numRoots,
                             const PrimRef* bufA, const PrimRef* bufB, BNode* bnodes, uint2* finalIds, Counters* ctr, const Params& prm, uint32_t lane) {
   PrimRef p{};
   uint32_t segB = 0, segE = 0, node = 0, gsb = 0;                 // my segment: lanes [segB, segE), binary node, where it begins in the id array
@@ -69,7 +72,7 @@ __device__ void micro_flush(uint32_t* R, uint32_t W, unsigned long long* s_key, 
         continue;
       }
       if (lane >= nAct && lane < nAct + n) { p = load_prim(src + r.begin + (lane - nAct)); segB = nAct; segE = nAct + n; node = r.bnode; gsb = r.begin; }
-      if (lane == nAct) for (int d = 0; d < 3; d++) { CB[nAct * 6u + d] = zlo(r.cmin[d]); CB[nAct * 6u + 3 + d] = zhi(r.cmax[d]); }
+      if (lane == nAct) for (int d = 0; d < 3; d++) { CB[d * 64 + nAct] = zlo(r.cmin[d]); CB[(3 + d) * 64 + nAct] = zhi(r.cmax[d]); }
       nAct += n;
     }
     if (nAct == 0u) break;
@@ -83,30 +86,26 @@ __device__ void micro_flush(uint32_t* R, uint32_t W, unsigned long long* s_key, 
     float ofs[3] = {0, 0, 0}, scale[3] = {0, 0, 0}; uint32_t nb = 4;
     if (act) {
       float cmin[3], cmax[3];
-      for (int d = 0; d < 3; d++) { cmin[d] = unzlo(CB[segB * 6u + d]); cmax[d] = unzhi(CB[segB * 6u + 3 + d]); }
+      for (int d = 0; d < 3; d++) { cmin[d] = unzlo(CB[d * 64 + segB]); cmax[d] = unzhi(CB[(3 + d) * 64 + segB]); }
       const Mapping m = make_mapping(n, cmin, cmax);
       for (int d = 0; d < 3; d++) { ofs[d] = m.ofs[d]; scale[d] = m.scale[d]; }
       nb = m.nb;
     }
     MICRO_SYNC();                                             // everybody has read the centroid bounds and is done with the exchange buffer
-    if (W == 32u) {
 #pragma unroll
-      for (uint32_t i = 0; i < 8u; i++) ((uint4*)R)[i * 64u + lane] = make_uint4(0u, 0u, 0u, 0u);
-    } else {
-#pragma unroll
-      for (uint32_t i = 0; i < 12u; i++) ((uint4*)R)[i * 64u + lane] = make_uint4(0u, 0u, 0u, 0u);
-    }
+    for (uint32_t i = 0; i < (W == 32u ? 7u : 12u); i++) ((uint4*)R)[i * 64u + lane] = make_uint4(0u, 0u, 0u, 0u);   // W = 32: the seven planes are the first 7 KB
     s_key[lane] = ~0ull;
     MICRO_SYNC();
     // ---- L1: bin (BinInfoT::bin, heuristic_binning.h:210-257)
-    uint32_t* const sb = R + segB * W;
+    constexpr uint32_t SS = W / 8u, P = 64u * SS;                // slots per lane, words per plane
+    uint32_t* const sb = R + segB * SS;
     if (act) {
       for (int d = 0; d < 3; d++) {
         const int b = bin_clamped(p.lo[d] + p.hi[d], ofs[d], scale[d], nb);
-        uint32_t* e = sb + ((uint32_t)d * nb + (uint32_t)b) * 8u;     // 8-word entries: lo.xyz hi.xyz count pad (two 16-byte reads)
-        atomicMax(&e[0], zlo(p.lo[0])); atomicMax(&e[1], zlo(p.lo[1])); atomicMax(&e[2], zlo(p.lo[2]));
-        atomicMax(&e[3], zhi(p.hi[0])); atomicMax(&e[4], zhi(p.hi[1])); atomicMax(&e[5], zhi(p.hi[2]));
-        atomicAdd(&e[6], 1u);
+        uint32_t* e = sb + (uint32_t)d * nb + (uint32_t)b;
+        atomicMax(&e[0], zlo(p.lo[0])); atomicMax(&e[P], zlo(p.lo[1])); atomicMax(&e[2u * P], zlo(p.lo[2]));
+        atomicMax(&e[3u * P], zhi(p.hi[0])); atomicMax(&e[4u * P], zhi(p.hi[1])); atomicMax(&e[5u * P], zhi(p.hi[2]));
+        atomicAdd(&e[6u * P], 1u);
       }
     }
     MICRO_SYNC();
@@ -119,14 +118,19 @@ __device__ void micro_flush(uint32_t* R, uint32_t W, unsigned long long* s_key, 
       // once (8 x 16 bytes) instead of once per candidate
       for (uint32_t axis = lane - segB; axis < 3u; axis += n) {
         if (sel3(axis, scale[0], scale[1], scale[2]) == 0.0f) continue;          // mapping.invalid(dim) :375
-        const uint4* e = (const uint4*)(sb + axis * 32u);
+        const uint32_t* e = sb + axis * 4u;                                     // plane k holds word k of the four bins side by side
+        uint32_t q[7][4];
+#pragma unroll
+        for (int k = 0; k < 7; k++) {
+          if (W == 32u) { const uint4 x = *(const uint4*)(e + k * P); q[k][0] = x.x; q[k][1] = x.y; q[k][2] = x.z; q[k][3] = x.w; }   // (16-byte aligned: 4 slots per lane)
+          else { const uint2 x = *(const uint2*)(e + k * P), y = *(const uint2*)(e + k * P + 2u); q[k][0] = x.x; q[k][1] = x.y; q[k][2] = y.x; q[k][3] = y.y; }
+        }
         float lo[4][3], hi[4][3]; uint32_t cn[4];                             // (an empty bin holds zeros: they decode to quiet NaNs, which vmin / vmax drop)
 #pragma unroll
         for (int b = 0; b < 4; b++) {
-          const uint4 x = e[2 * b], y = e[2 * b + 1];
-          cn[b] = y.z;
-          lo[b][0] = unzlo(x.x); lo[b][1] = unzlo(x.y); lo[b][2] = unzlo(x.z);
-          hi[b][0] = unzhi(x.w); hi[b][1] = unzhi(y.x); hi[b][2] = unzhi(y.y);
+          cn[b] = q[6][b];
+          lo[b][0] = unzlo(q[0][b]); lo[b][1] = unzlo(q[1][b]); lo[b][2] = unzlo(q[2][b]);
+          hi[b][0] = unzhi(q[3][b]); hi[b][1] = unzhi(q[4][b]); hi[b][2] = unzhi(q[5][b]);
         }
         float slo[4][3], shi[4][3]; uint32_t sn[4];                            // suffix: bins pos..3
         for (int d = 0; d < 3; d++) { slo[3][d] = lo[3][d]; shi[3][d] = hi[3][d]; } sn[3] = cn[3];
@@ -159,13 +163,12 @@ __device__ void micro_flush(uint32_t* R, uint32_t W, unsigned long long* s_key, 
         // both sides are merged as they lie in the bins (atomicMax encodings, zero = nothing) and decoded once
         uint32_t zl[6] = {0u, 0u, 0u, 0u, 0u, 0u}, zr[6] = {0u, 0u, 0u, 0u, 0u, 0u};
         uint32_t lN = 0, rN = 0;
-        const uint4* e = (const uint4*)(sb + axis * nb * 8u);
+        const uint32_t* e = sb + axis * nb;
         for (uint32_t b = 0; b < nb; b++) {
-          const uint4 x = e[2u * b], y = e[2u * b + 1u];
           const bool isL = b < pos;
-          const uint32_t v[6] = {x.x, x.y, x.z, x.w, y.x, y.y};
+          const uint32_t v[6] = {e[b], e[P + b], e[2u * P + b], e[3u * P + b], e[4u * P + b], e[5u * P + b]}, cnt = e[6u * P + b];
           for (int k = 0; k < 6; k++) { zl[k] = max(zl[k], isL ? v[k] : 0u); zr[k] = max(zr[k], isL ? 0u : v[k]); }
-          lN += isL ? y.z : 0u; rN += isL ? 0u : y.z;
+          lN += isL ? cnt : 0u; rN += isL ? 0u : cnt;
         }
         if (lN == 0u || rN == 0u) continue;
         float llo[3], lhi[3], rlo[3], rhi[3];
@@ -183,23 +186,23 @@ __device__ void micro_flush(uint32_t* R, uint32_t W, unsigned long long* s_key, 
     if (act && key != ~0ull) atomicMin(&s_key[segB], key);
     MICRO_SYNC();                                             // bins are dead from here on: R now holds split records + exchange buffer + next centroid bounds
     const unsigned long long win = act ? s_key[segB] : 0ull;
-    for (int k = 0; k < 6; k++) CB[lane * 6u + k] = 0u;          // (zero = the identity of the atomicMax encodings)
+    for (int k = 0; k < 6; k++) CB[k * 64 + lane] = 0u;          // (zero = the identity of the atomicMax encodings)
     const bool fb = act && win == ~0ull;                          // no valid candidate -> median split (split_template :144-147)
-    uint32_t* const rec = R + segB * 8u;
+    uint32_t* const rec = R + segB;                               // word j of my segment's record: rec[j * 64] (planes: neighbouring segments, neighbouring banks)
     if (act && !fb && key == win) {
       const uint32_t nb1 = nb - 1u, axis = (bestC >= nb1 ? 1u : 0u) + (bestC >= 2u * nb1 ? 1u : 0u), pos = bestC - axis * nb1 + 1u;
-      rec[0] = axis | (pos << 8); rec[1] = bestNL; rec[2] = __float_as_uint(bestSah);
-      for (int d = 0; d < 3; d++) { rec[4 + d] = __float_as_uint(bl[d]); rec[7 + d] = __float_as_uint(bh[d]); rec[10 + d] = __float_as_uint(rl[d]); rec[13 + d] = __float_as_uint(rh[d]); }
+      rec[0] = axis | (pos << 8); rec[64] = bestNL; rec[128] = __float_as_uint(bestSah);
+      for (int d = 0; d < 3; d++) { rec[(3 + d) * 64] = __float_as_uint(bl[d]); rec[(6 + d) * 64] = __float_as_uint(bh[d]); rec[(9 + d) * 64] = __float_as_uint(rl[d]); rec[(12 + d) * 64] = __float_as_uint(rh[d]); }
     }
     if (fb && lane == segB) {
-      rec[0] = 1u << 16; rec[1] = n >> 1; rec[2] = __float_as_uint(__builtin_inff());      // (begin + end) / 2 - begin
-      for (int k = 4; k < 16; k++) rec[k] = 0u;
+      rec[0] = 1u << 16; rec[64] = n >> 1; rec[128] = __float_as_uint(__builtin_inff());      // (begin + end) / 2 - begin
+      for (int k = 3; k < 15; k++) rec[k * 64] = 0u;
     }
     MICRO_SYNC();
     if (__ballot(fb) != 0ull) {                                   // child geometry bounds of a median split: reduce over the triangles
       if (fb) {
-        const uint32_t o = lane < segB + rec[1] ? 4u : 10u;
-        for (int d = 0; d < 3; d++) { atomicMax(&rec[o + d], zlo(p.lo[d])); atomicMax(&rec[o + 3 + d], zhi(p.hi[d])); }
+        const uint32_t o = lane < segB + rec[64] ? 3u : 9u;
+        for (int d = 0; d < 3; d++) { atomicMax(&rec[(o + d) * 64u], zlo(p.lo[d])); atomicMax(&rec[(o + 3u + d) * 64u], zhi(p.hi[d])); }
       }
       MICRO_SYNC();
     }
@@ -207,7 +210,7 @@ __device__ void micro_flush(uint32_t* R, uint32_t W, unsigned long long* s_key, 
     //      A child of <= min_leaf triangles is a leaf: its triangles write their ids and leave; the others close ranks.
     bool left = false; uint32_t nL = 0;
     if (act) {
-      const uint32_t w0 = rec[0], dim = w0 & 3u, pos = (w0 >> 8) & 0xFFu; nL = rec[1];
+      const uint32_t w0 = rec[0], dim = w0 & 3u, pos = (w0 >> 8) & 0xFFu; nL = rec[64];
       const float c2 = sel3(dim, p.lo[0] + p.hi[0], p.lo[1] + p.hi[1], p.lo[2] + p.hi[2]);
       left = (w0 >> 16) ? (lane < segB + nL) : (bin_unsafe(c2, sel3(dim, ofs[0], ofs[1], ofs[2]), sel3(dim, scale[0], scale[1], scale[2])) < (int)pos);
     }
@@ -229,18 +232,18 @@ __device__ void micro_flush(uint32_t* R, uint32_t W, unsigned long long* s_key, 
         if (leafHead) ((uint4*)(bnodes + nNode))[2] = make_uint4(NIL, NIL, __float_as_uint(__builtin_inff()), 0u);
       } else {
         const uint32_t cB = nSegB - below, cpos = npos - below;
-        for (int d = 0; d < 3; d++) { const float cc = p.lo[d] + p.hi[d]; atomicMax(&CB[cB * 6u + d], zlo(cc)); atomicMax(&CB[cB * 6u + 3 + d], zhi(cc)); }
-        uint32_t* X = R + 512u + cpos;
+        for (int d = 0; d < 3; d++) { const float cc = p.lo[d] + p.hi[d]; atomicMax(&CB[d * 64 + cB], zlo(cc)); atomicMax(&CB[(3 + d) * 64 + cB], zhi(cc)); }
+        uint32_t* X = R + 960u + cpos;
         X[0] = __float_as_uint(p.lo[0]); X[64] = __float_as_uint(p.lo[1]); X[128] = __float_as_uint(p.lo[2]); X[192] = p.geom;
         X[256] = __float_as_uint(p.hi[0]); X[320] = __float_as_uint(p.hi[1]); X[384] = __float_as_uint(p.hi[2]); X[448] = p.prim;
         X[512] = cB | ((cB + cs) << 8); X[576] = nNode; X[640] = ngsb;
       }
       if (lane == segB) {                                        // one lane per segment: my links, my children's boxes and ranges
         float cb[12];
-        for (int k = 0; k < 12; k++) cb[k] = __uint_as_float(rec[4 + k]);
-        if ((rec[0] >> 16) != 0u) for (int k = 0; k < 12; k++) cb[k] = (k % 6) < 3 ? unzlo(rec[4 + k]) : unzhi(rec[4 + k]);   // (median split: reduced with the atomicMax encodings)
+        for (int k = 0; k < 12; k++) cb[k] = __uint_as_float(rec[(3 + k) * 64]);
+        if ((rec[0] >> 16) != 0u) for (int k = 0; k < 12; k++) cb[k] = (k % 6) < 3 ? unzlo(rec[(3 + k) * 64]) : unzhi(rec[(3 + k) * 64]);   // (median split: reduced with the atomicMax encodings)
         const uint32_t L = node + 1u, Rr = node + 2u * nL;
-        ((uint4*)(bnodes + node))[2] = make_uint4(L, Rr, rec[2], 0u);
+        ((uint4*)(bnodes + node))[2] = make_uint4(L, Rr, rec[128], 0u);
         ((float4*)(bnodes + L))[0] = make_float4(cb[0], cb[1], cb[2], __uint_as_float(gsb));
         ((float4*)(bnodes + L))[1] = make_float4(cb[3], cb[4], cb[5], __uint_as_float(gsb + nL));
         ((float4*)(bnodes + Rr))[0] = make_float4(cb[6], cb[7], cb[8], __uint_as_float(gsb + nL));
@@ -252,7 +255,7 @@ __device__ void micro_flush(uint32_t* R, uint32_t W, unsigned long long* s_key, 
     MICRO_SYNC();
     // ---- L5: pick up the triangle that moved to my lane
     if (lane < nAct) {
-      const uint32_t* X = R + 512u + lane;
+      const uint32_t* X = R + 960u + lane;
       p.lo[0] = __uint_as_float(X[0]); p.lo[1] = __uint_as_float(X[64]); p.lo[2] = __uint_as_float(X[128]); p.geom = X[192];
       p.hi[0] = __uint_as_float(X[256]); p.hi[1] = __uint_as_float(X[320]); p.hi[2] = __uint_as_float(X[384]); p.prim = X[448];
       segB = X[512] & 0xFFu; segE = X[512] >> 8; node = X[576]; gsb = X[640];
@@ -381,7 +384,8 @@ __global__ __launch_bounds__(64) void small_build(const SmallEntry* entries, Pri
   }
   if (iter >= (1u << 20)) done = true;
   __syncthreads();
-  micro_flush(s_R, W, s_key, s_roots, numRoots, bufA, bufB, bnodes, finalIds, ctr, prm, lane);
+  if (W == 32u) micro_flush<32u>(s_R, s_key, s_roots, numRoots, bufA, bufB, bnodes, finalIds, ctr, prm, lane);
+  else micro_flush<48u>(s_R, s_key, s_roots, numRoots, bufA, bufB, bnodes, finalIds, ctr, prm, lane);
   numRoots = 0;
   }
 }
