@@ -20,11 +20,7 @@ __device__ __forceinline__ void bins_clear(uint32_t* bins, uint32_t tid, uint32_
   for (uint32_t w = tid; w < (uint32_t)BINS_WORDS; w += nthreads) { const uint32_t k = w % BINW; bins[w] = k < 3 ? ENC_POS_INF : (k < 6 ? ENC_NEG_INF : 0u); }
 }
 
-__device__ __forceinline__ uint32_t wave_uadd63(uint32_t v) {
-  v += dpp_u<0xB1, 0xF>(0u, v); v += dpp_u<0x4E, 0xF>(0u, v); v += dpp_u<0x114, 0xF>(0u, v);
-  v += dpp_u<0x118, 0xF>(0u, v); v += dpp_u<0x142, 0xA>(0u, v); v += dpp_u<0x143, 0xC>(0u, v);
-  return v;
-}
+__device__ __forceinline__ uint32_t wave_uadd63(uint32_t v) { asm volatile(MI355_WAVE_REDUCE63("v_add_u32_dpp") : "+v"(v)); return v; }
 
 // BinInfoT::bin (heuristic_binning.h:210-257) with run merging in front of the bins.  Same-word LDS atomics are what the binning
 // kernels wait for (PMC: SQ_WAIT_INST_LDS = 73 % of top_bin's wave cycles with one atomic per triangle, profiles/r01_build_history.md).
@@ -154,6 +150,34 @@ __device__ __forceinline__ uint32_t row_umax15(uint32_t v) {
   v = max(v, dpp_u<0x111, 0xF>(v, v)); v = max(v, dpp_u<0x112, 0xF>(v, v)); v = max(v, dpp_u<0x114, 0xF>(v, v)); v = max(v, dpp_u<0x118, 0xF>(v, v));
   return v;
 }
+// The same reductions with the DPP operand folded into the min / max (v_min_u32_dpp dst, dst, dst row_shr:k -- a lane without a source keeps its value).
+// The compiler does not fold them: each step of row_umin15 comes out as v_mov + v_mov_dpp + v_min and an s_nop (504 of the 656 VALU instructions top_bin
+// spends on a batch of 64 triangles, at 73 % VALU busy: profiles/r03_pmc_top_bin.md).  A DPP read needs two wait states after the VALU write of its
+// source; with several values in one block the other values' instructions are those wait states.
+#define MI355_DPP_ROW4(OP, R) \
+  OP " %" #R ", %" #R ", %" #R " row_shr:1 row_mask:0xf bank_mask:0xf\n"
+__device__ __forceinline__ void row_minmax15(uint32_t& mn, uint32_t& mx) {                // both end up in lane 15 of every row
+  asm volatile("s_nop 1\n"
+               "v_min_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n v_max_u32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n s_nop 0\n"
+               "v_min_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n v_max_u32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n s_nop 0\n"
+               "v_min_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n v_max_u32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n s_nop 0\n"
+               "v_min_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n v_max_u32_dpp %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf\n"
+               : "+v"(mn), "+v"(mx));
+}
+// two boxes at once: a[0..2] / c[0..2] are reduced with min, a[3..5] / c[3..5] with max
+__device__ __forceinline__ void row_boxes15(uint32_t (&a)[6], uint32_t (&c)[6]) {
+#define MI355_STEP(S) \
+  "v_min_u32_dpp %0, %0, %0 row_shr:" #S " row_mask:0xf bank_mask:0xf\n v_min_u32_dpp %1, %1, %1 row_shr:" #S " row_mask:0xf bank_mask:0xf\n" \
+  "v_min_u32_dpp %2, %2, %2 row_shr:" #S " row_mask:0xf bank_mask:0xf\n v_max_u32_dpp %3, %3, %3 row_shr:" #S " row_mask:0xf bank_mask:0xf\n" \
+  "v_max_u32_dpp %4, %4, %4 row_shr:" #S " row_mask:0xf bank_mask:0xf\n v_max_u32_dpp %5, %5, %5 row_shr:" #S " row_mask:0xf bank_mask:0xf\n" \
+  "v_min_u32_dpp %6, %6, %6 row_shr:" #S " row_mask:0xf bank_mask:0xf\n v_min_u32_dpp %7, %7, %7 row_shr:" #S " row_mask:0xf bank_mask:0xf\n" \
+  "v_min_u32_dpp %8, %8, %8 row_shr:" #S " row_mask:0xf bank_mask:0xf\n v_max_u32_dpp %9, %9, %9 row_shr:" #S " row_mask:0xf bank_mask:0xf\n" \
+  "v_max_u32_dpp %10, %10, %10 row_shr:" #S " row_mask:0xf bank_mask:0xf\n v_max_u32_dpp %11, %11, %11 row_shr:" #S " row_mask:0xf bank_mask:0xf\n"
+  asm volatile("s_nop 1\n" MI355_STEP(1) MI355_STEP(2) MI355_STEP(4) MI355_STEP(8)
+               : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]));
+#undef MI355_STEP
+}
+#undef MI355_DPP_ROW4
 __device__ __forceinline__ void bins_add_rows(uint32_t* bins, const Mapping& m, const PrimRef& p, bool valid, uint32_t lane) {
   uint32_t c[6];
   for (int k = 0; k < 3; k++) { c[k] = enc(p.lo[k]); c[3 + k] = enc(p.hi[k]); }
@@ -164,14 +188,13 @@ __device__ __forceinline__ void bins_add_rows(uint32_t* bins, const Mapping& m, 
   for (int d = 0; d < 3; d++) {
     const uint32_t b = valid ? (uint32_t)bin_clamped(p.lo[d] + p.hi[d], m.ofs[d], m.scale[d], m.nb) : 0u;
     // the row's lowest and highest bin (lane 15 holds the reduction; everybody reads it from there)
-    const uint32_t bmin = (uint32_t)__shfl((int)row_umin15(b), (int)(lane | 15u), 64), bmax = (uint32_t)__shfl((int)row_umax15(b), (int)(lane | 15u), 64);
+    uint32_t rmn = b, rmx = b; row_minmax15(rmn, rmx);
+    const uint32_t bmin = (uint32_t)__shfl((int)rmn, (int)(lane | 15u), 64), bmax = (uint32_t)__shfl((int)rmx, (int)(lane | 15u), 64);
     const bool inLo = rowFull && b == bmin, inHi = rowFull && b == bmax && bmax != bmin;
     // 16 consecutive triangles sit in one bin or straddle one boundary: two groups cover the row; a lane strictly between goes alone
     uint32_t lo[6], hi[6];
-    for (int k = 0; k < 3; k++) {
-      lo[k] = row_umin15(inLo ? c[k] : 0xFFFFFFFFu); lo[3 + k] = row_umax15(inLo ? c[3 + k] : 0u);
-      hi[k] = row_umin15(inHi ? c[k] : 0xFFFFFFFFu); hi[3 + k] = row_umax15(inHi ? c[3 + k] : 0u);
-    }
+    for (int k = 0; k < 3; k++) { lo[k] = inLo ? c[k] : 0xFFFFFFFFu; lo[3 + k] = inLo ? c[3 + k] : 0u; hi[k] = inHi ? c[k] : 0xFFFFFFFFu; hi[3 + k] = inHi ? c[3 + k] : 0u; }
+    row_boxes15(lo, hi);
     const uint32_t nLo = (uint32_t)__popcll((__ballot(inLo) >> rowBase) & 0xFFFFull), nHi = (uint32_t)__popcll((__ballot(inHi) >> rowBase) & 0xFFFFull);
     if ((lane & 15u) == 15u && rowFull) {
       uint32_t* e = bins + (d * NBINS + bmin) * BINW;
@@ -193,11 +216,6 @@ __device__ __forceinline__ void bins_add_rows(uint32_t* bins, const Mapping& m, 
     }
   }
 }
-
-// v_min_f32 / v_max_f32 as they are: fminf / fmaxf of values that come out of a bit cast are preceded by a canonicalising v_max x, x each (294 of the
-// kernel's 3100 VALU instructions); a quiet NaN operand loses against a number either way, which lets empty bins decode to NaN and drop out
-__device__ __forceinline__ float vmin(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-__device__ __forceinline__ float vmax(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 
 struct SplitResult { float sah; int dim, pos; uint32_t nL; float llo[3], lhi[3], rlo[3], rhi[3]; };
 

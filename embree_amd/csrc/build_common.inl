@@ -60,6 +60,11 @@ struct Params { uint32_t shift, minLeaf, maxLeaf, small; float travCost, intCost
 // order-preserving float <-> uint so that integer atomicMin/Max reduce floats exactly
 __device__ __forceinline__ uint32_t enc(float f) { uint32_t u = __float_as_uint(f); return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u); }
 __device__ __forceinline__ float dec(uint32_t u) { return __uint_as_float(u ^ ((u >> 31) ? 0x80000000u : 0xFFFFFFFFu)); }
+// v_min_f32 / v_max_f32 as they are: fminf / fmaxf of values that come out of a bit cast are preceded by a canonicalising v_max x, x each (294 of the
+// kernel's 3100 VALU instructions); a quiet NaN operand loses against a number either way, which lets empty bins decode to NaN and drop out
+__device__ __forceinline__ float vmin(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float vmax(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
 __device__ __forceinline__ float half_area3(float dx, float dy, float dz) { return fmaf(dx, dy + dz, dy * dz); }  // common/math/vec3fa.h:349
 __device__ __forceinline__ float sel3(uint32_t d, float a, float b, float c) { return d == 0u ? a : (d == 1u ? b : c); }   // no dynamically indexed register arrays (scratch)
 __device__ __forceinline__ bool valid_f(float x) { return x > -1.844E18f && x < 1.844E18f; }  // isvalid, FLT_LARGE constants.h:21
@@ -81,13 +86,11 @@ __device__ __forceinline__ void store_prim(PrimRef* p, const PrimRef& r) {
 template <int CTRL, int ROWMASK> __device__ __forceinline__ uint32_t dpp_u(uint32_t old, uint32_t v) {
   return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, ROWMASK, 0xF, false);
 }
-__device__ __forceinline__ uint32_t wave_umin63(uint32_t v) {
-  v = min(v, dpp_u<0xB1, 0xF>(v, v)); v = min(v, dpp_u<0x4E, 0xF>(v, v)); v = min(v, dpp_u<0x114, 0xF>(v, v));
-  v = min(v, dpp_u<0x118, 0xF>(v, v)); v = min(v, dpp_u<0x142, 0xA>(v, v)); v = min(v, dpp_u<0x143, 0xC>(v, v));
-  return v;
-}
-__device__ __forceinline__ uint32_t wave_umax63(uint32_t v) {
-  v = max(v, dpp_u<0xB1, 0xF>(v, v)); v = max(v, dpp_u<0x4E, 0xF>(v, v)); v = max(v, dpp_u<0x114, 0xF>(v, v));
-  v = max(v, dpp_u<0x118, 0xF>(v, v)); v = max(v, dpp_u<0x142, 0xA>(v, v)); v = max(v, dpp_u<0x143, 0xC>(v, v));
-  return v;
-}
+// (v_<op>_dpp dst, dst, dst: the DPP operand folded into the operation -- the compiler emits v_mov + v_mov_dpp + v_<op> per step; a lane without a source,
+// or in a row the row mask leaves out, keeps its value; two wait states between a VALU write and the DPP read of the same register)
+#define MI355_WAVE_REDUCE63(OP) \
+  "s_nop 1\n " OP " %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n s_nop 1\n " OP " %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n" \
+  "s_nop 1\n " OP " %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n s_nop 1\n " OP " %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n" \
+  "s_nop 1\n " OP " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n s_nop 1\n " OP " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
+__device__ __forceinline__ uint32_t wave_umin63(uint32_t v) { asm volatile(MI355_WAVE_REDUCE63("v_min_u32_dpp") : "+v"(v)); return v; }
+__device__ __forceinline__ uint32_t wave_umax63(uint32_t v) { asm volatile(MI355_WAVE_REDUCE63("v_max_u32_dpp") : "+v"(v)); return v; }

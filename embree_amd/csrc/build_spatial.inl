@@ -57,11 +57,11 @@ __device__ __forceinline__ void split_triangle(const float (&v)[3][3], uint32_t 
   for (int e = 0; e < 3; e++) {
     const int e1 = e == 2 ? 0 : e + 1;
     const float a0 = sel3(dim, v[e][0], v[e][1], v[e][2]), a1 = sel3(dim, v[e1][0], v[e1][1], v[e1][2]);
-    if (a0 <= pos) for (int d = 0; d < 3; d++) { Llo[d] = fminf(Llo[d], v[e][d]); Lhi[d] = fmaxf(Lhi[d], v[e][d]); }
-    if (a0 >= pos) for (int d = 0; d < 3; d++) { Rlo[d] = fminf(Rlo[d], v[e][d]); Rhi[d] = fmaxf(Rhi[d], v[e][d]); }
+    if (a0 <= pos) for (int d = 0; d < 3; d++) { Llo[d] = vmin(Llo[d], v[e][d]); Lhi[d] = vmax(Lhi[d], v[e][d]); }
+    if (a0 >= pos) for (int d = 0; d < 3; d++) { Rlo[d] = vmin(Rlo[d], v[e][d]); Rhi[d] = vmax(Rhi[d], v[e][d]); }
     if ((a0 < pos && pos < a1) || (a1 < pos && pos < a0)) {
       const float t = (pos - a0) * (1.0f / (a1 - a0));
-      for (int d = 0; d < 3; d++) { const float c = fmaf(t, v[e1][d] - v[e][d], v[e][d]); Llo[d] = fminf(Llo[d], c); Lhi[d] = fmaxf(Lhi[d], c); Rlo[d] = fminf(Rlo[d], c); Rhi[d] = fmaxf(Rhi[d], c); }
+      for (int d = 0; d < 3; d++) { const float c = fmaf(t, v[e1][d] - v[e][d], v[e][d]); Llo[d] = vmin(Llo[d], c); Lhi[d] = vmax(Lhi[d], c); Rlo[d] = vmin(Rlo[d], c); Rhi[d] = vmax(Rhi[d], c); }
     }
   }
   // The cut points are interpolated (t = (pos - a0) / (a1 - a0), c = v + t (v' - v)): each coordinate carries a rounding error of a few ulp OF ITS MAGNITUDE, so
@@ -69,11 +69,11 @@ __device__ __forceinline__ void split_triangle(const float (&v)[3][3], uint32_t 
   // through, tests/test_gpu_round2.py::test_fast_mode_far_from_the_origin).  Both boxes are therefore widened by 4 ulp of their largest coordinate before they
   // are clamped to the piece that is being cut (whose box is conservative by induction: the first one is the triangle's exact box).
   for (int d = 0; d < 3; d++) {
-    const float eL = 4.76837158e-7f * fmaxf(fabsf(Llo[d]), fabsf(Lhi[d])), eR = 4.76837158e-7f * fmaxf(fabsf(Rlo[d]), fabsf(Rhi[d]));
+    const float eL = 4.76837158e-7f * vmax(fabsf(Llo[d]), fabsf(Lhi[d])), eR = 4.76837158e-7f * vmax(fabsf(Rlo[d]), fabsf(Rhi[d]));
     if (Llo[d] <= Lhi[d]) { Llo[d] -= eL; Lhi[d] += eL; }
     if (Rlo[d] <= Rhi[d]) { Rlo[d] -= eR; Rhi[d] += eR; }
   }
-  for (int d = 0; d < 3; d++) { Llo[d] = fmaxf(Llo[d], curLo[d]); Lhi[d] = fminf(Lhi[d], curHi[d]); Rlo[d] = fmaxf(Rlo[d], curLo[d]); Rhi[d] = fminf(Rhi[d], curHi[d]); }
+  for (int d = 0; d < 3; d++) { Llo[d] = vmax(Llo[d], curLo[d]); Lhi[d] = vmin(Lhi[d], curHi[d]); Rlo[d] = vmax(Rlo[d], curLo[d]); Rhi[d] = vmin(Rhi[d], curHi[d]); }
 }
 __device__ __forceinline__ bool box_empty(const float* lo, const float* hi) { return lo[0] > hi[0] || lo[1] > hi[1] || lo[2] > hi[2]; }
 __device__ __forceinline__ void load_tri_masked(const GeomDesc* geoms, const PrimRef& r, float (&v)[3][3]) {
@@ -181,13 +181,12 @@ __device__ __forceinline__ void sbins_add_rows(uint32_t* bins, int d, uint32_t b
   const uint32_t rowBase = lane & 48u;
   const bool rowFull = ((sm >> rowBase) & 0xFFFFull) == 0xFFFFull;
   const uint32_t bb = simple ? b : 0u;
-  const uint32_t bmin = (uint32_t)__shfl((int)row_umin15(bb), (int)(lane | 15u), 64), bmax = (uint32_t)__shfl((int)row_umax15(bb), (int)(lane | 15u), 64);
+  uint32_t rmn = bb, rmx = bb; row_minmax15(rmn, rmx);
+  const uint32_t bmin = (uint32_t)__shfl((int)rmn, (int)(lane | 15u), 64), bmax = (uint32_t)__shfl((int)rmx, (int)(lane | 15u), 64);
   const bool inLo = rowFull && bb == bmin, inHi = rowFull && bb == bmax && bmax != bmin;
   uint32_t lo[6], hi[6];
-  for (int k = 0; k < 3; k++) {
-    lo[k] = row_umin15(inLo ? c[k] : 0xFFFFFFFFu); lo[3 + k] = row_umax15(inLo ? c[3 + k] : 0u);
-    hi[k] = row_umin15(inHi ? c[k] : 0xFFFFFFFFu); hi[3 + k] = row_umax15(inHi ? c[3 + k] : 0u);
-  }
+  for (int k = 0; k < 3; k++) { lo[k] = inLo ? c[k] : 0xFFFFFFFFu; lo[3 + k] = inLo ? c[3 + k] : 0u; hi[k] = inHi ? c[k] : 0xFFFFFFFFu; hi[3 + k] = inHi ? c[3 + k] : 0u; }
+  row_boxes15(lo, hi);
   const uint32_t nLo = (uint32_t)__popcll((__ballot(inLo) >> rowBase) & 0xFFFFull), nHi = (uint32_t)__popcll((__ballot(inHi) >> rowBase) & 0xFFFFull);
   if ((lane & 15u) == 15u && rowFull) {
     uint32_t* e = bins + (d * SBINS + bmin) * SBINW;
@@ -302,7 +301,7 @@ __global__ __launch_bounds__(64) void spatial_best(Seg* segs, SegX* sx, const ui
     for (int i = SBINS - 1; i > 0; i--) {
       const uint32_t* e = B + (d * SBINS + i) * SBINW;
       cnt += e[7]; rC[i] = cnt;
-      for (int k = 0; k < 3; k++) { lo[k] = fminf(lo[k], dec(e[k])); hi[k] = fmaxf(hi[k], dec(e[3 + k])); }
+      for (int k = 0; k < 3; k++) { lo[k] = vmin(lo[k], dec(e[k])); hi[k] = vmax(hi[k], dec(e[3 + k])); }
       rA[i] = (lo[0] > hi[0] || lo[1] > hi[1] || lo[2] > hi[2]) ? 0.0f : half_area3(hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]);
     }
     for (int k = 0; k < 3; k++) { lo[k] = __builtin_inff(); hi[k] = -__builtin_inff(); }
@@ -310,7 +309,7 @@ __global__ __launch_bounds__(64) void spatial_best(Seg* segs, SegX* sx, const ui
     for (int i = 1; i < SBINS; i++) {
       const uint32_t* e = B + (d * SBINS + (i - 1)) * SBINW;
       cnt += e[6];
-      for (int k = 0; k < 3; k++) { lo[k] = fminf(lo[k], dec(e[k])); hi[k] = fmaxf(hi[k], dec(e[3 + k])); }
+      for (int k = 0; k < 3; k++) { lo[k] = vmin(lo[k], dec(e[k])); hi[k] = vmax(hi[k], dec(e[3 + k])); }
       const float lA = (lo[0] > hi[0] || lo[1] > hi[1] || lo[2] > hi[2]) ? 0.0f : half_area3(hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]);
       const float sah = fmaf(lA, (float)((cnt + add) >> prm.shift), rA[i] * (float)((rC[i] + add) >> prm.shift));
       if (sah < best) { best = sah; bpos = (uint32_t)i; bl = cnt; br = rC[i]; }
