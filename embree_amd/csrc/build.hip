@@ -413,7 +413,6 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
     if (spatial) LAUNCH(spatial_partition, dim3(chunkBound), dim3(256), 0, st, cur, xcur, chunks.p, src, dst, dGeoms.p, ctr.p);
     LAUNCH(top_emit, dim3((segBound + 255u) / 256u), dim3(256), 0, st, cur, bnodes.p, nxt, small.p, ctr.p, prm,
            (level & 1u) ? 0u : 1u, maxSegs, maxSmall, (const SegX*)xcur, xnxt);
-    LAUNCH(top_advance, dim3(1), dim3(1), 0, st, ctr.p, maxSegs);
     Seg* t = cur; cur = nxt; nxt = t; SegX* tx = xcur; xcur = xnxt; xnxt = tx; level++;
   };
   if (numSegs && sahBuild) {
@@ -461,9 +460,9 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
     WideItem* t = wc; wc = wn; wn = t; wlevel++;
   };
   if (fast) {
-    // the depth of the wide tree is unknown here: 18 levels cover every scene measured so far (crown 12, powerplant 14); a deeper tree is finished below
-    // (every level enqueued beyond the last one costs three empty launches, ~13 us)
-    for (uint32_t i = 0; i < 18u; i++) enqueue_wide_level();
+    // the depth of the wide tree is unknown here: 16 levels cover every scene measured so far (crown 12, powerplant 13); a deeper tree is finished below
+    // (every level enqueued beyond the last one costs three empty launches, ~14 us)
+    for (uint32_t i = 0; i < 16u; i++) enqueue_wide_level();
     if (capturing) {                                             // end of the captured sequence: instantiate, keep, run
       hipGraph_t graph = nullptr;
       const hipError_t e = hipStreamEndCapture(st, &graph);
@@ -491,7 +490,7 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
     for (int d = 0; d < 3; d++) { info.bounds_lower[d] = decf(h.bounds[d]); info.bounds_upper[d] = decf(h.bounds[3 + d]); }
     info.top_levels = h.topLevels;
     bool redoLeaves = false;
-    while (h.wideCount[wlevel & 1u] != 0u) {                     // deeper than 24 levels: go on level by level, then write the leaf records again
+    while (h.wideCount[wlevel & 1u] != 0u) {                     // deeper than the levels enqueued: go on level by level, then write the leaf records again
       for (uint32_t i = 0; i < 4u; i++) enqueue_wide_level();
       SYNC_READ(h);
       if (h.overflow) return set_error(hipErrorOutOfMemory, "wide node pool overflow");
@@ -513,7 +512,7 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
   }
   info.num_triangles = n;
 #ifdef SM_STATS
-  fprintf(stderr, "[mi355 build] micro level passes %u, lanes in use %.1f of 64, passes with a set of >= 20: %u\n", h.padC[0], h.padC[0] ? (double)h.padC[1] / h.padC[0] : 0.0, h.padC[2]);
+  fprintf(stderr, "[mi355 build] micro level passes %u, lanes in use %.1f of 64\n", h.padC[0], h.padC[0] ? (double)h.padC[1] / h.padC[0] : 0.0);
 #endif
   const uint32_t depth = h.wideDepth;
 

@@ -52,7 +52,8 @@ struct Counters {
   unsigned long long areaFixed;                   // spatial-split builds: sum of the references' box areas / scene area, 2^-32 fixed point (build_spatial.inl)
   uint32_t compactFrom;                           // stable compaction: first position that moves (everything before the first hole stays where it is)
   uint32_t outlierCells, outlierPieces, outlierValid, outlierSkip;   // ... the places reserved for their pieces behind the references, the pieces that exist, the valid references counted, 1 = too many
-  uint32_t padC[3];
+  uint32_t emitBlocks;                            // top_emit: workgroups that are done with the level (the last one moves the work lists on)
+  uint32_t padC[2];
   uint32_t lvlStart[64];                          // first node of every level of the wide tree (numbering is breadth first): what a refit walks bottom-up
 };
 struct Params { uint32_t shift, minLeaf, maxLeaf, small; float travCost, intCost; uint32_t quality, spatial; };

@@ -154,7 +154,6 @@ __device__ void micro_flush(uint32_t* R, unsigned long long* s_key, const MicroR
       }
     } else if (act) {
 #ifdef SM_STATS
-      if (lane == (uint32_t)__builtin_ctzll(__ballot(act && nb != 4u))) atomicAdd(&ctr->padC[2], 1u);
 #endif
       const uint32_t nb1 = nb - 1u, ncand = 3u * nb1;
       for (uint32_t c = lane - segB; c < ncand; c += n) {

@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void top_partition(Seg* segs, const Chunk* chu
 __global__ void top_emit(const Seg* segs, BNode* bnodes, Seg* next, SmallEntry* small, Counters* ctr,
                          Params prm, uint32_t dstBuf, uint32_t maxNext, uint32_t maxSmall, const SegX* sx, SegX* nx) {
   const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= ctr->numSegs) return;
+  if (s < ctr->numSegs) {
   const Seg* sg = segs + s;
   const uint32_t capL = sx ? segx_cap_left(sx, s) : sg->nL;
   for (int side = 0; side < 2; side++) {
@@ -212,10 +212,17 @@ __global__ void top_emit(const Seg* segs, BNode* bnodes, Seg* next, SmallEntry* 
       if (nx) segx_child(nx, k, childExtEnd);
     }
   }
-}
-
-__global__ void top_advance(Counters* ctr, uint32_t maxNext) {      // end of a top level: next level's work list becomes current
-  if (ctr->numSegs) ctr->topLevels++;
-  if (ctr->numSegsNext > maxNext) ctr->overflow = 1u;
-  ctr->numSegs = ctr->numSegsNext < maxNext ? ctr->numSegsNext : maxNext; ctr->numSegsNext = 0; ctr->numChunks = 0;
+  }
+  // end of the level: the last workgroup to get here makes the next level's work list the current one (was a launch of its own: 21 x 4.8 us per commit).
+  // The counters the others advanced are read with an atomic: a plain load may be served from this XCD's L2, which does not see the other XCDs' atomics.
+  __syncthreads();
+  if (threadIdx.x == 0u) {
+    __threadfence();
+    if (atomicAdd(&ctr->emitBlocks, 1u) == gridDim.x - 1u) {
+      const uint32_t nextSegs = atomicAdd(&ctr->numSegsNext, 0u);
+      if (ctr->numSegs) ctr->topLevels++;
+      if (nextSegs > maxNext) ctr->overflow = 1u;
+      ctr->numSegs = nextSegs < maxNext ? nextSegs : maxNext; ctr->numSegsNext = 0; ctr->numChunks = 0; ctr->emitBlocks = 0;
+    }
+  }
 }

@@ -446,7 +446,7 @@ def test_device_filter_rule_kinds_and_instances(api, dev):
 
 
 def test_deep_tree_beyond_the_enqueued_levels(api, dev, restate):
-    """The one-round-trip commit enqueues 18 levels of the wide collapse; a tree that is deeper is finished level by level afterwards and its leaf records are
+    """The one-round-trip commit enqueues 16 levels of the wide collapse; a tree that is deeper is finished level by level afterwards and its leaf records are
     written again.  Triangles whose size and position double from one to the next make every SAH split peel one triangle off: a tree as deep as it gets."""
     n = 460                                                   # sizes up to 2^57.5: inside the reference's validity limit of 1.844e18
     vs, ts = [], []
