@@ -619,6 +619,8 @@ def main():
                             "node_step_clock_share": round(st["node_step_clocks"] / max(1, st["loop_clocks"]), 4)},
                 "note": "algorithmic bytes (SURVEY 8d) = rays x (48 read + 52 written on a hit) + node visits x 80 + triangle records x 48, visit counts from the counting build of the same "
                         "kernel on the same rays. Most of these bytes are served by L1 / L2 / Infinity Cache: hbm_counter_from_profile is what reaches the memory side."}
+        if roof["frac"] > 1.0:
+            roof["note"] += " frac > 1 here: the kernel consumes its algorithmic bytes faster than HBM could deliver them, because node and triangle reads are mostly cache hits."
         # what binds (profiles/r02_trace_history.md): every lane that fetches a 16-byte piece of a node / triangle / ray costs the CU's address path one slot, whatever
         # the width and whatever the cache level that answers: 5 per node visit, 3 per triangle test, 3 per ray read + the hit record stores
         acc = 5 * st["nodes"] + 3 * st["tris"] + M * 3 + (nhit * 4 if not shadow else nhit)

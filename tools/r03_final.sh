@@ -1,9 +1,11 @@
 #!/bin/bash
 # end-of-round measurements: the driver's bench command, the default one, kernel stats + PMC of the same kernel source, the all-configs table
 O=gpurun_out/r03z; mkdir -p $O
+# (PMC first: the bench line only takes counters collected for exactly this kernel source)
+bash tools/profile_round.sh r03 2>&1 | tail -3
+cp gpurun_out/r03_pmc_trace.json profiles/pmc_bench_latest.json 2>/dev/null
 timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench_driver.json 2> $O/bench_driver.err; echo "bench(driver cmd) rc=$?"
 timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "bench(default) rc=$?"
-bash tools/profile_round.sh r03 2>&1 | tail -3
 timeout 900 python tests/gpu_configs.py > $O/configs.md 2> $O/configs.err
 # counters of the largest kernel of a commit (three commits per pass; the first one is dropped by the summary)
 tools/pmc_run.sh gpurun_out/r03_pmc_sb python $PWD/tests/gpu_build_only.py "" 3 > gpurun_out/r03_pmc_sb.log 2>&1
