@@ -26,6 +26,8 @@ constexpr uint32_t SPLIT_SHIFT = 27u;
 constexpr int SBINS = 16;                          // NUM_SPATIAL_BINS, kernels/builders/bvh_builder_sah.h:11
 constexpr int SBINW = 8;                           // lo.xyz, hi.xyz (ordered uint), numBegin, numEnd
 constexpr int SBINS_WORDS = 3 * SBINS * SBINW;     // 384 words per set
+constexpr int SSLOTS = 3 * SBINS;                  // in LDS (spatial_bin) the bins are eight PLANES of 48 slots, word k of (axis, bin) at k * 48 + axis * 16 + bin: the lanes of
+                                                   // an atomic fall on neighbouring banks (8-word records put them on 4 of the 32); the sets' bins in memory stay records
 
 struct SegX {                                      // what a set of the top phase carries in addition to Seg when spatial splits are on
   uint32_t extEnd;                                 // end of the set's capacity: [begin, end) references, [end, extEnd) extended range
@@ -143,8 +145,8 @@ __global__ void spatial_decide(const Seg* segs, SegX* sx, const BNode* bnodes, u
 // ---- SpatialBinInfo::bin2 (heuristic_spatial.h:160-222) over the chunks of the sets that try a spatial split
 __device__ __forceinline__ void sbin_extend(uint32_t* bins, int dim, int bin, const float* lo, const float* hi) {
   if (box_empty(lo, hi)) return;
-  uint32_t* e = bins + (dim * SBINS + bin) * SBINW;
-  for (int d = 0; d < 3; d++) { atomicMin(&e[d], enc(lo[d])); atomicMax(&e[3 + d], enc(hi[d])); }
+  uint32_t* e = bins + (dim * SBINS + bin);
+  for (int d = 0; d < 3; d++) { atomicMin(&e[d * SSLOTS], enc(lo[d])); atomicMax(&e[(3 + d) * SSLOTS], enc(hi[d])); }
 }
 // The chain of cuts bin2 makes for ONE reference with budget on ONE axis (:186-218): the reference is clipped bin by bin from its first to its last bin;
 // l = the bin it is counted to begin in (numBegin), rr = the bin it is counted to end in (numEnd) -- a plane p then sees it on the left iff l < p and on the
@@ -189,22 +191,22 @@ __device__ __forceinline__ void sbins_add_rows(uint32_t* bins, int d, uint32_t b
   row_boxes15(lo, hi);
   const uint32_t nLo = (uint32_t)__popcll((__ballot(inLo) >> rowBase) & 0xFFFFull), nHi = (uint32_t)__popcll((__ballot(inHi) >> rowBase) & 0xFFFFull);
   if ((lane & 15u) == 15u && rowFull) {
-    uint32_t* e = bins + (d * SBINS + bmin) * SBINW;
-    atomicMin(&e[0], lo[0]); atomicMin(&e[1], lo[1]); atomicMin(&e[2], lo[2]);
-    atomicMax(&e[3], lo[3]); atomicMax(&e[4], lo[4]); atomicMax(&e[5], lo[5]);
-    atomicAdd(&e[6], nLo); atomicAdd(&e[7], nLo);
+    uint32_t* e = bins + (d * SBINS + bmin);
+    atomicMin(&e[0], lo[0]); atomicMin(&e[SSLOTS], lo[1]); atomicMin(&e[2 * SSLOTS], lo[2]);
+    atomicMax(&e[3 * SSLOTS], lo[3]); atomicMax(&e[4 * SSLOTS], lo[4]); atomicMax(&e[5 * SSLOTS], lo[5]);
+    atomicAdd(&e[6 * SSLOTS], nLo); atomicAdd(&e[7 * SSLOTS], nLo);
     if (nHi) {
-      uint32_t* f = bins + (d * SBINS + bmax) * SBINW;
-      atomicMin(&f[0], hi[0]); atomicMin(&f[1], hi[1]); atomicMin(&f[2], hi[2]);
-      atomicMax(&f[3], hi[3]); atomicMax(&f[4], hi[4]); atomicMax(&f[5], hi[5]);
-      atomicAdd(&f[6], nHi); atomicAdd(&f[7], nHi);
+      uint32_t* f = bins + (d * SBINS + bmax);
+      atomicMin(&f[0], hi[0]); atomicMin(&f[SSLOTS], hi[1]); atomicMin(&f[2 * SSLOTS], hi[2]);
+      atomicMax(&f[3 * SSLOTS], hi[3]); atomicMax(&f[4 * SSLOTS], hi[4]); atomicMax(&f[5 * SSLOTS], hi[5]);
+      atomicAdd(&f[6 * SSLOTS], nHi); atomicAdd(&f[7 * SSLOTS], nHi);
     }
   }
   if (simple && !inLo && !inHi) {
-    uint32_t* e = bins + (d * SBINS + b) * SBINW;
-    atomicMin(&e[0], c[0]); atomicMin(&e[1], c[1]); atomicMin(&e[2], c[2]);
-    atomicMax(&e[3], c[3]); atomicMax(&e[4], c[4]); atomicMax(&e[5], c[5]);
-    atomicAdd(&e[6], 1u); atomicAdd(&e[7], 1u);
+    uint32_t* e = bins + (d * SBINS + b);
+    atomicMin(&e[0], c[0]); atomicMin(&e[SSLOTS], c[1]); atomicMin(&e[2 * SSLOTS], c[2]);
+    atomicMax(&e[3 * SSLOTS], c[3]); atomicMax(&e[4 * SSLOTS], c[4]); atomicMax(&e[5 * SSLOTS], c[5]);
+    atomicAdd(&e[6 * SSLOTS], 1u); atomicAdd(&e[7 * SSLOTS], 1u);
   }
 }
 // The clipping chains are not run where they are found: a reference that spans several bins of an axis is the exception in a batch of 64, its chain is
@@ -223,7 +225,7 @@ __global__ __launch_bounds__(256) void spatial_bin(const Seg* segs, const SegX* 
   Chunk ck = chunks[c0];
   const SegX* x = sx + ck.seg;
   if (!x->trySpatial) return;
-  for (uint32_t w = tid; w < (uint32_t)SBINS_WORDS; w += 256u) { const uint32_t k = w % SBINW; s_b[w] = k < 3 ? ENC_POS_INF : (k < 6 ? ENC_NEG_INF : 0u); }
+  for (uint32_t w = tid; w < (uint32_t)SBINS_WORDS; w += 256u) { const uint32_t k = w / SSLOTS; s_b[w] = k < 3 ? ENC_POS_INF : (k < 6 ? ENC_NEG_INF : 0u); }
   if (tid == 0u) s_numChains = 0u;
   __syncthreads();
   float ofs[3], scale[3], inv[3];
@@ -254,7 +256,7 @@ __global__ __launch_bounds__(256) void spatial_bin(const Seg* segs, const SegX* 
               else {                                              // (cannot happen with CHUNK = 2048; kept for other chunk sizes)
                 float tv[3][3]; bool have = false; int l2, r2;
                 spatial_chain<true>(tv, have, geoms, r, d, ofs[d], scale[d], inv[d], s_b, l2, r2);
-                atomicAdd(&s_b[(d * SBINS + l2) * SBINW + 6], 1u); atomicAdd(&s_b[(d * SBINS + r2) * SBINW + 7], 1u);
+                atomicAdd(&s_b[6 * SSLOTS + d * SBINS + l2], 1u); atomicAdd(&s_b[7 * SSLOTS + d * SBINS + r2], 1u);
               }
             }
           }
@@ -271,15 +273,15 @@ __global__ __launch_bounds__(256) void spatial_bin(const Seg* segs, const SegX* 
       const PrimRef r = load_prim(src + first + (task & 0x3FFFFFFFu));
       float tv[3][3]; bool have = false; int l2, r2;
       spatial_chain<true>(tv, have, geoms, r, (int)d, sel3(d, ofs[0], ofs[1], ofs[2]), sel3(d, scale[0], scale[1], scale[2]), sel3(d, inv[0], inv[1], inv[2]), s_b, l2, r2);
-      atomicAdd(&s_b[(d * SBINS + (uint32_t)l2) * SBINW + 6], 1u); atomicAdd(&s_b[(d * SBINS + (uint32_t)r2) * SBINW + 7], 1u);
+      atomicAdd(&s_b[6 * SSLOTS + d * SBINS + (uint32_t)l2], 1u); atomicAdd(&s_b[7 * SSLOTS + d * SBINS + (uint32_t)r2], 1u);
     }
   }
   __syncthreads();
   const Seg* sg = segs + ck.seg;
   uint32_t* g = sbins + (size_t)ck.seg * SBINS_WORDS;
-  if (first == sg->begin && last == sg->end) { for (uint32_t w = tid; w < (uint32_t)SBINS_WORDS; w += 256u) g[w] = s_b[w]; return; }   // the whole set: these ARE its bins
+  if (first == sg->begin && last == sg->end) { for (uint32_t w = tid; w < (uint32_t)SBINS_WORDS; w += 256u) g[w] = s_b[(w % SBINW) * SSLOTS + w / SBINW]; return; }   // the whole set: these ARE its bins
   for (uint32_t w = tid; w < (uint32_t)SBINS_WORDS; w += 256u) {
-    const uint32_t k = w % SBINW, v = s_b[w];
+    const uint32_t k = w % SBINW, v = s_b[k * SSLOTS + w / SBINW];
     if (k < 3) { if (v != ENC_POS_INF) atomicMin(&g[w], v); } else if (k < 6) { if (v != ENC_NEG_INF) atomicMax(&g[w], v); } else if (v) atomicAdd(&g[w], v);
   }
 }
