@@ -759,7 +759,9 @@ __global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceAr
 //   ANY of its rays visits, so it wins when neighbouring rays share most of their path (primary rays of a moderately tessellated scene, shadow rays towards
 //   one light) and loses on incoherent batches -- the flag is the application's promise, as in the reference.
 constexpr int PSTACK = 128;                 // stack entries per packet: <= 7 siblings left behind per level
-struct PacketTraceArgs { const uint4* nodes; const float4* tris; uint32_t hasRoot; char* rays; uint32_t count, stride; uint32_t* deferList; uint32_t* deferCount; volatile uint32_t* status; uint32_t minServed; const uint4* rules; };
+struct PacketTraceArgs { const uint4* nodes; const float4* tris; uint32_t hasRoot; char* rays; uint32_t count, stride; uint32_t* deferList; uint32_t* deferCount; volatile uint32_t* status; uint32_t minServed; const uint4* rules;
+                         uint32_t part, bailAbove; };   // part: 0 = every packet, 1 = the sample (every PACKET_SAMPLE-th), 2 = the others; bailAbove: part 2 defers everything when the sample deferred more than this
+constexpr uint32_t PACKET_SAMPLE = 32;
 
 template <bool ANY, bool ROBUST>
 __global__ __launch_bounds__(64) void trace_packet_kernel(PacketTraceArgs a) {
@@ -769,7 +771,25 @@ __global__ __launch_bounds__(64) void trace_packet_kernel(PacketTraceArgs a) {
   const float4* __restrict__ tris = a.tris;
   // packets are dealt round-robin to the resident waves (no cursor: a single atomic word hands out ~88 packets per microsecond, which alone would take 0.19 ms
   // for the 16384 packets of a 2^20-ray batch -- more than the whole Cornell-box launch)
-  for (uint32_t pk = blockIdx.x;; pk += gridDim.x) {
+  // A batch whose packets do not stay together costs the packet attempt on top of the per-lane traversal (crown stand-in, primary rays: 1.06 instead of
+  // 1.46 Grays/s).  Large batches are therefore traced in two launches: every 32nd packet first (part 1), then the rest (part 2) -- which looks at how
+  // many packets of the sample gave up and, if that is more than a quarter, hands all of its packets to the per-lane kernel at once.
+  if (a.part == 2u && *(volatile uint32_t*)a.deferCount > a.bailAbove) {
+    // (64 packets per atomic: one word takes ~88 appends per microsecond, 15,000 single appends would cost more than the packets they save)
+    for (uint32_t j0 = blockIdx.x * 64u;; j0 += gridDim.x * 64u) {
+      const uint32_t j = j0 + lane, pk = j + j / (PACKET_SAMPLE - 1u) + 1u;
+      const bool mine = (unsigned long long)pk * 64ull < a.count;
+      const unsigned long long mm = __ballot(mine);
+      if (mm == 0ull) break;
+      uint32_t base = 0u;
+      if (lane == 0u) base = atomicAdd(a.deferCount, (uint32_t)__popcll(mm));
+      base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+      if (mine) a.deferList[base + (uint32_t)__popcll(mm & ((1ull << lane) - 1ull))] = pk;
+    }
+    return;
+  }
+  for (uint32_t j = blockIdx.x;; j += gridDim.x) {
+    const uint32_t pk = a.part == 0u ? j : (a.part == 1u ? j * PACKET_SAMPLE : j + j / (PACKET_SAMPLE - 1u) + 1u);
     const unsigned long long first = (unsigned long long)pk * 64ull;
     if (first >= a.count) break;
     const uint32_t idx = (uint32_t)first + lane;
@@ -1076,8 +1096,18 @@ static int launch_trace_coherent(Bvh* b, void* d_rays, uint32_t count, size_t st
     a.nodes = (const uint4*)b->d_nodes; a.tris = (const float4*)b->d_tris; a.hasRoot = b->root != MI355_EMPTY_REF ? 1u : 0u;
     a.rays = (char*)d_rays; a.count = count; a.stride = (uint32_t)stride; a.deferCount = defer; a.deferList = defer + 64; a.status = sc->statusDev; a.rules = (const uint4*)b->d_rules;
     static const uint32_t minLanes = env_u32("MI355_PACKET_MIN_LANES", 48, 0, 64);
+    static const uint32_t sampleMin = env_u32("MI355_PACKET_SAMPLE_MIN", 1024, 0, 0x7FFFFFFF);   // packets: smaller batches are traced in one launch
     a.minServed = 4u * minLanes;
-    hipLaunchKernelGGL(fn, dim3(blocks), dim3(64), 0, s, a);
+    if (packets >= sampleMin && packets >= 4u * PACKET_SAMPLE) {
+      const uint32_t nSample = (uint32_t)((packets + PACKET_SAMPLE - 1u) / PACKET_SAMPLE), nRest = (uint32_t)packets - nSample;
+      a.part = 1u; a.bailAbove = 0xFFFFFFFFu;
+      hipLaunchKernelGGL(fn, dim3(nSample < maxBlocks ? nSample : maxBlocks), dim3(64), 0, s, a);
+      a.part = 2u; a.bailAbove = nSample / 4u;
+      hipLaunchKernelGGL(fn, dim3(nRest < maxBlocks ? nRest : maxBlocks), dim3(64), 0, s, a);
+    } else {
+      a.part = 0u; a.bailAbove = 0xFFFFFFFFu;
+      hipLaunchKernelGGL(fn, dim3(blocks), dim3(64), 0, s, a);
+    }
     HIP_TRY(hipGetLastError()); }
   // the packets that gave up (their rays untouched), traced per lane right behind: the count stays on the device, a launch that finds none ends at once
   return launch_trace(b, d_rays, count, stride, any, s, nullptr, nullptr, nullptr, defer + 64, defer);

@@ -246,6 +246,10 @@ def test_coherent_flag_gives_the_incoherent_answers(api, dev, flags):
     prim = W.crown_camera_rays(m, 256, 256)
     cases.append(("crown primary", m, None, prim))
     cases.append(("crown incoherent", m, None, W.incoherent_rays(50000, [2, 2, 1.5], seed=9)))
+    # batches of >= 1024 packets are traced as a sample (every 32nd packet) and the rest: the rest goes straight to the per-lane kernel when the sample's
+    # packets fell apart (incoherent rays), through the packet kernel otherwise (primary rays)
+    cases.append(("crown primary, sampled", m, None, W.crown_camera_rays(m, 640, 480)))
+    cases.append(("crown incoherent, sampled", m, None, W.incoherent_rays(300001, [2, 2, 1.5], seed=11)))
     m2 = W.synthetic_crown(num_phi=12)
     masks = [1 << (i % 3) for i in range(len(m2))]
     r = W.incoherent_rays(30001, [2, 2, 1.5], seed=3)
