@@ -208,7 +208,33 @@ __device__ __forceinline__ void bins_add_rows(uint32_t* bins, const Mapping& m, 
         atomicAdd(&f[6], nHi);
       }
     }
-    if (valid && !inLo && !inHi) {
+    bool alone = valid && !inLo && !inHi;
+    // where a bin is about as wide as a triangle (the lower levels) a row covers three or four bins and most of its lanes are "between": a second pair of
+    // groups -- the lowest and the highest bin of what is left -- takes them in (wave-uniform: only when at least eight lanes of the wave would go alone)
+    if (__popcll(__ballot(alone)) >= 8) {
+      const bool mid = rowFull && alone;
+      uint32_t r2n = mid ? b : 0xFFFFFFFFu, r2x = mid ? b : 0u; row_minmax15(r2n, r2x);
+      const uint32_t b2min = (uint32_t)__shfl((int)r2n, (int)(lane | 15u), 64), b2max = (uint32_t)__shfl((int)r2x, (int)(lane | 15u), 64);
+      const bool in2Lo = mid && b == b2min, in2Hi = mid && b == b2max && b2max != b2min;
+      uint32_t lo2[6], hi2[6];
+      for (int k = 0; k < 3; k++) { lo2[k] = in2Lo ? c[k] : 0xFFFFFFFFu; lo2[3 + k] = in2Lo ? c[3 + k] : 0u; hi2[k] = in2Hi ? c[k] : 0xFFFFFFFFu; hi2[3 + k] = in2Hi ? c[3 + k] : 0u; }
+      row_boxes15(lo2, hi2);
+      const uint32_t n2Lo = (uint32_t)__popcll((__ballot(in2Lo) >> rowBase) & 0xFFFFull), n2Hi = (uint32_t)__popcll((__ballot(in2Hi) >> rowBase) & 0xFFFFull);
+      if ((lane & 15u) == 15u && n2Lo) {
+        uint32_t* e = bins + (d * NBINS + b2min) * BINW;
+        atomicMin(&e[0], lo2[0]); atomicMin(&e[1], lo2[1]); atomicMin(&e[2], lo2[2]);
+        atomicMax(&e[3], lo2[3]); atomicMax(&e[4], lo2[4]); atomicMax(&e[5], lo2[5]);
+        atomicAdd(&e[6], n2Lo);
+        if (n2Hi) {
+          uint32_t* f = bins + (d * NBINS + b2max) * BINW;
+          atomicMin(&f[0], hi2[0]); atomicMin(&f[1], hi2[1]); atomicMin(&f[2], hi2[2]);
+          atomicMax(&f[3], hi2[3]); atomicMax(&f[4], hi2[4]); atomicMax(&f[5], hi2[5]);
+          atomicAdd(&f[6], n2Hi);
+        }
+      }
+      alone = alone && !in2Lo && !in2Hi;
+    }
+    if (alone) {
       uint32_t* e = bins + (d * NBINS + b) * BINW;
       atomicMin(&e[0], c[0]); atomicMin(&e[1], c[1]); atomicMin(&e[2], c[2]);
       atomicMax(&e[3], c[3]); atomicMax(&e[4], c[4]); atomicMax(&e[5], c[5]);
