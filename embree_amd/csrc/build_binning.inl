@@ -75,66 +75,8 @@ __device__ __forceinline__ void runs_flush_wave(BinRuns& r, uint32_t* bins, uint
   for (int d = 0; d < 3; d++) runs_flush_axis(r, d, bins, lane);
 }
 
-// Lane-private variant for top_bin: a lane sees triangles i, i + 64, ... of its wave's span and keeps its OWN current bin per axis; a run
-// ends with 7 LDS atomics of that lane, what is pending at the end of the span is folded across the wave.  Measured on the full-size
-// passes of top_bin: 110 us against 129 us for the wave-uniform runs above (batches straddling a bin boundary send most lanes to the LDS
-// bins there), while the wave-uniform runs are the faster ones inside small_build (2.65 against 2.85 ms).
-struct LaneRuns { int b[3]; uint32_t lo[3][3], hi[3][3], n[3]; };
-__device__ __forceinline__ void lane_runs_init(LaneRuns& r) { for (int d = 0; d < 3; d++) { r.b[d] = -1; r.n[d] = 0u; for (int k = 0; k < 3; k++) { r.lo[d][k] = 0xFFFFFFFFu; r.hi[d][k] = 0u; } } }
-__device__ __forceinline__ void lane_runs_add(LaneRuns& r, uint32_t* bins, const Mapping& m, const PrimRef& p, bool valid) {
-  if (!valid) return;
-  uint32_t c[6];
-  for (int k = 0; k < 3; k++) { c[k] = enc(p.lo[k]); c[3 + k] = enc(p.hi[k]); }
-#pragma unroll
-  for (int d = 0; d < 3; d++) {
-    const int b = bin_clamped(p.lo[d] + p.hi[d], m.ofs[d], m.scale[d], m.nb);
-    if (b != r.b[d]) {
-      if (r.n[d]) {                                             // the run ends: its 7 atomics
-        uint32_t* e = bins + (d * NBINS + r.b[d]) * BINW;
-        atomicMin(&e[0], r.lo[d][0]); atomicMin(&e[1], r.lo[d][1]); atomicMin(&e[2], r.lo[d][2]);
-        atomicMax(&e[3], r.hi[d][0]); atomicMax(&e[4], r.hi[d][1]); atomicMax(&e[5], r.hi[d][2]);
-        atomicAdd(&e[6], r.n[d]);
-      }
-      r.b[d] = b; r.n[d] = 1u;
-      for (int k = 0; k < 3; k++) { r.lo[d][k] = c[k]; r.hi[d][k] = c[3 + k]; }
-    } else {
-      r.n[d]++;
-      for (int k = 0; k < 3; k++) { r.lo[d][k] = min(r.lo[d][k], c[k]); r.hi[d][k] = max(r.hi[d][k], c[3 + k]); }
-    }
-  }
-}
-// every lane of the wave calls it: the pending runs of the lanes that share a bin are reduced in registers, lane 63 issues the atomics
-__device__ __forceinline__ void lane_runs_flush_wave(LaneRuns& r, uint32_t* bins, uint32_t lane) {
-#pragma unroll
-  for (int d = 0; d < 3; d++) {
-    int b = r.n[d] ? r.b[d] : -1;
-    unsigned long long rem = __ballot(b >= 0);
-    for (int round = 0; round < 3; round++) {
-      if (__popcll(rem) < 8) break;
-      const int b0 = __builtin_amdgcn_readlane(b, __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(rem)));
-      const bool mt = b == b0;
-      const unsigned long long mm = __ballot(mt);
-      if (__popcll(mm) < 4) break;
-      uint32_t v[6];
-      for (int k = 0; k < 3; k++) { v[k] = wave_umin63(mt ? r.lo[d][k] : 0xFFFFFFFFu); v[3 + k] = wave_umax63(mt ? r.hi[d][k] : 0u); }
-      const uint32_t cnt = wave_uadd63(mt ? r.n[d] : 0u);
-      if (lane == 63u) {
-        uint32_t* e = bins + (d * NBINS + b0) * BINW;
-        atomicMin(&e[0], v[0]); atomicMin(&e[1], v[1]); atomicMin(&e[2], v[2]);
-        atomicMax(&e[3], v[3]); atomicMax(&e[4], v[4]); atomicMax(&e[5], v[5]);
-        atomicAdd(&e[6], cnt);
-      }
-      if (mt) b = -1;
-      rem &= ~mm;
-    }
-    if (b >= 0) {
-      uint32_t* e = bins + (d * NBINS + b) * BINW;
-      atomicMin(&e[0], r.lo[d][0]); atomicMin(&e[1], r.lo[d][1]); atomicMin(&e[2], r.lo[d][2]);
-      atomicMax(&e[3], r.hi[d][0]); atomicMax(&e[4], r.hi[d][1]); atomicMax(&e[5], r.hi[d][2]);
-      atomicAdd(&e[6], r.n[d]);
-    }
-  }
-}
+// (A lane-private variant -- every lane keeps its OWN current bin per axis over triangles i, i + 64, ... -- measured 110 us per full pass of top_bin against 129 us
+// for the wave-uniform runs above and 92 us for the row aggregation below, which replaced it: profiles/r01_build_history.md.)
 
 // Row aggregation for top_bin: the 16 lanes of a DPP row hold 16 consecutive triangles, which sit in one bin per axis or straddle ONE bin
 // boundary (measured with cycle counters on the crown stand-in: consecutive triangles march along a ring of a sphere, 16 of them cover
@@ -142,20 +84,10 @@ __device__ __forceinline__ void lane_runs_flush_wave(LaneRuns& r, uint32_t* bins
 // in its highest bin, reduces each with four row_shr steps (result in lane 15 of the row) and that lane issues 7 atomics per group;
 // a lane strictly between the two, and rows holding the end of the chunk, go lane by lane.  At most 4 x 14 instead of 64 x 7 same-word
 // LDS atomics per axis and batch -- the atomics are what top_bin waits for (PMC: SQ_WAIT_INST_LDS 73 % of the wave cycles).
-__device__ __forceinline__ uint32_t row_umin15(uint32_t v) {
-  v = min(v, dpp_u<0x111, 0xF>(v, v)); v = min(v, dpp_u<0x112, 0xF>(v, v)); v = min(v, dpp_u<0x114, 0xF>(v, v)); v = min(v, dpp_u<0x118, 0xF>(v, v));
-  return v;
-}
-__device__ __forceinline__ uint32_t row_umax15(uint32_t v) {
-  v = max(v, dpp_u<0x111, 0xF>(v, v)); v = max(v, dpp_u<0x112, 0xF>(v, v)); v = max(v, dpp_u<0x114, 0xF>(v, v)); v = max(v, dpp_u<0x118, 0xF>(v, v));
-  return v;
-}
-// The same reductions with the DPP operand folded into the min / max (v_min_u32_dpp dst, dst, dst row_shr:k -- a lane without a source keeps its value).
-// The compiler does not fold them: each step of row_umin15 comes out as v_mov + v_mov_dpp + v_min and an s_nop (504 of the 656 VALU instructions top_bin
+// Row reductions (result in lane 15 of every row) with the DPP operand folded into the min / max (v_min_u32_dpp dst, dst, dst row_shr:k -- a lane without a
+// source keeps its value).  The compiler does not fold them: written with __builtin_amdgcn_update_dpp each step comes out as v_mov + v_mov_dpp + v_min and an s_nop (504 of the 656 VALU instructions top_bin
 // spends on a batch of 64 triangles, at 73 % VALU busy: profiles/r03_pmc_top_bin.md).  A DPP read needs two wait states after the VALU write of its
 // source; with several values in one block the other values' instructions are those wait states.
-#define MI355_DPP_ROW4(OP, R) \
-  OP " %" #R ", %" #R ", %" #R " row_shr:1 row_mask:0xf bank_mask:0xf\n"
 __device__ __forceinline__ void row_minmax15(uint32_t& mn, uint32_t& mx) {                // both end up in lane 15 of every row
   asm volatile("s_nop 1\n"
                "v_min_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n v_max_u32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n s_nop 0\n"
@@ -177,7 +109,6 @@ __device__ __forceinline__ void row_boxes15(uint32_t (&a)[6], uint32_t (&c)[6]) 
                : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]));
 #undef MI355_STEP
 }
-#undef MI355_DPP_ROW4
 __device__ __forceinline__ void bins_add_rows(uint32_t* bins, const Mapping& m, const PrimRef& p, bool valid, uint32_t lane) {
   uint32_t c[6];
   for (int k = 0; k < 3; k++) { c[k] = enc(p.lo[k]); c[3 + k] = enc(p.hi[k]); }
