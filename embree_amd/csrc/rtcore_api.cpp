@@ -57,6 +57,7 @@ struct Device : RefCounted {
   unsigned shardMin = 16384;                                 // host-array / device-array batches of fewer rays than this per replica stay on replica 0 (config key shard_min)
   int verbose = 0;
   bool benchmark = false;
+  bool smallInPlace = true;                                  // config key small_in_place=0: small host queries go through device staging like the others (A/B)
   unsigned pipelineMin = 262144, pipelineChunk = 65536;   // host-array queries of at least pipelineMin rays are cut into chunks of pipelineChunk rays (config keys host_pipeline_min / host_pipeline_chunk)
   mi355_build_params build;
   RTCErrorFunction errorFn = nullptr; void* errorFnPtr = nullptr;
@@ -235,8 +236,24 @@ struct Replica {
   hipStream_t pipe[PIPE] = {nullptr, nullptr, nullptr, nullptr};   // large host-array queries: upload, download, two compute streams (pipelined_query)
   std::vector<hipEvent_t> pipeEvents;                       // ... and two events per chunk
   std::mutex pipeMtx;                                       // one pipelined query per replica at a time: the four streams, the events and the streams' status words are shared
-  struct Staging { char* d = nullptr; size_t cap = 0; };
+  struct Staging { char* d = nullptr; size_t cap = 0; char* h = nullptr; char* hd = nullptr; };   // h / hd: 4 KiB of pinned host memory and its device address
   std::map<size_t, Staging> staging;
+  static constexpr size_t SMALL_BYTES = 4096;               // queries of up to this many bytes (rtcIntersect1 .. a few dozen rays) are traced in place in pinned host memory
+  // One blocking rtcIntersect1 call used to be hipMemcpy up + launch + hipMemcpy down + status read = four round trips (77 us); the kernel now reads the ray
+  // from and writes the hit to a pinned, device-mapped buffer of the calling thread: one launch and one wait.
+  char* stage_host(char** devAddr) {
+    std::lock_guard<std::mutex> lk(mtx);
+    Staging& s = staging[Device::threadToken()];
+    if (!s.h) {
+      hip_check(hipSetDevice(gpu), "hipSetDevice");
+      void* h = nullptr; void* d = nullptr;
+      hip_check(hipHostMalloc(&h, SMALL_BYTES, hipHostMallocMapped | hipHostMallocPortable), "hipHostMalloc(small-query staging)");
+      hip_check(hipHostGetDevicePointer(&d, h, 0), "hipHostGetDevicePointer");
+      s.h = (char*)h; s.hd = (char*)d;
+    }
+    *devAddr = s.hd;
+    return s.h;
+  }
   hipStream_t shardStream = nullptr; hipEvent_t shardIn = nullptr, shardOut = nullptr;   // device-array queries sharded over the replicas (sharded_device_query)
   char* stage(size_t bytes) {
     std::lock_guard<std::mutex> lk(mtx);
@@ -255,7 +272,7 @@ struct Replica {
     if (bvh && bvh != flat) { mi355_bvh_destroy(bvh); device->memoryMonitor(-bvhBytes, true); }
     if (flat) { mi355_bvh_destroy(flat); device->memoryMonitor(-flatBytes, true); }
     bvh = flat = nullptr;
-    for (auto& kv : staging) if (kv.second.d) hipFree(kv.second.d);
+    for (auto& kv : staging) { if (kv.second.d) hipFree(kv.second.d); if (kv.second.h) hipHostFree(kv.second.h); }
     for (int k = 0; k < PIPE; k++) if (pipe[k]) hipStreamDestroy(pipe[k]);
     for (hipEvent_t e : pipeEvents) hipEventDestroy(e);
     if (shardStream) hipStreamDestroy(shardStream);
@@ -491,6 +508,7 @@ void parse_config(Device* d, const char* cfg) {
     else if (k == "presplits") d->build.presplits = atoi(v.c_str()) != 0 ? 1u : 0u;                    // state.cpp:443
     else if (k == "max_spatial_split_replications") d->build.split_factor = (float)atof(v.c_str());   // state.cpp:437
     else if (k == "host_pipeline_min") d->pipelineMin = (unsigned)atol(v.c_str());
+    else if (k == "small_in_place") d->smallInPlace = atoi(v.c_str()) != 0;
     else if (k == "host_pipeline_chunk") d->pipelineChunk = atol(v.c_str()) >= 1024 ? (unsigned)atol(v.c_str()) : 1024u;
     else if (k == "int_cost") d->build.int_cost = (float)atof(v.c_str());
     else if (k == "top_splits") d->build.top_splits = atoi(v.c_str()) != 0 ? 1u : 0u;                 // MEDIUM builds: references that dwarf all others are cut into grid pieces first
@@ -642,6 +660,17 @@ static void replica_query(Scene* s, size_t k, char* data, unsigned M, size_t str
   hip_check(hipSetDevice(r.gpu), "hipSetDevice");
   const size_t rec = any ? 48 : 96;
   const size_t bytes = (size_t)(M - 1) * stride + rec;
+  if (bytes <= Replica::SMALL_BYTES && s->device->smallInPlace) {
+    char* hd = nullptr; char* h = r.stage_host(&hd);
+    memcpy(h, data, bytes);
+    core_check(trace_launch(b, hd, M, stride, any, qflags, nullptr), "trace");
+    uint32_t flags = 0;
+    core_check(mi355_trace_status(b, nullptr, &flags), "trace status");   // (waits for the launch: the status words are read after it)
+    memcpy(data, h, bytes);
+    if (flags & MI355_TRACE_ITER_CAP_HIT) THROW(RTC_ERROR_UNKNOWN, "traversal stopped at its iteration cap: results are incomplete");
+    if (flags & MI355_TRACE_STACK_OVERFLOW) THROW(RTC_ERROR_UNKNOWN, "traversal stack overflow: results are incomplete");
+    return;
+  }
   char* d = r.stage(bytes);
   if (M >= s->device->pipelineMin && pipelined_query(s, r, data, d, M, stride, any, qflags, bytes, pinned)) return;
   hip_check(hipMemcpy(d, data, bytes, hipMemcpyHostToDevice), "hipMemcpy(rays H2D)");
