@@ -99,13 +99,21 @@ __device__ void micro_flush(uint32_t* R, unsigned long long* s_key, const MicroR
     // ---- L1: bin (BinInfoT::bin, heuristic_binning.h:210-257)
     constexpr uint32_t SS = W / 8u, P = 64u * SS;                // slots per lane, words per plane
     uint32_t* const sb = R + segB * SS;
-    if (act) {
+    {
+      // Lanes of an instruction that hit the SAME word cost the LDS ~3 cycles each (profiles/r03_lds_atomics.md), and neighbouring triangles of a segment usually
+      // share a bin: the even lane of a pair whose odd neighbour is in the same segment and bin hands its box over (quad_perm [1,0,3,2]) and stays out.
+      uint32_t z[6] = {zlo(p.lo[0]), zlo(p.lo[1]), zlo(p.lo[2]), zhi(p.hi[0]), zhi(p.hi[1]), zhi(p.hi[2])}, zo[6];
+      for (int k = 0; k < 6; k++) zo[k] = dpp_u<0xB1, 0xF>(z[k], z[k]);
       for (int d = 0; d < 3; d++) {
-        const int b = bin_clamped(p.lo[d] + p.hi[d], ofs[d], scale[d], nb);
-        uint32_t* e = sb + (uint32_t)d * nb + (uint32_t)b;
-        atomicMax(&e[0], zlo(p.lo[0])); atomicMax(&e[P], zlo(p.lo[1])); atomicMax(&e[2u * P], zlo(p.lo[2]));
-        atomicMax(&e[3u * P], zhi(p.hi[0])); atomicMax(&e[4u * P], zhi(p.hi[1])); atomicMax(&e[5u * P], zhi(p.hi[2]));
-        atomicAdd(&e[6u * P], 1u);
+        const uint32_t b = act ? (uint32_t)bin_clamped(p.lo[d] + p.hi[d], ofs[d], scale[d], nb) : 0u;
+        const uint32_t key = act ? ((segB << 8) | b) : (0xFFFF0000u | lane);
+        const bool same = dpp_u<0xB1, 0xF>(key, key) == key, taker = same && (lane & 1u) != 0u, giver = same && (lane & 1u) == 0u;
+        if (act && !giver) {
+          uint32_t* e = sb + (uint32_t)d * nb + b;
+          atomicMax(&e[0], taker ? max(z[0], zo[0]) : z[0]); atomicMax(&e[P], taker ? max(z[1], zo[1]) : z[1]); atomicMax(&e[2u * P], taker ? max(z[2], zo[2]) : z[2]);
+          atomicMax(&e[3u * P], taker ? max(z[3], zo[3]) : z[3]); atomicMax(&e[4u * P], taker ? max(z[4], zo[4]) : z[4]); atomicMax(&e[5u * P], taker ? max(z[5], zo[5]) : z[5]);
+          atomicAdd(&e[6u * P], taker ? 2u : 1u);
+        }
       }
     }
     MICRO_SYNC();
