@@ -692,6 +692,12 @@ __global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceAr
       k.bxy.x = bx - ex; k.bxy.y = by - ey; k.bzx.x = bz - ez; k.bzx.y = bx + ex; k.byz.x = by + ey; k.byz.y = bz + ez;
       hits = test4(nx0, ny0, nz0, fx0, fy0, fz0, n1.z, octinv4, k, tnearTrav, tmax0) |
              test4(nx1, ny1, nz1, fx1, fy1, fz1, n1.w, octinv4, k, tnearTrav, tmax0);
+      if (STATS && hits == 0u) {
+        // a visit that finds no child: is it a box the ray enters without entering any of its children (inherent to boxes), or does every child it enters lie
+        // behind the hit found since the entry was pushed (what a distance kept with the stack entry could skip)?  The same test against the ray's OWN limit tells.
+        const float tmaxOwn = fmaxf(tfar0, 0.0f);
+        if ((test4(nx0, ny0, nz0, fx0, fy0, fz0, n1.z, octinv4, k, tnearTrav, tmaxOwn) | test4(nx1, ny1, nz1, fx1, fy1, fz1, n1.w, octinv4, k, tnearTrav, tmaxOwn)) != 0u) stCulled++;
+      }
       }
       ngBase = n1.x; ngHits = (hits & 0xFF000000u) | (n0.w >> 24);
       tgBase = n1.y; tgHits = hits & 0x00FFFFFFu;
@@ -774,7 +780,9 @@ __global__ __launch_bounds__(64) void trace_packet_kernel(PacketTraceArgs a) {
   // A batch whose packets do not stay together costs the packet attempt on top of the per-lane traversal (crown stand-in, primary rays: 1.06 instead of
   // 1.46 Grays/s).  Large batches are therefore traced in two launches: every 32nd packet first (part 1), then the rest (part 2) -- which looks at how
   // many packets of the sample gave up and, if that is more than a quarter, hands all of its packets to the per-lane kernel at once.
-  if (a.part == 2u && *(volatile uint32_t*)a.deferCount > a.bailAbove) {
+  // The decision must be the same for every block of the launch (the two modes split the packet index space differently): it is taken on a SNAPSHOT of the
+  // sample's count (deferCount[1], copied between the two launches), which no packet kernel writes -- the live count grows while part 2 runs.
+  if (a.part == 2u && a.deferCount[1] > a.bailAbove) {
     // (64 packets per atomic: one word takes ~88 appends per microsecond, 15,000 single appends would cost more than the packets they save)
     for (uint32_t j0 = blockIdx.x * 64u;; j0 += gridDim.x * 64u) {
       const uint32_t j = j0 + lane, pk = j + j / (PACKET_SAMPLE - 1u) + 1u;
@@ -1020,8 +1028,9 @@ size_t trace_spill_bytes(int numCUs, uint32_t depth) {
   return (size_t)numCUs * MAX_BLOCKS_PER_CU * BLOCK * trace_spill_per_lane(depth) * sizeof(uint2) + 1024;   // + slack: after a (flagged) overflow a lane still pops what it believes it pushed
 }
 
-static int launch_trace(Bvh* b, void* d_rays, uint32_t count, size_t stride, bool any, hipStream_t s, uint64_t* statsOut,
-                        hipEvent_t evStart = nullptr, hipEvent_t evStop = nullptr, const uint32_t* deferList = nullptr, const uint32_t* deferCount = nullptr) {
+// (callers hold sc->enqueue of the stream's scratch: see launch_trace / launch_trace_coherent)
+static int launch_trace_locked(Bvh* b, TraceScratch* sc, void* d_rays, uint32_t count, size_t stride, bool any, hipStream_t s, uint64_t* statsOut,
+                               hipEvent_t evStart = nullptr, hipEvent_t evStop = nullptr, const uint32_t* deferList = nullptr, const uint32_t* deferCount = nullptr) {
   if (count == 0) return 0;
   if (stride < (any ? 48u : 96u) || (stride & 15u) || ((uintptr_t)d_rays & 15u)) return set_error(hipErrorInvalidValue, "ray array must be 16-byte aligned with a 16-byte-multiple stride");
   HIP_TRY(hipSetDevice(b->device));
@@ -1029,9 +1038,6 @@ static int launch_trace(Bvh* b, void* d_rays, uint32_t count, size_t stride, boo
   const uint32_t maxBlocks = resident_blocks(b, fn);
   uint32_t blocks = (count + BLOCK - 1) / BLOCK;
   if (blocks > maxBlocks) blocks = maxBlocks;
-  TraceScratch* sc = b->scratch_for(s);
-  if (!sc) return set_error(hipErrorOutOfMemory, "trace scratch allocation failed");
-  std::lock_guard<std::mutex> enqueueLock(*sc->enqueue);       // rtcIntersect* are thread safe: another thread's reset must not slip between my reset and my kernel
   HIP_TRY(hipMemsetAsync(sc->counter, 0, NUM_CURSORS * CURSOR_STRIDE * sizeof(uint32_t), s));
   TraceArgs a;
   a.nodes = (const uint4*)b->d_nodes; a.tris = (const float4*)b->d_tris; a.hasRoot = b->root != MI355_EMPTY_REF ? 1u : 0u;
@@ -1061,6 +1067,16 @@ static int launch_trace(Bvh* b, void* d_rays, uint32_t count, size_t stride, boo
   return 0;
 }
 
+static int launch_trace(Bvh* b, void* d_rays, uint32_t count, size_t stride, bool any, hipStream_t s, uint64_t* statsOut,
+                        hipEvent_t evStart = nullptr, hipEvent_t evStop = nullptr) {
+  if (count == 0) return 0;
+  HIP_TRY(hipSetDevice(b->device));
+  TraceScratch* sc = b->scratch_for(s);
+  if (!sc) return set_error(hipErrorOutOfMemory, "trace scratch allocation failed");
+  std::lock_guard<std::mutex> enqueueLock(*sc->enqueue);       // rtcIntersect* are thread safe: another thread's reset must not slip between my reset and my kernel
+  return launch_trace_locked(b, sc, d_rays, count, stride, any, s, statsOut, evStart, evStop);
+}
+
 typedef void (*PacketFn)(PacketTraceArgs);
 static int launch_trace_coherent(Bvh* b, void* d_rays, uint32_t count, size_t stride, bool any, hipStream_t s) {
   if (count == 0) return 0;
@@ -1084,7 +1100,10 @@ static int launch_trace_coherent(Bvh* b, void* d_rays, uint32_t count, size_t st
   if (!sc) return set_error(hipErrorOutOfMemory, "trace scratch allocation failed");
   const size_t packets = ((size_t)count + 63u) / 64u, need = (64u + packets) * sizeof(uint32_t);
   uint32_t* defer = nullptr;
-  { std::lock_guard<std::mutex> enqueueLock(*sc->enqueue);
+  // ONE lock over the packet launches and the per-lane pass behind them: the deferred list belongs to (tree, stream), and a second thread's coherent query
+  // on the same stream (all host queries use the null stream) must not reset or regrow it between my packets and my second pass
+  std::lock_guard<std::mutex> enqueueLock(*sc->enqueue);
+  {
     if (sc->deferCap < need) {                                  // (stream order keeps earlier launches' use of the old list apart: wait for them before it goes)
       if (sc->defer) { HIP_TRY(hipStreamSynchronize(s)); HIP_TRY(hipFree(sc->defer)); sc->defer = nullptr; sc->deferCap = 0; }
       const size_t cap = need < 65536 ? 65536 : need + need / 4;
@@ -1102,6 +1121,7 @@ static int launch_trace_coherent(Bvh* b, void* d_rays, uint32_t count, size_t st
       const uint32_t nSample = (uint32_t)((packets + PACKET_SAMPLE - 1u) / PACKET_SAMPLE), nRest = (uint32_t)packets - nSample;
       a.part = 1u; a.bailAbove = 0xFFFFFFFFu;
       hipLaunchKernelGGL(fn, dim3(nSample < maxBlocks ? nSample : maxBlocks), dim3(64), 0, s, a);
+      HIP_TRY(hipMemcpyAsync(defer + 1, defer, sizeof(uint32_t), hipMemcpyDeviceToDevice, s));   // the sample's verdict, frozen (words 1..63 of the area are free)
       a.part = 2u; a.bailAbove = nSample / 4u;
       hipLaunchKernelGGL(fn, dim3(nRest < maxBlocks ? nRest : maxBlocks), dim3(64), 0, s, a);
     } else {
@@ -1110,7 +1130,7 @@ static int launch_trace_coherent(Bvh* b, void* d_rays, uint32_t count, size_t st
     }
     HIP_TRY(hipGetLastError()); }
   // the packets that gave up (their rays untouched), traced per lane right behind: the count stays on the device, a launch that finds none ends at once
-  return launch_trace(b, d_rays, count, stride, any, s, nullptr, nullptr, nullptr, defer + 64, defer);
+  return launch_trace_locked(b, sc, d_rays, count, stride, any, s, nullptr, nullptr, nullptr, defer + 64, defer);
 }
 
 static int launch_packets(Bvh* b, const int* d_valid, void* d_pk, uint32_t K, uint32_t n, size_t pstride, bool any, hipStream_t s) {
