@@ -39,7 +39,7 @@ rtcSetGeometryIntersectFilterFunction rtcSetGeometryOccludedFilterFunction rtcSe
 rtcNewScene rtcGetSceneDevice rtcRetainScene rtcReleaseScene rtcGetSceneTraversable rtcAttachGeometry
 rtcAttachGeometryByID rtcDetachGeometry rtcGetGeometry rtcGetGeometryThreadSafe rtcCommitScene rtcJoinCommitScene
 rtcSetSceneProgressMonitorFunction rtcSetSceneBuildQuality rtcSetSceneFlags rtcGetSceneFlags rtcGetSceneBounds
-rtcIntersect1 rtcIntersect4 rtcIntersect8 rtcIntersect16 rtcOccluded1 rtcOccluded4 rtcOccluded8 rtcOccluded16
+rtcIntersect1 rtcIntersect4 rtcIntersect8 rtcIntersect16 rtcOccluded1 rtcOccluded4 rtcOccluded8 rtcOccluded16 rtcIntersect1MDeviceSharded rtcOccluded1MDeviceSharded
 rtcTraversableIntersect1 rtcTraversableIntersect4 rtcTraversableIntersect8 rtcTraversableIntersect16
 rtcTraversableOccluded1 rtcTraversableOccluded4 rtcTraversableOccluded8 rtcTraversableOccluded16
 rtcIntersect1M rtcOccluded1M rtcIntersect1MDevice rtcOccluded1MDevice""".split()
@@ -48,7 +48,7 @@ mi355_bvh_destroy mi355_bvh_build_instanced mi355_bvh_refit mi355_release_build_
 mi355_trace_query mi355_trace_closest_packet mi355_trace_any_packet mi355_trace_stats mi355_trace_timed mi355_trace_status mi355_malloc mi355_free mi355_memcpy_h2d
 mi355_memcpy_d2h mi355_synchronize mi355_device_synchronize mi355_memcpy_d2d_async mi355_stream_create
 mi355_stream_destroy mi355_event_create mi355_event_record mi355_event_elapsed_ms mi355_event_destroy
-mi355_comm_unique_id mi355_comm_init mi355_comm_destroy mi355_comm_allgather mi355_comm_gather mi355_pack_hits mi355_pack_occluded mi355_stream_query mi355_measure_bandwidth""".split()
+mi355_comm_unique_id mi355_comm_init mi355_comm_destroy mi355_comm_allgather mi355_comm_gather mi355_pack_hits mi355_pack_hits_inst mi355_pack_occluded mi355_stream_query mi355_stream_wait_event mi355_measure_bandwidth""".split()
 
 
 class FilterArguments(C.Structure):            # RTCFilterFunctionNArguments
@@ -202,6 +202,8 @@ def load():
     L.rtcIntersect1M.argtypes = [vp, vp, u32, sz, vp]
     L.rtcOccluded1M.argtypes = [vp, vp, u32, sz, vp]
     L.rtcIntersect1MDevice.argtypes = [vp, vp, u32, sz, vp, vp]
+    L.rtcIntersect1MDeviceSharded.argtypes = [vp, u32, vp, vp, sz, vp, vp]
+    L.rtcOccluded1MDeviceSharded.argtypes = [vp, u32, vp, vp, sz, vp, vp]
     L.rtcOccluded1MDevice.argtypes = [vp, vp, u32, sz, vp, vp]
     L.rtcGetSceneBVH_mi355.restype = vp
     L.rtcGetSceneBVH_mi355.argtypes = [vp]
@@ -243,6 +245,8 @@ def load():
     L.mi355_comm_gather.argtypes = [vp, vp, vp, sz, C.c_int, vp]
     L.mi355_pack_hits.argtypes = [vp, u32, sz, vp, vp]
     L.mi355_pack_occluded.argtypes = [vp, u32, sz, vp, vp]
+    L.mi355_pack_hits_inst.argtypes = [vp, u32, sz, vp, vp]
+    L.mi355_stream_wait_event.argtypes = [vp, vp]
     L.mi355_stream_query.argtypes = [vp]
     L.mi355_measure_bandwidth.argtypes = [C.c_int, sz, C.c_int, C.POINTER(C.c_double)]
     _lib = L
@@ -515,6 +519,17 @@ class Scene:
     def occluded1M_device(self, dptr, count, stride=48, stream=None, args=None):
         self.L.rtcOccluded1MDevice(self.h, dptr, count, stride, C.addressof(args) if args is not None else None, stream)
         self.dev.check()
+
+    def query_device_sharded(self, dptrs, counts, stride=96, streams=None, any_hit=False, args=None):
+        """rtcIntersect1MDeviceSharded / rtcOccluded1MDeviceSharded: shard k (counts[k] records at device pointer dptrs[k], memory of replica k's GPU) is traced
+        by replica k on streams[k]; nothing crosses xGMI"""
+        n = len(dptrs)
+        P = (C.c_void_p * n)(*[int(p) if p else None for p in dptrs])
+        N = (C.c_uint32 * n)(*[int(c) for c in counts])
+        S = (C.c_void_p * n)(*[(x.value if isinstance(x, C.c_void_p) else x) for x in streams]) if streams is not None else None
+        fn = self.L.rtcOccluded1MDeviceSharded if any_hit else self.L.rtcIntersect1MDeviceSharded
+        fn(self.h, n, P, N, stride, C.addressof(args) if args is not None else None, S)
+        self.device.check()
 
     def replica_bvh(self, k):
         """the tree on replica k of a device over several GPUs (rtcNewDevice("gpus=N")); None beyond the last"""

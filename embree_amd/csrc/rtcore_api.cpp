@@ -461,7 +461,13 @@ struct Scene : RefCounted {
         r.bvh = nb; r.bvhBytes = newBytes;
       }
     });
-    } catch (...) { if (refitBroken) committed = false; throw; }   // (a refit that stopped half way and a rebuild that failed: no usable tree)
+    } catch (...) {
+      // a refit that stopped half way and a rebuild that failed leave no usable tree; and with several replicas a failure on ONE GPU (out of memory, the memory
+      // monitor's veto) leaves the others with the NEW tree: sharded queries would then answer from different geometry depending on the shard a ray falls in
+      // -- the scene counts as not committed until a commit goes through on every GPU
+      if (refitBroken || reps.size() > 1) committed = false;
+      throw;
+    }
     builtFrom = from; builtFlags = nowFlags;
     mi355_bvh_info info; mi355_bvh_get_info(reps[0]->bvh, &info);
     setEmptyBounds();
@@ -725,6 +731,19 @@ static void sharded_device_query(Scene* s, char* d, unsigned M, size_t stride, b
   if (hi0) core_check(trace_launch(committed_bvh(s, 0), d, hi0, stride, any, qflags, stream), "trace");
   for (size_t k = 1; k < n; k++) if (s->reps[k]->shardOut && shard_begin(M, k + 1, n) > shard_begin(M, k, n)) hip_check(hipStreamWaitEvent(stream, s->reps[k]->shardOut, 0), "hipStreamWaitEvent");
 }
+// device arrays that already live where they are traced: shard k on replica k's GPU, on the caller's stream of that GPU; nothing travels
+static void sharded_pointer_query(Scene* s, unsigned numShards, void* const* d, const unsigned* counts, size_t stride, bool any, unsigned qflags, void* const* streams) {
+  if (!d || !counts) THROW(RTC_ERROR_INVALID_ARGUMENT, "invalid argument");
+  if (numShards > s->reps.size()) THROW(RTC_ERROR_INVALID_ARGUMENT, "more shards than GPUs behind this device (RTC_DEVICE_PROPERTY_GPU_COUNT)");
+  committed_bvh(s);
+  for (unsigned k = 0; k < numShards; k++) {
+    if (counts[k] == 0u) continue;
+    if (!d[k]) THROW(RTC_ERROR_INVALID_ARGUMENT, "shard pointer is NULL");
+    hip_check(hipSetDevice(s->reps[k]->gpu), "hipSetDevice");
+    core_check(trace_launch(committed_bvh(s, k), d[k], counts[k], stride, any, qflags, streams ? (hipStream_t)streams[k] : nullptr), "trace");
+  }
+  hip_check(hipSetDevice(s->device->gpu), "hipSetDevice");
+}
 static void device_query(Scene* s, void* d, unsigned M, size_t stride, bool any, unsigned qflags, void* stream) {
   if (M == 0) { committed_bvh(s); return; }
   const size_t n = s->reps.size();
@@ -802,6 +821,8 @@ RTC_API void rtcReleaseDevice(RTCDevice h) { CATCH_BEGIN dev_of(h)->release(); C
 RTC_API ssize_t rtcGetDeviceProperty(RTCDevice h, enum RTCDeviceProperty prop) {
   CATCH_BEGIN
   dev_of(h);
+  if ((int)prop >= (int)RTC_DEVICE_PROPERTY_GPU_OF_REPLICA_0 && (size_t)((int)prop - (int)RTC_DEVICE_PROPERTY_GPU_OF_REPLICA_0) < ((Device*)h)->gpus.size())
+    return (ssize_t)((Device*)h)->gpus[(size_t)((int)prop - (int)RTC_DEVICE_PROPERTY_GPU_OF_REPLICA_0)];
   switch (prop) {
     case RTC_DEVICE_PROPERTY_VERSION: return RTC_VERSION;
     case RTC_DEVICE_PROPERTY_VERSION_MAJOR: return RTC_VERSION_MAJOR;
@@ -1114,6 +1135,14 @@ RTC_API void rtcIntersect1MDevice(RTCScene h, void* d_rh, unsigned M, size_t str
 RTC_API void rtcOccluded1MDevice(RTCScene h, void* d_r, unsigned M, size_t stride, struct RTCOccludedArguments* a, void* stream) {
   CATCH_BEGIN Scene* s = scene_of(h); if (a) check_query_args(a->filter, (const void*)a->occluded);
   device_query(s, d_r, M, stride, true, a ? (unsigned)a->flags : 0u, stream); CATCH_END(SCENE_DEV(h))
+}
+RTC_API void rtcIntersect1MDeviceSharded(RTCScene h, unsigned n, void* const* d_rh, const unsigned* counts, size_t stride, struct RTCIntersectArguments* a, void* const* streams) {
+  CATCH_BEGIN Scene* s = scene_of(h); if (a) check_query_args(a->filter, (const void*)a->intersect);
+  sharded_pointer_query(s, n, d_rh, counts, stride, false, a ? (unsigned)a->flags : 0u, streams); CATCH_END(SCENE_DEV(h))
+}
+RTC_API void rtcOccluded1MDeviceSharded(RTCScene h, unsigned n, void* const* d_r, const unsigned* counts, size_t stride, struct RTCOccludedArguments* a, void* const* streams) {
+  CATCH_BEGIN Scene* s = scene_of(h); if (a) check_query_args(a->filter, (const void*)a->occluded);
+  sharded_pointer_query(s, n, d_r, counts, stride, true, a ? (unsigned)a->flags : 0u, streams); CATCH_END(SCENE_DEV(h))
 }
 // extension used by tests/bench: the core BVH handle behind a committed scene (NULL if not committed)
 extern "C" __attribute__((visibility("default"))) mi355_bvh_t rtcGetSceneBVH_mi355(RTCScene h) { return h ? ((Scene*)h)->bvh0() : nullptr; }

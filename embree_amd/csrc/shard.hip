@@ -35,6 +35,19 @@ __global__ void pack_hits_kernel(const char* rays, uint32_t count, uint32_t stri
     out[2 * (size_t)i + 1] = make_uint4(b.z, a.x, a.y, a.z);    // geomID, Ng
   }
 }
+// scenes with instances: + instID[0], instPrimID[0] (bytes 76..83 of the record) = 48 B per ray, three 16-byte stores
+__global__ void pack_hits_inst_kernel(const char* rays, uint32_t count, uint32_t stride, uint4* out) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+    const char* r = rays + (size_t)i * stride;
+    const uint32_t tfar = *(const uint32_t*)(r + 32);
+    const uint4 a = *(const uint4*)(r + 48);            // Ng_x, Ng_y, Ng_z, u
+    const uint4 b = *(const uint4*)(r + 64);            // v, primID, geomID, instID[0]
+    const uint32_t instPrim = *(const uint32_t*)(r + 80);
+    out[3 * (size_t)i] = make_uint4(tfar, a.w, b.x, b.y);
+    out[3 * (size_t)i + 1] = make_uint4(b.z, a.x, a.y, a.z);
+    out[3 * (size_t)i + 2] = make_uint4(b.w, instPrim, 0u, 0u);
+  }
+}
 // RTCRay after an occlusion query: only tfar changed (-inf = occluded)
 __global__ void pack_occluded_kernel(const char* rays, uint32_t count, uint32_t stride, uint32_t* out) {
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x)
@@ -127,6 +140,15 @@ int mi355_pack_hits(const void* d_rayhit, uint32_t count, size_t stride, void* d
   HIP_TRY(hipGetLastError());
   return 0;
 }
+int mi355_pack_hits_inst(const void* d_rayhit, uint32_t count, size_t stride, void* d_out, void* stream) {
+  if (count == 0) return 0;
+  if (stride < 96 || (stride & 15u) || ((uintptr_t)d_rayhit & 15u) || ((uintptr_t)d_out & 15u)) return mi355::set_error(hipErrorInvalidValue, "mi355_pack_hits_inst: 16-byte aligned RTCRayHit records expected");
+  const uint32_t blocks = (count + 255u) / 256u < 4096u ? (count + 255u) / 256u : 4096u;
+  hipLaunchKernelGGL(pack_hits_inst_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const char*)d_rayhit, count, (uint32_t)stride, (uint4*)d_out);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+int mi355_stream_wait_event(void* stream, void* event) { HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)event, 0)); return 0; }
 int mi355_pack_occluded(const void* d_ray, uint32_t count, size_t stride, void* d_out, void* stream) {
   if (count == 0) return 0;
   if (stride < 48 || (stride & 3u)) return mi355::set_error(hipErrorInvalidValue, "mi355_pack_occluded: RTCRay records expected");

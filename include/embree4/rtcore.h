@@ -154,7 +154,9 @@ enum RTCDeviceProperty {
   RTC_DEVICE_PROPERTY_SYCL_DEVICE = 141,
   /* extension: 1 on this library (HIP device behind the API) */
   RTC_DEVICE_PROPERTY_HIP_DEVICE = 142,
-  RTC_DEVICE_PROPERTY_GPU_COUNT = 143              /* extension: GPUs behind this device (rtcNewDevice("gpus=N")) */
+  RTC_DEVICE_PROPERTY_GPU_COUNT = 143,             /* extension: GPUs behind this device (rtcNewDevice("gpus=N")) */
+  RTC_DEVICE_PROPERTY_GPU_OF_REPLICA_0 = 1000      /* extension: + k = the HIP device ordinal replica k of this device lives on (k < GPU_COUNT): where shard k of
+                                                      rtcIntersect1MDeviceSharded / rtcOccluded1MDeviceSharded must be allocated */
 };
 
 /* [ref: rtcore_device.h:90-100] */
@@ -475,5 +477,15 @@ RTC_API void rtcIntersect1MDevice(RTCScene scene, void* rayhit, unsigned int M, 
                                   struct RTCIntersectArguments* args, void* stream);
 RTC_API void rtcOccluded1MDevice(RTCScene scene, void* ray, unsigned int M, size_t byteStride,
                                  struct RTCOccludedArguments* args, void* stream);
+/* One RTCDevice over N GPUs (rtcNewDevice("gpus=N")), rays resident where they are traced: shard k (counts[k] records at the HIP device pointer rayhits[k],
+   memory of the GPU RTC_DEVICE_PROPERTY_GPU_OF_REPLICA_0 + k names) is traced by replica k on streams[k] (a hipStream_t of that GPU; streams == NULL or
+   streams[k] == NULL = that GPU's default stream).  Nothing crosses xGMI: the committed tree exists once per GPU, every shard stays on its GPU, and what
+   the consumer needs afterwards travels in whatever form it chooses (include/embree_amd_hip.h: mi355_pack_hits + mi355_comm_gather).  numShards <= GPU_COUNT;
+   a shard with counts[k] == 0 is skipped.  Asynchronous, ordered on the shards' streams.  (The single-pointer forms above keep the array on the first GPU and
+   move 1 - 1/N of it over xGMI and back per call.) */
+RTC_API void rtcIntersect1MDeviceSharded(RTCScene scene, unsigned int numShards, void* const* rayhits, const unsigned int* counts, size_t byteStride,
+                                         struct RTCIntersectArguments* args, void* const* streams);
+RTC_API void rtcOccluded1MDeviceSharded(RTCScene scene, unsigned int numShards, void* const* rays, const unsigned int* counts, size_t byteStride,
+                                        struct RTCOccludedArguments* args, void* const* streams);
 
 #endif /* EMBREE4_MI355_RTCORE_H */

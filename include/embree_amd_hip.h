@@ -195,6 +195,11 @@ MI355_API int  mi355_comm_gather(mi355_comm_t comm, const void* d_send, void* d_
    closest hit: 32 B per ray = { tfar, u, v, primID | geomID, Ng_x, Ng_y, Ng_z } (two 16-byte halves); occlusion: 4 B per ray = tfar (-inf = occluded). */
 MI355_API int  mi355_pack_hits(const void* d_rayhit, uint32_t count, size_t byte_stride, void* d_out, void* stream);
 MI355_API int  mi355_pack_occluded(const void* d_ray, uint32_t count, size_t byte_stride, void* d_out, void* stream);
+/* closest hits of scenes with instances: 48 B per ray = the 32 bytes above + { instID[0], instPrimID[0], 0, 0 } (RTCHit, include/embree4/rtcore.h) */
+MI355_API int  mi355_pack_hits_inst(const void* d_rayhit, uint32_t count, size_t byte_stride, void* d_out, void* stream);
+/* hipStreamWaitEvent: work enqueued on `stream` after this call waits for `event` (a handle of mi355_event_create) -- how a gather on a communication stream
+   is ordered behind the traversal of its batch while the next batch is traced (bench.py) */
+MI355_API int  mi355_stream_wait_event(void* stream, void* event);
 MI355_API int  mi355_stream_query(void* stream);
 /* What a streaming kernel reaches on this GPU (the achievable figure beside the 8 TB/s vendor peak): out[0] = device-to-device copy,
    bytes read + written per second; out[1] = read only; GB/s, best of `reps` passes over `bytes` (use >= 1 GiB: the Infinity Cache holds 256 MB). Blocking. */

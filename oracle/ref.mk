@@ -16,16 +16,30 @@
 #
 #   make -f oracle/ref.mk -j8            # ~3-4 min on 8 cores
 REF   ?= /root/reference
-OUT   ?= oracle/_ref
+ROOT_OUT ?= oracle/_ref
+# ISA=avx2 (default): oracle/_ref/libembree4.so + libref_driver.so.   ISA=avx512: a second single-ISA library, oracle/_ref/avx512/libembree4_avx512.so +
+# libref_driver_avx512.so (other file names: two libraries of one name cannot live in one process), flags of common/cmake/gnu.cmake:20 (FLAGS_AVX512) and
+# the two 16-wide packet files kernels/CMakeLists.txt:198-202 adds above AVX2.  BASELINE.md asks for both on the CPU side of the comparison.
+ISA   ?= avx2
+ifeq ($(ISA),avx512)
+OUT   ?= $(ROOT_OUT)/avx512
+SUFFIX := _avx512
+ISAFLAGS := -march=skylake-avx512
+ISADEF := -DEMBREE_TARGET_AVX512
+else
+OUT   ?= $(ROOT_OUT)
+SUFFIX :=
+ISAFLAGS := -mf16c -mavx2 -mfma -mlzcnt -mbmi -mbmi2
+ISADEF := -DEMBREE_TARGET_AVX2
+endif
 GEN   := $(OUT)/gen
 CXX   ?= g++
 
-ISAFLAGS := -mf16c -mavx2 -mfma -mlzcnt -mbmi -mbmi2
 CXXFLAGS := -std=c++11 -O3 -DNDEBUG -fPIC -fsigned-char -flax-vector-conversions \
             -fno-strict-overflow -fno-delete-null-pointer-checks -fwrapv \
             -fvisibility=hidden -fvisibility-inlines-hidden -fno-strict-aliasing \
             -fno-tree-vectorize -w $(ISAFLAGS) \
-            -DTASKING_INTERNAL -DEMBREE_TARGET_AVX2 \
+            -DTASKING_INTERNAL $(ISADEF) \
             -I$(GEN)/kernels/common -I$(GEN)/kernels/bvh -I$(GEN)/include/embree4 \
             -I$(GEN)/kernels -I$(GEN)/include
 
@@ -68,12 +82,15 @@ ISA_SRC := \
   bvh/bvh_intersector1_bvh8.cpp \
   bvh/bvh_intersector_hybrid8_bvh4.cpp bvh/bvh_intersector_hybrid4_bvh8.cpp \
   bvh/bvh_intersector_hybrid8_bvh8.cpp
+ifeq ($(ISA),avx512)
+ISA_SRC += bvh/bvh_intersector_hybrid16_bvh8.cpp bvh/bvh_intersector_hybrid16_bvh4.cpp
+endif
 
 COMMON_OBJ := $(patsubst %.cpp,$(OUT)/obj/%.o,$(COMMON_SRC))
 MAIN_OBJ   := $(patsubst %.cpp,$(OUT)/obj/kernels/%.o,$(MAIN_SRC))
 ISA_OBJ    := $(patsubst %.cpp,$(OUT)/obj/kernels_avx2/%.o,$(ISA_SRC))
 
-all: $(OUT)/libembree4.so $(OUT)/libref_driver.so
+all: $(OUT)/libembree4$(SUFFIX).so $(OUT)/libref_driver$(SUFFIX).so
 
 HDRS := $(GEN)/kernels/config.h $(GEN)/kernels/hash.h $(GEN)/include/embree4/rtcore_config.h
 
@@ -121,7 +138,7 @@ $(OUT)/export.map:
 	@mkdir -p $(OUT)
 	printf '{ global: rtc*; local: *; };\n' > $@
 
-$(OUT)/libembree4.so: $(COMMON_OBJ) $(MAIN_OBJ) $(ISA_OBJ) $(OUT)/export.map
+$(OUT)/libembree4$(SUFFIX).so: $(COMMON_OBJ) $(MAIN_OBJ) $(ISA_OBJ) $(OUT)/export.map
 	$(CXX) -shared -o $@ $(COMMON_OBJ) $(MAIN_OBJ) $(ISA_OBJ) \
 	    -Wl,--version-script=$(OUT)/export.map -lpthread -ldl
 
@@ -130,8 +147,8 @@ clean:
 .PHONY: all clean
 
 # C-ABI shim used by tests/bench through ctypes (see oracle/ref_driver.cpp)
-driver: $(OUT)/libref_driver.so
-$(OUT)/libref_driver.so: oracle/ref_driver.cpp $(OUT)/libembree4.so
+driver: $(OUT)/libref_driver$(SUFFIX).so
+$(OUT)/libref_driver$(SUFFIX).so: oracle/ref_driver.cpp $(OUT)/libembree4$(SUFFIX).so
 	$(CXX) -std=c++17 -O2 -fPIC -shared -mavx2 -o $@ $< -I$(REF)/include -I$(GEN)/include/embree4 \
-	    -I$(GEN)/include -L$(OUT) -lembree4 -Wl,-rpath,'$$ORIGIN' -lpthread
+	    -I$(GEN)/include -L$(OUT) -lembree4$(SUFFIX) -Wl,-rpath,'$$ORIGIN' -lpthread
 .PHONY: driver

@@ -6,16 +6,23 @@
 // Python tests / bench.py drive the reference through ctypes:
 //   * as the parity checker for the HIP path (tests/, __graft_entry__.smoke),
 //   * as the "reference" CPU baseline (bench.py cpu_baseline leg): worker
-//     threads loop rtcIntersect1 / rtcOccluded1 over contiguous 1024-ray blocks
-//     with FTZ|DAZ set, exactly the blocking of the reference's own
+//     threads of a PERSISTENT, pinned pool (started before the clock) loop
+//     rtcIntersect1 / rtcOccluded1 over contiguous 1024-ray blocks with
+//     FTZ|DAZ set, exactly the blocking of the reference's own
 //     ParallelIntersectBenchmark (tutorials/verify/verify.cpp:5728-5755) and
 //     the MXCSR advice of README.md:10319-10340.
 // Built into oracle/_ref/libref_driver.so (git-ignored, travels with gpurun).
 #include <embree4/rtcore.h>
 #include <xmmintrin.h>
 #include <pmmintrin.h>
+#include <pthread.h>
+#include <sched.h>
+#include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <cstdio>
 #include <cstring>
 #include <thread>
@@ -29,29 +36,82 @@ struct RefScene {
 double now() {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
-template <typename F>
-double run_blocks(unsigned M, int threads, F&& body) {
-  const unsigned BLOCK = 1024;  // verify.cpp:5733 (numRays / 1024 blocks)
-  const unsigned nblocks = (M + BLOCK - 1) / BLOCK;
-  if (threads < 1) threads = 1;
-  std::atomic<unsigned> next(0);
-  auto worker = [&]() {
-    _MM_SET_FLUSH_ZERO_MODE(_MM_FLUSH_ZERO_ON);
-    _MM_SET_DENORMALS_ZERO_MODE(_MM_DENORMALS_ZERO_ON);
+// A persistent worker pool: the clock of a measurement must not contain the creation of 255 threads (a 2^20-ray job lasts ~10 ms).  The reference's own
+// ParallelIntersectBenchmark (tutorials/verify/verify.cpp:5728-5755) runs on the already-running threads of its tasking system; this is the same with
+// std::thread: workers are started (and pinned, one per hardware thread, FTZ|DAZ set: README.md:10319-10340) BEFORE the clock, sleep on a generation
+// counter between jobs, and a job is handed out in 1024-ray blocks through one atomic cursor (verify.cpp:5733).
+struct Pool {
+  std::vector<std::thread> workers;
+  std::vector<int> cpus;                                       // the hardware threads this process may run on
+  std::atomic<unsigned> gen{0}, next{0}, done{0}, quit{0};
+  std::mutex m, jobs; std::condition_variable cv;
+  std::function<void(unsigned, unsigned)> body;
+  unsigned M = 0, nblocks = 0, active = 0;
+  static const unsigned BLOCK = 1024;
+  void work() {
     for (;;) {
-      unsigned b = next.fetch_add(1);
+      const unsigned b = next.fetch_add(1, std::memory_order_relaxed);
       if (b >= nblocks) break;
-      unsigned lo = b * BLOCK, hi = lo + BLOCK < M ? lo + BLOCK : M;
+      const unsigned lo = b * BLOCK, hi = lo + BLOCK < M ? lo + BLOCK : M;
       body(lo, hi);
     }
-  };
-  double t0 = now();
-  std::vector<std::thread> pool;
-  for (int i = 1; i < threads; i++) pool.emplace_back(worker);
-  worker();
-  for (auto& t : pool) t.join();
-  return now() - t0;
-}
+  }
+  void loop(unsigned index) {
+    _MM_SET_FLUSH_ZERO_MODE(_MM_FLUSH_ZERO_ON);
+    _MM_SET_DENORMALS_ZERO_MODE(_MM_DENORMALS_ZERO_ON);
+    unsigned seen = 0;
+    for (;;) {
+      unsigned g; int spins = 0;
+      while ((g = gen.load(std::memory_order_acquire)) == seen) {   // spin for a moment (back-to-back jobs), then sleep (the GPU tests share this host)
+        if (quit.load(std::memory_order_relaxed)) return;
+        if (++spins < 20000) { _mm_pause(); continue; }
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { return gen.load(std::memory_order_acquire) != seen || quit.load() != 0u; });
+      }
+      seen = g;
+      if (index < active) work();
+      done.fetch_add(1, std::memory_order_release);
+    }
+  }
+  void ensure(unsigned n) {                                   // n workers besides the caller
+    if (cpus.empty()) {
+      cpu_set_t set; CPU_ZERO(&set);
+      if (sched_getaffinity(0, sizeof(set), &set) == 0) for (int c = 0; c < CPU_SETSIZE; c++) if (CPU_ISSET(c, &set)) cpus.push_back(c);
+      if (cpus.empty()) cpus.push_back(0);
+    }
+    while (workers.size() < n) {
+      const unsigned i = (unsigned)workers.size();
+      workers.emplace_back([this, i] { loop(i); });
+      cpu_set_t set; CPU_ZERO(&set); CPU_SET(cpus[(i + 1) % cpus.size()], &set);
+      pthread_setaffinity_np(workers.back().native_handle(), sizeof(set), &set);
+    }
+  }
+  void dispatch() {
+    next.store(0); done.store(0);
+    { std::lock_guard<std::mutex> lk(m); gen.fetch_add(1, std::memory_order_release); }
+    cv.notify_all();
+  }
+  void wait_all() { const unsigned all = (unsigned)workers.size(); while (done.load(std::memory_order_acquire) < all) _mm_pause(); }
+  double run(unsigned M_, int threads, std::function<void(unsigned, unsigned)> f) {
+    std::lock_guard<std::mutex> one(jobs);
+    if (threads < 1) threads = 1;
+    ensure((unsigned)threads - 1);                            // (outside the clock)
+    _MM_SET_FLUSH_ZERO_MODE(_MM_FLUSH_ZERO_ON);
+    _MM_SET_DENORMALS_ZERO_MODE(_MM_DENORMALS_ZERO_ON);
+    body = std::move(f); active = (unsigned)threads - 1;
+    M = 0; nblocks = 0; dispatch(); wait_all();               // an empty job first: every worker is awake and spinning when the clock starts
+    M = M_; nblocks = (M + BLOCK - 1) / BLOCK;
+    const double t0 = now();
+    dispatch();
+    work();
+    wait_all();
+    return now() - t0;
+  }
+  ~Pool() { quit.store(1); { std::lock_guard<std::mutex> lk(m); gen.fetch_add(1); } cv.notify_all(); for (auto& t : workers) t.join(); }
+};
+Pool& pool() { static Pool p; return p; }
+template <typename F>
+double run_blocks(unsigned M, int threads, F&& body) { return pool().run(M, threads, std::function<void(unsigned, unsigned)>(body)); }
 }  // namespace
 
 extern "C" {
@@ -311,4 +371,6 @@ __attribute__((visibility("default"))) void refd_free(void* h) {
 
 __attribute__((visibility("default"))) unsigned refd_sizeof_rayhit() { return (unsigned)sizeof(RTCRayHit); }
 __attribute__((visibility("default"))) unsigned refd_hw_threads() { return std::thread::hardware_concurrency(); }
+// which single-ISA build of the reference this driver is linked to (RTC_DEVICE_PROPERTY_NATIVE_RAY16_SUPPORTED is 1 only for the AVX-512 build, rtcore.cpp / device.cpp:getProperty)
+__attribute__((visibility("default"))) int refd_native16(void* h) { return (int)rtcGetDeviceProperty(((RefScene*)h)->device, RTC_DEVICE_PROPERTY_NATIVE_RAY16_SUPPORTED); }
 }

@@ -9,20 +9,30 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = os.path.join(_HERE, "_ref", "libref_driver.so")
+# two single-ISA builds of the reference (oracle/ref.mk): AVX2 (the default, what every parity test uses) and AVX-512 (ISA=avx512: the CPU baseline of bench.py
+# reports both).  Different file names: two libraries of one name cannot live in one process.
+_LIBS = {"avx2": os.path.join(_HERE, "_ref", "libref_driver.so"), "avx512": os.path.join(_HERE, "_ref", "avx512", "libref_driver_avx512.so")}
+_LIB = _LIBS["avx2"]
 
 
-def available():
-    return os.path.exists(_LIB)
+def available(isa="avx2"):
+    if not os.path.exists(_LIBS[isa]):
+        return False
+    if isa == "avx512":                                       # the library must also be able to RUN here
+        try:
+            flags = open("/proc/cpuinfo").read()
+            return all(f in flags for f in ("avx512f", "avx512dq", "avx512bw", "avx512vl", "avx512cd"))
+        except OSError:
+            return False
+    return True
 
 
-_lib = None
+_loaded = {}
 
 
-def _load():
-    global _lib
-    if _lib is None:
-        L = ctypes.CDLL(_LIB)
+def _load(isa="avx2"):
+    if isa not in _loaded:
+        L = ctypes.CDLL(_LIBS[isa])
         L.refd_new.restype = ctypes.c_void_p
         L.refd_new.argtypes = [ctypes.c_char_p]
         L.refd_set_flags.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
@@ -52,8 +62,10 @@ def _load():
             f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint, ctypes.c_int, ctypes.c_int, ctypes.c_uint]
             f.restype = ctypes.c_double
         L.refd_hw_threads.restype = ctypes.c_uint
-        _lib = L
-    return _lib
+        L.refd_native16.restype = ctypes.c_int
+        L.refd_native16.argtypes = [ctypes.c_void_p]
+        _loaded[isa] = L
+    return _loaded[isa]
 
 
 def hw_threads():
@@ -63,8 +75,9 @@ def hw_threads():
 class RefScene:
     """One device + one scene of the real reference."""
 
-    def __init__(self, cfg="", flags=0, quality=1, parent=None):
-        L = _load()
+    def __init__(self, cfg="", flags=0, quality=1, parent=None, isa="avx2"):
+        self.isa = parent.isa if parent is not None else isa
+        L = self._L = _load(self.isa)
         self._h = L.refd_new_object(parent._h) if parent is not None else L.refd_new(cfg.encode())
         if not self._h:
             raise RuntimeError("reference rtcNewDevice failed")
@@ -75,12 +88,12 @@ class RefScene:
     def add_mesh(self, verts, tris, mask=1):
         v = np.ascontiguousarray(verts, np.float32).reshape(-1, 3)
         t = np.ascontiguousarray(tris, np.uint32).reshape(-1, 3)
-        return _load().refd_add_mesh(self._h, v.ctypes.data, v.shape[0], t.ctypes.data, t.shape[0], mask)
+        return self._L.refd_add_mesh(self._h, v.ctypes.data, v.shape[0], t.ctypes.data, t.shape[0], mask)
 
     def add_quads(self, verts, quads, mask=1):
         v = np.ascontiguousarray(verts, np.float32).reshape(-1, 3)
         q = np.ascontiguousarray(quads, np.uint32).reshape(-1, 4)
-        return _load().refd_add_quads(self._h, v.ctypes.data, v.shape[0], q.ctypes.data, q.shape[0], mask)
+        return self._L.refd_add_quads(self._h, v.ctypes.data, v.shape[0], q.ctypes.data, q.shape[0], mask)
 
     def new_object(self, flags=0):
         """a second scene on this scene's device, to be instanced with add_instance (commit it first)"""
@@ -89,20 +102,20 @@ class RefScene:
     def add_instance(self, obj, local2world, mask=1):
         """RTC_GEOMETRY_TYPE_INSTANCE of `obj`; local2world = 12 floats, column major (vx, vy, vz, p)"""
         x = np.ascontiguousarray(local2world, np.float32).reshape(12)
-        return _load().refd_add_instance(self._h, obj._h, x.ctypes.data, mask)
+        return self._L.refd_add_instance(self._h, obj._h, x.ctypes.data, mask)
 
     def commit(self):
-        self.commit_seconds = _load().refd_commit(self._h)
+        self.commit_seconds = self._L.refd_commit(self._h)
         return self.commit_seconds
 
     def bounds(self):
         b = np.zeros(8, np.float32)
-        _load().refd_bounds(self._h, b.ctypes.data)
+        self._L.refd_bounds(self._h, b.ctypes.data)
         return b[0:3].copy(), b[4:7].copy()
 
     def _run(self, fn, arr, threads):
         assert arr.flags["C_CONTIGUOUS"]
-        return getattr(_load(), fn)(self._h, arr.ctypes.data, arr.shape[0], threads)
+        return getattr(self._L, fn)(self._h, arr.ctypes.data, arr.shape[0], threads)
 
     def intersect1(self, rayhits, threads=1):
         return self._run("refd_intersect1", rayhits, threads)
@@ -121,7 +134,7 @@ class RefScene:
         if valid is not None:
             v = np.ascontiguousarray(valid, np.int32)
             assert v.shape[0] == rays.shape[0]
-        dt = _load().refd_packet(self._h, K, 1 if any_hit else 0, rays.ctypes.data, rays.shape[0], v.ctypes.data if v is not None else None, threads)
+        dt = self._L.refd_packet(self._h, K, 1 if any_hit else 0, rays.ctypes.data, rays.shape[0], v.ctypes.data if v is not None else None, threads)
         assert dt >= 0.0, "unsupported packet size"
         return dt
 
@@ -130,20 +143,24 @@ class RefScene:
 
     def set_filters(self, ngeom, mode):
         """the fixed filter rules of ref_driver.cpp on geometries 0..ngeom-1: bit 0 intersect filter, bit 1 occluded filter, bit 2 accept the argument filter"""
-        _load().refd_set_filters(self._h, ngeom, mode)
+        self._L.refd_set_filters(self._h, ngeom, mode)
 
     def intersect1_args(self, rayhits, arg_rule=False, flags=0, threads=1):
-        return _load().refd_intersect1_args(self._h, rayhits.ctypes.data, rayhits.shape[0], threads, 1 if arg_rule else 0, flags)
+        return self._L.refd_intersect1_args(self._h, rayhits.ctypes.data, rayhits.shape[0], threads, 1 if arg_rule else 0, flags)
 
     def occluded1_args(self, rays, arg_rule=False, flags=0, threads=1):
-        return _load().refd_occluded1_args(self._h, rays.ctypes.data, rays.shape[0], threads, 1 if arg_rule else 0, flags)
+        return self._L.refd_occluded1_args(self._h, rays.ctypes.data, rays.shape[0], threads, 1 if arg_rule else 0, flags)
+
+    def native16(self):
+        """RTC_DEVICE_PROPERTY_NATIVE_RAY16_SUPPORTED of the library behind this scene: 1 for the AVX-512 build"""
+        return int(self._L.refd_native16(self._h))
 
     def error(self):
-        return _load().refd_error(self._h)
+        return self._L.refd_error(self._h)
 
     def close(self):
         if self._h:
-            _load().refd_free(self._h)
+            self._L.refd_free(self._h)
             self._h = None
 
     def __del__(self):
