@@ -9,33 +9,38 @@ crown.ecs is not shipped with the reference, so the scene is the seeded syntheti
 49 geometries) unless $EMBREE_MODEL_DIR/crown/crown.ecs exists; rays are the cosine-weighted bounce rays of a 1024 x 1024 camera image, generated
 with the reference's RandomSampler.  A "step" = one closest-hit pass over one batch of 2^20 rays through rtcIntersect1MDevice, rays already
 resident in HBM (every step has its own pristine copy of the batch, staged before the timed region).  The timed region issues the K steps back to
-back round-robin on --streams HIP streams (default 4), the way a wavefront renderer keeps several ray batches in flight: the persistent traversal
-kernel fills the chip, so the next batch's workgroups start as those of the previous one retire and the tail of a batch overlaps useful work.
-The roofline of the line is computed from exactly the launches that were timed (their own durations, HIP events on their streams).  One batch at a
-time (--streams 1) is measured right after the timed region and reported under "serial" (same kernel, same buffers): there the kernel's own
-duration is the step time.
+back on ONE HIP stream (--streams 1, the default since round 4): one 2^20-ray batch at a time, which is the metric as BASELINE.json words it
+("1M incoherent diffuse rays"); `value` is that.  Several batches in flight (--pipeline-streams 4: the way a wavefront renderer drives
+rtcIntersect1MDevice -- the persistent traversal kernel fills the chip, so the next batch's workgroups start as those of the previous one retire
+and the tail of a batch overlaps useful work) is measured right after the timed region and reported as the named extra "pipelined".
 
 Workload `shadow16m`: configs[3] = 16 Mi shadow rays (16 per hit point of the configs[2] rays) through rtcOccluded1MDevice, STRONG scaling: the
 16,777,216 rays are sharded contiguously over the N ranks (embree_amd/shard.py), each rank packs its 4-byte results and the shards are gathered on
 every GPU with one ncclAllGather over xGMI (--gather rccl; 64 MB in total); a step = the whole 16 Mi-ray job incl. pack + gather.
 
 Multi-GPU (--gpus N, launched by torch.distributed.run, one process per GPU): the BVH is replicated (every rank builds it from the same inputs:
-the build is deterministic), `crown` is weak scaling (2^20 rays per rank per step, no exchange inside the timed region; the RCCL gather of the
-packed hit records is exercised and timed AFTER it, reported under "gather"), `shadow16m` is strong scaling with the gather inside.  Rendezvous,
-barrier and MAX-over-ranks use torch.distributed (gloo) on the host; the data path uses RCCL through the library's own C ABI (mi355_comm_*).
+the build is deterministic) and nothing of the rays crosses xGMI before they are traced.  For N > 1 the north star's "hits gathered over RCCL/xGMI" is
+INSIDE the timed step of both workloads: `crown` (weak scaling, 2^20 rays per rank and step) packs the fields a hit writes (32 of the 96 bytes) and
+ncclGather-s them to rank 0; `shadow16m` (strong scaling) all-gathers the 4-byte results.  The collective of batch k runs on a communication stream,
+ordered behind the pack by an event, and overlaps the trace of batch k + 1 (the trace kernels still run one at a time); the timed region ends when
+every gather has landed; the root checks every rank's block against that rank's own checksums.  If RCCL cannot form a communicator the line is still
+printed, with "rccl_ranks": 0, the reason under "gather" and the metric string saying that nothing was gathered.  Rendezvous, barrier and
+MAX-over-ranks use torch.distributed (gloo) on the host; the data path uses RCCL through the library's own C ABI (mi355_comm_*).
 
 Printed JSON (rank 0, one line): metric/value/... as the driver contract, plus
-  roofline      bound "hbm" as SURVEY 8(d) prescribes: achieved = ALGORITHMIC bytes per launch / average kernel duration of the TIMED launches
-                (HIP events on the launch stream; agrees with rocprofv3 --kernel-trace of this command); bytes = rays*(48 read + 52 written on
-                hit) + visited nodes*80 + fetched triangle records*48, visit counts from the counting build of the same kernel on the same rays.
-                Most of those bytes are L1/L2/Infinity-Cache hits, so next to it: `hbm_counter` (PMC FETCH_SIZE x2 + WRITE_SIZE per launch, from
-                profiles/pmc_bench_latest.json, only if that file was collected for THIS kernel source -- else null) and `valu`, the roof that
-                actually binds (SQ_INSTS_VALU per launch x 4 cycles / (1024 SIMDs x measured clock) / kernel time).
-  roofline.address_rate   the resource that binds: scattered lane-addresses per second against 256 CUs x 1 per clock
-  serial        the same kernel launched alone, back to back on one stream (with --streams 1: `pipelined`, --pipeline-streams batches in flight)
+  roofline      achieved / peak / frac as SURVEY 8(d) prescribes: ALGORITHMIC bytes per launch / kernel duration of the TIMED launches (HIP events on the
+                launch stream; agrees with rocprofv3 --kernel-trace of this command) / 8 TB/s; bytes = rays*(48 read + 52 written on hit) + visited
+                nodes*80 + fetched triangle records*48, visit counts from the counting build of the same kernel on the same rays.  Most of those bytes
+                are L1/L2/Infinity-Cache hits ("frac_is": cache-served), so next to it: `hbm_counter_frac` / `hbm_counter_from_profile` = what reaches
+                the memory side (PMC FETCH_SIZE x2 + WRITE_SIZE per launch, from profiles/pmc_bench_latest.json, only if that file was collected for
+                THIS kernel source -- else null), and `bound`: what the kernel actually follows -- VALU issue (`valu_from_profile`; round 4 cut the
+                (lane, load) pairs by 16 % at +16 % VALU work: -8 %, profiles/r04_pair_records.md), with `address_rate` (scattered lane-addresses per
+                second against 256 CUs x 1 per clock) beside it.
+  pipelined     the same kernel with --pipeline-streams (4) batches in flight (with --streams > 1 the roles swap: `serial` = one batch at a time)
   end_to_end    rtcIntersect1M on a pageable host array: H2D + kernel + D2H (PCIe-inclusive; never `value`)
-  cpu_baseline  the REAL reference (oracle/_ref, Embree 4.4.1 AVX2) looping rtcIntersect1 over the same rays on the host threads (kind
-                "reference") with its rtcCommitScene timed 1 + 5 times, or the scalar C restatement on a sample (kind "port")
+  cpu_baseline  the REAL reference (oracle/_ref, Embree 4.4.1, AVX2 and AVX-512 single-ISA builds) looping rtcIntersect1 over 16 x the step's rays on a
+                persistent pinned pool of all host threads (kind "reference"; value_1Mi, rtcIntersect8/16 and rtcCommitScene beside it), or the scalar C
+                restatement on a sample (kind "port")
   parity_vs_reference  the timed kernel's output against the reference on all rays, exact-t ties classified (tests/helpers.py); bench.py FAILS on a mismatch
 """
 import argparse
@@ -292,13 +297,14 @@ def main():
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--workload", default="crown", choices=["crown", "shadow16m"])
     ap.add_argument("--rays", type=int, default=1 << 20, help="crown: rays per batch and GPU; shadow16m: hit points (x16 shadow rays), all GPUs together")
-    ap.add_argument("--streams", type=int, default=4, help="HIP streams the TIMED steps are issued on round-robin = ray batches in flight (1 = one batch at a time)")
+    ap.add_argument("--streams", type=int, default=1, help="HIP streams the TIMED steps are issued on round-robin = ray batches in flight (1 = one batch at a time: the metric as BASELINE.json words it, the default)")
     ap.add_argument("--pipeline-streams", type=int, default=4, help="batches in flight of the extra `pipelined` leg that is measured when --streams is 1 (0 = skip it)")
     ap.add_argument("--gather", default="auto", choices=["auto", "rccl", "none"], help="results gathered on the GPUs over RCCL (auto: rccl when more than one rank)")
     ap.add_argument("--phi", type=int, default=158, help="sphere tessellation of the synthetic crown (158 -> 4.76M triangles)")
     ap.add_argument("--config", default="", help="extra rtcNewDevice config, e.g. max_leaf=2,int_cost=0.5")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--dump", default="", help="shadow16m, rank 0: save the first 2^22 rays and their gathered result words to this .npz (tests/test_gpu_round3.py checks them against the reference)")
+    ap.add_argument("--dump", default="", help="shadow16m, rank 0: save the first --dump-rays rays and their gathered result words to this .npz (tests/test_gpu_round3.py checks them against the reference)")
+    ap.add_argument("--dump-rays", type=int, default=1 << 22)
     ap.add_argument("--inprocess-gpus", type=int, default=0, help="extra leg at N = 1: rtcIntersect1M through ONE RTCDevice over this many GPUs (0 = all GPUs of the node, 1 = skip; "
                                                                     "more than the node has = replicas share GPUs)")
     ap.add_argument("--scene", default="", help=".ecs / .xml / .obj scene file; default: $EMBREE_MODEL_DIR/crown/crown.ecs if it exists, "
@@ -469,16 +475,38 @@ def main():
             comm.close()
             comm, comm_err = None, comm_err or "another rank has no communicator"
         if comm is not None:
-            packed = api.DeviceArray(pack_bytes, gpu)
-            gathered = api.DeviceArray(pack_bytes * world, gpu)
+            # two result buffers: the gather of batch k runs on the communication stream while batch k + 1 is traced and packed
+            packed = [api.DeviceArray(pack_bytes, gpu) for _ in range(2)]
+            gathered = [api.DeviceArray(pack_bytes * world if (shadow or rank == 0) else 16, gpu) for _ in range(2)]
+    gather_in_step = comm is not None and (shadow or world > 1 or args.gather == "rccl")
+    comm_stream, ev_packed, ev_gathered, step_no = None, None, None, [0]
+    if gather_in_step:
+        cs = C.c_void_p()
+        assert L.mi355_stream_create(gpu, C.byref(cs)) == 0, L.mi355_last_error()
+        comm_stream = cs
+        ev_packed, ev_gathered = [C.c_void_p() for _ in range(2)], [C.c_void_p() for _ in range(2)]
+        for e in ev_packed + ev_gathered:
+            assert L.mi355_event_create(C.byref(e)) == 0
 
     def step(buf, stream, ev_a=None, ev_b=None):
-        """one pass of the hot path over one batch (+ pack and gather where the workload has them)"""
+        """one pass of the hot path over one batch: trace; with a communicator also pack the written fields and gather them over RCCL -- the gather of THIS batch
+        runs on the communication stream and overlaps the trace of the NEXT one (the trace kernels themselves still run one at a time on `stream`)"""
         rc = L.mi355_trace_timed(bvh, buf.ptr, M, rec, any_hit, stream, ev_a, ev_b)
         assert rc == 0, L.mi355_last_error()
-        if shadow and comm is not None:
-            assert L.mi355_pack_occluded(buf.ptr, M, rec, packed.ptr, stream) == 0, L.mi355_last_error()
-            comm.allgather(packed.ptr, gathered.ptr, pack_bytes, stream)
+        if gather_in_step:
+            k = step_no[0] & 1
+            if step_no[0] >= 2:                              # the result buffer of batch k - 2 must have left before it is packed over
+                assert L.mi355_stream_wait_event(stream, ev_gathered[k]) == 0
+            pack = L.mi355_pack_occluded if shadow else L.mi355_pack_hits
+            assert pack(buf.ptr, M, rec, packed[k].ptr, stream) == 0, L.mi355_last_error()
+            assert L.mi355_event_record(ev_packed[k], stream) == 0
+            assert L.mi355_stream_wait_event(comm_stream, ev_packed[k]) == 0
+            if shadow:
+                comm.allgather(packed[k].ptr, gathered[k].ptr, pack_bytes, comm_stream)
+            else:
+                comm.gather(packed[k].ptr, gathered[k].ptr, pack_bytes, 0, comm_stream)
+            assert L.mi355_event_record(ev_gathered[k], comm_stream) == 0
+            step_no[0] += 1
 
     for st_ in streams:                                     # per-stream traversal scratch exists before anything is timed (also when --warmup 0)
         assert L.mi355_trace_prepare(bvh, st_) == 0, L.mi355_last_error()
@@ -505,19 +533,40 @@ def main():
     for b in (bufs[args.warmup], bufs[-1]):
         assert b.download(dtype).tobytes() == result.tobytes(), "timed kernel and counting kernel disagree"
     gather_check = None
-    if shadow and comm is not None:                        # every rank holds all shards: rank r's part must be what rank r computed
-        g = gathered.download(np.uint32).reshape(world, M)
-        assert (g[rank] == result["tfar"].view(np.uint32)).all(), "gathered shard differs from the local result"
-        occl = np.array([int((g[r] == 0xFF800000).sum()) for r in range(world)], np.int64)
-        mine = dist[1].tensor([int(np.isneginf(result["tfar"]).sum())], dtype=dist[1].int64) if dist else None
-        if dist:
-            allc = [dist[1].zeros(1, dtype=dist[1].int64) for _ in range(world)]
-            dist[0].all_gather(allc, mine)
-            assert [int(a[0]) for a in allc] == occl.tolist(), "gathered occlusion counts differ from what the ranks computed"
-        gather_check = dict(transport="RCCL ncclAllGather over xGMI", bytes_total=pack_bytes * world, occluded_per_rank=occl.tolist())
-        if args.dump and rank == 0:
-            k = min(1 << 22, M)
-            np.savez(args.dump, rays=rays[:k], gathered=g.reshape(-1)[:k])
+    if gather_in_step:
+        L.mi355_synchronize(comm_stream)
+        last = (step_no[0] - 1) & 1                        # the result buffer the last timed batch was gathered into
+        if shadow:                                         # every rank holds all shards: rank r's part must be what rank r computed
+            g = gathered[last].download(np.uint32).reshape(world, M)
+            assert (g[rank] == result["tfar"].view(np.uint32)).all(), "gathered shard differs from the local result"
+            occl = np.array([int((g[r] == 0xFF800000).sum()) for r in range(world)], np.int64)
+            mine = dist[1].tensor([int(np.isneginf(result["tfar"]).sum())], dtype=dist[1].int64) if dist else None
+            if dist:
+                allc = [dist[1].zeros(1, dtype=dist[1].int64) for _ in range(world)]
+                dist[0].all_gather(allc, mine)
+                assert [int(a[0]) for a in allc] == occl.tolist(), "gathered occlusion counts differ from what the ranks computed"
+            gather_check = dict(transport="RCCL ncclAllGather over xGMI, on a communication stream: the gather of batch k overlaps the trace of batch k + 1", inside_timed_region=True,
+                                bytes_total=pack_bytes * world, occluded_per_rank=occl.tolist())
+            if args.dump and rank == 0:
+                k = min(args.dump_rays, M)
+                np.savez(args.dump, rays=rays[:k], gathered=g.reshape(-1)[:k])
+        else:                                              # the root holds every rank's packed hit records: rank r's block must be what rank r computed
+            sums = np.array([int(result["primID"].astype(np.uint64).sum()), int(result["tfar"].view(np.uint32).astype(np.uint64).sum()),
+                             int((result["geomID"] != INVALID_ID).sum())], np.int64)
+            allsums = [sums]
+            if dist:
+                tl = [dist[1].zeros(3, dtype=dist[1].int64) for _ in range(world)]
+                dist[0].all_gather(tl, dist[1].from_numpy(sums.copy()))
+                allsums = [t.numpy() for t in tl]
+            if rank == 0:
+                g = gathered[last].download(np.uint32).reshape(world, M, 8)          # { tfar, u, v, primID | geomID, Ng }
+                assert (g[0][:, 0] == result["tfar"].view(np.uint32)).all() and (g[0][:, 3] == result["primID"]).all() and (g[0][:, 4] == result["geomID"]).all(), "root's own block differs from its result"
+                for r in range(world):
+                    got = np.array([int(g[r][:, 3].astype(np.uint64).sum()), int(g[r][:, 0].astype(np.uint64).sum()), int((g[r][:, 4] != INVALID_ID).sum())], np.int64)
+                    assert (got == allsums[r]).all(), "gathered block of rank %d differs from what that rank computed" % r
+            gather_check = dict(transport="RCCL ncclGather of the packed hit records (32 B per ray) to rank 0 over xGMI, on a communication stream: the gather of batch k overlaps the trace "
+                                          "of batch k + 1", inside_timed_region=True, bytes_per_rank=pack_bytes, bytes_into_root_per_step=pack_bytes * (world - 1),
+                                checked="every rank's block on the root against that rank's own checksums (primID sum, tfar-bits sum, hit count)")
 
     # ---- extra legs, outside the timed region --------------------------------------------------------------------------------------
     pipelined = None
@@ -598,27 +647,6 @@ def main():
             except Exception as e:                            # noqa: BLE001
                 multi = dict(error=repr(e))
     gather = None
-    if not shadow and comm is not None:                    # crown: the north-star gather of the packed hit records, exercised and timed outside the headline
-        def do_gather():
-            evg = Events(L, 1)
-            L.mi355_event_record(evg.ev[0], streams[0])
-            assert L.mi355_pack_hits(bufs[-1].ptr, M, rec, packed.ptr, streams[0]) == 0, L.mi355_last_error()
-            comm.gather(packed.ptr, gathered.ptr, pack_bytes, 0, streams[0])
-            L.mi355_event_record(evg.ev[1], streams[0])
-            deadline = time.time() + 60
-            while L.mi355_stream_query(streams[0]) == 1:
-                if time.time() > deadline:
-                    return dict(error="gather did not complete within 60 s")
-                time.sleep(0.001)
-            ms = evg.ms(0)
-            out = dict(transport="RCCL ncclGather to GPU 0 over xGMI", bytes_per_rank=pack_bytes, ms=round(ms, 3))
-            if rank == 0:
-                g = gathered.download(np.uint32).reshape(world, M, 8)
-                assert (g[0][:, 0] == result["tfar"].view(np.uint32)).all() and (g[0][:, 3] == result["primID"]).all() and (g[0][:, 4] == result["geomID"]).all()
-                out["gb_per_s_into_root"] = round(pack_bytes * (world - 1) / (ms * 1e-3) / 1e9, 1) if world > 1 else None
-            return out
-        gather = run_guarded(do_gather, 90)
-
     if rank == 0:
         avg_ms = float(np.mean(kernel_ms))
         conc = float(np.sum(kernel_ms)) * 1e-3 / elapsed
@@ -630,7 +658,10 @@ def main():
         bw = (C.c_double * 2)()
         bw_ok = L.mi355_measure_bandwidth(gpu, 2 << 30, 5, bw) == 0          # what a streaming copy / read kernel reaches on THIS box ("also measure")
         pmc, pmc_note = load_pmc() if not shadow else (None, "PMC passes are collected for the closest-hit kernel only")
-        roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+        roof = {"bound": "valu", "bound_is": "what the kernel follows is VALU issue (valu_from_profile; address_rate beside it), not bytes: achieved / peak / frac below are the "
+                                             "SURVEY 8(d) figures (algorithmic bytes against the HBM peak), hbm_counter_frac is what reaches the memory side",
+                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "frac_is": "algorithmic bytes x launches / elapsed / HBM peak: mostly CACHE-SERVED bytes (L1 / L2 / Infinity Cache), not HBM traffic",
                 "traffic": int(pmc["hbm_traffic_bytes_per_launch"]) if pmc and "hbm_traffic_bytes_per_launch" in pmc else None,
                 "traffic_source": "profiles/pmc_bench_latest.json (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE per lone launch of this kernel source)" if pmc else None,
                 "peak_measured": {"copy_GBs": round(bw[0], 1), "read_GBs": round(bw[1], 1), "frac_of_copy": round(achieved / bw[0], 4) if bw_ok and bw[0] > 0 else None,
@@ -665,6 +696,7 @@ def main():
             clock_hz = pmc.get("kernel_cycles", 0.0) / (lone_ms * 1e-3) if (pmc.get("kernel_cycles") and lone_ms) else 2.4e9
             clock_hz = min(max(clock_hz, 1.0e9), 2.4e9)
             hbm_rate = pmc["hbm_traffic_bytes_per_launch"] * args.steps / elapsed / 1e9
+            roof["hbm_counter_frac"] = round(hbm_rate / HBM_PEAK_GBS, 4)
             roof["hbm_counter_from_profile"] = {"bytes_per_launch": int(pmc["hbm_traffic_bytes_per_launch"]), "achieved": round(hbm_rate, 1), "frac": round(hbm_rate / HBM_PEAK_GBS, 4),
                                                 "frac_of_copy": round(hbm_rate / bw[0], 4) if bw_ok and bw[0] > 0 else None,
                                                 "what": "rocprofv3 --pmc FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE per launch of this kernel source (profiles/pmc_bench_latest.json, hash %s) x launches timed / elapsed; includes Infinity-Cache hits" % pmc["source_hash"]}
@@ -678,7 +710,8 @@ def main():
             roof["pmc_note"] = pmc_note
         out = {
             "metric": ("Mrays/s (shadow rays, any-hit) on crown, 16 Mi rays sharded" if shadow else
-                       "Mrays/s (incoherent diffuse, closest-hit) on crown" + (", %d batches of 2^20 rays in flight (one batch at a time: serial.value)" % len(tstreams) if len(tstreams) > 1 else "")),
+                       "Mrays/s (incoherent diffuse, closest-hit) on crown" + (", %d batches of 2^20 rays in flight (one batch at a time: serial.value)" % len(tstreams) if len(tstreams) > 1 else "")
+                       + ((", hits packed and gathered to rank 0 over RCCL inside the step" if gather_in_step else ", NO gather (RCCL communicator unavailable)") if world > 1 else "")),
             "value": round(value, 2), "unit": "Mrays/s",
             "n_gpus": world, "ranks": world, "distinct_gpus": min(world, ngpu), "rccl_ranks": (world if comm is not None else 0), "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
             "higher_is_better": True, "scaling": "strong" if shadow else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic" if not scene_path else "file",
@@ -687,7 +720,7 @@ def main():
                                    ("configs[2]: %s, %d triangles, %d geometries, %d incoherent diffuse-bounce rays per GPU and step, closest-hit, rays + BVH resident in HBM, %s"
                                     % (scene_name, ntri, len(meshes), M, "one batch at a time" if len(tstreams) == 1 else "%d batches in flight" % len(tstreams))),
                        "rays_per_gpu": M, "triangles": ntri, "batches_in_flight": len(tstreams),
-                       "parallelism": "rays sharded x%d, BVH replicated (deterministic build on every rank), %s" % (world, "RCCL all-gather of the 4-byte results inside the step" if (shadow and comm is not None) else "no collective inside the step"),
+                       "parallelism": "rays sharded x%d, BVH replicated (deterministic build on every rank), %s" % (world, ("RCCL all-gather of the 4-byte results" if shadow else "RCCL gather of the packed 32-byte hit records to rank 0") + " inside the step, on a communication stream (overlaps the next batch's trace)" if gather_in_step else "no collective inside the step"),
                        "device_config": args.config},
             "roofline": roof,
             "build": {"metric": "BVH build Mprims/s", "gpu_build_ms": round(float(np.min(build_ms)), 3), "gpu_build_ms_median": round(float(np.median(build_ms)), 3),

@@ -139,6 +139,7 @@ TraceScratch* Bvh::scratch_for(hipStream_t s) {
   if (it != scratch.end()) return &it->second;
   TraceScratch sc;
   if (hipMalloc((void**)&sc.counter, 4096) != hipSuccess) return nullptr;
+  if (hipMemset(sc.counter, 0, 4096) != hipSuccess) return nullptr;   // the ray cursors start at zero; every launch leaves them at zero (trace.hip, wave_exit)
   if (hipMalloc(&sc.spill, trace_spill_bytes(numCUs, info.depth)) != hipSuccess) return nullptr;
   if (hipMalloc((void**)&sc.stats, 256) != hipSuccess) return nullptr;
   { void* h = nullptr; void* d = nullptr;

@@ -57,6 +57,7 @@ struct Device : RefCounted {
   unsigned shardMin = 16384;                                 // host-array / device-array batches of fewer rays than this per replica stay on replica 0 (config key shard_min)
   int verbose = 0;
   bool benchmark = false;
+  bool hostInPlace = false;                                  // config key host_in_place=1: large host arrays are traced where they lie (registered + mapped), see replica_query
   bool smallInPlace = true;                                  // config key small_in_place=0: small host queries go through device staging like the others (A/B)
   unsigned pipelineMin = 262144, pipelineChunk = 65536;   // host-array queries of at least pipelineMin rays are cut into chunks of pipelineChunk rays (config keys host_pipeline_min / host_pipeline_chunk)
   mi355_build_params build;
@@ -519,6 +520,7 @@ void parse_config(Device* d, const char* cfg) {
     else if (k == "int_cost") d->build.int_cost = (float)atof(v.c_str());
     else if (k == "top_splits") d->build.top_splits = atoi(v.c_str()) != 0 ? 1u : 0u;                 // MEDIUM builds: references that dwarf all others are cut into grid pieces first
     else if (k == "top_split_min") d->build.top_split_min = (uint32_t)atol(v.c_str());
+    else if (k == "host_in_place") d->hostInPlace = atoi(v.c_str()) != 0;                             // rtcIntersect1M / rtcOccluded1M on large host arrays: trace them in place over the host link
     else if (k == "top_split_rel") d->build.top_split_rel = (float)atof(v.c_str());
     else if (k == "top_split_cell") d->build.top_split_cell = (float)atof(v.c_str());
     else if (k == "trav_cost") d->build.trav_cost = (float)atof(v.c_str());
@@ -676,6 +678,24 @@ static void replica_query(Scene* s, size_t k, char* data, unsigned M, size_t str
     if (flags & MI355_TRACE_ITER_CAP_HIT) THROW(RTC_ERROR_UNKNOWN, "traversal stopped at its iteration cap: results are incomplete");
     if (flags & MI355_TRACE_STACK_OVERFLOW) THROW(RTC_ERROR_UNKNOWN, "traversal stack overflow: results are incomplete");
     return;
+  }
+  // "host_in_place=1" (or MI355_HOST_IN_PLACE=1): large host arrays are traced where they lie -- the caller's array is registered with the device (pinned + mapped) and the
+  // kernel reads the 48 bytes of every ray and writes the <= 52 bytes of every hit over the host link itself, instead of 96 bytes each way through a staging
+  // copy.  Off by default until measured against the chunked pipeline below on the round's box (bench.py end_to_end; tests/gpu_hostpath.py).
+  static const bool envInPlace = getenv("MI355_HOST_IN_PLACE") && atoi(getenv("MI355_HOST_IN_PLACE")) != 0;
+  if ((envInPlace || s->device->hostInPlace) && M >= s->device->pipelineMin) {
+    const bool reg = pinned || hipHostRegister(data, bytes, hipHostRegisterMapped) == hipSuccess;
+    if (!reg) (void)hipGetLastError();
+    void* dp = nullptr;
+    if (reg && hipHostGetDevicePointer(&dp, data, 0) == hipSuccess && dp) {
+      struct Unpin { void* p; ~Unpin() { if (p) hipHostUnregister(p); } } unpin{pinned ? nullptr : data};
+      std::lock_guard<std::mutex> pipeLock(r.pipeMtx);
+      core_check(trace_launch(b, dp, M, stride, any, qflags, nullptr), "trace");
+      check_trace_status(b, nullptr);                        // (waits for the launch)
+      return;
+    }
+    (void)hipGetLastError();
+    if (reg && !pinned) hipHostUnregister(data);
   }
   char* d = r.stage(bytes);
   if (M >= s->device->pipelineMin && pipelined_query(s, r, data, d, M, stride, any, qflags, bytes, pinned)) return;

@@ -262,6 +262,7 @@ constexpr uint32_t QCAP = MI355_QCAP;      // ring capacity (pairs) per wave
 constexpr uint32_t PUSH_ROUNDS_DEFAULT = 5;  // triangle bits a lane may queue per iteration (the rest waits one iteration; env MI355_PUSH_ROUNDS)
 constexpr uint32_t NUM_CURSORS = 8;        // ray cursors per launch (one per XCD)
 constexpr uint32_t CURSOR_STRIDE = 64;     // words between cursors: each one in its own 256-byte block
+constexpr uint32_t EXIT_WORD = NUM_CURSORS * CURSOR_STRIDE;   // behind the cursors: waves of the running launch that have left (the last one zeroes the cursors for the next launch)
 
 #ifndef MI355_TRACE_ATTR
 #define MI355_TRACE_ATTR
@@ -373,8 +374,19 @@ __global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceAr
   unsigned long long stRefillClk = 0, stLoopClk = 0, stNodeClk = 0; uint32_t stRefillEv = 0;      // STATS: shader clocks (s_memtime) inside the hand-out block / the whole loop / the node step, hand-out events
   const unsigned long long stClk0 = STATS ? __builtin_readcyclecounter() : 0ull;
 
+  // The ray cursors are zero when a launch starts because the LAST wave of the launch before it left them so (a hipMemsetAsync in front of every launch was a
+  // second node on the stream per query: rtcIntersect1 pays it per ray).  A wave leaves only when every cursor is dry, so the wave that counts itself out last
+  // knows nobody reads them any more.
+  auto wave_exit = [&]() {
+    if (lane == 0u) {
+      if (atomicAdd(a.counter + EXIT_WORD, 1u) == gridDim.x * (BLOCK / 64u) - 1u) {
+        for (uint32_t c = 0; c < NUM_CURSORS; c++) atomicExch(a.counter + c * CURSOR_STRIDE, 0u);
+        atomicExch(a.counter + EXIT_WORD, 0u);
+      }
+    }
+  };
   const uint32_t rayCount = a.deferCount ? *a.deferCount * 64u : a.count;   // (wave-uniform) rays to hand out: all of them, or those of the deferred packets
-  if (rayCount == 0u) return;                                               // (the pass behind a packet launch none of whose packets gave up)
+  if (rayCount == 0u) { wave_exit(); return; }                              // (the pass behind a packet launch none of whose packets gave up)
   uint32_t iter = 0;
   for (; iter < a.iterCap; iter++) {
     // ------------------------------------------------------------------ 0. a full batch of queued pairs is waiting: issue the loads of its triangle records now, so that
@@ -731,6 +743,7 @@ __global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceAr
 
   if (!ANY && dCount != 0u) flush_done();                        // the last finished rays
   if (iter >= a.iterCap) a.status[STATUS_ITER_CAP] = 1u;        // left the loop through the cap, not through "no rays left": results are incomplete
+  wave_exit();
   if (STATS) {
     atomicAdd(&a.stats[0], (unsigned long long)stNodes);
     atomicAdd(&a.stats[1], (unsigned long long)stTris);
@@ -1038,8 +1051,7 @@ static int launch_trace_locked(Bvh* b, TraceScratch* sc, void* d_rays, uint32_t 
   const uint32_t maxBlocks = resident_blocks(b, fn);
   uint32_t blocks = (count + BLOCK - 1) / BLOCK;
   if (blocks > maxBlocks) blocks = maxBlocks;
-  HIP_TRY(hipMemsetAsync(sc->counter, 0, NUM_CURSORS * CURSOR_STRIDE * sizeof(uint32_t), s));
-  TraceArgs a;
+  TraceArgs a;                                                 // (the ray cursors are zero: the last wave of the previous launch on this stream left them so, see wave_exit)
   a.nodes = (const uint4*)b->d_nodes; a.tris = (const float4*)b->d_tris; a.hasRoot = b->root != MI355_EMPTY_REF ? 1u : 0u;
   a.rays = (char*)d_rays; a.count = count; a.stride = (uint32_t)stride; a.insts = (const float4*)b->d_insts; a.deferList = deferList; a.deferCount = deferCount; a.rules = (const uint4*)b->d_rules;
   a.counter = sc->counter; a.spill = (uint2*)sc->spill; a.spillPerLane = trace_spill_per_lane(b->info.depth); a.stats = nullptr;

@@ -1,0 +1,308 @@
+"""GPU tests added in round 4 (pytest -m gpu), all through the C ABI -- the parity corners VERDICT r03 names:
+
+  * RTC_BUILD_QUALITY_HIGH and _LOW trees of configs[2] (crown stand-in, 4.76 M triangles) and configs[4] (powerplant stand-in, 12.7 M) at FULL size against the
+    REAL reference on 2^20 rays (round 3 compared them with the repo's own MEDIUM tree only);
+  * the Cornell-box golden rays through a HIGH tree under the tie rule (round 3 accepted 99.5 % equal IDs);
+  * the reference's own tutorials/minimal/minimal.cpp, compiled UNMODIFIED in the build container against include/embree4/rtcore.h + libembree4_mi355.so
+    (__graft_entry__.build()), run here: its two known answers;
+  * a 64 M-triangle commit (32-bit index arithmetic, level margins, arena sizing) + 2^18 rays against the real reference;
+  * rtcIntersect1MDeviceSharded / rtcOccluded1MDeviceSharded (per-GPU pointers) = the single-GPU bytes; mi355_pack_hits_inst carries instID;
+  * two threads issuing RTC_RAY_QUERY_FLAG_COHERENT queries on one scene at the same time (the deferred list is per (tree, stream)).
+"""
+import ctypes as C
+import os
+import subprocess
+import threading
+
+import numpy as np
+import pytest
+
+from embree_amd import workloads as W
+from embree_amd.rtypes import rays_of, INVALID_ID, RAYHIT_DTYPE, RAY_DTYPE
+from tests.helpers import compare_closest, compare_closest_arbitrated, compare_occluded
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def api():
+    from embree_amd import api as A
+    A.load()
+    assert A.load().mi355_device_count() > 0, "no HIP device: the product has no CPU fallback"
+    return A
+
+
+@pytest.fixture(scope="module")
+def dev(api):
+    d = api.Device("gpu=0")
+    yield d
+    d.release()
+
+
+@pytest.fixture(scope="module")
+def ref():
+    from oracle import refembree
+    if not refembree.available():
+        pytest.skip("oracle/_ref not present on this box (make -f oracle/ref.mk in the build container)")
+    return refembree
+
+
+def ref_scene(ref, meshes, flags=0):
+    R = ref.RefScene("threads=%d" % ref.hw_threads(), flags=flags)
+    for v, t in meshes:
+        R.add_mesh(v, t)
+    R.commit()
+    assert R.error() == 0
+    return R
+
+
+def tri_t_of(meshes):
+    from oracle import restate
+    o = restate.OracleScene()
+    for v, t in meshes:
+        o.add_mesh(v, t)
+    return o.triangle_t
+
+
+# ------------------------------------------------------------------------------------------- HIGH / LOW trees at full size against the real reference
+@pytest.mark.parametrize("scene", ["crown", "powerplant"])
+def test_high_and_low_quality_full_size_vs_real_reference(api, dev, ref, scene):
+    """configs[2] / configs[4] at full size through RTC_BUILD_QUALITY_HIGH (spatial splits) and RTC_BUILD_QUALITY_LOW (Morton) trees: closest hit on 2^20 rays and
+    occlusion against the real reference tracing the same rays -- fast mode, with its robust mode as the arbiter where its fast node test loses a hit
+    (tests/helpers.py compare_closest_arbitrated).  Hits do not depend on the tree: what this checks is that these two builders drop or misplace nothing at
+    4.8 M / 12.7 M triangles (round 3 only compared them with the MEDIUM tree of the same library)."""
+    if scene == "crown":
+        meshes = W.synthetic_crown(num_phi=158)
+        R = ref_scene(ref, meshes)
+        prim = W.crown_camera_rays(meshes, 1024, 1024)
+        R.intersect1(prim, ref.hw_threads())
+        rays = W.diffuse_bounce_rays(prim, meshes, seed=1)           # configs[2]'s ray set, from primaries the ORACLE traced
+        tie_frac = 1e-4
+    else:
+        meshes = W.synthetic_powerplant()
+        R = ref_scene(ref, meshes)
+        lo, hi = W.scene_bounds(meshes)
+        rays = W.incoherent_rays(1 << 20, (lo + hi) / 2, seed=11)
+        tie_frac = 2e-3                                              # boxes: coplanar faces meet at edges
+    want = rays.copy()
+    R.intersect1(want, ref.hw_threads())
+    wr = rays_of(rays)
+    R.occluded1(wr, ref.hw_threads())
+    R.close()
+    RR = ref_scene(ref, meshes, flags=4)                             # RTC_SCENE_FLAG_ROBUST: the arbiter
+    robust = rays.copy()
+    RR.intersect1(robust, ref.hw_threads())
+    RR.close()
+    tt = tri_t_of(meshes)
+    ntri = W.num_triangles(meshes)
+    for quality, name in ((api.RTC_BUILD_QUALITY_HIGH, "HIGH"), (api.RTC_BUILD_QUALITY_LOW, "LOW")):
+        s = api.make_scene(dev, meshes, quality=quality, device_resident=True)
+        info = s.info()
+        assert info["num_triangles"] - info["num_presplit"] == ntri, (name, info["num_triangles"], info["num_presplit"], ntri)
+        got = rays.copy()
+        s.intersect1M(got)
+        st = compare_closest_arbitrated(got, want, robust, rays, tt, max_tie_frac=tie_frac, label="%s %s tree, full size, vs reference" % (scene, name))
+        assert st["hits"] > 0.3 * st["rays"]
+        gr = rays_of(rays)
+        s.occluded1M(gr)
+        g, w = np.isneginf(gr["tfar"]), np.isneginf(wr["tfar"])
+        assert not (w & ~g).any(), "%s %s: %d rays occluded for the reference are not occluded on the GPU" % (scene, name, int((w & ~g).sum()))
+        assert (g & ~w).sum() <= 1e-4 * g.size                       # (a flip this way = a hit the fast reference lost)
+        assert (gr["tfar"][~g] == rays_of(rays)["tfar"][~g]).all()
+        print("%s %s tree at full size: %d references (+%d), commit %.2f ms, %s" % (scene, name, info["num_triangles"], info["num_presplit"], info["build_ms"], st))
+        s.release()
+
+
+@pytest.mark.parametrize("flags", [0, 4])
+def test_cornell_golden_through_a_high_quality_tree_tie_rule(api, dev, flags):
+    """The Cornell box's golden rays (tests/golden/ref_cornell_4k.npz: the real reference's answers) through a HIGH-quality tree, under the tie rule of
+    tests/helpers.py: an ID may differ only where the two hits are the same distance to 4 ulp (the wall seams of the box) -- round 3 accepted 99.5 % equal IDs."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "ref_cornell_4k.npz"))
+    meshes = W.cornell_box()
+    s = api.make_scene(dev, meshes, flags=flags, quality=api.RTC_BUILD_QUALITY_HIGH)
+    got = g["rays"].copy()
+    s.intersect1M(got)
+    # (the golden answers are the fast mode's; the robust scene goes through the same gate.)  34 triangles: a seam along every wall edge, hence the tie budget
+    st = compare_closest(got, g["hits"], g["rays"], tri_t_of(meshes), max_tie_frac=5e-3, label="cornell HIGH (flags %d) vs golden" % flags)
+    assert st["hits"] > 0
+    s.release()
+
+
+# ------------------------------------------------------------------------------------------- the reference's own minimal tutorial, unmodified
+def test_reference_minimal_tutorial_unmodified():
+    """tutorials/minimal/minimal.cpp of the reference, compiled UNMODIFIED against include/embree4/rtcore.h and linked against libembree4_mi355.so by
+    __graft_entry__.build() in the build container (the source is not copied into this repository; the binary travels like the built library): its two known
+    answers (hit on geometry 0, primitive 0 at tfar = 1 / no intersection)."""
+    exe = os.path.join(ROOT, "tests", "golden", "_bin", "ref_minimal")
+    if not os.path.exists(exe):
+        pytest.skip("tests/golden/_bin/ref_minimal was not built (needs /root/reference: __graft_entry__.build() in the build container)")
+    out = subprocess.run([exe], input=b"\n", capture_output=True, timeout=120)
+    txt = out.stdout.decode()
+    assert out.returncode == 0, (out.returncode, txt, out.stderr.decode()[-2000:])
+    lines = [l for l in txt.splitlines() if l.strip()]
+    assert "0.330000, 0.330000, -1.000000: Found intersection on geometry 0, primitive 0 at tfar=1.000000" in lines[0], lines
+    assert "1.000000, 1.000000, -1.000000: Did not find any intersection." in lines[1], lines
+    assert "error" not in txt.lower(), txt
+
+
+# ------------------------------------------------------------------------------------------- 64 M triangles
+def test_64m_triangle_commit_and_rays_vs_real_reference(api, dev, ref):
+    """A commit 13 x the headline scene: 48 noisy spheres of 1,329,408 triangles each + the room = 63.8 M triangles (the reference's builder settings are
+    size-agnostic, bvh_builder_sah.cpp:467; 288 GB of HBM invite such scenes).  Exercises the 32-bit reference / node / record indices, the level margins of the
+    one-round-trip commit and the arena sizing; 2^18 incoherent rays + occlusion against the real reference."""
+    meshes = W.synthetic_crown(num_phi=577)
+    ntri = W.num_triangles(meshes)
+    assert 63_000_000 < ntri < 65_000_000
+    s = api.make_scene(dev, meshes, device_resident=True)
+    info = s.info()
+    assert info["num_triangles"] - info["num_presplit"] == ntri and info["num_nodes"] > ntri // 12
+    lo, hi = W.scene_bounds(meshes)
+    blo, bhi = s.bounds()
+    R = ref_scene(ref, meshes)
+    rlo, rhi = R.bounds()
+    assert (blo == rlo).all() and (bhi == rhi).all()
+    rays = W.incoherent_rays(1 << 18, (lo + hi) / 2 + np.float32(0.37), seed=21)
+    want, got = rays.copy(), rays.copy()
+    R.intersect1(want, ref.hw_threads())
+    wr, gr = rays_of(rays), rays_of(rays)
+    R.occluded1(wr, ref.hw_threads())
+    R.close()
+    s.intersect1M(got)
+    s.occluded1M(gr)
+    RR = ref_scene(ref, meshes, flags=4)
+    robust = rays.copy()
+    RR.intersect1(robust, ref.hw_threads())
+    RR.close()
+    st = compare_closest_arbitrated(got, want, robust, rays, tri_t_of(meshes), label="64M-triangle scene vs reference")
+    assert st["hits"] == st["rays"]                                  # a closed room: every ray ends somewhere
+    g, w = np.isneginf(gr["tfar"]), np.isneginf(wr["tfar"])
+    assert not (w & ~g).any() and (g & ~w).sum() <= 1e-4 * g.size
+    print("64M triangles: %d nodes, depth %d, commit %.1f ms = %.0f Mprims/s, %d launches; %s" % (info["num_nodes"], info["depth"], info["build_ms"],
+          ntri / info["build_ms"] / 1e3, info["num_launches"], st))
+    s.release()
+    api.load().mi355_release_build_scratch(0)                        # (the 20 GB of build scratch go back before the next test)
+
+
+# ------------------------------------------------------------------------------------------- per-GPU pointers; packed hits with instID
+@pytest.mark.parametrize("gpus", [1, 3])
+def test_sharded_pointer_queries_equal_the_single_gpu_bytes(api, dev, gpus):
+    """rtcIntersect1MDeviceSharded / rtcOccluded1MDeviceSharded: shard k lives on replica k's GPU (RTC_DEVICE_PROPERTY_GPU_OF_REPLICA_0 + k) and is traced there on
+    its own stream -- nothing crosses xGMI.  On a 1-GPU box the replicas share the GPU (gpu_oversubscribe=1): same code path.  Ragged shards, an empty shard."""
+    L = api.load()
+    ngpu = L.mi355_device_count()
+    md = api.Device("gpu=0,gpus=%d%s" % (gpus, ",gpu_oversubscribe=1" if gpus > ngpu else ""))
+    assert md.gpu_count() == gpus
+    where = [int(L.rtcGetDeviceProperty(md.h, 1000 + k)) for k in range(gpus)]
+    assert all(0 <= w < ngpu for w in where)
+    meshes = W.synthetic_crown(num_phi=24)
+    single, ms = api.make_scene(dev, meshes), api.make_scene(md, meshes)
+    prim = W.crown_camera_rays(meshes, 200, 200)
+    a = prim.copy()
+    single.intersect1M(a)
+    rays = W.diffuse_bounce_rays(a, meshes)
+    want = rays.copy()
+    single.intersect1M(want)
+    wr = rays_of(rays)
+    single.occluded1M(wr)
+    M = rays.shape[0]
+    cuts = [0] + sorted({(M * (k + 1)) // gpus - (17 * k if k + 1 < gpus else 0) for k in range(gpus)})
+    cuts[-1] = M
+    if gpus == 3:
+        cuts = [0, 1234, 1234, M]                                    # shard 1 is empty
+    for any_hit in (False, True):
+        src = rays_of(rays) if any_hit else rays
+        bufs, streams = [], []
+        for k in range(gpus):
+            part = src[cuts[k]:cuts[k + 1]]
+            bufs.append(api.DeviceArray.from_numpy(part, where[k]) if part.shape[0] else None)
+            st = C.c_void_p()
+            assert L.mi355_stream_create(where[k], C.byref(st)) == 0
+            streams.append(st)
+        ms.query_device_sharded([b.ptr if b else None for b in bufs], [cuts[k + 1] - cuts[k] for k in range(gpus)], stride=48 if any_hit else 96, streams=streams, any_hit=any_hit)
+        for k in range(gpus):
+            assert L.mi355_synchronize(streams[k]) == 0
+            if bufs[k] is None:
+                continue
+            got = bufs[k].download(RAY_DTYPE if any_hit else RAYHIT_DTYPE)
+            exp = (wr if any_hit else want)[cuts[k]:cuts[k + 1]]
+            assert got.tobytes() == exp.tobytes(), "shard %d of the %s query differs from the single-GPU answer" % (k, "occlusion" if any_hit else "closest-hit")
+            bufs[k].free()
+            L.mi355_stream_destroy(streams[k])
+    # more shards than GPUs behind the device is an argument error, recorded, not a crash
+    one = api.DeviceArray.from_numpy(rays[:64], 0)
+    try:
+        ms.query_device_sharded([one.ptr] * (gpus + 1), [64] * (gpus + 1))
+        raise AssertionError("more shards than replicas was accepted")
+    except api.RTCErrorException as e:
+        assert e.code == api.RTC_ERROR_INVALID_ARGUMENT
+    one.free()
+    single.release(); ms.release(); md.release()
+
+
+def test_packed_hits_carry_the_instance_id(api, dev):
+    """mi355_pack_hits_inst: 48 bytes per ray = the 32 bytes of mi355_pack_hits + instID[0], instPrimID[0] -- the gathered hits of a scene with instances name
+    their instance (the 32-byte form dropped it)."""
+    L = api.load()
+    obj_meshes = [W.triangle_sphere(np.zeros(3, np.float32), 1.0, 12)]
+    obj = api.make_scene(dev, obj_meshes)
+    top = api.Scene(dev)
+    for k in range(5):
+        x = np.array([1, 0, 0, 0, 1, 0, 0, 0, 1, 3.0 * k, 0, 0], np.float32)
+        top.add_instance(obj, x)
+    top.commit()
+    org = np.stack([np.linspace(-1.0, 13.0, 4096, dtype=np.float32), np.full(4096, 0.1, np.float32), np.full(4096, -5.0, np.float32)], -1)
+    from embree_amd.rtypes import make_rayhits
+    rays = make_rayhits(org, np.broadcast_to(np.array([0, 0, 1], np.float32), org.shape))
+    d = api.DeviceArray.from_numpy(rays, 0)
+    top.intersect1M_device(d.ptr, rays.shape[0])
+    packed = api.DeviceArray(48 * rays.shape[0], 0)
+    assert L.mi355_pack_hits_inst(d.ptr, rays.shape[0], 96, packed.ptr, None) == 0, L.mi355_last_error()
+    L.mi355_device_synchronize(0)
+    got = d.download(RAYHIT_DTYPE)
+    p = packed.download(np.uint32).reshape(-1, 12)
+    hit = got["geomID"] != INVALID_ID
+    assert hit.sum() > 1000 and len(set(got["instID"][hit].tolist())) == 5
+    assert (p[:, 0] == got["tfar"].view(np.uint32)).all() and (p[:, 3] == got["primID"]).all() and (p[:, 4] == got["geomID"]).all()
+    assert (p[:, 8] == got["instID"]).all() and (p[hit, 9] == 0).all()
+    assert (p[:, 1] == got["u"].view(np.uint32)).all() and (p[:, 5] == got["Ng_x"].view(np.uint32)).all()
+    d.free(); packed.free(); top.release(); obj.release()
+
+
+# ------------------------------------------------------------------------------------------- coherent queries from two threads at once
+def test_two_threads_issue_coherent_queries_on_one_scene(api, dev):
+    """RTC_RAY_QUERY_FLAG_COHERENT from two host threads on the same committed scene (rtcIntersect* are thread safe: doc/src/api/rtcCommitScene.md).  The packets a
+    launch gives up on wait on a list that belongs to (tree, stream), and host queries all use the null stream: one lock now spans the packet launches and the
+    per-lane pass behind them.  Semi-coherent batches (many packets give up), different sizes per thread so that the list is regrown under load."""
+    meshes = W.synthetic_crown(num_phi=32)
+    s = api.make_scene(dev, meshes)
+    prim = W.crown_camera_rays(meshes, 384, 384)
+    a = prim.copy()
+    s.intersect1M(a)
+    bounce = W.diffuse_bounce_rays(a, meshes)
+    batches = [np.concatenate([prim[:60000], bounce[:40000]]), np.concatenate([bounce[40000:70000], prim[60000:147456]])]
+    want = []
+    for b in batches:
+        w = b.copy()
+        s.intersect1M(w)
+        want.append(w)
+    args = api.QueryArguments(flags=api.RTC_RAY_QUERY_FLAG_COHERENT)
+    errors = []
+
+    def worker(i):
+        try:
+            for rep in range(12):
+                n = batches[i].shape[0] - 4096 * (rep % 3)
+                g = batches[i][:n].copy()
+                s.intersect1M(g, args)
+                if g.tobytes() != want[i][:n].tobytes():
+                    errors.append("thread %d rep %d: %d records differ" % (i, rep, int((g.view(np.uint8).reshape(n, -1) != want[i][:n].view(np.uint8).reshape(n, -1)).any(1).sum())))
+        except Exception as e:                                      # noqa: BLE001
+            errors.append(repr(e))
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors[:4]
+    s.release()
