@@ -44,7 +44,7 @@ rtcTraversableIntersect1 rtcTraversableIntersect4 rtcTraversableIntersect8 rtcTr
 rtcTraversableOccluded1 rtcTraversableOccluded4 rtcTraversableOccluded8 rtcTraversableOccluded16
 rtcIntersect1M rtcOccluded1M rtcIntersect1MDevice rtcOccluded1MDevice""".split()
 MI355_SYMBOLS = """mi355_default_build_params mi355_last_error mi355_device_count mi355_device_name mi355_bvh_build
-mi355_bvh_destroy mi355_bvh_build_instanced mi355_bvh_refit mi355_release_build_scratch mi355_bvh_get_info mi355_bvh_set_filter_rules mi355_bvh_download mi355_trace_prepare mi355_trace_closest mi355_trace_any
+mi355_bvh_destroy mi355_bvh_build_instanced mi355_bvh_refit mi355_bvh_refit_instanced mi355_release_build_scratch mi355_bvh_get_info mi355_bvh_set_filter_rules mi355_bvh_download mi355_trace_prepare mi355_trace_closest mi355_trace_any
 mi355_trace_query mi355_trace_closest_packet mi355_trace_any_packet mi355_trace_stats mi355_trace_timed mi355_trace_status mi355_malloc mi355_free mi355_memcpy_h2d
 mi355_memcpy_d2h mi355_synchronize mi355_device_synchronize mi355_memcpy_d2d_async mi355_stream_create
 mi355_stream_destroy mi355_event_create mi355_event_record mi355_event_elapsed_ms mi355_event_destroy
@@ -420,6 +420,13 @@ class Scene:
         self.dev.check()
         return gid
 
+    def set_instance_transform(self, gid, local2world, fmt=RTC_FORMAT_FLOAT3X4_COLUMN_MAJOR):
+        """rtcSetGeometryTransform + rtcCommitGeometry on an attached instance (the caller commits the scene): a MOVE -- the next rtcCommitScene refits the top tree"""
+        g = self.L.rtcGetGeometry(self.h, gid)
+        x = np.ascontiguousarray(local2world, np.float32).ravel()
+        self.L.rtcSetGeometryTransform(g, 0, fmt, x.ctypes.data)
+        self.L.rtcCommitGeometry(g)
+
     def set_geometry_build_quality(self, gid, quality):
         """rtcSetGeometryBuildQuality; RTC_BUILD_QUALITY_REFIT makes the next commit after a vertex update refit the tree."""
         self.L.rtcSetGeometryBuildQuality(self.L.rtcGetGeometry(self.h, gid), quality)
@@ -529,7 +536,7 @@ class Scene:
         S = (C.c_void_p * n)(*[(x.value if isinstance(x, C.c_void_p) else x) for x in streams]) if streams is not None else None
         fn = self.L.rtcOccluded1MDeviceSharded if any_hit else self.L.rtcIntersect1MDeviceSharded
         fn(self.h, n, P, N, stride, C.addressof(args) if args is not None else None, S)
-        self.device.check()
+        self.dev.check()
 
     def replica_bvh(self, k):
         """the tree on replica k of a device over several GPUs (rtcNewDevice("gpus=N")); None beyond the last"""

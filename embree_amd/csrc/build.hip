@@ -158,6 +158,9 @@ Bvh::~Bvh() {
   if (d_ids) hipFree(d_ids);
   if (d_insts) hipFree(d_insts);
   if (d_rules) hipFree(d_rules);
+  if (d_topVerts) hipFree(d_topVerts);
+  if (d_topIdx) hipFree(d_topIdx);
+  delete top;
 }
 
 // A commit is enqueued as ONE sequence of launches with no host round trip inside (MEDIUM quality, the default): the number of valid triangles, the
@@ -676,15 +679,15 @@ static int build_instanced_impl(int device, Bvh* own, const mi355_instance* inst
     fi[(size_t)k * 3] = 3 * k; fi[(size_t)k * 3 + 1] = 3 * k + 1; fi[(size_t)k * 3 + 2] = 3 * k + 2;
   }
   float* dfv = nullptr; uint32_t* dfi = nullptr; InstRec* dRecs = nullptr;
-  struct TmpGuard { float*& a; uint32_t*& b; ~TmpGuard() { if (a) hipFree(a); if (b) hipFree(b); } } tmpGuard{dfv, dfi};
+  struct TmpGuard { float*& a; uint32_t*& b; ~TmpGuard() { if (a) hipFree(a); if (b) hipFree(b); } } tmpGuard{dfv, dfi};   // (handed to the tree at the end: then both are nullptr)
   HIP_TRY(hipMalloc((void**)&dfv, fv.size() * 4)); HIP_TRY(hipMalloc((void**)&dfi, fi.size() * 4));
   HIP_TRY(hipMemcpyAsync(dfv, fv.data(), fv.size() * 4, hipMemcpyHostToDevice, st)); HIP_TRY(hipMemcpyAsync(dfi, fi.data(), fi.size() * 4, hipMemcpyHostToDevice, st));
   mi355_mesh fake{}; fake.d_vertices = dfv; fake.vertex_stride = 12; fake.num_vertices = 3 * R; fake.d_indices = dfi; fake.index_stride = 12; fake.num_triangles = R; fake.geom_id = 0; fake.mask = 0xFFFFFFFFu;
-  mi355_build_params tp = *bp; tp.refit = 0; tp.quality = 0;
+  mi355_build_params tp = *bp; tp.refit = 1; tp.quality = 0;     // (refit data: instances that only MOVE refit this tree, mi355_bvh_refit_instanced)
   Bvh* top = nullptr;
   tp.top_splits = 0;                                            // (the "triangles" of this build are the instances' boxes: one leaf record each)
   { const int rc = build_retry(device, &fake, 1, &tp, st, &top); if (rc) return rc; }
-  struct TopGuard { Bvh* t; ~TopGuard() { delete t; } } topGuard{top};
+  struct TopGuard { Bvh*& t; ~TopGuard() { delete t; } } topGuard{top};   // (handed to the tree at the end: then nullptr)
   if (top->info.num_triangles != R) return set_error(hipErrorInvalidValue, "top-level build dropped an instance");
   bvh->numCUs = top->numCUs;
 
@@ -738,7 +741,62 @@ static int build_instanced_impl(int device, Bvh* own, const mi355_instance* inst
   info.bytes_nodes = nNodes * sizeof(CNode); info.bytes_triangles = nTris * sizeof(TriRec) + (uint64_t)R * sizeof(InstRec);
   info.sah = top->info.sah; info.build_ms = top->info.build_ms; info.top_levels = top->info.top_levels;
   info.depth = 2u * top->info.depth + maxDepth + 2u;             // a top level leaves up to two entries on a lane's stack (inner children, other instances)
+  // kept for mi355_bvh_refit_instanced: the top tree, its box "mesh", the records, the objects behind them
+  bvh->h_insts.assign((const uint8_t*)recs.data(), (const uint8_t*)recs.data() + recs.size() * sizeof(InstRec));
+  bvh->instObjects.assign(recObj.begin(), recObj.end()); bvh->topHasOwn = hasOwn; if (hasOwn) bvh->instObjects[0] = nullptr;
+  bvh->top = top; top = nullptr; bvh->d_topVerts = dfv; dfv = nullptr; bvh->d_topIdx = dfi; dfi = nullptr;
   guard.ok = true; *out = bvh;
+  return 0;
+}
+
+// Instances that only moved (or changed their mask): the top tree keeps its topology and is refitted over the new world boxes (the reference: BVHNRefitT,
+// kernels/bvh/bvh_refit.cpp, for the top level of its two-level scenes); the object trees behind it are not touched, nothing is concatenated again.
+// Same records in the same order naming the same objects, else MI355_REFIT_IMPOSSIBLE (the caller builds anew).
+static int refit_instanced_impl(Bvh* bvh, const mi355_instance* insts, uint32_t numInsts, hipStream_t st) {
+  if (!bvh || !bvh->top || !bvh->d_insts || !bvh->d_topVerts) return MI355_REFIT_IMPOSSIBLE;
+  HIP_TRY(hipSetDevice(bvh->device));
+  const size_t R = bvh->h_insts.size() / sizeof(InstRec);
+  std::vector<InstRec> recs(R); memcpy(recs.data(), bvh->h_insts.data(), R * sizeof(InstRec));
+  std::vector<float> fv(R * 9 + 4, 0.0f);
+  float blo[3] = {INFINITY, INFINITY, INFINITY}, bhi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  size_t k = 0;
+  auto put_box = [&](size_t at, const float* lo, const float* hi) {
+    for (int d = 0; d < 3; d++) { fv[at * 9 + d] = lo[d]; fv[at * 9 + 3 + d] = hi[d]; fv[at * 9 + 6 + d] = lo[d]; blo[d] = fminf(blo[d], lo[d]); bhi[d] = fmaxf(bhi[d], hi[d]); }
+  };
+  if (bvh->topHasOwn) {                                          // the scene's own geometry: record 0, where it was (box: what the build copied into the top tree's mesh)
+    float own[9]; HIP_TRY(hipMemcpy(own, bvh->d_topVerts, sizeof(own), hipMemcpyDeviceToHost));
+    put_box(0, own, own + 3); k = 1;
+  }
+  for (uint32_t i = 0; i < numInsts; i++) {
+    Bvh* ob = (Bvh*)insts[i].object;
+    if (!ob || ob->info.num_triangles == 0) continue;
+    const float* l2w = insts[i].local2world;
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int c = 0; c < 8; c++) {
+      const float p[3] = {(c & 4) ? ob->info.bounds_upper[0] : ob->info.bounds_lower[0], (c & 2) ? ob->info.bounds_upper[1] : ob->info.bounds_lower[1], (c & 1) ? ob->info.bounds_upper[2] : ob->info.bounds_lower[2]};
+      float q[3]; affine_point(l2w, p, q);
+      for (int d = 0; d < 3; d++) { lo[d] = fminf(lo[d], q[d]); hi[d] = fmaxf(hi[d], q[d]); }
+    }
+    bool ok = true; for (int d = 0; d < 3; d++) ok = ok && lo[d] > -1.844E18f && hi[d] < 1.844E18f && lo[d] <= hi[d];
+    if (!ok) continue;
+    if (k >= R || bvh->instObjects[k] != (const void*)ob) return MI355_REFIT_IMPOSSIBLE;   // another object, another count: not a move
+    affine_inverse(l2w, recs[k].w2l); recs[k].instID = insts[i].inst_id; recs[k].mask = insts[i].mask;
+    put_box(k, lo, hi); k++;
+  }
+  if (k != R) return MI355_REFIT_IMPOSSIBLE;
+  Bvh* top = bvh->top;
+  HIP_TRY(hipMemcpyAsync(bvh->d_topVerts, fv.data(), fv.size() * 4, hipMemcpyHostToDevice, st));
+  mi355_mesh fake{}; fake.d_vertices = bvh->d_topVerts; fake.vertex_stride = 12; fake.num_vertices = (uint32_t)(3 * R); fake.d_indices = bvh->d_topIdx; fake.index_stride = 12;
+  fake.num_triangles = (uint32_t)R; fake.geom_id = 0; fake.mask = 0xFFFFFFFFu;
+  const int rc = refit_impl(top, &fake, 1, st);                  // (waits for its kernels; fv may go)
+  if (rc != 0) return rc;
+  HIP_TRY(hipMemcpyAsync(bvh->d_nodes, top->d_nodes, (size_t)top->info.num_nodes * sizeof(CNode), hipMemcpyDeviceToDevice, st));
+  HIP_TRY(hipMemcpyAsync(bvh->d_tris, top->d_tris, (size_t)top->info.num_triangles * sizeof(TriRec), hipMemcpyDeviceToDevice, st));
+  HIP_TRY(hipMemcpyAsync(bvh->d_insts, recs.data(), R * sizeof(InstRec), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  memcpy(bvh->h_insts.data(), recs.data(), R * sizeof(InstRec));
+  for (int d = 0; d < 3; d++) { bvh->info.bounds_lower[d] = blo[d]; bvh->info.bounds_upper[d] = bhi[d]; }
+  bvh->info.build_ms = top->info.build_ms; bvh->info.num_refits++;
   return 0;
 }
 
@@ -768,6 +826,9 @@ int mi355_bvh_build_instanced(int device, mi355_bvh_t own, const mi355_instance*
   mi355::Bvh* b = nullptr;
   const int rc = mi355::build_instanced_impl(device, (mi355::Bvh*)own, instances, num_instances, params, (hipStream_t)stream, &b);
   *out = (mi355_bvh_t)b; return rc;
+}
+int mi355_bvh_refit_instanced(mi355_bvh_t bvh, const mi355_instance* instances, uint32_t num_instances, void* stream) {
+  return mi355::refit_instanced_impl((mi355::Bvh*)bvh, instances, num_instances, (hipStream_t)stream);
 }
 int mi355_bvh_refit(mi355_bvh_t bvh, const mi355_mesh* meshes, uint32_t num_meshes, void* stream) {
   if (!bvh) return MI355_REFIT_IMPOSSIBLE;

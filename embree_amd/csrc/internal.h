@@ -45,6 +45,11 @@ struct Bvh {
   std::vector<uint32_t> lvlStart;
   struct MeshSig { uint32_t geomID, numPrims, numVerts, quads; };
   std::vector<MeshSig> sig;
+  // instanced trees: what mi355_bvh_refit_instanced needs when only transforms / masks changed -- the top tree (built with refit data) and its "mesh" of one box per
+  // instance record (9 floats each), the records as they were built (root node, rule base: unchanged by a move), and which object each record names
+  Bvh* top = nullptr; float* d_topVerts = nullptr; uint32_t* d_topIdx = nullptr; bool topHasOwn = false;
+  std::vector<uint8_t> h_insts;                     // InstRec[] (64 B each)
+  std::vector<const void*> instObjects;             // per record: the object tree it was built from (nullptr: the scene's own geometry)
   std::mutex mtx;
   std::map<hipStream_t, TraceScratch> scratch;
   TraceScratch* scratch_for(hipStream_t s);

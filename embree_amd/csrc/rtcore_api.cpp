@@ -57,9 +57,10 @@ struct Device : RefCounted {
   unsigned shardMin = 16384;                                 // host-array / device-array batches of fewer rays than this per replica stay on replica 0 (config key shard_min)
   int verbose = 0;
   bool benchmark = false;
+  bool noInstanceRefit = false;                              // config key instance_refit=0: moved instances rebuild the top tree and concatenate the object trees again (A/B)
   bool hostInPlace = false;                                  // config key host_in_place=1: large host arrays are traced where they lie (registered + mapped), see replica_query
   bool smallInPlace = true;                                  // config key small_in_place=0: small host queries go through device staging like the others (A/B)
-  unsigned pipelineMin = 262144, pipelineChunk = 65536;   // host-array queries of at least pipelineMin rays are cut into chunks of pipelineChunk rays (config keys host_pipeline_min / host_pipeline_chunk)
+  unsigned pipelineMin = 262144, pipelineChunk = 131072;   // host-array queries of at least pipelineMin rays are cut into chunks of pipelineChunk rays (config keys host_pipeline_min / host_pipeline_chunk)
   mi355_build_params build;
   RTCErrorFunction errorFn = nullptr; void* errorFnPtr = nullptr;
   RTCMemoryMonitorFunction memFn = nullptr; void* memFnPtr = nullptr;
@@ -419,6 +420,11 @@ struct Scene : RefCounted {
         }
       }
     }
+    // ---- instances that only MOVED (rtcSetGeometryTransform / mask; same instances, same objects, objects not re-committed, the scene's own geometry and rules as
+    // they were): the top tree is refitted in place and the records get their new transforms -- no top build, no copy of the object trees (mi355_bvh_refit_instanced)
+    bool instMoveOnly = keepFlat && !instGeoms.empty() && haveTree && nowFlags == builtFlags && instFrom.size() == builtInst.size() && !device->noInstanceRefit;
+    for (size_t i = 0; instMoveOnly && i < instFrom.size(); i++) { const InstFrom &a = instFrom[i], &b = builtInst[i]; instMoveOnly = a.id == b.id && a.g == b.g && a.object == b.object && a.topo == b.topo && a.objSerial == b.objSerial; }
+    for (size_t i = 0; instMoveOnly && i < from.size(); i++) instMoveOnly = from[i].rule == builtFrom[i].rule;
     // ---- every replica does the same thing on its own GPU, side by side (one host thread per GPU; the build is deterministic, so the replicas come out bit-identical)
     std::vector<int> didRefit(reps.size(), 0);
     std::atomic<bool> refitBroken{false};
@@ -445,15 +451,20 @@ struct Scene : RefCounted {
       }
       // device-side filter rules of this scene's geometries: one 12-word entry per geometry id + the bit arrays (mi355_bvh_set_filter_rules)
       core_check(mi355_bvh_set_filter_rules(r.flat, ruleTable.empty() ? nullptr : ruleTable.data(), ruleTable.size(), ruleGeoms), "filter rules");
+      std::vector<mi355_instance> insts;
+      for (const InstGeom& ig : instGeoms) {
+        mi355_instance in; in.object = ig.g->object->reps[k]->flat;   // a second level inside the object is dropped, like the reference does at RTC_MAX_INSTANCE_LEVEL_COUNT = 1 (instance_stack.h:36-47)
+        memcpy(in.local2world, ig.g->l2w, sizeof(in.local2world)); in.inst_id = ig.id; in.mask = ig.g->mask;
+        insts.push_back(in);
+      }
+      if (instMoveOnly && r.bvh && r.bvh != r.flat) {
+        const int rc = mi355_bvh_refit_instanced(r.bvh, insts.data(), (uint32_t)insts.size(), nullptr);
+        if (rc == 0) { didRefit[k] = 1; return; }
+        if (rc != MI355_REFIT_IMPOSSIBLE && rc != MI355_REFIT_BROKEN) core_check(rc, "instanced BVH refit");   // (impossible / broken: the tree is built anew below)
+      }
       if (r.bvh && r.bvh != r.flat) { mi355_bvh_destroy(r.bvh); device->memoryMonitor(-r.bvhBytes, true); r.bvhBytes = 0; }
       r.bvh = r.flat;
       if (!instGeoms.empty()) {
-        std::vector<mi355_instance> insts;
-        for (const InstGeom& ig : instGeoms) {
-          mi355_instance in; in.object = ig.g->object->reps[k]->flat;   // a second level inside the object is dropped, like the reference does at RTC_MAX_INSTANCE_LEVEL_COUNT = 1 (instance_stack.h:36-47)
-          memcpy(in.local2world, ig.g->l2w, sizeof(in.local2world)); in.inst_id = ig.id; in.mask = ig.g->mask;
-          insts.push_back(in);
-        }
         mi355_bvh_t nb = nullptr;
         core_check(mi355_bvh_build_instanced(r.gpu, r.flat, insts.data(), (uint32_t)insts.size(), &bp, nullptr, &nb), "instanced BVH build");
         mi355_bvh_get_info(nb, &info);
@@ -520,6 +531,7 @@ void parse_config(Device* d, const char* cfg) {
     else if (k == "int_cost") d->build.int_cost = (float)atof(v.c_str());
     else if (k == "top_splits") d->build.top_splits = atoi(v.c_str()) != 0 ? 1u : 0u;                 // MEDIUM builds: references that dwarf all others are cut into grid pieces first
     else if (k == "top_split_min") d->build.top_split_min = (uint32_t)atol(v.c_str());
+    else if (k == "instance_refit") d->noInstanceRefit = atoi(v.c_str()) == 0;
     else if (k == "host_in_place") d->hostInPlace = atoi(v.c_str()) != 0;                             // rtcIntersect1M / rtcOccluded1M on large host arrays: trace them in place over the host link
     else if (k == "top_split_rel") d->build.top_split_rel = (float)atof(v.c_str());
     else if (k == "top_split_cell") d->build.top_split_cell = (float)atof(v.c_str());
@@ -601,18 +613,19 @@ static size_t view_bytes(RTCFormat fmt, size_t stride, size_t n) { return n ? (n
 // the candidate's distance while they run), and a ray whose candidate was rejected is traced again from just behind it.  The closest ACCEPTED hit -- what
 // the reference returns -- comes out the same; differences: a callback sees candidates in distance order and only the closest ones (the reference: in
 // traversal order, possibly farther ones first), a second triangle at exactly a rejected distance is skipped with it, and occlusion queries with filters
-// cost a closest-hit search per round.  Instanced scenes are not covered (the hit's geometry lives in another scene object).
-static bool scene_has_filters(Scene* s, const RTCFilterFunctionN argFilter, unsigned flags, bool any) {
+// cost a closest-hit search per round.  Scenes with instances: the filter is the one of the instanced scene's geometry (instID[0] names the instance).
+static bool scene_has_filters(Scene* s, const RTCFilterFunctionN argFilter, unsigned flags, bool any, bool top = true) {
   for (auto& kv : s->geoms) {
     Geometry* g = kv.second;
     if (any ? g->occludedFilter != nullptr : g->intersectFilter != nullptr) return true;
-    if (argFilter && (g->argFilter || (flags & RTC_RAY_QUERY_FLAG_INVOKE_ARGUMENT_FILTER))) return true;
+    if (argFilter && g->type != RTC_GEOMETRY_TYPE_INSTANCE && (g->argFilter || (flags & RTC_RAY_QUERY_FLAG_INVOKE_ARGUMENT_FILTER))) return true;
+    // the geometries of an instanced scene carry their own filters (one level, like the traversal)
+    if (top && g->type == RTC_GEOMETRY_TYPE_INSTANCE && g->enabled && g->object && g->object != s && scene_has_filters(g->object, argFilter, flags, any, false)) return true;
   }
   return false;
 }
 static void plain_query(Scene* s, void* data, unsigned M, size_t stride, bool any, unsigned qflags);
 static void filtered_query(Scene* s, void* data, unsigned M, size_t stride, bool any, RTCFilterFunctionN argFilter, unsigned qflags, RTCRayQueryContext* uctx) {
-  for (auto& kv : s->geoms) if (kv.second->type == RTC_GEOMETRY_TYPE_INSTANCE && kv.second->enabled) THROW(RTC_ERROR_INVALID_OPERATION, "filter callbacks are not supported in scenes with instances");
   RTCRayQueryContext defctx; rtcInitRayQueryContext(&defctx);
   RTCRayQueryContext* ctx = uctx ? uctx : &defctx;
   std::vector<RTCRayHit> work(M);                            // the rays still searching, as closest-hit records
@@ -632,8 +645,18 @@ static void filtered_query(Scene* s, void* data, unsigned M, size_t stride, bool
       RTCRayHit& w = work[k];
       if (w.hit.geomID == RTC_INVALID_GEOMETRY_ID) continue;  // nothing (left) on this ray: the caller's record stays as it is
       char* dst = (char*)data + (size_t)who[k] * stride;
-      auto it = s->geoms.find(w.hit.geomID);
-      Geometry* g = it == s->geoms.end() ? nullptr : it->second;
+      // whose filter: a hit inside an instance names the instance in instID[0] and the geometry of the INSTANCED scene in geomID (instance_intersector.cpp:26-60);
+      // the callback sees the instance in context->instID[0] as well, like the reference's traversal has it while inside the instance
+      Scene* owner = s;
+      if (w.hit.instID[0] != RTC_INVALID_GEOMETRY_ID) {
+        auto ii = s->geoms.find(w.hit.instID[0]);
+        owner = (ii != s->geoms.end() && ii->second->type == RTC_GEOMETRY_TYPE_INSTANCE) ? ii->second->object : nullptr;
+      }
+      Geometry* g = nullptr;
+      if (owner) { auto it = owner->geoms.find(w.hit.geomID); if (it != owner->geoms.end()) g = it->second; }
+      const unsigned ctxInst = ctx->instID[0], ctxPrim = ctx->instPrimID[0];
+      ctx->instID[0] = w.hit.instID[0]; ctx->instPrimID[0] = w.hit.instPrimID[0];
+      struct Restore { RTCRayQueryContext* c; unsigned a, b; ~Restore() { c->instID[0] = a; c->instPrimID[0] = b; } } restore{ctx, ctxInst, ctxPrim};
       int valid = -1;
       RTCRayHit cand = w;                                     // the callbacks may change the hit and shorten tfar
       RTCFilterFunctionNArguments fa; fa.valid = &valid; fa.geometryUserPtr = g ? g->userPtr : nullptr; fa.context = ctx;

@@ -378,6 +378,9 @@ __global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceAr
   // second node on the stream per query: rtcIntersect1 pays it per ray).  A wave leaves only when every cursor is dry, so the wave that counts itself out last
   // knows nobody reads them any more.
   auto wave_exit = [&]() {
+    // (every cursor atomic of this wave has been PERFORMED before it counts itself out -- also the block reserved ahead whose answer nobody waited for: atomics
+    // on different words may reach L2 in any order, and one that lands after the last wave's reset leaves a cursor at 1: the next launch skips 16 rays)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane == 0u) {
       if (atomicAdd(a.counter + EXIT_WORD, 1u) == gridDim.x * (BLOCK / 64u) - 1u) {
         for (uint32_t c = 0; c < NUM_CURSORS; c++) atomicExch(a.counter + c * CURSOR_STRIDE, 0u);

@@ -120,6 +120,11 @@ MI355_API int mi355_bvh_build_instanced(int device, mi355_bvh_t own, const mi355
 #define MI355_REFIT_IMPOSSIBLE (-2)
 #define MI355_REFIT_BROKEN (-3)
 MI355_API int mi355_bvh_refit(mi355_bvh_t bvh, const mi355_mesh* meshes, uint32_t num_meshes, void* stream);
+/* A tree of mi355_bvh_build_instanced whose instances only MOVED (or changed mask / id): same instances in the same order naming the same objects.  The top tree
+   keeps its topology and is refitted over the new world boxes, the instance records get their new world2local; the object trees are not touched and nothing
+   is concatenated again (the reference refits / rebuilds only the top level of its two-level scenes, kernels/bvh/bvh_refit.cpp, bvh_builder_twolevel.cpp).
+   Returns 0, or MI355_REFIT_IMPOSSIBLE when the list is not a move of what the tree was built from (the tree is untouched: build again). */
+MI355_API int mi355_bvh_refit_instanced(mi355_bvh_t bvh, const mi355_instance* instances, uint32_t num_instances, void* stream);
 /* Build scratch (prim refs, binary tree, work lists) is kept per device between commits, and so are the node / triangle arrays of up to four destroyed
    trees (the next commit of a similar size takes them over instead of paying hipFree + hipMalloc); this returns all of it to the driver. */
 MI355_API void mi355_release_build_scratch(int device);

@@ -16,6 +16,7 @@
 #include <xmmintrin.h>
 #include <pmmintrin.h>
 #include <pthread.h>
+#include <sys/mman.h>
 #include <sched.h>
 #include <algorithm>
 #include <atomic>
@@ -217,6 +218,41 @@ __attribute__((visibility("default"))) double refd_occluded1(void* h, RTCRay* r,
   return run_blocks(M, threads, [&](unsigned lo, unsigned hi) {
     for (unsigned i = lo; i < hi; i++) rtcOccluded1(s->scene, &r[i]);
   });
+}
+
+// The CPU-baseline job of bench.py: `tiles` copies of the M records, one after the other (verify.cpp:5923-5983 runs 16 Mi rays), in a buffer the POOL fills --
+// first touch by the threads that will trace it, like the reference's benchmark, whose rays are made inside its parallel tasks.  (A 1.5 GB numpy array written
+// by one Python thread sits on one NUMA node: 256 threads then traced it at 20 Mrays/s instead of 200.)  Returns the seconds of the traced pass only.
+// mode bit 0: static ranges (worker i fills AND traces records [i n / T, (i + 1) n / T): every page is traced by the thread that touched it first) instead of the
+// 1024-ray blocks handed out dynamically; bit 1: madvise(MADV_HUGEPAGE) on the buffer.
+__attribute__((visibility("default"))) double refd_run_tiled_mode(void* h, const void* rays, unsigned M, unsigned tiles, int any, int threads, unsigned mode);
+__attribute__((visibility("default"))) double refd_run_tiled(void* h, const void* rays, unsigned M, unsigned tiles, int any, int threads) { return refd_run_tiled_mode(h, rays, M, tiles, any, threads, 0u); }
+__attribute__((visibility("default"))) double refd_run_tiled_mode(void* h, const void* rays, unsigned M, unsigned tiles, int any, int threads, unsigned mode) {
+  RefScene* s = (RefScene*)h;
+  const size_t rec = any ? sizeof(RTCRay) : sizeof(RTCRayHit);
+  const unsigned long long total64 = (unsigned long long)M * tiles;
+  if (M == 0 || tiles == 0 || total64 > 0xFFFFFFFFull) return -1.0;
+  const unsigned total = (unsigned)total64;
+  char* buf = (char*)aligned_alloc(2u << 20, (((size_t)total * rec) + (2u << 20) - 1) & ~(size_t)((2u << 20) - 1));
+  if (!buf) return -1.0;
+  if (mode & 2u) madvise(buf, (size_t)total * rec, MADV_HUGEPAGE);
+  const char* src = (const char*)rays;
+  if (mode & 1u) {
+    const unsigned T = (unsigned)(threads < 1 ? 1 : threads);
+    // one "block" per thread: run_blocks over T * 1024 pseudo-records, block b = thread slice b (each worker takes about one; a slice is filled and traced as a unit)
+    auto slice = [&](unsigned b, unsigned& lo, unsigned& hi) { lo = (unsigned)((unsigned long long)total * b / T); hi = (unsigned)((unsigned long long)total * (b + 1) / T); };
+    run_blocks(T * 1024u, threads, [&](unsigned blo, unsigned) { unsigned lo, hi; slice(blo / 1024u, lo, hi); for (unsigned i = lo; i < hi; i++) memcpy(buf + (size_t)i * rec, src + (size_t)(i % M) * rec, rec); });
+    const double dt = run_blocks(T * 1024u, threads, [&](unsigned blo, unsigned) { unsigned lo, hi; slice(blo / 1024u, lo, hi);
+      if (any) for (unsigned i = lo; i < hi; i++) rtcOccluded1(s->scene, (RTCRay*)(buf + (size_t)i * rec));
+      else for (unsigned i = lo; i < hi; i++) rtcIntersect1(s->scene, (RTCRayHit*)(buf + (size_t)i * rec)); });
+    free(buf);
+    return dt;
+  }
+  run_blocks(total, threads, [&](unsigned lo, unsigned hi) { for (unsigned i = lo; i < hi; i++) memcpy(buf + (size_t)i * rec, src + (size_t)(i % M) * rec, rec); });
+  const double dt = any ? run_blocks(total, threads, [&](unsigned lo, unsigned hi) { for (unsigned i = lo; i < hi; i++) rtcOccluded1(s->scene, (RTCRay*)(buf + (size_t)i * rec)); })
+                        : run_blocks(total, threads, [&](unsigned lo, unsigned hi) { for (unsigned i = lo; i < hi; i++) rtcIntersect1(s->scene, (RTCRayHit*)(buf + (size_t)i * rec)); });
+  free(buf);
+  return dt;
 }
 
 // packet entry points, driven from AoS input for convenience: gathers K rays

@@ -62,6 +62,10 @@ def _load(isa="avx2"):
             f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint, ctypes.c_int, ctypes.c_int, ctypes.c_uint]
             f.restype = ctypes.c_double
         L.refd_hw_threads.restype = ctypes.c_uint
+        L.refd_run_tiled.restype = ctypes.c_double
+        L.refd_run_tiled.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint, ctypes.c_uint, ctypes.c_int, ctypes.c_int]
+        L.refd_run_tiled_mode.restype = ctypes.c_double
+        L.refd_run_tiled_mode.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint, ctypes.c_uint, ctypes.c_int, ctypes.c_int, ctypes.c_uint]
         L.refd_native16.restype = ctypes.c_int
         L.refd_native16.argtypes = [ctypes.c_void_p]
         _loaded[isa] = L
@@ -136,6 +140,13 @@ class RefScene:
             assert v.shape[0] == rays.shape[0]
         dt = self._L.refd_packet(self._h, K, 1 if any_hit else 0, rays.ctypes.data, rays.shape[0], v.ctypes.data if v is not None else None, threads)
         assert dt >= 0.0, "unsupported packet size"
+        return dt
+
+    def run_tiled(self, rays, tiles, threads, any_hit=False, mode=0):
+        """rtcIntersect1 / rtcOccluded1 over `tiles` copies of `rays` in a buffer the worker pool itself fills (first touch where it is traced); seconds of the traced pass"""
+        assert rays.flags["C_CONTIGUOUS"] and rays.dtype.itemsize == (48 if any_hit else 96)
+        dt = self._L.refd_run_tiled_mode(self._h, rays.ctypes.data, rays.shape[0], tiles, 1 if any_hit else 0, threads, mode)
+        assert dt >= 0.0
         return dt
 
     def occluded1(self, rays, threads=1):

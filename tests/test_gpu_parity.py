@@ -829,7 +829,7 @@ def test_full_size_vs_real_reference(api, dev, crown_full):
     if not refembree.available():
         pytest.skip("oracle/_ref not present on this box")
     meshes, s, rays = crown_full
-    R = refembree.RefScene("threads=%d" % refembree.hw_threads())
+    R = refembree.RefScene("threads=%d" % min(16, refembree.hw_threads()))
     for v, t in meshes:
         R.add_mesh(v, t)
     R.commit()

@@ -46,7 +46,7 @@ def ref():
 
 
 def ref_scene(ref, meshes, masks=None, flags=0, threads=None):
-    R = ref.RefScene("threads=%d" % (threads or ref.hw_threads()), flags=flags)
+    R = ref.RefScene("threads=%d" % (threads or min(16, ref.hw_threads())), flags=flags)   # (its tasking system builds fastest with few threads; queries run on the caller's threads)
     for i, (v, t) in enumerate(meshes):
         R.add_mesh(v, t, 1 if masks is None else masks[i])
     R.commit()

@@ -222,7 +222,7 @@ def test_shadow16m_whole_job_vs_reference_all_rays(api, ref, tmp_path):
     rays, words = z["rays"], z["gathered"]
     assert rays.shape[0] == 1 << 24 and words.shape[0] == 1 << 24
     meshes = W.synthetic_crown(num_phi=158)
-    R = ref.RefScene("threads=%d" % ref.hw_threads())
+    R = ref.RefScene("threads=%d" % min(16, ref.hw_threads()))
     for v, t in meshes:
         R.add_mesh(v, t)
     R.commit()

@@ -49,7 +49,7 @@ def ref():
 
 
 def ref_scene(ref, meshes, flags=0):
-    R = ref.RefScene("threads=%d" % ref.hw_threads(), flags=flags)
+    R = ref.RefScene("threads=%d" % min(16, ref.hw_threads()), flags=flags)   # (its tasking system builds fastest with few threads: 0.14 s vs 4.4 s with all 256 for 4.8 M triangles; queries run on the caller's threads)
     for v, t in meshes:
         R.add_mesh(v, t)
     R.commit()
@@ -306,3 +306,150 @@ def test_two_threads_issue_coherent_queries_on_one_scene(api, dev):
         t.join()
     assert not errors, errors[:4]
     s.release()
+
+
+# ------------------------------------------------------------------------------------------- instances that only move: the top tree is refitted
+def test_moved_instances_refit_the_top_tree(api, dev):
+    """4096 instances of one object, every one of them moved between two commits (rtcSetGeometryTransform): the second rtcCommitScene refits the top tree in
+    place and rewrites the instance records (mi355_bvh_refit_instanced; the reference refits / rebuilds only the top level of a two-level scene,
+    kernels/bvh/bvh_refit.cpp) instead of building the top tree and concatenating the object trees again.  Answers = those of a scene BUILT with the moved
+    transforms (closest hit, instID, occlusion); a changed instance COUNT falls back to a build; "instance_refit=0" gives the same answers."""
+    import time
+    L = api.load()
+    obj = api.make_scene(dev, [W.triangle_sphere(np.zeros(3, np.float32), 0.4, 10)])
+    rng = np.random.default_rng(11)
+
+    def transforms(seed):
+        r = np.random.default_rng(seed)
+        out = []
+        for k in range(4096):
+            a = r.uniform(0, 2 * np.pi)
+            sc = r.uniform(0.5, 1.5)
+            c, s_ = np.cos(a) * sc, np.sin(a) * sc
+            p = np.array([(k % 16) * 2.0, ((k // 16) % 16) * 2.0, (k // 256) * 2.0], np.float32) + r.uniform(-0.4, 0.4, 3).astype(np.float32)
+            out.append(np.array([c, s_, 0, -s_, c, 0, 0, 0, sc, p[0], p[1], p[2]], np.float32))
+        return out
+
+    def build(xf, cfg_dev=None):
+        d = cfg_dev or dev
+        o = obj if cfg_dev is None else api.make_scene(d, [W.triangle_sphere(np.zeros(3, np.float32), 0.4, 10)])
+        t = api.Scene(d)
+        ids = [t.add_instance(o, x) for x in xf]
+        t.commit()
+        return t, ids, o
+
+    a0, a1 = transforms(1), transforms(2)
+    top, ids, _ = build(a0)
+    org = rng.uniform(-2, 34, (60000, 3)).astype(np.float32)
+    dirs = rng.normal(size=(60000, 3)).astype(np.float32)
+    from embree_amd.rtypes import make_rayhits
+    rays = make_rayhits(org, dirs)
+    before = rays.copy(); top.intersect1M(before)
+    launches0 = top.info()
+    for gid, x in zip(ids, a1):
+        top.set_instance_transform(gid, x)
+    t0 = time.perf_counter(); top.commit(); wall = time.perf_counter() - t0
+    info = top.info()
+    assert info["num_refits"] >= 1, "the commit after a move did not refit the top tree"
+    fresh, _, _ = build(a1)
+    got, want = rays.copy(), rays.copy()
+    top.intersect1M(got); fresh.intersect1M(want)
+    assert (want["geomID"] != INVALID_ID).sum() > 2000 and (got.tobytes() != before.tobytes())
+    same = (got["instID"] == want["instID"]) & (got["primID"] == want["primID"]) & (got["tfar"] == want["tfar"])
+    assert same.mean() > 0.9999, "refitted and built scene disagree on %d rays" % int((~same).sum())
+    gr, wr = rays_of(rays), rays_of(rays)
+    top.occluded1M(gr); fresh.occluded1M(wr)
+    assert (np.isneginf(gr["tfar"]) == np.isneginf(wr["tfar"])).all()
+    blo, bhi = top.bounds(); flo, fhi = fresh.bounds()
+    assert (blo == flo).all() and (bhi == fhi).all()
+    # a second move, timed alone (transforms set before the clock): the whole commit
+    for gid, x in zip(ids, a0):
+        top.set_instance_transform(gid, x)
+    t0 = time.perf_counter(); top.commit(); wall2 = time.perf_counter() - t0
+    got2 = rays.copy(); top.intersect1M(got2)
+    assert ((got2["instID"] == before["instID"]) & (got2["tfar"] == before["tfar"])).mean() > 0.9999
+    print("4096 moved instances: commit %.3f ms / %.3f ms wall (refit %.3f ms GPU); built scene: %.3f ms GPU" % (wall * 1e3, wall2 * 1e3, info["build_ms"], fresh.info()["build_ms"]))
+    assert wall2 < 2e-3, "a move of 4096 instances took %.2f ms" % (wall2 * 1e3)
+    # one instance more: not a move -> built anew, still right
+    top.add_instance(obj, a1[7] + np.float32(0.01))
+    top.commit()
+    assert top.info()["num_refits"] == 0
+    fresh.release(); top.release()
+    # the same through the rebuild path
+    d2 = api.Device("gpu=0,instance_refit=0")
+    t2, ids2, o2 = build(a0, d2)
+    for gid, x in zip(ids2, a1):
+        t2.set_instance_transform(gid, x)
+    t2.commit()
+    assert t2.info()["num_refits"] == 0
+    g2 = rays.copy(); t2.intersect1M(g2)
+    assert ((g2["instID"] == want["instID"]) & (g2["tfar"] == want["tfar"])).mean() > 0.9999
+    t2.release(); o2.release(); d2.release(); obj.release()
+
+
+# ------------------------------------------------------------------------------------------- filter callbacks inside instanced scenes
+@pytest.mark.parametrize("flags", [0, 4])
+def test_filter_callbacks_inside_instances_vs_reference(api, dev, ref, flags):
+    """Host filter callbacks on the geometries of an INSTANCED scene (round 3 threw RTC_ERROR_INVALID_OPERATION): a hit inside an instance names the instance in
+    instID[0] and the object's geometry in geomID, the filter is that geometry's (instance_intersector.cpp:26-60, kernels/geometry/filter.h:14-80) and sees the
+    instance in context->instID[0].  The same rule ("primID % 3 == 0 or u > 0.7": oracle/ref_driver.cpp) runs as an in-traversal callback in the real reference."""
+    from embree_amd.rtypes import make_rayhits
+    sph = W.triangle_sphere(np.zeros(3, np.float32), 0.5, 24, noise=0.1, seed=3)
+    xfs = []
+    rng = np.random.default_rng(5)
+    for k in range(9):
+        a = rng.uniform(0, 2 * np.pi); sc = rng.uniform(0.6, 1.3)
+        c, s_ = np.cos(a) * sc, np.sin(a) * sc
+        xfs.append(np.array([c, s_, 0, -s_, c, 0, 0, 0, sc, (k % 3) * 1.4, (k // 3) * 1.4, 0.2 * k], np.float32))
+    own = W.triangle_sphere(np.array([1.4, 1.4, -1.5], np.float32), 0.8, 16)
+    # reference
+    R = ref.RefScene(flags=flags)
+    Ro = R.new_object(flags=flags)
+    Ro.add_mesh(*sph); Ro.set_filters(1, 1 | 2); Ro.commit()
+    gid_own = R.add_mesh(*own)
+    for x in xfs:
+        R.add_instance(Ro, x)
+    R.commit()
+    # here
+    calls = {"n": 0, "inst": set()}
+
+    def rule_geometry(a):
+        a = a.contents; calls["n"] += 1
+        calls["inst"].add(int(C.cast(a.context, C.POINTER(C.c_uint32))[0]))          # RTCRayQueryContext.instID[0]
+        for i in range(a.N):
+            if a.valid[i] != -1:
+                continue
+            prim = C.cast(a.hit, C.POINTER(C.c_uint32))[5 * a.N + i]; u = a.hit[3 * a.N + i]
+            if prim % 3 == 0 or u > 0.7:
+                a.valid[i] = 0
+    f = api.FILTER_FN(rule_geometry)
+    obj = api.make_scene(dev, [sph], flags=flags)
+    obj.set_filters(0, intersect=f, occluded=f)
+    obj.commit()
+    top = api.Scene(dev, flags)
+    assert top.add_triangle_mesh(*own) == gid_own
+    inst_ids = [top.add_instance(obj, x) for x in xfs]
+    top.commit()
+    n = 20000
+    org = rng.uniform(-1.5, 4.5, (n, 3)).astype(np.float32); org[:, 2] = rng.uniform(3.0, 5.0, n).astype(np.float32)
+    tgt = rng.uniform(-0.5, 3.3, (n, 3)).astype(np.float32); tgt[:, 2] = rng.uniform(-1.5, 1.5, n).astype(np.float32)
+    rays = make_rayhits(org, tgt - org)
+    want, got = rays.copy(), rays.copy()
+    R.intersect1(want, 8)
+    top.intersect1M(got)
+    hit = want["geomID"] != INVALID_ID
+    assert hit.sum() > 3000 and (want["instID"][hit] != INVALID_ID).sum() > 1500
+    same = (got["geomID"] == want["geomID"]) & (got["primID"] == want["primID"]) & (got["instID"] == want["instID"])
+    far = np.abs(got["tfar"] - want["tfar"]) > 1e-4 * np.abs(want["tfar"])
+    assert ((~same) & far & hit).sum() <= 2e-3 * n, "%d rays end elsewhere than in the reference" % int(((~same) & far & hit).sum())   # (exact-t ties aside)
+    assert calls["n"] > 1000 and len(calls["inst"] & set(inst_ids)) >= 5, (calls["n"], sorted(calls["inst"])[:12])   # the callbacks saw the instances in context->instID[0]
+    nof = rays.copy()
+    obj.set_filters(0, intersect=None, occluded=None); obj.commit(); top.commit()
+    top.intersect1M(nof)
+    assert ((nof["primID"] != got["primID"]) | (nof["instID"] != got["instID"])).sum() > 500, "the filters changed nothing: the test would prove nothing"
+    obj.set_filters(0, intersect=f, occluded=f); obj.commit(); top.commit()
+    wr, gr = rays_of(rays), rays_of(rays)
+    R.occluded1(wr, 8)
+    top.occluded1M(gr)
+    compare_occluded(gr["tfar"], wr["tfar"], rays_of(rays)["tfar"], max_flip_frac=3e-3, label="occlusion filter inside instances")
+    top.release(); obj.release(); Ro.close(); R.close()
