@@ -139,7 +139,11 @@ def cpu_baseline(meshes, rays, any_hit=False, budget_s=25.0):
                 warm = rays.copy()                             # (the AVX2 library's answers: what the parity block compares with)
                 (s.occluded1 if any_hit else s.intersect1)(warm, hw)
             s.run_tiled(src, 1, hw, any_hit)                   # warm-up: pool started, tree paged in
-            d1 = [s.run_tiled(src, 1, hw, any_hit) for _ in range(7)]
+            d1 = []
+            for _ in range(7):
+                if quota is not None:
+                    time.sleep(0.25)                           # (a fresh cgroup period: the burst must not start on a quota the job before it used up)
+                d1.append(s.run_tiled(src, 1, hw, any_hit))
             d16, spent = [], 0.0
             while len(d16) < 5 and spent < budget_s / len(isas):
                 dt = s.run_tiled(src, 16, hw, any_hit)        # 16 Mi records (verify.cpp's job size), filled by the pool's own threads
@@ -152,6 +156,8 @@ def cpu_baseline(meshes, rays, any_hit=False, budget_s=25.0):
                     dk = []
                     for _ in range(3):
                         r = rays.copy()
+                        if quota is not None:
+                            time.sleep(0.25)
                         dk.append(s.packet(K, r, threads=hw))
                     rec["rtcIntersect%d_mrays_1Mi" % K] = n / min(dk) / 1e6
             per_isa[isa] = {k: (round(v, 1) if isinstance(v, float) else v) for k, v in rec.items()}
@@ -496,6 +502,29 @@ def main():
         ev_packed, ev_gathered = [C.c_void_p() for _ in range(2)], [C.c_void_p() for _ in range(2)]
         for e in ev_packed + ev_gathered:
             assert L.mi355_event_create(C.byref(e)) == 0
+
+        # one collective on trial before anything is timed: a gather that never completes (a link that does not come up) must cost the line its gather, not the line
+        def trial():
+            if shadow:
+                comm.allgather(packed[0].ptr, gathered[0].ptr, pack_bytes, comm_stream)
+            else:
+                comm.gather(packed[0].ptr, gathered[0].ptr, pack_bytes, 0, comm_stream)
+            deadline = time.time() + 90
+            while L.mi355_stream_query(comm_stream) == 1:
+                if time.time() > deadline:
+                    return dict(error="the trial collective did not complete within 90 s")
+                time.sleep(0.002)
+            return True
+        res = run_guarded(trial, 120)
+        ok = 1.0 if res is True else 0.0
+        if dist:
+            tt = dist[1].tensor([ok], dtype=dist[1].float64)
+            dist[0].all_reduce(tt, op=dist[0].ReduceOp.MIN)
+            ok = float(tt[0])
+        if ok < 1.0:
+            comm_err = (res.get("error") if isinstance(res, dict) else None) or "the trial collective failed on another rank"
+            log("rank %d: %s: results stay in the per-rank buffers" % (rank, comm_err))
+            gather_in_step, comm = False, None                # (the communicator is left alone: destroying one with a collective in flight can hang as well)
 
     def step(buf, stream, ev_a=None, ev_b=None):
         """one pass of the hot path over one batch: trace; with a communicator also pack the written fields and gather them over RCCL -- the gather of THIS batch
