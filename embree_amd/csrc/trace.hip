@@ -68,7 +68,8 @@ struct TraceArgs {
   uint32_t* counter;     // global ray cursor (zeroed before launch)
   uint2* spill;          // [gridDim.x * BLOCK][spillPerLane]
   uint32_t spillPerLane;
-  uint32_t refillMin, pushRounds, numCursors, drainWaiters;
+  uint32_t refillMin, pushRounds, numCursors, drainWaiters;   // refillMin and numCursors are powers of two (gShift, cShift: their logarithms): the hand-out arithmetic is shifts and 32-bit adds
+  uint32_t gShift, cShift;
   uint32_t iterCap, helpers;
   volatile uint32_t* status;  // host-mapped: [STATUS_ITER_CAP], [STATUS_SPILL] set to 1 when a safety net dropped work
   unsigned long long* stats;  // optional counters
@@ -91,7 +92,7 @@ __device__ __forceinline__ uint32_t test4(uint32_t nx, uint32_t ny, uint32_t nz,
                                           uint32_t octinv4, const SlabCoef& k, float tmin0, float tmax0) {
   // meta byte: inner = 001 11sss (bits 3 and 4 set), leaf = ccc ooooo with offset <= 23, empty = 0
   const uint32_t isInner4 = (meta4 & (meta4 << 1)) & 0x10101010u;
-  const uint32_t innerMask4 = (isInner4 >> 4) * 7u;                   // 0x07 in the bytes of inner slots
+  const uint32_t innerMask4 = (isInner4 >> 1) - (isInner4 >> 4);      // 0x07 in the bytes of inner slots (0x08 - 0x01 per byte: v_mul_lo_u32 is a quarter-rate instruction)
   const uint32_t bitIndex4 = meta4 ^ (octinv4 & innerMask4);          // low 5 bits: position in the hit word
   const uint32_t childBits4 = (meta4 >> 5) & 0x07070707u;             // inner: 1, leaf: unary triangle count, empty: 0
   uint32_t hits = 0;
@@ -122,7 +123,7 @@ __device__ __forceinline__ uint32_t test4_robust(uint32_t nx, uint32_t ny, uint3
                                                  float scx, float scy, float scz, float nox, float noy, float noz, float ox, float oy, float oz,
                                                  float rnx, float rny, float rnz, float rfx, float rfy, float rfz, float tmin0, float tmax0) {
   const uint32_t isInner4 = (meta4 & (meta4 << 1)) & 0x10101010u;
-  const uint32_t innerMask4 = (isInner4 >> 4) * 7u;
+  const uint32_t innerMask4 = (isInner4 >> 1) - (isInner4 >> 4);
   const uint32_t bitIndex4 = meta4 ^ (octinv4 & innerMask4);
   const uint32_t childBits4 = (meta4 >> 5) & 0x07070707u;
   uint32_t hits = 0;
@@ -390,6 +391,7 @@ __global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceAr
   };
   const uint32_t rayCount = a.deferCount ? *a.deferCount * 64u : a.count;   // (wave-uniform) rays to hand out: all of them, or those of the deferred packets
   if (rayCount == 0u) { wave_exit(); return; }                              // (the pass behind a packet launch none of whose packets gave up)
+  const uint32_t totalBlocks = (rayCount + a.refillMin - 1u) >> a.gShift;      // (wave-uniform) blocks of refillMin rays in this launch
   uint32_t iter = 0;
   for (; iter < a.iterCap; iter++) {
     // ------------------------------------------------------------------ 0. a full batch of queued pairs is waiting: issue the loads of its triangle records now, so that
@@ -444,27 +446,30 @@ __global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceAr
           // (b) claim the reserved block for free lanes
           const unsigned long long freeLanes = __ballot(!active);
           const bool canGrab = !exhausted && (uint32_t)__popcll(freeLanes) >= G;
-          bool got = false; uint32_t newIdx = 0; float4 r0 = make_float4(0, 0, 0, 0), r1 = r0, r2 = r0;
+          bool got = false; uint32_t newIdx = 0; float4 r0, r1, r2;
+          MI355_UNDEF4(r0); MI355_UNDEF4(r1); MI355_UNDEF4(r2);               // (only read under `got`: no twelve v_mov per pass to give them a value)
           if (canGrab) {
             while (!exhausted) {
               // A wave without a reserved block (launch start: all 64 lanes free) takes as many blocks as it has room for with ONE atomic: 4096 waves asking
               // for four blocks one after the other is 16384 atomics on eight words, ~20 us in which nobody traverses.  Blocks v, v + 1, ... of a cursor are
               // not neighbours in the ray array (cursors interleave), which is as good as any other order.
               uint32_t take = 1u;
-              if (!resValid) { take = max(1u, (uint32_t)__popcll(freeLanes) / G); if (lane == 0u) resV = atomicAdd(a.counter + cursor * CURSOR_STRIDE, take); resValid = true; }
+              if (!resValid) { take = max(1u, (uint32_t)__popcll(freeLanes) >> a.gShift); if (lane == 0u) resV = atomicAdd(a.counter + cursor * CURSOR_STRIDE, take); resValid = true; }
               const uint32_t base = __builtin_amdgcn_readfirstlane(resV);
-              const unsigned long long firstRay = ((unsigned long long)base * a.numCursors + cursor) * G;
+              // 32-bit arithmetic throughout (the launch refuses more than 0xFFF00000 rays; a dry cursor is over-asked by a few blocks per wave at most): block
+              // (base << cShift) + cursor of the batch, rays block << gShift ...  (64-bit products and two divisions by run-time values were a tenth of this block)
+              const uint32_t block = (base << a.cShift) + cursor;
               resValid = false;
-              if (firstRay >= rayCount) {                                 // this cursor is dry: try the next one
-                cursor = (cursor + 1u) % a.numCursors;
+              if (block >= totalBlocks) {                                 // this cursor is dry: try the next one
+                cursor = (cursor + 1u) & (a.numCursors - 1u);
                 if (++dryCursors >= a.numCursors) exhausted = true;
                 continue;
               }
               const uint32_t rank = (uint32_t)__popcll(freeLanes & ((1ull << lane) - 1ull));
-              const unsigned long long myRay = (((unsigned long long)base + rank / G) * a.numCursors + cursor) * G + rank % G;   // block rank / G of this grab, ray rank % G of it
-              got = ((freeLanes >> lane) & 1ull) != 0ull && rank < take * G && myRay < rayCount;
-              if (got && a.deferList) { const uint32_t q = (uint32_t)myRay; newIdx = a.deferList[q >> 6] * 64u + (q & 63u); got = newIdx < a.count; }   // (the last packet of a batch may be ragged)
-              else if (got) newIdx = (uint32_t)myRay;
+              const uint32_t myRay = ((((base + (rank >> a.gShift)) << a.cShift) + cursor) << a.gShift) + (rank & (G - 1u));   // block rank / G of this grab, ray rank % G of it
+              got = ((freeLanes >> lane) & 1ull) != 0ull && rank < (take << a.gShift) && myRay < rayCount;
+              if (got && a.deferList) { const uint32_t q = myRay; newIdx = a.deferList[q >> 6] * 64u + (q & 63u); got = newIdx < a.count; }   // (the last packet of a batch may be ragged)
+              else if (got) newIdx = myRay;
               if (got) {
                 const float4* rp = (const float4*)(a.rays + (size_t)newIdx * a.stride);
                 r0 = rp[0]; r1 = rp[1]; r2 = rp[2];
@@ -1049,6 +1054,7 @@ static int launch_trace_locked(Bvh* b, TraceScratch* sc, void* d_rays, uint32_t 
                                hipEvent_t evStart = nullptr, hipEvent_t evStop = nullptr, const uint32_t* deferList = nullptr, const uint32_t* deferCount = nullptr) {
   if (count == 0) return 0;
   if (stride < (any ? 48u : 96u) || (stride & 15u) || ((uintptr_t)d_rays & 15u)) return set_error(hipErrorInvalidValue, "ray array must be 16-byte aligned with a 16-byte-multiple stride");
+  if (count > 0xFFF00000u) return set_error(hipErrorInvalidValue, "more than 0xFFF00000 rays in one launch (the hand-out arithmetic is 32-bit)");
   HIP_TRY(hipSetDevice(b->device));
   const TraceFn fn = pick_kernel(any, statsOut != nullptr, b->robust, b->d_insts != nullptr, b->d_rules != nullptr);
   const uint32_t maxBlocks = resident_blocks(b, fn);
@@ -1062,7 +1068,9 @@ static int launch_trace_locked(Bvh* b, TraceScratch* sc, void* d_rays, uint32_t 
   static const uint32_t pushRounds = env_u32("MI355_PUSH_ROUNDS", PUSH_ROUNDS_DEFAULT, 1, 24);
   static const uint32_t numCursors = env_u32("MI355_NUM_CURSORS", NUM_CURSORS, 1, NUM_CURSORS);
   static const uint32_t drainWaiters = env_u32("MI355_DRAIN_WAITERS", 3, 1, 65);
-  a.refillMin = refillMin; a.pushRounds = pushRounds; a.numCursors = numCursors; a.drainWaiters = drainWaiters;
+  auto log2floor = [](uint32_t v) { uint32_t l = 0; while ((2u << l) <= v) l++; return l; };
+  a.gShift = log2floor(refillMin); a.cShift = log2floor(numCursors);
+  a.refillMin = 1u << a.gShift; a.numCursors = 1u << a.cShift; a.pushRounds = pushRounds; a.drainWaiters = drainWaiters;
   { const char* e = getenv("MI355_TRACE_ITER_CAP"); const long v = e ? atol(e) : 0; a.iterCap = v > 0 && v < (long)ITER_CAP ? (uint32_t)v : ITER_CAP; }
   a.status = sc->statusDev;
   { const char* e = getenv("MI355_TRACE_HELPERS"); a.helpers = e && atoi(e) == 0 ? 0u : 1u; }   // tail helpers (step 1b) on unless MI355_TRACE_HELPERS=0
