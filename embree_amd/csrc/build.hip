@@ -65,6 +65,10 @@ struct Arena {
   hipStream_t stream = nullptr;                              // commits enqueue here when the caller gives no stream (a capture needs a real stream)
   std::vector<uint64_t> graphKey; hipGraphExec_t graphExec = nullptr; bool graphBroken = false;   // graphBroken: capture / instantiate failed once on this device: plain launches from then on
   uint32_t marginFailedN = 0;                                // a commit of this many triangles outgrew the level margins of the one-round-trip path: the next one goes stepwise at once
+  // What the last one-round-trip commit of a scene of this many triangles needed: its top-phase levels and the depth of its wide tree.  The next commit of the
+  // same size (a scene re-committed every frame) enqueues those + 1 instead of the blind margins (levels N implies + 8, 16 wide levels): every level that does
+  // not exist still costs its launches (~4.7 us each, ~35 of the 169 of a crown commit).  A commit that outgrows the learned counts forgets them and runs again.
+  uint32_t learnedN = 0, learnedTop = 0, learnedWide = 0;
   void drop_graph() { if (graphExec) { hipGraphExecDestroy(graphExec); graphExec = nullptr; } graphKey.clear(); }
   void reset() { for (auto& b : blocks) b.used = 0; }
   hipError_t take(size_t bytes, void** out) {
@@ -170,7 +174,7 @@ Bvh::~Bvh() {
 // looks at the counters between groups of levels like the first generations of this builder did.  Why: a host round trip costs 20-40 us on an idle
 // box but was measured at ~0.8 ms each on the round-end driver's box (commit 13.9 ms there, 7.0 ms here, same code), and there were nine of them.
 // LOW (Morton: the sort needs n on the host) and HIGH (presplit: the budget loop) keep one round trip after primref_gen.
-static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, const mi355_build_params* bp, hipStream_t st, Bvh** out, bool allowFast = true, bool allowTopSplits = true) {
+static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, const mi355_build_params* bp, hipStream_t st, Bvh** out, bool allowFast = true, bool allowTopSplits = true, bool allowLearned = true) {
   HIP_TRY(hipSetDevice(device));
   Arena* arena = arena_of(device);
   std::lock_guard<std::mutex> arenaLock(arena->mtx);
@@ -223,6 +227,8 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
     st = arena->stream;
   }
   const bool useGraph = fast && envGraph && st != nullptr && !arena->graphBroken;
+  static const bool envLearn = !(getenv("MI355_BUILD_LEARN") && atoi(getenv("MI355_BUILD_LEARN")) == 0);
+  const bool learned = fast && allowLearned && envLearn && arena->learnedN == N && arena->learnedTop != 0u;
   uint32_t launches = 0, syncs = 0;
   bool replay = false, capturing = false;                       // fast path: the launches below are replayed from the cached graph / are being captured into one
   // MI355_BUILD_DEBUG=1: every launch is named on stderr and waited for (finds the kernel behind a device fault; use with MI355_BUILD_GRAPH=0)
@@ -271,7 +277,7 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
     const void* ptrs[] = {dGeoms.p, bufA.p, bufB.p, finalIds.p, bnodes.p, segs0.p, segs1.p, bins.p, chunks.p, small.p, ctr.p, w0.p, w1.p, wnodes.p, outIds.p, plans.p, itemCnt.p, groupSum.p, tileCount.p, chunkCnt.p, chunkBase.p, segx0.p, segx1.p, sbins.p, outlierCnt.p, outlierTile.p, outlierTotal.p, (const void*)st};
     std::vector<uint64_t> key; for (const void* q : ptrs) key.push_back((uint64_t)(uintptr_t)q);
     uint32_t pw[sizeof(Params) / 4]; memcpy(pw, &prm, sizeof(prm)); for (uint32_t w : pw) key.push_back(w);
-    key.push_back(N); key.push_back(gd.size()); key.push_back(bp->robust); key.push_back(spatialMin); key.push_back(NC); { uint32_t w; memcpy(&w, &topSplitRel, 4); key.push_back(w); memcpy(&w, &topSplitCell, 4); key.push_back(w); } key.push_back(topSplits ? 1u : 0u);
+    key.push_back(N); key.push_back(gd.size()); key.push_back(bp->robust); key.push_back(spatialMin); key.push_back(NC); { uint32_t w; memcpy(&w, &topSplitRel, 4); key.push_back(w); memcpy(&w, &topSplitCell, 4); key.push_back(w); } key.push_back(topSplits ? 1u : 0u); key.push_back(learned ? (arena->learnedTop << 8) | arena->learnedWide : 0u);
     if (arena->graphExec && arena->graphKey == key) replay = true;
     else {
       arena->drop_graph(); arena->graphKey = key;
@@ -421,7 +427,10 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
   };
   if (numSegs && sahBuild) {
     uint32_t sure = 1; while (sure < 40u && ((uint64_t)prm.small << sure) < n) sure++;   // the largest segment halves at best: that many levels exist
-    if (fast) { for (uint32_t i = 0; i < sure + 8u; i++) enqueue_top_level(); }              // + margin: SAH splits are uneven (crown: 17 levels where 13 are implied)
+    if (fast) {                                                                             // + margin: SAH splits are uneven (crown: 17 levels where 13 are implied)
+      const uint32_t levels = learned ? min(sure + 8u, arena->learnedTop + 1u) : sure + 8u;   // (what the last commit of this size needed, + 1)
+      for (uint32_t i = 0; i < levels; i++) enqueue_top_level();
+    }
     else {
       for (uint32_t i = 0; i < sure; i++) enqueue_top_level();
       for (;;) {
@@ -466,7 +475,7 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
   if (fast) {
     // the depth of the wide tree is unknown here: 16 levels cover every scene measured so far (crown 12, powerplant 13); a deeper tree is finished below
     // (every level enqueued beyond the last one costs three empty launches, ~14 us)
-    for (uint32_t i = 0; i < 16u; i++) enqueue_wide_level();
+    { const uint32_t levels = learned && arena->learnedWide ? min(16u, arena->learnedWide + 1u) : 16u; for (uint32_t i = 0; i < levels; i++) enqueue_wide_level(); }
     if (capturing) {                                             // end of the captured sequence: instantiate, keep, run
       hipGraph_t graph = nullptr;
       const hipError_t e = hipStreamEndCapture(st, &graph);
@@ -484,8 +493,9 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
     LAUNCH(tri_records, dim3((NC + 255u) / 256u), dim3(256), 0, st, outIds.p, NC, dGeoms.p, (TriRec*)bvh->d_tris, bp->robust ? 1u : 0u, (const Counters*)ctr.p);
     SYNC_READ(h);                                                // the ONE round trip of the commit
     if (h.overflow) return set_error(hipErrorOutOfMemory, "work list overflow (pathological input)");
-    if (h.numSegs != 0u) {                                       // the top phase needed more levels than N implies + 8: what came after it worked on an unfinished tree
-      arena->marginFailedN = N;
+    if (h.numSegs != 0u) {                                       // the top phase needed more levels than were enqueued: what came after it worked on an unfinished tree
+      if (learned) { arena->learnedN = 0; arena->learnedTop = arena->learnedWide = 0; return -1001; }   // (counts learned from another scene of this size: again, with the blind margins)
+      arena->marginFailedN = N;                                  // more than N implies + 8
       return -1000;                                              // (the guard frees the half-built tree) the caller repeats the commit on the stepwise path
     }
     n = h.numPrims;
@@ -500,6 +510,7 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
       if (h.overflow) return set_error(hipErrorOutOfMemory, "wide node pool overflow");
       redoLeaves = true;
     }
+    arena->learnedN = N; arena->learnedTop = h.topLevels; arena->learnedWide = h.wideDepth;   // (a tree deeper than the wide levels enqueued is finished below either way)
     if (redoLeaves) LAUNCH(tri_records, dim3((NC + 255u) / 256u), dim3(256), 0, st, outIds.p, NC, dGeoms.p, (TriRec*)bvh->d_tris, bp->robust ? 1u : 0u, (const Counters*)ctr.p);
   } else {
     for (uint32_t i = 0; i < 8u; i++) enqueue_wide_level();
@@ -552,6 +563,7 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
 // the one-round-trip path can ask for the commit to be repeated on the stepwise path (-1000: level margins exceeded); that path does not cut outliers
 static int build_retry(int device, const mi355_mesh* meshes, uint32_t numMeshes, const mi355_build_params* bp, hipStream_t st, Bvh** out) {
   int rc = build_impl(device, meshes, numMeshes, bp, st, out);
+  if (rc == -1001) rc = build_impl(device, meshes, numMeshes, bp, st, out, true, true, false);   // the level counts learned from the last commit of this size were too few
   if (rc == -1000) rc = build_impl(device, meshes, numMeshes, bp, st, out, false, false);
   return rc;
 }
