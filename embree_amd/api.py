@@ -45,7 +45,7 @@ rtcTraversableOccluded1 rtcTraversableOccluded4 rtcTraversableOccluded8 rtcTrave
 rtcIntersect1M rtcOccluded1M rtcIntersect1MDevice rtcOccluded1MDevice""".split()
 MI355_SYMBOLS = """mi355_default_build_params mi355_last_error mi355_device_count mi355_device_name mi355_bvh_build
 mi355_bvh_destroy mi355_bvh_build_instanced mi355_bvh_refit mi355_bvh_refit_instanced mi355_release_build_scratch mi355_bvh_get_info mi355_bvh_set_filter_rules mi355_bvh_download mi355_trace_prepare mi355_trace_closest mi355_trace_any
-mi355_trace_query mi355_trace_closest_packet mi355_trace_any_packet mi355_trace_stats mi355_trace_timed mi355_trace_status mi355_malloc mi355_free mi355_memcpy_h2d
+mi355_trace_query mi355_trace_closest_packet mi355_trace_any_packet mi355_trace_stats mi355_trace_timed mi355_trace_status mi355_malloc mi355_malloc_retry mi355_free mi355_memcpy_h2d
 mi355_memcpy_d2h mi355_synchronize mi355_device_synchronize mi355_memcpy_d2d_async mi355_stream_create
 mi355_stream_destroy mi355_event_create mi355_event_record mi355_event_elapsed_ms mi355_event_destroy
 mi355_comm_unique_id mi355_comm_init mi355_comm_destroy mi355_comm_allgather mi355_comm_gather mi355_pack_hits mi355_pack_hits_inst mi355_pack_occluded mi355_stream_query mi355_stream_wait_event mi355_measure_bandwidth""".split()

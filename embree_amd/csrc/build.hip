@@ -91,8 +91,10 @@ struct Arena {
     *cap = bytes; return p;
   }
   void give_output(void* p, size_t cap) {
-    if (spares.size() >= 4) { hipFree(spares.front().p); spares.erase(spares.begin()); }
+    // at most four arrays and 1 GiB in all (the API has told the memory monitor they are freed: what sits here is memory the application believes it has)
     spares.push_back({p, cap});
+    size_t total = 0; for (auto& sp : spares) total += sp.cap;
+    while (!spares.empty() && (spares.size() > 4 || total > ((size_t)1 << 30))) { total -= spares.front().cap; hipFree(spares.front().p); spares.erase(spares.begin()); }
   }
   void release() { drop_graph(); if (stream) { hipStreamDestroy(stream); stream = nullptr; } for (auto& b : blocks) hipFree(b.p); blocks.clear(); }
   void release_spares() { for (auto& sp : spares) hipFree(sp.p); spares.clear(); }
@@ -540,7 +542,7 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
   }
   bvh->robust = bp->robust != 0;
   if (bp->refit && h.numInvalid == 0u && depth < 64u && prm.quality != 2u && !spatial) {        // keep the leaf order and the level table for mi355_bvh_refit
-    HIP_TRY(hipMalloc(&bvh->d_ids, (size_t)n * sizeof(uint2)));
+    { const int rc = mi355_malloc_retry(device, (size_t)n * sizeof(uint2), &bvh->d_ids); if (rc) return rc; }
     HIP_TRY(hipMemcpyAsync(bvh->d_ids, outIds.p, (size_t)n * sizeof(uint2), hipMemcpyDeviceToDevice, st));
     bvh->lvlStart.assign(h.lvlStart, h.lvlStart + depth); bvh->lvlStart.push_back(numNodes);
     for (const GeomDesc& g : gd) bvh->sig.push_back({g.geomID, g.nt, g.nv, g.quad});
@@ -712,8 +714,7 @@ static int build_instanced_impl(int device, Bvh* own, const mi355_instance* inst
     if (objs[k]->info.depth > maxDepth) maxDepth = objs[k]->info.depth;
   }
   if (nNodes >= (1ull << 32) || nTris >= (1ull << 32)) return set_error(hipErrorInvalidValue, "instanced scene exceeds the 32-bit node / triangle index");
-  HIP_TRY(hipMalloc(&bvh->d_nodes, (size_t)nNodes * sizeof(CNode)));
-  HIP_TRY(hipMalloc(&bvh->d_tris, (size_t)nTris * sizeof(TriRec) + 128));
+  { int rc = mi355_malloc_retry(device, (size_t)nNodes * sizeof(CNode), &bvh->d_nodes); if (rc) return rc; rc = mi355_malloc_retry(device, (size_t)nTris * sizeof(TriRec) + 128, &bvh->d_tris); if (rc) return rc; }
   HIP_TRY(hipMemcpyAsync(bvh->d_nodes, top->d_nodes, (size_t)top->info.num_nodes * sizeof(CNode), hipMemcpyDeviceToDevice, st));
   HIP_TRY(hipMemcpyAsync(bvh->d_tris, top->d_tris, (size_t)top->info.num_triangles * sizeof(TriRec), hipMemcpyDeviceToDevice, st));
   for (size_t k = 0; k < objs.size(); k++) {
@@ -870,6 +871,17 @@ int mi355_bvh_download(mi355_bvh_t bvh, void* nodes, size_t nb, void* tris, size
   mi355::Bvh* b = (mi355::Bvh*)bvh; HIP_TRY(hipSetDevice(b->device));
   if (nodes && nb) { if (nb > b->info.bytes_nodes) nb = b->info.bytes_nodes; if (nb) HIP_TRY(hipMemcpy(nodes, b->d_nodes, nb, hipMemcpyDeviceToHost)); }
   if (tris && tb) { if (tb > b->info.bytes_triangles) tb = b->info.bytes_triangles; if (tb) HIP_TRY(hipMemcpy(tris, b->d_tris, tb, hipMemcpyDeviceToHost)); }
+  return 0;
+}
+int mi355_malloc_retry(int device, size_t bytes, void** d) {
+  HIP_TRY(hipSetDevice(device));
+  hipError_t e = hipMalloc(d, bytes ? bytes : 1);
+  if (e == hipErrorOutOfMemory) {                               // the arena's spare tree arrays first, then once more
+    (void)hipGetLastError();
+    { std::lock_guard<std::mutex> lk(g_spareMtx); arena_of(device)->release_spares(); }
+    e = hipMalloc(d, bytes ? bytes : 1);
+  }
+  if (e != hipSuccess) { *d = nullptr; return mi355::set_error(e, "hipMalloc"); }
   return 0;
 }
 int mi355_malloc(int device, size_t bytes, void** d) { HIP_TRY(hipSetDevice(device)); HIP_TRY(hipMalloc(d, bytes ? bytes : 1)); return 0; }

@@ -142,7 +142,7 @@ struct Buffer : RefCounted {
       hip_check(hipSetDevice(device->gpu), "hipSetDevice");
       if (!dev) {
         device->memoryMonitor((ssize_t)bytes, false);
-        if (hipMalloc((void**)&dev, bytes + 16) != hipSuccess) { dev = nullptr; device->memoryMonitor(-(ssize_t)bytes, true); THROW(RTC_ERROR_OUT_OF_MEMORY, "hipMalloc(geometry buffer)"); }
+        if (mi355_malloc_retry(device->gpu, bytes + 16, (void**)&dev) != 0) { dev = nullptr; device->memoryMonitor(-(ssize_t)bytes, true); THROW(RTC_ERROR_OUT_OF_MEMORY, "hipMalloc(geometry buffer)"); }
         ownsDev = true;
       }
       if (bytes) hip_check(hipMemcpy(dev, host, bytes, hipMemcpyHostToDevice), "hipMemcpy(geometry buffer)");
@@ -154,7 +154,7 @@ struct Buffer : RefCounted {
       hip_check(hipSetDevice(g), "hipSetDevice");
       if (!peers[k]) {
         device->memoryMonitor((ssize_t)bytes, false);
-        if (hipMalloc((void**)&peers[k], bytes + 16) != hipSuccess) { peers[k] = nullptr; device->memoryMonitor(-(ssize_t)bytes, true); THROW(RTC_ERROR_OUT_OF_MEMORY, "hipMalloc(geometry buffer replica)"); }
+        if (mi355_malloc_retry(g, bytes + 16, (void**)&peers[k]) != 0) { peers[k] = nullptr; device->memoryMonitor(-(ssize_t)bytes, true); THROW(RTC_ERROR_OUT_OF_MEMORY, "hipMalloc(geometry buffer replica)"); }
       }
       if (!bytes) continue;
       if (sharedDevMem) hip_check(hipMemcpyPeer(peers[k], g, dev, device->gpu, bytes), "hipMemcpyPeer(geometry buffer)");
@@ -227,6 +227,11 @@ struct Geometry : RefCounted {
   }
 };
 
+// Ray staging is kept per calling thread (Device::threadToken()).  The workers a sharded host query starts for replicas 1 .. N-1 are fresh threads every call:
+// keyed by their own thread-local address every call could leave another staging buffer behind.  They carry the APPLICATION thread's key instead.
+static thread_local size_t t_stagingKey = 0;
+static inline size_t staging_key() { return t_stagingKey ? t_stagingKey : Device::threadToken(); }
+
 // What a scene keeps on ONE GPU.  A device over N GPUs ("gpus=N") commits N bit-identical replicas (the build is deterministic) and shards ray batches over them.
 struct Replica {
   int gpu = 0;
@@ -245,7 +250,7 @@ struct Replica {
   // from and writes the hit to a pinned, device-mapped buffer of the calling thread: one launch and one wait.
   char* stage_host(char** devAddr) {
     std::lock_guard<std::mutex> lk(mtx);
-    Staging& s = staging[Device::threadToken()];
+    Staging& s = staging[staging_key()];
     if (!s.h) {
       hip_check(hipSetDevice(gpu), "hipSetDevice");
       void* h = nullptr; void* d = nullptr;
@@ -259,13 +264,13 @@ struct Replica {
   hipStream_t shardStream = nullptr; hipEvent_t shardIn = nullptr, shardOut = nullptr;   // device-array queries sharded over the replicas (sharded_device_query)
   char* stage(size_t bytes) {
     std::lock_guard<std::mutex> lk(mtx);
-    Staging& s = staging[Device::threadToken()];
+    Staging& s = staging[staging_key()];
     if (s.cap < bytes) {
       hip_check(hipSetDevice(gpu), "hipSetDevice");
       if (s.d) hipFree(s.d);
       s.cap = bytes < 4096 ? 4096 : bytes + bytes / 4;
       s.d = nullptr;
-      hip_check(hipMalloc((void**)&s.d, s.cap), "hipMalloc(ray staging)");
+      core_check(mi355_malloc_retry(gpu, s.cap, (void**)&s.d), "hipMalloc(ray staging)");
     }
     return s.d;
   }
@@ -288,7 +293,8 @@ template <typename F> static void for_each_replica(size_t n, F fn) {
   if (n == 1) { fn((size_t)0); return; }
   std::vector<std::exception_ptr> err(n);
   std::vector<std::thread> th;
-  for (size_t k = 1; k < n; k++) th.emplace_back([&, k]() { try { fn(k); } catch (...) { err[k] = std::current_exception(); } });
+  const size_t callerKey = staging_key();
+  for (size_t k = 1; k < n; k++) th.emplace_back([&, k, callerKey]() { t_stagingKey = callerKey; try { fn(k); } catch (...) { err[k] = std::current_exception(); } });
   try { fn((size_t)0); } catch (...) { err[0] = std::current_exception(); }
   for (auto& t : th) t.join();
   for (size_t k = 0; k < n; k++) if (err[k]) std::rethrow_exception(err[k]);

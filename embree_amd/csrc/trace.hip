@@ -1130,7 +1130,7 @@ static int launch_trace_coherent(Bvh* b, void* d_rays, uint32_t count, size_t st
     if (sc->deferCap < need) {                                  // (stream order keeps earlier launches' use of the old list apart: wait for them before it goes)
       if (sc->defer) { HIP_TRY(hipStreamSynchronize(s)); HIP_TRY(hipFree(sc->defer)); sc->defer = nullptr; sc->deferCap = 0; }
       const size_t cap = need < 65536 ? 65536 : need + need / 4;
-      HIP_TRY(hipMalloc((void**)&sc->defer, cap)); sc->deferCap = cap;
+      { const int rc = mi355_malloc_retry(b->device, cap, (void**)&sc->defer); if (rc) return rc; } sc->deferCap = cap;
     }
     defer = sc->defer;
     HIP_TRY(hipMemsetAsync(defer, 0, sizeof(uint32_t), s));
@@ -1169,7 +1169,7 @@ static int launch_packets(Bvh* b, const int* d_valid, void* d_pk, uint32_t K, ui
     if (sc->pktCap < total * rec) {
       if (sc->pkt) { HIP_TRY(hipStreamSynchronize(s)); HIP_TRY(hipFree(sc->pkt)); sc->pkt = nullptr; sc->pktCap = 0; }
       const size_t cap = total * rec < 65536 ? 65536 : total * rec;
-      HIP_TRY(hipMalloc(&sc->pkt, cap)); sc->pktCap = cap;
+      { const int rc = mi355_malloc_retry(b->device, cap, &sc->pkt); if (rc) return rc; } sc->pktCap = cap;
     }
     aos = (char*)sc->pkt; }
   PacketArgs p{d_valid, (char*)d_pk, K, n, pstride, aos};

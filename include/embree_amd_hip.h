@@ -124,6 +124,9 @@ MI355_API int mi355_bvh_refit(mi355_bvh_t bvh, const mi355_mesh* meshes, uint32_
    keeps its topology and is refitted over the new world boxes, the instance records get their new world2local; the object trees are not touched and nothing
    is concatenated again (the reference refits / rebuilds only the top level of its two-level scenes, kernels/bvh/bvh_refit.cpp, bvh_builder_twolevel.cpp).
    Returns 0, or MI355_REFIT_IMPOSSIBLE when the list is not a move of what the tree was built from (the tree is untouched: build again). */
+/* hipMalloc for everything this library and its host layer allocate next to the trees: on hipErrorOutOfMemory the node / triangle arrays of destroyed trees that
+   the build arena keeps for the next commit (up to 1 GiB, see mi355_release_build_scratch) are returned to the driver and the allocation is tried once more. */
+MI355_API int mi355_malloc_retry(int device, size_t bytes, void** d);
 MI355_API int mi355_bvh_refit_instanced(mi355_bvh_t bvh, const mi355_instance* instances, uint32_t num_instances, void* stream);
 /* Build scratch (prim refs, binary tree, work lists) is kept per device between commits, and so are the node / triangle arrays of up to four destroyed
    trees (the next commit of a similar size takes them over instead of paying hipFree + hipMalloc); this returns all of it to the driver. */
