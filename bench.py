@@ -711,7 +711,8 @@ def main():
                 "algorithmic_bytes_per_launch": int(alg_bytes),
                 "per_ray": {"nodes": round(st["nodes"] / M, 2), "node_step_simd_util": round(st["nodes"] / max(1, 64 * st["node_blocks"]), 3),
                             "tri_step_simd_util": round(st["tris"] / max(1, 64 * st["tri_blocks"]), 3),
-                            "triangles": round(st["tris"] / M, 2), "empty_node_visits": round(st["empty_nodes"] / M, 2), "bytes": round(alg_bytes / M, 1),
+                            "triangles": round(st["tris"] / M, 2), "empty_node_visits": round(st["empty_nodes"] / M, 2), "stale_node_visits": round(st["culled_groups"] / M, 2),
+                            "bytes": round(alg_bytes / M, 1),
                             "wave_iterations": int(st["wave_iters"]), "node_step_blocks": int(st["node_blocks"]), "tri_step_blocks": int(st["tri_blocks"]),
                             "handout_events": int(st["refill_events"]), "handout_clock_share": round(st["refill_clocks"] / max(1, st["loop_clocks"]), 4),
                             "node_step_clock_share": round(st["node_step_clocks"] / max(1, st["loop_clocks"]), 4)},
@@ -724,8 +725,9 @@ def main():
         acc = 5 * st["nodes"] + 3 * st["tris"] + M * 3 + (nhit * 4 if not shadow else nhit)
         roof["address_rate"] = {"lane_accesses_per_launch": int(acc), "per_ray": round(acc / M, 1), "achieved_G_per_s": round(acc * args.steps / elapsed / 1e9, 1),
                                 "peak_G_per_s": round(256 * 2.4, 1), "frac": round(acc * args.steps / elapsed / (256 * 2.4e9), 4),
-                                "what": "scattered lane-addresses per second over all launches in flight against 256 CUs x 1 address per clock x 2.4 GHz: the resource this kernel "
-                                        "saturates (an extra 4-, 8- or 16-byte load per triangle test costs the same 11-12 %; throughput follows 1 / accesses when the leaf size changes)"}
+                                "what": "scattered lane-addresses ((lane, 16-byte load) pairs) per second over all launches in flight against 256 CUs x 1 address per clock x 2.4 GHz. "
+                                        "Round 2 read this as the binding resource (an extra load per triangle test cost 11-12 %); round 4 removed 16 % of the pairs at +16 % VALU work "
+                                        "(two triangles per leaf record) and lost 8 %: the kernel follows VALU issue first (profiles/r04_pair_records.md)"}
         if pmc:
             # PMC counters are per LAUNCH (lone launches of the PMC run, from profiles/); the rates below are for the whole chip over the timed region:
             # counter x launches timed / elapsed

@@ -802,7 +802,8 @@ __global__ __launch_bounds__(64) void trace_packet_kernel(PacketTraceArgs a) {
   // 1.46 Grays/s).  Large batches are therefore traced in two launches: every 32nd packet first (part 1), then the rest (part 2) -- which looks at how
   // many packets of the sample gave up and, if that is more than a quarter, hands all of its packets to the per-lane kernel at once.
   // The decision must be the same for every block of the launch (the two modes split the packet index space differently): it is taken on a SNAPSHOT of the
-  // sample's count (deferCount[1], copied between the two launches), which no packet kernel writes -- the live count grows while part 2 runs.
+  // sample's count (deferCount[1], written by the LAST block of the sample launch, see the end of this kernel), which no block of part 2 writes -- the live
+  // count grows while part 2 runs.  (A 4-byte device-to-device copy between the two launches did the same and cost the Cornell box 40 % of its rate.)
   if (a.part == 2u && a.deferCount[1] > a.bailAbove) {
     // (64 packets per atomic: one word takes ~88 appends per microsecond, 15,000 single appends would cost more than the packets they save)
     for (uint32_t j0 = blockIdx.x * 64u;; j0 += gridDim.x * 64u) {
@@ -974,6 +975,9 @@ __global__ __launch_bounds__(64) void trace_packet_kernel(PacketTraceArgs a) {
       }
     }
   }
+  if (a.part == 1u && lane == 0u) {                              // the sample's verdict, frozen by the last block to leave (its appends above returned: they are performed)
+    if (atomicAdd(a.deferCount + 2, 1u) == gridDim.x - 1u) { a.deferCount[1] = atomicAdd(a.deferCount, 0u); atomicExch(a.deferCount + 2, 0u); }
+  }
 }
 
 // ---- packet adaptor: SoA RTCRayHitK / RTCRayK <-> the AoS records the trace kernels consume ----
@@ -1133,7 +1137,7 @@ static int launch_trace_coherent(Bvh* b, void* d_rays, uint32_t count, size_t st
       { const int rc = mi355_malloc_retry(b->device, cap, (void**)&sc->defer); if (rc) return rc; } sc->deferCap = cap;
     }
     defer = sc->defer;
-    HIP_TRY(hipMemsetAsync(defer, 0, sizeof(uint32_t), s));
+    HIP_TRY(hipMemsetAsync(defer, 0, 3 * sizeof(uint32_t), s));   // [0] packets that gave up, [1] the sample's count as part 2 sees it, [2] blocks of the sample launch that have left
     PacketTraceArgs a;
     a.nodes = (const uint4*)b->d_nodes; a.tris = (const float4*)b->d_tris; a.hasRoot = b->root != MI355_EMPTY_REF ? 1u : 0u;
     a.rays = (char*)d_rays; a.count = count; a.stride = (uint32_t)stride; a.deferCount = defer; a.deferList = defer + 64; a.status = sc->statusDev; a.rules = (const uint4*)b->d_rules;
@@ -1144,7 +1148,6 @@ static int launch_trace_coherent(Bvh* b, void* d_rays, uint32_t count, size_t st
       const uint32_t nSample = (uint32_t)((packets + PACKET_SAMPLE - 1u) / PACKET_SAMPLE), nRest = (uint32_t)packets - nSample;
       a.part = 1u; a.bailAbove = 0xFFFFFFFFu;
       hipLaunchKernelGGL(fn, dim3(nSample < maxBlocks ? nSample : maxBlocks), dim3(64), 0, s, a);
-      HIP_TRY(hipMemcpyAsync(defer + 1, defer, sizeof(uint32_t), hipMemcpyDeviceToDevice, s));   // the sample's verdict, frozen (words 1..63 of the area are free)
       a.part = 2u; a.bailAbove = nSample / 4u;
       hipLaunchKernelGGL(fn, dim3(nRest < maxBlocks ? nRest : maxBlocks), dim3(64), 0, s, a);
     } else {
