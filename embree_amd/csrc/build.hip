@@ -145,7 +145,10 @@ TraceScratch* Bvh::scratch_for(hipStream_t s) {
   if (it != scratch.end()) return &it->second;
   TraceScratch sc;
   if (hipMalloc((void**)&sc.counter, 4096) != hipSuccess) return nullptr;
-  if (hipMemset(sc.counter, 0, 4096) != hipSuccess) return nullptr;   // the ray cursors start at zero; every launch leaves them at zero (trace.hip, wave_exit)
+  // the ray cursors start at zero and every launch leaves them at zero (trace.hip, wave_exit).  Zeroed ON THE STREAM the scratch belongs to: a hipMemset goes to
+  // the null stream, which a non-blocking stream does not wait for -- the first launch could start on recycled memory, or be zeroed half way (rays skipped in the
+  // launch after it: found as an intermittent idempotence failure at full size)
+  if (hipMemsetAsync(sc.counter, 0, 4096, s) != hipSuccess) return nullptr;
   if (hipMalloc(&sc.spill, trace_spill_bytes(numCUs, info.depth)) != hipSuccess) return nullptr;
   if (hipMalloc((void**)&sc.stats, 256) != hipSuccess) return nullptr;
   { void* h = nullptr; void* d = nullptr;
