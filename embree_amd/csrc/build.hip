@@ -269,7 +269,8 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
   const uint32_t tiles = (N + 255u) / 256u;
   HIP_TRY(tileCount.alloc((NC + 255u) / 256u));
   DevBuf<uint32_t> outlierCnt, outlierTile, outlierTotal;      // MEDIUM: grid cells every reference asks for (0 unless it is an outlier), their tile sums / offsets, the total
-  if (topSplits) { HIP_TRY(outlierCnt.alloc(N)); HIP_TRY(outlierTile.alloc(tiles)); HIP_TRY(outlierTotal.alloc(1)); }
+  DevBuf<OutlierWork> outlierWork;                            // ... the outliers themselves (every one asks for >= 2 cells: at most half the reserve)
+  if (topSplits) { HIP_TRY(outlierCnt.alloc(N)); HIP_TRY(outlierTile.alloc(tiles)); HIP_TRY(outlierTotal.alloc(1)); HIP_TRY(outlierWork.alloc((NC - N) / 2u + 16u)); }
   DevBuf<uint32_t> chunkCnt; DevBuf<uint2> chunkBase;          // per chunk of a level: its bin counts, then its places in the two children (top_bin -> top_split -> top_partition)
   HIP_TRY(chunkCnt.alloc((size_t)maxChunks * 3u * NBINS)); HIP_TRY(chunkBase.alloc(maxChunks));
   DevBuf<SegX> segx0, segx1; DevBuf<uint32_t> sbins;            // spatial-split builds: extended ranges of the top phase's sets, their spatial bins
@@ -279,7 +280,7 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
   struct EvGuard { hipEvent_t a, b; ~EvGuard() { hipEventDestroy(a); hipEventDestroy(b); } } evg{ev0, ev1};
   if (useGraph) {
     HIP_TRY(hipStreamSynchronize(st));                         // (the geometry table above is in place before anything is captured)
-    const void* ptrs[] = {dGeoms.p, bufA.p, bufB.p, finalIds.p, bnodes.p, segs0.p, segs1.p, bins.p, chunks.p, small.p, ctr.p, w0.p, w1.p, wnodes.p, outIds.p, plans.p, itemCnt.p, groupSum.p, tileCount.p, chunkCnt.p, chunkBase.p, segx0.p, segx1.p, sbins.p, outlierCnt.p, outlierTile.p, outlierTotal.p, (const void*)st};
+    const void* ptrs[] = {dGeoms.p, bufA.p, bufB.p, finalIds.p, bnodes.p, segs0.p, segs1.p, bins.p, chunks.p, small.p, ctr.p, w0.p, w1.p, wnodes.p, outIds.p, plans.p, itemCnt.p, groupSum.p, tileCount.p, chunkCnt.p, chunkBase.p, segx0.p, segx1.p, sbins.p, outlierCnt.p, outlierTile.p, outlierTotal.p, outlierWork.p, (const void*)st};
     std::vector<uint64_t> key; for (const void* q : ptrs) key.push_back((uint64_t)(uintptr_t)q);
     uint32_t pw[sizeof(Params) / 4]; memcpy(pw, &prm, sizeof(prm)); for (uint32_t w : pw) key.push_back(w);
     key.push_back(N); key.push_back(gd.size()); key.push_back(bp->robust); key.push_back(spatialMin); key.push_back(NC); { uint32_t w; memcpy(&w, &topSplitRel, 4); key.push_back(w); memcpy(&w, &topSplitCell, 4); key.push_back(w); } key.push_back(topSplits ? 1u : 0u); key.push_back(learned ? (arena->learnedTop << 8) | arena->learnedWide : 0u);
@@ -307,7 +308,9 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
       LAUNCH(outlier_area, dim3(ab), dim3(256), 0, st, bufA.p, N, ctr.p);
       LAUNCH(outlier_mark, dim3(tiles), dim3(256), 0, st, bufA.p, N, ctr.p, topSplitRel, topSplitCell, outlierCnt.p, outlierTile.p);
       LAUNCH(presplit_scan, dim3(1), dim3(1024), 0, st, outlierTile.p, tiles, outlierTotal.p);
-      LAUNCH(outlier_emit, dim3(tiles), dim3(256), 0, st, bufA.p, N, NC - N, dGeoms.p, outlierCnt.p, outlierTile.p, outlierTotal.p, ctr.p, topSplitRel, topSplitCell);
+      LAUNCH(outlier_emit, dim3(tiles), dim3(256), 0, st, bufA.p, N, NC - N, outlierCnt.p, outlierTile.p, outlierTotal.p, ctr.p, outlierWork.p);
+      LAUNCH(outlier_clip, dim3(1024), dim3(256), 0, st, bufA.p, NC - N, dGeoms.p, outlierTotal.p, ctr.p, outlierWork.p, topSplitRel, topSplitCell);
+      LAUNCH(outlier_retire, dim3(16), dim3(256), 0, st, bufA.p, NC - N, outlierTotal.p, (const Counters*)ctr.p, outlierWork.p);
     }
     // invalid triangles (and the holes of the outlier grid) are squeezed out on the device, if there are any; then the root
     LAUNCH(compact_count, dim3(ctiles), dim3(256), 0, st, bufA.p, NC, tileCount.p, ctr.p, N);

@@ -53,6 +53,7 @@ struct Counters {
   uint32_t compactFrom;                           // stable compaction: first position that moves (everything before the first hole stays where it is)
   uint32_t outlierCells, outlierPieces, outlierValid, outlierSkip;   // ... the places reserved for their pieces behind the references, the pieces that exist, the valid references counted, 1 = too many
   uint32_t emitBlocks;                            // top_emit: workgroups that are done with the level (the last one moves the work lists on)
+  unsigned long long outlierWork;                 // outlier_emit -> outlier_clip: outliers listed << 32 | 256-cell chunks handed out so far (ONE atomic: list order = chunk order)
   uint32_t padC[2];
   uint32_t lvlStart[64];                          // first node of every level of the wide tree (numbering is breadth first): what a refit walks bottom-up
 };

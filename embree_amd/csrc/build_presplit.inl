@@ -273,31 +273,51 @@ __device__ int clip_halfspace(float (*p)[3], int n, int axis, float pos, bool ke
   for (int i = 0; i < m; i++) for (int d = 0; d < 3; d++) p[i][d] = q[i][d];
   return m;
 }
-__global__ __launch_bounds__(256) void outlier_emit(PrimRef* prims, uint32_t n, uint32_t cap, const GeomDesc* geoms, const uint32_t* cnt, const uint32_t* tileOfs, const uint32_t* total,
-                                                    Counters* ctr, float minRel, float cellFrac) {
-  __shared__ uint32_t s_cnt[256], s_scan[256], s_pieces, s_holes, s_cut;
+// outlier_emit lists the outliers of its tile -- {reference, first place of its pieces, cells} -- and retires the originals; outlier_clip does the clipping, one 256-cell chunk of
+// one outlier per workgroup pass.  (One kernel did both: the twelve room triangles of the crown stand-in sit in ONE tile, whose single workgroup then clipped 12 x 1024 cells
+// alone: 204 us of a 6.2 ms commit.)  Places come from the scans, so which workgroup clips what does not matter: rebuilds stay bit-identical.
+struct OutlierWork { uint32_t src, base, cells, chunk0; };
+__global__ __launch_bounds__(256) void outlier_emit(PrimRef* prims, uint32_t n, uint32_t cap, const uint32_t* cnt, const uint32_t* tileOfs, const uint32_t* total,
+                                                    Counters* ctr, OutlierWork* work) {
+  __shared__ uint32_t s_scan[256];
   const uint32_t tid = threadIdx.x, i = blockIdx.x * 256u + tid;
   const uint32_t tot = total[0];
   if (tot == 0u) return;
   if (tot > cap) { if (blockIdx.x == 0u && tid == 0u) ctr->outlierSkip = 1u; return; }          // too many / too large outliers for the reserve: nothing is cut
   if (blockIdx.x == 0u && tid == 0u) ctr->outlierCells = tot;
   const uint32_t c = i < n ? cnt[i] : 0u;
-  if (__syncthreads_or(c != 0u) == 0) return;                                                    // no outlier in this tile (all but a dozen of the 18,605 tiles of the crown stand-in: the scan below made this kernel 217 us)
-  s_cnt[tid] = c; s_scan[tid] = c;
-  if (tid == 0u) { s_pieces = 0u; s_holes = 0u; s_cut = 0u; }
+  if (__syncthreads_or(c != 0u) == 0) return;                                                    // no outlier in this tile (all but a dozen of the 18,605 tiles of the crown stand-in)
+  s_scan[tid] = c;
   __syncthreads();
   for (uint32_t o = 1; o < 256u; o <<= 1) { uint32_t x = 0; if (tid >= o) x = s_scan[tid - o]; __syncthreads(); s_scan[tid] += x; __syncthreads(); }
-  uint32_t pieces = 0u, holes = 0u;
-  for (uint32_t r_ = 0; r_ < 256u; r_++) {
-    const uint32_t cells = s_cnt[r_];
-    if (cells == 0u) continue;                                                                   // (block-uniform)
-    const uint32_t src = blockIdx.x * 256u + r_, base = n + tileOfs[blockIdx.x] + s_scan[r_] - cells;
-    const PrimRef ref = load_prim(prims + src);
+  if (c != 0u) {
+    const uint32_t chunks = (c + 255u) / 256u;
+    const unsigned long long w = atomicAdd(&ctr->outlierWork, (1ull << 32) | chunks);
+    OutlierWork ow; ow.src = i; ow.base = n + tileOfs[blockIdx.x] + s_scan[tid] - c; ow.cells = c; ow.chunk0 = (uint32_t)w;
+    work[(uint32_t)(w >> 32)] = ow;
+  }
+}
+__global__ __launch_bounds__(256) void outlier_clip(PrimRef* prims, uint32_t cap, const GeomDesc* geoms, const uint32_t* total, Counters* ctr, const OutlierWork* work,
+                                                    float minRel, float cellFrac) {
+  __shared__ uint32_t s_pieces, s_holes;
+  const uint32_t tid = threadIdx.x;
+  const uint32_t tot = total[0];
+  if (tot == 0u || tot > cap) return;
+  const unsigned long long w = ctr->outlierWork;                                                 // (final: outlier_emit is over)
+  const uint32_t numWork = (uint32_t)(w >> 32), numChunks = (uint32_t)w;
+  if (tid == 0u) { s_pieces = 0u; s_holes = 0u; }
+  __syncthreads();
+  uint32_t pieces = 0u, holes = 0u, cut = 0u;
+  for (uint32_t ch = blockIdx.x; ch < numChunks; ch += gridDim.x) {
+    uint32_t lo_ = 0u, hi_ = numWork;                                                            // the outlier this chunk belongs to: the last one with chunk0 <= ch (the list is in chunk order)
+    while (hi_ - lo_ > 1u) { const uint32_t mid = (lo_ + hi_) >> 1; if (work[mid].chunk0 <= ch) lo_ = mid; else hi_ = mid; }
+    const OutlierWork ow = work[lo_];
+    const PrimRef ref = load_prim(prims + ow.src);                                               // (its geometry word is not touched before the end of this kernel)
     uint32_t nc[3]; float cell[3];
     outlier_cells(ref, ctr, minRel, cellFrac, nc, cell);
     float v[3][3]; load_tri(geoms, ref, v);
-    __syncthreads();                                                                             // (everybody has read the reference before thread 0 retires it below)
-    for (uint32_t k = tid; k < cells; k += 256u) {
+    const uint32_t k = (ch - ow.chunk0) * 256u + tid;
+    if (k < ow.cells) {
       const uint32_t cx = k % nc[0], cy = (k / nc[0]) % nc[1], cz = k / (nc[0] * nc[1]);
       float lo[3], hi[3];
       const uint32_t ci[3] = {cx, cy, cz};
@@ -318,13 +338,23 @@ __global__ __launch_bounds__(256) void outlier_emit(PrimRef* prims, uint32_t n, 
         }
         pieces++;
       } else { o.geom = NIL; holes++; }                                                          // the triangle does not cross this cell: a hole, squeezed out by the compaction
-      store_prim(prims + base + k, o);
+      store_prim(prims + ow.base + k, o);
     }
-    if (tid == 0u) { PrimRef dead = ref; dead.geom = NIL; store_prim(prims + src, dead); atomicAdd(&s_cut, 1u); }   // the original goes: its pieces stand for it
+    if (tid == 0u && ch == ow.chunk0) cut++;                                                     // (counted once per outlier; the original is retired by outlier_retire)
   }
-  atomicAdd(&s_pieces, pieces); atomicAdd(&s_holes, holes);
+  if (pieces) atomicAdd(&s_pieces, pieces);
+  if (holes) atomicAdd(&s_holes, holes);
   __syncthreads();
-  if (tid == 0u) { atomicAdd(&ctr->outlierPieces, s_pieces); atomicAdd(&ctr->numOutliers, s_cut); atomicAdd(&ctr->numInvalid, s_holes + s_cut); }
+  if (tid == 0u && (s_pieces | s_holes | cut)) { atomicAdd(&ctr->outlierPieces, s_pieces); atomicAdd(&ctr->numOutliers, cut); atomicAdd(&ctr->numInvalid, s_holes + cut); }
+}
+// the originals go once every chunk has read them: their pieces stand for them
+__global__ __launch_bounds__(256) void outlier_retire(PrimRef* prims, uint32_t cap, const uint32_t* total, const Counters* ctr, const OutlierWork* work) {
+  const uint32_t tot = total[0];
+  if (tot == 0u || tot > cap) return;
+  const uint32_t numWork = (uint32_t)(ctr->outlierWork >> 32);
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < numWork; i += gridDim.x * 256u) {
+    PrimRef dead = load_prim(prims + work[i].src); dead.geom = NIL; store_prim(prims + work[i].src, dead);
+  }
 }
 __global__ void centroid_reset(Counters* ctr) {                 // the pieces' centres are not the triangles': the centroid box is measured again (centroid_bounds)
   if (threadIdx.x == 0u && blockIdx.x == 0u && ctr->outlierPieces != 0u) for (int k = 6; k < 12; k++) ctr->bounds[k] = k < 9 ? ENC_POS_INF : ENC_NEG_INF;
