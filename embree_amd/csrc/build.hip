@@ -68,7 +68,7 @@ struct Arena {
   // What the last one-round-trip commit of a scene of this many triangles needed: its top-phase levels and the depth of its wide tree.  The next commit of the
   // same size (a scene re-committed every frame) enqueues those + 1 instead of the blind margins (levels N implies + 8, 16 wide levels): every level that does
   // not exist still costs its launches (~4.7 us each, ~35 of the 169 of a crown commit).  A commit that outgrows the learned counts forgets them and runs again.
-  uint32_t learnedN = 0, learnedTop = 0, learnedWide = 0;
+  uint32_t learnedN = 0, learnedTop = 0, learnedWide = 0, learnedChunked = 0, learnedLocalFirst = 0;
   void drop_graph() { if (graphExec) { hipGraphExecDestroy(graphExec); graphExec = nullptr; } graphKey.clear(); }
   void reset() { for (auto& b : blocks) b.used = 0; }
   hipError_t take(size_t bytes, void** out) {
@@ -283,7 +283,7 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
     const void* ptrs[] = {dGeoms.p, bufA.p, bufB.p, finalIds.p, bnodes.p, segs0.p, segs1.p, bins.p, chunks.p, small.p, ctr.p, w0.p, w1.p, wnodes.p, outIds.p, plans.p, itemCnt.p, groupSum.p, tileCount.p, chunkCnt.p, chunkBase.p, segx0.p, segx1.p, sbins.p, outlierCnt.p, outlierTile.p, outlierTotal.p, outlierWork.p, (const void*)st};
     std::vector<uint64_t> key; for (const void* q : ptrs) key.push_back((uint64_t)(uintptr_t)q);
     uint32_t pw[sizeof(Params) / 4]; memcpy(pw, &prm, sizeof(prm)); for (uint32_t w : pw) key.push_back(w);
-    key.push_back(N); key.push_back(gd.size()); key.push_back(bp->robust); key.push_back(spatialMin); key.push_back(NC); { uint32_t w; memcpy(&w, &topSplitRel, 4); key.push_back(w); memcpy(&w, &topSplitCell, 4); key.push_back(w); } key.push_back(topSplits ? 1u : 0u); key.push_back(learned ? (arena->learnedTop << 8) | arena->learnedWide : 0u);
+    key.push_back(N); key.push_back(gd.size()); key.push_back(bp->robust); key.push_back(spatialMin); key.push_back(NC); { uint32_t w; memcpy(&w, &topSplitRel, 4); key.push_back(w); memcpy(&w, &topSplitCell, 4); key.push_back(w); } key.push_back(topSplits ? 1u : 0u); key.push_back(learned ? (arena->learnedTop << 8) | arena->learnedWide : 0u); key.push_back(learned ? (arena->learnedChunked << 8) | (arena->learnedLocalFirst & 0xFFu) : 0u);
     if (arena->graphExec && arena->graphKey == key) replay = true;
     else {
       arena->drop_graph(); arena->graphKey = key;
@@ -419,9 +419,21 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
     PrimRef* src = (level & 1u) ? bufB.p : bufA.p; PrimRef* dst = (level & 1u) ? bufA.p : bufB.p;
     const uint32_t segBound = level < 31u && (1u << level) < maxSegs ? (1u << level) : maxSegs;
     const uint32_t chunkBound = (spatial ? NC : n) / CHUNK + segBound + 1u;
-    LAUNCH(top_setup, dim3(segBound), dim3(256), 0, st, cur, bins.p, chunks.p, ctr.p);
-    LAUNCH(top_bin, dim3(chunkBound), dim3(256), 0, st, cur, chunks.p, src, bins.p, ctr.p, chunkCnt.p);
-    LAUNCH(top_split, dim3(segBound), dim3(64), 0, st, cur, bins.p, bnodes.p, ctr.p, prm, level >= 96u ? 1u : 0u, xcur, (const uint32_t*)chunkCnt.p, chunkBase.p);
+    // sets of at most CHUNK references are one workgroup's (top_local); the others go through the chunked path.  A commit that knows the last commit of
+    // this size enqueues only what that one needed (+ a level of margin either way): the chunked path up to its last level with a large set, top_local
+    // from its first level with a small one.  A large set where no chunked path was enqueued raises overflow 3: the commit runs again, blind.
+    const bool local = !spatial && (!learned || level + 1u >= arena->learnedLocalFirst);
+    const bool chunked = !local || !learned || level <= arena->learnedChunked;
+    const uint32_t localMax = local ? CHUNK : 0u, dstBuf = (level & 1u) ? 0u : 1u, forceFallback = level >= 96u ? 1u : 0u;
+    if (!chunked) {
+      LAUNCH(top_local, dim3(segBound), dim3(256), 0, st, (const Seg*)cur, (const PrimRef*)src, dst, bnodes.p, nxt, small.p, ctr.p, prm, dstBuf, maxSegs, maxSmall, forceFallback, level, 1u);
+      LAUNCH(top_emit, dim3((segBound + 255u) / 256u), dim3(256), 0, st, cur, bnodes.p, nxt, small.p, ctr.p, prm, dstBuf, maxSegs, maxSmall, (const SegX*)nullptr, (SegX*)nullptr, 0xFFFFFFFFu);   // (moves the work lists on)
+      Seg* t = cur; cur = nxt; nxt = t; level++;
+      return;
+    }
+    LAUNCH(top_setup, dim3(segBound), dim3(256), 0, st, cur, bins.p, chunks.p, ctr.p, localMax, level);
+    LAUNCH(top_bin, dim3(chunkBound), dim3(256), 0, st, cur, chunks.p, src, bins.p, ctr.p, chunkCnt.p, maxChunks);
+    LAUNCH(top_split, dim3(segBound), dim3(64), 0, st, cur, bins.p, bnodes.p, ctr.p, prm, forceFallback, xcur, (const uint32_t*)chunkCnt.p, chunkBase.p, localMax, maxChunks);
     if (spatial) {                                          // sets whose object split leaves overlapping children try a spatial split
       LAUNCH(spatial_decide, dim3(segBound), dim3(128), 0, st, cur, xcur, bnodes.p, sbins.p, ctr.p, spatialMin);
       LAUNCH(spatial_bin, dim3(chunkBound), dim3(256), 0, st, cur, xcur, chunks.p, src, dGeoms.p, sbins.p, ctr.p);
@@ -429,8 +441,9 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
     }
     LAUNCH(top_partition, dim3(chunkBound), dim3(256), 0, st, cur, chunks.p, src, dst, ctr.p, (const uint2*)chunkBase.p);
     if (spatial) LAUNCH(spatial_partition, dim3(chunkBound), dim3(256), 0, st, cur, xcur, chunks.p, src, dst, dGeoms.p, ctr.p);
+    if (local) LAUNCH(top_local, dim3(segBound), dim3(256), 0, st, (const Seg*)cur, (const PrimRef*)src, dst, bnodes.p, nxt, small.p, ctr.p, prm, dstBuf, maxSegs, maxSmall, forceFallback, level, 0u);
     LAUNCH(top_emit, dim3((segBound + 255u) / 256u), dim3(256), 0, st, cur, bnodes.p, nxt, small.p, ctr.p, prm,
-           (level & 1u) ? 0u : 1u, maxSegs, maxSmall, (const SegX*)xcur, xnxt);
+           dstBuf, maxSegs, maxSmall, (const SegX*)xcur, xnxt, localMax);
     Seg* t = cur; cur = nxt; nxt = t; SegX* tx = xcur; xcur = xnxt; xnxt = tx; level++;
   };
   if (numSegs && sahBuild) {
@@ -500,6 +513,7 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
     if (!bvh->d_tris) return set_error(hipErrorOutOfMemory, "leaf record array");
     LAUNCH(tri_records, dim3((NC + 255u) / 256u), dim3(256), 0, st, outIds.p, NC, dGeoms.p, (TriRec*)bvh->d_tris, bp->robust ? 1u : 0u, (const Counters*)ctr.p);
     SYNC_READ(h);                                                // the ONE round trip of the commit
+    if (h.overflow == 3u && learned) { arena->learnedN = 0; arena->learnedTop = arena->learnedWide = 0; return -1001; }   // a large set below the last level the chunked path was enqueued for
     if (h.overflow) return set_error(hipErrorOutOfMemory, "work list overflow (pathological input)");
     if (h.numSegs != 0u) {                                       // the top phase needed more levels than were enqueued: what came after it worked on an unfinished tree
       if (learned) { arena->learnedN = 0; arena->learnedTop = arena->learnedWide = 0; return -1001; }   // (counts learned from another scene of this size: again, with the blind margins)
@@ -518,7 +532,7 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
       if (h.overflow) return set_error(hipErrorOutOfMemory, "wide node pool overflow");
       redoLeaves = true;
     }
-    arena->learnedN = N; arena->learnedTop = h.topLevels; arena->learnedWide = h.wideDepth;   // (a tree deeper than the wide levels enqueued is finished below either way)
+    arena->learnedN = N; arena->learnedTop = h.topLevels; arena->learnedWide = h.wideDepth; arena->learnedChunked = h.chunkedLevels; arena->learnedLocalFirst = h.localFirst < 255u ? h.localFirst : 255u;   // (a tree deeper than the wide levels enqueued is finished below either way)
     if (redoLeaves) LAUNCH(tri_records, dim3((NC + 255u) / 256u), dim3(256), 0, st, outIds.p, NC, dGeoms.p, (TriRec*)bvh->d_tris, bp->robust ? 1u : 0u, (const Counters*)ctr.p);
   } else {
     for (uint32_t i = 0; i < 8u; i++) enqueue_wide_level();
@@ -534,6 +548,9 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
     LAUNCH(tri_records, dim3((n + 255u) / 256u), dim3(256), 0, st, outIds.p, n, dGeoms.p, (TriRec*)bvh->d_tris, bp->robust ? 1u : 0u, (const Counters*)nullptr);
   }
   info.num_triangles = n;
+#ifdef SM_TIME
+  fprintf(stderr, "[mi355 build] small_build wave Mcycles: bin %.1f, price %.1f, partition %.1f, micro %.1f\n", h.smTime[0] * 1e-6, h.smTime[1] * 1e-6, h.smTime[2] * 1e-6, h.smTime[3] * 1e-6);
+#endif
 #ifdef SM_STATS
   fprintf(stderr, "[mi355 build] micro level passes %u, lanes in use %.1f of 64\n", h.padC[0], h.padC[0] ? (double)h.padC[1] / h.padC[0] : 0.0);
 #endif

@@ -174,6 +174,47 @@ __device__ __forceinline__ void bins_add_rows(uint32_t* bins, const Mapping& m, 
   }
 }
 
+// Private copies of the bins instead of combining lanes in registers: lane l of a wave bins into copy l mod BIN_COPIES, so consecutive references -- which share a bin more
+// often than not -- do not meet on a word, and an atomic instruction of 64 lanes finds at least BIN_COPIES different words on as many banks
+// (the copies are an odd number of words apart).  10-14 cycles per instruction (profiles/r03_lds_atomics.md) with 16 copies, a little more with 8, which let more workgroups share a CU (measured: 8 is faster) and ~25 VALU instructions per
+// reference and axis, where the row aggregation of bins_add_rows spends ~110 VALU instructions to get the same-word lanes down to two per row: the kernels
+// that bin whole chunks were bound by exactly those (top_bin: 70 us per pass over the crown stand-in = 4.76 M references).  The copies are folded once per
+// workgroup; min / max / count do not care in which order.
+#ifndef MI355_BIN_COPIES
+#define MI355_BIN_COPIES 8
+#endif
+constexpr uint32_t BIN_COPIES = MI355_BIN_COPIES, COPY_STRIDE = BINS_WORDS + 1u;
+__device__ __forceinline__ void bins_clear_copies(uint32_t* bins, uint32_t tid, uint32_t nthreads) {
+  for (uint32_t w = tid; w < (uint32_t)BINS_WORDS; w += nthreads) {
+    const uint32_t k = w % BINW, v = k < 3 ? ENC_POS_INF : (k < 6 ? ENC_NEG_INF : 0u);
+#pragma unroll
+    for (uint32_t c = 0; c < BIN_COPIES; c++) bins[c * COPY_STRIDE + w] = v;
+  }
+}
+__device__ __forceinline__ void bins_add_copies(uint32_t* bins, const Mapping& m, const PrimRef& p, bool valid, uint32_t lane) {
+  if (!valid) return;
+  uint32_t c[6];
+  for (int k = 0; k < 3; k++) { c[k] = enc(p.lo[k]); c[3 + k] = enc(p.hi[k]); }
+  uint32_t* mine = bins + (lane & (BIN_COPIES - 1u)) * COPY_STRIDE;
+#pragma unroll
+  for (int d = 0; d < 3; d++) {
+    const uint32_t b = (uint32_t)bin_clamped(p.lo[d] + p.hi[d], m.ofs[d], m.scale[d], m.nb);
+    uint32_t* e = mine + (d * NBINS + b) * BINW;
+    atomicMin(&e[0], c[0]); atomicMin(&e[1], c[1]); atomicMin(&e[2], c[2]);
+    atomicMax(&e[3], c[3]); atomicMax(&e[4], c[4]); atomicMax(&e[5], c[5]);
+    atomicAdd(&e[6], 1u);
+  }
+}
+// every word of copy 0 becomes the fold of its copies (the caller puts a barrier on either side)
+__device__ __forceinline__ void bins_fold_copies(uint32_t* bins, uint32_t tid, uint32_t nthreads) {
+  for (uint32_t w = tid; w < (uint32_t)BINS_WORDS; w += nthreads) {
+    const uint32_t k = w % BINW; uint32_t v = bins[w];
+#pragma unroll
+    for (uint32_t c = 1; c < BIN_COPIES; c++) { const uint32_t x = bins[c * COPY_STRIDE + w]; v = k < 3 ? min(v, x) : (k < 6 ? max(v, x) : v + x); }
+    bins[w] = v;
+  }
+}
+
 struct SplitResult { float sah; int dim, pos; uint32_t nL; float llo[3], lhi[3], rlo[3], rhi[3]; };
 
 // BinInfoT::best (heuristic_binning.h:339-386) by ONE wavefront as two scans: lanes 0-31 hold the 32 bins of one axis, lanes

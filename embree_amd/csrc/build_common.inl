@@ -54,7 +54,9 @@ struct Counters {
   uint32_t outlierCells, outlierPieces, outlierValid, outlierSkip;   // ... the places reserved for their pieces behind the references, the pieces that exist, the valid references counted, 1 = too many
   uint32_t emitBlocks;                            // top_emit: workgroups that are done with the level (the last one moves the work lists on)
   unsigned long long outlierWork;                 // outlier_emit -> outlier_clip: outliers listed << 32 | 256-cell chunks handed out so far (ONE atomic: list order = chunk order)
+  uint32_t chunkedLevels, localFirst;             // top phase: levels that had a set of more than CHUNK references; the first level with a smaller one (top_local's) -- what the next commit enqueues
   uint32_t padC[2];
+  unsigned long long smTime[4];                   // -DSM_TIME: wave cycles small_build spent binning / pricing / partitioning / in the micro mode
   uint32_t lvlStart[64];                          // first node of every level of the wide tree (numbering is breadth first): what a refit walks bottom-up
 };
 struct Params { uint32_t shift, minLeaf, maxLeaf, small; float travCost, intCost; uint32_t quality, spatial; };

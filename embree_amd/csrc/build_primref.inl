@@ -65,7 +65,7 @@ __global__ void build_begin(Counters* ctr) {
   for (uint32_t i = t; i < sizeof(Counters) / 4u; i += blockDim.x) w[i] = 0u;
   __syncthreads();
   if (t < 12u) ctr->bounds[t] = (t % 6u < 3u) ? ENC_POS_INF : ENC_NEG_INF;
-  if (t == 0u) ctr->rootRef = MI355_EMPTY_REF;
+  if (t == 0u) { ctr->rootRef = MI355_EMPTY_REF; ctr->localFirst = 0xFFFFFFFFu; }
 }
 
 // rare path: stable compaction of the valid PrimRefs (tile = 256 consecutive entries).  `ctr` != nullptr: the commit runs without a host round trip

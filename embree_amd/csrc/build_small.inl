@@ -290,6 +290,14 @@ __global__ __launch_bounds__(64) void small_build(const SmallEntry* entries, Pri
   uint32_t sp = 0;
   bool done = false;
   uint32_t iter = 0;
+#ifdef SM_TIME
+  unsigned long long tm[4] = {0, 0, 0, 0}, t0;
+#define SM_T0() t0 = __builtin_readcyclecounter()
+#define SM_T(k) do { const unsigned long long t1_ = __builtin_readcyclecounter(); tm[k] += t1_ - t0; t0 = t1_; } while (0)
+#else
+#define SM_T0()
+#define SM_T(k)
+#endif
   while (!done) {
   for (; iter < (1u << 20); iter++) {         // the cap is a safety net only: <= 2*small_threshold iterations are possible
     const uint32_t n = cur.end - cur.begin;
@@ -308,6 +316,7 @@ __global__ __launch_bounds__(64) void small_build(const SmallEntry* entries, Pri
       if (numRoots == MICRO_ROOTS) break;                        // (only with small_threshold > 1024)
       continue;
     }
+    SM_T0();
     const Mapping m = make_mapping(n, cur.cmin, cur.cmax);
     bins_clear(s_bins, lane, 64u);
     if (lane < 24) s_acc[lane / 12][lane % 12] = (lane % 6 < 3) ? ENC_POS_INF : ENC_NEG_INF;
@@ -322,8 +331,10 @@ __global__ __launch_bounds__(64) void small_build(const SmallEntry* entries, Pri
       runs_flush_wave(runs, s_bins, lane);
     }
     __syncthreads();
+    SM_T(0);
     sah_best_wave(s_bins, m, prm.shift, &s_res, lane);
     __syncthreads();
+    SM_T(1);
     const SplitResult r = s_res;
     const bool fallback = r.dim < 0;
     const uint32_t mid = fallback ? (cur.begin + cur.end) / 2u : cur.begin + r.nL;
@@ -388,11 +399,17 @@ __global__ __launch_bounds__(64) void small_build(const SmallEntry* entries, Pri
     sp++;
     cur = keep;
     __syncthreads();
+    SM_T(2);
   }
   if (iter >= (1u << 20)) done = true;
   __syncthreads();
+  SM_T0();
   if (W == 32u) micro_flush<32u>(s_R, s_key, s_roots, numRoots, bufA, bufB, bnodes, finalIds, ctr, prm, lane);
   else micro_flush<48u>(s_R, s_key, s_roots, numRoots, bufA, bufB, bnodes, finalIds, ctr, prm, lane);
   numRoots = 0;
+  SM_T(3);
   }
+#ifdef SM_TIME
+  if (lane == 0u) for (int k = 0; k < 4; k++) atomicAdd(&ctr->smTime[k], tm[k]);
+#endif
 }

@@ -1,12 +1,15 @@
 // build_top.inl -- K2: level-synchronous top phase.
 // Part of build.hip (included inside its anonymous namespace); see the header of build.hip for the pipeline.
 // ------------------------------------------------------------------------------------ K2 top phase
-__global__ __launch_bounds__(256) void top_setup(Seg* segs, uint32_t* bins, Chunk* chunks, Counters* ctr) {
+// localMax: sets of at most this many references are top_local's at this level (0: none are), the four kernels of the chunked path leave them alone
+__global__ __launch_bounds__(256) void top_setup(Seg* segs, uint32_t* bins, Chunk* chunks, Counters* ctr, uint32_t localMax, uint32_t level) {
   __shared__ uint32_t s_base;
   const uint32_t s = blockIdx.x, tid = threadIdx.x;
   if (s >= ctr->numSegs) return;                                // the grid is an upper bound (2^level segments at most)
   Seg* sg = segs + s;
   const uint32_t begin = sg->begin, end = sg->end, n = end - begin;
+  if (n <= localMax) return;
+  if (tid == 0u) ctr->chunkedLevels = level + 1u;               // (every writer of a level writes the same value; levels are launches, in order)
   bins_clear(bins + (size_t)s * BINS_WORDS, tid, 256u);
   const uint32_t nch = (n + CHUNK - 1u) / CHUNK;
   if (tid == 0) {
@@ -23,27 +26,30 @@ __global__ __launch_bounds__(256) void top_setup(Seg* segs, uint32_t* bins, Chun
   }
 }
 
-// chunkCnt: per chunk, how many of its references fell into every bin (3 x NBINS words): top_split turns them into the chunk's places in the two children,
+// chunkCnt: per chunk, how many of its references fell into every bin and the bins before it (3 x NBINS words): top_split turns them into the chunk's places in the two children,
 // so that where a reference lands does not depend on which chunk reached a cursor first (top_partition)
-__global__ __launch_bounds__(256) void top_bin(const Seg* segs, const Chunk* chunks, const PrimRef* src, uint32_t* bins, const Counters* ctr, uint32_t* chunkCnt) {
-  __shared__ uint32_t s_bins[BINS_WORDS];
+__global__ __launch_bounds__(256) void top_bin(const Seg* segs, const Chunk* chunks, const PrimRef* src, uint32_t* bins, const Counters* ctr, uint32_t* chunkCnt, uint32_t chunkStride) {
+  __shared__ uint32_t s_bins[BIN_COPIES * COPY_STRIDE];
   const uint32_t tid = threadIdx.x;
   if (blockIdx.x >= ctr->numChunks) return;
   const Chunk ck = chunks[blockIdx.x];
   const Seg* sg = segs + ck.seg;
   Mapping m; for (int d = 0; d < 3; d++) { m.ofs[d] = sg->ofs[d]; m.scale[d] = sg->scale[d]; } m.nb = sg->nb;
-  bins_clear(s_bins, tid, 256u);
+  bins_clear_copies(s_bins, tid, 256u);
   __syncthreads();
-  {                                                             // each wave owns a contiguous quarter of the chunk (see BinRuns)
-    const uint32_t lane = tid & 63u, span = ck.begin + (tid >> 6) * (CHUNK / 4u), spanEnd = min(span + CHUNK / 4u, ck.end);
-    for (uint32_t i0 = span; i0 < spanEnd; i0 += 64u) {         // wave-uniform trip count
-      const uint32_t i = i0 + lane; const bool v = i < spanEnd;
-      PrimRef r{}; if (v) r = load_prim(src + i);
-      bins_add_rows(s_bins, m, r, v, lane);
-    }
+  {
+    const uint32_t lane = tid & 63u;
+#pragma unroll 2
+    for (uint32_t i = ck.begin + tid; i < ck.end; i += 256u) bins_add_copies(s_bins, m, load_prim(src + i), true, lane);
   }
   __syncthreads();
-  if (tid < 3u * (uint32_t)NBINS) chunkCnt[(size_t)blockIdx.x * (3u * NBINS) + tid] = s_bins[tid * BINW + 6];
+  bins_fold_copies(s_bins, tid, 256u);
+  __syncthreads();
+  if (tid < 3u * (uint32_t)NBINS) {                              // (running sums along every axis: top_split reads ONE word per chunk, "left of the plane")
+    const uint32_t b = tid % (uint32_t)NBINS; uint32_t sum = 0u;
+    for (uint32_t k = 0; k <= b; k++) sum += s_bins[(tid - b + k) * BINW + 6];
+    chunkCnt[(size_t)tid * chunkStride + blockIdx.x] = sum;     // [axis][bin][chunk]: what top_split reads of a set's chunks -- one (axis, bin) -- lies together
+  }
   uint32_t* g = bins + (size_t)ck.seg * BINS_WORDS;
   if (ck.begin == sg->begin && ck.end == sg->end) {             // the set's only chunk (every set of the lower levels): its bins ARE the set's bins, no atomics
     for (uint32_t w = tid; w < (uint32_t)BINS_WORDS; w += 256u) g[w] = s_bins[w];
@@ -62,12 +68,13 @@ __device__ __forceinline__ void segx_object_split(SegX* sx, uint32_t s, uint32_t
 __device__ __forceinline__ uint32_t segx_cap_left(const SegX* sx, uint32_t s);
 __device__ __forceinline__ void segx_child(SegX* nx, uint32_t k, uint32_t extEnd);
 __global__ __launch_bounds__(64) void top_split(Seg* segs, const uint32_t* bins, BNode* bnodes, Counters* ctr, Params prm, uint32_t forceFallback, SegX* sx,
-                                                const uint32_t* chunkCnt, uint2* chunkBase) {
+                                                const uint32_t* chunkCnt, uint2* chunkBase, uint32_t localMax, uint32_t chunkStride) {
   __shared__ SplitResult s_res;
   __shared__ uint32_t s_plan[4];                                // fallback, dim, pos, capacity of the left child
   const uint32_t s = blockIdx.x, lane = threadIdx.x;
   if (s >= ctr->numSegs) return;
   Seg* sg = segs + s;
+  if (sg->end - sg->begin <= localMax) return;
   Mapping m; for (int d = 0; d < 3; d++) { m.ofs[d] = sg->ofs[d]; m.scale[d] = sg->scale[d]; } m.nb = sg->nb;
   sah_best_wave(bins + (size_t)s * BINS_WORDS, m, prm.shift, &s_res, lane);
   __syncthreads();
@@ -100,14 +107,21 @@ __global__ __launch_bounds__(64) void top_split(Seg* segs, const uint32_t* bins,
   if (s_plan[0] == 0u) {
     const uint32_t begin = sg->begin, n = sg->end - begin, nch = (n + CHUNK - 1u) / CHUNK, c0 = sg->chunk0, dim = s_plan[1], pos = s_plan[2], capL = s_plan[3];
     uint32_t carry = 0u;
-    for (uint32_t cb = 0; cb < nch; cb += 64u) {                 // wave-uniform trip count
-      const uint32_t c = cb + lane;
-      uint32_t cntL = 0u;
-      if (c < nch) { const uint32_t* h = chunkCnt + (size_t)(c0 + c) * (3u * NBINS) + dim * NBINS; for (uint32_t b = 0; b < pos; b++) cntL += h[b]; }
-      uint32_t incl = cntL;
+    for (uint32_t cb = 0; cb < nch; cb += 512u) {                // wave-uniform trip count; eight consecutive chunks per lane: their loads are in flight together
+      uint32_t v[8], tot = 0u;
+#pragma unroll
+      for (uint32_t k = 0; k < 8u; k++) { const uint32_t c = cb + lane * 8u + k; v[k] = (c < nch && pos) ? chunkCnt[(size_t)(dim * NBINS + pos - 1u) * chunkStride + c0 + c] : 0u; }
+#pragma unroll
+      for (uint32_t k = 0; k < 8u; k++) tot += v[k];
+      uint32_t incl = tot;
       for (int o = 1; o < 64; o <<= 1) { const uint32_t u = (uint32_t)__shfl_up((int)incl, o, 64); if (lane >= (uint32_t)o) incl += u; }
-      const uint32_t exclL = carry + incl - cntL;
-      if (c < nch) chunkBase[c0 + c] = make_uint2(begin + exclL, begin + capL + (c * CHUNK - exclL));
+      uint32_t exclL = carry + incl - tot;
+#pragma unroll
+      for (uint32_t k = 0; k < 8u; k++) {
+        const uint32_t c = cb + lane * 8u + k;
+        if (c < nch) chunkBase[c0 + c] = make_uint2(begin + exclL, begin + capL + (c * CHUNK - exclL));
+        exclL += v[k];
+      }
       carry += (uint32_t)__shfl((int)incl, 63, 64);
     }
   }
@@ -180,10 +194,149 @@ __global__ __launch_bounds__(256) void top_partition(Seg* segs, const Chunk* chu
   }
 }
 
+// the end of a level: the last workgroup to get here makes the next level's work list the current one (was a launch of its own: 21 x 4.8 us per commit).
+// The counters the others advanced are read with an atomic: a plain load may be served from this XCD's L2, which does not see the other XCDs' atomics.
+__device__ __forceinline__ void top_level_end(Counters* ctr, uint32_t maxNext) {
+  __syncthreads();
+  if (threadIdx.x == 0u) {
+    __threadfence();
+    if (atomicAdd(&ctr->emitBlocks, 1u) == gridDim.x - 1u) {
+      const uint32_t nextSegs = atomicAdd(&ctr->numSegsNext, 0u);
+      if (ctr->numSegs) ctr->topLevels++;
+      if (nextSegs > maxNext) ctr->overflow = 1u;
+      ctr->numSegs = nextSegs < maxNext ? nextSegs : maxNext; ctr->numSegsNext = 0; ctr->numChunks = 0; ctr->emitBlocks = 0;
+    }
+  }
+}
+__device__ __forceinline__ void top_emit_child(uint32_t b, uint32_t e, uint32_t child, const float* cmin, const float* cmax, Seg* next, SmallEntry* small, Counters* ctr,
+                                               const Params& prm, uint32_t dstBuf, uint32_t maxNext, uint32_t maxSmall, SegX* nx, uint32_t childExtEnd) {
+  if (e - b <= prm.small) {
+    const uint32_t k = atomicAdd(&ctr->numSmall, 1u);
+    if (k >= maxSmall) { ctr->overflow = 1u; return; }
+    SmallEntry se; se.begin = b; se.end = e; se.bnode = child; se.buf = dstBuf;
+    for (int d = 0; d < 3; d++) { se.cmin[d] = cmin[d]; se.cmax[d] = cmax[d]; }
+    small[k] = se;
+  } else {
+    const uint32_t k = atomicAdd(&ctr->numSegsNext, 1u);
+    if (k >= maxNext) { ctr->overflow = 1u; return; }
+    Seg ns{}; ns.begin = b; ns.end = e; ns.bnode = child;
+    for (int d = 0; d < 3; d++) { ns.cmin[d] = cmin[d]; ns.cmax[d] = cmax[d]; }
+    next[k] = ns;
+    if (nx) segx_child(nx, k, childExtEnd);
+  }
+}
+
+// A set of at most CHUNK references is ONE workgroup's: it holds them in registers, bins them into LDS, one of its waves prices the planes, and it writes
+// them out partitioned -- one read and one write per level and one launch, where the chunked path below it needs two reads, the bins and the chunk counts
+// through memory, and five launches (the crown stand-in's last eight levels: 740 us -> see profiles/r04_commit_timeline_medium.txt).  The partition is
+// the same stable one (left and right keep their order), the bins are min / max / count: the tree does not depend on which path a set takes.
+// lastOfLevel: the chunked path was not enqueued at this level (the last commit of this size had no large set here): a large set now means the commit is repeated.
+// (The work lists are moved on by top_emit either way: every workgroup of this kernel arriving at a counter behind a fence cost 100 us per level.)
+#ifdef MI355_LOCAL_WAVES
+__attribute__((amdgpu_waves_per_eu(MI355_LOCAL_WAVES, MI355_LOCAL_WAVES)))
+#endif
+__global__ __launch_bounds__(256) void top_local(const Seg* segs, const PrimRef* src, PrimRef* dst, BNode* bnodes, Seg* next, SmallEntry* small, Counters* ctr,
+                                                 Params prm, uint32_t dstBuf, uint32_t maxNext, uint32_t maxSmall, uint32_t forceFallback, uint32_t level, uint32_t lastOfLevel) {
+  __shared__ uint32_t s_bins[BIN_COPIES * COPY_STRIDE];
+  __shared__ SplitResult s_res;
+  __shared__ uint32_t s_cnt[CHUNK_ROUNDS * 4][2], s_off[CHUNK_ROUNDS * 4][2], s_acc[2][12];
+  const uint32_t s = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const Seg* sg = segs + s;
+  const uint32_t numSegs = ctr->numSegs;
+  const uint32_t begin = s < numSegs ? sg->begin : 0u, end = s < numSegs ? sg->end : 0u, n = end - begin;
+  if (s < numSegs && n <= CHUNK) {                               // (workgroup-uniform)
+    if (tid == 0u) atomicMin(&ctr->localFirst, level);
+    float cmn[3], cmx[3]; for (int d = 0; d < 3; d++) { cmn[d] = sg->cmin[d]; cmx[d] = sg->cmax[d]; }
+    const Mapping m = make_mapping(n, cmn, cmx);
+    bins_clear_copies(s_bins, tid, 256u);
+    if (tid < 24u) s_acc[tid / 12u][tid % 12u] = (tid % 6u < 3u) ? ENC_POS_INF : ENC_NEG_INF;
+    __syncthreads();
+    PrimRef pr[CHUNK_ROUNDS];
+#pragma unroll
+    for (int r = 0; r < CHUNK_ROUNDS; r++) {
+      const uint32_t i = begin + (uint32_t)r * 256u + tid;
+      if (i - lane < end) {                                      // wave-uniform: this wave's 64 places of the round hold something
+        const bool v = i < end;
+        pr[r] = PrimRef{}; if (v) pr[r] = load_prim(src + i);
+        bins_add_copies(s_bins, m, pr[r], v, lane);
+      }
+    }
+    __syncthreads();
+    bins_fold_copies(s_bins, tid, 256u);
+    __syncthreads();
+    if (wave == 0u) sah_best_wave(s_bins, m, prm.shift, &s_res, lane);
+    __syncthreads();
+    const int rdim = s_res.dim;
+    const bool fallback = (rdim < 0) || forceFallback;          // split invalid -> median split (split_template :144-147)
+    const uint32_t nL = fallback ? ((begin + end) / 2u - begin) : s_res.nL, mid = begin + nL;
+    const uint32_t dim = fallback ? 0u : (uint32_t)rdim; const int pos = s_res.pos;
+    const float ofs = sel3(dim, m.ofs[0], m.ofs[1], m.ofs[2]), scale = sel3(dim, m.scale[0], m.scale[1], m.scale[2]);
+    uint32_t sideBits = 0u; unsigned long long lm[CHUNK_ROUNDS], rm[CHUNK_ROUNDS];
+    uint32_t aL[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u}, aR[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
+#pragma unroll
+    for (int r = 0; r < CHUNK_ROUNDS; r++) {
+      const uint32_t i = begin + (uint32_t)r * 256u + tid;
+      lm[r] = rm[r] = 0ull;
+      if (i - lane < end) {
+        const bool v = i < end;
+        bool left = false;
+        if (v) {
+          const float c2 = sel3(dim, pr[r].lo[0] + pr[r].hi[0], pr[r].lo[1] + pr[r].hi[1], pr[r].lo[2] + pr[r].hi[2]);
+          left = fallback ? (i < mid) : (bin_unsafe(c2, ofs, scale) < pos);           // isLeft: bin_unsafe(center2) < pos (:161)
+          for (int d = 0; d < 3; d++) {                                                // extend_center2 of the child (:168), thread-private first
+            const uint32_t cc = enc(pr[r].lo[d] + pr[r].hi[d]);
+            if (left) { aL[d] = min(aL[d], cc); aL[3 + d] = max(aL[3 + d], cc); } else { aR[d] = min(aR[d], cc); aR[3 + d] = max(aR[3 + d], cc); }
+          }
+          if (fallback) for (int d = 0; d < 3; d++) { atomicMin(&s_acc[left ? 0 : 1][6 + d], enc(pr[r].lo[d])); atomicMax(&s_acc[left ? 0 : 1][9 + d], enc(pr[r].hi[d])); }
+        }
+        lm[r] = __ballot(v && left); rm[r] = __ballot(v && !left);
+        if (left) sideBits |= 1u << r;
+      }
+      if (lane == 0u) { s_cnt[r * 4 + (int)wave][0] = (uint32_t)__popcll(lm[r]); s_cnt[r * 4 + (int)wave][1] = (uint32_t)__popcll(rm[r]); }
+    }
+    for (int k = 0; k < 6; k++) {                                                      // wave-reduce the private bounds, one lane publishes
+      const uint32_t x = k < 3 ? wave_umin63(aL[k]) : wave_umax63(aL[k]), y = k < 3 ? wave_umin63(aR[k]) : wave_umax63(aR[k]);
+      if (lane == 63u) { if (k < 3) { atomicMin(&s_acc[0][k], x); atomicMin(&s_acc[1][k], y); } else { atomicMax(&s_acc[0][k], x); atomicMax(&s_acc[1][k], y); } }
+    }
+    __syncthreads();
+    if (tid < (uint32_t)(CHUNK_ROUNDS * 4)) {                                          // exclusive scan of the (round, wave) counts: where every wave's lefts and rights start
+      uint32_t l = s_cnt[tid][0], rr = s_cnt[tid][1]; const uint32_t l0 = l, r0 = rr;
+      for (int o = 1; o < CHUNK_ROUNDS * 4; o <<= 1) { const uint32_t ul = (uint32_t)__shfl_up((int)l, o, 64), ur = (uint32_t)__shfl_up((int)rr, o, 64); if (tid >= (uint32_t)o) { l += ul; rr += ur; } }
+      s_off[tid][0] = l - l0; s_off[tid][1] = rr - r0;
+    }
+    __syncthreads();
+    const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int r = 0; r < CHUNK_ROUNDS; r++) {
+      const uint32_t i = begin + (uint32_t)r * 256u + tid;
+      if (i < end) {
+        const bool left = (sideBits >> r) & 1u;
+        const uint32_t o = left ? begin + s_off[r * 4 + (int)wave][0] + (uint32_t)__popcll(lm[r] & lt)
+                                : mid + s_off[r * 4 + (int)wave][1] + (uint32_t)__popcll(rm[r] & lt);
+        store_prim(dst + o, pr[r]);
+      }
+    }
+    if (tid < 2u) {                                                                    // the two children: their binary nodes, their places in the work lists
+      const uint32_t side = tid, parent = sg->bnode, idL = parent + 1u, idR = parent + 2u * nL, child = side ? idR : idL;
+      if (side == 0u) { BNode* par = bnodes + parent; par->left = idL; par->right = idR; par->splitSah = s_res.sah; }
+      BNode c{};
+      c.begin = side ? mid : begin; c.end = side ? end : mid; c.left = c.right = NIL; c.splitSah = __builtin_inff();
+      for (int d = 0; d < 3; d++) {
+        c.lo[d] = fallback ? dec(s_acc[side][6 + d]) : (side ? s_res.rlo[d] : s_res.llo[d]);
+        c.hi[d] = fallback ? dec(s_acc[side][9 + d]) : (side ? s_res.rhi[d] : s_res.lhi[d]);
+      }
+      bnodes[child] = c;
+      float cmin[3], cmax[3];
+      for (int d = 0; d < 3; d++) { cmin[d] = dec(s_acc[side][d]); cmax[d] = dec(s_acc[side][3 + d]); }
+      top_emit_child(c.begin, c.end, child, cmin, cmax, next, small, ctr, prm, dstBuf, maxNext, maxSmall, nullptr, 0u);
+    }
+  } else if (s < numSegs && lastOfLevel) { if (tid == 0u) ctr->overflow = 3u; }         // a set for the chunked path at a level that was enqueued without it: the commit is repeated
+}
+
 __global__ void top_emit(const Seg* segs, BNode* bnodes, Seg* next, SmallEntry* small, Counters* ctr,
-                         Params prm, uint32_t dstBuf, uint32_t maxNext, uint32_t maxSmall, const SegX* sx, SegX* nx) {
+                         Params prm, uint32_t dstBuf, uint32_t maxNext, uint32_t maxSmall, const SegX* sx, SegX* nx, uint32_t localMax) {
   const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s < ctr->numSegs) {
+  if (s < ctr->numSegs && segs[s].end - segs[s].begin > localMax) {
   const Seg* sg = segs + s;
   const uint32_t capL = sx ? segx_cap_left(sx, s) : sg->nL;
   for (int side = 0; side < 2; side++) {
@@ -197,32 +350,8 @@ __global__ void top_emit(const Seg* segs, BNode* bnodes, Seg* next, SmallEntry* 
     for (int d = 0; d < 3; d++) { cmin[d] = dec(sg->acc[side][d]); cmax[d] = dec(sg->acc[side][3 + d]); }
     if (sg->flags & 3u) for (int d = 0; d < 3; d++) { bnodes[child].lo[d] = dec(sg->acc[side][6 + d]); bnodes[child].hi[d] = dec(sg->acc[side][9 + d]); }
     if (sg->flags & 2u) { bnodes[child].begin = b; bnodes[child].end = e; }
-    if (e - b <= prm.small) {
-      const uint32_t k = atomicAdd(&ctr->numSmall, 1u);
-      if (k >= maxSmall) { ctr->overflow = 1u; continue; }
-      SmallEntry se; se.begin = b; se.end = e; se.bnode = child; se.buf = dstBuf;
-      for (int d = 0; d < 3; d++) { se.cmin[d] = cmin[d]; se.cmax[d] = cmax[d]; }
-      small[k] = se;
-    } else {
-      const uint32_t k = atomicAdd(&ctr->numSegsNext, 1u);
-      if (k >= maxNext) { ctr->overflow = 1u; continue; }
-      Seg ns{}; ns.begin = b; ns.end = e; ns.bnode = child;
-      for (int d = 0; d < 3; d++) { ns.cmin[d] = cmin[d]; ns.cmax[d] = cmax[d]; }
-      next[k] = ns;
-      if (nx) segx_child(nx, k, childExtEnd);
-    }
+    top_emit_child(b, e, child, cmin, cmax, next, small, ctr, prm, dstBuf, maxNext, maxSmall, nx, childExtEnd);
   }
   }
-  // end of the level: the last workgroup to get here makes the next level's work list the current one (was a launch of its own: 21 x 4.8 us per commit).
-  // The counters the others advanced are read with an atomic: a plain load may be served from this XCD's L2, which does not see the other XCDs' atomics.
-  __syncthreads();
-  if (threadIdx.x == 0u) {
-    __threadfence();
-    if (atomicAdd(&ctr->emitBlocks, 1u) == gridDim.x - 1u) {
-      const uint32_t nextSegs = atomicAdd(&ctr->numSegsNext, 0u);
-      if (ctr->numSegs) ctr->topLevels++;
-      if (nextSegs > maxNext) ctr->overflow = 1u;
-      ctr->numSegs = nextSegs < maxNext ? nextSegs : maxNext; ctr->numSegsNext = 0; ctr->numChunks = 0; ctr->emitBlocks = 0;
-    }
-  }
+  top_level_end(ctr, maxNext);
 }
