@@ -217,56 +217,66 @@ __device__ __forceinline__ void bins_fold_copies(uint32_t* bins, uint32_t tid, u
 
 struct SplitResult { float sah; int dim, pos; uint32_t nL; float llo[3], lhi[3], rlo[3], rhi[3]; };
 
-// BinInfoT::best (heuristic_binning.h:339-386) by ONE wavefront as two scans: lanes 0-31 hold the 32 bins of one axis, lanes
-// 32-63 those of the next (second pass: the third axis).  An inclusive prefix scan gives "everything left of the plane", a
-// suffix scan "everything right of it"; lane pos then prices the candidate (axis, pos).  The reference's "first strict minimum
-// per axis, then first better axis" is the lexicographic minimum of (sah, axis, pos).  Result lands in `res` (LDS).
-// (The first version let every candidate loop over all bins: 3 x 31 x 32 bin visits, ~1900 instructions per lane.)
+// BinInfoT::best (heuristic_binning.h:339-386) by ONE wavefront, one axis per pass: lanes 0-31 hold the axis' 32 bins in order, lanes 32-63 hold them
+// REVERSED, so ONE inclusive prefix scan over 32-lane halves -- four row_shr steps and a row_bcast:15, DPP folded into the min / max / add -- leaves
+// "everything left of the plane" in the lower half and "everything right of it" in the upper half.  Lane b - 1 prices the left side of candidate b,
+// lane 63 - b its right side; lane b combines them (two lane shifts and one bpermute per axis).  The reference's "first strict minimum per axis, then
+// first better axis" is the lexicographic minimum of (sah, axis, pos).  Result lands in `res` (LDS).
+// (The first version let every candidate loop over all bins: ~1900 instructions per lane.  The second scanned two axes per pass with __shfl_up / __shfl_down:
+// 140 ds_bpermute round trips per call, 15 % of small_build's wave cycles and the stretch of top_local where three of its four waves wait.)
+#define MI355_SCAN7(CTRL) \
+  "v_min_f32_dpp %0, %0, %0 " CTRL "\n v_min_f32_dpp %1, %1, %1 " CTRL "\n v_min_f32_dpp %2, %2, %2 " CTRL "\n" \
+  "v_max_f32_dpp %3, %3, %3 " CTRL "\n v_max_f32_dpp %4, %4, %4 " CTRL "\n v_max_f32_dpp %5, %5, %5 " CTRL "\n v_add_u32_dpp %6, %6, %6 " CTRL "\n"
+__device__ __forceinline__ void scan32_box(float (&lo)[3], float (&hi)[3], uint32_t& n) {      // inclusive, over each half of the wave; a lane without a source keeps its value
+  asm volatile("s_nop 1\n"
+               MI355_SCAN7("row_shr:1 row_mask:0xf bank_mask:0xf") MI355_SCAN7("row_shr:2 row_mask:0xf bank_mask:0xf")
+               MI355_SCAN7("row_shr:4 row_mask:0xf bank_mask:0xf") MI355_SCAN7("row_shr:8 row_mask:0xf bank_mask:0xf")
+               MI355_SCAN7("row_bcast:15 row_mask:0xa bank_mask:0xf")
+               : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]), "+v"(n));
+}
+#undef MI355_SCAN7
+__device__ __forceinline__ float lane_shr1(float v) { return __uint_as_float(dpp_u<0x138, 0xF>(__float_as_uint(v), __float_as_uint(v))); }   // wave_shr:1 (lane 0 keeps its value)
 __device__ void sah_best_wave(const uint32_t* bins, const Mapping& m, uint32_t shift, SplitResult* res, uint32_t lane) {
-  const uint32_t b = lane & 31u, half = lane >> 5;
+  const bool upper = lane >= 32u;
+  const uint32_t b = upper ? 63u - lane : lane;                   // my bin
   const uint32_t add = (1u << shift) - 1u;
-  unsigned long long bestKey = ~0ull; uint32_t bestNL = 0;
-  float bl[3] = {0, 0, 0}, bh[3] = {0, 0, 0}, rl[3] = {0, 0, 0}, rh[3] = {0, 0, 0};
+  unsigned long long bestKey = ~0ull;
+  float klo[3][3], khi[3][3]; uint32_t kn[3];                      // my scan results per axis: the winner's two lanes write them out
 #pragma unroll
-  for (uint32_t pass = 0; pass < 2u; pass++) {
-    const uint32_t axis = pass * 2u + half;
-    const bool live = axis < 3u && b < m.nb;
-    float plo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, phi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
-    uint32_t pn = 0;
-    if (live) {
+  for (uint32_t axis = 0; axis < 3u; axis++) {
+    float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, hi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+    uint32_t n = 0;
+    if (b < m.nb) {
       const uint32_t* e = bins + (axis * NBINS + b) * BINW;
-      pn = e[6];
-      if (pn) for (int d = 0; d < 3; d++) { plo[d] = dec(e[d]); phi[d] = dec(e[3 + d]); }
+      n = e[6];
+      if (n) for (int d = 0; d < 3; d++) { lo[d] = dec(e[d]); hi[d] = dec(e[3 + d]); }
     }
-    float slo[3] = {plo[0], plo[1], plo[2]}, shi[3] = {phi[0], phi[1], phi[2]}; uint32_t sn = pn;
-    for (int o = 1; o < 32; o <<= 1) {
-      const uint32_t un = (uint32_t)__shfl_up((int)pn, o, 32), dn = (uint32_t)__shfl_down((int)sn, o, 32);
-      float ul[3], uh[3], dl[3], dh[3];
-      for (int d = 0; d < 3; d++) { ul[d] = __shfl_up(plo[d], o, 32); uh[d] = __shfl_up(phi[d], o, 32); dl[d] = __shfl_down(slo[d], o, 32); dh[d] = __shfl_down(shi[d], o, 32); }
-      if (b >= (uint32_t)o) { pn += un; for (int d = 0; d < 3; d++) { plo[d] = vmin(plo[d], ul[d]); phi[d] = vmax(phi[d], uh[d]); } }
-      if (b + (uint32_t)o < 32u) { sn += dn; for (int d = 0; d < 3; d++) { slo[d] = vmin(slo[d], dl[d]); shi[d] = vmax(shi[d], dh[d]); } }
-    }
-    // candidate pos = b: left = prefix of lane b-1, right = my suffix
-    const uint32_t lN = (uint32_t)__shfl_up((int)pn, 1, 32);
-    float llo[3], lhi[3];
-    for (int d = 0; d < 3; d++) { llo[d] = __shfl_up(plo[d], 1, 32); lhi[d] = __shfl_up(phi[d], 1, 32); }
-    const bool cand = live && b != 0u && sel3(axis, m.scale[0], m.scale[1], m.scale[2]) != 0.0f && lN != 0u && sn != 0u;   // mapping.invalid(dim) :375, pos != 0 :379; an empty side is never selected
+    scan32_box(lo, hi, n);
+    for (int d = 0; d < 3; d++) { klo[axis][d] = lo[d]; khi[axis][d] = hi[d]; } kn[axis] = n;
+    // my side of a candidate: lower lane b = left side of candidate b + 1, upper lane 63 - b = right side of candidate b
+    const float A = half_area3(hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]);
+    const float cntf = (float)((n + add) >> shift);
+    const float rprod = n ? A * cntf : -1.0f;                      // (an empty side is never selected)
+    const float lA = lane_shr1(A), lcnt = lane_shr1(cntf);         // candidate b: its left side comes from lane b - 1 ...
+    const uint32_t lN = dpp_u<0x138, 0xF>(n, n);
+    const float rp = __shfl(rprod, (int)(63u - lane), 64);         // ... its right side from lane 63 - b
+    const bool cand = !upper && b != 0u && b < m.nb && sel3(axis, m.scale[0], m.scale[1], m.scale[2]) != 0.0f && lN != 0u && rp >= 0.0f;   // mapping.invalid(dim) :375, pos != 0 :379
     if (cand) {
-      const float lA = half_area3(lhi[0] - llo[0], lhi[1] - llo[1], lhi[2] - llo[2]);
-      const float rA = half_area3(shi[0] - slo[0], shi[1] - slo[1], shi[2] - slo[2]);
-      const float sah = fmaf(lA, (float)((lN + add) >> shift), rA * (float)((sn + add) >> shift));   // :367
+      const float sah = fmaf(lA, lcnt, rp);                        // :367
       const unsigned long long key = ((unsigned long long)__float_as_uint(sah) << 32) | ((axis << 5) | b);   // sah >= 0: its bit pattern is order preserving
-      if (key < bestKey) {
-        bestKey = key; bestNL = lN;
-        for (int d = 0; d < 3; d++) { bl[d] = llo[d]; bh[d] = lhi[d]; rl[d] = slo[d]; rh[d] = shi[d]; }
-      }
+      if (key < bestKey) bestKey = key;
     }
   }
   unsigned long long k = bestKey;
   for (int o = 32; o >= 1; o >>= 1) { const unsigned long long other = __shfl_xor(k, o, 64); k = other < k ? other : k; }
   if (lane == 0) { res->sah = __builtin_inff(); res->dim = -1; res->pos = 0; res->nL = 0; }
-  if (k != ~0ull && bestKey == k) {                              // exactly one lane owns the minimum (the candidate index is unique)
-    res->sah = __uint_as_float((uint32_t)(k >> 32)); res->dim = (int)((k >> 5) & 3u); res->pos = (int)(k & 31u); res->nL = bestNL;
-    for (int d = 0; d < 3; d++) { res->llo[d] = bl[d]; res->lhi[d] = bh[d]; res->rlo[d] = rl[d]; res->rhi[d] = rh[d]; }
+  if (k != ~0ull) {                                                // (wave-uniform)
+    const uint32_t axis = (uint32_t)(k >> 5) & 3u, pos = (uint32_t)k & 31u;
+    float lo[3], hi[3]; uint32_t n;
+    for (int d = 0; d < 3; d++) { lo[d] = axis == 0u ? klo[0][d] : (axis == 1u ? klo[1][d] : klo[2][d]); hi[d] = axis == 0u ? khi[0][d] : (axis == 1u ? khi[1][d] : khi[2][d]); }
+    n = axis == 0u ? kn[0] : (axis == 1u ? kn[1] : kn[2]);
+    if (lane == pos) { res->sah = __uint_as_float((uint32_t)(k >> 32)); res->dim = (int)axis; res->pos = (int)pos; }
+    if (lane == pos - 1u) { res->nL = n; for (int d = 0; d < 3; d++) { res->llo[d] = lo[d]; res->lhi[d] = hi[d]; } }
+    if (lane == 63u - pos) { for (int d = 0; d < 3; d++) { res->rlo[d] = lo[d]; res->rhi[d] = hi[d]; } }
   }
 }

@@ -98,3 +98,14 @@ template <int CTRL, int ROWMASK> __device__ __forceinline__ uint32_t dpp_u(uint3
   "s_nop 1\n " OP " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n s_nop 1\n " OP " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
 __device__ __forceinline__ uint32_t wave_umin63(uint32_t v) { asm volatile(MI355_WAVE_REDUCE63("v_min_u32_dpp") : "+v"(v)); return v; }
 __device__ __forceinline__ uint32_t wave_umax63(uint32_t v) { asm volatile(MI355_WAVE_REDUCE63("v_max_u32_dpp") : "+v"(v)); return v; }
+
+// s[0..1024) becomes its exclusive scan, the total is returned to every thread (a serial loop of thread 0 over the 1024 partial sums took ~10 us)
+__device__ __forceinline__ uint32_t block_exclusive_scan_1024(uint32_t* s, uint32_t tid) {
+  const uint32_t mine = s[tid];
+  for (uint32_t o = 1; o < 1024u; o <<= 1) { uint32_t x = 0; if (tid >= o) x = s[tid - o]; __syncthreads(); s[tid] += x; __syncthreads(); }
+  const uint32_t total = s[1023], excl = s[tid] - mine;
+  __syncthreads();
+  s[tid] = excl;
+  __syncthreads();
+  return total;
+}

@@ -146,12 +146,26 @@ __global__ __launch_bounds__(256) void presplit_count(const PrimRef* prims, uint
 }
 __global__ __launch_bounds__(1024) void presplit_scan(uint32_t* tileSum, uint32_t numTiles, uint32_t* total) {
   __shared__ uint32_t s_part[1024];
-  const uint32_t tid = threadIdx.x, per = (numTiles + 1023u) / 1024u, b = min(tid * per, numTiles), e = min(b + per, numTiles);
-  uint32_t sum = 0; for (uint32_t i = b; i < e; i++) sum += tileSum[i];
+  const uint32_t tid = threadIdx.x, per = ((numTiles + 1023u) / 1024u + 7u) & ~7u, b = min(tid * per, numTiles), e = min(b + per, numTiles);
+  uint32_t sum = 0;
+  for (uint32_t i = b; i < e; i += 8u) {                         // eight loads in flight per step (see wide_scan)
+    uint32_t x[8];
+#pragma unroll
+    for (uint32_t k = 0; k < 8u; k++) x[k] = i + k < e ? tileSum[i + k] : 0u;
+#pragma unroll
+    for (uint32_t k = 0; k < 8u; k++) sum += x[k];
+  }
   s_part[tid] = sum; __syncthreads();
-  if (tid == 0) { uint32_t run = 0; for (int i = 0; i < 1024; i++) { const uint32_t t = s_part[i]; s_part[i] = run; run += t; } total[0] = run; }
-  __syncthreads();
-  uint32_t run = s_part[tid]; for (uint32_t i = b; i < e; i++) { const uint32_t t = tileSum[i]; tileSum[i] = run; run += t; }
+  const uint32_t totalAll = block_exclusive_scan_1024(s_part, tid);
+  if (tid == 0) total[0] = totalAll;
+  uint32_t run = s_part[tid];
+  for (uint32_t i = b; i < e; i += 8u) {
+    uint32_t x[8];
+#pragma unroll
+    for (uint32_t k = 0; k < 8u; k++) x[k] = i + k < e ? tileSum[i + k] : 0u;
+#pragma unroll
+    for (uint32_t k = 0; k < 8u; k++) if (i + k < e) { tileSum[i + k] = run; run += x[k]; }
+  }
 }
 // piece 0 replaces the reference, the others go behind the n original references at the scanned offset
 __global__ __launch_bounds__(256) void presplit_emit(PrimRef* prims, uint32_t n, const GeomDesc* geoms, SplitGrid g, const uint32_t* cnt, const uint32_t* tileOfs) {

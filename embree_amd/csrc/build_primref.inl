@@ -82,17 +82,27 @@ __global__ __launch_bounds__(256) void compact_count(const PrimRef* in, uint32_t
 __global__ __launch_bounds__(1024) void compact_scan(uint32_t* tileCount, uint32_t numTiles, Counters* ctr, uint32_t guarded) {
   __shared__ uint32_t s_part[1024], s_first[1024];
   if (guarded && ctr->numInvalid == 0u) return;
-  const uint32_t tid = threadIdx.x, per = (numTiles + 1023u) / 1024u, b = tid * per, e = min(b + per, numTiles);
+  const uint32_t tid = threadIdx.x, per = ((numTiles + 1023u) / 1024u + 7u) & ~7u, b = min(tid * per, numTiles), e = min(b + per, numTiles);
   uint32_t sum = 0, first = 0xFFFFFFFFu;                       // first tile that is not completely valid: nothing in front of it moves
-  for (uint32_t i = b; i < e; i++) { const uint32_t c = tileCount[i]; sum += c; if (c != 256u && first == 0xFFFFFFFFu) first = i; }
-  s_part[tid] = sum; s_first[tid] = first; __syncthreads();
-  if (tid == 0) {
-    uint32_t run = 0, f = 0xFFFFFFFFu;
-    for (int i = 0; i < 1024; i++) { const uint32_t t = s_part[i]; s_part[i] = run; run += t; if (s_first[i] < f) f = s_first[i]; }
-    ctr->numPrims = run; ctr->compactFrom = f == 0xFFFFFFFFu ? run : f * 256u;
+  for (uint32_t i = b; i < e; i += 8u) {                         // eight loads in flight per step (see wide_scan)
+    uint32_t x[8];
+#pragma unroll
+    for (uint32_t k = 0; k < 8u; k++) x[k] = i + k < e ? tileCount[i + k] : 256u;
+#pragma unroll
+    for (uint32_t k = 0; k < 8u; k++) { if (i + k < e) sum += x[k]; if (x[k] != 256u && first == 0xFFFFFFFFu) first = i + k; }
   }
-  __syncthreads();
-  uint32_t run = s_part[tid]; for (uint32_t i = b; i < e; i++) { const uint32_t t = tileCount[i]; tileCount[i] = run; run += t; }
+  s_part[tid] = sum; s_first[tid] = first; __syncthreads();
+  for (uint32_t o = 512u; o > 0u; o >>= 1) { if (tid < o) s_first[tid] = min(s_first[tid], s_first[tid + o]); __syncthreads(); }
+  const uint32_t total = block_exclusive_scan_1024(s_part, tid);
+  if (tid == 0) { const uint32_t f = s_first[0]; ctr->numPrims = total; ctr->compactFrom = f == 0xFFFFFFFFu ? total : f * 256u; }
+  uint32_t run = s_part[tid];
+  for (uint32_t i = b; i < e; i += 8u) {
+    uint32_t x[8];
+#pragma unroll
+    for (uint32_t k = 0; k < 8u; k++) x[k] = i + k < e ? tileCount[i + k] : 0u;
+#pragma unroll
+    for (uint32_t k = 0; k < 8u; k++) if (i + k < e) { tileCount[i + k] = run; run += x[k]; }
+  }
 }
 __global__ __launch_bounds__(256) void compact_scatter(const PrimRef* in, uint32_t n, const uint32_t* tileOfs, PrimRef* out, const Counters* ctr, uint32_t base) {
   __shared__ uint32_t s_w[4];

@@ -158,9 +158,17 @@ __global__ __launch_bounds__(64) void wide_plan(const WideItem* items, const BNo
 __global__ __launch_bounds__(1024) void wide_scan(uint2* groupSum, Counters* ctr, uint32_t parity, uint32_t maxNodes) {
   __shared__ uint2 s_part[1024];
   const uint32_t numItems = ctr->wideCount[parity], numGroups = (numItems + 7u) / 8u;
-  const uint32_t tid = threadIdx.x, per = (numGroups + 1023u) / 1024u, b = min(tid * per, numGroups), e = min(b + per, numGroups);
+  // every thread owns a run of `per` consecutive groups (a multiple of 8: four 16-byte loads in flight per step -- one load per step and thread made the
+  // two passes of the widest level 37 dependent L2 round trips each, 91 us)
+  const uint32_t tid = threadIdx.x, per = ((numGroups + 1023u) / 1024u + 7u) & ~7u, b = min(tid * per, numGroups), e = min(b + per, numGroups);
   uint2 sum = make_uint2(0, 0);
-  for (uint32_t i = b; i < e; i++) { const uint2 x = groupSum[i]; sum.x += x.x; sum.y += x.y; }
+  for (uint32_t i = b; i < e; i += 8u) {
+    uint4 x[4];
+#pragma unroll
+    for (uint32_t k = 0; k < 4u; k++) x[k] = i + 2u * k < e ? ((const uint4*)(groupSum + i))[k] : make_uint4(0, 0, 0, 0);   // (an odd last group: the array has 16 spare entries; what lies there is not counted)
+#pragma unroll
+    for (uint32_t k = 0; k < 4u; k++) { sum.x += x[k].x; sum.y += x[k].y; if (i + 2u * k + 1u < e) { sum.x += x[k].z; sum.y += x[k].w; } }
+  }
   s_part[tid] = sum; __syncthreads();
   for (uint32_t o = 1; o < 1024u; o <<= 1) {                    // Hillis-Steele inclusive scan
     uint2 x = make_uint2(0, 0); if (tid >= o) x = s_part[tid - o];
@@ -168,7 +176,16 @@ __global__ __launch_bounds__(1024) void wide_scan(uint2* groupSum, Counters* ctr
   }
   const uint2 total = s_part[1023];
   uint2 run = tid ? s_part[tid - 1] : make_uint2(0, 0);
-  for (uint32_t i = b; i < e; i++) { const uint2 x = groupSum[i]; groupSum[i] = run; run.x += x.x; run.y += x.y; }
+  for (uint32_t i = b; i < e; i += 8u) {
+    uint4 x[4];
+#pragma unroll
+    for (uint32_t k = 0; k < 4u; k++) x[k] = i + 2u * k < e ? ((const uint4*)(groupSum + i))[k] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (uint32_t k = 0; k < 4u; k++) {
+      if (i + 2u * k < e) { groupSum[i + 2u * k] = run; run.x += x[k].x; run.y += x[k].y; }
+      if (i + 2u * k + 1u < e) { groupSum[i + 2u * k + 1u] = run; run.x += x[k].z; run.y += x[k].w; }
+    }
+  }
   __syncthreads();
   if (tid == 0) {
     ctr->lvlNodeBase = ctr->numWide; ctr->lvlTriBase = ctr->numTrisOut;
