@@ -274,7 +274,8 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
   DevBuf<uint32_t> chunkCnt; DevBuf<uint2> chunkBase;          // per chunk of a level: its bin counts, then its places in the two children (top_bin -> top_split -> top_partition)
   HIP_TRY(chunkCnt.alloc((size_t)maxChunks * 3u * NBINS)); HIP_TRY(chunkBase.alloc(maxChunks));
   DevBuf<SegX> segx0, segx1; DevBuf<uint32_t> sbins;            // spatial-split builds: extended ranges of the top phase's sets, their spatial bins
-  if (spatial) { HIP_TRY(segx0.alloc(maxSegs)); HIP_TRY(segx1.alloc(maxSegs)); HIP_TRY(sbins.alloc((size_t)maxSegs * SBINS_WORDS)); }
+  DevBuf<uint32_t> chunkFlag;                                  // ... per chunk: what it sends to either side of a spatial split (spatial_partition)
+  if (spatial) { HIP_TRY(segx0.alloc(maxSegs)); HIP_TRY(segx1.alloc(maxSegs)); HIP_TRY(sbins.alloc((size_t)maxSegs * SBINS_WORDS)); HIP_TRY(chunkFlag.alloc(maxChunks)); }
 
   hipEvent_t ev0, ev1; HIP_TRY(hipEventCreate(&ev0)); HIP_TRY(hipEventCreate(&ev1));
   struct EvGuard { hipEvent_t a, b; ~EvGuard() { hipEventDestroy(a); hipEventDestroy(b); } } evg{ev0, ev1};
@@ -431,7 +432,7 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
       Seg* t = cur; cur = nxt; nxt = t; level++;
       return;
     }
-    LAUNCH(top_setup, dim3(segBound), dim3(256), 0, st, cur, bins.p, chunks.p, ctr.p, localMax, level);
+    LAUNCH(top_setup, dim3(segBound), dim3(256), 0, st, cur, bins.p, chunks.p, ctr.p, localMax, level, chunkFlag.p);
     LAUNCH(top_bin, dim3(chunkBound), dim3(256), 0, st, cur, chunks.p, src, bins.p, ctr.p, chunkCnt.p, maxChunks);
     LAUNCH(top_split, dim3(segBound), dim3(64), 0, st, cur, bins.p, bnodes.p, ctr.p, prm, forceFallback, xcur, (const uint32_t*)chunkCnt.p, chunkBase.p, localMax, maxChunks);
     if (spatial) {                                          // sets whose object split leaves overlapping children try a spatial split
@@ -440,7 +441,7 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
       LAUNCH(spatial_best, dim3(segBound), dim3(64), 0, st, cur, xcur, sbins.p, bnodes.p, ctr.p, prm);
     }
     LAUNCH(top_partition, dim3(chunkBound), dim3(256), 0, st, cur, chunks.p, src, dst, ctr.p, (const uint2*)chunkBase.p);
-    if (spatial) LAUNCH(spatial_partition, dim3(chunkBound), dim3(256), 0, st, cur, xcur, chunks.p, src, dst, dGeoms.p, ctr.p);
+    if (spatial) LAUNCH(spatial_partition, dim3(chunkBound), dim3(256), 0, st, cur, xcur, chunks.p, src, dst, dGeoms.p, ctr.p, chunkFlag.p);
     if (local) LAUNCH(top_local, dim3(segBound), dim3(256), 0, st, (const Seg*)cur, (const PrimRef*)src, dst, bnodes.p, nxt, small.p, ctr.p, prm, dstBuf, maxSegs, maxSmall, forceFallback, level, 0u);
     LAUNCH(top_emit, dim3((segBound + 255u) / 256u), dim3(256), 0, st, cur, bnodes.p, nxt, small.p, ctr.p, prm,
            dstBuf, maxSegs, maxSmall, (const SegX*)xcur, xnxt, localMax);

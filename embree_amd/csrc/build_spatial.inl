@@ -214,9 +214,13 @@ __device__ __forceinline__ void sbins_add_rows(uint32_t* bins, int d, uint32_t b
 // of the 17.5 ms of a HIGH commit; parked chains: 7.0 of 16.4.  At the lower levels, where a bin is about as wide as a triangle, nearly every pair is a
 // chain and the LDS atomics of the pieces -- six per piece -- are what is left).  The (reference, axis) pairs go to a list in LDS instead, and once the chunk's simple references are binned the workgroup's 256 lanes take
 // one chain each.  What a chain adds to the bins is min / max / add atomics, so the bins do not depend on the order the chains are run in.
+#ifndef MI355_SBIN_COPIES
+#define MI355_SBIN_COPIES 8
+#endif
+constexpr uint32_t SBIN_COPIES = MI355_SBIN_COPIES, SCOPY_STRIDE = SBINS_WORDS + 1u;
 constexpr uint32_t CHAIN_CAP = 3u * CHUNK;                           // every (reference, axis) pair of a chunk fits
 __global__ __launch_bounds__(256) void spatial_bin(const Seg* segs, const SegX* sx, const Chunk* chunks, const PrimRef* src, const GeomDesc* geoms, uint32_t* sbins, const Counters* ctr) {
-  __shared__ uint32_t s_b[SBINS_WORDS];
+  __shared__ uint32_t s_b[SBIN_COPIES * SCOPY_STRIDE];              // private copies of the bins, lane l works on copy l mod SBIN_COPIES (see bins_add_copies); folded below
   __shared__ uint32_t s_chain[CHAIN_CAP];                           // reference index | axis << 30
   __shared__ uint32_t s_numChains;
   const uint32_t tid = threadIdx.x, lane = tid & 63u;
@@ -225,7 +229,12 @@ __global__ __launch_bounds__(256) void spatial_bin(const Seg* segs, const SegX* 
   Chunk ck = chunks[c0];
   const SegX* x = sx + ck.seg;
   if (!x->trySpatial) return;
-  for (uint32_t w = tid; w < (uint32_t)SBINS_WORDS; w += 256u) { const uint32_t k = w / SSLOTS; s_b[w] = k < 3 ? ENC_POS_INF : (k < 6 ? ENC_NEG_INF : 0u); }
+  for (uint32_t w = tid; w < (uint32_t)SBINS_WORDS; w += 256u) {
+    const uint32_t k = w / SSLOTS, v = k < 3 ? ENC_POS_INF : (k < 6 ? ENC_NEG_INF : 0u);
+#pragma unroll
+    for (uint32_t c = 0; c < SBIN_COPIES; c++) s_b[c * SCOPY_STRIDE + w] = v;
+  }
+  uint32_t* const mine = s_b + (lane & (SBIN_COPIES - 1u)) * SCOPY_STRIDE;
   if (tid == 0u) s_numChains = 0u;
   __syncthreads();
   float ofs[3], scale[3], inv[3];
@@ -255,13 +264,18 @@ __global__ __launch_bounds__(256) void spatial_bin(const Seg* segs, const SegX* 
               if (slot < CHAIN_CAP) s_chain[slot] = (i - first) | ((uint32_t)d << 30);
               else {                                              // (cannot happen with CHUNK = 2048; kept for other chunk sizes)
                 float tv[3][3]; bool have = false; int l2, r2;
-                spatial_chain<true>(tv, have, geoms, r, d, ofs[d], scale[d], inv[d], s_b, l2, r2);
-                atomicAdd(&s_b[6 * SSLOTS + d * SBINS + l2], 1u); atomicAdd(&s_b[7 * SSLOTS + d * SBINS + r2], 1u);
+                spatial_chain<true>(tv, have, geoms, r, d, ofs[d], scale[d], inv[d], mine, l2, r2);
+                atomicAdd(&mine[6 * SSLOTS + d * SBINS + l2], 1u); atomicAdd(&mine[7 * SSLOTS + d * SBINS + r2], 1u);
               }
             }
           }
         }
-        sbins_add_rows(s_b, d, b, simple, c6, lane);
+        if (simple) {
+          uint32_t* e = mine + (d * SBINS + b);
+          atomicMin(&e[0], c6[0]); atomicMin(&e[SSLOTS], c6[1]); atomicMin(&e[2 * SSLOTS], c6[2]);
+          atomicMax(&e[3 * SSLOTS], c6[3]); atomicMax(&e[4 * SSLOTS], c6[4]); atomicMax(&e[5 * SSLOTS], c6[5]);
+          atomicAdd(&e[6 * SSLOTS], 1u); atomicAdd(&e[7 * SSLOTS], 1u);
+        }
       }
     }
   }
@@ -272,9 +286,16 @@ __global__ __launch_bounds__(256) void spatial_bin(const Seg* segs, const SegX* 
       const uint32_t task = s_chain[t], d = task >> 30;
       const PrimRef r = load_prim(src + first + (task & 0x3FFFFFFFu));
       float tv[3][3]; bool have = false; int l2, r2;
-      spatial_chain<true>(tv, have, geoms, r, (int)d, sel3(d, ofs[0], ofs[1], ofs[2]), sel3(d, scale[0], scale[1], scale[2]), sel3(d, inv[0], inv[1], inv[2]), s_b, l2, r2);
-      atomicAdd(&s_b[6 * SSLOTS + d * SBINS + (uint32_t)l2], 1u); atomicAdd(&s_b[7 * SSLOTS + d * SBINS + (uint32_t)r2], 1u);
+      spatial_chain<true>(tv, have, geoms, r, (int)d, sel3(d, ofs[0], ofs[1], ofs[2]), sel3(d, scale[0], scale[1], scale[2]), sel3(d, inv[0], inv[1], inv[2]), mine, l2, r2);
+      atomicAdd(&mine[6 * SSLOTS + d * SBINS + (uint32_t)l2], 1u); atomicAdd(&mine[7 * SSLOTS + d * SBINS + (uint32_t)r2], 1u);
     }
+  }
+  __syncthreads();
+  for (uint32_t w = tid; w < (uint32_t)SBINS_WORDS; w += 256u) {    // fold the copies into copy 0
+    const uint32_t k = w / SSLOTS; uint32_t v = s_b[w];
+#pragma unroll
+    for (uint32_t c = 1; c < SBIN_COPIES; c++) { const uint32_t y = s_b[c * SCOPY_STRIDE + w]; v = k < 3 ? min(v, y) : (k < 6 ? max(v, y) : v + y); }
+    s_b[w] = v;
   }
   __syncthreads();
   const Seg* sg = segs + ck.seg;
@@ -293,7 +314,10 @@ __global__ __launch_bounds__(64) void spatial_best(Seg* segs, SegX* sx, const ui
   if (s >= ctr->numSegs) return;
   Seg* sg = segs + s; SegX* x = sx + s;
   if (!x->trySpatial) return;
-  const uint32_t* B = sbins + (size_t)s * SBINS_WORDS;
+  __shared__ uint32_t s_B[SBINS_WORDS];                            // the set's bins, fetched by the whole wave at once (three lanes walking them in global memory: 13 us per level)
+  for (uint32_t w = lane; w < (uint32_t)SBINS_WORDS; w += 64u) s_B[w] = sbins[(size_t)s * SBINS_WORDS + w];
+  __syncthreads();
+  const uint32_t* B = s_B;
   const uint32_t add = (1u << prm.shift) - 1u;
   if (lane < 3u) {
     const uint32_t d = lane;
@@ -364,7 +388,7 @@ __device__ __forceinline__ void spatial_sides(const PrimRef& r, uint32_t dim, in
     }
   } else { toL = sbin(0.5f * (rlo + rhi), ofs, scale) < pos; toR = !toL; }   // whole, to the side its centre lies on
 }
-__global__ __launch_bounds__(256) void spatial_partition(Seg* segs, const SegX* sx, const Chunk* chunks, const PrimRef* src, PrimRef* dst, const GeomDesc* geoms, Counters* ctr) {
+__global__ __launch_bounds__(256) void spatial_partition(Seg* segs, const SegX* sx, const Chunk* chunks, const PrimRef* src, PrimRef* dst, const GeomDesc* geoms, Counters* ctr, uint32_t* chunkFlag) {
   __shared__ uint32_t s_cnt[CHUNK_ROUNDS][4][2], s_off[CHUNK_ROUNDS][4][2], s_baseL, s_baseR;
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   if (blockIdx.x >= ctr->numChunks) return;
@@ -390,7 +414,25 @@ __global__ __launch_bounds__(256) void spatial_partition(Seg* segs, const SegX* 
   if (tid == 0u) {
     uint32_t l = 0, rr = 0;
     for (int r = 0; r < CHUNK_ROUNDS; r++) for (int w = 0; w < 4; w++) { s_off[r][w][0] = l; s_off[r][w][1] = rr; l += s_cnt[r][w][0]; rr += s_cnt[r][w][1]; }
-    s_baseL = l ? atomicAdd(&sg->curL, l) : 0u; s_baseR = rr ? atomicAdd(&sg->curR, rr) : 0u;
+    // The chunk's places: behind everything the chunks BEFORE it in the set send to the same side -- every chunk says how many that is (one word: flag, left,
+    // right) and sums what its predecessors said, waiting for those that have not yet (workgroups start in index order: a predecessor is running or done).
+    // Reserving the places with the set's cursors handed them out in the order the chunks ARRIVED: the children held the same references in another order
+    // from run to run, and what a median split further down cuts off depends on the order (two leaves of a HIGH tree swapped a triangle between commits).
+    __hip_atomic_store(chunkFlag + blockIdx.x, 0x80000000u | (l << 12) | rr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (l) atomicAdd(&sg->curL, l);                                // (the cursors only COUNT: top_emit reads the children's ends from them)
+    if (rr) atomicAdd(&sg->curR, rr);
+    s_baseL = sg->begin; s_baseR = sg->begin + x->capL;
+  }
+  __syncthreads();
+  {
+    uint32_t pl = 0u, pr = 0u;
+    for (uint32_t j = sg->chunk0 + tid; j < blockIdx.x; j += 256u) {
+      uint32_t v;
+      do { v = __hip_atomic_load(chunkFlag + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (!(v >> 31)) __builtin_amdgcn_s_sleep(2); } while (!(v >> 31));
+      pl += (v >> 12) & 0xFFFu; pr += v & 0xFFFu;
+    }
+    for (int o = 32; o > 0; o >>= 1) { pl += (uint32_t)__shfl_down((int)pl, o, 64); pr += (uint32_t)__shfl_down((int)pr, o, 64); }
+    if (lane == 0u && (pl | pr)) { atomicAdd(&s_baseL, pl); atomicAdd(&s_baseR, pr); }
   }
   __syncthreads();
   uint32_t acc[2][12];                                           // this thread's share of the children's centroid / geometry bounds (ordered uint), folded across the wave at the end

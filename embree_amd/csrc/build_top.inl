@@ -2,7 +2,7 @@
 // Part of build.hip (included inside its anonymous namespace); see the header of build.hip for the pipeline.
 // ------------------------------------------------------------------------------------ K2 top phase
 // localMax: sets of at most this many references are top_local's at this level (0: none are), the four kernels of the chunked path leave them alone
-__global__ __launch_bounds__(256) void top_setup(Seg* segs, uint32_t* bins, Chunk* chunks, Counters* ctr, uint32_t localMax, uint32_t level) {
+__global__ __launch_bounds__(256) void top_setup(Seg* segs, uint32_t* bins, Chunk* chunks, Counters* ctr, uint32_t localMax, uint32_t level, uint32_t* chunkFlag) {
   __shared__ uint32_t s_base;
   const uint32_t s = blockIdx.x, tid = threadIdx.x;
   if (s >= ctr->numSegs) return;                                // the grid is an upper bound (2^level segments at most)
@@ -10,8 +10,8 @@ __global__ __launch_bounds__(256) void top_setup(Seg* segs, uint32_t* bins, Chun
   const uint32_t begin = sg->begin, end = sg->end, n = end - begin;
   if (n <= localMax) return;
   if (tid == 0u) ctr->chunkedLevels = level + 1u;               // (every writer of a level writes the same value; levels are launches, in order)
-  bins_clear(bins + (size_t)s * BINS_WORDS, tid, 256u);
   const uint32_t nch = (n + CHUNK - 1u) / CHUNK;
+  if (nch > 1u) bins_clear(bins + (size_t)s * BINS_WORDS, tid, 256u);   // (a set of one chunk: top_bin writes its bins as they are -- clearing them was 54 MB per level of a HIGH commit)
   if (tid == 0) {
     const Mapping m = make_mapping(n, sg->cmin, sg->cmax);
     for (int d = 0; d < 3; d++) { sg->ofs[d] = m.ofs[d]; sg->scale[d] = m.scale[d]; }
@@ -23,6 +23,7 @@ __global__ __launch_bounds__(256) void top_setup(Seg* segs, uint32_t* bins, Chun
   for (uint32_t c = tid; c < nch; c += 256u) {
     Chunk ck; ck.seg = s; ck.begin = begin + c * CHUNK; ck.end = min(ck.begin + CHUNK, end);
     chunks[s_base + c] = ck;
+    if (chunkFlag) chunkFlag[s_base + c] = 0u;                    // spatial-split builds: "this chunk has not said yet how many references it sends to either side" (spatial_partition)
   }
 }
 
