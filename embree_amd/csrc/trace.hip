@@ -47,7 +47,7 @@ constexpr int MAX_BLOCKS_PER_CU = MI355_MAX_BLOCKS_PER_CU * 256 / BLOCK;
 constexpr uint32_t ITER_CAP = 1u << 24;    // safety net only: a corrupt tree must not hang the GPU (env MI355_TRACE_ITER_CAP lowers it for the test of the flag below)
 // Neither safety net may fail silently: a wave that runs into the iteration cap, or a lane whose stack would outgrow its spill area, raises a word
 // in host-visible memory (TraceScratch::status); the blocking entry points turn it into RTC_ERROR_UNKNOWN, mi355_trace_status() reads it for device-pointer callers.
-constexpr uint32_t STATUS_ITER_CAP = 0, STATUS_SPILL = 1;
+constexpr uint32_t STATUS_ITER_CAP = 0, STATUS_SPILL = 1, STATUS_COHERENT = 2;   // words of TraceScratch::status (64 bytes of host-mapped memory); COHERENT: 1 = the last packet sample kept its packets, 2 = it did not
 constexpr uint32_t REFILL_MIN_DEFAULT = 16;  // rays are handed out in blocks of this many, once that many lanes are free (env MI355_REFILL_MIN); 32 before finished rays went to the done queue
 
 __device__ __forceinline__ float rcp_nr(float a) {  // v_rcp_f32 + one Newton step (reference: RCPPS + Newton, vfloat4_sse2.h:304)
@@ -788,7 +788,7 @@ __global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceAr
 //   one light) and loses on incoherent batches -- the flag is the application's promise, as in the reference.
 constexpr int PSTACK = 128;                 // stack entries per packet: <= 7 siblings left behind per level
 struct PacketTraceArgs { const uint4* nodes; const float4* tris; uint32_t hasRoot; char* rays; uint32_t count, stride; uint32_t* deferList; uint32_t* deferCount; volatile uint32_t* status; uint32_t minServed; const uint4* rules;
-                         uint32_t part, bailAbove; };   // part: 0 = every packet, 1 = the sample (every PACKET_SAMPLE-th), 2 = the others; bailAbove: part 2 defers everything when the sample deferred more than this
+                         uint32_t part, bailAbove, verdictAbove; };   // part: 0 = every packet, 1 = the sample (every PACKET_SAMPLE-th), 2 = the others; bailAbove: part 2 defers everything when the sample deferred more than this
 constexpr uint32_t PACKET_SAMPLE = 32;
 
 template <bool ANY, bool ROBUST>
@@ -977,7 +977,11 @@ __global__ __launch_bounds__(64) void trace_packet_kernel(PacketTraceArgs a) {
     }
   }
   if (a.part == 1u && lane == 0u) {                              // the sample's verdict, frozen by the last block to leave (its appends above returned: they are performed)
-    if (atomicAdd(a.deferCount + 2, 1u) == gridDim.x - 1u) { a.deferCount[1] = atomicAdd(a.deferCount, 0u); atomicExch(a.deferCount + 2, 0u); }
+    if (atomicAdd(a.deferCount + 2, 1u) == gridDim.x - 1u) {
+      const uint32_t gaveUp = atomicAdd(a.deferCount, 0u);
+      a.deferCount[1] = gaveUp; atomicExch(a.deferCount + 2, 0u);
+      a.status[STATUS_COHERENT] = gaveUp > a.verdictAbove ? 2u : 1u;   // what the host remembers for the next coherent query on this (tree, stream): launch_trace_coherent
+    }
   }
 }
 
@@ -1131,6 +1135,13 @@ static int launch_trace_coherent(Bvh* b, void* d_rays, uint32_t count, size_t st
   // ONE lock over the packet launches and the per-lane pass behind them: the deferred list belongs to (tree, stream), and a second thread's coherent query
   // on the same stream (all host queries use the null stream) must not reset or regrow it between my packets and my second pass
   std::lock_guard<std::mutex> enqueueLock(*sc->enqueue);
+  // What the sample of the LAST large coherent query on this (tree, stream) said is still in the host-mapped status word: "its packets do not stay together"
+  // (crown stand-in, primary rays: the sample launch, the list of packets that gave up and the indirection through it cost 10 % of the per-lane rate).  Then
+  // this query goes to the per-lane kernel as it is; every 16th one is sampled again (a camera that moved into the open keeps its packets).  Results do not
+  // depend on the path.
+  static const bool remember = env_u32("MI355_PACKET_REMEMBER", 1, 0, 1) != 0u;
+  if (remember && packets >= 1024u && packets >= 4u * PACKET_SAMPLE && sc->statusHost[STATUS_COHERENT] == 2u && (++sc->coherentCalls & 15u) != 0u)
+    return launch_trace_locked(b, sc, d_rays, count, stride, any, s, nullptr, nullptr, nullptr);
   {
     if (sc->deferCap < need) {                                  // (stream order keeps earlier launches' use of the old list apart: wait for them before it goes)
       if (sc->defer) { HIP_TRY(hipStreamSynchronize(s)); HIP_TRY(hipFree(sc->defer)); sc->defer = nullptr; sc->deferCap = 0; }
@@ -1145,8 +1156,10 @@ static int launch_trace_coherent(Bvh* b, void* d_rays, uint32_t count, size_t st
     static const uint32_t minLanes = env_u32("MI355_PACKET_MIN_LANES", 48, 0, 64);
     static const uint32_t sampleMin = env_u32("MI355_PACKET_SAMPLE_MIN", 1024, 0, 0x7FFFFFFF);   // packets: smaller batches are traced in one launch
     a.minServed = 4u * minLanes;
+    a.verdictAbove = 0xFFFFFFFFu;
     if (packets >= sampleMin && packets >= 4u * PACKET_SAMPLE) {
       const uint32_t nSample = (uint32_t)((packets + PACKET_SAMPLE - 1u) / PACKET_SAMPLE), nRest = (uint32_t)packets - nSample;
+      a.verdictAbove = nSample / 4u;
       a.part = 1u; a.bailAbove = 0xFFFFFFFFu;
       hipLaunchKernelGGL(fn, dim3(nSample < maxBlocks ? nSample : maxBlocks), dim3(64), 0, s, a);
       a.part = 2u; a.bailAbove = nSample / 4u;
