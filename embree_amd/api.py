@@ -95,7 +95,7 @@ class BvhInfo(C.Structure):
                 ("build_ms", C.c_float), ("root_ref", C.c_uint32), ("top_levels", C.c_uint32),
                 ("max_leaf", C.c_uint32), ("depth", C.c_uint32),
                 ("bytes_refit", C.c_uint64), ("num_refits", C.c_uint32), ("num_presplit", C.c_uint32),
-                ("num_launches", C.c_uint32), ("num_host_syncs", C.c_uint32)]
+                ("num_launches", C.c_uint32), ("num_host_syncs", C.c_uint32), ("build_attempts", C.c_uint32), ("reserved0", C.c_uint32)]
 
     def as_dict(self):
         d = {k: getattr(self, k) for k, _ in self._fields_ if not k.startswith("bounds")}

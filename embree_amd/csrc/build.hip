@@ -588,9 +588,11 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
 
 // the one-round-trip path can ask for the commit to be repeated on the stepwise path (-1000: level margins exceeded); that path does not cut outliers
 static int build_retry(int device, const mi355_mesh* meshes, uint32_t numMeshes, const mi355_build_params* bp, hipStream_t st, Bvh** out) {
+  uint32_t attempts = 1;
   int rc = build_impl(device, meshes, numMeshes, bp, st, out);
-  if (rc == -1001) rc = build_impl(device, meshes, numMeshes, bp, st, out, true, true, false);   // the level counts learned from the last commit of this size were too few
-  if (rc == -1000) rc = build_impl(device, meshes, numMeshes, bp, st, out, false, false);
+  if (rc == -1001) { attempts++; rc = build_impl(device, meshes, numMeshes, bp, st, out, true, true, false); }   // the level counts learned from the last commit of this size were too few
+  if (rc == -1000) { attempts++; rc = build_impl(device, meshes, numMeshes, bp, st, out, false, false); }
+  if (rc == 0 && *out) (*out)->info.build_attempts = attempts;
   return rc;
 }
 

@@ -87,6 +87,9 @@ typedef struct mi355_bvh_info {
   uint32_t num_presplit;     /* quality 2: references added by pre-splitting (num_triangles counts references = leaf records) */
   uint32_t num_launches;     /* kernel launches of the last build */
   uint32_t num_host_syncs;   /* host round trips (stream synchronisations) of the last build: 2 on the default path (counters, final copy) */
+  uint32_t build_attempts;   /* 1; 2 = the launch sequence learned from the last commit of this size was too short for this scene, the commit ran again with the blind margins;
+                                + 1 if those were exceeded too and the stepwise path built the tree */
+  uint32_t reserved0;
 } mi355_bvh_info;
 
 MI355_API void mi355_default_build_params(mi355_build_params* p);

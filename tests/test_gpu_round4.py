@@ -501,3 +501,79 @@ def test_single_ray_call_latency(api, dev):
     print("rtcIntersect1: median %.1f us, min %.1f us (hit geom %d prim %d t %.6f)" % (med, 1e6 * min(ts), q["geomID"][0], q["primID"][0], q["tfar"][0]))
     assert q["geomID"][0] != INVALID_ID and med < 150.0
     s.release()
+
+
+# ------------------------------------------------------------------------------------------- round 4, second half: the builder's learned launch sequence
+def _soup(n, seed, clustered):
+    """n small triangles: spread evenly over a cube, or (clustered) 7/8 of them in a corner 1/64 of its size -- same n, very different level structure."""
+    rng = np.random.default_rng(seed)
+    c = rng.random((n, 3), dtype=np.float32) * 100.0
+    if clustered:
+        k = n - n // 8
+        c[:k] = c[:k] / 64.0
+    d = (rng.random((n, 3, 3), dtype=np.float32) - 0.5) * 0.05
+    v = (c[:, None, :] + d).reshape(-1, 3).astype(np.float32)
+    t = np.arange(3 * n, dtype=np.uint32).reshape(n, 3)
+    return [(v, t)]
+
+
+def test_commit_with_level_counts_learned_from_another_scene_of_the_same_size(api, dev):
+    """A default-quality commit enqueues the launch sequence the LAST commit of the same triangle count needed (top levels, levels of the chunked path, first
+    level of top_local, wide levels: build.hip, Arena::learned*).  A different scene of the same size may need more: the commit notices (unfinished work list /
+    a large set where only top_local was enqueued), forgets what it learned and runs again blind.  Whatever way a tree was enqueued, it is the same tree."""
+    n = 600_000
+    trees = {}; attempts = []
+    for name, clustered in (("even", False), ("clustered", True), ("even", False), ("clustered", True)):
+        s = api.make_scene(dev, _soup(n, 7, clustered))          # first commit of this scene: learned counts are the OTHER scene's
+        nodes, tris = s.download_bvh()
+        first = (nodes.tobytes(), tris.tobytes())
+        attempts.append(s.info()["build_attempts"])
+        for _ in range(2):                                        # commits with its own learned counts
+            s.touch(); s.commit()
+            nodes, tris = s.download_bvh()
+            assert (nodes.tobytes(), tris.tobytes()) == first, "%s: a re-commit built another tree" % name
+            assert s.info()["build_attempts"] == 1, "a commit with the scene's own learned counts ran twice"
+        if name in trees:
+            assert trees[name] == first, "%s: the tree depends on what was committed before it" % name
+        trees[name] = first
+        info = s.info()
+        assert info["num_host_syncs"] <= 3
+        s.release()
+    assert trees["even"] != trees["clustered"]
+    assert max(attempts[1:]) >= 2, "the learned sequence of the other scene was never too short (%r): the retry path was not exercised" % (attempts,)
+
+
+def test_high_quality_commits_of_the_crown_are_bit_identical(api, dev):
+    """RTC_BUILD_QUALITY_HIGH at the bench's size: the chunks of a set that splits spatially take their places in chunk order (spatial_partition sums what its
+    predecessors send to each side; they used to take them in arrival order, and two leaves could swap a triangle from one commit to the next)."""
+    meshes = W.synthetic_crown()
+    s = api.Scene(dev, 0, 2)
+    for v, t in meshes:
+        s.add_triangle_mesh(v, t, device_resident=True)
+    got = []
+    for _ in range(3):
+        s.touch(); s.commit()
+        nodes, tris = s.download_bvh()
+        got.append((nodes.tobytes(), tris.tobytes()))
+    assert got[0] == got[1] == got[2]
+    s.release()
+
+
+def test_coherent_flag_with_a_remembered_sample(api, dev):
+    """Large RTC_RAY_QUERY_FLAG_COHERENT batches whose packets do not stay together: the first query samples every 32nd packet, the next ones remember what it
+    said and go to the per-lane kernel as they are (launch_trace_coherent); coherent batches on the same scene in between still take the packet kernel.
+    Same bytes every time."""
+    meshes = W.synthetic_crown(num_phi=48)
+    s = api.make_scene(dev, meshes)
+    prim = W.crown_camera_rays(meshes, 512, 512)
+    want = prim.copy(); s.intersect1M(want)
+    bounce = W.diffuse_bounce_rays(want, meshes)[:200_000]
+    wantB = bounce.copy(); s.intersect1M(wantB)
+    args = api.QueryArguments(flags=api.RTC_RAY_QUERY_FLAG_COHERENT)
+    for rep in range(20):                                         # (more than 16: one of them samples again)
+        src, w = (bounce, wantB) if rep % 5 != 4 else (prim, want)
+        g = src.copy(); s.intersect1M(g, args)
+        assert g.tobytes() == w.tobytes(), "repetition %d" % rep
+        r = rays_of(src); s.occluded1M(r, args)
+        assert np.array_equal(np.isneginf(r["tfar"]), w["geomID"] != INVALID_ID), "occluded, repetition %d" % rep
+    s.release()
