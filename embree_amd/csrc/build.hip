@@ -223,7 +223,8 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
   if (total == 0) { guard.ok = true; *out = bvh; return 0; }
   const uint32_t N = (uint32_t)total;
   static const bool envSync = getenv("MI355_BUILD_STEPWISE") != nullptr;         // A/B: force the stepwise path
-  const bool fast = allowFast && !envSync && prm.quality == 0u && !(arena->marginFailedN != 0u && arena->marginFailedN == N);
+  // (HIGH with spatial splits takes the one-round-trip path as well -- round 4: its nine host round trips were ~0.4 ms of idle GPU; HIGH with presplits keeps its budget loop on the host)
+  const bool fast = allowFast && !envSync && (prm.quality == 0u || prm.spatial != 0u) && !(arena->marginFailedN != 0u && arena->marginFailedN == N);
   static const bool envGraph = !(getenv("MI355_BUILD_GRAPH") && atoi(getenv("MI355_BUILD_GRAPH")) == 0);
   if (fast && envGraph && !st && !arena->graphBroken) {        // the graph needs a stream of its own
     // a BLOCKING stream (default flags): it keeps the implicit ordering with the legacy null stream that a commit on the null stream had -- work the application
@@ -324,6 +325,11 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
     }
     LAUNCH(root_setup, dim3(1), dim3(1), 0, st, ctr.p, bnodes.p, segs0.p, small.p, N, prm.small);
     numSegs = N > prm.small ? 1u : 0u;
+    if (prm.spatial && numSegs) {                                 // split budgets of the references; the root set owns everything behind them
+      LAUNCH(spatial_area_sum, dim3(tiles < 2048u ? tiles : 2048u), dim3(256), 0, st, bufA.p, N, ctr.p, 1u);
+      LAUNCH(spatial_budgets, dim3(tiles), dim3(256), 0, st, bufA.p, N, (const Counters*)ctr.p, 1u);
+      LAUNCH(segx_root, dim3(1), dim3(1), 0, st, segx0.p, NC);
+    }
   } else {
     SYNC_READ(h);
     h.numPrims = N - h.numInvalid;
@@ -372,7 +378,7 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
     // root binary node + first work item
     BNode rootB{}; for (int d = 0; d < 3; d++) { rootB.lo[d] = glo[d]; rootB.hi[d] = ghi[d]; } rootB.begin = 0; rootB.end = n; rootB.left = rootB.right = NIL; rootB.splitSah = INFINITY;
     HIP_TRY(hipMemcpyAsync(bnodes.p, &rootB, sizeof(rootB), hipMemcpyHostToDevice, st));
-    h.numBLeaves = 0; h.numSegsNext = 0; h.numChunks = 0; h.numSmall = 0; h.numSegs = n > prm.small ? 1u : 0u; h.topLevels = 0;
+    h.numBLeaves = 0; h.numSegsNext = 0; h.numChunks = 0; h.numSmall = 0; h.numSegs = (n > prm.small && prm.quality != 1u) ? 1u : 0u; h.topLevels = 0;   // (LOW has no top phase: a work list that nobody empties would read as "unfinished" to wide_root)
     h.rootArea = fmaf(ghi[0] - glo[0], (ghi[1] - glo[1]) + (ghi[2] - glo[2]), (ghi[1] - glo[1]) * (ghi[2] - glo[2]));
     h.areaFixed = 0ull;
     if (n > prm.small) {
@@ -385,8 +391,8 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
     HIP_TRY(hipMemcpyAsync(ctr.p, &h, sizeof(h), hipMemcpyHostToDevice, st));
     if (spatial && n > prm.small) {                              // split budgets of the references; the root set owns everything behind them
       const uint32_t ab = (n + 255u) / 256u < 2048u ? (n + 255u) / 256u : 2048u;
-      LAUNCH(spatial_area_sum, dim3(ab), dim3(256), 0, st, bufA.p, n, ctr.p);
-      LAUNCH(spatial_budgets, dim3((n + 255u) / 256u), dim3(256), 0, st, bufA.p, n, ctr.p);
+      LAUNCH(spatial_area_sum, dim3(ab), dim3(256), 0, st, bufA.p, n, ctr.p, 0u);
+      LAUNCH(spatial_budgets, dim3((n + 255u) / 256u), dim3(256), 0, st, bufA.p, n, (const Counters*)ctr.p, 0u);
       SegX x0{}; x0.extEnd = NC;
       HIP_TRY(hipMemcpyAsync(segx0.p, &x0, sizeof(x0), hipMemcpyHostToDevice, st));
     }
@@ -514,6 +520,7 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
     if (!bvh->d_tris) return set_error(hipErrorOutOfMemory, "leaf record array");
     LAUNCH(tri_records, dim3((NC + 255u) / 256u), dim3(256), 0, st, outIds.p, NC, dGeoms.p, (TriRec*)bvh->d_tris, bp->robust ? 1u : 0u, (const Counters*)ctr.p);
     SYNC_READ(h);                                                // the ONE round trip of the commit
+    if (h.overflow == 2u && spatial) return set_error(hipErrorOutOfMemory, "spatial split ran out of its extended range");
     if (h.overflow == 3u && learned) { arena->learnedN = 0; arena->learnedTop = arena->learnedWide = 0; return -1001; }   // a large set below the last level the chunked path was enqueued for
     if (h.overflow) return set_error(hipErrorOutOfMemory, "work list overflow (pathological input)");
     if (h.numSegs != 0u) {                                       // the top phase needed more levels than were enqueued: what came after it worked on an unfinished tree
@@ -533,6 +540,7 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
       if (h.overflow) return set_error(hipErrorOutOfMemory, "wide node pool overflow");
       redoLeaves = true;
     }
+    if (spatial) { info.num_presplit = h.numTrisOut > n ? h.numTrisOut - n : 0u; n = h.numTrisOut; }   // the references the spatial splits created are leaf entries like any other
     arena->learnedN = N; arena->learnedTop = h.topLevels; arena->learnedWide = h.wideDepth; arena->learnedChunked = h.chunkedLevels; arena->learnedLocalFirst = h.localFirst < 255u ? h.localFirst : 255u;   // (a tree deeper than the wide levels enqueued is finished below either way)
     if (redoLeaves) LAUNCH(tri_records, dim3((NC + 255u) / 256u), dim3(256), 0, st, outIds.p, NC, dGeoms.p, (TriRec*)bvh->d_tris, bp->robust ? 1u : 0u, (const Counters*)ctr.p);
   } else {

@@ -83,8 +83,10 @@ __device__ __forceinline__ void load_tri_masked(const GeomDesc* geoms, const Pri
 }
 
 // ---- split budgets (bvh_builder_sah.h:574-601): two passes over the references, the sum in fixed point relative to the scene's area
-__global__ __launch_bounds__(256) void spatial_area_sum(const PrimRef* prims, uint32_t n, Counters* ctr) {
+// fromCtr (one-round-trip commits): n is an upper bound, the number of valid references is on the device; nothing to do when the whole scene is one small sub-tree
+__global__ __launch_bounds__(256) void spatial_area_sum(const PrimRef* prims, uint32_t n, Counters* ctr, uint32_t fromCtr) {
   __shared__ unsigned long long s_w[4];
+  if (fromCtr) { if (ctr->numSegs == 0u) return; n = ctr->numPrims; }
   const float rootArea2 = 2.0f * ctr->rootArea;
   unsigned long long acc = 0ull;
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
@@ -97,7 +99,8 @@ __global__ __launch_bounds__(256) void spatial_area_sum(const PrimRef* prims, ui
   __syncthreads();
   if (threadIdx.x == 0u) atomicAdd(&ctr->areaFixed, s_w[0] + s_w[1] + s_w[2] + s_w[3]);
 }
-__global__ __launch_bounds__(256) void spatial_budgets(PrimRef* prims, uint32_t n, const Counters* ctr) {
+__global__ __launch_bounds__(256) void spatial_budgets(PrimRef* prims, uint32_t n, const Counters* ctr, uint32_t fromCtr) {
+  if (fromCtr) { if (ctr->numSegs == 0u) return; n = ctr->numPrims; }
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i >= n) return;
   const float rootArea2 = 2.0f * ctr->rootArea;
@@ -110,6 +113,8 @@ __global__ __launch_bounds__(256) void spatial_budgets(PrimRef* prims, uint32_t 
   r.geom = (r.geom & GEOM_MASK) | (budget << SPLIT_SHIFT);
   store_prim(prims + i, r);
 }
+
+__global__ void segx_root(SegX* sx, uint32_t extEnd) { SegX x0{}; x0.extEnd = extEnd; sx[0] = x0; }   // the root set owns everything behind the references
 
 // ---- per level, after top_split: does the object split leave overlapping children?  (HeuristicArraySpatialSAH::find, heuristic_spatial_array.h:171-186)
 __global__ void spatial_decide(const Seg* segs, SegX* sx, const BNode* bnodes, uint32_t* sbins, const Counters* ctr, uint32_t minSize) {

@@ -39,7 +39,11 @@ struct WidePlan { uint32_t ch[8]; uint32_t imask, leafMask, nch, pad; };   // by
 
 __global__ void wide_root(WideItem* items, Counters* ctr) {
   items[0].bnode = 0; items[0].node = 0;                       // the root is always CNode 0
-  const bool any = ctr->numPrims != 0u;                        // (a scene whose triangles are all invalid has no tree)
+  // A top phase that was enqueued with too few levels (one-round-trip commits: the margins, or the counts learned from another scene of this size) leaves sets
+  // unsplit: binary "leaves" of thousands of references whose ids nobody wrote.  The commit is repeated anyway (the host sees numSegs / overflow); until then
+  // nothing may walk that tree -- leaf ids from whatever the arena held sent tri_records to wild addresses (a rare abort in the test suite, found in round 4).
+  const bool unfinished = ctr->numSegs != 0u || ctr->overflow != 0u;
+  const bool any = ctr->numPrims != 0u && !unfinished;         // (a scene whose triangles are all invalid has no tree)
   ctr->rootRef = any ? 0u : MI355_EMPTY_REF; ctr->numWide = any ? 1u : 0u; ctr->wideCount[0] = any ? 1u : 0u; ctr->wideCount[1] = 0; ctr->wideDepth = 0; ctr->lvlStart[0] = 0; ctr->numLeaves = 0; ctr->numTrisOut = 0; ctr->sahFixed = 0ull;
 }
 

@@ -59,8 +59,8 @@ def commit_ms(scene, reps=3):
     return min(ms)
 
 
-def scene_of(meshes):
-    s = api.Scene(dev)
+def scene_of(meshes, quality=None):
+    s = api.Scene(dev, 0, quality)
     for v, t in meshes:
         s.add_triangle_mesh(v, t, device_resident=True)
     s.commit()
@@ -111,6 +111,12 @@ rows.append(("configs[3] crown stand-in, one rank's shard of the 16 Mi shadow ra
 a, b = rate(s, sh, True, reps=8, coherent=True)
 rows.append(("  same rays, RTC_RAY_QUERY_FLAG_COHERENT (16 consecutive rays share a hit point)", W.num_triangles(m), cms, "any hit", a, b))
 s.release()
+for q, qn in ((2, "RTC_BUILD_QUALITY_HIGH (spatial splits)"), (0, "RTC_BUILD_QUALITY_LOW (Morton codes)")):   # the other two build qualities on the bench's scene and rays
+    s = scene_of(m, q)
+    cq = commit_ms(s, 4)
+    a, b = rate(s, bounce, False)
+    rows.append(("  configs[2] scene and rays, %s" % qn, W.num_triangles(m), cq, "closest", a, b))
+    s.release()
 # configs[4]: powerplant stand-in
 m = W.synthetic_powerplant()
 s = scene_of(m)
@@ -121,6 +127,11 @@ bounce = W.diffuse_bounce_rays(tr, m)
 cms = commit_ms(s)
 a, b = rate(s, bounce, False)
 rows.append(("configs[4] powerplant stand-in, 2^20 incoherent diffuse rays", W.num_triangles(m), cms, "closest", a, b))
+s.release()
+s = scene_of(m, 2)
+cq = commit_ms(s, 3)
+a, b = rate(s, bounce, False)
+rows.append(("  configs[4] scene and rays, RTC_BUILD_QUALITY_HIGH (spatial splits)", W.num_triangles(m), cq, "closest", a, b))
 s.release()
 
 print("| config | triangles | rtcCommitScene GPU ms | Mprims/s | query | Mrays/s, lone launches | Mrays/s, 4 launches in flight |")
