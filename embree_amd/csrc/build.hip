@@ -456,7 +456,8 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
   if (numSegs && sahBuild) {
     uint32_t sure = 1; while (sure < 40u && ((uint64_t)prm.small << sure) < n) sure++;   // the largest segment halves at best: that many levels exist
     if (fast) {                                                                             // + margin: SAH splits are uneven (crown: 17 levels where 13 are implied)
-      const uint32_t levels = learned ? min(sure + 8u, arena->learnedTop + 1u) : sure + 8u;   // (what the last commit of this size needed, + 1)
+      const uint32_t margin = spatial ? 10u : 8u;                                           // (spatial splits add references on the way down: the powerplant stand-in's HIGH tree has 25 levels where 16 are implied)
+      const uint32_t levels = learned ? min(sure + margin, arena->learnedTop + 1u) : sure + margin;   // (what the last commit of this size needed, + 1)
       for (uint32_t i = 0; i < levels; i++) enqueue_top_level();
     }
     else {
