@@ -75,104 +75,10 @@ __device__ __forceinline__ void runs_flush_wave(BinRuns& r, uint32_t* bins, uint
   for (int d = 0; d < 3; d++) runs_flush_axis(r, d, bins, lane);
 }
 
-// (A lane-private variant -- every lane keeps its OWN current bin per axis over triangles i, i + 64, ... -- measured 110 us per full pass of top_bin against 129 us
-// for the wave-uniform runs above and 92 us for the row aggregation below, which replaced it: profiles/r01_build_history.md.)
-
-// Row aggregation for top_bin: the 16 lanes of a DPP row hold 16 consecutive triangles, which sit in one bin per axis or straddle ONE bin
-// boundary (measured with cycle counters on the crown stand-in: consecutive triangles march along a ring of a sphere, 16 of them cover
-// about one bin width, so "everything in one bin" is the exception there).  A row therefore forms two groups, the lanes in its lowest and
-// in its highest bin, reduces each with four row_shr steps (result in lane 15 of the row) and that lane issues 7 atomics per group;
-// a lane strictly between the two, and rows holding the end of the chunk, go lane by lane.  At most 4 x 14 instead of 64 x 7 same-word
-// LDS atomics per axis and batch -- the atomics are what top_bin waits for (PMC: SQ_WAIT_INST_LDS 73 % of the wave cycles).
-// Row reductions (result in lane 15 of every row) with the DPP operand folded into the min / max (v_min_u32_dpp dst, dst, dst row_shr:k -- a lane without a
-// source keeps its value).  The compiler does not fold them: written with __builtin_amdgcn_update_dpp each step comes out as v_mov + v_mov_dpp + v_min and an s_nop (504 of the 656 VALU instructions top_bin
-// spends on a batch of 64 triangles, at 73 % VALU busy: profiles/r03_pmc_top_bin.md).  A DPP read needs two wait states after the VALU write of its
-// source; with several values in one block the other values' instructions are those wait states.
-__device__ __forceinline__ void row_minmax15(uint32_t& mn, uint32_t& mx) {                // both end up in lane 15 of every row
-  asm volatile("s_nop 1\n"
-               "v_min_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n v_max_u32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n s_nop 0\n"
-               "v_min_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n v_max_u32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n s_nop 0\n"
-               "v_min_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n v_max_u32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n s_nop 0\n"
-               "v_min_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n v_max_u32_dpp %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf\n"
-               : "+v"(mn), "+v"(mx));
-}
-// two boxes at once: a[0..2] / c[0..2] are reduced with min, a[3..5] / c[3..5] with max
-__device__ __forceinline__ void row_boxes15(uint32_t (&a)[6], uint32_t (&c)[6]) {
-#define MI355_STEP(S) \
-  "v_min_u32_dpp %0, %0, %0 row_shr:" #S " row_mask:0xf bank_mask:0xf\n v_min_u32_dpp %1, %1, %1 row_shr:" #S " row_mask:0xf bank_mask:0xf\n" \
-  "v_min_u32_dpp %2, %2, %2 row_shr:" #S " row_mask:0xf bank_mask:0xf\n v_max_u32_dpp %3, %3, %3 row_shr:" #S " row_mask:0xf bank_mask:0xf\n" \
-  "v_max_u32_dpp %4, %4, %4 row_shr:" #S " row_mask:0xf bank_mask:0xf\n v_max_u32_dpp %5, %5, %5 row_shr:" #S " row_mask:0xf bank_mask:0xf\n" \
-  "v_min_u32_dpp %6, %6, %6 row_shr:" #S " row_mask:0xf bank_mask:0xf\n v_min_u32_dpp %7, %7, %7 row_shr:" #S " row_mask:0xf bank_mask:0xf\n" \
-  "v_min_u32_dpp %8, %8, %8 row_shr:" #S " row_mask:0xf bank_mask:0xf\n v_max_u32_dpp %9, %9, %9 row_shr:" #S " row_mask:0xf bank_mask:0xf\n" \
-  "v_max_u32_dpp %10, %10, %10 row_shr:" #S " row_mask:0xf bank_mask:0xf\n v_max_u32_dpp %11, %11, %11 row_shr:" #S " row_mask:0xf bank_mask:0xf\n"
-  asm volatile("s_nop 1\n" MI355_STEP(1) MI355_STEP(2) MI355_STEP(4) MI355_STEP(8)
-               : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]));
-#undef MI355_STEP
-}
-__device__ __forceinline__ void bins_add_rows(uint32_t* bins, const Mapping& m, const PrimRef& p, bool valid, uint32_t lane) {
-  uint32_t c[6];
-  for (int k = 0; k < 3; k++) { c[k] = enc(p.lo[k]); c[3 + k] = enc(p.hi[k]); }
-  const unsigned long long vm = __ballot(valid);
-  const uint32_t rowBase = lane & 48u;
-  const bool rowFull = ((vm >> rowBase) & 0xFFFFull) == 0xFFFFull;          // all 16 lanes of my row hold a triangle
-#pragma unroll
-  for (int d = 0; d < 3; d++) {
-    const uint32_t b = valid ? (uint32_t)bin_clamped(p.lo[d] + p.hi[d], m.ofs[d], m.scale[d], m.nb) : 0u;
-    // the row's lowest and highest bin (lane 15 holds the reduction; everybody reads it from there)
-    uint32_t rmn = b, rmx = b; row_minmax15(rmn, rmx);
-    const uint32_t bmin = (uint32_t)__shfl((int)rmn, (int)(lane | 15u), 64), bmax = (uint32_t)__shfl((int)rmx, (int)(lane | 15u), 64);
-    const bool inLo = rowFull && b == bmin, inHi = rowFull && b == bmax && bmax != bmin;
-    // 16 consecutive triangles sit in one bin or straddle one boundary: two groups cover the row; a lane strictly between goes alone
-    uint32_t lo[6], hi[6];
-    for (int k = 0; k < 3; k++) { lo[k] = inLo ? c[k] : 0xFFFFFFFFu; lo[3 + k] = inLo ? c[3 + k] : 0u; hi[k] = inHi ? c[k] : 0xFFFFFFFFu; hi[3 + k] = inHi ? c[3 + k] : 0u; }
-    row_boxes15(lo, hi);
-    const uint32_t nLo = (uint32_t)__popcll((__ballot(inLo) >> rowBase) & 0xFFFFull), nHi = (uint32_t)__popcll((__ballot(inHi) >> rowBase) & 0xFFFFull);
-    if ((lane & 15u) == 15u && rowFull) {
-      uint32_t* e = bins + (d * NBINS + bmin) * BINW;
-      atomicMin(&e[0], lo[0]); atomicMin(&e[1], lo[1]); atomicMin(&e[2], lo[2]);
-      atomicMax(&e[3], lo[3]); atomicMax(&e[4], lo[4]); atomicMax(&e[5], lo[5]);
-      atomicAdd(&e[6], nLo);
-      if (nHi) {
-        uint32_t* f = bins + (d * NBINS + bmax) * BINW;
-        atomicMin(&f[0], hi[0]); atomicMin(&f[1], hi[1]); atomicMin(&f[2], hi[2]);
-        atomicMax(&f[3], hi[3]); atomicMax(&f[4], hi[4]); atomicMax(&f[5], hi[5]);
-        atomicAdd(&f[6], nHi);
-      }
-    }
-    bool alone = valid && !inLo && !inHi;
-    // where a bin is about as wide as a triangle (the lower levels) a row covers three or four bins and most of its lanes are "between": a second pair of
-    // groups -- the lowest and the highest bin of what is left -- takes them in (wave-uniform: only when at least eight lanes of the wave would go alone)
-    if (__popcll(__ballot(alone)) >= 8) {
-      const bool mid = rowFull && alone;
-      uint32_t r2n = mid ? b : 0xFFFFFFFFu, r2x = mid ? b : 0u; row_minmax15(r2n, r2x);
-      const uint32_t b2min = (uint32_t)__shfl((int)r2n, (int)(lane | 15u), 64), b2max = (uint32_t)__shfl((int)r2x, (int)(lane | 15u), 64);
-      const bool in2Lo = mid && b == b2min, in2Hi = mid && b == b2max && b2max != b2min;
-      uint32_t lo2[6], hi2[6];
-      for (int k = 0; k < 3; k++) { lo2[k] = in2Lo ? c[k] : 0xFFFFFFFFu; lo2[3 + k] = in2Lo ? c[3 + k] : 0u; hi2[k] = in2Hi ? c[k] : 0xFFFFFFFFu; hi2[3 + k] = in2Hi ? c[3 + k] : 0u; }
-      row_boxes15(lo2, hi2);
-      const uint32_t n2Lo = (uint32_t)__popcll((__ballot(in2Lo) >> rowBase) & 0xFFFFull), n2Hi = (uint32_t)__popcll((__ballot(in2Hi) >> rowBase) & 0xFFFFull);
-      if ((lane & 15u) == 15u && n2Lo) {
-        uint32_t* e = bins + (d * NBINS + b2min) * BINW;
-        atomicMin(&e[0], lo2[0]); atomicMin(&e[1], lo2[1]); atomicMin(&e[2], lo2[2]);
-        atomicMax(&e[3], lo2[3]); atomicMax(&e[4], lo2[4]); atomicMax(&e[5], lo2[5]);
-        atomicAdd(&e[6], n2Lo);
-        if (n2Hi) {
-          uint32_t* f = bins + (d * NBINS + b2max) * BINW;
-          atomicMin(&f[0], hi2[0]); atomicMin(&f[1], hi2[1]); atomicMin(&f[2], hi2[2]);
-          atomicMax(&f[3], hi2[3]); atomicMax(&f[4], hi2[4]); atomicMax(&f[5], hi2[5]);
-          atomicAdd(&f[6], n2Hi);
-        }
-      }
-      alone = alone && !in2Lo && !in2Hi;
-    }
-    if (alone) {
-      uint32_t* e = bins + (d * NBINS + b) * BINW;
-      atomicMin(&e[0], c[0]); atomicMin(&e[1], c[1]); atomicMin(&e[2], c[2]);
-      atomicMax(&e[3], c[3]); atomicMax(&e[4], c[4]); atomicMax(&e[5], c[5]);
-      atomicAdd(&e[6], 1u);
-    }
-  }
-}
+// History of top_bin's inner loop (profiles/r01_build_history.md): wave-uniform runs (above, still what one wavefront of small_build uses) 129 us per full pass;
+// a lane-private current bin per axis 110 us; DPP row aggregation -- the 16 lanes of a row form two groups, lowest and highest bin, reduced with row_shr steps, lane 15 issues the
+// atomics -- 92 us, 70 us with the DPP operands folded into v_min / v_max (round 3).  All of them pay ~100+ VALU instructions per reference and axis to keep lanes off the same word;
+// round 4 replaced them by private copies of the bins (below): ~52 us.
 
 // Private copies of the bins instead of combining lanes in registers: lane l of a wave bins into copy l mod BIN_COPIES, so consecutive references -- which share a bin more
 // often than not -- do not meet on a word, and an atomic instruction of 64 lanes finds at least BIN_COPIES different words on as many banks

@@ -180,53 +180,19 @@ __device__ __forceinline__ void spatial_chain(float (&v)[3][3], bool& have, cons
   if (EXTEND) sbin_extend(bins, d, bin, restLo, restHi);
   rr = rr < 0 ? 0 : rr; l = l > rr ? rr : l;                                       // degenerate pieces: still counted on one side of every plane
 }
-// References that lie in ONE bin of an axis (nearly all) are not sent to the LDS bins one by one: like top_bin (bins_add_rows), the 16 lanes of a DPP row
-// hold 16 consecutive references, which sit in one bin or straddle one boundary; the row's lowest and highest bin are reduced with row_shr steps and lane 15
-// issues the atomics of the two groups (same-word LDS atomics of a wave are executed one lane after the other: they are what binning waits for).
-__device__ __forceinline__ void sbins_add_rows(uint32_t* bins, int d, uint32_t b, bool simple, const uint32_t (&c)[6], uint32_t lane) {
-  const unsigned long long sm = __ballot(simple);
-  const uint32_t rowBase = lane & 48u;
-  const bool rowFull = ((sm >> rowBase) & 0xFFFFull) == 0xFFFFull;
-  const uint32_t bb = simple ? b : 0u;
-  uint32_t rmn = bb, rmx = bb; row_minmax15(rmn, rmx);
-  const uint32_t bmin = (uint32_t)__shfl((int)rmn, (int)(lane | 15u), 64), bmax = (uint32_t)__shfl((int)rmx, (int)(lane | 15u), 64);
-  const bool inLo = rowFull && bb == bmin, inHi = rowFull && bb == bmax && bmax != bmin;
-  uint32_t lo[6], hi[6];
-  for (int k = 0; k < 3; k++) { lo[k] = inLo ? c[k] : 0xFFFFFFFFu; lo[3 + k] = inLo ? c[3 + k] : 0u; hi[k] = inHi ? c[k] : 0xFFFFFFFFu; hi[3 + k] = inHi ? c[3 + k] : 0u; }
-  row_boxes15(lo, hi);
-  const uint32_t nLo = (uint32_t)__popcll((__ballot(inLo) >> rowBase) & 0xFFFFull), nHi = (uint32_t)__popcll((__ballot(inHi) >> rowBase) & 0xFFFFull);
-  if ((lane & 15u) == 15u && rowFull) {
-    uint32_t* e = bins + (d * SBINS + bmin);
-    atomicMin(&e[0], lo[0]); atomicMin(&e[SSLOTS], lo[1]); atomicMin(&e[2 * SSLOTS], lo[2]);
-    atomicMax(&e[3 * SSLOTS], lo[3]); atomicMax(&e[4 * SSLOTS], lo[4]); atomicMax(&e[5 * SSLOTS], lo[5]);
-    atomicAdd(&e[6 * SSLOTS], nLo); atomicAdd(&e[7 * SSLOTS], nLo);
-    if (nHi) {
-      uint32_t* f = bins + (d * SBINS + bmax);
-      atomicMin(&f[0], hi[0]); atomicMin(&f[SSLOTS], hi[1]); atomicMin(&f[2 * SSLOTS], hi[2]);
-      atomicMax(&f[3 * SSLOTS], hi[3]); atomicMax(&f[4 * SSLOTS], hi[4]); atomicMax(&f[5 * SSLOTS], hi[5]);
-      atomicAdd(&f[6 * SSLOTS], nHi); atomicAdd(&f[7 * SSLOTS], nHi);
-    }
-  }
-  if (simple && !inLo && !inHi) {
-    uint32_t* e = bins + (d * SBINS + b);
-    atomicMin(&e[0], c[0]); atomicMin(&e[SSLOTS], c[1]); atomicMin(&e[2 * SSLOTS], c[2]);
-    atomicMax(&e[3 * SSLOTS], c[3]); atomicMax(&e[4 * SSLOTS], c[4]); atomicMax(&e[5 * SSLOTS], c[5]);
-    atomicAdd(&e[6 * SSLOTS], 1u); atomicAdd(&e[7 * SSLOTS], 1u);
-  }
-}
 // The clipping chains are not run where they are found: a reference that spans several bins of an axis is the exception in a batch of 64, its chain is
 // up to 15 dependent cuts long, and a wave that runs it on the spot waits for its longest chain -- three times per batch, once per axis (spatial_bin was 8.2
 // of the 17.5 ms of a HIGH commit; parked chains: 7.0 of 16.4.  At the lower levels, where a bin is about as wide as a triangle, nearly every pair is a
-// chain and the LDS atomics of the pieces -- six per piece -- are what is left).  The (reference, axis) pairs go to a list in LDS instead, and once the chunk's simple references are binned the workgroup's 256 lanes take
-// one chain each.  What a chain adds to the bins is min / max / add atomics, so the bins do not depend on the order the chains are run in.
+// chain and the LDS atomics of the pieces -- six per piece -- are what is left).  The references that need clipping go to a list in LDS instead (round 4: one entry per reference with its axes, not one per (reference, axis) pair -- 8 KB instead of 24, and the vertices are
+// fetched once), and once the chunk's simple references are binned the workgroup's 256 lanes take one reference each.  What a chain adds to the bins is min / max / add atomics, so the bins do not depend on the order the chains are run in.
 #ifndef MI355_SBIN_COPIES
 #define MI355_SBIN_COPIES 8
 #endif
 constexpr uint32_t SBIN_COPIES = MI355_SBIN_COPIES, SCOPY_STRIDE = SBINS_WORDS + 1u;
-constexpr uint32_t CHAIN_CAP = 3u * CHUNK;                           // every (reference, axis) pair of a chunk fits
+constexpr uint32_t CHAIN_CAP = CHUNK;                                // every reference of a chunk fits (one task per reference: its axes in the top three bits)
 __global__ __launch_bounds__(256) void spatial_bin(const Seg* segs, const SegX* sx, const Chunk* chunks, const PrimRef* src, const GeomDesc* geoms, uint32_t* sbins, const Counters* ctr) {
   __shared__ uint32_t s_b[SBIN_COPIES * SCOPY_STRIDE];              // private copies of the bins, lane l works on copy l mod SBIN_COPIES (see bins_add_copies); folded below
-  __shared__ uint32_t s_chain[CHAIN_CAP];                           // reference index | axis << 30
+  __shared__ uint32_t s_chain[CHAIN_CAP];                           // reference index | axes to clip on << 29
   __shared__ uint32_t s_numChains;
   const uint32_t tid = threadIdx.x, lane = tid & 63u;
   const uint32_t numChunks = ctr->numChunks, c0 = blockIdx.x;
@@ -252,7 +218,7 @@ __global__ __launch_bounds__(256) void spatial_bin(const Seg* segs, const SegX* 
       const uint32_t i = i0 + lane; const bool v = i < spanEnd;
       PrimRef r{}; if (v) r = load_prim(src + i);
       const uint32_t budget = r.geom >> SPLIT_SHIFT;
-      uint32_t c6[6];
+      uint32_t c6[6], chainAxes = 0u;
       for (int k = 0; k < 3; k++) { c6[k] = enc(r.lo[k]); c6[3 + k] = enc(r.hi[k]); }
 #pragma unroll
       for (int d = 0; d < 3; d++) {
@@ -264,15 +230,7 @@ __global__ __launch_bounds__(256) void spatial_bin(const Seg* segs, const SegX* 
           else if (scale[d] != 0.0f) {
             const int l = sbin(r.lo[d], ofs[d], scale[d]), rr = sbin(r.hi[d], ofs[d], scale[d]);
             if (l == rr) { simple = true; b = (uint32_t)l; }
-            else {
-              const uint32_t slot = atomicAdd(&s_numChains, 1u);
-              if (slot < CHAIN_CAP) s_chain[slot] = (i - first) | ((uint32_t)d << 30);
-              else {                                              // (cannot happen with CHUNK = 2048; kept for other chunk sizes)
-                float tv[3][3]; bool have = false; int l2, r2;
-                spatial_chain<true>(tv, have, geoms, r, d, ofs[d], scale[d], inv[d], mine, l2, r2);
-                atomicAdd(&mine[6 * SSLOTS + d * SBINS + l2], 1u); atomicAdd(&mine[7 * SSLOTS + d * SBINS + r2], 1u);
-              }
-            }
+            else chainAxes |= 1u << d;
           }
         }
         if (simple) {
@@ -282,17 +240,27 @@ __global__ __launch_bounds__(256) void spatial_bin(const Seg* segs, const SegX* 
           atomicAdd(&e[6 * SSLOTS], 1u); atomicAdd(&e[7 * SSLOTS], 1u);
         }
       }
+      if (chainAxes) s_chain[atomicAdd(&s_numChains, 1u)] = (i - first) | (chainAxes << 29);   // (at most one per reference of the chunk: the list cannot overflow)
     }
   }
   __syncthreads();
   {
     const uint32_t numChains = min(s_numChains, CHAIN_CAP);
-    for (uint32_t t = tid; t < numChains; t += 256u) {
-      const uint32_t task = s_chain[t], d = task >> 30;
-      const PrimRef r = load_prim(src + first + (task & 0x3FFFFFFFu));
-      float tv[3][3]; bool have = false; int l2, r2;
-      spatial_chain<true>(tv, have, geoms, r, (int)d, sel3(d, ofs[0], ofs[1], ofs[2]), sel3(d, scale[0], scale[1], scale[2]), sel3(d, inv[0], inv[1], inv[2]), mine, l2, r2);
-      atomicAdd(&mine[6 * SSLOTS + d * SBINS + (uint32_t)l2], 1u); atomicAdd(&mine[7 * SSLOTS + d * SBINS + (uint32_t)r2], 1u);
+    // few references to clip (the upper levels: big triangles, chains of up to 15 cuts): a lane per (reference, axis), the chains of a reference side by side;
+    // many (the lower levels): a lane per reference, which fetches the vertices once (measured both ways on the crown and the powerplant stand-ins)
+    const bool perAxis = numChains * 3u <= 256u;
+    for (uint32_t t = tid; t < (perAxis ? numChains * 3u : numChains); t += 256u) {
+      const uint32_t entry = s_chain[perAxis ? t / 3u : t];
+      const uint32_t task = perAxis ? ((entry & 0x1FFFFFFFu) | (entry & (0x20000000u << (t % 3u)))) : entry;
+      const PrimRef r = load_prim(src + first + (task & 0x1FFFFFFFu));
+      float tv[3][3]; bool have = false;                         // (the vertices are fetched once for all axes of the reference: one task per (reference, axis) fetched them up to three times)
+#pragma unroll
+      for (uint32_t d = 0; d < 3u; d++) {
+        if (!((task >> (29u + d)) & 1u)) continue;
+        int l2, r2;
+        spatial_chain<true>(tv, have, geoms, r, (int)d, ofs[d], scale[d], inv[d], mine, l2, r2);
+        atomicAdd(&mine[6 * SSLOTS + d * SBINS + (uint32_t)l2], 1u); atomicAdd(&mine[7 * SSLOTS + d * SBINS + (uint32_t)r2], 1u);
+      }
     }
   }
   __syncthreads();
