@@ -1,6 +1,7 @@
 """CPU-side checks of the drop-in boundary: the C-ABI library loads without a GPU and exports every symbol the
 headers declare; struct layouts match the reference's default ABI; no compute calls here."""
 import ctypes
+import ctypes as C
 import os
 import re
 import subprocess
@@ -65,6 +66,27 @@ int main(void) {
     assert vals == ["48", "48", "96", "336", "672", "1344", "32", "48", "20", "28", "32", "32", "64", str(0x9003), str(0x5003), "0"], vals
     from embree_amd.rtypes import RAY_DTYPE, RAYHIT_DTYPE
     assert RAY_DTYPE.fields["tfar"][1] == 32 and RAYHIT_DTYPE.fields["Ng_x"][1] == 48 and RAYHIT_DTYPE.fields["primID"][1] == 68
+
+
+def test_kernel_abi_structs_match_their_ctypes_mirrors(tmp_path):
+    """include/embree_amd_hip.h is valid C, and the structs the ctypes mirror (embree_amd/api.py) hands to it have the header's sizes and field offsets --
+    mi355_bvh_info grew in round 4 (build_attempts): a mirror that lags behind would let the library write past the Python object."""
+    src = tmp_path / "kabi.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include <stddef.h>
+#include <embree_amd_hip.h>
+int main(void) {
+  printf("%zu %zu %zu %zu %zu %zu\n", sizeof(mi355_bvh_info), offsetof(mi355_bvh_info, build_ms), offsetof(mi355_bvh_info, bytes_refit),
+         offsetof(mi355_bvh_info, num_launches), offsetof(mi355_bvh_info, build_attempts), sizeof(mi355_build_params));
+  return 0; }''')
+    exe = tmp_path / "kabi"
+    subprocess.check_call(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    vals = [int(v) for v in subprocess.check_output([str(exe)]).decode().split()]
+    from embree_amd import api
+    I = api.BvhInfo
+    assert vals[:5] == [C.sizeof(I), I.build_ms.offset, I.bytes_refit.offset, I.num_launches.offset, I.build_attempts.offset], (vals, C.sizeof(I))
+    assert vals[5] == C.sizeof(api.BuildParams), (vals[5], C.sizeof(api.BuildParams))
 
 
 def test_header_against_real_reference_header(tmp_path):
