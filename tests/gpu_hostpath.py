@@ -16,7 +16,8 @@ from embree_amd.rtypes import rays_of                             # noqa: E402
 meshes = W.synthetic_crown()
 rays = None
 ref = None
-for cfg in ("host_pipeline_min=4000000000", "host_in_place=1", "host_pipeline_chunk=65536", "host_pipeline_chunk=131072", "host_pipeline_chunk=262144", "host_pipeline_chunk=524288"):
+CONFIGS = ("host_pipeline_min=4000000000", "host_in_place=1", "host_pipeline_chunk=65536", "host_pipeline_chunk=131072", "host_pipeline_chunk=262144", "host_pipeline_chunk=524288")
+for cfg in (sys.argv[1:] or CONFIGS):                          # (configs on the command line: only those)
     dev = api.Device(cfg)
     s = api.Scene(dev)
     for v, t in meshes:
