@@ -25,6 +25,7 @@ struct TraceScratch {
   void* pkt = nullptr; size_t pktCap = 0;    // AoS staging of the packet entry points (grows on demand)
   uint32_t* defer = nullptr; size_t deferCap = 0;   // RTC_RAY_QUERY_FLAG_COHERENT: [0] = number of packets the packet kernel gave up on, [64 ...] = their indices (grows on demand)
   volatile uint32_t* statusHost = nullptr;   // pinned host memory the kernels raise their "work was dropped" words in (iteration cap, stack overflow) ...
+  uint32_t divergeStreak = 0;                // packet samples in a row (large coherent queries on this (tree, stream)) that said "the packets do not stay together"
   uint32_t coherentCalls = 0;                // large RTC_RAY_QUERY_FLAG_COHERENT queries that skipped the packet sample since the last one that took it
   volatile uint32_t* statusDev = nullptr;    // ... and its device address
 };

@@ -1139,9 +1139,16 @@ static int launch_trace_coherent(Bvh* b, void* d_rays, uint32_t count, size_t st
   // (crown stand-in, primary rays: the sample launch, the list of packets that gave up and the indirection through it cost 10 % of the per-lane rate).  Then
   // this query goes to the per-lane kernel as it is; every 16th one is sampled again (a camera that moved into the open keeps its packets).  Results do not
   // depend on the path.
+  // (Only after THREE samples in a row said so -- a sample that finds its packets together resets the count: an application that alternates coherent and incoherent
+  // batches on one scene keeps sampling, because sending a coherent batch to the per-lane kernel costs far more than a sample does.)
   static const bool remember = env_u32("MI355_PACKET_REMEMBER", 1, 0, 1) != 0u;
-  if (remember && packets >= 1024u && packets >= 4u * PACKET_SAMPLE && sc->statusHost[STATUS_COHERENT] == 2u && (++sc->coherentCalls & 15u) != 0u)
-    return launch_trace_locked(b, sc, d_rays, count, stride, any, s, nullptr, nullptr, nullptr);
+  static const uint32_t sampleMin = env_u32("MI355_PACKET_SAMPLE_MIN", 1024, 0, 0x7FFFFFFF);   // packets: smaller batches are traced in one launch
+  if (remember && packets >= sampleMin && packets >= 4u * PACKET_SAMPLE) {
+    const uint32_t said = sc->statusHost[STATUS_COHERENT];     // the last sampled launch's verdict, once it has run (0: not yet, or taken already)
+    if (said) { sc->statusHost[STATUS_COHERENT] = 0u; sc->divergeStreak = said == 2u ? sc->divergeStreak + 1u : 0u; }
+    if (sc->divergeStreak >= 3u && (++sc->coherentCalls & 15u) != 0u)
+      return launch_trace_locked(b, sc, d_rays, count, stride, any, s, nullptr, nullptr, nullptr);
+  }
   {
     if (sc->deferCap < need) {                                  // (stream order keeps earlier launches' use of the old list apart: wait for them before it goes)
       if (sc->defer) { HIP_TRY(hipStreamSynchronize(s)); HIP_TRY(hipFree(sc->defer)); sc->defer = nullptr; sc->deferCap = 0; }
@@ -1154,7 +1161,6 @@ static int launch_trace_coherent(Bvh* b, void* d_rays, uint32_t count, size_t st
     a.nodes = (const uint4*)b->d_nodes; a.tris = (const float4*)b->d_tris; a.hasRoot = b->root != MI355_EMPTY_REF ? 1u : 0u;
     a.rays = (char*)d_rays; a.count = count; a.stride = (uint32_t)stride; a.deferCount = defer; a.deferList = defer + 64; a.status = sc->statusDev; a.rules = (const uint4*)b->d_rules;
     static const uint32_t minLanes = env_u32("MI355_PACKET_MIN_LANES", 48, 0, 64);
-    static const uint32_t sampleMin = env_u32("MI355_PACKET_SAMPLE_MIN", 1024, 0, 0x7FFFFFFF);   // packets: smaller batches are traced in one launch
     a.minServed = 4u * minLanes;
     a.verdictAbove = 0xFFFFFFFFu;
     if (packets >= sampleMin && packets >= 4u * PACKET_SAMPLE) {

@@ -560,9 +560,9 @@ def test_high_quality_commits_of_the_crown_are_bit_identical(api, dev):
 
 
 def test_coherent_flag_with_a_remembered_sample(api, dev):
-    """Large RTC_RAY_QUERY_FLAG_COHERENT batches whose packets do not stay together: the first query samples every 32nd packet, the next ones remember what it
-    said and go to the per-lane kernel as they are (launch_trace_coherent); coherent batches on the same scene in between still take the packet kernel.
-    Same bytes every time."""
+    """Large RTC_RAY_QUERY_FLAG_COHERENT batches whose packets do not stay together: a query samples every 32nd packet; once three samples in a row have said
+    "they fall apart" the next queries go to the per-lane kernel as they are (launch_trace_coherent), every 16th samples again, and a sample that finds its
+    packets together (the primary rays in between) starts the count anew.  Same bytes every time, whichever path a query took."""
     meshes = W.synthetic_crown(num_phi=48)
     s = api.make_scene(dev, meshes)
     prim = W.crown_camera_rays(meshes, 512, 512)
@@ -570,7 +570,7 @@ def test_coherent_flag_with_a_remembered_sample(api, dev):
     bounce = W.diffuse_bounce_rays(want, meshes)[:200_000]
     wantB = bounce.copy(); s.intersect1M(wantB)
     args = api.QueryArguments(flags=api.RTC_RAY_QUERY_FLAG_COHERENT)
-    for rep in range(20):                                         # (more than 16: one of them samples again)
+    for rep in range(40):                                         # (three samples, then skipping, a sample again after 16, coherent batches in between)
         src, w = (bounce, wantB) if rep % 5 != 4 else (prim, want)
         g = src.copy(); s.intersect1M(g, args)
         assert g.tobytes() == w.tobytes(), "repetition %d" % rep
