@@ -16,6 +16,11 @@ HEADERS = ["bvh_common.h", "internal.h", "../../include/embree4/rtcore.h", "../.
            "build_morton.inl", "build_wide.inl", "build_leaves.inl"]    # parts of build.hip (one translation unit)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden",
          "-Wall", "-Wno-unused-function", "-Wno-unused-variable", "-Wno-unused-value", "-Wno-unused-result"]
+# per-source flags.  trace.hip: the SLP vectoriser pairs scalar fp32 operations of the node set-up and of the triangle test into v_pk_mul / v_pk_add / v_pk_fma_f32 and
+# pays for it with v_mov (to bring operands into adjacent registers) and v_and (|x| has no packed form) -- on gfx950 a packed fp32 instruction issues in the time of two
+# scalar ones (profiles/r02_valu_issue_costs.txt), so the pairs buy nothing and the moves cost: +3.7 % rays per second without it (profiles/r05_trace.md).  The packed
+# FMAs of the slab test are written by hand (test4) and stay.  Same arithmetic either way (-ffp-contract=off): results are bit-identical.
+EXTRA_FLAGS = {"trace.hip": ["-fno-slp-vectorize"]}
 
 
 def _stale():
@@ -34,7 +39,7 @@ def build(force=False, verbose=False):
     objs = []
     for src in SOURCES:
         obj = os.path.join(LIBDIR, src + ".o")
-        cmd = [hipcc, "-x", "hip"] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc, "-x", "hip"] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

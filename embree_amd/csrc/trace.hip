@@ -54,8 +54,14 @@ __device__ __forceinline__ float rcp_nr(float a) {  // v_rcp_f32 + one Newton st
   float r = __builtin_amdgcn_rcpf(a);
   return fmaf(r, fmaf(-a, r, 1.0f), r);
 }
+// set bits of a lane mask below this lane: v_mbcnt_lo + v_mbcnt_hi (the compiler does not find them in popcount(m & ((1 << lane) - 1)): two v_and + two v_bcnt and two registers for the constant)
+__device__ __forceinline__ uint32_t rank_below(unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
 __device__ __forceinline__ float xor_sign(float a, uint32_t s) { return __uint_as_float(__float_as_uint(a) ^ s); }
 #define MI355_UNDEF4(n) asm volatile("" : "=v"(n.x), "=v"(n.y), "=v"(n.z), "=v"(n.w))
+// "all four words of this load are used": the plain kernels read only e2.z and the mask from a triangle record's third 16 bytes, and the compiler then fetches them as TWO
+// one-word loads -- four (lane, load) pairs per triangle test instead of three, on a kernel that runs into the CU's address path once its instruction count is down (round 5:
+// 352 -> 306 lane-accesses per ray, profiles/r05_trace.md)
+#define MI355_KEEP4(n) asm volatile("" : "+v"(n.x), "+v"(n.y), "+v"(n.z), "+v"(n.w))
 template <int J> __device__ __forceinline__ float ubyte(uint32_t w) { return (float)((w >> (8 * J)) & 0xFFu); }   // v_cvt_f32_ubyteJ
 
 struct TraceArgs {
@@ -88,6 +94,25 @@ struct TraceArgs {
 // the reference's own fast mode loses 55 of 2^20 hits that its robust mode finds; this test loses none (tests/test_gpu_round2.py).
 typedef float f2 __attribute__((ext_vector_type(2)));   // v_pk_fma_f32: two fp32 FMAs per VALU issue on gfx950
 struct SlabCoef { f2 sxy, szx, syz, bxy, bzx, byz; };  // plane distance = q * scale + base, paired (near x, near y) (near z, far x) (far y, far z)
+// (round 5) Lane masks of the node step in SGPR pairs, selects in the VOP3 form, the hit word's shifts as SDWA instructions that pick their bytes themselves:
+// the compiler spent v_bfe + v_lshrrev + v_lshlrev per child on what v_lshlrev_b32_sdwa does in one (205 -> 199 VALU instructions per node step, +0.6 %).
+// (The VOP2 form of v_cndmask with its implicit VCC measures 23 cycles in tools/valu_bench.hip when nothing writes VCC -- and 4.3 like every other form behind a
+// v_cmp, which is how the node step uses it: profiles/r05_valu_issue_costs.txt.  No gain from avoiding VCC; the SGPR pairs only keep VCC free for the scheduler.)
+#ifndef MI355_SEL_SGPR
+#define MI355_SEL_SGPR 1
+#endif
+typedef unsigned long long lanemask_t;
+__device__ __forceinline__ lanemask_t cmp_neg_s(float a) { lanemask_t m; asm("v_cmp_gt_f32_e64 %0, 0, %1" : "=s"(m) : "v"(a)); return m; }   // a < 0
+__device__ __forceinline__ lanemask_t cmp_le_s(float a, float b) { lanemask_t m; asm("v_cmp_le_f32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b)); return m; }
+__device__ __forceinline__ uint32_t sel_s(uint32_t ifClear, uint32_t ifSet, lanemask_t m) { uint32_t r; asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(ifClear), "v"(ifSet), "s"(m)); return r; }
+__device__ __forceinline__ uint32_t sel0_s(uint32_t ifSet, lanemask_t m) { uint32_t r; asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(ifSet), "s"(m)); return r; }
+// byte J of `bits` shifted left by the low five bits of byte J of `index`
+#define MI355_SHL_BYTES(J, DST, INDEX, BITS) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_" #J " src1_sel:BYTE_" #J : "=v"(DST) : "v"(INDEX), "v"(BITS))
+#if MI355_SEL_SGPR
+#define MI355_CHILD_HIT(J) { uint32_t sh; MI355_SHL_BYTES(J, sh, bitIndex4, childBits4); hits |= sel0_s(sh, cmp_le_s(tN, tF)); }
+#else
+#define MI355_CHILD_HIT(J) { const uint32_t cb = (childBits4 >> (8 * J)) & 0xFFu, bi = (bitIndex4 >> (8 * J)) & 0x1Fu; hits |= (tN <= tF) ? (cb << bi) : 0u; }
+#endif
 __device__ __forceinline__ uint32_t test4(uint32_t nx, uint32_t ny, uint32_t nz, uint32_t fx, uint32_t fy, uint32_t fz, uint32_t meta4,
                                           uint32_t octinv4, const SlabCoef& k, float tmin0, float tmax0) {
   // meta byte: inner = 001 11sss (bits 3 and 4 set), leaf = ccc ooooo with offset <= 23, empty = 0
@@ -105,8 +130,7 @@ __device__ __forceinline__ uint32_t test4(uint32_t nx, uint32_t ny, uint32_t nz,
     c = __builtin_elementwise_fma(c, k.syz, k.byz);   /* tfy, tfz */                                           \
     const float tN = fmaxf(fmaxf(a.x, a.y), fmaxf(b.x, tmin0));                                                \
     const float tF = fminf(fminf(b.y, c.x), fminf(c.y, tmax0));                                                \
-    const uint32_t cb = (childBits4 >> (8 * J)) & 0xFFu, bi = (bitIndex4 >> (8 * J)) & 0x1Fu;                  \
-    hits |= (tN <= tF) ? (cb << bi) : 0u;                                                                      \
+    MI355_CHILD_HIT(J)                                                                                         \
   }
   MI355_CHILD(0) MI355_CHILD(1) MI355_CHILD(2) MI355_CHILD(3)
 #undef MI355_CHILD
@@ -133,8 +157,7 @@ __device__ __forceinline__ uint32_t test4_robust(uint32_t nx, uint32_t ny, uint3
     const float tfx = (fmaf(ubyte<J>(fx), scx, nox) - ox) * rfx, tfy = (fmaf(ubyte<J>(fy), scy, noy) - oy) * rfy, tfz = (fmaf(ubyte<J>(fz), scz, noz) - oz) * rfz; \
     const float tN = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, tmin0));                                                \
     const float tF = fminf(fminf(tfx, tfy), fminf(tfz, tmax0));                                                \
-    const uint32_t cb = (childBits4 >> (8 * J)) & 0xFFu, bi = (bitIndex4 >> (8 * J)) & 0x1Fu;                  \
-    hits |= (tN <= tF) ? (cb << bi) : 0u;                                                                      \
+    MI355_CHILD_HIT(J)                                                                                         \
   }
   MI355_CHILD(0) MI355_CHILD(1) MI355_CHILD(2) MI355_CHILD(3)
 #undef MI355_CHILD
@@ -260,7 +283,8 @@ constexpr int QSTACK_LDS = MI355_QSTACK_LDS;   // stack entries per lane in LDS
 #define MI355_QCAP 256
 #endif
 constexpr uint32_t QCAP = MI355_QCAP;      // ring capacity (pairs) per wave
-constexpr uint32_t PUSH_ROUNDS_DEFAULT = 5;  // triangle bits a lane may queue per iteration (the rest waits one iteration; env MI355_PUSH_ROUNDS)
+constexpr uint32_t PUSH_ROUNDS_DEFAULT = 8;  // triangle bits a lane may queue per iteration (the rest waits one iteration: the lane cannot open a node; env MI355_PUSH_ROUNDS).  5 while every
+                                             // bit cost the wave a queueing round; with the scan of step 5 a lane with more bits costs only its own loop passes (lanes blocked 7 % -> 2 %)
 constexpr uint32_t NUM_CURSORS = 8;        // ray cursors per launch (one per XCD)
 constexpr uint32_t CURSOR_STRIDE = 64;     // words between cursors: each one in its own 256-byte block
 constexpr uint32_t EXIT_WORD = NUM_CURSORS * CURSOR_STRIDE;   // behind the cursors: waves of the running launch that have left (the last one zeroes the cursors for the next launch)
@@ -270,6 +294,9 @@ constexpr uint32_t EXIT_WORD = NUM_CURSORS * CURSOR_STRIDE;   // behind the curs
 #endif
 #ifndef MI355_TRI_PREFETCH
 #define MI355_TRI_PREFETCH 1
+#endif
+#ifndef MI355_PUSH_SCAN
+#define MI355_PUSH_SCAN 1
 #endif
 constexpr uint32_t NO_INST = 0xFFFFFFFFu;
 // InstanceIntersector1 (kernels/geometry/instance_intersector.cpp:26-31): org' = xfmPoint(world2local, org), dir' = xfmVector(world2local, dir),
@@ -310,7 +337,7 @@ __device__ __forceinline__ void setup_rdir(float dx, float dy, float dz, float& 
 template <bool ANY, bool STATS, bool ROBUST, bool INST, bool FILT>
 __global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceArgs a) {
   __shared__ uint2 s_stack[BLOCK / 64][QSTACK_LDS][64];
-  __shared__ uint2 s_queue[BLOCK / 64][QCAP];
+  __shared__ __attribute__((aligned(QCAP * 8))) uint2 s_queue[BLOCK / 64][QCAP];   // (aligned to its size: a ring position is one v_and away from its address)
   __shared__ unsigned long long s_best[BLOCK / 64][64];
   __shared__ uint32_t s_pend[BLOCK / 64][64], s_lastT[BLOCK / 64][64];   // per ray slot: helper sub-trees in flight, last ring ticket pushed by helpers
   __shared__ uint2 s_done[BLOCK / 64][INST ? 96 : 64];                    // finished closest-hit rays {ray index, winning triangle}: their hit records are written 64 at a time (flush_done);
@@ -403,7 +430,7 @@ __global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceAr
     if (pre) {
       pe = queue[(qHead + lane) & (QCAP - 1u)];
       const float4* tp = a.tris + (size_t)pe.x * 3u;
-      pq0 = tp[0]; pq1 = tp[1]; pq2 = tp[2];
+      pq0 = tp[0]; pq1 = tp[1]; pq2 = tp[2]; MI355_KEEP4(pq2);
     }
     // ------------------------------------------------------------------ 1. retire finished rays, hand out new ones
     // Ray indices are handed out in blocks of G = refillMin consecutive rays.  Block B belongs to cursor B % numCursors, so
@@ -434,7 +461,7 @@ __global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceAr
             const uint32_t k = (uint32_t)__popcll(hm);
             if (dCount + k > 64u) flush_done();                  // room for this batch (wave-uniform)
             if (hasHit) {
-              const uint32_t pos = dCount + (uint32_t)__popcll(hm & ((1ull << lane) - 1ull));
+              const uint32_t pos = dCount + rank_below(hm);
               done[pos] = make_uint2(rayIdx, htri);
               if (INST) doneInst[pos] = bestInst;
             }
@@ -466,7 +493,7 @@ __global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceAr
                 if (++dryCursors >= a.numCursors) exhausted = true;
                 continue;
               }
-              const uint32_t rank = (uint32_t)__popcll(freeLanes & ((1ull << lane) - 1ull));
+              const uint32_t rank = rank_below(freeLanes);
               const uint32_t myRay = ((((base + (rank >> a.gShift)) << a.cShift) + cursor) << a.gShift) + (rank & (G - 1u));   // block rank / G of this grab, ray rank % G of it
               got = ((freeLanes >> lane) & 1ull) != 0ull && rank < (take << a.gShift) && myRay < rayCount;
               if (got && a.deferList) { const uint32_t q = myRay; newIdx = a.deferList[q >> 6] * 64u + (q & 63u); got = newIdx < a.count; }   // (the last packet of a batch may be ragged)
@@ -518,12 +545,11 @@ __global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceAr
       const unsigned long long giveM = __ballot(canGive);
       if (freeM != 0ull && giveM != 0ull) {
         helpersUsed = true;
-        const unsigned long long lt = (1ull << lane) - 1ull;
         const uint32_t k = min((uint32_t)__popcll(freeM), (uint32_t)__popcll(giveM));
-        const bool gives = canGive && (uint32_t)__popcll(giveM & lt) < k;
+        const bool gives = canGive && rank_below(giveM) < k;
         uint2 e = make_uint2(0u, 0u);
         if (gives) { sp--; e = stk[sp * 64u]; }
-        const uint32_t rf = (uint32_t)__popcll(freeM & lt);
+        const uint32_t rf = rank_below(freeM);
         const bool takes = !active && rf < k;
         // lane of the rf-th giver: rf-th set bit of giveM
         uint32_t n = takes ? rf : 0u, pos = 0u, w = (uint32_t)giveM, c = (uint32_t)__popc(w);
@@ -669,7 +695,7 @@ __global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceAr
       if (mine) {
         float4 q0, q1, q2;
         if (usePre) { q0 = pq0; q1 = pq1; q2 = pq2; }
-        else { const float4* tp = a.tris + (size_t)e.x * 3u; q0 = tp[0]; q1 = tp[1]; q2 = tp[2]; }
+        else { const float4* tp = a.tris + (size_t)e.x * 3u; q0 = tp[0]; q1 = tp[1]; q2 = tp[2]; MI355_KEEP4(q2); }
         if (STATS) stTris++;
         const uint32_t tmask = __float_as_uint(q2.w);
         TriOut w;
@@ -694,10 +720,17 @@ __global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceAr
       const float ady = __uint_as_float(((n0.w >> 8) & 0xFFu) << 23) * rdy;
       const float adz = __uint_as_float(((n0.w >> 16) & 0xFFu) << 23) * rdz;
       const float bx = (__uint_as_float(n0.x) - ox) * rdx, by = (__uint_as_float(n0.y) - oy) * rdy, bz = (__uint_as_float(n0.z) - oz) * rdz;
+#if MI355_SEL_SGPR
+      const lanemask_t sx = cmp_neg_s(rdx), sy = cmp_neg_s(rdy), sz = cmp_neg_s(rdz);
+      const uint32_t nx0 = sel_s(n2.x, n3.z, sx), nx1 = sel_s(n2.y, n3.w, sx), fx0 = sel_s(n3.z, n2.x, sx), fx1 = sel_s(n3.w, n2.y, sx);
+      const uint32_t ny0 = sel_s(n2.z, n4.x, sy), ny1 = sel_s(n2.w, n4.y, sy), fy0 = sel_s(n4.x, n2.z, sy), fy1 = sel_s(n4.y, n2.w, sy);
+      const uint32_t nz0 = sel_s(n3.x, n4.z, sz), nz1 = sel_s(n3.y, n4.w, sz), fz0 = sel_s(n4.z, n3.x, sz), fz1 = sel_s(n4.w, n3.y, sz);
+#else
       const bool sx = rdx < 0.0f, sy = rdy < 0.0f, sz = rdz < 0.0f;
       const uint32_t nx0 = sx ? n3.z : n2.x, nx1 = sx ? n3.w : n2.y, fx0 = sx ? n2.x : n3.z, fx1 = sx ? n2.y : n3.w;
       const uint32_t ny0 = sy ? n4.x : n2.z, ny1 = sy ? n4.y : n2.w, fy0 = sy ? n2.z : n4.x, fy1 = sy ? n2.w : n4.y;
       const uint32_t nz0 = sz ? n4.z : n3.x, nz1 = sz ? n4.w : n3.y, fz0 = sz ? n3.x : n4.z, fz1 = sz ? n3.y : n4.w;
+#endif
       const float tmax0 = fmaxf(tfar, 0.0f);
       uint32_t hits;
       if (ROBUST) {
@@ -732,7 +765,40 @@ __global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceAr
       if (!active) stIdle++; else if (travDone) { if ((int)(qHead - lastTicket) >= 0) stWaitBatch++; else stWaitDrain++; } else if (!doNode) stBlocked++;
     }
 
-    // ------------------------------------------------------------------ 5. queue triangle bits: one pair per lane and round
+    // ------------------------------------------------------------------ 5. queue triangle bits
+#if MI355_PUSH_SCAN
+    // Every lane queues its triangle bits (at most pushRounds of them per iteration) behind those of the lanes below it: the places come from ONE inclusive prefix scan over
+    // the wave (six DPP adds).  Before, a round queued one pair per lane -- ballot, popcount, rank, ~15 wave instructions -- and some lane holds five or more bits in nearly
+    // every iteration: 5 rounds = 74 of the ~420 VALU instructions of an iteration, each serving ~14 lanes (profiles/r05_trace.md).  The loop below is 8 per pair of the busiest lane.
+    // The order of the pairs in the ring changes (lane by lane instead of round by round); the result is the minimum over all candidates whatever the order.
+    {
+      const bool has = tgHits != 0u && (!INST || inst != NO_INST);       // only active, traversing lanes hold triangle bits (INST: in world space they are instances, see 2b)
+      if (__ballot(has) != 0ull) {
+        uint32_t c = has ? min((uint32_t)__popc(tgHits), a.pushRounds) : 0u;
+        uint32_t incl = c;
+        asm volatile("s_nop 1\n v_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n s_nop 1\n v_add_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n"
+                     "s_nop 1\n v_add_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n s_nop 1\n v_add_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n"
+                     "s_nop 1\n v_add_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n s_nop 1\n v_add_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n s_nop 1\n" : "+v"(incl));
+        uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        const uint32_t room = QCAP - (qTail - qHead);
+        if (total > room) {                                               // rare (launch start: 64 rays meet the same first leaves): the lanes whose pairs still fit queue theirs, the
+          const uint32_t m = (uint32_t)__popcll(__ballot(incl <= room));  // others wait -- incl grows with the lane number, so those are lanes 0 .. m - 1.  (All or nothing would be a
+          total = m != 0u ? (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)(m - 1u)) : 0u;   // deadlock: a ring below 64 pairs is not drained while lanes traverse.)  m == 0: the ring
+          if (lane >= m) c = 0u;                                          // holds more than 250 pairs and step 4 of the next iteration drains it.
+        }
+        uint32_t p8 = (qTail + incl - c) << 3;                            // byte position of this lane's first pair (the ring is aligned to its size: one v_and per address)
+        if (c != 0u) lastTicket = qTail + incl;                           // one behind this lane's last pair
+#pragma unroll 1
+        for (uint32_t k = c; k != 0u; k--) {
+          const uint32_t bitk = (uint32_t)__builtin_ctz(tgHits);
+          tgHits &= tgHits - 1u;
+          *(uint2*)((char*)queue + (p8 & (QCAP * 8u - 1u))) = make_uint2(tgBase + bitk, owner);
+          p8 += 8u;
+        }
+        qTail += total;
+      }
+    }
+#else
     for (uint32_t r = 0; r < a.pushRounds; r++) {
       const bool has = tgHits != 0u && (!INST || inst != NO_INST);       // only active, traversing lanes hold triangle bits (INST: in world space they are instances, see 2b)
       const unsigned long long m = __ballot(has);
@@ -742,12 +808,13 @@ __global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceAr
       if (has) {
         const uint32_t k = (uint32_t)__builtin_ctz(tgHits);
         tgHits &= tgHits - 1u;
-        const uint32_t pos = qTail + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        const uint32_t pos = qTail + rank_below(m);
         queue[pos & (QCAP - 1u)] = make_uint2(tgBase + k, owner);
         lastTicket = pos + 1u;
       }
       qTail += n;
     }
+#endif
   }
 
   if (!ANY && dCount != 0u) flush_done();                        // the last finished rays
@@ -815,7 +882,7 @@ __global__ __launch_bounds__(64) void trace_packet_kernel(PacketTraceArgs a) {
       uint32_t base = 0u;
       if (lane == 0u) base = atomicAdd(a.deferCount, (uint32_t)__popcll(mm));
       base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-      if (mine) a.deferList[base + (uint32_t)__popcll(mm & ((1ull << lane) - 1ull))] = pk;
+      if (mine) a.deferList[base + rank_below(mm)] = pk;
     }
     return;
   }
