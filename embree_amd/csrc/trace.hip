@@ -430,7 +430,7 @@ __global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceAr
     if (pre) {
       pe = queue[(qHead + lane) & (QCAP - 1u)];
       const float4* tp = a.tris + (size_t)pe.x * 3u;
-      pq0 = tp[0]; pq1 = tp[1]; pq2 = tp[2]; MI355_KEEP4(pq2);
+      pq0 = tp[0]; pq1 = tp[1]; pq2 = tp[2];                               // (all of pq2: MI355_KEEP4 where it is consumed, step 4 -- here it would wait for the load)
     }
     // ------------------------------------------------------------------ 1. retire finished rays, hand out new ones
     // Ray indices are handed out in blocks of G = refillMin consecutive rays.  Block B belongs to cursor B % numCursors, so
@@ -602,7 +602,10 @@ __global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceAr
           if (sp != 0u) {
             sp--;
             uint2 e = stk[min(sp, (uint32_t)(QSTACK_LDS - 1)) * 64u];
-            if (__builtin_expect(sp >= (uint32_t)QSTACK_LDS, 0)) e = spill[sp - QSTACK_LDS];
+            // (an LDS read of its own: the compiler otherwise selects between the two ADDRESSES and issues one flat_load -- slower than ds_read for the LDS case, and a flat
+            // load is waited for with vmcnt(0), i.e. together with the triangle records step 0 has just asked for: their round trip no longer overlapped steps 2 - 3a)
+            asm volatile("" : "+v"(e.x), "+v"(e.y));
+            if (__builtin_expect(sp >= (uint32_t)QSTACK_LDS, 0)) { e = spill[sp - QSTACK_LDS]; asm volatile("" : "+v"(e.x), "+v"(e.y)); }   // (waited for in here, not with vmcnt(0) where the paths join)
             if (INST && e.y <= 0x00FFFFFFu) { tgBase = e.x; tgHits = e.y; }   // instances of a top node that are still to be visited
             else { ngBase = e.x; ngHits = e.y; }
           } else finished = true;
@@ -650,8 +653,8 @@ __global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceAr
 
     // ------------------------------------------------------------------ 3a. node step, first half: pick the child, issue its loads
     const bool doNode = active && !travDone && tgHits == 0u && ngHits > 0x00FFFFFFu;
-    uint4 n0, n1, n2, n3, n4;                                   // only read under doNode: tell the compiler they are "defined"
-    MI355_UNDEF4(n0); MI355_UNDEF4(n1); MI355_UNDEF4(n2); MI355_UNDEF4(n3); MI355_UNDEF4(n4);   // (20 v_mov per iteration otherwise)
+    uint4 n0, n1, n2, n3, n4;
+    uint32_t nodeIdx = 0u;                                      // (lanes that open no node fetch the root: see below)
     if (doNode) {
       const uint32_t bit = 31u - (uint32_t)__clz((int)ngHits);
       ngHits &= ~(1u << bit);
@@ -664,8 +667,15 @@ __global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceAr
       }
       const uint32_t slot = (bit ^ octinv4) & 7u;
       const uint32_t rel = (uint32_t)__popc(ngHits & ~(0xFFFFFFFFu << slot));
-      const uint4* np = a.nodes + (size_t)(ngBase + rel) * 5u;
-      n0 = np[0]; n1 = np[1]; n2 = np[2]; n3 = np[3]; n4 = np[4];   // issued here, consumed after the triangle block: one memory round trip per iteration
+      nodeIdx = ngBase + rel;
+    }
+    // The five node loads are issued here and consumed in 3b, behind the triangle block -- by EVERY lane, whether it opens a node or not: s_waitcnt counts loads, not
+    // registers, so the triangle block can only wait for "all but the five youngest loads" (= its prefetched records, step 0) if those five are issued on every path.  Under
+    // `if (doNode)` the compiler has to assume they may be missing and waits with vmcnt(0): the node round trip then started only behind the triangle tests (rounds 1 - 4).
+    // (a lane without a node reads the root: 64 lanes, one address)
+    {
+      const uint4* np = a.nodes + (size_t)nodeIdx * 5u;
+      n0 = np[0]; n1 = np[1]; n2 = np[2]; n3 = np[3]; n4 = np[4];
     }
 
     // ------------------------------------------------------------------ 4. test queued pairs (queued in earlier iterations), 64 at a time (fewer only when nothing else can run)
@@ -677,8 +687,8 @@ __global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceAr
       if (count < 64u && anyTraversing && (!INST || (uint32_t)__popcll(__ballot(waitDrain)) < a.drainWaiters)) break;   // INST: lanes that wait to leave an instance force a partial batch
       const uint32_t n = min(count, 64u);
       const bool mine = lane < n;
-      uint2 e;
-      if (usePre) e = pe; else e = queue[(qHead + (mine ? lane : 0u)) & (QCAP - 1u)];
+      if (!usePre) pe = queue[(qHead + (mine ? lane : 0u)) & (QCAP - 1u)];
+      const uint2 e = pe;
       const int owner = (int)e.y;
       // the owner's ray (all 64 lanes execute the permutes; lanes without a pair read pair 0's owner and drop the result)
       const float gox = __shfl(ox, owner, 64), goy = __shfl(oy, owner, 64), goz = __shfl(oz, owner, 64);
@@ -692,10 +702,10 @@ __global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceAr
       const float gtfar0 = __shfl(tfar0, owner, 64);
       const uint32_t ginst = (INST && FILT) ? (uint32_t)__shfl((int)inst, owner, 64) : NO_INST;   // (rules of an instanced scene's geometries sit behind that instance's base)
       if (STATS && lane == 0u) stTriBlk++;
-      if (mine) {
-        float4 q0, q1, q2;
-        if (usePre) { q0 = pq0; q1 = pq1; q2 = pq2; }
-        else { const float4* tp = a.tris + (size_t)e.x * 3u; q0 = tp[0]; q1 = tp[1]; q2 = tp[2]; MI355_KEEP4(q2); }
+      // (two copies of the test, one per source of the record: where the paths joined the registers were merged with v_mov -- and the compiler's s_waitcnt at the join has
+      // to serve both: vmcnt(0).  Apart, the prefetched path waits for "all but the five node loads of 3a", the other one for its own loads.)
+      auto test_pair = [&](const float4 q0, const float4 q1, float4 q2) {
+        MI355_KEEP4(q2);
         if (STATS) stTris++;
         const uint32_t tmask = __float_as_uint(q2.w);
         TriOut w;
@@ -708,6 +718,15 @@ __global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceAr
           ok = rule_accepts<ANY, ROBUST>(a.rules, ri, q0, q1, q2, w.t, gox, goy, goz, gdx, gdy, gdz);
         }
         if (ok) atomicMin(&best[owner], ((unsigned long long)__float_as_uint(w.t + 0.0f) << 32) | e.x);   // + 0: a hit at -0 must not sort as a huge key
+      };
+      if (mine) {
+        if (usePre) { asm volatile("; prefetched records"); test_pair(pq0, pq1, pq2); }
+        else {                                                            // a second batch in one iteration, or a partial one: no prefetch
+          asm volatile("; records fetched here");
+          const float4* tp = a.tris + (size_t)e.x * 3u;
+          const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
+          test_pair(q0, q1, q2);
+        }
       }
       qHead += n; usePre = false;
     }
