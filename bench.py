@@ -322,6 +322,9 @@ def main():
     ap.add_argument("--dump-rays", type=int, default=1 << 22)
     ap.add_argument("--inprocess-gpus", type=int, default=0, help="extra leg at N = 1: rtcIntersect1M through ONE RTCDevice over this many GPUs (0 = all GPUs of the node, 1 = skip; "
                                                                     "more than the node has = replicas share GPUs)")
+    ap.add_argument("--scaling", default="both", choices=["weak", "both"], help="crown at N > 1: `value` is always the WEAK-scaling figure (2^20 rays per GPU and step); `both` adds the strong-scaling "
+                                                                               "leg (ONE 2^20-ray batch sharded over the N GPUs, gathered to rank 0) as `strong`")
+    ap.add_argument("--sustain", type=float, default=6.0, help="seconds of back-to-back batches after the timed region (rank 0, N = 1): long enough for a 5-second utilisation sampler to see the GPU busy; 0 = skip")
     ap.add_argument("--scene", default="", help=".ecs / .xml / .obj scene file; default: $EMBREE_MODEL_DIR/crown/crown.ecs if it exists, "
                                                  "else the synthetic crown stand-in")
     args = ap.parse_args()
@@ -480,7 +483,7 @@ def main():
         alg_bytes = M * 48 + nhit * 52 + st["nodes"] * 80 + st["tris"] * 48
 
     # ---- RCCL: communicator + result buffers (shadow16m: used inside the timed region; crown: exercised after it)
-    comm, comm_err, packed, gathered = None, None, None, None
+    comm, comm_err = None, None
     pack_bytes = M * (4 if shadow else 32)
     if use_rccl:
         res = run_guarded(lambda: shard.Communicator(gpu, rank, world, dist[0] if dist else None), 120)
@@ -497,26 +500,74 @@ def main():
         if ok < 1.0 and comm is not None:
             comm.close()
             comm, comm_err = None, comm_err or "another rank has no communicator"
-        if comm is not None:
-            # two result buffers: the gather of batch k runs on the communication stream while batch k + 1 is traced and packed
-            packed = [api.DeviceArray(pack_bytes, gpu) for _ in range(2)]
-            gathered = [api.DeviceArray(pack_bytes * world if (shadow or rank == 0) else 16, gpu) for _ in range(2)]
     gather_in_step = comm is not None and (shadow or world > 1 or args.gather == "rccl")
-    comm_stream, ev_packed, ev_gathered, step_no = None, None, None, [0]
+    comm_stream = None
     if gather_in_step:
         cs = C.c_void_p()
         assert L.mi355_stream_create(gpu, C.byref(cs)) == 0, L.mi355_last_error()
         comm_stream = cs
-        ev_packed, ev_gathered = [C.c_void_p() for _ in range(2)], [C.c_void_p() for _ in range(2)]
-        for e in ev_packed + ev_gathered:
-            assert L.mi355_event_create(C.byref(e)) == 0
 
+    class Stepper:
+        """One pass of the hot path over one batch of `m` rays: trace; with a communicator also pack the written fields and gather them over RCCL -- the gather of THIS
+        batch runs on the communication stream and overlaps the trace of the NEXT one (the trace kernels themselves still run one at a time on `stream`).  Two result
+        buffers: the pack of batch k + 2 waits for the gather of batch k.  Every gather is bracketed by events on the communication stream (gather_ms)."""
+
+        def __init__(self, m, max_steps):
+            self.m, self.pack_bytes, self.step_no, self.gather_ev = m, m * (4 if shadow else 32), 0, []
+            self.packed = self.gathered = self.ev_packed = self.ev_gathered = None
+            if gather_in_step:
+                self.packed = [api.DeviceArray(self.pack_bytes, gpu) for _ in range(2)]
+                self.gathered = [api.DeviceArray(self.pack_bytes * world if (shadow or rank == 0) else 16, gpu) for _ in range(2)]
+                self.ev_packed, self.ev_gathered = [C.c_void_p() for _ in range(2)], [C.c_void_p() for _ in range(2)]
+                for e in self.ev_packed + self.ev_gathered:
+                    assert L.mi355_event_create(C.byref(e)) == 0
+                self.pool = [C.c_void_p() for _ in range(2 * max_steps)]
+                for e in self.pool:
+                    assert L.mi355_event_create(C.byref(e)) == 0
+
+        def collective(self, k):
+            if shadow:
+                comm.allgather(self.packed[k].ptr, self.gathered[k].ptr, self.pack_bytes, comm_stream)
+            else:
+                comm.gather(self.packed[k].ptr, self.gathered[k].ptr, self.pack_bytes, 0, comm_stream)
+
+        def __call__(self, buf, stream, ev_a=None, ev_b=None, timed=False):
+            rc = L.mi355_trace_timed(bvh, buf.ptr, self.m, rec, any_hit, stream, ev_a, ev_b)
+            assert rc == 0, L.mi355_last_error()
+            if gather_in_step:
+                k = self.step_no & 1
+                if self.step_no >= 2:                            # the result buffer of batch k - 2 must have left before it is packed over
+                    assert L.mi355_stream_wait_event(stream, self.ev_gathered[k]) == 0
+                pack = L.mi355_pack_occluded if shadow else L.mi355_pack_hits
+                assert pack(buf.ptr, self.m, rec, self.packed[k].ptr, stream) == 0, L.mi355_last_error()
+                assert L.mi355_event_record(self.ev_packed[k], stream) == 0
+                assert L.mi355_stream_wait_event(comm_stream, self.ev_packed[k]) == 0
+                g0 = g1 = None
+                if timed and 2 * len(self.gather_ev) + 1 < len(self.pool):
+                    g0, g1 = self.pool[2 * len(self.gather_ev)], self.pool[2 * len(self.gather_ev) + 1]
+                    self.gather_ev.append((g0, g1))
+                    assert L.mi355_event_record(g0, comm_stream) == 0
+                self.collective(k)
+                if g1 is not None:
+                    assert L.mi355_event_record(g1, comm_stream) == 0
+                assert L.mi355_event_record(self.ev_gathered[k], comm_stream) == 0
+                self.step_no += 1
+
+        def gather_ms(self):
+            """milliseconds each timed collective spent on the communication stream (from the moment its packed block was ready: includes waiting for the slowest peer)"""
+            out_ = []
+            for g0, g1 in self.gather_ev:
+                v = C.c_float()
+                L.mi355_event_elapsed_ms(g0, g1, C.byref(v))
+                out_.append(v.value)
+            self.gather_ev = []
+            return out_
+
+    step = Stepper(M, 2 * (args.steps + args.warmup) + 64)
+    if gather_in_step:
         # one collective on trial before anything is timed: a gather that never completes (a link that does not come up) must cost the line its gather, not the line
         def trial():
-            if shadow:
-                comm.allgather(packed[0].ptr, gathered[0].ptr, pack_bytes, comm_stream)
-            else:
-                comm.gather(packed[0].ptr, gathered[0].ptr, pack_bytes, 0, comm_stream)
+            step.collective(0)
             deadline = time.time() + 90
             while L.mi355_stream_query(comm_stream) == 1:
                 if time.time() > deadline:
@@ -534,26 +585,6 @@ def main():
             log("rank %d: %s: results stay in the per-rank buffers" % (rank, comm_err))
             gather_in_step, comm = False, None                # (the communicator is left alone: destroying one with a collective in flight can hang as well)
 
-    def step(buf, stream, ev_a=None, ev_b=None):
-        """one pass of the hot path over one batch: trace; with a communicator also pack the written fields and gather them over RCCL -- the gather of THIS batch
-        runs on the communication stream and overlaps the trace of the NEXT one (the trace kernels themselves still run one at a time on `stream`)"""
-        rc = L.mi355_trace_timed(bvh, buf.ptr, M, rec, any_hit, stream, ev_a, ev_b)
-        assert rc == 0, L.mi355_last_error()
-        if gather_in_step:
-            k = step_no[0] & 1
-            if step_no[0] >= 2:                              # the result buffer of batch k - 2 must have left before it is packed over
-                assert L.mi355_stream_wait_event(stream, ev_gathered[k]) == 0
-            pack = L.mi355_pack_occluded if shadow else L.mi355_pack_hits
-            assert pack(buf.ptr, M, rec, packed[k].ptr, stream) == 0, L.mi355_last_error()
-            assert L.mi355_event_record(ev_packed[k], stream) == 0
-            assert L.mi355_stream_wait_event(comm_stream, ev_packed[k]) == 0
-            if shadow:
-                comm.allgather(packed[k].ptr, gathered[k].ptr, pack_bytes, comm_stream)
-            else:
-                comm.gather(packed[k].ptr, gathered[k].ptr, pack_bytes, 0, comm_stream)
-            assert L.mi355_event_record(ev_gathered[k], comm_stream) == 0
-            step_no[0] += 1
-
     for st_ in streams:                                     # per-stream traversal scratch exists before anything is timed (also when --warmup 0)
         assert L.mi355_trace_prepare(bvh, st_) == 0, L.mi355_last_error()
     for i in range(args.warmup):
@@ -566,13 +597,14 @@ def main():
     L.mi355_device_synchronize(gpu)
     t0 = time.perf_counter()
     for k in range(args.steps):
-        step(bufs[args.warmup + k], tstreams[k % len(tstreams)], ev.ev[2 * k], ev.ev[2 * k + 1])
+        step(bufs[args.warmup + k], tstreams[k % len(tstreams)], ev.ev[2 * k], ev.ev[2 * k + 1], timed=True)
     L.mi355_device_synchronize(gpu)
     barrier()
     elapsed = max_over_ranks(time.perf_counter() - t0)
     # ================================================================================================
     kernel_ms = [ev.ms(k) for k in range(args.steps)]
     ev.free()
+    gather_ms = step.gather_ms() if gather_in_step else []
     for st_ in tstreams:
         assert scene.trace_status(st_) == 0, "a traversal safety net dropped work"
     # every timed buffer must hold the same answer as the counting run (same rays, same tree)
@@ -581,7 +613,8 @@ def main():
     gather_check = None
     if gather_in_step:
         L.mi355_synchronize(comm_stream)
-        last = (step_no[0] - 1) & 1                        # the result buffer the last timed batch was gathered into
+        last = (step.step_no - 1) & 1                      # the result buffer the last timed batch was gathered into
+        gathered = step.gathered
         if shadow:                                         # every rank holds all shards: rank r's part must be what rank r computed
             g = gathered[last].download(np.uint32).reshape(world, M)
             assert (g[rank] == result["tfar"].view(np.uint32)).all(), "gathered shard differs from the local result"
@@ -613,6 +646,67 @@ def main():
             gather_check = dict(transport="RCCL ncclGather of the packed hit records (32 B per ray) to rank 0 over xGMI, on a communication stream: the gather of batch k overlaps the trace "
                                           "of batch k + 1", inside_timed_region=True, bytes_per_rank=pack_bytes, bytes_into_root_per_step=pack_bytes * (world - 1),
                                 checked="every rank's block on the root against that rank's own checksums (primID sum, tfar-bits sum, hit count)")
+
+    # ---- N > 1, crown: the other reading of "1M incoherent diffuse rays at 1/2/4/8 GPUs" -- ONE 2^20-ray batch sharded N ways (strong scaling), gather to rank 0 in the step
+    strong = None
+    if not shadow and world > 1 and args.scaling == "both":
+        all_rays = W.diffuse_bounce_rays(traced, meshes, seed=1)          # rank 0's batch, the same on every rank (seeded)
+        Ms = all_rays.shape[0] // world                                  # (equal shards: RCCL's gather takes one size; a remainder below N rays is dropped and named)
+        shard_rays = all_rays[rank * Ms:(rank + 1) * Ms].copy()
+        sp_ = api.DeviceArray.from_numpy(shard_rays, gpu)
+        nst = args.steps
+        sbufs = [api.DeviceArray(shard_rays.nbytes, gpu) for _ in range(nst + 4)]
+        for b in sbufs:
+            L.mi355_memcpy_d2d_async(b.ptr, sp_.ptr, shard_rays.nbytes, streams[0])
+        L.mi355_synchronize(streams[0])
+        sstep = Stepper(Ms, 2 * (nst + 4) + 8)
+        for i in range(4):
+            sstep(sbufs[nst + i], tstreams[0])
+        L.mi355_device_synchronize(gpu)
+        sev = Events(L, nst)
+        barrier()
+        L.mi355_device_synchronize(gpu)
+        t1 = time.perf_counter()
+        for k in range(nst):
+            sstep(sbufs[k], tstreams[0], sev.ev[2 * k], sev.ev[2 * k + 1], timed=True)
+        L.mi355_device_synchronize(gpu)
+        barrier()
+        sel = max_over_ranks(time.perf_counter() - t1)
+        sk = [sev.ms(k) for k in range(nst)]
+        sev.free()
+        sg = sstep.gather_ms() if gather_in_step else []
+        want_ = shard_rays.copy()                                        # this rank's shard must be what a lone trace of the same rays gives (same tree on every rank)
+        chk = api.DeviceArray.from_numpy(want_, gpu)
+        scene.intersect1M_device(chk.ptr, Ms)
+        L.mi355_device_synchronize(gpu)
+        assert sbufs[0].download(dtype).tobytes() == chk.download(dtype).tobytes(), "strong-scaling shard differs from a lone trace of the same rays"
+        chk.free()
+        strong = dict(value=round(Ms * world * nst / sel / 1e6, 2), unit="Mrays/s", scaling="strong", rays_total=Ms * world, rays_per_gpu=Ms, steps=nst, ms_per_step=round(1e3 * sel / nst, 4),
+                      trace_ms=round(float(np.mean(sk)), 4), gather_ms=round(float(np.mean(sg)), 4) if sg else None,
+                      gather_bound=bool(sg and float(np.mean(sg)) > 0.9 * (1e3 * sel / nst)) if sg else None,
+                      what="ONE batch of %d incoherent diffuse rays cut into %d contiguous shards, every shard traced on its own GPU, the packed hit records gathered to rank 0 over RCCL inside "
+                           "the step (the gather of batch k overlaps the trace of batch k + 1); whole-job rays per second, max over ranks" % (Ms * world, world))
+        for b in sbufs:
+            b.free()
+        sp_.free()
+
+    # ---- a leg long enough for an outside sampler (the driver polls utilisation every few seconds; the timed region is 15 ms): the same batches back to back for --sustain seconds
+    sustained = None
+    if not shadow and world == 1 and rank == 0 and args.sustain > 0:
+        nsu = min(len(bufs), 32)
+        t1 = time.perf_counter()
+        launches_ = 0
+        while time.perf_counter() - t1 < args.sustain:
+            for b in bufs[:nsu]:
+                L.mi355_memcpy_d2d_async(b.ptr, pristine.ptr, rays.nbytes, tstreams[0])
+                assert L.mi355_trace_closest(bvh, b.ptr, M, rec, tstreams[0]) == 0, L.mi355_last_error()
+            L.mi355_synchronize(tstreams[0])
+            launches_ += nsu
+        sdt = time.perf_counter() - t1
+        assert bufs[0].download(dtype).tobytes() == result.tobytes()
+        sustained = dict(seconds=round(sdt, 2), launches=launches_, value=round(M * launches_ / sdt / 1e6, 1), unit="Mrays/s",
+                         what="the timed batches again, back to back on one stream for %.0f s, each behind a device-to-device copy that restores its rays (the copies are inside this figure): "
+                              "not the metric -- a leg long enough for a utilisation sampler to see the GPU at work" % args.sustain)
 
     # ---- extra legs, outside the timed region --------------------------------------------------------------------------------------
     pipelined = None
@@ -648,8 +742,13 @@ def main():
             scene.intersect1M(h)
             times.append(time.perf_counter() - t1)
         assert h.tobytes() == result.tobytes()
+        link = (C.c_double * 3)()
+        link_ok = L.mi355_measure_host_link(gpu, rays.nbytes, 3, link) == 0 and link[2] > 0
         e2e = dict(value=round(M / min(times) / 1e6, 1), unit="Mrays/s", ms=round(1e3 * min(times), 3),
-                   what="rtcIntersect1M on a pageable host array of %d RTCRayHit: pin + H2D (96 MB) + kernel + D2H (96 MB), pipelined in chunks; best of 3" % M)
+                   link_floor_ms=round(link[2], 3) if link_ok else None, frac_of_link_floor=round(link[2] / (1e3 * min(times)), 3) if link_ok else None,
+                   link_GBs={"upload": round(link[0], 1), "download": round(link[1], 1)} if link_ok else None,
+                   what="rtcIntersect1M on a pageable host array of %d RTCRayHit: pin + H2D (96 MB) + kernel + D2H (96 MB), pipelined in chunks; best of 3.  link_floor_ms = the same bytes "
+                        "up from and down to PINNED host memory, both directions at once and nothing else (mi355_measure_host_link): what the host link allows" % M)
     latency = None
     if not shadow and rank == 0:                           # the per-ray entry points are "not the measured path and the report must say so": what one call costs
         one = rays[:1].copy()
@@ -756,13 +855,27 @@ def main():
                                                      "(~4 cycles per wave instruction: tools/valu_bench.hip; clock = kernel cycles of the PMC run / duration of a lone launch, capped at 2.4 GHz)"}
         else:
             roof["pmc_note"] = pmc_note
+        # rtcCommitScene against ITS roofline: bytes the build algorithm has to move -- vertices + indices in and references out (primref_gen), every level of
+        # the binary binned-SAH build reads the references once to bin them and once to partition them and writes them once (32 B each way), the wide nodes and the
+        # leaf records are written once, the leaf records gather their vertices again -- over the GPU time of the commit.  Levels = log2(leaves): what a balanced tree needs.
+        b_levels = float(np.log2(max(2, info["num_leaves"])))
+        b_bytes = ntri * (48 + 32) + b_levels * ntri * 96.0 + info["num_nodes"] * 80 + ntri * (48 + 48)
+        b_s = float(np.min(build_ms)) * 1e-3
+        build_roof = {"bound": "hbm on paper; measured: LDS atomics and wave-instruction issue of the many small sets (profiles/r05_pmc_small_build.md)", "algorithmic_bytes": int(b_bytes),
+                      "achieved": round(b_bytes / b_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(b_bytes / b_s / 1e9 / HBM_PEAK_GBS, 4),
+                      "frac_of_copy": round(b_bytes / b_s / 1e9 / bw[0], 4) if bw_ok and bw[0] > 0 else None, "dominant_kernel": "small_build",
+                      "how": "triangles x (48 read + 32 written) + log2(leaves) = %.1f levels x triangles x (32 binned + 32 read + 32 written) + nodes x 80 + triangles x (48 gathered + 48 written), "
+                             "over the fastest of the timed commits; traffic of the commit as the counters see it: profiles/" % b_levels}
         out = {
             "metric": ("Mrays/s (shadow rays, any-hit) on crown, 16 Mi rays sharded" if shadow else
                        "Mrays/s (incoherent diffuse, closest-hit) on crown" + (", %d batches of 2^20 rays in flight (one batch at a time: serial.value)" % len(tstreams) if len(tstreams) > 1 else "")
                        + ((", hits packed and gathered to rank 0 over RCCL inside the step" if gather_in_step else ", NO gather (RCCL communicator unavailable)") if world > 1 else "")),
             "value": round(value, 2), "unit": "Mrays/s",
             "n_gpus": world, "ranks": world, "distinct_gpus": min(world, ngpu), "rccl_ranks": (world if comm is not None else 0), "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
-            "higher_is_better": True, "scaling": "strong" if shadow else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic" if not scene_path else "file",
+            "higher_is_better": True, "scaling": "strong" if shadow else "weak",
+            "scaling_is": ("strong: the 16 Mi shadow rays of configs[3] are one job cut over the ranks" if shadow else
+                           "weak: every GPU traces its own 2^20-ray batch per step (value = all of them per second); the strong-scaling figure of ONE 2^20-ray batch cut N ways is `strong`" if world > 1 else
+                           "N = 1 (both readings coincide)"), "vs_baseline": None, "dtype": "f32", "data": "synthetic" if not scene_path else "file",
             "config": {"workload": ("configs[3]: %s, %d triangles, %d shadow rays (16 per hit point) in total, %d per GPU, rtcOccluded1MDevice, rays + BVH resident in HBM, results %s"
                                     % (scene_name, ntri, total_rays, M, "packed and all-gathered over RCCL" if comm is not None else "left in the per-rank buffers")) if shadow else
                                    ("configs[2]: %s, %d triangles, %d geometries, %d incoherent diffuse-bounce rays per GPU and step, closest-hit, rays + BVH resident in HBM, %s"
@@ -771,7 +884,7 @@ def main():
                        "parallelism": "rays sharded x%d, BVH replicated (deterministic build on every rank), %s" % (world, ("RCCL all-gather of the 4-byte results" if shadow else "RCCL gather of the packed 32-byte hit records to rank 0") + " inside the step, on a communication stream (overlaps the next batch's trace)" if gather_in_step else "no collective inside the step"),
                        "device_config": args.config},
             "roofline": roof,
-            "build": {"metric": "BVH build Mprims/s", "gpu_build_ms": round(float(np.min(build_ms)), 3), "gpu_build_ms_median": round(float(np.median(build_ms)), 3),
+            "build": {"metric": "BVH build Mprims/s", "roofline": build_roof, "gpu_build_ms": round(float(np.min(build_ms)), 3), "gpu_build_ms_median": round(float(np.median(build_ms)), 3),
                       "mprims_per_s_gpu": round(ntri / (float(np.min(build_ms)) * 1e-3) / 1e6, 1),
                       "commit_wall_ms": round(1e3 * float(np.min(commit_wall)), 3), "commit_wall_ms_median": round(1e3 * float(np.median(commit_wall)), 3),
                       "mprims_per_s_commit": round(ntri / float(np.min(commit_wall)) / 1e6, 1), "reps": "1 warm-up + %d timed (buildbench_device.cpp:385-387)" % len(build_ms),
@@ -787,6 +900,16 @@ def main():
         }
         if pipelined:
             out["pipelined" if npipe > 1 else "serial"] = pipelined
+        if strong:
+            out["strong"] = strong
+        if sustained:
+            out["sustained"] = sustained
+        if gather_in_step and gather_ms:
+            out["step_timing"] = {"trace_ms": round(avg_ms, 4), "gather_ms": round(float(np.mean(gather_ms)), 4), "gather_ms_max": round(float(np.max(gather_ms)), 4),
+                                  "ms_per_step": round(1e3 * elapsed / args.steps, 4), "gather_bound": bool(float(np.mean(gather_ms)) > 0.9 * (1e3 * elapsed / args.steps)),
+                                  "what": "per timed step on rank 0: the trace kernel (HIP events on the launch stream) and the collective (HIP events on the communication stream, from the moment the "
+                                          "packed block was ready: includes waiting for the slowest peer).  gather_bound: the collective takes more than 0.9 of a step -- the pack of batch k + 2 "
+                                          "waits for the gather of batch k, so the line is then the link's, not the kernel's"}
         if e2e:
             out["end_to_end"] = e2e
         if latency:

@@ -67,8 +67,20 @@ struct Arena {
   uint32_t marginFailedN = 0;                                // a commit of this many triangles outgrew the level margins of the one-round-trip path: the next one goes stepwise at once
   // What the last one-round-trip commit of a scene of this many triangles needed: its top-phase levels and the depth of its wide tree.  The next commit of the
   // same size (a scene re-committed every frame) enqueues those + 1 instead of the blind margins (levels N implies + 8, 16 wide levels): every level that does
-  // not exist still costs its launches (~4.7 us each, ~35 of the 169 of a crown commit).  A commit that outgrows the learned counts forgets them and runs again.
-  uint32_t learnedN = 0, learnedTop = 0, learnedWide = 0, learnedChunked = 0, learnedLocalFirst = 0;
+  // not exist still costs its launches (~4.7 us each, ~35 of the 169 of a crown commit).  A commit that outgrows the learned counts runs again with the blind margins.
+  // (round 5) The counts are kept PER KIND of commit -- triangle count, geometry count, build parameters (quality, spatial, leaf sizes, outlier cut ...) -- not per
+  // triangle count alone: bench.py commits its scene MEDIUM, then HIGH, then MEDIUM again, and every other commit found the counts of the other quality, failed and ran
+  // twice.  Within a kind the counts only GROW (maximum of what the commits of that kind needed; first top_local level: minimum): two scenes of one kind that need different
+  // depths, committed in turn, cost the shallower one a few empty launches instead of costing the deeper one a second commit every time.
+  struct Learned { uint64_t kind = 0; uint32_t top = 0, wide = 0, chunked = 0, localFirst = 255u; uint64_t used = 0; };
+  Learned learned[8]; uint64_t learnedClock = 0;               // (eight kinds per device, the least recently used one is replaced)
+  Learned* find_learned(uint64_t kind) { for (auto& l : learned) if (l.kind == kind && l.top != 0u) { l.used = ++learnedClock; return &l; } return nullptr; }
+  void learn(uint64_t kind, uint32_t top, uint32_t wide, uint32_t chunked, uint32_t localFirst) {
+    Learned* l = find_learned(kind);
+    if (!l) { l = &learned[0]; for (auto& c : learned) if (c.used < l->used) l = &c; *l = Learned(); l->kind = kind; }
+    l->top = top > l->top ? top : l->top; l->wide = wide > l->wide ? wide : l->wide; l->chunked = chunked > l->chunked ? chunked : l->chunked;
+    l->localFirst = localFirst < l->localFirst ? localFirst : l->localFirst; l->used = ++learnedClock;
+  }
   void drop_graph() { if (graphExec) { hipGraphExecDestroy(graphExec); graphExec = nullptr; } graphKey.clear(); }
   void reset() { for (auto& b : blocks) b.used = 0; }
   hipError_t take(size_t bytes, void** out) {
@@ -234,7 +246,14 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
   }
   const bool useGraph = fast && envGraph && st != nullptr && !arena->graphBroken;
   static const bool envLearn = !(getenv("MI355_BUILD_LEARN") && atoi(getenv("MI355_BUILD_LEARN")) == 0);
-  const bool learned = fast && allowLearned && envLearn && arena->learnedN == N && arena->learnedTop != 0u;
+  // the kind of this commit (see Arena::Learned): FNV-1a over everything that shapes the launch sequence
+  uint64_t kind = 1469598103934665603ull;
+  { auto mix = [&](uint64_t v) { for (int i = 0; i < 8; i++) { kind ^= (v >> (8 * i)) & 0xFFu; kind *= 1099511628211ull; } };
+    uint32_t pw[sizeof(Params) / 4]; memcpy(pw, &prm, sizeof(prm)); for (uint32_t w : pw) mix(w);
+    mix(N); mix(numMeshes); mix(bp->robust); mix(bp->presplits); mix(bp->refit); mix(topSplits ? 1u : 0u); }
+  const Arena::Learned* const lc = (fast && allowLearned && envLearn) ? arena->find_learned(kind) : nullptr;
+  const bool learned = lc != nullptr;
+  const uint32_t learnedTop = lc ? lc->top : 0u, learnedWide = lc ? lc->wide : 0u, learnedChunked = lc ? lc->chunked : 0u, learnedLocalFirst = lc ? lc->localFirst : 0u;
   uint32_t launches = 0, syncs = 0;
   bool replay = false, capturing = false;                       // fast path: the launches below are replayed from the cached graph / are being captured into one
   // MI355_BUILD_DEBUG=1: every launch is named on stderr and waited for (finds the kernel behind a device fault; use with MI355_BUILD_GRAPH=0)
@@ -285,7 +304,7 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
     const void* ptrs[] = {dGeoms.p, bufA.p, bufB.p, finalIds.p, bnodes.p, segs0.p, segs1.p, bins.p, chunks.p, small.p, ctr.p, w0.p, w1.p, wnodes.p, outIds.p, plans.p, itemCnt.p, groupSum.p, tileCount.p, chunkCnt.p, chunkBase.p, segx0.p, segx1.p, sbins.p, outlierCnt.p, outlierTile.p, outlierTotal.p, outlierWork.p, (const void*)st};
     std::vector<uint64_t> key; for (const void* q : ptrs) key.push_back((uint64_t)(uintptr_t)q);
     uint32_t pw[sizeof(Params) / 4]; memcpy(pw, &prm, sizeof(prm)); for (uint32_t w : pw) key.push_back(w);
-    key.push_back(N); key.push_back(gd.size()); key.push_back(bp->robust); key.push_back(spatialMin); key.push_back(NC); { uint32_t w; memcpy(&w, &topSplitRel, 4); key.push_back(w); memcpy(&w, &topSplitCell, 4); key.push_back(w); } key.push_back(topSplits ? 1u : 0u); key.push_back(learned ? (arena->learnedTop << 8) | arena->learnedWide : 0u); key.push_back(learned ? (arena->learnedChunked << 8) | (arena->learnedLocalFirst & 0xFFu) : 0u);
+    key.push_back(N); key.push_back(gd.size()); key.push_back(bp->robust); key.push_back(spatialMin); key.push_back(NC); { uint32_t w; memcpy(&w, &topSplitRel, 4); key.push_back(w); memcpy(&w, &topSplitCell, 4); key.push_back(w); } key.push_back(topSplits ? 1u : 0u); key.push_back(learned ? (learnedTop << 8) | learnedWide : 0u); key.push_back(learned ? (learnedChunked << 8) | (learnedLocalFirst & 0xFFu) : 0u);
     if (arena->graphExec && arena->graphKey == key) replay = true;
     else {
       arena->drop_graph(); arena->graphKey = key;
@@ -429,8 +448,8 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
     // sets of at most CHUNK references are one workgroup's (top_local); the others go through the chunked path.  A commit that knows the last commit of
     // this size enqueues only what that one needed (+ a level of margin either way): the chunked path up to its last level with a large set, top_local
     // from its first level with a small one.  A large set where no chunked path was enqueued raises overflow 3: the commit runs again, blind.
-    const bool local = !spatial && (!learned || level + 1u >= arena->learnedLocalFirst);
-    const bool chunked = !local || !learned || level <= arena->learnedChunked;
+    const bool local = !spatial && (!learned || level + 1u >= learnedLocalFirst);
+    const bool chunked = !local || !learned || level <= learnedChunked;
     const uint32_t localMax = local ? CHUNK : 0u, dstBuf = (level & 1u) ? 0u : 1u, forceFallback = level >= 96u ? 1u : 0u;
     if (!chunked) {
       LAUNCH(top_local, dim3(segBound), dim3(256), 0, st, (const Seg*)cur, (const PrimRef*)src, dst, bnodes.p, nxt, small.p, ctr.p, prm, dstBuf, maxSegs, maxSmall, forceFallback, level, 1u);
@@ -457,7 +476,7 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
     uint32_t sure = 1; while (sure < 40u && ((uint64_t)prm.small << sure) < n) sure++;   // the largest segment halves at best: that many levels exist
     if (fast) {                                                                             // + margin: SAH splits are uneven (crown: 17 levels where 13 are implied)
       const uint32_t margin = spatial ? 10u : 8u;                                           // (spatial splits add references on the way down: the powerplant stand-in's HIGH tree has 25 levels where 16 are implied)
-      const uint32_t levels = learned ? min(sure + margin, arena->learnedTop + 1u) : sure + margin;   // (what the last commit of this size needed, + 1)
+      const uint32_t levels = learned ? min(sure + margin, learnedTop + 1u) : sure + margin;   // (what the last commit of this size needed, + 1)
       for (uint32_t i = 0; i < levels; i++) enqueue_top_level();
     }
     else {
@@ -504,7 +523,7 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
   if (fast) {
     // the depth of the wide tree is unknown here: 16 levels cover every scene measured so far (crown 12, powerplant 13); a deeper tree is finished below
     // (every level enqueued beyond the last one costs three empty launches, ~14 us)
-    { const uint32_t levels = learned && arena->learnedWide ? min(16u, arena->learnedWide + 1u) : 16u; for (uint32_t i = 0; i < levels; i++) enqueue_wide_level(); }
+    { const uint32_t levels = learned && learnedWide ? min(16u, learnedWide + 1u) : 16u; for (uint32_t i = 0; i < levels; i++) enqueue_wide_level(); }
     if (capturing) {                                             // end of the captured sequence: instantiate, keep, run
       hipGraph_t graph = nullptr;
       const hipError_t e = hipStreamEndCapture(st, &graph);
@@ -522,10 +541,13 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
     LAUNCH(tri_records, dim3((NC + 255u) / 256u), dim3(256), 0, st, outIds.p, NC, dGeoms.p, (TriRec*)bvh->d_tris, bp->robust ? 1u : 0u, (const Counters*)ctr.p);
     SYNC_READ(h);                                                // the ONE round trip of the commit
     if (h.overflow == 2u && spatial) return set_error(hipErrorOutOfMemory, "spatial split ran out of its extended range");
-    if (h.overflow == 3u && learned) { arena->learnedN = 0; arena->learnedTop = arena->learnedWide = 0; return -1001; }   // a large set below the last level the chunked path was enqueued for
+    // Any overflow of a commit that ran on learned counts is first of all a doubt about those counts (a large set below the last level the chunked path was enqueued for raises 3;
+    // a work list that a later kernel found too short may overwrite that 3 with 1): the commit runs again with the blind margins, which report what this scene needs -- the
+    // counts of its kind grow to that (Arena::learn takes the maximum) -- and only an overflow of THAT run is an error.  (it was a hard out-of-memory error.)
+    if (h.overflow && learned) return -1001;
     if (h.overflow) return set_error(hipErrorOutOfMemory, "work list overflow (pathological input)");
     if (h.numSegs != 0u) {                                       // the top phase needed more levels than were enqueued: what came after it worked on an unfinished tree
-      if (learned) { arena->learnedN = 0; arena->learnedTop = arena->learnedWide = 0; return -1001; }   // (counts learned from another scene of this size: again, with the blind margins)
+      if (learned) return -1001;                                 // (counts learned from another scene of this kind: again, with the blind margins; what that run needs is added to them)
       arena->marginFailedN = N;                                  // more than N implies + 8
       return -1000;                                              // (the guard frees the half-built tree) the caller repeats the commit on the stepwise path
     }
@@ -542,7 +564,7 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
       redoLeaves = true;
     }
     if (spatial) { info.num_presplit = h.numTrisOut > n ? h.numTrisOut - n : 0u; n = h.numTrisOut; }   // the references the spatial splits created are leaf entries like any other
-    arena->learnedN = N; arena->learnedTop = h.topLevels; arena->learnedWide = h.wideDepth; arena->learnedChunked = h.chunkedLevels; arena->learnedLocalFirst = h.localFirst < 255u ? h.localFirst : 255u;   // (a tree deeper than the wide levels enqueued is finished below either way)
+    arena->learn(kind, h.topLevels, h.wideDepth, h.chunkedLevels, h.localFirst < 255u ? h.localFirst : 255u);   // (a tree deeper than the wide levels enqueued is finished below either way)
     if (redoLeaves) LAUNCH(tri_records, dim3((NC + 255u) / 256u), dim3(256), 0, st, outIds.p, NC, dGeoms.p, (TriRec*)bvh->d_tris, bp->robust ? 1u : 0u, (const Counters*)ctr.p);
   } else {
     for (uint32_t i = 0; i < 8u; i++) enqueue_wide_level();

@@ -227,6 +227,47 @@ int mi355_measure_bandwidth(int device, size_t bytes, int reps, double out[2]) {
   out[0] = bestCopy; out[1] = bestRead;
   return 0;
 }
+// What the host link allows for a host-array query (bench.py's end_to_end leg is read against it): `bytes` from pinned host memory to the device and `bytes` back,
+// each direction alone and both at once on two streams (the two copy engines), best of `reps`.  out[0] = upload GB/s, out[1] = download GB/s, out[2] = milliseconds for
+// both directions at once = the floor of rtcIntersect1M on an array of that size with a perfect pipeline (profiles/r04_host_link.md).
+int mi355_measure_host_link(int device, size_t bytes, int reps, double out[3]) {
+  HIP_TRY(hipSetDevice(device));
+  if (bytes < (1u << 20)) bytes = 1u << 20;
+  char *hUp = nullptr, *hDown = nullptr, *dUp = nullptr, *dDown = nullptr;
+  hipStream_t s0 = nullptr, s1 = nullptr; hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+  hipError_t err = hipHostMalloc((void**)&hUp, bytes, hipHostMallocDefault);
+  if (err == hipSuccess) err = hipHostMalloc((void**)&hDown, bytes, hipHostMallocDefault);
+  if (err == hipSuccess) err = hipMalloc((void**)&dUp, bytes);
+  if (err == hipSuccess) err = hipMalloc((void**)&dDown, bytes);
+  if (err == hipSuccess) err = hipStreamCreateWithFlags(&s0, hipStreamNonBlocking);
+  if (err == hipSuccess) err = hipStreamCreateWithFlags(&s1, hipStreamNonBlocking);
+  if (err == hipSuccess) err = hipEventCreate(&e0);
+  if (err == hipSuccess) err = hipEventCreate(&e1);
+  if (err == hipSuccess) err = hipEventCreate(&e2);
+  double up = 0.0, down = 0.0, both = 1e30;
+  if (err == hipSuccess) {
+    memset(hUp, 1, bytes); (void)hipMemset(dDown, 2, bytes);
+    for (int r = 0; r < reps + 1 && err == hipSuccess; r++) {
+      float ms = 0;
+      hipEventRecord(e0, s0); hipMemcpyAsync(dUp, hUp, bytes, hipMemcpyHostToDevice, s0); hipEventRecord(e1, s0); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
+      if (r && ms > 0) { const double g = (double)bytes / (ms * 1e-3) / 1e9; if (g > up) up = g; }
+      hipEventRecord(e0, s1); hipMemcpyAsync(hDown, dDown, bytes, hipMemcpyDeviceToHost, s1); hipEventRecord(e1, s1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
+      if (r && ms > 0) { const double g = (double)bytes / (ms * 1e-3) / 1e9; if (g > down) down = g; }
+      hipDeviceSynchronize();
+      hipEventRecord(e0, s0); hipStreamWaitEvent(s1, e0, 0);                                  // both directions start together
+      hipMemcpyAsync(dUp, hUp, bytes, hipMemcpyHostToDevice, s0); hipMemcpyAsync(hDown, dDown, bytes, hipMemcpyDeviceToHost, s1);
+      hipEventRecord(e2, s1); hipStreamWaitEvent(s0, e2, 0); hipEventRecord(e1, s0);            // ... and e1 is behind both
+      err = hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
+      if (r && ms > 0 && ms < both) both = ms;
+    }
+  }
+  if (e0) hipEventDestroy(e0); if (e1) hipEventDestroy(e1); if (e2) hipEventDestroy(e2);
+  if (s0) hipStreamDestroy(s0); if (s1) hipStreamDestroy(s1);
+  if (hUp) hipHostFree(hUp); if (hDown) hipHostFree(hDown); if (dUp) hipFree(dUp); if (dDown) hipFree(dDown);
+  if (err != hipSuccess) { (void)hipGetLastError(); return mi355::set_error(err, "mi355_measure_host_link"); }
+  out[0] = up; out[1] = down; out[2] = both < 1e29 ? both : 0.0;
+  return 0;
+}
 int mi355_stream_query(void* stream) {                           // 0 = everything enqueued on the stream has finished, 1 = still running, < 0 = error
   const hipError_t e = hipStreamQuery((hipStream_t)stream);
   if (e == hipSuccess) return 0;

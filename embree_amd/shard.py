@@ -1,6 +1,10 @@
 """Multi-GPU partitioning of a ray batch: rays are independent and the BVH is read-only,
 so a batch is split into contiguous per-rank ranges and the BVH is replicated (every rank builds it from
-the same inputs).  There is no data-path collective; ranks only meet at host-side barriers.
+the same inputs: the build is deterministic, the replicas are bit-identical, nothing is broadcast).
+Tracing needs no exchange between the ranks.  What the consumer of the results needs afterwards is the one
+real exchange step of the path: the fields a query WRITES are packed on the GPU (mi355_pack_hits /
+mi355_pack_occluded, embree_amd/csrc/shard.hip) and gathered over RCCL / xGMI -- `Communicator` below:
+ncclGather to rank 0 for closest hits, ncclAllGather for occlusion results (north star of BASELINE.json).
 The reference has no multi-process code at all (single-process library) -- this is new design."""
 
 

@@ -215,6 +215,10 @@ MI355_API int  mi355_stream_query(void* stream);
 /* What a streaming kernel reaches on this GPU (the achievable figure beside the 8 TB/s vendor peak): out[0] = device-to-device copy,
    bytes read + written per second; out[1] = read only; GB/s, best of `reps` passes over `bytes` (use >= 1 GiB: the Infinity Cache holds 256 MB). Blocking. */
 MI355_API int  mi355_measure_bandwidth(int device, size_t bytes, int reps, double out[2]);             /* hipStreamQuery: 0 = idle, 1 = work pending, < 0 = error */
+/* the host link of `device`: `bytes` up from pinned host memory and `bytes` down, alone and both at once (two streams = the two copy engines), best of `reps`:
+ * out[0] = upload GB/s, out[1] = download GB/s, out[2] = ms for both directions at once -- the floor of a host-array query of that size (bench.py end_to_end.link_floor_ms).
+ * No counterpart in the reference (its rays never leave host memory). */
+MI355_API int  mi355_measure_host_link(int device, size_t bytes, int reps, double out[3]);
 
 /* raw device memory helpers for hosts without a HIP binding (ctypes tests / bench) */
 MI355_API int mi355_malloc(int device, size_t bytes, void** d_ptr);

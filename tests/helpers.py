@@ -84,12 +84,15 @@ def compare_occluded(got_tfar, want_tfar, rays_tfar_in, max_flip_frac=0.0, label
     return dict(rays=g.shape[0], occluded=int(w.sum()), flips=flips)
 
 
-def compare_closest_arbitrated(got, want_fast, want_robust, rays_in, tri_t, max_tie_frac=1e-4, max_ref_miss_frac=1e-3, label=""):
+def compare_closest_arbitrated(got, want_fast, want_robust, rays_in, tri_t, max_tie_frac=1e-4, max_ref_miss_frac=1e-4, label=""):
     """Fast-mode parity on geometry where the REFERENCE's fast mode is itself not exact.  Embree's default node test (node_intersector1.h:484-531,
     rdir from an approximate reciprocal, no safety margin) loses hits on long thin or axis-aligned geometry; RTC_SCENE_FLAG_ROBUST exists for that
     reason.  A ray on which the tested path and the fast reference disagree is therefore accepted iff it is an exact-t tie or the tested
     path reports exactly what the ROBUST reference reports (a hit the fast reference lost); and the tested path itself must never be farther than the
-    robust reference's hit (it must not lose anything).  Returns counts; asserts on anything else."""
+    robust reference's hit (it must not lose anything).  Returns counts; asserts on anything else.
+    max_ref_miss_frac: the share of the rays that may follow the robust reference -- 1e-4 (round 5; 1e-3 before: twenty times what is measured, 55 of 2^20 on the
+    powerplant stand-in, room for a regression to hide in); tests on geometry that provokes the reference's fast mode (a scene 1e5 away from the origin, the
+    fuzzed degenerate scenes) state their own, larger share."""
     n = got.shape[0]
     same = (got["geomID"] == want_fast["geomID"]) & (got["primID"] == want_fast["primID"])
     idx = np.nonzero(~same)[0]

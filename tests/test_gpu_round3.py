@@ -65,7 +65,7 @@ def tri_t_of(meshes):
 
 
 # ------------------------------------------------------------------------------------------- one RTCDevice over N GPUs
-@pytest.mark.parametrize("gpus", [1, 2, 3])
+@pytest.mark.parametrize("gpus", [1, 2, 3, 8])
 def test_one_device_over_several_gpus(api, dev, gpus):
     """rtcNewDevice("gpus=N") (the reference's shape: a GPU device behind the same RTCDevice, kernels/common/scene.cpp:866-872; the ray count of its own
     benchmark, tutorials/verify/verify.cpp:5933, is what gets sharded).  gpus=1 drives the very same code with one replica."""

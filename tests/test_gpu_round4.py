@@ -185,7 +185,7 @@ def test_64m_triangle_commit_and_rays_vs_real_reference(api, dev, ref):
 
 
 # ------------------------------------------------------------------------------------------- per-GPU pointers; packed hits with instID
-@pytest.mark.parametrize("gpus", [1, 3])
+@pytest.mark.parametrize("gpus", [1, 3, 8])
 def test_sharded_pointer_queries_equal_the_single_gpu_bytes(api, dev, gpus):
     """rtcIntersect1MDeviceSharded / rtcOccluded1MDeviceSharded: shard k lives on replica k's GPU (RTC_DEVICE_PROPERTY_GPU_OF_REPLICA_0 + k) and is traced there on
     its own stream -- nothing crosses xGMI.  On a 1-GPU box the replicas share the GPU (gpu_oversubscribe=1): same code path.  Ragged shards, an empty shard."""
@@ -520,7 +520,7 @@ def _soup(n, seed, clustered):
 def test_commit_with_level_counts_learned_from_another_scene_of_the_same_size(api, dev):
     """A default-quality commit enqueues the launch sequence the LAST commit of the same triangle count needed (top levels, levels of the chunked path, first
     level of top_local, wide levels: build.hip, Arena::learned*).  A different scene of the same size may need more: the commit notices (unfinished work list /
-    a large set where only top_local was enqueued), forgets what it learned and runs again blind.  Whatever way a tree was enqueued, it is the same tree."""
+    a large set where only top_local was enqueued) and runs again blind; what that run needed is ADDED to the counts of the kind.  Whatever way a tree was enqueued, it is the same tree."""
     n = 600_000
     trees = {}; attempts = []
     for name, clustered in (("even", False), ("clustered", True), ("even", False), ("clustered", True)):
@@ -541,6 +541,23 @@ def test_commit_with_level_counts_learned_from_another_scene_of_the_same_size(ap
         s.release()
     assert trees["even"] != trees["clustered"]
     assert max(attempts[1:]) >= 2, "the learned sequence of the other scene was never too short (%r): the retry path was not exercised" % (attempts,)
+    # (round 5) the counts of a kind of commit only grow: once both scenes have been seen, neither pays a second commit again
+    assert attempts[2:] == [1, 1], "two scenes of one size committed in turn keep failing on each other's level counts: %r" % (attempts,)
+
+
+def test_alternating_build_qualities_keep_their_own_level_counts(api, dev):
+    """the learned level counts were keyed by the triangle count alone, so a scene committed MEDIUM, then HIGH, then MEDIUM (what bench.py does)
+    found the other quality's counts every time, failed with -1001 and ran twice.  They are kept per kind of commit now (build.hip, Arena::Learned)."""
+    meshes = _soup(300_000, 11, True)
+    attempts = []
+    for quality in (None, 2, None, 2, None, 2):
+        s = api.Scene(dev, 0, quality)
+        for v, t in meshes:
+            s.add_triangle_mesh(v, t, device_resident=True)
+        s.commit()
+        attempts.append(s.info()["build_attempts"])
+        s.release()
+    assert attempts[2:] == [1, 1, 1, 1], "a commit ran twice although its kind had been committed before: %r" % (attempts,)
 
 
 def test_high_quality_commits_of_the_crown_are_bit_identical(api, dev):
