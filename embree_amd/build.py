@@ -10,8 +10,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libembree4_mi355.so")
-SOURCES = ["build.hip", "trace.hip", "shard.hip", "rtcore_api.cpp"]
-HEADERS = ["bvh_common.h", "internal.h", "../../include/embree4/rtcore.h", "../../include/embree_amd_hip.h",
+SOURCES = ["build.hip", "trace.hip", "trace_fptr.hip", "shard.hip", "rtcore_api.cpp"]
+HEADERS = ["trace.hip", "bvh_common.h", "internal.h", "../../include/embree4/rtcore.h", "../../include/embree_amd_hip.h",
            "build_common.inl", "build_primref.inl", "build_presplit.inl", "build_binning.inl", "build_top.inl", "build_spatial.inl", "build_small.inl",
            "build_morton.inl", "build_wide.inl", "build_leaves.inl"]    # parts of build.hip (one translation unit)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden",
@@ -20,7 +20,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 # pays for it with v_mov (to bring operands into adjacent registers) and v_and (|x| has no packed form) -- on gfx950 a packed fp32 instruction issues in the time of two
 # scalar ones (profiles/r02_valu_issue_costs.txt), so the pairs buy nothing and the moves cost: +3.7 % rays per second without it (profiles/r05_trace.md).  The packed
 # FMAs of the slab test are written by hand (test4) and stay.  Same arithmetic either way (-ffp-contract=off): results are bit-identical.
-EXTRA_FLAGS = {"trace.hip": ["-fno-slp-vectorize"]}
+# trace_fptr.hip = trace.hip again, for the kernels that call a device filter function only, at -O1 (the reason is in trace.hip, MI355_FPTR_TU)
+EXTRA_FLAGS = {"trace.hip": ["-fno-slp-vectorize"], "trace_fptr.hip": ["-fno-slp-vectorize", "-O1"]}
 
 
 def _stale():

@@ -28,6 +28,7 @@ struct TraceScratch {
   uint32_t divergeStreak = 0;                // packet samples in a row (large coherent queries on this (tree, stream)) that said "the packets do not stay together"
   uint32_t coherentCalls = 0;                // large RTC_RAY_QUERY_FLAG_COHERENT queries that skipped the packet sample since the last one that took it
   volatile uint32_t* statusDev = nullptr;    // ... and its device address
+  bool cursorsDirty = false;                 // a launch on this (tree, stream) left through the iteration cap: its ray cursors are zeroed before the next launch (trace.hip)
 };
 
 struct Bvh {

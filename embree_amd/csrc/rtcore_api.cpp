@@ -11,6 +11,7 @@
 // There is NO CPU fallback: every ray query and every commit runs on the GPU or reports an error.
 #include <hip/hip_runtime.h>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -59,6 +60,9 @@ struct Device : RefCounted {
   bool benchmark = false;
   bool noInstanceRefit = false;                              // config key instance_refit=0: moved instances rebuild the top tree and concatenate the object trees again (A/B)
   bool hostInPlace = false;                                  // config key host_in_place=1: large host arrays are traced where they lie (registered + mapped), see replica_query
+  bool deviceFilters = false;                                // config key device_filter_functions=1: RTCIntersectArguments::filter / RTCOccludedArguments::filter of the *Device entry points
+                                                             // is the address of a __device__ function (include/embree4/rtcore.h, "device filter functions"); off: a non-NULL filter there is an error
+  bool pollSmall = true;                                     // config key small_poll=0: a blocking single-ray call sleeps on the stream instead of polling it (A/B)
   bool smallInPlace = true;                                  // config key small_in_place=0: small host queries go through device staging like the others (A/B)
   unsigned pipelineMin = 262144, pipelineChunk = 131072;   // host-array queries of at least pipelineMin rays are cut into chunks of pipelineChunk rays (config keys host_pipeline_min / host_pipeline_chunk)
   mi355_build_params build;
@@ -411,15 +415,19 @@ struct Scene : RefCounted {
     // ---- device-side filter rules (rtcSetGeometryFilterRule): the table every replica uploads
     std::vector<uint32_t> ruleTable; uint32_t ruleGeoms = geoms.empty() ? 0u : geoms.rbegin()->first + 1u;
     { bool any = false;
-      for (auto& kv : geoms) any = any || (kv.second->enabled && kv.second->hasRule && kv.second->rule.kinds != 0u);
+      // (device filter FUNCTIONS, config device_filter_functions=1: a geometry that enabled the argument filter says so in bit 16 of its first word and brings its user pointer)
+      const bool fptr = device->deviceFilters;
+      for (auto& kv : geoms) any = any || (kv.second->enabled && ((kv.second->hasRule && kv.second->rule.kinds != 0u) || (fptr && kv.second->argFilter)));
       if (any) {
         ruleTable.assign((size_t)ruleGeoms * 12u, 0u);
         for (auto& kv : geoms) {
           Geometry* g = kv.second;
-          if (!g->enabled || !g->hasRule || g->rule.kinds == 0u) continue;
-          const RTCFilterRule& q = g->rule;
+          const bool hasRule = g->hasRule && g->rule.kinds != 0u, argF = fptr && g->argFilter;
+          if (!g->enabled || !(hasRule || argF)) continue;
+          const RTCFilterRule q = hasRule ? g->rule : RTCFilterRule{};
           uint32_t e[12] = {0}; float f[4] = {q.tmin, q.tmax, q.umax, q.vmax};
-          e[0] = (q.kinds & 0xFFu) | ((q.apply & 3u) << 8); e[1] = q.modulus; e[2] = q.remainder; e[3] = (q.primFactor & 0xFFFFu) | ((q.geomFactor & 0xFFFFu) << 16);
+          if (argF) { e[0] |= 1u << 16; const unsigned long long up = (unsigned long long)(uintptr_t)g->userPtr; e[10] = (uint32_t)up; e[11] = (uint32_t)(up >> 32); }
+          e[0] |= (q.kinds & 0xFFu) | ((q.apply & 3u) << 8); e[1] = q.modulus; e[2] = q.remainder; e[3] = (q.primFactor & 0xFFFFu) | ((q.geomFactor & 0xFFFFu) << 16);
           memcpy(&e[4], f, 16);
           if ((q.kinds & RTC_FILTER_RULE_PRIMITIVE_BITS) && !g->ruleBits.empty()) { e[8] = (uint32_t)ruleTable.size(); e[9] = q.numBits; ruleTable.insert(ruleTable.end(), g->ruleBits.begin(), g->ruleBits.end()); }
           else e[0] &= ~(uint32_t)RTC_FILTER_RULE_PRIMITIVE_BITS;
@@ -534,6 +542,8 @@ void parse_config(Device* d, const char* cfg) {
     else if (k == "max_spatial_split_replications") d->build.split_factor = (float)atof(v.c_str());   // state.cpp:437
     else if (k == "host_pipeline_min") d->pipelineMin = (unsigned)atol(v.c_str());
     else if (k == "small_in_place") d->smallInPlace = atoi(v.c_str()) != 0;
+    else if (k == "small_poll") d->pollSmall = atoi(v.c_str()) != 0;
+    else if (k == "device_filter_functions") d->deviceFilters = atoi(v.c_str()) != 0;
     else if (k == "host_pipeline_chunk") d->pipelineChunk = atol(v.c_str()) >= 1024 ? (unsigned)atol(v.c_str()) : 1024u;
     else if (k == "int_cost") d->build.int_cost = (float)atof(v.c_str());
     else if (k == "top_splits") d->build.top_splits = atoi(v.c_str()) != 0 ? 1u : 0u;                 // MEDIUM builds: references that dwarf all others are cut into grid pieces first
@@ -552,7 +562,8 @@ static std::atomic<bool> g_anyFilterEver{false};            // some geometry was
 // launches (filtered_query), the device-pointer entry points cannot
 void check_query_args(const RTCFilterFunctionN filter, const void* callback, bool hostEntry = false) {
   if (callback) THROW(RTC_ERROR_INVALID_OPERATION, "user-geometry callbacks are not supported (no user geometries on the GPU path)");
-  if (filter && !hostEntry) THROW(RTC_ERROR_INVALID_OPERATION, "a filter callback is a host function: use the host-array entry points (rtcIntersect1/4/8/16/1M), not the device-pointer ones");
+  if (filter && !hostEntry) THROW(RTC_ERROR_INVALID_OPERATION, "a filter callback is a host function: use the host-array entry points (rtcIntersect1/4/8/16/1M), not the device-pointer ones "
+                                                               "(or create the device with device_filter_functions=1 and pass the address of a __device__ function)");
 }
 mi355_bvh_t committed_bvh(Scene* s, size_t k = 0) {
   if (!s->committed || !s->reps[k]->bvh) THROW(RTC_ERROR_INVALID_OPERATION, "scene not committed");   // missing_rtcCommit, scene.cpp:66
@@ -702,6 +713,16 @@ static void replica_query(Scene* s, size_t k, char* data, unsigned M, size_t str
     char* hd = nullptr; char* h = r.stage_host(&hd);
     memcpy(h, data, bytes);
     core_check(trace_launch(b, hd, M, stride, any, qflags, nullptr), "trace");
+    // (round 5) The launch of a single ray takes ~25 us; hipStreamSynchronize puts the thread to sleep on the completion signal and is woken by an interrupt, which adds
+    // 10 - 25 us to every call (36 us minimum, 51 us median on the driver's box in round 4).  A thread that waits for one ray polls instead -- hipStreamQuery reads the
+    // signal without sleeping -- for at most ~200 us, after which it falls back to the blocking wait (a long kernel ahead of it in the stream, a preempted process).
+    if (s->device->pollSmall) {
+      const auto t0 = std::chrono::steady_clock::now();
+      while (hipStreamQuery(nullptr) == hipErrorNotReady) {
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(200)) break;
+      }
+      (void)hipGetLastError();                                 // (hipErrorNotReady is not an error)
+    }
     uint32_t flags = 0;
     core_check(mi355_trace_status(b, nullptr, &flags), "trace status");   // (waits for the launch: the status words are read after it)
     memcpy(data, h, bytes);
@@ -794,9 +815,16 @@ static void sharded_pointer_query(Scene* s, unsigned numShards, void* const* d, 
   }
   hip_check(hipSetDevice(s->device->gpu), "hipSetDevice");
 }
-static void device_query(Scene* s, void* d, unsigned M, size_t stride, bool any, unsigned qflags, void* stream) {
+// filterFn: the address of a __device__ filter function (device_filter_functions=1), 0 = none; the reference's GPU path calls the pointer it finds in the arguments the same
+// way (filter_sycl.h:31-43, under RTC_FEATURE_FLAG_FILTER_FUNCTION_IN_ARGUMENTS)
+static void device_query(Scene* s, void* d, unsigned M, size_t stride, bool any, unsigned qflags, void* stream, uint64_t filterFn = 0, void* filterCtx = nullptr) {
   if (M == 0) { committed_bvh(s); return; }
   const size_t n = s->reps.size();
+  if (filterFn) {
+    if (n > 1) THROW(RTC_ERROR_INVALID_OPERATION, "device filter functions need a device over ONE GPU (a function address belongs to one GPU's code object)");
+    core_check(mi355_trace_query_filtered(committed_bvh(s), d, M, stride, any ? 1 : 0, qflags, filterFn, filterCtx, (hipStream_t)stream), "trace");
+    return;
+  }
   if (n > 1 && M >= s->device->shardMin * n) { sharded_device_query(s, (char*)d, M, stride, any, qflags, (hipStream_t)stream); return; }
   core_check(trace_launch(committed_bvh(s), d, M, stride, any, qflags, (hipStream_t)stream), "trace");
 }
@@ -1084,7 +1112,12 @@ RTC_API void rtcSetGeometryFilterRule(RTCGeometry h, const struct RTCFilterRule*
   g->ruleCounter++;
   CATCH_END(GEOM_DEV(h))
 }
-RTC_API void rtcSetGeometryEnableFilterFunctionFromArguments(RTCGeometry h, bool enable) { CATCH_BEGIN geom_of(h)->argFilter = enable; CATCH_END(GEOM_DEV(h)) }
+RTC_API void rtcSetGeometryEnableFilterFunctionFromArguments(RTCGeometry h, bool enable) {
+  CATCH_BEGIN Geometry* g = geom_of(h);
+  if (g->argFilter != enable && g->device->deviceFilters) g->ruleCounter++;   // (with device filter functions the flag travels to the GPU in the rule table: the next commit uploads it)
+  g->argFilter = enable;
+  CATCH_END(GEOM_DEV(h))
+}
 
 // ============================================================================================= scene
 #define SCENE_DEV(h) ((h) ? ((Scene*)(h))->device : nullptr)
@@ -1179,12 +1212,16 @@ RTC_API void rtcOccluded1M(RTCScene h, struct RTCRay* r, unsigned M, size_t stri
   CATCH_BEGIN Scene* s = scene_of(h); if (a) check_query_args(a->filter, (const void*)a->occluded, true); host_query(s, r, M, stride, true, a ? a->filter : nullptr, a ? (unsigned)a->flags : 0u, a ? a->context : nullptr); CATCH_END(SCENE_DEV(h))
 }
 RTC_API void rtcIntersect1MDevice(RTCScene h, void* d_rh, unsigned M, size_t stride, struct RTCIntersectArguments* a, void* stream) {
-  CATCH_BEGIN Scene* s = scene_of(h); if (a) check_query_args(a->filter, (const void*)a->intersect);
-  device_query(s, d_rh, M, stride, false, a ? (unsigned)a->flags : 0u, stream); CATCH_END(SCENE_DEV(h))
+  CATCH_BEGIN Scene* s = scene_of(h);
+  const bool fptr = a && a->filter && s->device->deviceFilters && (a->feature_mask & RTC_FEATURE_FLAG_FILTER_FUNCTION_IN_ARGUMENTS);
+  if (a) check_query_args(fptr ? nullptr : a->filter, (const void*)a->intersect);
+  device_query(s, d_rh, M, stride, false, a ? (unsigned)a->flags : 0u, stream, fptr ? (uint64_t)(uintptr_t)a->filter : 0ull, fptr ? (void*)a->context : nullptr); CATCH_END(SCENE_DEV(h))
 }
 RTC_API void rtcOccluded1MDevice(RTCScene h, void* d_r, unsigned M, size_t stride, struct RTCOccludedArguments* a, void* stream) {
-  CATCH_BEGIN Scene* s = scene_of(h); if (a) check_query_args(a->filter, (const void*)a->occluded);
-  device_query(s, d_r, M, stride, true, a ? (unsigned)a->flags : 0u, stream); CATCH_END(SCENE_DEV(h))
+  CATCH_BEGIN Scene* s = scene_of(h);
+  const bool fptr = a && a->filter && s->device->deviceFilters && (a->feature_mask & RTC_FEATURE_FLAG_FILTER_FUNCTION_IN_ARGUMENTS);
+  if (a) check_query_args(fptr ? nullptr : a->filter, (const void*)a->occluded);
+  device_query(s, d_r, M, stride, true, a ? (unsigned)a->flags : 0u, stream, fptr ? (uint64_t)(uintptr_t)a->filter : 0ull, fptr ? (void*)a->context : nullptr); CATCH_END(SCENE_DEV(h))
 }
 RTC_API void rtcIntersect1MDeviceSharded(RTCScene h, unsigned n, void* const* d_rh, const unsigned* counts, size_t stride, struct RTCIntersectArguments* a, void* const* streams) {
   CATCH_BEGIN Scene* s = scene_of(h); if (a) check_query_args(a->filter, (const void*)a->intersect);

@@ -29,6 +29,7 @@
 //   with -ffp-contract=off so only the explicit fmaf()s fuse).  MFMA is not used: no dense contraction here.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <map>
 #include <mutex>
@@ -81,6 +82,7 @@ struct TraceArgs {
   unsigned long long* stats;  // optional counters
   const float4* insts;   // INST kernels: InstRec[] as 4 x float4 (world2local vx,vy,vz,p | root node, instID, mask, flags)
   const uint4* rules;    // device-side filter rules, 48 B per geometry (+ bit arrays behind them), or nullptr
+  unsigned long long filterFn; void* filterCtx; uint32_t filterEnforce;   // FILT == 2: address of a __device__ filter function (RTCIntersectArguments::filter of a *Device query), its context, RTC_RAY_QUERY_FLAG_INVOKE_ARGUMENT_FILTER
   const uint32_t* deferList; const uint32_t* deferCount;   // second pass of a RTC_RAY_QUERY_FLAG_COHERENT query: the packets (64 consecutive rays each) the packet kernel gave up on; nullptr otherwise
 };
 
@@ -245,11 +247,12 @@ __device__ __forceinline__ bool tri_pluecker(const float4 q0, const float4 q1, c
 // of (primID, geomID, t, u, v), so "closest accepted hit" / "any accepted hit" do not depend on the order candidates are met in.  48 bytes per geometry:
 //   w0 kinds | apply << 8   w1 modulus   w2 remainder   w3 primID factor | geomID factor << 16     w4-7 tmin tmax umax vmax     w8 bit array offset (words)  w9 bits
 constexpr uint32_t RULE_MODULO = 1u, RULE_BITS = 2u, RULE_TWINDOW = 4u, RULE_UV = 8u, RULE_APPLY_INTERSECT = 1u << 8, RULE_APPLY_OCCLUDED = 2u << 8;
+constexpr uint32_t RULE_ARG_FILTER = 1u << 16;   // w0 bit 16: rtcSetGeometryEnableFilterFunctionFromArguments (w10, w11: the geometry's user pointer, handed to the filter function)
 template <bool ANY, bool ROBUST>
 __device__ __forceinline__ bool rule_accepts(const uint4* rules, uint32_t ruleIdx, const float4 q0, const float4 q1, const float4 q2, float t,
                                              float ox, float oy, float oz, float dx, float dy, float dz) {
   const uint4 r0 = rules[(size_t)ruleIdx * 3u];
-  if ((r0.x & 0xFFu) == 0u || !(r0.x & (ANY ? RULE_APPLY_OCCLUDED : RULE_APPLY_INTERSECT))) return true;
+  if ((r0.x & 0xFFu) == 0u || !(r0.x & (ANY ? RULE_APPLY_OCCLUDED : RULE_APPLY_INTERSECT))) return true;   // (bits 0-7: the rule kinds; bit 16 is RULE_ARG_FILTER)
   const uint4 r1 = rules[(size_t)ruleIdx * 3u + 1u], r2 = rules[(size_t)ruleIdx * 3u + 2u];
   const uint32_t pidRaw = __float_as_uint(q2.y), pid = pidRaw & 0x7FFFFFFFu, gid = __float_as_uint(q2.z);
   bool reject = false;
@@ -263,6 +266,36 @@ __device__ __forceinline__ bool rule_accepts(const uint4* rules, uint32_t ruleId
     reject = reject || w.u > __uint_as_float(r1.z) || w.v > __uint_as_float(r1.w);
   }
   return !reject;
+}
+
+// ---- device filter FUNCTIONS (round 5): the address of a __device__ function in RTCIntersectArguments::filter / RTCOccludedArguments::filter of a *Device query is called
+// for every candidate hit of a geometry that enabled it (rtcSetGeometryEnableFilterFunctionFromArguments) or of every geometry (RTC_RAY_QUERY_FLAG_INVOKE_ARGUMENT_FILTER),
+// where the reference's GPU path calls its function pointer: runIntersectionFilter1SYCL / runOcclusionFilter1SYCL, kernels/geometry/filter_sycl.h:12-120 -- after the
+// geometry's own rules, before the candidate is published.  The callee sees what the reference hands over: RTCFilterFunctionNArguments with N = 1, valid[0] = -1,
+// ray.tfar = the candidate's distance, the full hit (Ng, u, v, primID, geomID, instID[0]); clearing valid[0] rejects the candidate.  ABI: include/embree4/rtcore.h,
+// INTEGRATION.md (the function lives in the CALLER's code object; both are compiled for gfx950 by the same compiler: one calling convention, one address space).
+struct DevRay { float org_x, org_y, org_z, tnear, dir_x, dir_y, dir_z, time, tfar; uint32_t mask, id, flags; };                 // RTCRay (rtcore_ray.h:19-36)
+struct DevHit { float Ng_x, Ng_y, Ng_z, u, v; uint32_t primID, geomID, instID0, instPrimID0; };                                  // RTCHit (rtcore_ray.h:39-53), RTC_MAX_INSTANCE_LEVEL_COUNT = 1
+struct DevFilterArgs { int* valid; void* geometryUserPtr; void* context; DevRay* ray; DevHit* hit; unsigned int N; };          // RTCFilterFunctionNArguments (rtcore_common.h:318-326)
+typedef void (*DevFilterFn)(const DevFilterArgs*);
+// (inlined into the kernel ON PURPOSE: as a function of its own, the kernel's register allocation trusted what THIS function is seen to clobber -- inter-procedural register
+// allocation -- and kept values in v0-v7 / s0-s3 across it, which the caller's function, compiled elsewhere, is free to overwrite: the robust kernels lost their rays.  With the
+// indirect call in the kernel itself the full clobber set of the calling convention applies.)
+template <bool ROBUST>
+__device__ __forceinline__ bool call_device_filter(unsigned long long fn, void* ctx, void* userPtr, const float4 q0, const float4 q1, const float4 q2,
+                                                float ox, float oy, float oz, float dx, float dy, float dz, float tnear, uint32_t mask, uint32_t rayId, uint32_t instID) {
+  TriOut w;
+  const uint32_t pid = __float_as_uint(q2.y);
+  if (ROBUST) tri_pluecker<true>(q0, q1, q2, ox, oy, oz, dx, dy, dz, 0.0f, 0.0f, w, (pid >> 31) != 0u);
+  else tri_moeller<true>(q0, q1, q2, ox, oy, oz, dx, dy, dz, 0.0f, 0.0f, w, (pid >> 31) != 0u);
+  DevRay ray{ox, oy, oz, tnear, dx, dy, dz, 0.0f, w.t, mask, rayId, 0u};
+  DevHit hit{w.Ngx, w.Ngy, w.Ngz, w.u, w.v, pid & 0x7FFFFFFFu, __float_as_uint(q2.z), instID, instID == MI355_EMPTY_REF ? MI355_EMPTY_REF : 0u};
+  int valid = -1;
+  DevFilterArgs args{&valid, userPtr, ctx, &ray, &hit, 1u};
+#ifndef MI355_FPTR_NOCALL                     /* (debugging: everything but the call itself) */
+  ((DevFilterFn)fn)(&args);
+#endif
+  return valid != 0;
 }
 
 // =============================================================================================
@@ -334,8 +367,10 @@ __device__ __forceinline__ void setup_rdir(float dx, float dy, float dz, float& 
 // recomputed in that instance's space when the ray retires.  Tail helpers (1b) only take sub-trees that lie inside an instance.
 // FILT: the scene has device-side filter rules (rule_accepts above).  A template parameter, not a run-time test: the rule code (a second, finishing triangle
 // test for the u/v cut-off) costs 6 - 12 VGPRs, which takes the robust kernels from 128 to 134 = from four to three waves per SIMD for every scene.
-template <bool ANY, bool STATS, bool ROBUST, bool INST, bool FILT>
-__global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceArgs a) {
+// FILT == 2: rules + a device filter FUNCTION (call_device_filter above): an indirect call inside the triangle block -- a stack in scratch memory and the register budget of a
+// callee the compiler cannot see; only the queries that pass a function pay for it (profiles/r05_device_filter.md).
+template <bool ANY, bool STATS, bool ROBUST, bool INST, int FILT>
+__global__ __launch_bounds__(BLOCK, FILT == 2 ? 4 : 1) MI355_TRACE_ATTR void trace_kernel_q(TraceArgs a) {
   __shared__ uint2 s_stack[BLOCK / 64][QSTACK_LDS][64];
   __shared__ __attribute__((aligned(QCAP * 8))) uint2 s_queue[BLOCK / 64][QCAP];   // (aligned to its size: a ring position is one v_and away from its address)
   __shared__ unsigned long long s_best[BLOCK / 64][64];
@@ -701,6 +736,7 @@ __global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceAr
       // the ray's own limit now reaches the atomic-min, which takes the minimum of (t bits, triangle index): the answer no longer depends on the order.
       const float gtfar0 = __shfl(tfar0, owner, 64);
       const uint32_t ginst = (INST && FILT) ? (uint32_t)__shfl((int)inst, owner, 64) : NO_INST;   // (rules of an instanced scene's geometries sit behind that instance's base)
+      const uint32_t grayIdx = FILT == 2 ? (uint32_t)__shfl((int)rayIdx, owner, 64) : 0u;       // (what the filter function finds in ray.id: the index of the ray in the batch)
       if (STATS && lane == 0u) stTriBlk++;
       // (two copies of the test, one per source of the record: where the paths joined the registers were merged with v_mov -- and the compiler's s_waitcnt at the join has
       // to serve both: vmcnt(0).  Apart, the prefetched path waits for "all but the five node loads of 3a", the other one for its own loads.)
@@ -716,6 +752,15 @@ __global__ __launch_bounds__(BLOCK) MI355_TRACE_ATTR void trace_kernel_q(TraceAr
           uint32_t ri = __float_as_uint(q2.z);
           if (INST && ginst != NO_INST) ri += __float_as_uint(a.insts[(size_t)ginst * 4u + 3u].w) >> 8;
           ok = rule_accepts<ANY, ROBUST>(a.rules, ri, q0, q1, q2, w.t, gox, goy, goz, gdx, gdy, gdz);
+          if (FILT == 2 && ok && a.filterFn != 0ull) {                  // ... and the filter FUNCTION of the query (filter_sycl.h:31-43: the geometry enabled it, or the query enforces it)
+            const uint4 r0 = a.rules[(size_t)ri * 3u];
+            if (a.filterEnforce != 0u || (r0.x & RULE_ARG_FILTER) != 0u) {
+              const uint4 r2 = a.rules[(size_t)ri * 3u + 2u];
+              ok = call_device_filter<ROBUST>(a.filterFn, a.filterCtx, (void*)(((unsigned long long)r2.w << 32) | r2.z), q0, q1, q2, gox, goy, goz, gdx, gdy, gdz, gtnear, grmask, grayIdx, MI355_EMPTY_REF);
+            }
+          }
+        } else if (FILT == 2 && ok && a.filterFn != 0ull && a.filterEnforce != 0u) {   // (no rule table: no geometry enabled the function; an enforcing query calls it for all of them)
+          ok = call_device_filter<ROBUST>(a.filterFn, a.filterCtx, nullptr, q0, q1, q2, gox, goy, goz, gdx, gdy, gdz, gtnear, grmask, grayIdx, MI355_EMPTY_REF);
         }
         if (ok) atomicMin(&best[owner], ((unsigned long long)__float_as_uint(w.t + 0.0f) << 32) | e.x);   // + 0: a hit at -0 must not sort as a huge key
       };
@@ -1103,15 +1148,29 @@ __global__ void packet_scatter(PacketArgs p, int withHit) {
 
 }  // namespace
 
+#ifdef MI355_FPTR_TU
+// ------------------------------------------------------------------------------------- trace_fptr.hip: this file again, for the FILT == 2 instantiations only
+// The kernels that CALL a device filter function are compiled in a translation unit of their own (embree_amd/csrc/trace_fptr.hip = this file with MI355_FPTR_TU defined)
+// at -O1: at -O2 and above the ROCm 7.2 compiler produces a traversal loop around the indirect call that loses its rays -- with ANY callee, an empty function included,
+// and not without the call (profiles/r05_device_filter.md: bisected on the GPU with tests/gpu_devfilter.py WHICH=1; -O1, -Os, -O2, -O3, IPRA off, no AGPR spilling).  The
+// ordinary kernels stay at -O3 in trace.hip; everything below this block (the host side) exists once, there.
+namespace mi355 {
+void* fptr_kernel(bool any, bool robust) {
+  if (robust) return any ? (void*)trace_kernel_q<true, false, true, false, 2> : (void*)trace_kernel_q<false, false, true, false, 2>;
+  return any ? (void*)trace_kernel_q<true, false, false, false, 2> : (void*)trace_kernel_q<false, false, false, false, 2>;
+}
+}  // namespace mi355
+#else
 // ------------------------------------------------------------------------------------- host side
 namespace mi355 {
+void* fptr_kernel(bool any, bool robust);                       // the FILT == 2 kernels (device filter functions): trace_fptr.hip
 
 typedef void (*TraceFn)(TraceArgs);
 static uint32_t env_u32(const char* name, uint32_t def, uint32_t lo, uint32_t hi) {
   const char* e = getenv(name); if (!e) return def;
   const long v = atol(e); return v < (long)lo || v > (long)hi ? def : (uint32_t)v;
 }
-template <bool INST, bool FILT> static TraceFn pick_kernel_if(bool any, bool robust) {
+template <bool INST, int FILT> static TraceFn pick_kernel_if(bool any, bool robust) {
   if (robust) return any ? trace_kernel_q<true, false, true, INST, FILT> : trace_kernel_q<false, false, true, INST, FILT>;
   return any ? trace_kernel_q<true, false, false, INST, FILT> : trace_kernel_q<false, false, false, INST, FILT>;
 }
@@ -1119,7 +1178,8 @@ template <bool INST> static TraceFn pick_stats_i(bool any, bool robust) {       
   if (robust) return any ? trace_kernel_q<true, true, true, INST, true> : trace_kernel_q<false, true, true, INST, true>;
   return any ? trace_kernel_q<true, true, false, INST, true> : trace_kernel_q<false, true, false, INST, true>;
 }
-static TraceFn pick_kernel(bool any, bool stats, bool robust, bool inst, bool filt) {
+static TraceFn pick_kernel(bool any, bool stats, bool robust, bool inst, bool filt, bool fptr = false) {
+  if (fptr) return (TraceFn)fptr_kernel(any, robust);            // (a filter function: scenes without instances only, checked by the caller; compiled in trace_fptr.hip)
   if (stats) return inst ? pick_stats_i<true>(any, robust) : pick_stats_i<false>(any, robust);
   if (inst) return filt ? pick_kernel_if<true, true>(any, robust) : pick_kernel_if<true, false>(any, robust);
   return filt ? pick_kernel_if<false, true>(any, robust) : pick_kernel_if<false, false>(any, robust);
@@ -1145,13 +1205,16 @@ size_t trace_spill_bytes(int numCUs, uint32_t depth) {
 }
 
 // (callers hold sc->enqueue of the stream's scratch: see launch_trace / launch_trace_coherent)
+struct FilterCall { unsigned long long fn = 0; void* ctx = nullptr; uint32_t enforce = 0; };   // a __device__ filter function of the caller (mi355_trace_query_filtered)
 static int launch_trace_locked(Bvh* b, TraceScratch* sc, void* d_rays, uint32_t count, size_t stride, bool any, hipStream_t s, uint64_t* statsOut,
-                               hipEvent_t evStart = nullptr, hipEvent_t evStop = nullptr, const uint32_t* deferList = nullptr, const uint32_t* deferCount = nullptr) {
+                               hipEvent_t evStart = nullptr, hipEvent_t evStop = nullptr, const uint32_t* deferList = nullptr, const uint32_t* deferCount = nullptr,
+                               const FilterCall* fc = nullptr) {
   if (count == 0) return 0;
   if (stride < (any ? 48u : 96u) || (stride & 15u) || ((uintptr_t)d_rays & 15u)) return set_error(hipErrorInvalidValue, "ray array must be 16-byte aligned with a 16-byte-multiple stride");
   if (count > 0xFFF00000u) return set_error(hipErrorInvalidValue, "more than 0xFFF00000 rays in one launch (the hand-out arithmetic is 32-bit)");
   HIP_TRY(hipSetDevice(b->device));
-  const TraceFn fn = pick_kernel(any, statsOut != nullptr, b->robust, b->d_insts != nullptr, b->d_rules != nullptr);
+  if (fc && fc->fn && b->d_insts) return set_error(hipErrorNotSupported, "device filter functions are not supported in scenes with instances");
+  const TraceFn fn = pick_kernel(any, statsOut != nullptr, b->robust, b->d_insts != nullptr, b->d_rules != nullptr, fc && fc->fn != 0ull);
   const uint32_t maxBlocks = resident_blocks(b, fn);
   uint32_t blocks = (count + BLOCK - 1) / BLOCK;
   if (blocks > maxBlocks) blocks = maxBlocks;
@@ -1159,12 +1222,21 @@ static int launch_trace_locked(Bvh* b, TraceScratch* sc, void* d_rays, uint32_t 
   a.nodes = (const uint4*)b->d_nodes; a.tris = (const float4*)b->d_tris; a.hasRoot = b->root != MI355_EMPTY_REF ? 1u : 0u;
   a.rays = (char*)d_rays; a.count = count; a.stride = (uint32_t)stride; a.insts = (const float4*)b->d_insts; a.deferList = deferList; a.deferCount = deferCount; a.rules = (const uint4*)b->d_rules;
   a.counter = sc->counter; a.spill = (uint2*)sc->spill; a.spillPerLane = trace_spill_per_lane(b->info.depth); a.stats = nullptr;
+  a.filterFn = fc ? fc->fn : 0ull; a.filterCtx = fc ? fc->ctx : nullptr; a.filterEnforce = fc ? fc->enforce : 0u;
   static const uint32_t refillMin = env_u32("MI355_REFILL_MIN", REFILL_MIN_DEFAULT, 1, 64);
   static const uint32_t pushRounds = env_u32("MI355_PUSH_ROUNDS", PUSH_ROUNDS_DEFAULT, 1, 24);
   static const uint32_t numCursors = env_u32("MI355_NUM_CURSORS", NUM_CURSORS, 1, NUM_CURSORS);
   static const uint32_t drainWaiters = env_u32("MI355_DRAIN_WAITERS", 3, 1, 65);
   auto log2floor = [](uint32_t v) { uint32_t l = 0; while ((2u << l) <= v) l++; return l; };
   a.gShift = log2floor(refillMin); a.cShift = log2floor(numCursors);
+  { static bool warned = false;                                  // (an environment value that is not a power of two used to be rounded down without a word)
+    if (!warned && ((1u << a.gShift) != refillMin || (1u << a.cShift) != numCursors)) {
+      warned = true; fprintf(stderr, "[mi355] MI355_REFILL_MIN / MI355_NUM_CURSORS must be powers of two: using %u / %u\n", 1u << a.gShift, 1u << a.cShift); } }
+  // The cursors are zero because the last wave of the previous launch on this (tree, stream) left them so (wave_exit).  A launch that did NOT run to its end -- it raised the
+  // iteration-cap word, or the application reset the device under it -- may have left them anywhere: after a raised status word the cursors are zeroed on the stream before the next
+  // launch (mi355_trace_status, below); MI355_TRACE_MEMSET=1 zeroes them in front of EVERY launch, as rounds 1 - 3 did (A/B and debugging: ADVICE r04).
+  static const bool memsetAlways = env_u32("MI355_TRACE_MEMSET", 0, 0, 1) != 0u;
+  if (memsetAlways || sc->cursorsDirty) { HIP_TRY(hipMemsetAsync(sc->counter, 0, (EXIT_WORD + 1u) * sizeof(uint32_t), s)); sc->cursorsDirty = false; }
   a.refillMin = 1u << a.gShift; a.numCursors = 1u << a.cShift; a.pushRounds = pushRounds; a.drainWaiters = drainWaiters;
   { const char* e = getenv("MI355_TRACE_ITER_CAP"); const long v = e ? atol(e) : 0; a.iterCap = v > 0 && v < (long)ITER_CAP ? (uint32_t)v : ITER_CAP; }
   a.status = sc->statusDev;
@@ -1186,13 +1258,13 @@ static int launch_trace_locked(Bvh* b, TraceScratch* sc, void* d_rays, uint32_t 
 }
 
 static int launch_trace(Bvh* b, void* d_rays, uint32_t count, size_t stride, bool any, hipStream_t s, uint64_t* statsOut,
-                        hipEvent_t evStart = nullptr, hipEvent_t evStop = nullptr) {
+                        hipEvent_t evStart = nullptr, hipEvent_t evStop = nullptr, const FilterCall* fc = nullptr) {
   if (count == 0) return 0;
   HIP_TRY(hipSetDevice(b->device));
   TraceScratch* sc = b->scratch_for(s);
   if (!sc) return set_error(hipErrorOutOfMemory, "trace scratch allocation failed");
   std::lock_guard<std::mutex> enqueueLock(*sc->enqueue);       // rtcIntersect* are thread safe: another thread's reset must not slip between my reset and my kernel
-  return launch_trace_locked(b, sc, d_rays, count, stride, any, s, statsOut, evStart, evStop);
+  return launch_trace_locked(b, sc, d_rays, count, stride, any, s, statsOut, evStart, evStop, nullptr, nullptr, fc);
 }
 
 typedef void (*PacketFn)(PacketTraceArgs);
@@ -1304,6 +1376,7 @@ int mi355_trace_status(mi355_bvh_t bvh, void* stream, uint32_t* out) {
   HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
   const uint32_t v = (sc->statusHost[0] ? MI355_TRACE_ITER_CAP_HIT : 0u) | (sc->statusHost[1] ? MI355_TRACE_STACK_OVERFLOW : 0u);
   sc->statusHost[0] = 0u; sc->statusHost[1] = 0u;
+  if (v & MI355_TRACE_ITER_CAP_HIT) sc->cursorsDirty = true;    // waves left through the cap: nobody knows where the ray cursors stand (launch_trace_locked zeroes them before the next launch)
   if (out) *out = v;
   return 0;
 }
@@ -1319,6 +1392,11 @@ int mi355_trace_query(mi355_bvh_t bvh, void* d, uint32_t n, size_t stride, int a
   if ((query_flags & MI355_QUERY_COHERENT) && !b->d_insts) return mi355::launch_trace_coherent(b, d, n, stride, any_hit != 0, (hipStream_t)stream);
   return mi355::launch_trace(b, d, n, stride, any_hit != 0, (hipStream_t)stream, nullptr);
 }
+int mi355_trace_query_filtered(mi355_bvh_t bvh, void* d, uint32_t n, size_t stride, int any_hit, uint32_t query_flags, uint64_t filter_fn, void* filter_ctx, void* stream) {
+  mi355::FilterCall fc; fc.fn = filter_fn; fc.ctx = filter_ctx; fc.enforce = (query_flags & MI355_QUERY_INVOKE_ARGUMENT_FILTER) ? 1u : 0u;
+  // (a query with a filter function goes to the per-lane kernel whatever RTC_RAY_QUERY_FLAG_COHERENT says: the packet kernel does not call functions)
+  return mi355::launch_trace((mi355::Bvh*)bvh, d, n, stride, any_hit != 0, (hipStream_t)stream, nullptr, nullptr, nullptr, filter_fn ? &fc : nullptr);
+}
 int mi355_trace_timed(mi355_bvh_t bvh, void* d, uint32_t n, size_t stride, int any_hit, void* stream, void* ev_start, void* ev_stop) {
   return mi355::launch_trace((mi355::Bvh*)bvh, d, n, stride, any_hit != 0, (hipStream_t)stream, nullptr, (hipEvent_t)ev_start, (hipEvent_t)ev_stop);
 }
@@ -1333,3 +1411,4 @@ int mi355_trace_any_packet(mi355_bvh_t bvh, const int* v, void* d, uint32_t K, u
   return mi355::launch_packets((mi355::Bvh*)bvh, v, d, K, n, ps, true, (hipStream_t)stream);
 }
 }
+#endif  // MI355_FPTR_TU

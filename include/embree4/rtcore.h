@@ -472,7 +472,17 @@ RTC_API void rtcOccluded1M(RTCScene scene, struct RTCRay* ray, unsigned int M, s
                            struct RTCOccludedArguments* args RTC_OPTIONAL_ARGUMENT);
 /* Device-resident forms: `rayhit`/`ray` are HIP device pointers on the scene's
    GPU, `stream` is a hipStream_t (NULL = the default stream).  Asynchronous:
-   returns after enqueueing; results are ordered on `stream`. */
+   returns after enqueueing; results are ordered on `stream`.  One call takes at
+   most 0xFFF00000 (4,293,918,720) rays: the kernels' hand-out arithmetic is
+   32-bit; a larger M records RTC_ERROR_INVALID_ARGUMENT (split the batch).
+   Device filter FUNCTIONS (extension, off by default: rtcNewDevice("device_filter_functions=1")): args->filter of these two calls may then be the ADDRESS of a
+       __device__ void f(const struct RTCFilterFunctionNArguments* args)      (gfx950, the caller's own code object; N = 1, args->valid[0] = -1 on entry)
+   which the traversal kernel calls where the reference's GPU path calls its function pointer (kernels/geometry/filter_sycl.h:12-120): for every candidate hit -- after the
+   ray-mask test and the geometry's filter rule -- of the geometries that called rtcSetGeometryEnableFilterFunctionFromArguments, or of all geometries with
+   RTC_RAY_QUERY_FLAG_INVOKE_ARGUMENT_FILTER; args->ray->tfar is the candidate's distance, args->hit the full hit, args->geometryUserPtr / args->context what the
+   application set (device-accessible memory, if the function dereferences them).  Clearing args->valid[0] rejects the candidate and the traversal goes on.  Requires
+   args->feature_mask to contain RTC_FEATURE_FLAG_FILTER_FUNCTION_IN_ARGUMENTS (the default mask does), a device over ONE GPU and a scene without instances.  Without the
+   config key a non-NULL filter in these calls records RTC_ERROR_INVALID_OPERATION (a host function cannot run on the GPU).  How to take the address: INTEGRATION.md. */
 RTC_API void rtcIntersect1MDevice(RTCScene scene, void* rayhit, unsigned int M, size_t byteStride,
                                   struct RTCIntersectArguments* args, void* stream);
 RTC_API void rtcOccluded1MDevice(RTCScene scene, void* ray, unsigned int M, size_t byteStride,

@@ -148,7 +148,7 @@ MI355_API int mi355_bvh_set_filter_rules(mi355_bvh_t bvh, const uint32_t* words,
 MI355_API int mi355_bvh_download(mi355_bvh_t bvh, void* nodes, size_t nodes_bytes, void* tris, size_t tris_bytes);
 
 /* Ray queries on DEVICE-resident AoS arrays (RTCRayHit = 96 B / RTCRay = 48 B records, byte_stride apart).
-   Asynchronous on `stream`.  Per-ray contract = rtcIntersect1 / rtcOccluded1. */
+   Asynchronous on `stream`.  Per-ray contract = rtcIntersect1 / rtcOccluded1.  count <= 0xFFF00000 per launch (32-bit hand-out arithmetic; hipErrorInvalidValue beyond). */
 /* Optional: create the traversal scratch of `stream` (ray cursors, stack spill area) ahead of the first launch on it (which would otherwise allocate it). */
 MI355_API int mi355_trace_prepare(mi355_bvh_t bvh, void* stream);
 MI355_API int mi355_trace_closest(mi355_bvh_t bvh, void* d_rayhit, uint32_t count, size_t byte_stride, void* stream);
@@ -159,6 +159,17 @@ MI355_API int mi355_trace_any(mi355_bvh_t bvh, void* d_ray, uint32_t count, size
    the 64 rays of a wavefront walk the tree TOGETHER (one node fetch for all of them).  Results are those of the incoherent kernels. */
 #define MI355_QUERY_COHERENT 0x10000u
 MI355_API int mi355_trace_query(mi355_bvh_t bvh, void* d_rays, uint32_t count, size_t byte_stride, int any_hit, uint32_t query_flags, void* stream);
+/* The same query with a filter FUNCTION on the device (the reference's GPU path: runIntersectionFilter1SYCL / runOcclusionFilter1SYCL, kernels/geometry/filter_sycl.h:12-120,
+   the function pointer of RTCIntersectArguments::filter / RTCOccludedArguments::filter called from inside the traversal).  filter_fn is the ADDRESS of a
+       __device__ void f(const struct RTCFilterFunctionNArguments* args)          (N = 1; clear args->valid[0] to reject the candidate)
+   in a gfx950 code object loaded in this process (the caller's own .so / hipModule: take the address on the device, e.g. a __device__ variable initialised with it and read
+   back with hipMemcpyFromSymbol); filter_ctx becomes args->context.  The function is called for every candidate hit that passed the geometry's mask test and rules -- of the
+   geometries that enabled it (mi355_bvh_set_filter_rules, w0 bit 16) or, with MI355_QUERY_INVOKE_ARGUMENT_FILTER (= RTC_RAY_QUERY_FLAG_INVOKE_ARGUMENT_FILTER), of every
+   geometry.  Scenes with instances: hipErrorNotSupported.  The callee runs on the traversal kernel's wave: keep it small (it is compiled to the budget of 128 VGPRs the
+   kernel runs with: declare it __attribute__((amdgpu_waves_per_eu(4,4))) if it is large); INTEGRATION.md, "device filter functions". */
+#define MI355_QUERY_INVOKE_ARGUMENT_FILTER 0x2u
+MI355_API int mi355_trace_query_filtered(mi355_bvh_t bvh, void* d_rays, uint32_t count, size_t byte_stride, int any_hit, uint32_t query_flags,
+                                         uint64_t filter_fn, void* filter_ctx, void* stream);
 /* Same launch with a HIP event recorded on `stream` immediately before and after the traversal kernel
    (after the 4-byte cursor reset), so that the interval is the kernel alone.  any_hit selects the kernel. */
 MI355_API int mi355_trace_timed(mi355_bvh_t bvh, void* d_rays, uint32_t count, size_t byte_stride, int any_hit,

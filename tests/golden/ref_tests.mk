@@ -43,8 +43,14 @@ $(OBJ)/%.o: $(REF)/%.cpp
 	@mkdir -p $(dir $@)
 	$(CXX) $(CXXFLAGS) -c $< -o $@
 
-$(OUT)/ref_verify: $(OBJ)/tutorials/verify/verify.o $(OBJ)/tutorials/common/tutorial/application.o $(LIB_OBJ)
-	$(CXX) -o $@ $^ $(COMMON_OBJ) $(LINK)
+# (the one file of this repository in these binaries: see its header)
+$(OBJ)/ref_tests_shim.o: tests/golden/ref_tests_shim.cpp
+	@mkdir -p $(dir $@)
+	$(CXX) $(CXXFLAGS) -I$(REF) -c $< -o $@
 
-$(OUT)/ref_triangle_geometry: $(OBJ)/tutorials/triangle_geometry/triangle_geometry.o $(OBJ)/tutorials/triangle_geometry/triangle_geometry_device.o $(TUT_OBJ) $(LIB_OBJ)
-	$(CXX) -o $@ $^ $(COMMON_OBJ) $(LINK)
+# (the shim goes LAST: static initialisers run in link order, and its one call needs the scheduler's own statics constructed)
+$(OUT)/ref_verify: $(OBJ)/tutorials/verify/verify.o $(OBJ)/tutorials/common/tutorial/application.o $(LIB_OBJ) $(OBJ)/ref_tests_shim.o
+	$(CXX) -o $@ $(filter-out %ref_tests_shim.o,$^) $(COMMON_OBJ) $(OBJ)/ref_tests_shim.o $(LINK)
+
+$(OUT)/ref_triangle_geometry: $(OBJ)/tutorials/triangle_geometry/triangle_geometry.o $(OBJ)/tutorials/triangle_geometry/triangle_geometry_device.o $(TUT_OBJ) $(LIB_OBJ) $(OBJ)/ref_tests_shim.o
+	$(CXX) -o $@ $(filter-out %ref_tests_shim.o,$^) $(COMMON_OBJ) $(OBJ)/ref_tests_shim.o $(LINK)

@@ -26,6 +26,7 @@ ap.add_argument("--high", action="store_true", help="RTC_BUILD_QUALITY_HIGH (pre
 ap.add_argument("--sort", default="", help="experiment: reorder the rays on the host before the upload: origin | origin+octant | octant")
 ap.add_argument("--powerplant", action="store_true", help="configs[4]: the 12.7 M triangle powerplant stand-in instead of the crown stand-in")
 ap.add_argument("--primary", action="store_true")
+ap.add_argument("--shadow", action="store_true", help="configs[3]: one rank's shard (2^21 rays) of the 16 Mi shadow rays, any hit")
 ap.add_argument("--tag", default="")
 ap.add_argument("--tess-room", type=int, default=0, help="experiment: the 12 room triangles of the crown stand-in replaced by K x K quads per wall (what cutting them into sphere-sized pieces would give)")
 ap.add_argument("--retrace", action="store_true", help="trace once, then time the same rays with tfar preset to the hit distance (perfect-culling bound)")
@@ -83,7 +84,15 @@ if a.sort:
     octant = (rays["dir_x"] < 0).astype(np.int64) | ((rays["dir_y"] < 0).astype(np.int64) << 1) | ((rays["dir_z"] < 0).astype(np.int64) << 2)
     key = {"origin": cell, "origin+octant": (cell << 3) | octant, "octant": octant, "octant+origin": (octant << 15) | cell}[a.sort]
     rays = rays[np.argsort(key, kind="stable")].copy()
-if a.any:
+if a.shadow:                                                     # (as tests/gpu_configs.py: 16 shadow rays per hit point of the first 2^17 bounce rays)
+    db = api.DeviceArray.from_numpy(rays)
+    s.intersect1M_device(db.ptr, rays.shape[0])
+    L.mi355_device_synchronize(0)
+    bt = db.download(RAYHIT_DTYPE)
+    db.free()
+    rays = W.shadow_rays(bt[: 1 << 17], meshes, samples=16)
+    a.any = True
+elif a.any:
     rays = rays_of(rays)
 M, rec = rays.shape[0], rays.dtype.itemsize
 pristine = api.DeviceArray.from_numpy(rays)
@@ -103,7 +112,7 @@ for i in range(a.reps + 2):
 res = work.download(rays.dtype)
 L.mi355_memcpy_d2d_async(work.ptr, pristine.ptr, rays.nbytes, None)
 st = s.trace_stats(work.ptr, M, rec, a.any)
-alg = M * 48 + (0 if a.any else int((res["geomID"] != 0xFFFFFFFF).sum()) * 52) + st["nodes"] * 80 + st["tris"] * 48
+alg = M * 48 + (M * 4 if a.any else int((res["geomID"] != 0xFFFFFFFF).sum()) * 52) + st["nodes"] * 80 + st["tris"] * 48
 best = min(ms)
 print("PERF %-24s cfg='%s' build=%.2fms nodes=%d leaves=%d depth=%d sah=%.1f | kernel min %.3f avg %.3f ms -> %.1f Mrays/s | "
       "alg %.0f B/ray %.0f GB/s frac %.3f | per ray: nodes %.2f tris %.2f | wave_iters %d util node %.2f tri %.2f | spills %d stack %d | md5 %s"

@@ -499,7 +499,7 @@ def test_single_ray_call_latency(api, dev):
         q = r.copy(); t0 = time.perf_counter(); s.intersect1(q); ts.append(time.perf_counter() - t0)
     med = 1e6 * float(np.median(ts))
     print("rtcIntersect1: median %.1f us, min %.1f us (hit geom %d prim %d t %.6f)" % (med, 1e6 * min(ts), q["geomID"][0], q["primID"][0], q["tfar"][0]))
-    assert q["geomID"][0] != INVALID_ID and med < 150.0
+    assert q["geomID"][0] != INVALID_ID and med < 60.0, "rtcIntersect1 median %.1f us (round 4: 51 us sleeping on the stream; round 5 polls it: small_poll=0 restores the sleep)" % med
     s.release()
 
 

@@ -6,5 +6,5 @@ D=embree_amd/lib; C=embree_amd/csrc
 python -c "from embree_amd import build; build.build()" > /dev/null
 F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fvisibility=hidden -fno-slp-vectorize -w"   # (the flags of embree_amd/build.py for trace.hip)
 /opt/rocm/bin/hipcc -x hip $F "$@" -c $C/trace.hip -o $D/v_${N}_trace.hip.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -Wl,-z,now -o $D/variant_$N.so $D/build.hip.o $D/v_${N}_trace.hip.o $D/shard.hip.o $D/rtcore_api.cpp.o -ldl
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -Wl,-z,now -o $D/variant_$N.so $D/build.hip.o $D/v_${N}_trace.hip.o $D/trace_fptr.hip.o $D/shard.hip.o $D/rtcore_api.cpp.o -ldl
 rm -f $D/v_${N}_*.o; ls -la $D/variant_$N.so
