@@ -540,6 +540,7 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
     if (!bvh->d_tris) return set_error(hipErrorOutOfMemory, "leaf record array");
     LAUNCH(tri_records, dim3((NC + 255u) / 256u), dim3(256), 0, st, outIds.p, NC, dGeoms.p, (TriRec*)bvh->d_tris, bp->robust ? 1u : 0u, (const Counters*)ctr.p);
     SYNC_READ(h);                                                // the ONE round trip of the commit
+    if (h.overflow == 4u && spatial) return set_error(hipErrorLaunchFailure, "spatial_partition gave up waiting for a predecessor chunk (workgroups not started in index order?)");
     if (h.overflow == 2u && spatial) return set_error(hipErrorOutOfMemory, "spatial split ran out of its extended range");
     // Any overflow of a commit that ran on learned counts is first of all a doubt about those counts (a large set below the last level the chunked path was enqueued for raises 3;
     // a work list that a later kernel found too short may overwrite that 3 with 1): the commit runs again with the blind margins, which report what this scene needs -- the

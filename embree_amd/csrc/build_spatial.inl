@@ -400,8 +400,11 @@ __global__ __launch_bounds__(256) void spatial_partition(Seg* segs, const SegX* 
   {
     uint32_t pl = 0u, pr = 0u;
     for (uint32_t j = sg->chunk0 + tid; j < blockIdx.x; j += 256u) {
-      uint32_t v;
-      do { v = __hip_atomic_load(chunkFlag + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (!(v >> 31)) __builtin_amdgcn_s_sleep(2); } while (!(v >> 31));
+      uint32_t v, spins = 0u;
+      // (the wait is BOUNDED.  It relies on workgroups being started in index order -- a predecessor is then running or done -- which the hardware does and HIP
+      // does not promise: should a predecessor ever be kept off the chip by its waiting successors, they give up after ~2^20 naps (a tenth of a second), the commit reports
+      // overflow = 4 and the host returns an error instead of the GPU hanging for ever)
+      do { v = __hip_atomic_load(chunkFlag + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (!(v >> 31)) { __builtin_amdgcn_s_sleep(2); if (++spins > (1u << 20)) { ctr->overflow = 4u; v = 0x80000000u; } } } while (!(v >> 31));
       pl += (v >> 12) & 0xFFFu; pr += v & 0xFFFu;
     }
     for (int o = 32; o > 0; o >>= 1) { pl += (uint32_t)__shfl_down((int)pl, o, 64); pr += (uint32_t)__shfl_down((int)pr, o, 64); }

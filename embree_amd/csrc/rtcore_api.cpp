@@ -58,6 +58,7 @@ struct Device : RefCounted {
   unsigned shardMin = 16384;                                 // host-array / device-array batches of fewer rays than this per replica stay on replica 0 (config key shard_min)
   int verbose = 0;
   bool benchmark = false;
+  unsigned instanceRefitMax = 32;                            // config key instance_refit_max=<n>: after n refits in a row of the top tree over moved instances, the next commit rebuilds it
   bool noInstanceRefit = false;                              // config key instance_refit=0: moved instances rebuild the top tree and concatenate the object trees again (A/B)
   bool hostInPlace = false;                                  // config key host_in_place=1: large host arrays are traced where they lie (registered + mapped), see replica_query
   bool deviceFilters = false;                                // config key device_filter_functions=1: RTCIntersectArguments::filter / RTCOccludedArguments::filter of the *Device entry points
@@ -317,6 +318,7 @@ struct Scene : RefCounted {
   std::vector<BuiltFrom> builtFrom; unsigned builtFlags = 0;
   struct InstFrom { unsigned id; unsigned long long g; unsigned long long object; unsigned topo, data; unsigned long long objSerial; };   // g = Geometry::serial, object = Scene::serial
   std::vector<InstFrom> builtInst;
+  unsigned instRefitsInARow = 0;                              // commits in a row that refitted the top tree over moved instances (bounded: instance_refit_max)
   unsigned long long commitSerial = 0;                       // changes with every commit that built or refitted something (instances of this scene notice)
   RTCBounds bounds;
   RTCProgressMonitorFunction progress = nullptr; void* progressPtr = nullptr;
@@ -440,6 +442,10 @@ struct Scene : RefCounted {
     bool instMoveOnly = keepFlat && !instGeoms.empty() && haveTree && nowFlags == builtFlags && instFrom.size() == builtInst.size() && !device->noInstanceRefit;
     for (size_t i = 0; instMoveOnly && i < instFrom.size(); i++) { const InstFrom &a = instFrom[i], &b = builtInst[i]; instMoveOnly = a.id == b.id && a.g == b.g && a.object == b.object && a.topo == b.topo && a.objSerial == b.objSerial; }
     for (size_t i = 0; instMoveOnly && i < from.size(); i++) instMoveOnly = from[i].rule == builtFrom[i].rule;
+    //  A refit keeps the top tree's SHAPE: instances that swap places or scatter leave it worse with every commit, and nothing bounded that.  Every
+    // `instance_refit_max`-th commit in a row that would refit builds the top tree anew instead (default 32; the reference rebuilds its top level on every commit of a
+    // dynamic two-level scene, bvh_builder_twolevel.cpp -- the refit is this library's shortcut, so the bound errs on the side of rebuilding).
+    if (instMoveOnly && instRefitsInARow >= device->instanceRefitMax) instMoveOnly = false;
     // ---- every replica does the same thing on its own GPU, side by side (one host thread per GPU; the build is deterministic, so the replicas come out bit-identical)
     std::vector<int> didRefit(reps.size(), 0);
     std::atomic<bool> refitBroken{false};
@@ -508,6 +514,7 @@ struct Scene : RefCounted {
              (unsigned long long)info.num_triangles, (unsigned long long)(info.bytes_nodes + info.bytes_triangles));
     if (progress) progress(progressPtr, 1.0);
     builtInst = instFrom;
+    { bool all = !instGeoms.empty(); for (int d : didRefit) all = all && d != 0; instRefitsInARow = (all && instMoveOnly) ? instRefitsInARow + 1u : 0u; }
     committed = true; modified = false; commitSerial = ++g_commitSerial;
   }
 };
@@ -549,6 +556,7 @@ void parse_config(Device* d, const char* cfg) {
     else if (k == "top_splits") d->build.top_splits = atoi(v.c_str()) != 0 ? 1u : 0u;                 // MEDIUM builds: references that dwarf all others are cut into grid pieces first
     else if (k == "top_split_min") d->build.top_split_min = (uint32_t)atol(v.c_str());
     else if (k == "instance_refit") d->noInstanceRefit = atoi(v.c_str()) == 0;
+    else if (k == "instance_refit_max") d->instanceRefitMax = (unsigned)atol(v.c_str());
     else if (k == "host_in_place") d->hostInPlace = atoi(v.c_str()) != 0;                             // rtcIntersect1M / rtcOccluded1M on large host arrays: trace them in place over the host link
     else if (k == "top_split_rel") d->build.top_split_rel = (float)atof(v.c_str());
     else if (k == "top_split_cell") d->build.top_split_cell = (float)atof(v.c_str());

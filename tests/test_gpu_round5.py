@@ -259,3 +259,44 @@ def test_device_filter_function_vs_reference_callback(api, ref, flags):
     assert ei.value.code == api.RTC_ERROR_INVALID_OPERATION
     d.free(); counters.free()
     r.close(); r2.close(); s.release(); s0.release(); fdev.release(); s0dev.release()
+
+
+# ------------------------------------------------------------------------------------------- the refit of moved instances is bounded
+def test_instance_refits_are_bounded(api):
+    """Instances that only move refit the top tree in place -- but a refit keeps the tree's shape, so `instance_refit_max` refits in a row are followed by a rebuild
+    (rtcore_api.cpp: instRefitsInARow).  256 instances reshuffled six times with instance_refit_max=2: answers equal a scene BUILT with the current transforms after
+    every commit, and the third and sixth commits are builds (num_refits stays where it was)."""
+    from embree_amd.rtypes import make_rayhits
+    d = api.Device("gpu=0,instance_refit_max=2")
+    obj = api.make_scene(d, [W.triangle_sphere(np.zeros(3, np.float32), 0.4, 8)])
+
+    def transforms(seed):
+        r = np.random.default_rng(seed)
+        slots = r.permutation(256)
+        return [np.array([1, 0, 0, 0, 1, 0, 0, 0, 1, (s % 16) * 2.0, (s // 16) * 2.0, r.uniform(-0.3, 0.3)], np.float32) for s in slots]
+
+    top = api.Scene(d)
+    ids = [top.add_instance(obj, x) for x in transforms(0)]
+    top.commit()
+    rng = np.random.default_rng(3)
+    rays = make_rayhits(rng.uniform(-2, 34, (20000, 3)).astype(np.float32), rng.normal(size=(20000, 3)).astype(np.float32))
+    refits = []
+    for step in range(1, 7):
+        xf = transforms(step)
+        for gid, x in zip(ids, xf):
+            top.set_instance_transform(gid, x)
+        top.commit()
+        refits.append(top.info()["num_refits"])
+        fresh = api.Scene(d)
+        for x in xf:
+            fresh.add_instance(obj, x)
+        fresh.commit()
+        got, want = rays.copy(), rays.copy()
+        top.intersect1M(got); fresh.intersect1M(want)
+        assert (want["geomID"] != INVALID_ID).sum() > 500
+        same = (got["tfar"] == want["tfar"]) & (got["primID"] == want["primID"])
+        assert same.all(), "step %d: %d rays differ from a scene built with the moved transforms" % (step, int((~same).sum()))
+        fresh.release()
+    grew = [b > a for a, b in zip([0] + refits[:-1], refits)]
+    assert grew == [True, True, False, True, True, False], "refit / rebuild pattern with instance_refit_max=2: num_refits %r" % (refits,)
+    top.release(); obj.release(); d.release()
