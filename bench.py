@@ -809,6 +809,8 @@ def main():
                 "frac_is": "algorithmic bytes x launches / elapsed / HBM peak: mostly CACHE-SERVED bytes (L1 / L2 / Infinity Cache), not HBM traffic",
                 "traffic": int(pmc["hbm_traffic_bytes_per_launch"]) if pmc and "hbm_traffic_bytes_per_launch" in pmc else None,
                 "traffic_source": "profiles/pmc_bench_latest.json (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE per lone launch of this kernel source)" if pmc else None,
+                "traffic_is": "an UPPER bound: FETCH_SIZE counts 64 bytes per memory-side request whatever its size -- x 2 is right for streaming reads (128-byte requests), x 1 for lone 16-byte loads, "
+                              "x 1.33 for 80-byte records at random addresses (tools/fetch_calib.hip, profiles/r05_fetch_calibration.md); this kernel's node / triangle reads are of the last two kinds" if pmc else None,
                 "peak_measured": {"copy_GBs": round(bw[0], 1), "read_GBs": round(bw[1], 1), "frac_of_copy": round(achieved / bw[0], 4) if bw_ok and bw[0] > 0 else None,
                                   "what": "mi355_measure_bandwidth on this GPU: device-to-device copy (bytes read + written) and read-only streaming kernels over 2 GiB, best of 5"} if bw_ok else None,
                 "kernel": "trace_kernel_q<%s>" % ("any" if shadow else "closest"),
@@ -928,6 +930,10 @@ def main():
                 cb, ref_traced = cpu_baseline(meshes, rays, any_hit=shadow)
                 if cb:
                     out["cpu_baseline"] = cb
+                    if cb.get("value_1Mi") and cb.get("value_16Mi"):   # (a GPU / CPU ratio quoted from this line must say WHICH CPU figure it divides by -- both, named)
+                        out["gpu_over_cpu"] = {"vs_burst_1Mi": round(out["value"] / cb["value_1Mi"], 1), "vs_sustained_16Mi": round(out["value"] / cb["value_16Mi"], 1),
+                                               "what": "value / the reference's rtcIntersect1 on %d hardware threads: the 2^20-ray job (a ~5 ms burst at full speed) and the 16 Mi-ray job (which this "
+                                                       "container's cgroup quota of %s CPUs throttles); a reported baseline, not a target -- the roofline block says how good the kernel is" % (cb["cores"], cb.get("cpu_quota_cores"))}
                 if not shadow:
                     try:
                         out["reference_visits"] = reference_visits(meshes, rays)

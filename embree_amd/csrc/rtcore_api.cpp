@@ -268,6 +268,16 @@ struct Replica {
     return s.h;
   }
   hipStream_t shardStream = nullptr; hipEvent_t shardIn = nullptr, shardOut = nullptr;   // device-array queries sharded over the replicas (sharded_device_query)
+  // Small host queries (rtcIntersect1 ... a few dozen rays, traced in place in pinned memory) run on a NON-BLOCKING stream of their own: on the legacy null stream a poll
+  // (hipStreamQuery) and the launch itself have to look at every blocking stream of the process first -- 49 us per call inside bench.py, which holds a dozen streams, against
+  // 33 us in a process that holds none.  Their inputs are copied from host memory at call time and the committed tree does not change under a query: nothing they could be
+  // ordered against lives on the null stream.
+  hipStream_t smallStream = nullptr;
+  hipStream_t small_stream() {
+    std::lock_guard<std::mutex> lk(mtx);
+    if (!smallStream) { hip_check(hipSetDevice(gpu), "hipSetDevice"); hip_check(hipStreamCreateWithFlags(&smallStream, hipStreamNonBlocking), "hipStreamCreate(small queries)"); }
+    return smallStream;
+  }
   char* stage(size_t bytes) {
     std::lock_guard<std::mutex> lk(mtx);
     Staging& s = staging[staging_key()];
@@ -289,6 +299,7 @@ struct Replica {
     for (int k = 0; k < PIPE; k++) if (pipe[k]) hipStreamDestroy(pipe[k]);
     for (hipEvent_t e : pipeEvents) hipEventDestroy(e);
     if (shardStream) hipStreamDestroy(shardStream);
+    if (smallStream) hipStreamDestroy(smallStream);
     if (shardIn) hipEventDestroy(shardIn);
     if (shardOut) hipEventDestroy(shardOut);
   }
@@ -720,19 +731,20 @@ static void replica_query(Scene* s, size_t k, char* data, unsigned M, size_t str
   if (bytes <= Replica::SMALL_BYTES && s->device->smallInPlace) {
     char* hd = nullptr; char* h = r.stage_host(&hd);
     memcpy(h, data, bytes);
-    core_check(trace_launch(b, hd, M, stride, any, qflags, nullptr), "trace");
+    const hipStream_t sq = s->device->pollSmall ? r.small_stream() : nullptr;
+    core_check(trace_launch(b, hd, M, stride, any, qflags, sq), "trace");
     // (round 5) The launch of a single ray takes ~25 us; hipStreamSynchronize puts the thread to sleep on the completion signal and is woken by an interrupt, which adds
     // 10 - 25 us to every call (36 us minimum, 51 us median on the driver's box in round 4).  A thread that waits for one ray polls instead -- hipStreamQuery reads the
     // signal without sleeping -- for at most ~200 us, after which it falls back to the blocking wait (a long kernel ahead of it in the stream, a preempted process).
     if (s->device->pollSmall) {
       const auto t0 = std::chrono::steady_clock::now();
-      while (hipStreamQuery(nullptr) == hipErrorNotReady) {
+      while (hipStreamQuery(sq) == hipErrorNotReady) {
         if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(200)) break;
       }
       (void)hipGetLastError();                                 // (hipErrorNotReady is not an error)
     }
     uint32_t flags = 0;
-    core_check(mi355_trace_status(b, nullptr, &flags), "trace status");   // (waits for the launch: the status words are read after it)
+    core_check(mi355_trace_status(b, sq, &flags), "trace status");   // (waits for the launch: the status words are read after it)
     memcpy(data, h, bytes);
     if (flags & MI355_TRACE_ITER_CAP_HIT) THROW(RTC_ERROR_UNKNOWN, "traversal stopped at its iteration cap: results are incomplete");
     if (flags & MI355_TRACE_STACK_OVERFLOW) THROW(RTC_ERROR_UNKNOWN, "traversal stack overflow: results are incomplete");
