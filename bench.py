@@ -58,6 +58,7 @@ sys.path.insert(0, ROOT)
 # HIP multiplexes its streams onto 4 hardware queues by default, one of them the null stream's: streams that share a queue
 # run one after the other.  Ask for 8 so that every batch stream gets its own queue (must be set before the runtime starts).
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")           # (RCCL between processes: the host driver only supports dmabuf IPC)
 from embree_amd import api, loaders, shard, workloads as W           # noqa: E402  (loads the HIP library before anything else)
 from embree_amd.rtypes import RAYHIT_DTYPE, RAY_DTYPE, INVALID_ID, rays_of   # noqa: E402
 from tools.kernel_hash import trace_kernel_hash                        # noqa: E402
