@@ -818,6 +818,7 @@ def main():
                 "how": "algorithmic bytes per launch x launches timed / elapsed of the timed region / peak (launches overlap: %.2f in flight); lone launches: see `serial`" % conc,
                 "launches_timed": args.steps, "launches_in_flight": round(conc, 3),
                 "kernel_ms_avg_overlapping": round(avg_ms, 4), "kernel_ms_min": round(float(np.min(kernel_ms)), 4),
+                "kernel_ms_first4": [round(float(x), 4) for x in kernel_ms[:4]], "kernel_ms_last4": [round(float(x), 4) for x in kernel_ms[-4:]],   # (the device is still raising its clocks in the first steps of a short region)
                 "algorithmic_bytes_per_launch": int(alg_bytes),
                 "per_ray": {"nodes": round(st["nodes"] / M, 2), "node_step_simd_util": round(st["nodes"] / max(1, 64 * st["node_blocks"]), 3),
                             "tri_step_simd_util": round(st["tris"] / max(1, 64 * st["tri_blocks"]), 3),

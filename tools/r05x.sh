@@ -1,3 +1,10 @@
 #!/bin/bash
 O=gpurun_out/r05x; mkdir -p $O
-MI355_LIB=$PWD/embree_amd/lib/variant_prof.so timeout 120 python tests/gpu_segclk.py 2>&1 | grep SEGCLK > $O/segclk.log; cat $O/segclk.log
+for w in 5 5; do
+timeout 300 python bench.py --steps 20 --warmup $w --no-cpu --sustain 0 > $O/bench_w$w.json 2> $O/bench_w$w.err
+python - <<PY
+import json
+d=json.loads(open('$O/bench_w$w.json').read().strip().splitlines()[-1]); r=d['roofline']
+print('w$w', d['value'], d['pipelined']['value'], r['kernel_ms_avg_overlapping'], r['kernel_ms_min'], r['kernel_ms_first4'], r['kernel_ms_last4'])
+PY
+done
