@@ -769,7 +769,7 @@ def main():
         # ONE process, one RTCDevice over K GPUs (rtcNewDevice("gpus=K")): the BVH committed on every GPU, the host ray array sharded over them by rtcIntersect1M
         k_gpus = args.inprocess_gpus if args.inprocess_gpus > 0 else ngpu
         if k_gpus > 1:
-            try:
+            def multi_leg():                                  # (guarded: a device that does not answer on a node never seen before must cost the line this leg, not the line)
                 mdev = api.Device(("gpu=%d,gpus=%d,%s" % (gpu, k_gpus, "gpu_oversubscribe=1," if k_gpus > ngpu else "")) + args.config)
                 msc = api.Scene(mdev)
                 for v, t in meshes:
@@ -784,14 +784,14 @@ def main():
                     msc.intersect1M(h)
                     times.append(time.perf_counter() - t1)
                 assert h.tobytes() == result.tobytes(), "the sharded in-process query disagrees with the single-GPU answer"
-                multi = dict(gpus=k_gpus, distinct_gpus=min(k_gpus, ngpu), value=round(M / min(times) / 1e6, 1), unit="Mrays/s", ms=round(1e3 * min(times), 3),
+                out_ = dict(gpus=k_gpus, distinct_gpus=min(k_gpus, ngpu), value=round(M / min(times) / 1e6, 1), unit="Mrays/s", ms=round(1e3 * min(times), 3),
                              commit_all_replicas_ms=round(1e3 * commit_s, 2),
                              what="rtcNewDevice(\"gpus=%d\"): one process, the tree committed on every GPU, rtcIntersect1M on a pageable host array of %d RTCRayHit split contiguously over the "
                                   "replicas (one host thread per GPU, results copied straight into the caller's array); PCIe-inclusive; result identical to the single-GPU answer" % (k_gpus, M))
                 msc.release()
                 mdev.release()
-            except Exception as e:                            # noqa: BLE001
-                multi = dict(error=repr(e))
+                return out_
+            multi = run_guarded(multi_leg, 240)
     gather = None
     if rank == 0:
         avg_ms = float(np.mean(kernel_ms))
