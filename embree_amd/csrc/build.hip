@@ -815,6 +815,10 @@ static int build_instanced_impl(int device, Bvh* own, const mi355_instance* inst
   // kept for mi355_bvh_refit_instanced: the top tree, its box "mesh", the records, the objects behind them
   bvh->h_insts.assign((const uint8_t*)recs.data(), (const uint8_t*)recs.data() + recs.size() * sizeof(InstRec));
   bvh->instObjects.assign(recObj.begin(), recObj.end()); bvh->topHasOwn = hasOwn; if (hasOwn) bvh->instObjects[0] = nullptr;
+  if (hasOwn) {                                                  // the own geometry's box stays on the host for the refits (kept in the top tree's otherwise unused record bytes:
+    float ob[6]; for (int d = 0; d < 3; d++) { ob[d] = own->info.bounds_lower[d]; ob[3 + d] = own->info.bounds_upper[d]; }   // every refit read it back from the device)
+    top->h_insts.assign((const uint8_t*)ob, (const uint8_t*)ob + sizeof(ob));
+  }
   bvh->top = top; top = nullptr; bvh->d_topVerts = dfv; dfv = nullptr; bvh->d_topIdx = dfi; dfi = nullptr;
   guard.ok = true; *out = bvh;
   return 0;
@@ -835,7 +839,8 @@ static int refit_instanced_impl(Bvh* bvh, const mi355_instance* insts, uint32_t 
     for (int d = 0; d < 3; d++) { fv[at * 9 + d] = lo[d]; fv[at * 9 + 3 + d] = hi[d]; fv[at * 9 + 6 + d] = lo[d]; blo[d] = fminf(blo[d], lo[d]); bhi[d] = fmaxf(bhi[d], hi[d]); }
   };
   if (bvh->topHasOwn) {                                          // the scene's own geometry: record 0, where it was (box: what the build copied into the top tree's mesh)
-    float own[9]; HIP_TRY(hipMemcpy(own, bvh->d_topVerts, sizeof(own), hipMemcpyDeviceToHost));
+    if (bvh->top->h_insts.size() != 6 * sizeof(float)) return MI355_REFIT_IMPOSSIBLE;
+    float own[6]; memcpy(own, bvh->top->h_insts.data(), sizeof(own));
     put_box(0, own, own + 3); k = 1;
   }
   for (uint32_t i = 0; i < numInsts; i++) {
@@ -856,6 +861,7 @@ static int refit_instanced_impl(Bvh* bvh, const mi355_instance* insts, uint32_t 
   }
   if (k != R) return MI355_REFIT_IMPOSSIBLE;
   Bvh* top = bvh->top;
+  if (!top->d_ids || top->info.num_triangles != R || top->info.num_nodes == 0) return MI355_REFIT_IMPOSSIBLE;   // (what refit_impl would refuse: nothing has been written yet)
   HIP_TRY(hipMemcpyAsync(bvh->d_topVerts, fv.data(), fv.size() * 4, hipMemcpyHostToDevice, st));
   mi355_mesh fake{}; fake.d_vertices = bvh->d_topVerts; fake.vertex_stride = 12; fake.num_vertices = (uint32_t)(3 * R); fake.d_indices = bvh->d_topIdx; fake.index_stride = 12;
   fake.num_triangles = (uint32_t)R; fake.geom_id = 0; fake.mask = 0xFFFFFFFFu;

@@ -300,3 +300,47 @@ def test_instance_refits_are_bounded(api):
     grew = [b > a for a, b in zip([0] + refits[:-1], refits)]
     assert grew == [True, True, False, True, True, False], "refit / rebuild pattern with instance_refit_max=2: num_refits %r" % (refits,)
     top.release(); obj.release(); d.release()
+
+
+@pytest.mark.gpu
+def test_instance_refit_with_own_geometry(api):
+    """A scene that holds triangles of its own NEXT to instances: when only the instances move, the top tree is refitted and the record of the scene's own geometry
+    keeps its box (build.hip refit_instanced_impl: the box stays on the host -- ADVICE r04: every refit read it back from the device).  Answers = a scene built with
+    the moved transforms; the own geometry is still hit."""
+    from embree_amd.rtypes import make_rayhits
+    d = api.Device("gpu=0")
+    obj = api.make_scene(d, [W.triangle_sphere(np.zeros(3, np.float32), 0.4, 8)])
+    floor_v = np.array([[-4, -4, -1], [36, -4, -1], [36, 36, -1], [-4, 36, -1]], np.float32)
+    floor_t = np.array([[0, 1, 2], [0, 2, 3]], np.uint32)
+
+    def transforms(seed):
+        r = np.random.default_rng(seed)
+        return [np.array([1, 0, 0, 0, 1, 0, 0, 0, 1, (k % 8) * 4.0 + r.uniform(-1, 1), (k // 8) * 4.0 + r.uniform(-1, 1), r.uniform(0, 2)], np.float32) for k in range(64)]
+
+    def build(xf):
+        t = api.Scene(d)
+        t.add_triangle_mesh(floor_v, floor_t)
+        ids = [t.add_instance(obj, x) for x in xf]
+        t.commit()
+        return t, ids
+
+    top, ids = build(transforms(0))
+    rng = np.random.default_rng(5)
+    org = rng.uniform(-2, 34, (20000, 3)).astype(np.float32); org[:, 2] = rng.uniform(3, 6, 20000)
+    dirs = rng.normal(size=(20000, 3)).astype(np.float32); dirs[:, 2] = -np.abs(dirs[:, 2]) - 0.5
+    rays = make_rayhits(org, dirs)
+    for step in (1, 2, 3):
+        xf = transforms(step)
+        for gid, x in zip(ids, xf):
+            top.set_instance_transform(gid, x)
+        top.commit()
+        assert top.info()["num_refits"] == step, "the commit after a move did not refit the top tree"
+        fresh, _ = build(xf)
+        got, want = rays.copy(), rays.copy()
+        top.intersect1M(got); fresh.intersect1M(want)
+        own_hits = int(((want["geomID"] == 0) & (want["instID"] == INVALID_ID)).sum())
+        assert own_hits > 5000 and (want["geomID"] != INVALID_ID).sum() > own_hits + 200
+        same = (got["tfar"] == want["tfar"]) & (got["primID"] == want["primID"]) & (got["geomID"] == want["geomID"])
+        assert same.all(), "step %d: %d rays differ from a scene built with the moved transforms" % (step, int((~same).sum()))
+        fresh.release()
+    top.release(); obj.release(); d.release()
