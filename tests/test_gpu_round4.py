@@ -363,9 +363,11 @@ def test_moved_instances_refit_the_top_tree(api, dev):
     blo, bhi = top.bounds(); flo, fhi = fresh.bounds()
     assert (blo == flo).all() and (bhi == fhi).all()
     # a second move, timed alone (transforms set before the clock): the whole commit
-    for gid, x in zip(ids, a0):
-        top.set_instance_transform(gid, x)
-    t0 = time.perf_counter(); top.commit(); wall2 = time.perf_counter() - t0
+    wall2 = 1e9                                             # (best of three moves a0, a1, a0: one wall-clock sample on a shared host is not a measurement)
+    for xf in (a0, a1, a0):
+        for gid, x in zip(ids, xf):
+            top.set_instance_transform(gid, x)
+        t0 = time.perf_counter(); top.commit(); wall2 = min(wall2, time.perf_counter() - t0)
     got2 = rays.copy(); top.intersect1M(got2)
     assert ((got2["instID"] == before["instID"]) & (got2["tfar"] == before["tfar"])).mean() > 0.9999
     print("4096 moved instances: commit %.3f ms / %.3f ms wall (refit %.3f ms GPU); built scene: %.3f ms GPU" % (wall * 1e3, wall2 * 1e3, info["build_ms"], fresh.info()["build_ms"]))
