@@ -386,11 +386,28 @@ class Scene:
         self.dev.check()
         return gid
 
-    def add_quad_mesh(self, verts, quads, mask=None):
-        """rtcNewGeometry(QUAD): float3 vertices, uint4 indices (shared host buffers)."""
+    def add_quad_mesh(self, verts, quads, mask=None, index_words=None, index_stride=16):
+        """rtcNewGeometry(QUAD): float3 vertices, uint4 indices (shared host buffers).  `index_words` + `index_stride`: the index view as the application lays it
+        out -- a flat uint32 array in which quad i is the four words at byte i * index_stride (12: consecutive quads overlap in one word, BufferStrideTest,
+        tutorials/verify/verify.cpp:995-1008); `quads` then only gives the count."""
         L = self.L
         v = np.ascontiguousarray(verts, np.float32).reshape(-1, 3)
         q = np.ascontiguousarray(quads, np.uint32).reshape(-1, 4)
+        if index_words is not None:
+            w = np.ascontiguousarray(index_words, np.uint32).ravel()
+            g = L.rtcNewGeometry(self.dev.h, RTC_GEOMETRY_TYPE_QUAD)
+            self.dev.check()
+            vp = np.concatenate([v.ravel(), np.zeros(4, np.float32)])
+            self._keep += [vp, w]
+            L.rtcSetSharedGeometryBuffer(g, RTC_BUFFER_TYPE_VERTEX, 0, RTC_FORMAT_FLOAT3, vp.ctypes.data, 0, 12, v.shape[0])
+            L.rtcSetSharedGeometryBuffer(g, RTC_BUFFER_TYPE_INDEX, 0, RTC_FORMAT_UINT4, w.ctypes.data, 0, index_stride, q.shape[0])
+            if mask is not None:
+                L.rtcSetGeometryMask(g, mask)
+            L.rtcCommitGeometry(g)
+            gid = L.rtcAttachGeometry(self.h, g)
+            L.rtcReleaseGeometry(g)
+            self.dev.check()
+            return gid
         g = L.rtcNewGeometry(self.dev.h, RTC_GEOMETRY_TYPE_QUAD)
         self.dev.check()
         vp = np.concatenate([v.ravel(), np.zeros(4, np.float32)])

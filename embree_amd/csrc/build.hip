@@ -223,7 +223,9 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
   for (uint32_t i = 0; i < numMeshes; i++) {
     const mi355_mesh& m = meshes[i];
     if (m.num_triangles == 0) continue;
-    if (m.vertex_stride < 12 || (m.vertex_stride & 3) || m.index_stride < (m.quads ? 16u : 12u) || (m.index_stride & 3)) return set_error(hipErrorInvalidValue, "buffer stride");
+    // (no "stride >= element size": the reference accepts views whose elements overlap -- BufferStrideTest, tutorials/verify/verify.cpp:995-1008, binds UINT4 quad
+    // indices with a 12-byte stride -- and every kernel here reads element i word by word at offset + i * stride: prim_indices, primref_gen, tri_records, refit_level)
+    if ((m.vertex_stride & 3) || (m.index_stride & 3)) return set_error(hipErrorInvalidValue, "buffer stride");
     GeomDesc g{}; g.verts = (const char*)m.d_vertices; g.idx = (const char*)m.d_indices; g.vstride = (uint32_t)m.vertex_stride; g.istride = (uint32_t)m.index_stride;
     g.nv = m.num_vertices; g.quad = m.quads ? 1u : 0u; g.nt = m.num_triangles * (g.quad ? 2u : 1u); g.geomID = m.geom_id; g.mask = m.mask; g.primOffset = (uint32_t)total;
     total += g.nt; gd.push_back(g);
@@ -636,7 +638,7 @@ static int refit_impl(Bvh* bvh, const mi355_mesh* meshes, uint32_t numMeshes, hi
   for (uint32_t i = 0; i < numMeshes; i++) {
     const mi355_mesh& m = meshes[i];
     if (m.num_triangles == 0) continue;
-    if (m.vertex_stride < 12 || (m.vertex_stride & 3) || m.index_stride < (m.quads ? 16u : 12u) || (m.index_stride & 3)) return set_error(hipErrorInvalidValue, "buffer stride");
+    if ((m.vertex_stride & 3) || (m.index_stride & 3)) return set_error(hipErrorInvalidValue, "buffer stride");
     GeomDesc g{}; g.verts = (const char*)m.d_vertices; g.idx = (const char*)m.d_indices; g.vstride = (uint32_t)m.vertex_stride; g.istride = (uint32_t)m.index_stride;
     g.nv = m.num_vertices; g.quad = m.quads ? 1u : 0u; g.nt = m.num_triangles * (g.quad ? 2u : 1u); g.geomID = m.geom_id; g.mask = m.mask; g.primOffset = (uint32_t)total;
     total += g.nt; gd.push_back(g);

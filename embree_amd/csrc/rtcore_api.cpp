@@ -932,13 +932,21 @@ RTC_API ssize_t rtcGetDeviceProperty(RTCDevice h, enum RTCDeviceProperty prop) {
     case RTC_DEVICE_PROPERTY_TRIANGLE_GEOMETRY_SUPPORTED: case RTC_DEVICE_PROPERTY_QUAD_GEOMETRY_SUPPORTED: return 1;
     case RTC_DEVICE_PROPERTY_HIP_DEVICE: return 1;
     case RTC_DEVICE_PROPERTY_GPU_COUNT: return (ssize_t)((Device*)h)->gpus.size();
+    // What is BUILT answers 1, like the reference's default configuration does for the same feature (kernels/common/device.cpp:480-600):
+    //  * filter functions: rtcSetGeometryIntersect/OccludedFilterFunction and the argument filter run for every entry point (host callbacks between launches, rules
+    //    and device functions inside the kernels) -- EMBREE_FILTER_FUNCTION, device.cpp:515.  tutorials/verify registers its intersection_filter group on this answer.
+    //  * rtcJoinCommitScene: Scene::commit holds the scene's lock and an unmodified scene returns at once, so threads that join find the tree built when their call
+    //    returns (device.cpp:566-572: 1 with the internal tasking system).
+    case RTC_DEVICE_PROPERTY_FILTER_FUNCTION_SUPPORTED: case RTC_DEVICE_PROPERTY_JOIN_COMMIT_SUPPORTED: return 1;
+    // What is NOT built, or is off in the reference's default configuration too (backface culling, compact polys, ignore-invalid-rays: CMake options that default to OFF),
+    // answers 0; TASKING_SYSTEM 0 = "internal" (the GPU is the worker pool); commits of one device are serialised by the build arena: no parallel commit.
     case RTC_DEVICE_PROPERTY_BACKFACE_CULLING_ENABLED: case RTC_DEVICE_PROPERTY_BACKFACE_CULLING_CURVES_ENABLED:
-    case RTC_DEVICE_PROPERTY_BACKFACE_CULLING_SPHERES_ENABLED: case RTC_DEVICE_PROPERTY_FILTER_FUNCTION_SUPPORTED:
+    case RTC_DEVICE_PROPERTY_BACKFACE_CULLING_SPHERES_ENABLED:
     case RTC_DEVICE_PROPERTY_IGNORE_INVALID_RAYS_ENABLED: case RTC_DEVICE_PROPERTY_COMPACT_POLYS_ENABLED:
     case RTC_DEVICE_PROPERTY_SUBDIVISION_GEOMETRY_SUPPORTED:
     case RTC_DEVICE_PROPERTY_CURVE_GEOMETRY_SUPPORTED: case RTC_DEVICE_PROPERTY_USER_GEOMETRY_SUPPORTED:
     case RTC_DEVICE_PROPERTY_POINT_GEOMETRY_SUPPORTED: case RTC_DEVICE_PROPERTY_TASKING_SYSTEM:
-    case RTC_DEVICE_PROPERTY_JOIN_COMMIT_SUPPORTED: case RTC_DEVICE_PROPERTY_PARALLEL_COMMIT_SUPPORTED:
+    case RTC_DEVICE_PROPERTY_PARALLEL_COMMIT_SUPPORTED:
     case RTC_DEVICE_PROPERTY_CPU_DEVICE: case RTC_DEVICE_PROPERTY_SYCL_DEVICE: return 0;
     default: THROW(RTC_ERROR_INVALID_ARGUMENT, "unknown readable property");
   }

@@ -78,6 +78,8 @@ struct TraceArgs {
   uint32_t refillMin, pushRounds, numCursors, drainWaiters;   // refillMin and numCursors are powers of two (gShift, cShift: their logarithms): the hand-out arithmetic is shifts and 32-bit adds
   uint32_t gShift, cShift;
   uint32_t iterCap, helpers;
+  uint32_t staticRays;   // 0: rays are handed out through the cursors.  R (a power of two <= 64): a SMALL batch -- no more rays than lane slots in the grid -- wave w owns rays [w R, (w + 1) R): no cursor, no
+                         // atomic, no reserve-ahead; lanes R .. 63 (and every lane whose ray is done) are tail helpers from the first iteration on (step 1b)
   volatile uint32_t* status;  // host-mapped: [STATUS_ITER_CAP], [STATUS_SPILL] set to 1 when a safety net dropped work
   unsigned long long* stats;  // optional counters
   const float4* insts;   // INST kernels: InstRec[] as 4 x float4 (world2local vx,vy,vz,p | root node, instID, mask, flags)
@@ -444,17 +446,46 @@ __global__ __launch_bounds__(BLOCK, FILT == 2 ? 4 : 1) MI355_TRACE_ATTR void tra
     // (every cursor atomic of this wave has been PERFORMED before it counts itself out -- also the block reserved ahead whose answer nobody waited for: atomics
     // on different words may reach L2 in any order, and one that lands after the last wave's reset leaves a cursor at 1: the next launch skips 16 rays)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane == 0u) {
+    if (lane == 0u && a.staticRays == 0u) {                     // (a static launch never touched a cursor: nothing to reset, nobody to count)
       if (atomicAdd(a.counter + EXIT_WORD, 1u) == gridDim.x * (BLOCK / 64u) - 1u) {
         for (uint32_t c = 0; c < NUM_CURSORS; c++) atomicExch(a.counter + c * CURSOR_STRIDE, 0u);
         atomicExch(a.counter + EXIT_WORD, 0u);
       }
     }
   };
+  // a lane takes a ray: TravRay set-up (setup_rdir), the root as "the one hit child of a virtual node", its best[] / helper words
+  auto start_ray = [&](const uint32_t newIdx, const float4 r0, const float4 r1, const float4 r2) {
+    rayIdx = newIdx;
+    ox = r0.x; oy = r0.y; oz = r0.z; tnear = r0.w;
+    dx = r1.x; dy = r1.y; dz = r1.z;
+    tfar = r2.x; tfar0 = r2.x; rmask = __float_as_uint(r2.y);
+    setup_rdir<ROBUST>(dx, dy, dz, rdx, rdy, rdz, rfx, rfy, rfz, octinv4);
+    tnearTrav = fmaxf(tnear, 0.0f);                               // tnear/tfar clamped to >= 0 for traversal (bvh_intersector1.cpp:65)
+    if (INST) { inst = NO_INST; bestInst = NO_INST; }
+    sp = 0; ngBase = 0; ngHits = 0x80000000u; tgBase = 0; tgHits = 0;   // "the root is the one hit child of a virtual node"
+    lastTicket = qHead; travDone = false;
+    best[lane] = ((unsigned long long)__float_as_uint(tfar) << 32) | 0xFFFFFFFFull;
+    pend[lane] = 0u; lastT[lane] = qHead;
+    active = a.hasRoot != 0u && !(ANY && tfar < 0.0f);            // empty scene / already occluded (bvh_intersector1.cpp:128)
+    if (STATS) stRays++;
+  };
   const uint32_t rayCount = a.deferCount ? *a.deferCount * 64u : a.count;   // (wave-uniform) rays to hand out: all of them, or those of the deferred packets
   if (rayCount == 0u) return;                                               // (the pass behind a packet launch none of whose packets gave up: nobody touches a cursor, nobody counts
                                                                             // itself out -- 4096 waves leaving at once through one atomic word cost the Cornell box 40 % of its coherent rate)
   const uint32_t totalBlocks = (rayCount + a.refillMin - 1u) >> a.gShift;      // (wave-uniform) blocks of refillMin rays in this launch
+  // SMALL batches (round 6; SURVEY 8e: one 2^20-ray batch over 8 GPUs is 2^17 rays per launch).  A launch with no more rays than the grid has lane slots used to run
+  // through the same hand-out: every wave took its 64 rays with one atomic, found the eight cursors dry one atomic round trip after the other (that is when `exhausted`
+  // rises and the tail helpers may start), and counted itself out through a ninth -- and with 64 rays per wave half of the SIMDs' wave slots stayed empty.  Such a launch
+  // is all ramp and tail, so: the host picks R = rays per wave so that the grid fills every wave slot (launch_trace_locked), wave w owns rays [w R, (w + 1) R), nobody
+  // touches a cursor, and the lanes without a ray help from the first iteration on.  Same rays, same candidates, same minimum: the hit records are the bytes of a large batch.
+  if (a.staticRays != 0u) {
+    const uint32_t idx = blockIdx.x * (BLOCK / 64u) * a.staticRays + (tid >> 6) * a.staticRays + lane;
+    if (lane < a.staticRays && idx < rayCount) {
+      const float4* rp = (const float4*)(a.rays + (size_t)idx * a.stride);
+      start_ray(idx, rp[0], rp[1], rp[2]);
+    }
+    exhausted = true;
+  }
   uint32_t iter = 0;
   for (; iter < a.iterCap; iter++) {
     // ------------------------------------------------------------------ 0. a full batch of queued pairs is waiting: issue the loads of its triangle records now, so that
@@ -543,21 +574,7 @@ __global__ __launch_bounds__(BLOCK, FILT == 2 ? 4 : 1) MI355_TRACE_ATTR void tra
             }
           }
           // (d) start the new rays
-          if (got) {
-            rayIdx = newIdx;
-            ox = r0.x; oy = r0.y; oz = r0.z; tnear = r0.w;
-            dx = r1.x; dy = r1.y; dz = r1.z;
-            tfar = r2.x; tfar0 = r2.x; rmask = __float_as_uint(r2.y);
-            setup_rdir<ROBUST>(dx, dy, dz, rdx, rdy, rdz, rfx, rfy, rfz, octinv4);
-            tnearTrav = fmaxf(tnear, 0.0f);                               // tnear/tfar clamped to >= 0 for traversal (bvh_intersector1.cpp:65)
-            if (INST) { inst = NO_INST; bestInst = NO_INST; }
-            sp = 0; ngBase = 0; ngHits = 0x80000000u; tgBase = 0; tgHits = 0;   // "the root is the one hit child of a virtual node"
-            lastTicket = qHead; travDone = false;
-            best[lane] = ((unsigned long long)__float_as_uint(tfar) << 32) | 0xFFFFFFFFull;
-            pend[lane] = 0u; lastT[lane] = qHead;
-            active = a.hasRoot != 0u && !(ANY && tfar < 0.0f);            // empty scene / already occluded (bvh_intersector1.cpp:128)
-            if (STATS) stRays++;
-          }
+          if (got) start_ray(newIdx, r0, r1, r2);
           more = canGrab && !exhausted;                                   // more free lanes than one block (launch start, small G)
         }
         if (STATS) stRefillClk += __builtin_readcyclecounter() - stT0;
@@ -1166,6 +1183,7 @@ namespace mi355 {
 void* fptr_kernel(bool any, bool robust);                       // the FILT == 2 kernels (device filter functions): trace_fptr.hip
 
 typedef void (*TraceFn)(TraceArgs);
+static uint32_t log2floor_u32(uint32_t v) { uint32_t l = 0; while ((2u << l) <= v) l++; return l; }
 static uint32_t env_u32(const char* name, uint32_t def, uint32_t lo, uint32_t hi) {
   const char* e = getenv(name); if (!e) return def;
   const long v = atol(e); return v < (long)lo || v > (long)hi ? def : (uint32_t)v;
@@ -1218,11 +1236,29 @@ static int launch_trace_locked(Bvh* b, TraceScratch* sc, void* d_rays, uint32_t 
   const uint32_t maxBlocks = resident_blocks(b, fn);
   uint32_t blocks = (count + BLOCK - 1) / BLOCK;
   if (blocks > maxBlocks) blocks = maxBlocks;
+  // The launch shape follows the ray count (round 6; the sweep behind the numbers: profiles/r06_batch_sweep.md).  More rays than lane slots: the persistent grid with the
+  // cursor hand-out, as before.  A batch that fits into HALF the resident waves at 16 rays each or more (count <= 2^16 on 256 CUs): static ownership, R rays per wave with
+  // R the smallest power of two >= 16 that keeps the grid at two waves per SIMD or fewer -- a launch of 2^12 .. 2^15 rays is ONE ray's dependent chain of node
+  // fetches long (84 us for 4096 rays), and 48 helper lanes per wave from the first iteration on shorten that chain (2^15 rays: 136 -> 106 us).  More waves than two per
+  // SIMD do NOT help: an iteration costs a wave the same ~420 instructions whether 16 or 64 of its lanes hold a ray, and two waves already keep a SIMD's issue port busy
+  // (2^17 rays: 4096 waves x 32 rays 186 us, 2048 x 64 171 us).  MI355_STATIC_RAYS=0 switches the static shape off, =16/32/64 fixes R for every batch that fits.
+  static const uint32_t staticEnv = env_u32("MI355_STATIC_RAYS", 1, 0, 64);
+  static const uint32_t smallFrac8 = env_u32("MI355_SMALL_FRAC8", 8, 1, 8);       // A/B: a batch with fewer rays than lane slots runs on this many eighths of the waves it could fill (the rest is refill)
+  uint32_t staticRays = 0u;
+  if (!deferList && !statsOut && BLOCK == 64 && (uint64_t)count <= (uint64_t)maxBlocks * 64u) {
+    if (staticEnv == 1u) {
+      uint32_t R = 16u; while (R < 64u && (uint64_t)(maxBlocks / 2u) * R < count) R <<= 1;
+      if ((uint64_t)(maxBlocks / 2u) * R >= count && R < 64u) staticRays = R;
+    } else if (staticEnv >= 16u) staticRays = 1u << log2floor_u32(staticEnv);
+    if (staticRays) { blocks = (count + staticRays - 1u) / staticRays; if (blocks > maxBlocks) { staticRays = 0u; blocks = (count + BLOCK - 1) / BLOCK; } }
+    if (!staticRays && smallFrac8 < 8u) { blocks = (uint32_t)(((uint64_t)blocks * smallFrac8 + 7u) / 8u); if (blocks == 0u) blocks = 1u; }
+  }
   TraceArgs a;                                                 // (the ray cursors are zero: the last wave of the previous launch on this stream left them so, see wave_exit)
   a.nodes = (const uint4*)b->d_nodes; a.tris = (const float4*)b->d_tris; a.hasRoot = b->root != MI355_EMPTY_REF ? 1u : 0u;
   a.rays = (char*)d_rays; a.count = count; a.stride = (uint32_t)stride; a.insts = (const float4*)b->d_insts; a.deferList = deferList; a.deferCount = deferCount; a.rules = (const uint4*)b->d_rules;
   a.counter = sc->counter; a.spill = (uint2*)sc->spill; a.spillPerLane = trace_spill_per_lane(b->info.depth); a.stats = nullptr;
   a.filterFn = fc ? fc->fn : 0ull; a.filterCtx = fc ? fc->ctx : nullptr; a.filterEnforce = fc ? fc->enforce : 0u;
+  a.staticRays = staticRays;
   static const uint32_t refillMin = env_u32("MI355_REFILL_MIN", REFILL_MIN_DEFAULT, 1, 64);
   static const uint32_t pushRounds = env_u32("MI355_PUSH_ROUNDS", PUSH_ROUNDS_DEFAULT, 1, 24);
   static const uint32_t numCursors = env_u32("MI355_NUM_CURSORS", NUM_CURSORS, 1, NUM_CURSORS);

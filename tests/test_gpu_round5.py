@@ -4,6 +4,7 @@ import ctypes as C
 import hashlib
 import os
 import subprocess
+import time
 
 import numpy as np
 import pytest
@@ -114,7 +115,14 @@ VERIFY_MUST_PASS = [
     (".*triangle_split_epsilon.*", 1), (".*interpolate.triangles.*", 6),
     (".*ray_alignment_test.*sphere.triangles", 8), (".*ray_alignment_test.*sphere.quads", 8),   # RayAlignmentTest :3759
     (".*user_geometry_id.*", 5),
+    # IntersectionFilterTest :2762-2836, registered at :6497-6508 when rtcGetDeviceProperty(RTC_DEVICE_PROPERTY_FILTER_FUNCTION_SUPPORTED) answers 1 (round 6: it does --
+    # the filters were built in round 3 and the property still said 0, which hid this group): a geometry filter that rejects primID & 2 on a 4 x 4 triangle plane, through
+    # rtcIntersect1/4/8/16 and rtcOccluded1/4/8/16 with every scene flag set.  The subdivision half of the group is out of scope (VERIFY_OUT_OF_SCOPE).
+    (".*intersection_filter.triangles.*", 120),
 ]
+# Every group runs at the program's full --intensity 1.0 (round 5 ran everything at 0.2); an entry here lowers it for a group whose call count scales with the intensity
+# and whose every call is one kernel launch, should the box need it (MI355_VERIFY_INTENSITY=<float> overrides all)
+VERIFY_INTENSITY = {".*ray_alignment_test.*sphere.triangles": 0.25, ".*ray_alignment_test.*sphere.quads": 0.25}   # (at 1.0: 70 s each, 16 tests x 15 packet sizes x 1000 launches; everything else < 45 s)
 # Groups that cannot pass BY SCOPE: each of them builds its scene from geometry types SURVEY 8 marks out of scope (an Embree built without those types would not register them
 # either -- but they do not ask rtcGetDeviceProperty first).  Named here with the reason so that nobody reads a silent omission as a pass.
 VERIFY_OUT_OF_SCOPE = {
@@ -124,6 +132,8 @@ VERIFY_OUT_OF_SCOPE = {
     "enable_disable_geometry / disable_detach_geometry / new_delete_geometry / update": "the same four-type scene (addSubdivSphere, addHair: :1523-1720, :1835)",
     "build / many_build / build_garbage_geom / overlapping_primitives": "motion-blur meshes, grids, subdivision surfaces and hair next to the triangle meshes (:1173-1260, :1915)",
     "ray_alignment_test.*grids|subdiv, watertight_grids|subdiv|*_mb, get_linear_bounds, interpolate, point_query, instance_arrays": "grids, subdivision, motion blur, instance arrays, point queries",
+    "intersection_filter.subdiv": "the same filter over a SUBDIVISION plane (addSubdivPlane, :2796); the triangle half of the group is in VERIFY_MUST_PASS",
+    "regression_static|dynamic(_build_join|_memory_monitor)": "random scenes of all geometry types incl. hair, subdivision, motion blur (rtcore_regression_*_thread, :4700-5100)",
     "geometry_state_tests / scene_modified_geometry_tests": "cast RTCGeometry / RTCScene handles to the reference's internal classes (:4480-4600)",
 }
 
@@ -136,25 +146,31 @@ def _run_verify(pattern, intensity=0.2, timeout=300):
     return r.returncode, (int(p.group(1)) if p else -1), (int(f.group(1)) if f else -1), out
 
 
-@pytest.mark.skipif(not os.path.exists(VERIFY), reason="tests/golden/_bin/ref_verify not built (make -f tests/golden/ref_tests.mk in the build container)")
+def _must_exist(path, how):
+    """ A missing build product is a FAILURE on the GPU box, not a skip: a box where tests/golden/ref_tests.mk failed would otherwise look green."""
+    assert os.path.exists(path), "%s is missing: %s must have run in the build container before the snapshot was taken" % (os.path.relpath(path, ROOT), how)
+
+
 def test_reference_verify_program_unmodified(api, dev):
     """The reference's own API / intersection test program, tutorials/verify/verify.cpp, compiled UNMODIFIED (tests/golden/ref_tests.mk) and linked against
     libembree4_mi355.so: the triangle / quad / instance groups (VERIFY_MUST_PASS) pass test by test, on the GPU.  Reduced intensity: every ray of these tests is one
     rtcIntersect1/4/8/16 call = one kernel launch."""
+    _must_exist(VERIFY, "make -f tests/golden/ref_tests.mk (__graft_entry__.build())")
     report = []
     for entry in VERIFY_MUST_PASS:
         pattern, at_least, out_of_scope = entry[0], entry[1], (entry[2] if len(entry) > 2 else 0)
-        rc, passed, failed, out = _run_verify(pattern)
-        report.append((pattern, rc, passed, failed))
+        t0 = time.time()
+        rc, passed, failed, out = _run_verify(pattern, intensity=float(os.environ.get("MI355_VERIFY_INTENSITY", VERIFY_INTENSITY.get(pattern, 1.0))), timeout=900)
+        report.append((pattern, rc, passed, "%.1fs" % (time.time() - t0)))
         assert failed == out_of_scope and passed >= at_least and (rc == 0 or out_of_scope), "reference verify --run '%s': rc %d, %d passed, %d failed\n%s" % (pattern, rc, passed, failed, out[-1500:])
-    print("reference verify:", ", ".join("%s %d" % (p, n) for p, _, n, _ in report))
+    print("reference verify:", ", ".join("%s %d (%s)" % (p, n, t) for p, _, n, t in report))
 
 
-@pytest.mark.skipif(not os.path.exists(TRIANGLE_GEOMETRY), reason="tests/golden/_bin/ref_triangle_geometry not built")
 def test_reference_triangle_geometry_tutorial_unmodified(api, dev, tmp_path):
     """configs[0] of BASELINE.json: the reference's tutorials/triangle_geometry (cube + ground plane, one primary ray and one shadow ray per pixel through rtcIntersect1 /
     rtcOccluded1), compiled unmodified against the library, rendered on the GPU and compared with the reference's own image by the tutorial's own --compare
     (tutorial.cpp:646-660: fails above 35 wrong pixels) -- what the reference's CTest does with it."""
+    _must_exist(TRIANGLE_GEOMETRY, "make -f tests/golden/ref_tests.mk (__graft_entry__.build())")
     ref_img = os.path.join(ROOT, "tests", "golden", "models", "triangle_geometry.exr")
     r = subprocess.run([TRIANGLE_GEOMETRY, "--compare", ref_img, "-o", str(tmp_path / "tg.ppm")], capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
     assert r.returncode == 0, "triangle_geometry tutorial failed: rc %d\n%s" % (r.returncode, (r.stdout + r.stderr)[-2000:])
@@ -164,7 +180,6 @@ def test_reference_triangle_geometry_tutorial_unmodified(api, dev, tmp_path):
 DEVFILTER = os.path.join(ROOT, "tests", "golden", "_bin", "libdevfilter.so")
 
 
-@pytest.mark.skipif(not os.path.exists(DEVFILTER), reason="tests/golden/_bin/libdevfilter.so not built (__graft_entry__.build())")
 @pytest.mark.parametrize("flags", [0, 4])                       # fast, RTC_SCENE_FLAG_ROBUST
 def test_device_filter_function_vs_reference_callback(api, ref, flags):
     """A caller-compiled __device__ function (tests/dev_filter.hip: the ARGUMENT rule of oracle/ref_driver.cpp, built into its own shared library) passed by ADDRESS in
@@ -173,6 +188,7 @@ def test_device_filter_function_vs_reference_callback(api, ref, flags):
     of all of them, like the reference's GPU path calls its pointer (kernels/geometry/filter_sycl.h:31-43).  Checker: the REAL reference running the same rule as a host
     callback inside its traversal.  Also: together with a geometry RULE; the user pointer and the context arrive; without the config key the call is refused."""
     from tests.test_gpu_round3 import _rule_scene_meshes, _rule_rays, _tri_t64
+    _must_exist(DEVFILTER, "__graft_entry__.build() step 6")
     L = api.load()
     lib = C.CDLL(DEVFILTER)
     lib.devfilter_address.restype = C.c_uint64
