@@ -290,6 +290,8 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
   HIP_TRY(plans.alloc(maxLevelItems)); HIP_TRY(itemCnt.alloc(maxLevelItems)); HIP_TRY(groupSum.alloc(maxLevelItems / 8u + 16u));
   const uint32_t tiles = (N + 255u) / 256u;
   HIP_TRY(tileCount.alloc((NC + 255u) / 256u));
+  const uint32_t genBlocks = (N + 1023u) / 1024u < 4096u ? (N + 1023u) / 1024u : 4096u;   // primref_gen: 1024 triangles per workgroup and step
+  DevBuf<AreaPart> areaPart; HIP_TRY(areaPart.alloc(genBlocks));                             // ... and what every workgroup leaves for outlier_stats
   DevBuf<uint32_t> outlierCnt, outlierTile, outlierTotal;      // MEDIUM: grid cells every reference asks for (0 unless it is an outlier), their tile sums / offsets, the total
   DevBuf<OutlierWork> outlierWork;                            // ... the outliers themselves (every one asks for >= 2 cells: at most half the reserve)
   if (topSplits) { HIP_TRY(outlierCnt.alloc(N)); HIP_TRY(outlierTile.alloc(tiles)); HIP_TRY(outlierTotal.alloc(1)); HIP_TRY(outlierWork.alloc((NC - N) / 2u + 16u)); }
@@ -303,7 +305,7 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
   struct EvGuard { hipEvent_t a, b; ~EvGuard() { hipEventDestroy(a); hipEventDestroy(b); } } evg{ev0, ev1};
   if (useGraph) {
     HIP_TRY(hipStreamSynchronize(st));                         // (the geometry table above is in place before anything is captured)
-    const void* ptrs[] = {dGeoms.p, bufA.p, bufB.p, finalIds.p, bnodes.p, segs0.p, segs1.p, bins.p, chunks.p, small.p, ctr.p, w0.p, w1.p, wnodes.p, outIds.p, plans.p, itemCnt.p, groupSum.p, tileCount.p, chunkCnt.p, chunkBase.p, segx0.p, segx1.p, sbins.p, outlierCnt.p, outlierTile.p, outlierTotal.p, outlierWork.p, (const void*)st};
+    const void* ptrs[] = {dGeoms.p, bufA.p, bufB.p, finalIds.p, bnodes.p, segs0.p, segs1.p, bins.p, chunks.p, small.p, ctr.p, w0.p, w1.p, wnodes.p, outIds.p, plans.p, itemCnt.p, groupSum.p, tileCount.p, chunkCnt.p, chunkBase.p, segx0.p, segx1.p, sbins.p, outlierCnt.p, outlierTile.p, outlierTotal.p, outlierWork.p, areaPart.p, (const void*)st};
     std::vector<uint64_t> key; for (const void* q : ptrs) key.push_back((uint64_t)(uintptr_t)q);
     uint32_t pw[sizeof(Params) / 4]; memcpy(pw, &prm, sizeof(prm)); for (uint32_t w : pw) key.push_back(w);
     key.push_back(N); key.push_back(gd.size()); key.push_back(bp->robust); key.push_back(spatialMin); key.push_back(NC); { uint32_t w; memcpy(&w, &topSplitRel, 4); key.push_back(w); memcpy(&w, &topSplitCell, 4); key.push_back(w); } key.push_back(topSplits ? 1u : 0u); key.push_back(learned ? (learnedTop << 8) | learnedWide : 0u); key.push_back(learned ? (learnedChunked << 8) | (learnedLocalFirst & 0xFFu) : 0u);
@@ -318,8 +320,7 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
 
   Counters h{};
   LAUNCH(build_begin, dim3(1), dim3(256), 0, st, ctr.p);
-  const uint32_t genBlocks = (N + 255u) / 256u < 4096u ? (N + 255u) / 256u : 4096u;
-  LAUNCH(primref_gen, dim3(genBlocks), dim3(256), 0, st, dGeoms.p, (uint32_t)gd.size(), N, bufA.p, ctr.p);
+  LAUNCH(primref_gen, dim3(genBlocks), dim3(256), 0, st, dGeoms.p, (uint32_t)gd.size(), N, bufA.p, ctr.p, areaPart.p);
   uint32_t n = N;                                              // fast path: an upper bound of the valid triangles (the device knows the number)
   auto decf = [](uint32_t u) { uint32_t v = u ^ ((u >> 31) ? 0x80000000u : 0xFFFFFFFFu); float f; memcpy(&f, &v, 4); return f; };
   float glo[3], ghi[3], clo[3], chi[3];
@@ -327,8 +328,7 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
   if (fast) {
     const uint32_t ctiles = (NC + 255u) / 256u;                  // tiles of the compaction: the references and, behind them, the reserve for outlier pieces
     if (topSplits) {                                             // references that dwarf all others are cut into grid pieces (build_presplit.inl): holes and originals become "invalid"
-      const uint32_t ab = tiles < 2048u ? tiles : 2048u;
-      LAUNCH(outlier_area, dim3(ab), dim3(256), 0, st, bufA.p, N, ctr.p);
+      LAUNCH(outlier_stats, dim3(1), dim3(1024), 0, st, (const AreaPart*)areaPart.p, genBlocks, ctr.p);
       LAUNCH(outlier_mark, dim3(tiles), dim3(256), 0, st, bufA.p, N, ctr.p, topSplitRel, topSplitCell, outlierCnt.p, outlierTile.p);
       LAUNCH(presplit_scan, dim3(1), dim3(1024), 0, st, outlierTile.p, tiles, outlierTotal.p);
       LAUNCH(outlier_emit, dim3(tiles), dim3(256), 0, st, bufA.p, N, NC - N, outlierCnt.p, outlierTile.p, outlierTotal.p, ctr.p, outlierWork.p);
@@ -540,7 +540,7 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
     // the leaf records can be written as soon as the leaf order is known; their array is sized by the upper bound N
     bvh->d_tris = output_alloc(device, (size_t)NC * sizeof(TriRec) + 128, &bvh->trisCap);
     if (!bvh->d_tris) return set_error(hipErrorOutOfMemory, "leaf record array");
-    LAUNCH(tri_records, dim3((NC + 255u) / 256u), dim3(256), 0, st, outIds.p, NC, dGeoms.p, (TriRec*)bvh->d_tris, bp->robust ? 1u : 0u, (const Counters*)ctr.p);
+    LAUNCH(tri_records, dim3((NC + 1023u) / 1024u), dim3(256), 0, st, outIds.p, NC, dGeoms.p, (TriRec*)bvh->d_tris, bp->robust ? 1u : 0u, (const Counters*)ctr.p);
     SYNC_READ(h);                                                // the ONE round trip of the commit
     if (h.overflow == 4u && spatial) return set_error(hipErrorLaunchFailure, "spatial_partition gave up waiting for a predecessor chunk (workgroups not started in index order?)");
     if (h.overflow == 2u && spatial) return set_error(hipErrorOutOfMemory, "spatial split ran out of its extended range");
@@ -568,7 +568,7 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
     }
     if (spatial) { info.num_presplit = h.numTrisOut > n ? h.numTrisOut - n : 0u; n = h.numTrisOut; }   // the references the spatial splits created are leaf entries like any other
     arena->learn(kind, h.topLevels, h.wideDepth, h.chunkedLevels, h.localFirst < 255u ? h.localFirst : 255u);   // (a tree deeper than the wide levels enqueued is finished below either way)
-    if (redoLeaves) LAUNCH(tri_records, dim3((NC + 255u) / 256u), dim3(256), 0, st, outIds.p, NC, dGeoms.p, (TriRec*)bvh->d_tris, bp->robust ? 1u : 0u, (const Counters*)ctr.p);
+    if (redoLeaves) LAUNCH(tri_records, dim3((NC + 1023u) / 1024u), dim3(256), 0, st, outIds.p, NC, dGeoms.p, (TriRec*)bvh->d_tris, bp->robust ? 1u : 0u, (const Counters*)ctr.p);
   } else {
     for (uint32_t i = 0; i < 8u; i++) enqueue_wide_level();
     for (;;) {
@@ -580,7 +580,7 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
     if (spatial) { info.num_presplit = h.numTrisOut > n ? h.numTrisOut - n : 0u; n = h.numTrisOut; }   // the references the splits created are leaf entries like any other
     bvh->d_tris = output_alloc(device, (size_t)n * sizeof(TriRec) + 128, &bvh->trisCap);
     if (!bvh->d_tris) return set_error(hipErrorOutOfMemory, "leaf record array");
-    LAUNCH(tri_records, dim3((n + 255u) / 256u), dim3(256), 0, st, outIds.p, n, dGeoms.p, (TriRec*)bvh->d_tris, bp->robust ? 1u : 0u, (const Counters*)nullptr);
+    LAUNCH(tri_records, dim3((n + 1023u) / 1024u), dim3(256), 0, st, outIds.p, n, dGeoms.p, (TriRec*)bvh->d_tris, bp->robust ? 1u : 0u, (const Counters*)nullptr);
   }
   info.num_triangles = n;
 #ifdef SM_TIME
@@ -658,7 +658,7 @@ static int refit_impl(Bvh* bvh, const mi355_mesh* meshes, uint32_t numMeshes, hi
   HIP_TRY(hipEventRecord(ev0, st));
   HIP_TRY(hipMemcpyAsync(dGeoms.p, gd.data(), gd.size() * sizeof(GeomDesc), hipMemcpyHostToDevice, st));
   HIP_TRY(hipMemsetAsync(flag.p, 0, 4, st));
-  hipLaunchKernelGGL(tri_records, dim3((n + 255u) / 256u), dim3(256), 0, st, (const uint2*)bvh->d_ids, n, dGeoms.p, (TriRec*)bvh->d_tris, bvh->robust ? 1u : 0u, (const Counters*)nullptr);
+  hipLaunchKernelGGL(tri_records, dim3((n + 1023u) / 1024u), dim3(256), 0, st, (const uint2*)bvh->d_ids, n, dGeoms.p, (TriRec*)bvh->d_tris, bvh->robust ? 1u : 0u, (const Counters*)nullptr);
   for (size_t l = bvh->lvlStart.size() - 1; l-- > 0;) {        // deepest level first
     const uint32_t first = bvh->lvlStart[l], count = bvh->lvlStart[l + 1] - first;
     if (!count) continue;

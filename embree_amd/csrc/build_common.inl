@@ -50,6 +50,7 @@ struct Counters {
   float rootArea;                                 // half area of the scene bounds (SAH statistics are relative to it); written by root_setup
   uint32_t numOutliers;                           // MEDIUM builds: references cut up front because their box dwarfs the average one (build_presplit.inl, outlier_*)
   unsigned long long areaFixed;                   // spatial-split builds: sum of the references' box areas / scene area, 2^-32 fixed point (build_spatial.inl)
+  double areaSum;                                 // MEDIUM builds: sum of the valid references' box areas (primref_gen's per-workgroup parts added in index order by outlier_stats)
   uint32_t compactFrom;                           // stable compaction: first position that moves (everything before the first hole stays where it is)
   uint32_t outlierCells, outlierPieces, outlierValid, outlierSkip;   // ... the places reserved for their pieces behind the references, the pieces that exist, the valid references counted, 1 = too many
   uint32_t emitBlocks;                            // top_emit: workgroups that are done with the level (the last one moves the work lists on)

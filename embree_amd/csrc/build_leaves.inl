@@ -1,31 +1,50 @@
 // build_leaves.inl -- K5: leaf records; refit; node rebasing for instanced scenes.
 // Part of build.hip (included inside its anonymous namespace); see the header of build.hip for the pipeline.
 // --------------------------------------------------------------------------------- K5 tri_records
+// (round 6) Four records per thread -- record k * 256 + i of a tile of 1024 is thread i's -- with the ids, then the geometry entries and indices, then the vertices of all
+// four in flight together: one record per thread was a chain of four dependent round trips (id, geometry table, indices, vertices), 130 us for 228 MB written.
 __global__ __launch_bounds__(256) void tri_records(const uint2* finalIds, uint32_t n, const GeomDesc* geoms, TriRec* out, uint32_t robust, const Counters* ctr) {
-  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   // ctr: the grid is an upper bound, the number of leaf records is on the device: what the wide collapse has numbered so far.  Of a tree deeper than the levels
   // enqueued with this launch that is a part only -- the ids behind it are whatever the arena held (a device fault, found when tree buffers began to be
   // recycled); the host runs the remaining levels and launches this kernel again
-  if (i >= (ctr ? ctr->numTrisOut : n)) return;
-  uint2 id = finalIds[i];
-  const GeomDesc g = geoms[id.x];
-  uint32_t i0, i1, i2, pid;
-  prim_indices(g, id.y, i0, i1, i2, pid);
-  id.y = pid;                                                   // quads: quad index, bit 31 = second half (cleared again when a hit is written)
-  const float* a = (const float*)(g.verts + (size_t)i0 * g.vstride);
-  const float* b = (const float*)(g.verts + (size_t)i1 * g.vstride);
-  const float* c = (const float*)(g.verts + (size_t)i2 * g.vstride);
-  float4* o = (float4*)(out + i);
-  if (robust) {   // TriangleMv: the three vertices (kernels/geometry/trianglev.h), same 48-byte record
-    o[0] = make_float4(a[0], a[1], a[2], b[0]);
-    o[1] = make_float4(b[1], b[2], c[0], c[1]);
-    o[2] = make_float4(c[2], __uint_as_float(id.y), __uint_as_float(g.geomID), __uint_as_float(g.mask));
-    return;
+  const uint32_t count = ctr ? ctr->numTrisOut : n;
+  const uint32_t base = blockIdx.x * 1024u + threadIdx.x;
+  if (blockIdx.x * 1024u >= count) return;
+  uint2 id[4]; bool on[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) { const uint32_t i = base + (uint32_t)k * 256u; on[k] = i < count; id[k] = make_uint2(0u, 0u); if (on[k]) id[k] = finalIds[i]; }
+  uint32_t i0[4], i1[4], i2[4], pid[4], vs[4], gid[4], msk[4]; const char* vb[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    i0[k] = i1[k] = i2[k] = 0u; pid[k] = 0u; vs[k] = 0u; gid[k] = 0u; msk[k] = 0u; vb[k] = nullptr;
+    if (on[k]) { const GeomDesc g = geoms[id[k].x]; prim_indices(g, id[k].y, i0[k], i1[k], i2[k], pid[k]); vs[k] = g.vstride; vb[k] = g.verts; gid[k] = g.geomID; msk[k] = g.mask; }
   }
-  // TriangleM ctor: e1 = v0 - v1, e2 = v2 - v0 (kernels/geometry/triangle.h:40-41)
-  o[0] = make_float4(a[0], a[1], a[2], a[0] - b[0]);
-  o[1] = make_float4(a[1] - b[1], a[2] - b[2], c[0] - a[0], c[1] - a[1]);
-  o[2] = make_float4(c[2] - a[2], __uint_as_float(id.y), __uint_as_float(g.geomID), __uint_as_float(g.mask));
+  float a[4][3], b[4][3], c[4][3];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    for (int d = 0; d < 3; d++) a[k][d] = b[k][d] = c[k][d] = 0.0f;
+    if (on[k]) {
+      const float* pa = (const float*)(vb[k] + (size_t)i0[k] * vs[k]);
+      const float* pb = (const float*)(vb[k] + (size_t)i1[k] * vs[k]);
+      const float* pc = (const float*)(vb[k] + (size_t)i2[k] * vs[k]);
+      for (int d = 0; d < 3; d++) { a[k][d] = pa[d]; b[k][d] = pb[d]; c[k][d] = pc[d]; }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    if (!on[k]) continue;
+    float4* o = (float4*)(out + base + (uint32_t)k * 256u);
+    // pid: quads: quad index, bit 31 = second half (cleared again when a hit is written)
+    if (robust) {   // TriangleMv: the three vertices (kernels/geometry/trianglev.h), same 48-byte record
+      o[0] = make_float4(a[k][0], a[k][1], a[k][2], b[k][0]);
+      o[1] = make_float4(b[k][1], b[k][2], c[k][0], c[k][1]);
+      o[2] = make_float4(c[k][2], __uint_as_float(pid[k]), __uint_as_float(gid[k]), __uint_as_float(msk[k]));
+    } else {        // TriangleM ctor: e1 = v0 - v1, e2 = v2 - v0 (kernels/geometry/triangle.h:40-41)
+      o[0] = make_float4(a[k][0], a[k][1], a[k][2], a[k][0] - b[k][0]);
+      o[1] = make_float4(a[k][1] - b[k][1], a[k][2] - b[k][2], c[k][0] - a[k][0], c[k][1] - a[k][1]);
+      o[2] = make_float4(c[k][2] - a[k][2], __uint_as_float(pid[k]), __uint_as_float(gid[k]), __uint_as_float(msk[k]));
+    }
+  }
 }
 
 // --------------------------------------------------------------------------------- refit (RTC_BUILD_QUALITY_REFIT, kernels/bvh/bvh_refit.cpp)

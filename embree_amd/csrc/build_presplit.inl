@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void centroid_bounds(const PrimRef* prims, uin
 // ray, +11 % rays per second) comes from the twelve room-sized triangles -- and a tree built by object splits alone over the same room cut into a grid of
 // pieces gains the same (tests/gpu_perf.py --tess-room: 32.5 / 47.2 with 16 pieces per wall triangle, 32.0 / 44.9 with 1024).  So a MEDIUM commit cuts such
 // references before the build, on the device, inside the one-round-trip commit:
-//   outlier_area   sum of the valid references' box areas (fixed point, order independent) and their number
+//   outlier_stats  sum of the valid references' box areas and their number (the per-workgroup parts primref_gen left, added in index order: order independent)
 //   outlier_mark   a reference is an OUTLIER if its box area is >= top_split_rel (32) x the mean box area and longer than one cell of a uniform grid of
 //                  top_split_cell (1/8) of the scene's largest extent; it asks for one place per grid cell its box covers (<= 32 cells per axis)
 //   presplit_scan  places behind the references, in reference order (no atomic decides an index: rebuilds are bit-identical)
@@ -218,38 +218,26 @@ __device__ __forceinline__ float ctr_root_area2(const Counters* ctr, float (&ext
   for (int d = 0; d < 3; d++) ext[d] = dec(ctr->bounds[3 + d]) - dec(ctr->bounds[d]);
   return 2.0f * half_area3(ext[0], ext[1], ext[2]);
 }
-__global__ __launch_bounds__(256) void outlier_area(const PrimRef* prims, uint32_t n, Counters* ctr) {
-  __shared__ unsigned long long s_w[4]; __shared__ uint32_t s_c[4];
-  float ext[3]; const float rootArea2 = ctr_root_area2(ctr, ext);
-  unsigned long long acc = 0ull; uint32_t cnt = 0u;
-  const uint32_t stride = gridDim.x * 256u;
-  for (uint32_t i0 = blockIdx.x * 256u + threadIdx.x; i0 < n; i0 += 4u * stride) {   // four references per thread and step: their loads are in flight together (one was 69 us for 152 MB)
-    PrimRef r[4];
-#pragma unroll
-    for (uint32_t k = 0; k < 4u; k++) { r[k].geom = NIL; if (i0 + k * stride < n) r[k] = load_prim(prims + i0 + k * stride); }
-#pragma unroll
-    for (uint32_t k = 0; k < 4u; k++) {
-      if (r[k].geom == NIL) continue;
-      const float a = 2.0f * half_area3(r[k].hi[0] - r[k].lo[0], r[k].hi[1] - r[k].lo[1], r[k].hi[2] - r[k].lo[2]);
-      if (rootArea2 > 0.0f) acc += (unsigned long long)((double)(a / rootArea2) * 4294967296.0);
-      cnt++;
-    }
-  }
-  for (int o = 32; o > 0; o >>= 1) { acc += __shfl_down(acc, o, 64); cnt += (uint32_t)__shfl_down((int)cnt, o, 64); }
-  if ((threadIdx.x & 63u) == 0u) { s_w[threadIdx.x >> 6] = acc; s_c[threadIdx.x >> 6] = cnt; }
-  __syncthreads();
-  if (threadIdx.x == 0u) { atomicAdd(&ctr->areaFixed, s_w[0] + s_w[1] + s_w[2] + s_w[3]); atomicAdd(&ctr->outlierValid, s_c[0] + s_c[1] + s_c[2] + s_c[3]); }
+// the workgroups' parts of primref_gen (build_primref.inl) in index order: every thread its run, then a fixed tree -- the sum does not depend on timing
+__global__ __launch_bounds__(1024) void outlier_stats(const AreaPart* part, uint32_t numParts, Counters* ctr) {
+  __shared__ double s_a[1024]; __shared__ unsigned long long s_c[1024];
+  const uint32_t tid = threadIdx.x, per = (numParts + 1023u) / 1024u, b = min(tid * per, numParts), e = min(b + per, numParts);
+  double a = 0.0; unsigned long long c = 0ull;
+  for (uint32_t i = b; i < e; i++) { a += part[i].area; c += part[i].count; }
+  s_a[tid] = a; s_c[tid] = c; __syncthreads();
+  for (uint32_t o = 512u; o > 0u; o >>= 1) { if (tid < o) { s_a[tid] += s_a[tid + o]; s_c[tid] += s_c[tid + o]; } __syncthreads(); }
+  if (tid == 0u) { ctr->areaSum = s_a[0]; ctr->outlierValid = (uint32_t)s_c[0]; }
 }
 // grid cells of one reference (1 = not an outlier)
 __device__ __forceinline__ uint32_t outlier_cells(const PrimRef& r, const Counters* ctr, float minRel, float cellFrac, uint32_t (&nc)[3], float (&cell)[3]) {
   nc[0] = nc[1] = nc[2] = 1u; cell[0] = cell[1] = cell[2] = 0.0f;
   if (r.geom == NIL) return 1u;
   float ext[3]; const float rootArea2 = ctr_root_area2(ctr, ext);
-  const double sumRel = (double)ctr->areaFixed / 4294967296.0;
+  const double sum = ctr->areaSum;
   const uint32_t valid = ctr->outlierValid;
-  if (!(rootArea2 > 0.0f) || !(sumRel > 0.0) || valid < 1024u) return 1u;           // (small scenes have no "average" worth the name)
+  if (!(rootArea2 > 0.0f) || !(sum > 0.0) || valid < 1024u) return 1u;              // (small scenes have no "average" worth the name)
   const float a = 2.0f * half_area3(r.hi[0] - r.lo[0], r.hi[1] - r.lo[1], r.hi[2] - r.lo[2]);
-  const float rel = (float)((double)valid * ((double)(a / rootArea2) / sumRel));     // this box's area / the mean box area
+  const float rel = (float)((double)valid * ((double)a / sum));                      // this box's area / the mean box area
   if (!(rel >= minRel)) return 1u;
   const float L = fmaxf(ext[0], fmaxf(ext[1], ext[2])) * cellFrac;
   if (!(L > 0.0f)) return 1u;

@@ -5,57 +5,92 @@
 // block costs ~11 ns each, 0.2 ms for a 4.8 M triangle scene, and makes the order depend on block timing).  Invalid
 // triangles (index out of range, non-finite or huge coordinate) are marked geom = NIL and counted; only if there are
 // any does primref_compact squeeze them out afterwards (stable, so the order is still the input order).
+// (round 6) Four triangles per thread and step -- tile t of 1024 consecutive triangles is one workgroup's, thread i takes t * 1024 + k * 256 + i, k = 0 .. 3 -- so that the
+// index loads of all four, then the vertex loads of all four are in flight together: one triangle per step was a chain of three dependent round trips (geometry table,
+// indices, vertices) with nothing behind it, 133 us for 4.76 M triangles where the bytes need 40.  And the statistics of the outlier cut (build_presplit.inl) are taken here,
+// where the boxes are in registers: every workgroup leaves the sum of its valid boxes' areas and their number in areaPart[blockIdx] -- a fixed assignment of triangles to
+// threads and a fixed reduction order, so the sums do not depend on timing -- and outlier_stats adds the workgroups' parts in index order (was: outlier_area, a pass of its
+// own over the 152 MB of references, 63 us).
+struct AreaPart { double area; unsigned long long count; };
 __global__ __launch_bounds__(256) void primref_gen(const GeomDesc* geoms, uint32_t numGeoms, uint32_t totalPrims,
-                                                   PrimRef* out, Counters* ctr) {
+                                                   PrimRef* out, Counters* ctr, AreaPart* areaPart) {
   __shared__ uint32_t s_acc[12];
+  __shared__ double s_area[4]; __shared__ uint32_t s_cnt[4];
   const uint32_t tid = threadIdx.x, lane = tid & 63u;
   if (tid < 12) s_acc[tid] = (tid % 6 < 3) ? ENC_POS_INF : ENC_NEG_INF;
   __syncthreads();
   uint32_t acc[12]; for (int k = 0; k < 12; k++) acc[k] = (k % 6 < 3) ? 0xFFFFFFFFu : 0u;
-  uint32_t gi = 0, nInvalid = 0; GeomDesc g = geoms[0];
-  for (uint32_t p = blockIdx.x * 256u + tid; p < totalPrims; p += gridDim.x * 256u) {
-    if (p - g.primOffset >= g.nt) {                             // not in the cached geometry: last geometry with primOffset <= p
-      uint32_t lo = 0, hi = numGeoms - 1;
-      while (lo < hi) { uint32_t mid = (lo + hi + 1) >> 1; if (geoms[mid].primOffset <= p) lo = mid; else hi = mid - 1; }
-      gi = lo; g = geoms[lo];
-    }
-    const uint32_t j = p - g.primOffset;
-    uint32_t i0, i1, i2, pid;
-    prim_indices(g, j, i0, i1, i2, pid);
-    bool ok = false; PrimRef r{};
-    if (i0 < g.nv && i1 < g.nv && i2 < g.nv) {
-      const float* a = (const float*)(g.verts + (size_t)i0 * g.vstride);
-      const float* b = (const float*)(g.verts + (size_t)i1 * g.vstride);
-      const float* c = (const float*)(g.verts + (size_t)i2 * g.vstride);
-      ok = true;
-      for (int d = 0; d < 3; d++) {
-        const float x = a[d], y = b[d], z = c[d];
-        ok = ok && valid_f(x) && valid_f(y) && valid_f(z);
-        r.lo[d] = fminf(fminf(x, y), z); r.hi[d] = fmaxf(fmaxf(x, y), z);
+  uint32_t gi = 0, nInvalid = 0, nValid = 0; GeomDesc g = geoms[0];
+  double areaSum = 0.0;
+  for (uint32_t t0 = blockIdx.x * 1024u; t0 < totalPrims; t0 += gridDim.x * 1024u) {
+    uint32_t gk[4], jk[4], i0[4], i1[4], i2[4], nv[4], vs[4], quad[4]; const char* vb[4]; const char* ib[4]; uint32_t is[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {                                 // geometry of every triangle, its three indices
+      const uint32_t p = t0 + (uint32_t)k * 256u + tid;
+      gk[k] = NIL; jk[k] = 0; i0[k] = i1[k] = i2[k] = 0xFFFFFFFFu; nv[k] = 0; vs[k] = 0; quad[k] = 0; vb[k] = nullptr; ib[k] = nullptr; is[k] = 0;
+      if (p < totalPrims) {
+        if (p - g.primOffset >= g.nt) {                           // not in the cached geometry: last geometry with primOffset <= p
+          uint32_t lo = 0, hi = numGeoms - 1;
+          while (lo < hi) { uint32_t mid = (lo + hi + 1) >> 1; if (geoms[mid].primOffset <= p) lo = mid; else hi = mid - 1; }
+          gi = lo; g = geoms[lo];
+        }
+        gk[k] = gi; jk[k] = p - g.primOffset; nv[k] = g.nv; vs[k] = g.vstride; quad[k] = g.quad; vb[k] = g.verts; ib[k] = g.idx; is[k] = g.istride;
+        uint32_t pid;
+        prim_indices(g, jk[k], i0[k], i1[k], i2[k], pid);
       }
     }
-    if (ok && g.quad) {                                       // non-finite fourth vertex: the reference drops the whole quad
-      const uint32_t* q = (const uint32_t*)(g.idx + (size_t)(j >> 1) * g.istride);
-      const float* o4 = (const float*)(g.verts + (size_t)((j & 1u) ? q[0] : q[2]) * g.vstride);
-      ok = valid_f(o4[0]) && valid_f(o4[1]) && valid_f(o4[2]);
-    }
-    r.geom = ok ? gi : NIL; r.prim = j;
-    store_prim(out + p, r);
-    if (ok) {
-      for (int d = 0; d < 3; d++) {
-        const uint32_t l = enc(r.lo[d]), h = enc(r.hi[d]), c2 = enc(r.lo[d] + r.hi[d]);   // centroid proxy = lower+upper, never halved (priminfo.h:46-52)
-        acc[d] = min(acc[d], l); acc[3 + d] = max(acc[3 + d], h); acc[6 + d] = min(acc[6 + d], c2); acc[9 + d] = max(acc[9 + d], c2);
+    float vx[4][9]; bool inr[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {                                 // the vertices
+      inr[k] = gk[k] != NIL && i0[k] < nv[k] && i1[k] < nv[k] && i2[k] < nv[k];
+      for (int q = 0; q < 9; q++) vx[k][q] = 0.0f;
+      if (inr[k]) {
+        const float* a = (const float*)(vb[k] + (size_t)i0[k] * vs[k]);
+        const float* b = (const float*)(vb[k] + (size_t)i1[k] * vs[k]);
+        const float* c = (const float*)(vb[k] + (size_t)i2[k] * vs[k]);
+        for (int d = 0; d < 3; d++) { vx[k][d] = a[d]; vx[k][3 + d] = b[d]; vx[k][6 + d] = c[d]; }
       }
-    } else nInvalid++;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      if (gk[k] == NIL) continue;                                 // (behind the last triangle)
+      const uint32_t p = t0 + (uint32_t)k * 256u + tid;
+      bool ok = inr[k]; PrimRef r{};
+      if (ok) {
+        for (int d = 0; d < 3; d++) {
+          const float x = vx[k][d], y = vx[k][3 + d], z = vx[k][6 + d];
+          ok = ok && valid_f(x) && valid_f(y) && valid_f(z);
+          r.lo[d] = fminf(fminf(x, y), z); r.hi[d] = fmaxf(fmaxf(x, y), z);
+        }
+      }
+      if (ok && quad[k]) {                                        // non-finite fourth vertex: the reference drops the whole quad
+        const uint32_t* q = (const uint32_t*)(ib[k] + (size_t)(jk[k] >> 1) * is[k]);
+        const float* o4 = (const float*)(vb[k] + (size_t)((jk[k] & 1u) ? q[0] : q[2]) * vs[k]);
+        ok = valid_f(o4[0]) && valid_f(o4[1]) && valid_f(o4[2]);
+      }
+      r.geom = ok ? gk[k] : NIL; r.prim = jk[k];
+      store_prim(out + p, r);
+      if (ok) {
+        for (int d = 0; d < 3; d++) {
+          const uint32_t l = enc(r.lo[d]), h = enc(r.hi[d]), c2 = enc(r.lo[d] + r.hi[d]);   // centroid proxy = lower+upper, never halved (priminfo.h:46-52)
+          acc[d] = min(acc[d], l); acc[3 + d] = max(acc[3 + d], h); acc[6 + d] = min(acc[6 + d], c2); acc[9 + d] = max(acc[9 + d], c2);
+        }
+        areaSum += (double)(2.0f * half_area3(r.hi[0] - r.lo[0], r.hi[1] - r.lo[1], r.hi[2] - r.lo[2]));
+        nValid++;
+      } else nInvalid++;
+    }
   }
   for (int k = 0; k < 12; k++) {
     const uint32_t x = (k % 6 < 3) ? wave_umin63(acc[k]) : wave_umax63(acc[k]);
     if (lane == 63u) { if (k % 6 < 3) atomicMin(&s_acc[k], x); else atomicMax(&s_acc[k], x); }
   }
+  for (int o = 32; o > 0; o >>= 1) { areaSum += __shfl_down(areaSum, o, 64); nValid += (uint32_t)__shfl_down((int)nValid, o, 64); }
+  if (lane == 0u) { s_area[tid >> 6] = areaSum; s_cnt[tid >> 6] = nValid; }
   const unsigned long long bad = __ballot(nInvalid != 0u);
   if (bad != 0ull && nInvalid) atomicAdd(&ctr->numInvalid, nInvalid);
   __syncthreads();
   if (tid < 12) { if (tid % 6 < 3) atomicMin(&ctr->bounds[tid], s_acc[tid]); else atomicMax(&ctr->bounds[tid], s_acc[tid]); }
+  if (tid == 0u && areaPart) { AreaPart ap; ap.area = ((s_area[0] + s_area[1]) + s_area[2]) + s_area[3]; ap.count = (unsigned long long)s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3]; areaPart[blockIdx.x] = ap; }
 }
 
 // first kernel of a commit: the counters' initial state (what the host used to upload)

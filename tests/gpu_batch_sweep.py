@@ -22,6 +22,7 @@ ap.add_argument("--reps", type=int, default=30)
 ap.add_argument("--phi", type=int, default=158)
 ap.add_argument("--tag", default=os.environ.get("MI355_STATIC_RAYS", "auto"))
 ap.add_argument("--md", action="store_true", help="print a markdown table row per size")
+ap.add_argument("--census", action="store_true", help="lane-iteration census of the counting kernel per size (cursor hand-out whatever the setting)")
 a = ap.parse_args()
 L = api.load()
 dev = api.Device("gpu=0")
@@ -74,6 +75,13 @@ for k in range(a.lo, a.hi + 1):
     ms, res = run(n, a.reps if k <= 20 else max(5, a.reps // 3))
     same = res.tobytes() == full[:n].tobytes()
     us_min, us_med = 1e3 * ms.min(), 1e3 * float(np.median(ms))
+    if a.census:
+        L.mi355_memcpy_d2d_async(work.ptr, pristine.ptr, n * rec, None)
+        st = s.trace_stats(work.ptr, n, rec, False)
+        li = 64.0 * max(1, st["wave_iters"])
+        print("CENSUS rays=2^%-2d wave_iters %d (%.1f per 64 rays) lanes: node %.3f idle %.3f wait_batch %.3f wait_drain %.3f blocked %.3f | per ray nodes %.2f tris %.2f | tri batches filled %.2f"
+              % (k, st["wave_iters"], st["wave_iters"] * 64.0 / n, st["nodes"] / li, st["lanes_idle"] / li, st["lanes_wait_batch"] / li, st["lanes_wait_drain"] / li,
+                 st["lanes_blocked"] / li, st["nodes"] / n, st["tris"] / n, st["tris"] / max(1, 64 * st["tri_blocks"])), flush=True)
     if a.md:
         print("| %s | 2^%d | %.1f | %.1f | %.0f | %s |" % (a.tag, k, us_min, us_med, n / us_med, "yes" if same else "NO"), flush=True)
     else:
