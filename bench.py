@@ -323,8 +323,12 @@ def main():
     ap.add_argument("--dump-rays", type=int, default=1 << 22)
     ap.add_argument("--inprocess-gpus", type=int, default=0, help="extra leg at N = 1: rtcIntersect1M through ONE RTCDevice over this many GPUs (0 = all GPUs of the node, 1 = skip; "
                                                                     "more than the node has = replicas share GPUs)")
-    ap.add_argument("--scaling", default="both", choices=["weak", "both"], help="crown at N > 1: `value` is always the WEAK-scaling figure (2^20 rays per GPU and step); `both` adds the strong-scaling "
-                                                                               "leg (ONE 2^20-ray batch sharded over the N GPUs, gathered to rank 0) as `strong`")
+    ap.add_argument("--scaling", default="both", choices=["weak", "both"], help="crown at N > 1: `both` (default) measures the strong-scaling leg (ONE 2^20-ray batch sharded over the N GPUs, gathered to "
+                                                                               "rank 0: the literal metric) and makes it `value`, the weak figure (2^20 rays per GPU and step) stands beside it as `weak`; "
+                                                                               "`weak` measures the weak leg only")
+    ap.add_argument("--spin-up", type=float, default=0.5, help="seconds of the same launches between the warm-up steps and the timed region: the timed region of 20 steps is 13 ms, inside the "
+                                                             "ramp of the GPU's clocks (round 5: the first four kernels 0.71 .. 0.67 ms, the last four 0.65 .. 0.63); the reference's own benchmark protocol "
+                                                             "skips its start-up frames too (scripts/run-benchmark.sh:16-18).  0 = off")
     ap.add_argument("--sustain", type=float, default=6.0, help="seconds of back-to-back batches after the timed region (rank 0, N = 1): long enough for a 5-second utilisation sampler to see the GPU busy; 0 = skip")
     ap.add_argument("--scene", default="", help=".ecs / .xml / .obj scene file; default: $EMBREE_MODEL_DIR/crown/crown.ecs if it exists, "
                                                  "else the synthetic crown stand-in")
@@ -591,6 +595,19 @@ def main():
     for i in range(args.warmup):
         step(bufs[i], tstreams[i % len(tstreams)])
     L.mi355_device_synchronize(gpu)
+    # the clocks: the same launches (restore + trace of a batch of their own) for --spin-up seconds, so that the K timed steps run at the clock the GPU sustains
+    spin_launches = 0
+    if args.spin_up > 0:
+        spin_buf = api.DeviceArray(rays.nbytes, gpu)
+        t_sp = time.perf_counter()
+        while time.perf_counter() - t_sp < args.spin_up:
+            for _ in range(8):
+                L.mi355_memcpy_d2d_async(spin_buf.ptr, pristine.ptr, rays.nbytes, tstreams[0])
+                rc_ = L.mi355_trace_timed(bvh, spin_buf.ptr, M, rec, any_hit, tstreams[0], None, None)
+                assert rc_ == 0, L.mi355_last_error()
+            L.mi355_synchronize(tstreams[0])
+            spin_launches += 8
+        spin_buf.free()
 
     # ================================================================================================ the timed region
     ev = Events(L, args.steps)
@@ -709,6 +726,23 @@ def main():
                          what="the timed batches again, back to back on one stream for %.0f s, each behind a device-to-device copy that restores its rays (the copies are inside this figure): "
                               "not the metric -- a leg long enough for a utilisation sampler to see the GPU at work" % args.sustain)
 
+    # ---- small batches (one 2^20-ray batch over 8 GPUs is 2^17 rays per launch): lone launches over the first 2^17 / 2^15 rays of the batch
+    small_batch = None
+    if not shadow and rank == 0 and world == 1 and M >= (1 << 17):
+        small_batch = []
+        for nsm in (1 << 17, 1 << 15):
+            evs = Events(L, 24)
+            sb_ = api.DeviceArray(nsm * rec, gpu)
+            for k in range(24 + 4):
+                L.mi355_memcpy_d2d_async(sb_.ptr, pristine.ptr, nsm * rec, tstreams[0])
+                e0_, e1_ = (evs.ev[2 * (k - 4)], evs.ev[2 * (k - 4) + 1]) if k >= 4 else (None, None)
+                assert L.mi355_trace_timed(bvh, sb_.ptr, nsm, rec, any_hit, tstreams[0], e0_, e1_) == 0, L.mi355_last_error()
+            L.mi355_synchronize(tstreams[0])
+            sms = np.array([evs.ms(k) for k in range(24)])
+            evs.free()
+            assert sb_.download(dtype, nsm).tobytes() == result[:nsm].tobytes(), "a small batch and the full batch disagree on the same rays"
+            sb_.free()
+            small_batch.append(dict(rays=nsm, us=round(1e3 * float(np.median(sms)), 1), us_min=round(1e3 * float(sms.min()), 1), mrays=round(nsm / float(np.median(sms)) / 1e3, 1)))
     # ---- extra legs, outside the timed region --------------------------------------------------------------------------------------
     pipelined = None
     if npipe >= 1 and npipe != len(tstreams) and not shadow:   # the other mode: several batches in flight as a wavefront renderer keeps them / one batch at a time
@@ -804,21 +838,31 @@ def main():
         bw = (C.c_double * 2)()
         bw_ok = L.mi355_measure_bandwidth(gpu, 2 << 30, 5, bw) == 0          # what a streaming copy / read kernel reaches on THIS box ("also measure")
         pmc, pmc_note = load_pmc() if not shadow else (None, "PMC passes are collected for the closest-hit kernel only")
-        roof = {"bound": "valu", "bound_is": "what the kernel follows is VALU issue (valu_from_profile; address_rate beside it), not bytes: achieved / peak / frac below are the "
-                                             "SURVEY 8(d) figures (algorithmic bytes against the HBM peak), hbm_counter_frac is what reaches the memory side",
-                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "frac_is": "algorithmic bytes x launches / elapsed / HBM peak: mostly CACHE-SERVED bytes (L1 / L2 / Infinity Cache), not HBM traffic",
+        hbm_alg = {"achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                   "is": "SURVEY 8(d)'s figure: algorithmic bytes x launches / elapsed against the HBM peak.  NOT a bound and not HBM traffic: it charges every re-visit of a node, and L1 / L2 / the "
+                         "Infinity Cache serve most of them (a value above 1 means exactly that)",
+                   "peak_measured": {"copy_GBs": round(bw[0], 1), "read_GBs": round(bw[1], 1), "frac_of_copy": round(achieved / bw[0], 4) if bw_ok and bw[0] > 0 else None,
+                                     "what": "mi355_measure_bandwidth on this GPU: device-to-device copy (bytes read + written) and read-only streaming kernels over 2 GiB, best of 5"} if bw_ok else None}
+        # the bytes a launch cannot avoid: every DISTINCT node and triangle record it fetches once (a bit per record, set by the counting kernel), its rays in, its hit records out
+        compulsory = int(st["unique_nodes"] * 80 + st["unique_tris"] * 48 + M * 48 + (M * 4 if shadow else nhit * 52)) if st.get("unique_nodes") else None
+        roof = {"bound": "valu", "bound_is": "VALU instruction issue binds this kernel, not bytes (VERDICT r05): frac = the share of the timed region in which the 1024 SIMDs' vector pipes issue",
+                "achieved": None, "peak": None, "unit": "G wave-instructions/s", "frac": None,
+                "frac_algorithmic_cache_served": hbm_alg["frac"], "hbm_algorithmic": hbm_alg,
                 "traffic": int(pmc["hbm_traffic_bytes_per_launch"]) if pmc and "hbm_traffic_bytes_per_launch" in pmc else None,
                 "traffic_source": "profiles/pmc_bench_latest.json (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE per lone launch of this kernel source)" if pmc else None,
                 "traffic_is": "an UPPER bound: FETCH_SIZE counts 64 bytes per memory-side request whatever its size -- x 2 is right for streaming reads (128-byte requests), x 1 for lone 16-byte loads, "
                               "x 1.33 for 80-byte records at random addresses (tools/fetch_calib.hip, profiles/r05_fetch_calibration.md); this kernel's node / triangle reads are of the last two kinds" if pmc else None,
-                "peak_measured": {"copy_GBs": round(bw[0], 1), "read_GBs": round(bw[1], 1), "frac_of_copy": round(achieved / bw[0], 4) if bw_ok and bw[0] > 0 else None,
-                                  "what": "mi355_measure_bandwidth on this GPU: device-to-device copy (bytes read + written) and read-only streaming kernels over 2 GiB, best of 5"} if bw_ok else None,
+                "compulsory_bytes": compulsory,
+                "compulsory_is": "distinct nodes fetched x 80 + distinct triangle records fetched x 48 (one bit per record, set by the counting kernel on the same rays) + rays x 48 read + hit records written: "
+                                 "what a perfect cache in front of the memory would still move once per launch",
+                "unique_nodes": int(st.get("unique_nodes", 0)), "unique_triangle_records": int(st.get("unique_tris", 0)),
+                "traffic_over_compulsory": round(pmc["hbm_traffic_bytes_per_launch"] / compulsory, 2) if (pmc and compulsory and "hbm_traffic_bytes_per_launch" in pmc) else None,
                 "kernel": "trace_kernel_q<%s>" % ("any" if shadow else "closest"),
                 "how": "algorithmic bytes per launch x launches timed / elapsed of the timed region / peak (launches overlap: %.2f in flight); lone launches: see `serial`" % conc,
                 "launches_timed": args.steps, "launches_in_flight": round(conc, 3),
+                "spin_up": {"seconds": args.spin_up, "launches": spin_launches, "what": "the same launches between the warm-up steps and the timed region (not timed): the GPU's clocks are up when the K steps start"},
                 "kernel_ms_avg_overlapping": round(avg_ms, 4), "kernel_ms_min": round(float(np.min(kernel_ms)), 4),
-                "kernel_ms_first4": [round(float(x), 4) for x in kernel_ms[:4]], "kernel_ms_last4": [round(float(x), 4) for x in kernel_ms[-4:]],   # (the device is still raising its clocks in the first steps of a short region)
+                "kernel_ms_first4": [round(float(x), 4) for x in kernel_ms[:4]], "kernel_ms_last4": [round(float(x), 4) for x in kernel_ms[-4:]],
                 "algorithmic_bytes_per_launch": int(alg_bytes),
                 "per_ray": {"nodes": round(st["nodes"] / M, 2), "node_step_simd_util": round(st["nodes"] / max(1, 64 * st["node_blocks"]), 3),
                             "tri_step_simd_util": round(st["tris"] / max(1, 64 * st["tri_blocks"]), 3),
@@ -829,8 +873,6 @@ def main():
                             "node_step_clock_share": round(st["node_step_clocks"] / max(1, st["loop_clocks"]), 4)},
                 "note": "algorithmic bytes (SURVEY 8d) = rays x (48 read + 52 written on a hit) + node visits x 80 + triangle records x 48, visit counts from the counting build of the same "
                         "kernel on the same rays. Most of these bytes are served by L1 / L2 / Infinity Cache: hbm_counter_from_profile is what reaches the memory side."}
-        if roof["frac"] > 1.0:
-            roof["note"] += " frac > 1 here: the kernel consumes its algorithmic bytes faster than HBM could deliver them, because node and triangle reads are mostly cache hits."
         # what binds (profiles/r02_trace_history.md): every lane that fetches a 16-byte piece of a node / triangle / ray costs the CU's address path one slot, whatever
         # the width and whatever the cache level that answers: 5 per node visit, 3 per triangle test, 3 per ray read + the hit record stores
         acc = 5 * st["nodes"] + 3 * st["tris"] + M * 3 + (nhit * 4 if not shadow else nhit)
@@ -853,12 +895,21 @@ def main():
                                                 "what": "rocprofv3 --pmc FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE per launch of this kernel source (profiles/pmc_bench_latest.json, hash %s) x launches timed / elapsed; includes Infinity-Cache hits" % pmc["source_hash"]}
             if "SQ_INSTS_VALU" in c:
                 valu_s = c["SQ_INSTS_VALU"] * 4.0 / (NUM_SIMDS * clock_hz)
+                roof["achieved"] = round(c["SQ_INSTS_VALU"] * args.steps / elapsed / 1e9, 2)
+                roof["peak"] = round(NUM_SIMDS * clock_hz / 4.0 / 1e9, 2)
+                roof["frac"] = round(valu_s * args.steps / elapsed, 4)
+                roof["frac_is"] = ("wave instructions on the vector pipes per second (SQ_INSTS_VALU per launch, profiles/pmc_bench_latest.json, x launches timed / elapsed) against 1024 SIMDs x clock / 4 cycles "
+                                   "per instruction: the BINDING resource of this kernel.  The SURVEY 8(d) bytes-over-HBM-peak figure is frac_algorithmic_cache_served")
                 roof["valu_from_profile"] = {"wave_instructions_per_launch": int(c["SQ_INSTS_VALU"]), "cycles_per_instruction": 4, "clock_ghz": round(clock_hz / 1e9, 3),
                                              "issue_ms": round(valu_s * 1e3, 4), "frac": round(valu_s * args.steps / elapsed, 4),
                                              "what": "SQ_INSTS_VALU (profiles/pmc_bench_latest.json) x 4 cycles / (1024 SIMDs x clock) per launch x launches timed / elapsed: the share of the timed region in which the VALU pipes issue "
                                                      "(~4 cycles per wave instruction: tools/valu_bench.hip; clock = kernel cycles of the PMC run / duration of a lone launch, capped at 2.4 GHz)"}
         else:
             roof["pmc_note"] = pmc_note
+        if roof["frac"] is None:                              # no counters for this build of the kernel: the only live figure is the algorithmic one -- say so instead of leaving the field empty
+            roof.update({"bound": "hbm", "achieved": hbm_alg["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_alg["frac"],
+                         "frac_is": "NO PMC profile for this kernel source (%s): this is SURVEY 8(d)'s algorithmic-bytes figure against the HBM peak -- cache-served bytes, not the binding resource "
+                                    "(VALU issue: ~0.76 of the region in round 5's profile)" % (pmc_note or "none")})
         # rtcCommitScene against ITS roofline: bytes the build algorithm has to move -- vertices + indices in and references out (primref_gen), every level of
         # the binary binned-SAH build reads the references once to bin them and once to partition them and writes them once (32 B each way), the wide nodes and the
         # leaf records are written once, the leaf records gather their vertices again -- over the GPU time of the commit.  Levels = log2(leaves): what a balanced tree needs.
@@ -870,15 +921,21 @@ def main():
                       "frac_of_copy": round(b_bytes / b_s / 1e9 / bw[0], 4) if bw_ok and bw[0] > 0 else None, "dominant_kernel": "small_build",
                       "how": "triangles x (48 read + 32 written) + log2(leaves) = %.1f levels x triangles x (32 binned + 32 read + 32 written) + nodes x 80 + triangles x (48 gathered + 48 written), "
                              "over the fastest of the timed commits; traffic of the commit as the counters see it: profiles/" % b_levels}
+        weak_value, weak_ms = value, 1e3 * elapsed / args.steps
+        strong_is_value = strong is not None                     # N > 1, crown: the LITERAL metric is one 2^20-ray batch over the N GPUs
         out = {
             "metric": ("Mrays/s (shadow rays, any-hit) on crown, 16 Mi rays sharded" if shadow else
                        "Mrays/s (incoherent diffuse, closest-hit) on crown" + (", %d batches of 2^20 rays in flight (one batch at a time: serial.value)" % len(tstreams) if len(tstreams) > 1 else "")
+                       + ((", ONE batch of 2^20 rays cut over the %d GPUs (strong scaling; every GPU its own 2^20 rays: `weak`)" % world) if strong_is_value else "")
                        + ((", hits packed and gathered to rank 0 over RCCL inside the step" if gather_in_step else ", NO gather (RCCL communicator unavailable)") if world > 1 else "")),
-            "value": round(value, 2), "unit": "Mrays/s",
-            "n_gpus": world, "ranks": world, "distinct_gpus": min(world, ngpu), "rccl_ranks": (world if comm is not None else 0), "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
-            "higher_is_better": True, "scaling": "strong" if shadow else "weak",
+            "value": strong["value"] if strong_is_value else round(value, 2), "unit": "Mrays/s",
+            "n_gpus": world, "ranks": world, "distinct_gpus": min(world, ngpu), "rccl_ranks": (world if comm is not None else 0), "steps": args.steps, "warmup": args.warmup, "ms_per_step": strong["ms_per_step"] if strong_is_value else round(1e3 * elapsed / args.steps, 4),
+            "higher_is_better": True, "scaling": "strong" if (shadow or strong_is_value) else "weak",
             "scaling_is": ("strong: the 16 Mi shadow rays of configs[3] are one job cut over the ranks" if shadow else
-                           "weak: every GPU traces its own 2^20-ray batch per step (value = all of them per second); the strong-scaling figure of ONE 2^20-ray batch cut N ways is `strong`" if world > 1 else
+                           "strong: BASELINE.json words the metric on 1M rays at 1/2/4/8 GPUs -- ONE 2^20-ray batch cut into N contiguous shards, gathered to rank 0 inside the step (K steps, barrier + "
+                           "synchronize on both sides, max over ranks).  `weak` is the other reading: every GPU its own 2^20-ray batch per step; the roofline block describes THAT launch (2^20 rays "
+                           "on one GPU)" if strong_is_value else
+                           "weak: every GPU traces its own 2^20-ray batch per step (value = all of them per second); --scaling both makes the strong figure the value" if world > 1 else
                            "N = 1 (both readings coincide)"), "vs_baseline": None, "dtype": "f32", "data": "synthetic" if not scene_path else "file",
             "config": {"workload": ("configs[3]: %s, %d triangles, %d shadow rays (16 per hit point) in total, %d per GPU, rtcOccluded1MDevice, rays + BVH resident in HBM, results %s"
                                     % (scene_name, ntri, total_rays, M, "packed and all-gathered over RCCL" if comm is not None else "left in the per-rank buffers")) if shadow else
@@ -906,6 +963,13 @@ def main():
             out["pipelined" if npipe > 1 else "serial"] = pipelined
         if strong:
             out["strong"] = strong
+            out["weak"] = dict(value=round(weak_value, 2), unit="Mrays/s", scaling="weak", rays_per_gpu=M, steps=args.steps, ms_per_step=round(weak_ms, 4),
+                               what="every GPU traces its own 2^20-ray batch per step, hits gathered to rank 0 inside the step; all GPUs' rays per second, max over ranks")
+        if small_batch:
+            out["small_batch"] = {"legs": small_batch, "rays": small_batch[0]["rays"], "us": small_batch[0]["us"], "mrays": small_batch[0]["mrays"],
+                                  "what": "lone launches over the first 2^17 (and 2^15) rays of the timed batch, HIP events around each, median of 24: what ONE GPU of eight is handed when a 2^20-ray batch is "
+                                          "cut eight ways.  <= 2^16 rays take the static launch shape (no cursor, helpers from the first iteration; profiles/r06_batch_sweep.md); hit records byte-identical to "
+                                          "the full batch's"}
         if sustained:
             out["sustained"] = sustained
         if gather_in_step and gather_ms:

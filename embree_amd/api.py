@@ -578,7 +578,8 @@ class Scene:
         return dict(nodes=out[0], tris=out[1], rays=out[2], spills=out[3], max_depth=out[4], wave_iters=out[5],
                     node_blocks=out[6], tri_blocks=out[7], lanes_idle=out[8], lanes_wait_batch=out[9],
                     lanes_wait_drain=out[10], lanes_blocked=out[11], empty_nodes=out[12], culled_groups=out[13],
-                    refill_clocks=out[14], refill_events=out[15], loop_clocks=out[16], node_step_clocks=out[17])
+                    refill_clocks=out[14], refill_events=out[15], loop_clocks=out[16], node_step_clocks=out[17],
+                    unique_nodes=out[18], unique_tris=out[19])
 
     def release(self):
         if self.h:

@@ -20,8 +20,11 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 # pays for it with v_mov (to bring operands into adjacent registers) and v_and (|x| has no packed form) -- on gfx950 a packed fp32 instruction issues in the time of two
 # scalar ones (profiles/r02_valu_issue_costs.txt), so the pairs buy nothing and the moves cost: +3.7 % rays per second without it (profiles/r05_trace.md).  The packed
 # FMAs of the slab test are written by hand (test4) and stay.  Same arithmetic either way (-ffp-contract=off): results are bit-identical.
-# trace_fptr.hip = trace.hip again, for the kernels that call a device filter function only, at -O1 (the reason is in trace.hip, MI355_FPTR_TU)
-EXTRA_FLAGS = {"trace.hip": ["-fno-slp-vectorize"], "trace_fptr.hip": ["-fno-slp-vectorize", "-O1"]}
+# trace_fptr.hip = trace.hip again, for the kernels that call a device filter function only.  Round 5 built them at -O1: above it the loop around the indirect call lost rays or
+# faulted with ANY callee.  Round 6 bisected that on the GPU (tools/r06_fptr_variants.sh, profiles/r06_device_filter.md): it is the record PREFETCH of step 0 -- triangle records
+# asked for at the top of an iteration and still in flight, together with the five node loads of step 3a, when step 4 calls through the pointer -- and none of the other
+# hand-written pieces (SGPR lane masks, the DPP scan, the "undefined register" asm): without the prefetch the calling kernels are correct at -O2 and -O3, bit for bit what -O1 gave.
+EXTRA_FLAGS = {"trace.hip": ["-fno-slp-vectorize"], "trace_fptr.hip": ["-fno-slp-vectorize", "-DMI355_TRI_PREFETCH=0"]}
 
 
 def _stale():

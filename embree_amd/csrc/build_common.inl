@@ -100,13 +100,38 @@ template <int CTRL, int ROWMASK> __device__ __forceinline__ uint32_t dpp_u(uint3
 __device__ __forceinline__ uint32_t wave_umin63(uint32_t v) { asm volatile(MI355_WAVE_REDUCE63("v_min_u32_dpp") : "+v"(v)); return v; }
 __device__ __forceinline__ uint32_t wave_umax63(uint32_t v) { asm volatile(MI355_WAVE_REDUCE63("v_max_u32_dpp") : "+v"(v)); return v; }
 
-// s[0..1024) becomes its exclusive scan, the total is returned to every thread (a serial loop of thread 0 over the 1024 partial sums took ~10 us)
+// inclusive prefix sum over the 64 lanes of a wave: four row_shr steps, row_bcast:15, row_bcast:31 (the DPP operand folded into the add; a lane without a source keeps its value)
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
+  asm volatile("s_nop 1\n v_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n s_nop 1\n v_add_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n"
+               "s_nop 1\n v_add_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n s_nop 1\n v_add_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n"
+               "s_nop 1\n v_add_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n s_nop 1\n v_add_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n s_nop 1\n" : "+v"(v));
+  return v;
+}
+// Exclusive prefix sums of one pair per thread over a workgroup of 1024 threads: every wave scans its 64 pairs with DPP, wave 0 scans the 16 wave totals, three barriers.
+// (round 6: was a Hillis-Steele scan through LDS, ten rounds of two barriers each = ~6 us of every single-block scan kernel -- compact_scan, presplit_scan and the 13
+// wide_scan launches of a commit.)  s_w: 17 pairs of LDS.  Returns the exclusive prefix of this thread; total = the sum over the workgroup.
+__device__ __forceinline__ uint2 block_exclusive_scan_1024_u2(uint2 v, uint2* s_w, uint32_t tid, uint2& total) {
+  const uint32_t lane = tid & 63u, wave = tid >> 6;
+  uint2 incl; incl.x = wave_incl_scan_u32(v.x); incl.y = wave_incl_scan_u32(v.y);
+  if (lane == 63u) s_w[wave] = incl;
+  __syncthreads();
+  if (tid < 64u) {
+    uint2 w = tid < 16u ? s_w[tid] : make_uint2(0u, 0u);
+    uint2 wi; wi.x = wave_incl_scan_u32(w.x); wi.y = wave_incl_scan_u32(w.y);
+    if (tid < 16u) s_w[tid] = make_uint2(wi.x - w.x, wi.y - w.y);
+    if (tid == 15u) s_w[16] = wi;
+  }
+  __syncthreads();
+  const uint2 base = s_w[wave]; total = s_w[16];
+  __syncthreads();                                               // (s_w may be used again at once)
+  return make_uint2(base.x + incl.x - v.x, base.y + incl.y - v.y);
+}
+// s[0..1024) becomes its exclusive scan, the total is returned to every thread
 __device__ __forceinline__ uint32_t block_exclusive_scan_1024(uint32_t* s, uint32_t tid) {
-  const uint32_t mine = s[tid];
-  for (uint32_t o = 1; o < 1024u; o <<= 1) { uint32_t x = 0; if (tid >= o) x = s[tid - o]; __syncthreads(); s[tid] += x; __syncthreads(); }
-  const uint32_t total = s[1023], excl = s[tid] - mine;
+  __shared__ uint2 s_w[17];
+  uint2 total;
+  const uint2 ex = block_exclusive_scan_1024_u2(make_uint2(s[tid], 0u), s_w, tid, total);
+  s[tid] = ex.x;
   __syncthreads();
-  s[tid] = excl;
-  __syncthreads();
-  return total;
+  return total.x;
 }

@@ -404,7 +404,7 @@ __global__ __launch_bounds__(256) void spatial_partition(Seg* segs, const SegX* 
       // (the wait is BOUNDED.  It relies on workgroups being started in index order -- a predecessor is then running or done -- which the hardware does and HIP
       // does not promise: should a predecessor ever be kept off the chip by its waiting successors, they give up after ~2^20 naps (a tenth of a second), the commit reports
       // overflow = 4 and the host returns an error instead of the GPU hanging for ever)
-      do { v = __hip_atomic_load(chunkFlag + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (!(v >> 31)) { __builtin_amdgcn_s_sleep(2); if (++spins > (1u << 20)) { ctr->overflow = 4u; v = 0x80000000u; } } } while (!(v >> 31));
+      do { v = __hip_atomic_load(chunkFlag + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (!(v >> 31)) { __builtin_amdgcn_s_sleep(2); if (++spins > (1u << 20)) { atomicMax(&ctr->overflow, 4u); v = 0x80000000u; } } } while (!(v >> 31));
       pl += (v >> 12) & 0xFFFu; pr += v & 0xFFFu;
     }
     for (int o = 32; o > 0; o >>= 1) { pl += (uint32_t)__shfl_down((int)pl, o, 64); pr += (uint32_t)__shfl_down((int)pr, o, 64); }
@@ -443,8 +443,8 @@ __global__ __launch_bounds__(256) void spatial_partition(Seg* segs, const SegX* 
     }
     // (the limits cannot be reached -- the counts of spatial_best are upper bounds -- but a store past a set's capacity would corrupt a sibling: guarded)
     const uint32_t oL = s_baseL + s_off[round][wave][0] + (uint32_t)__popcll(lm[round] & lt), oR = s_baseR + s_off[round][wave][1] + (uint32_t)__popcll(rm[round] & lt);
-    if (toL) { if (oL < limL) store_prim(dst + oL, L); else ctr->overflow = 2u; }
-    if (toR) { if (oR < limR) store_prim(dst + oR, R); else ctr->overflow = 2u; }
+    if (toL) { if (oL < limL) store_prim(dst + oL, L); else atomicMax(&ctr->overflow, 2u); }
+    if (toR) { if (oR < limR) store_prim(dst + oR, R); else atomicMax(&ctr->overflow, 2u); }
   }
   // fold the bounds: lanes of a wave (DPP), the four waves of the workgroup (LDS), then 24 atomics per chunk -- atomics of many chunks on the one cache line
   // of a big set's record are what this kernel waited for (one per wave: 0.95 of the 1.14 ms of the root's level)

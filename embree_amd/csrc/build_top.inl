@@ -204,7 +204,7 @@ __device__ __forceinline__ void top_level_end(Counters* ctr, uint32_t maxNext) {
     if (atomicAdd(&ctr->emitBlocks, 1u) == gridDim.x - 1u) {
       const uint32_t nextSegs = atomicAdd(&ctr->numSegsNext, 0u);
       if (ctr->numSegs) ctr->topLevels++;
-      if (nextSegs > maxNext) ctr->overflow = 1u;
+      if (nextSegs > maxNext) atomicMax(&ctr->overflow, 1u);
       ctr->numSegs = nextSegs < maxNext ? nextSegs : maxNext; ctr->numSegsNext = 0; ctr->numChunks = 0; ctr->emitBlocks = 0;
     }
   }
@@ -213,13 +213,13 @@ __device__ __forceinline__ void top_emit_child(uint32_t b, uint32_t e, uint32_t 
                                                const Params& prm, uint32_t dstBuf, uint32_t maxNext, uint32_t maxSmall, SegX* nx, uint32_t childExtEnd) {
   if (e - b <= prm.small) {
     const uint32_t k = atomicAdd(&ctr->numSmall, 1u);
-    if (k >= maxSmall) { ctr->overflow = 1u; return; }
+    if (k >= maxSmall) { atomicMax(&ctr->overflow, 1u); return; }
     SmallEntry se; se.begin = b; se.end = e; se.bnode = child; se.buf = dstBuf;
     for (int d = 0; d < 3; d++) { se.cmin[d] = cmin[d]; se.cmax[d] = cmax[d]; }
     small[k] = se;
   } else {
     const uint32_t k = atomicAdd(&ctr->numSegsNext, 1u);
-    if (k >= maxNext) { ctr->overflow = 1u; return; }
+    if (k >= maxNext) { atomicMax(&ctr->overflow, 1u); return; }
     Seg ns{}; ns.begin = b; ns.end = e; ns.bnode = child;
     for (int d = 0; d < 3; d++) { ns.cmin[d] = cmin[d]; ns.cmax[d] = cmax[d]; }
     next[k] = ns;
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(256) void top_local(const Seg* segs, const PrimRef*
       for (int d = 0; d < 3; d++) { cmin[d] = dec(s_acc[side][d]); cmax[d] = dec(s_acc[side][3 + d]); }
       top_emit_child(c.begin, c.end, child, cmin, cmax, next, small, ctr, prm, dstBuf, maxNext, maxSmall, nullptr, 0u);
     }
-  } else if (s < numSegs && lastOfLevel) { if (tid == 0u) ctr->overflow = 3u; }         // a set for the chunked path at a level that was enqueued without it: the commit is repeated
+  } else if (s < numSegs && lastOfLevel) { if (tid == 0u) atomicMax(&ctr->overflow, 3u); }         // a set for the chunked path at a level that was enqueued without it: the commit is repeated
 }
 
 __global__ void top_emit(const Seg* segs, BNode* bnodes, Seg* next, SmallEntry* small, Counters* ctr,

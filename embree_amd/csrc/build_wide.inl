@@ -160,7 +160,7 @@ __global__ __launch_bounds__(64) void wide_plan(const WideItem* items, const BNo
 
 // one block: exclusive scan of the per-wave totals in item order; publishes the level's bases and the next level's item count
 __global__ __launch_bounds__(1024) void wide_scan(uint2* groupSum, Counters* ctr, uint32_t parity, uint32_t maxNodes) {
-  __shared__ uint2 s_part[1024];
+  __shared__ uint2 s_part[17];
   const uint32_t numItems = ctr->wideCount[parity], numGroups = (numItems + 7u) / 8u;
   // every thread owns a run of `per` consecutive groups (a multiple of 8: four 16-byte loads in flight per step -- one load per step and thread made the
   // two passes of the widest level 37 dependent L2 round trips each, 91 us)
@@ -173,13 +173,8 @@ __global__ __launch_bounds__(1024) void wide_scan(uint2* groupSum, Counters* ctr
 #pragma unroll
     for (uint32_t k = 0; k < 4u; k++) { sum.x += x[k].x; sum.y += x[k].y; if (i + 2u * k + 1u < e) { sum.x += x[k].z; sum.y += x[k].w; } }
   }
-  s_part[tid] = sum; __syncthreads();
-  for (uint32_t o = 1; o < 1024u; o <<= 1) {                    // Hillis-Steele inclusive scan
-    uint2 x = make_uint2(0, 0); if (tid >= o) x = s_part[tid - o];
-    __syncthreads(); if (tid >= o) { s_part[tid].x += x.x; s_part[tid].y += x.y; } __syncthreads();
-  }
-  const uint2 total = s_part[1023];
-  uint2 run = tid ? s_part[tid - 1] : make_uint2(0, 0);
+  uint2 total;
+  uint2 run = block_exclusive_scan_1024_u2(sum, s_part, tid, total);   // (DPP wave scans + 16 wave totals: three barriers, build_common.inl)
   for (uint32_t i = b; i < e; i += 8u) {
     uint4 x[4];
 #pragma unroll
@@ -194,7 +189,7 @@ __global__ __launch_bounds__(1024) void wide_scan(uint2* groupSum, Counters* ctr
   if (tid == 0) {
     ctr->lvlNodeBase = ctr->numWide; ctr->lvlTriBase = ctr->numTrisOut;
     if (numItems) { ctr->wideDepth++; if (ctr->wideDepth < 64u) ctr->lvlStart[ctr->wideDepth] = ctr->numWide; }
-    if ((uint64_t)ctr->numWide + total.x > maxNodes) { ctr->overflow = 2u; ctr->wideCount[parity ^ 1u] = 0u; }
+    if ((uint64_t)ctr->numWide + total.x > maxNodes) { atomicMax(&ctr->overflow, 2u); ctr->wideCount[parity ^ 1u] = 0u; }
     else { ctr->numWide += total.x; ctr->numTrisOut += total.y; ctr->wideCount[parity ^ 1u] = total.x; }
   }
 }

@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
 #include <map>
 #include <mutex>
 #include <set>
@@ -60,6 +61,8 @@ struct Device : RefCounted {
   bool benchmark = false;
   unsigned instanceRefitMax = 32;                            // config key instance_refit_max=<n>: after n refits in a row of the top tree over moved instances, the next commit rebuilds it
   bool noInstanceRefit = false;                              // config key instance_refit=0: moved instances rebuild the top tree and concatenate the object trees again (A/B)
+  bool coherentMemory = true;                                // config key coherent_memory=0: RTC_RAY_QUERY_FLAG_COHERENT queries never skip their packet sample on the strength of earlier queries (MI355_QUERY_COHERENT_NO_MEMORY)
+  bool hostRegister = false;                                 // config key host_register=1: large host ray arrays are registered with the device for the duration of a query (zero-copy transfers; rounds 3 - 5) instead of staged
   bool hostInPlace = false;                                  // config key host_in_place=1: large host arrays are traced where they lie (registered + mapped), see replica_query
   bool deviceFilters = false;                                // config key device_filter_functions=1: RTCIntersectArguments::filter / RTCOccludedArguments::filter of the *Device entry points
                                                              // is the address of a __device__ function (include/embree4/rtcore.h, "device filter functions"); off: a non-NULL filter there is an error
@@ -121,6 +124,81 @@ void core_check(int rc, const char* what) {
   THROW(rc == (int)hipErrorOutOfMemory ? RTC_ERROR_OUT_OF_MEMORY : RTC_ERROR_UNKNOWN, m.c_str());
 }
 
+
+// ---- host memory never meets the GPU directly (round 6) --------------------------------------------------------------------------------------------------
+// Rounds 3 - 5 let the GPU work on the CALLER's host arrays: rtcIntersect1M / rtcOccluded1M registered the ray array with the device for the duration of the call
+// (hipHostRegister: zero-copy uploads and downloads), geometry buffers and small batches went through hipMemcpy on pageable memory (which the runtime pins chunk by
+// chunk above a size of its own).  Either way the GPU's view of those pages is a "userptr" mapping that the kernel driver has to keep in step with whatever the CPU side
+// does to the pages -- NUMA balancing, huge-page collapse, compaction, a neighbouring free() that trims the heap.  On the round's boxes that goes wrong about once in ten
+// runs of the GPU suite: "Memory access fault by GPU node-2 on address 0x5abc3ebda000. Reason: Unknown" -- a page-aligned address in the process's brk heap, inside or next
+// to a ray array, in the middle of a host-array query or a download; the process is aborted by the runtime.  Measured with round 5's library as well (1 of 12 suite runs;
+// this round's: 4 of 38; profiles/r06_host_memory_fault.md), so it is not new, it was luck.  The GPU now only ever touches memory this library allocated itself:
+// hipHostMalloc'ed staging buffers (really pinned, not userptr), filled and drained by the CPU -- several threads for large arrays (copy_pool below).  "host_register=1"
+// in the device config restores the registration of the caller's array (faster on a quiet box: the link instead of the CPU's memcpy is the limit).
+struct CopyPool {                                              // a few threads that do nothing but memcpy: one 96 MB array at ~10 GB/s per thread is 10 ms, the link moves it in 2
+  static constexpr size_t MIN_PART = (size_t)1 << 20;
+  struct Job { char* dst; const char* src; size_t n; std::atomic<int>* left; };
+  std::mutex mtx; std::condition_variable cv; std::vector<Job> jobs; std::vector<std::thread> workers; bool stop = false;
+  void start(unsigned n) {
+    for (unsigned i = 0; i < n; i++) workers.emplace_back([this]() {
+      for (;;) {
+        Job j;
+        { std::unique_lock<std::mutex> lk(mtx); cv.wait(lk, [this]() { return stop || !jobs.empty(); }); if (stop && jobs.empty()) return; j = jobs.back(); jobs.pop_back(); }
+        memcpy(j.dst, j.src, j.n);
+        j.left->fetch_sub(1, std::memory_order_release);
+      }
+    });
+  }
+  ~CopyPool() { { std::lock_guard<std::mutex> lk(mtx); stop = true; } cv.notify_all(); for (auto& t : workers) t.join(); }
+  void copy(void* dst, const void* src, size_t n) {
+    static const unsigned want = []() { const char* e = getenv("MI355_COPY_THREADS"); const long v = e ? atol(e) : 6; return (unsigned)(v < 0 ? 0 : (v > 32 ? 32 : v)); }();
+    if (n < 2 * MIN_PART || want == 0) { memcpy(dst, src, n); return; }
+    { std::lock_guard<std::mutex> lk(mtx); if (workers.empty()) start(want); }
+    size_t parts = n / MIN_PART; if (parts > workers.size() + 1) parts = workers.size() + 1;
+    const size_t per = ((n / parts) + 63) & ~(size_t)63;
+    std::atomic<int> left{0};
+    size_t ofs = per;                                           // (the caller copies the first part itself)
+    { std::lock_guard<std::mutex> lk(mtx);
+      for (; ofs < n; ofs += per) { left.fetch_add(1, std::memory_order_relaxed); jobs.push_back({(char*)dst + ofs, (const char*)src + ofs, n - ofs < per ? n - ofs : per, &left}); } }
+    cv.notify_all();
+    memcpy(dst, src, per < n ? per : n);
+    while (left.load(std::memory_order_acquire) != 0) std::this_thread::yield();
+  }
+};
+static CopyPool& copy_pool() { static CopyPool* p = new CopyPool; return *p; }   // (never destroyed: worker threads must not be joined from a static destructor at exit)
+
+// Pinned staging of one GPU for everything that is NOT a ray query (geometry buffers at commit; mi355_* helpers have their own): two buffers, so that the CPU fills one
+// while the link empties the other.  Blocking, serialised per GPU.
+struct HostStage {
+  static constexpr size_t PIECE = (size_t)8 << 20;
+  std::mutex mtx; char* buf[2] = {nullptr, nullptr}; hipEvent_t ev[2] = {nullptr, nullptr}; hipStream_t st = nullptr;
+  void ensure(int gpu) {
+    hip_check(hipSetDevice(gpu), "hipSetDevice");
+    if (st) return;
+    hip_check(hipStreamCreateWithFlags(&st, hipStreamNonBlocking), "hipStreamCreate(host staging)");
+    for (int k = 0; k < 2; k++) { void* h = nullptr; hip_check(hipHostMalloc(&h, PIECE, hipHostMallocPortable), "hipHostMalloc(host staging)"); buf[k] = (char*)h;
+                                  hip_check(hipEventCreateWithFlags(&ev[k], hipEventDisableTiming), "hipEventCreate"); }
+  }
+  void h2d(int gpu, void* dev, const void* host, size_t bytes) {
+    std::lock_guard<std::mutex> lk(mtx); ensure(gpu);
+    hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize");   // (what the blocking hipMemcpy this replaces did: earlier work on the destination is over)
+    size_t c = 0;
+    for (size_t ofs = 0; ofs < bytes; ofs += PIECE, c++) {
+      const size_t n = bytes - ofs < PIECE ? bytes - ofs : PIECE; const int k = (int)(c & 1u);
+      if (c >= 2) hip_check(hipEventSynchronize(ev[k]), "hipEventSynchronize");
+      copy_pool().copy(buf[k], (const char*)host + ofs, n);
+      hip_check(hipMemcpyAsync((char*)dev + ofs, buf[k], n, hipMemcpyHostToDevice, st), "hipMemcpyAsync(staged H2D)");
+      hip_check(hipEventRecord(ev[k], st), "hipEventRecord");
+    }
+    hip_check(hipStreamSynchronize(st), "hipStreamSynchronize");
+  }
+};
+static HostStage& host_stage(int gpu) {
+  static std::mutex m; static std::map<int, HostStage*> all;
+  std::lock_guard<std::mutex> lk(m);
+  HostStage*& h = all[gpu]; if (!h) h = new HostStage; return *h;
+}
+
 struct Buffer : RefCounted {
   Device* device; size_t bytes; char* host = nullptr; bool ownsHost = false;
   char* dev = nullptr; bool ownsDev = false; bool devDirty = true;   // the copy on the device's first GPU (or the application's own device memory there)
@@ -150,7 +228,7 @@ struct Buffer : RefCounted {
         if (mi355_malloc_retry(device->gpu, bytes + 16, (void**)&dev) != 0) { dev = nullptr; device->memoryMonitor(-(ssize_t)bytes, true); THROW(RTC_ERROR_OUT_OF_MEMORY, "hipMalloc(geometry buffer)"); }
         ownsDev = true;
       }
-      if (bytes) hip_check(hipMemcpy(dev, host, bytes, hipMemcpyHostToDevice), "hipMemcpy(geometry buffer)");
+      if (bytes) host_stage(device->gpu).h2d(device->gpu, dev, host, bytes);   // (staged: the GPU never reads the application's pages, see "host memory never meets the GPU")
     } else if (!sharedDevMem && peers.size() + 1 == device->numReplicas()) return;
     // replicas: from the host copy, or -- memory the application shared as device memory -- from the first GPU, peer to peer (xGMI)
     if (peers.size() + 1 < device->numReplicas()) peers.resize(device->numReplicas() - 1, nullptr);
@@ -163,7 +241,7 @@ struct Buffer : RefCounted {
       }
       if (!bytes) continue;
       if (sharedDevMem) hip_check(hipMemcpyPeer(peers[k], g, dev, device->gpu, bytes), "hipMemcpyPeer(geometry buffer)");
-      else hip_check(hipMemcpy(peers[k], host, bytes, hipMemcpyHostToDevice), "hipMemcpy(geometry buffer replica)");
+      else host_stage(g).h2d(g, peers[k], host, bytes);
     }
     hip_check(hipSetDevice(device->gpu), "hipSetDevice");
     devDirty = false;
@@ -249,6 +327,8 @@ struct Replica {
   hipStream_t pipe[PIPE] = {nullptr, nullptr, nullptr, nullptr};   // large host-array queries: upload, download, two compute streams (pipelined_query)
   std::vector<hipEvent_t> pipeEvents;                       // ... and two events per chunk
   std::mutex pipeMtx;                                       // one pipelined query per replica at a time: the four streams, the events and the streams' status words are shared
+  char* pinUp[2] = {nullptr, nullptr}; char* pinDown[2] = {nullptr, nullptr}; size_t pinCap = 0;   // ... and the pinned staging of the chunks (staged_query): two on the way up, two on the way down
+  hipEvent_t pinUpEv[2] = {nullptr, nullptr}, pinDownEv[2] = {nullptr, nullptr};
   struct Staging { char* d = nullptr; size_t cap = 0; char* h = nullptr; char* hd = nullptr; };   // h / hd: 4 KiB of pinned host memory and its device address
   std::map<size_t, Staging> staging;
   static constexpr size_t SMALL_BYTES = 4096;               // queries of up to this many bytes (rtcIntersect1 .. a few dozen rays) are traced in place in pinned host memory
@@ -297,6 +377,7 @@ struct Replica {
     bvh = flat = nullptr;
     for (auto& kv : staging) { if (kv.second.d) hipFree(kv.second.d); if (kv.second.h) hipHostFree(kv.second.h); }
     for (int k = 0; k < PIPE; k++) if (pipe[k]) hipStreamDestroy(pipe[k]);
+    for (int k = 0; k < 2; k++) { if (pinUp[k]) hipHostFree(pinUp[k]); if (pinDown[k]) hipHostFree(pinDown[k]); if (pinUpEv[k]) hipEventDestroy(pinUpEv[k]); if (pinDownEv[k]) hipEventDestroy(pinDownEv[k]); pinUp[k] = pinDown[k] = nullptr; }
     for (hipEvent_t e : pipeEvents) hipEventDestroy(e);
     if (shardStream) hipStreamDestroy(shardStream);
     if (smallStream) hipStreamDestroy(smallStream);
@@ -568,6 +649,8 @@ void parse_config(Device* d, const char* cfg) {
     else if (k == "top_split_min") d->build.top_split_min = (uint32_t)atol(v.c_str());
     else if (k == "instance_refit") d->noInstanceRefit = atoi(v.c_str()) == 0;
     else if (k == "instance_refit_max") d->instanceRefitMax = (unsigned)atol(v.c_str());
+    else if (k == "coherent_memory") d->coherentMemory = atoi(v.c_str()) != 0;
+    else if (k == "host_register") d->hostRegister = atoi(v.c_str()) != 0;                           // the caller's ray arrays are hipHostRegister'ed for the duration of a query (see "host memory never meets the GPU")
     else if (k == "host_in_place") d->hostInPlace = atoi(v.c_str()) != 0;                             // rtcIntersect1M / rtcOccluded1M on large host arrays: trace them in place over the host link
     else if (k == "top_split_rel") d->build.top_split_rel = (float)atof(v.c_str());
     else if (k == "top_split_cell") d->build.top_split_cell = (float)atof(v.c_str());
@@ -596,7 +679,8 @@ static void check_trace_status(mi355_bvh_t b, hipStream_t q) {
   if (flags & MI355_TRACE_ITER_CAP_HIT) THROW(RTC_ERROR_UNKNOWN, "traversal stopped at its iteration cap: results are incomplete");
   if (flags & MI355_TRACE_STACK_OVERFLOW) THROW(RTC_ERROR_UNKNOWN, "traversal stack overflow: results are incomplete");
 }
-static int trace_launch(mi355_bvh_t b, void* d, unsigned n, size_t stride, bool any, unsigned qflags, hipStream_t q) {
+static int trace_launch(const Scene* s, mi355_bvh_t b, void* d, unsigned n, size_t stride, bool any, unsigned qflags, hipStream_t q) {
+  if ((qflags & MI355_QUERY_COHERENT) && !s->device->coherentMemory) qflags |= MI355_QUERY_COHERENT_NO_MEMORY;   // rtcNewDevice("coherent_memory=0")
   return mi355_trace_query(b, d, n, stride, any ? 1 : 0, qflags, q);
 }
 
@@ -605,6 +689,56 @@ static int trace_launch(mi355_bvh_t b, void* d, unsigned n, size_t stride, bool 
 // directions of the link are busy all the time that way (tests/gpu_pcie.py: upload + download streams alone 2.4 ms for 96 MB each way; chunks that go round
 // k streams, each doing its own H2D - kernel - D2H: 3.3 ms and up, the copy engines then serve one direction at a time for long stretches).
 // Returns false when the array cannot be pinned (the plain path takes over).  `pinned`: the caller has pinned the whole array already (sharded queries).
+// The default since round 6: the same pipeline -- upload stream, two compute streams, download stream, an event between each -- but what the link reads and writes are
+// four pinned buffers of this replica (two chunks on the way up, two on the way down); the calling thread fills and drains them with the CPU (copy_pool: several threads
+// for a 12 MB chunk) while the GPU works on the chunks in between.  The caller's array is never registered and never seen by the GPU.
+static void staged_query(Scene* s, Replica& r, char* data, char* d, unsigned M, size_t stride, bool any, unsigned qflags) {
+  std::lock_guard<std::mutex> pipeLock(r.pipeMtx);
+  mi355_bvh_t b = r.bvh;
+  const size_t rec = any ? 48 : 96;
+  const unsigned chunk = M < s->device->pipelineMin ? M : s->device->pipelineChunk, nchunks = (M + chunk - 1u) / chunk;
+  const size_t chunkBytes = (size_t)(chunk - 1) * stride + rec;
+  hipStream_t up, down, comp[2];
+  std::vector<hipEvent_t> ev;
+  { std::lock_guard<std::mutex> lk(r.mtx);
+    for (int k = 0; k < Replica::PIPE; k++) if (!r.pipe[k]) hip_check(hipStreamCreateWithFlags(&r.pipe[k], hipStreamNonBlocking), "hipStreamCreate");
+    while (r.pipeEvents.size() < 2u * (size_t)nchunks) { hipEvent_t e; hip_check(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate"); r.pipeEvents.push_back(e); }
+    if (r.pinCap < chunkBytes) {
+      for (int k = 0; k < 2; k++) { if (r.pinUp[k]) hipHostFree(r.pinUp[k]); if (r.pinDown[k]) hipHostFree(r.pinDown[k]); r.pinUp[k] = r.pinDown[k] = nullptr; }
+      r.pinCap = 0;
+      const size_t cap = chunkBytes + chunkBytes / 4 + 4096;
+      for (int k = 0; k < 2; k++) { void* h = nullptr; hip_check(hipHostMalloc(&h, cap, hipHostMallocPortable), "hipHostMalloc(ray staging)"); r.pinUp[k] = (char*)h;
+                                    h = nullptr; hip_check(hipHostMalloc(&h, cap, hipHostMallocPortable), "hipHostMalloc(ray staging)"); r.pinDown[k] = (char*)h; }
+      r.pinCap = cap;
+    }
+    for (int k = 0; k < 2; k++) { if (!r.pinUpEv[k]) hip_check(hipEventCreateWithFlags(&r.pinUpEv[k], hipEventDisableTiming), "hipEventCreate");
+                                  if (!r.pinDownEv[k]) hip_check(hipEventCreateWithFlags(&r.pinDownEv[k], hipEventDisableTiming), "hipEventCreate"); }
+    up = r.pipe[0]; down = r.pipe[1]; comp[0] = r.pipe[2]; comp[1] = r.pipe[3]; ev = r.pipeEvents; }
+  auto span = [&](unsigned c, size_t& ofs, size_t& nb, unsigned& n) { const unsigned first = c * chunk; n = M - first < chunk ? M - first : chunk; ofs = (size_t)first * stride; nb = (size_t)(n - 1) * stride + rec; };
+  auto drain = [&](unsigned c) {                               // chunk c has come down into its pinned buffer: hand it to the caller's array
+    size_t ofs, nb; unsigned n; span(c, ofs, nb, n);
+    hip_check(hipEventSynchronize(r.pinDownEv[c & 1u]), "hipEventSynchronize");
+    copy_pool().copy(data + ofs, r.pinDown[c & 1u], nb);
+  };
+  for (unsigned c = 0; c < nchunks; c++) {
+    size_t ofs, nb; unsigned n; span(c, ofs, nb, n);
+    const unsigned k = c & 1u; hipStream_t q = comp[k];
+    if (c >= 2) hip_check(hipEventSynchronize(r.pinUpEv[k]), "hipEventSynchronize");     // (the upload of chunk c - 2 has left this buffer)
+    copy_pool().copy(r.pinUp[k], data + ofs, nb);
+    hip_check(hipMemcpyAsync(d + ofs, r.pinUp[k], nb, hipMemcpyHostToDevice, up), "hipMemcpyAsync(rays H2D)");
+    hip_check(hipEventRecord(r.pinUpEv[k], up), "hipEventRecord");
+    hip_check(hipEventRecord(ev[2u * c], up), "hipEventRecord"); hip_check(hipStreamWaitEvent(q, ev[2u * c], 0), "hipStreamWaitEvent");
+    core_check(trace_launch(s, b, d + ofs, n, stride, any, qflags, q), "trace");
+    hip_check(hipEventRecord(ev[2u * c + 1u], q), "hipEventRecord"); hip_check(hipStreamWaitEvent(down, ev[2u * c + 1u], 0), "hipStreamWaitEvent");
+    if (c >= 2) drain(c - 2);                                   // (its pinned buffer is the one chunk c comes down into)
+    hip_check(hipMemcpyAsync(r.pinDown[k], d + ofs, nb, hipMemcpyDeviceToHost, down), "hipMemcpyAsync(rays D2H)");
+    hip_check(hipEventRecord(r.pinDownEv[k], down), "hipEventRecord");
+  }
+  if (nchunks >= 2) drain(nchunks - 2);
+  drain(nchunks - 1);
+  check_trace_status(b, comp[0]); if (nchunks > 1) check_trace_status(b, comp[1]);
+}
+
 static bool pipelined_query(Scene* s, Replica& r, char* data, char* d, unsigned M, size_t stride, bool any, unsigned qflags, size_t bytes, bool pinned) {
   if (!pinned && hipHostRegister(data, bytes, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); return false; }
   struct Unpin { void* p; ~Unpin() { if (p) hipHostUnregister(p); } } unpin{pinned ? nullptr : data};
@@ -625,7 +759,7 @@ static bool pipelined_query(Scene* s, Replica& r, char* data, char* d, unsigned 
     hipStream_t q = comp[c & 1u];
     hip_check(hipMemcpyAsync(d + ofs, data + ofs, nb, hipMemcpyHostToDevice, up), "hipMemcpyAsync(rays H2D)");
     hip_check(hipEventRecord(ev[2u * c], up), "hipEventRecord"); hip_check(hipStreamWaitEvent(q, ev[2u * c], 0), "hipStreamWaitEvent");
-    core_check(trace_launch(b, d + ofs, n, stride, any, qflags, q), "trace");
+    core_check(trace_launch(s, b, d + ofs, n, stride, any, qflags, q), "trace");
     hip_check(hipEventRecord(ev[2u * c + 1u], q), "hipEventRecord"); hip_check(hipStreamWaitEvent(down, ev[2u * c + 1u], 0), "hipStreamWaitEvent");
     hip_check(hipMemcpyAsync(data + ofs, d + ofs, nb, hipMemcpyDeviceToHost, down), "hipMemcpyAsync(rays D2H)");
   }
@@ -732,7 +866,7 @@ static void replica_query(Scene* s, size_t k, char* data, unsigned M, size_t str
     char* hd = nullptr; char* h = r.stage_host(&hd);
     memcpy(h, data, bytes);
     const hipStream_t sq = s->device->pollSmall ? r.small_stream() : nullptr;
-    core_check(trace_launch(b, hd, M, stride, any, qflags, sq), "trace");
+    core_check(trace_launch(s, b, hd, M, stride, any, qflags, sq), "trace");
     // (round 5) The launch of a single ray takes ~25 us; hipStreamSynchronize puts the thread to sleep on the completion signal and is woken by an interrupt, which adds
     // 10 - 25 us to every call (36 us minimum, 51 us median on the driver's box in round 4).  A thread that waits for one ray polls instead -- hipStreamQuery reads the
     // signal without sleeping -- for at most ~200 us, after which it falls back to the blocking wait (a long kernel ahead of it in the stream, a preempted process).
@@ -754,14 +888,14 @@ static void replica_query(Scene* s, size_t k, char* data, unsigned M, size_t str
   // kernel reads the 48 bytes of every ray and writes the <= 52 bytes of every hit over the host link itself, instead of 96 bytes each way through a staging
   // copy.  Off by default until measured against the chunked pipeline below on the round's box (bench.py end_to_end; tests/gpu_hostpath.py).
   static const bool envInPlace = getenv("MI355_HOST_IN_PLACE") && atoi(getenv("MI355_HOST_IN_PLACE")) != 0;
-  if ((envInPlace || s->device->hostInPlace) && M >= s->device->pipelineMin) {
+  if ((envInPlace || s->device->hostInPlace) && M >= s->device->pipelineMin) {   // (host_in_place registers the caller's array by definition)
     const bool reg = pinned || hipHostRegister(data, bytes, hipHostRegisterMapped) == hipSuccess;
     if (!reg) (void)hipGetLastError();
     void* dp = nullptr;
     if (reg && hipHostGetDevicePointer(&dp, data, 0) == hipSuccess && dp) {
       struct Unpin { void* p; ~Unpin() { if (p) hipHostUnregister(p); } } unpin{pinned ? nullptr : data};
       std::lock_guard<std::mutex> pipeLock(r.pipeMtx);
-      core_check(trace_launch(b, dp, M, stride, any, qflags, nullptr), "trace");
+      core_check(trace_launch(s, b, dp, M, stride, any, qflags, nullptr), "trace");
       check_trace_status(b, nullptr);                        // (waits for the launch)
       return;
     }
@@ -769,9 +903,10 @@ static void replica_query(Scene* s, size_t k, char* data, unsigned M, size_t str
     if (reg && !pinned) hipHostUnregister(data);
   }
   char* d = r.stage(bytes);
+  if (!s->device->hostRegister) { staged_query(s, r, data, d, M, stride, any, qflags); return; }
   if (M >= s->device->pipelineMin && pipelined_query(s, r, data, d, M, stride, any, qflags, bytes, pinned)) return;
   hip_check(hipMemcpy(d, data, bytes, hipMemcpyHostToDevice), "hipMemcpy(rays H2D)");
-  core_check(trace_launch(b, d, M, stride, any, qflags, nullptr), "trace");
+  core_check(trace_launch(s, b, d, M, stride, any, qflags, nullptr), "trace");
   hip_check(hipMemcpy(data, d, bytes, hipMemcpyDeviceToHost), "hipMemcpy(rays D2H)");
   check_trace_status(b, nullptr);
 }
@@ -783,7 +918,7 @@ static void plain_query(Scene* s, void* data, unsigned M, size_t stride, bool an
   const size_t n = s->reps.size();
   if (n == 1 || M < s->device->shardMin * n) { replica_query(s, 0, (char*)data, M, stride, any, qflags, false); return; }
   const size_t rec = any ? 48 : 96, bytes = (size_t)(M - 1) * stride + rec;
-  const bool pinned = hipHostRegister(data, bytes, hipHostRegisterPortable) == hipSuccess;    // once, for all GPUs (portable: every device's copies may use it)
+  const bool pinned = s->device->hostRegister && hipHostRegister(data, bytes, hipHostRegisterPortable) == hipSuccess;    // "host_register=1": once, for all GPUs (portable: every device's copies may use it)
   if (!pinned) (void)hipGetLastError();
   struct Unpin { void* p; ~Unpin() { if (p) hipHostUnregister(p); } } unpin{pinned ? data : nullptr};
   for_each_replica(n, [&](size_t k) {
@@ -813,13 +948,13 @@ static void sharded_device_query(Scene* s, char* d, unsigned M, size_t stride, b
     char* st = r.stage(nb);
     hip_check(hipStreamWaitEvent(r.shardStream, r0.shardIn, 0), "hipStreamWaitEvent");
     hip_check(hipMemcpyPeerAsync(st, r.gpu, d + (size_t)lo * stride, r0.gpu, nb, r.shardStream), "hipMemcpyPeerAsync(shard out)");
-    core_check(trace_launch(committed_bvh(s, k), st, hi - lo, stride, any, qflags, r.shardStream), "trace");
+    core_check(trace_launch(s, committed_bvh(s, k), st, hi - lo, stride, any, qflags, r.shardStream), "trace");
     hip_check(hipMemcpyPeerAsync(d + (size_t)lo * stride, r0.gpu, st, r.gpu, nb, r.shardStream), "hipMemcpyPeerAsync(shard back)");
     hip_check(hipEventRecord(r.shardOut, r.shardStream), "hipEventRecord");
   }
   hip_check(hipSetDevice(r0.gpu), "hipSetDevice");
   const unsigned hi0 = shard_begin(M, 1, n);
-  if (hi0) core_check(trace_launch(committed_bvh(s, 0), d, hi0, stride, any, qflags, stream), "trace");
+  if (hi0) core_check(trace_launch(s, committed_bvh(s, 0), d, hi0, stride, any, qflags, stream), "trace");
   for (size_t k = 1; k < n; k++) if (s->reps[k]->shardOut && shard_begin(M, k + 1, n) > shard_begin(M, k, n)) hip_check(hipStreamWaitEvent(stream, s->reps[k]->shardOut, 0), "hipStreamWaitEvent");
 }
 // device arrays that already live where they are traced: shard k on replica k's GPU, on the caller's stream of that GPU; nothing travels
@@ -831,7 +966,7 @@ static void sharded_pointer_query(Scene* s, unsigned numShards, void* const* d, 
     if (counts[k] == 0u) continue;
     if (!d[k]) THROW(RTC_ERROR_INVALID_ARGUMENT, "shard pointer is NULL");
     hip_check(hipSetDevice(s->reps[k]->gpu), "hipSetDevice");
-    core_check(trace_launch(committed_bvh(s, k), d[k], counts[k], stride, any, qflags, streams ? (hipStream_t)streams[k] : nullptr), "trace");
+    core_check(trace_launch(s, committed_bvh(s, k), d[k], counts[k], stride, any, qflags, streams ? (hipStream_t)streams[k] : nullptr), "trace");
   }
   hip_check(hipSetDevice(s->device->gpu), "hipSetDevice");
 }
@@ -846,7 +981,7 @@ static void device_query(Scene* s, void* d, unsigned M, size_t stride, bool any,
     return;
   }
   if (n > 1 && M >= s->device->shardMin * n) { sharded_device_query(s, (char*)d, M, stride, any, qflags, (hipStream_t)stream); return; }
-  core_check(trace_launch(committed_bvh(s), d, M, stride, any, qflags, (hipStream_t)stream), "trace");
+  core_check(trace_launch(s, committed_bvh(s), d, M, stride, any, qflags, (hipStream_t)stream), "trace");
 }
 void host_query(Scene* s, void* data, unsigned M, size_t stride, bool any, RTCFilterFunctionN argFilter = nullptr, unsigned qflags = 0, RTCRayQueryContext* uctx = nullptr) {
   if (M == 0) return;
@@ -1121,7 +1256,15 @@ RTC_API void rtcGetGeometryTransform(RTCGeometry h, float, enum RTCFormat fmt, v
   else THROW(RTC_ERROR_INVALID_OPERATION, "invalid matrix format");
   CATCH_END(GEOM_DEV(h))
 }
-RTC_API void rtcSetGeometryUserData(RTCGeometry h, void* p) { CATCH_BEGIN geom_of(h)->userPtr = p; CATCH_END(GEOM_DEV(h)) }
+//  With device filter functions the user pointer of a geometry that enabled the argument filter travels to the GPU in the rule table (words 10 / 11 of its entry,
+// written at commit): a changed pointer counts as a changed rule, so that the next rtcCommitScene uploads it instead of returning early on an "unmodified" scene.  (The reference
+// applies setUserData at once, geometry.cpp:137; the host filter path here reads g->userPtr live.  For a __device__ filter function: rtcCommitScene after rtcSetGeometryUserData.)
+RTC_API void rtcSetGeometryUserData(RTCGeometry h, void* p) {
+  CATCH_BEGIN Geometry* g = geom_of(h);
+  if (g->userPtr != p && g->device->deviceFilters && g->argFilter) g->ruleCounter++;
+  g->userPtr = p;
+  CATCH_END(GEOM_DEV(h))
+}
 RTC_API void* rtcGetGeometryUserData(RTCGeometry h) { CATCH_BEGIN return geom_of(h)->userPtr; CATCH_END(GEOM_DEV(h)) return nullptr; }
 // Filter callbacks are host functions; the host-array entry points run them between launches (filtered_query above).  A geometry tells the scenes it is
 // attached to lazily: the flag below is looked at by every host query.

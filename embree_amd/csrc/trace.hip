@@ -34,6 +34,7 @@
 #include <map>
 #include <mutex>
 #include <utility>
+#include <vector>
 #include "bvh_common.h"
 #include "../../include/embree_amd_hip.h"
 #include "internal.h"
@@ -58,7 +59,13 @@ __device__ __forceinline__ float rcp_nr(float a) {  // v_rcp_f32 + one Newton st
 // set bits of a lane mask below this lane: v_mbcnt_lo + v_mbcnt_hi (the compiler does not find them in popcount(m & ((1 << lane) - 1)): two v_and + two v_bcnt and two registers for the constant)
 __device__ __forceinline__ uint32_t rank_below(unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
 __device__ __forceinline__ float xor_sign(float a, uint32_t s) { return __uint_as_float(__float_as_uint(a) ^ s); }
+#ifndef MI355_NO_UNDEF                                          /* (-DMI355_NO_UNDEF: the registers are zeroed instead -- a variant for the bisection of profiles/r06_device_filter.md) */
 #define MI355_UNDEF4(n) asm volatile("" : "=v"(n.x), "=v"(n.y), "=v"(n.z), "=v"(n.w))
+#define MI355_UNDEF2(n) asm volatile("" : "=v"(n.x), "=v"(n.y))
+#else
+#define MI355_UNDEF4(n) do { n.x = 0; n.y = 0; n.z = 0; n.w = 0; } while (0)
+#define MI355_UNDEF2(n) do { n.x = 0; n.y = 0; } while (0)
+#endif
 // "all four words of this load are used": the plain kernels read only e2.z and the mask from a triangle record's third 16 bytes, and the compiler then fetches them as TWO
 // one-word loads -- four (lane, load) pairs per triangle test instead of three, on a kernel that runs into the CU's address path once its instruction count is down (round 5:
 // 352 -> 306 lane-accesses per ray, profiles/r05_trace.md)
@@ -82,6 +89,7 @@ struct TraceArgs {
                          // atomic, no reserve-ahead; lanes R .. 63 (and every lane whose ray is done) are tail helpers from the first iteration on (step 1b)
   volatile uint32_t* status;  // host-mapped: [STATUS_ITER_CAP], [STATUS_SPILL] set to 1 when a safety net dropped work
   unsigned long long* stats;  // optional counters
+  uint32_t* touch; uint32_t touchTriWord;   // counting build only: one bit per node (from word 0) and per triangle record (from word touchTriWord), set when it is fetched: the UNIQUE bytes a launch needs
   const float4* insts;   // INST kernels: InstRec[] as 4 x float4 (world2local vx,vy,vz,p | root node, instID, mask, flags)
   const uint4* rules;    // device-side filter rules, 48 B per geometry (+ bit arrays behind them), or nullptr
   unsigned long long filterFn; void* filterCtx; uint32_t filterEnforce;   // FILT == 2: address of a __device__ filter function (RTCIntersectArguments::filter of a *Device query), its context, RTC_RAY_QUERY_FLAG_INVOKE_ARGUMENT_FILTER
@@ -492,7 +500,7 @@ __global__ __launch_bounds__(BLOCK, FILT == 2 ? 4 : 1) MI355_TRACE_ATTR void tra
     // their round trip overlaps steps 1 - 3a instead of being waited for in step 4 (the node loads of 3a already overlap step 4)
     const bool pre = MI355_TRI_PREFETCH && (qTail - qHead) >= 64u;          // wave-uniform
     uint2 pe; float4 pq0, pq1, pq2;
-    asm volatile("" : "=v"(pe.x), "=v"(pe.y)); MI355_UNDEF4(pq0); MI355_UNDEF4(pq1); MI355_UNDEF4(pq2);
+    MI355_UNDEF2(pe); MI355_UNDEF4(pq0); MI355_UNDEF4(pq1); MI355_UNDEF4(pq2);
     if (pre) {
       pe = queue[(qHead + lane) & (QCAP - 1u)];
       const float4* tp = a.tris + (size_t)pe.x * 3u;
@@ -759,12 +767,14 @@ __global__ __launch_bounds__(BLOCK, FILT == 2 ? 4 : 1) MI355_TRACE_ATTR void tra
       // to serve both: vmcnt(0).  Apart, the prefetched path waits for "all but the five node loads of 3a", the other one for its own loads.)
       auto test_pair = [&](const float4 q0, const float4 q1, float4 q2) {
         MI355_KEEP4(q2);
-        if (STATS) stTris++;
+        if (STATS) { stTris++; if (a.touch) atomicOr(&a.touch[a.touchTriWord + (e.x >> 5)], 1u << (e.x & 31u)); }
         const uint32_t tmask = __float_as_uint(q2.w);
         TriOut w;
         bool ok = ROBUST ? tri_pluecker<false>(q0, q1, q2, gox, goy, goz, gdx, gdy, gdz, gtnear, gtfar0, w)
                          : tri_moeller<false>(q0, q1, q2, gox, goy, goz, gdx, gdy, gdz, gtnear, gtfar0, w);
         ok = ok && ((tmask & grmask) != 0u);                           // EMBREE_RAY_MASK, intersector_epilog.h:256-262
+        uint32_t finst = MI355_EMPTY_REF;                              // FILT == 2: what the function finds in hit.instID[0] (instanced scenes: the id of the instance the owner is in)
+        if (FILT == 2 && INST && ginst != NO_INST) { const float4 i3 = a.insts[(size_t)ginst * 4u + 3u]; if ((__float_as_uint(i3.w) & 1u) == 0u) finst = __float_as_uint(i3.y); }
         if (FILT && ok && a.rules) {                                   // device-side filter rule of the candidate's geometry: where the reference calls the filter callback
           uint32_t ri = __float_as_uint(q2.z);
           if (INST && ginst != NO_INST) ri += __float_as_uint(a.insts[(size_t)ginst * 4u + 3u].w) >> 8;
@@ -773,11 +783,11 @@ __global__ __launch_bounds__(BLOCK, FILT == 2 ? 4 : 1) MI355_TRACE_ATTR void tra
             const uint4 r0 = a.rules[(size_t)ri * 3u];
             if (a.filterEnforce != 0u || (r0.x & RULE_ARG_FILTER) != 0u) {
               const uint4 r2 = a.rules[(size_t)ri * 3u + 2u];
-              ok = call_device_filter<ROBUST>(a.filterFn, a.filterCtx, (void*)(((unsigned long long)r2.w << 32) | r2.z), q0, q1, q2, gox, goy, goz, gdx, gdy, gdz, gtnear, grmask, grayIdx, MI355_EMPTY_REF);
+              ok = call_device_filter<ROBUST>(a.filterFn, a.filterCtx, (void*)(((unsigned long long)r2.w << 32) | r2.z), q0, q1, q2, gox, goy, goz, gdx, gdy, gdz, gtnear, grmask, grayIdx, finst);
             }
           }
         } else if (FILT == 2 && ok && a.filterFn != 0ull && a.filterEnforce != 0u) {   // (no rule table: no geometry enabled the function; an enforcing query calls it for all of them)
-          ok = call_device_filter<ROBUST>(a.filterFn, a.filterCtx, nullptr, q0, q1, q2, gox, goy, goz, gdx, gdy, gdz, gtnear, grmask, grayIdx, MI355_EMPTY_REF);
+          ok = call_device_filter<ROBUST>(a.filterFn, a.filterCtx, nullptr, q0, q1, q2, gox, goy, goz, gdx, gdy, gdz, gtnear, grmask, grayIdx, finst);
         }
         if (ok) atomicMin(&best[owner], ((unsigned long long)__float_as_uint(w.t + 0.0f) << 32) | e.x);   // + 0: a hit at -0 must not sort as a huge key
       };
@@ -796,7 +806,7 @@ __global__ __launch_bounds__(BLOCK, FILT == 2 ? 4 : 1) MI355_TRACE_ATTR void tra
     // ------------------------------------------------------------------ 3b. node step, second half: 8 slab tests
     const unsigned long long stN0 = STATS ? __builtin_readcyclecounter() : 0ull;
     if (doNode) {
-      if (STATS) stNodes++;
+      if (STATS) { stNodes++; if (a.touch) atomicOr(&a.touch[nodeIdx >> 5], 1u << (nodeIdx & 31u)); }
       const float adx = __uint_as_float((n0.w & 0xFFu) << 23) * rdx;
       const float ady = __uint_as_float(((n0.w >> 8) & 0xFFu) << 23) * rdy;
       const float adz = __uint_as_float(((n0.w >> 16) & 0xFFu) << 23) * rdz;
@@ -1168,19 +1178,21 @@ __global__ void packet_scatter(PacketArgs p, int withHit) {
 #ifdef MI355_FPTR_TU
 // ------------------------------------------------------------------------------------- trace_fptr.hip: this file again, for the FILT == 2 instantiations only
 // The kernels that CALL a device filter function are compiled in a translation unit of their own (embree_amd/csrc/trace_fptr.hip = this file with MI355_FPTR_TU defined)
-// at -O1: at -O2 and above the ROCm 7.2 compiler produces a traversal loop around the indirect call that loses its rays -- with ANY callee, an empty function included,
-// and not without the call (profiles/r05_device_filter.md: bisected on the GPU with tests/gpu_devfilter.py WHICH=1; -O1, -Os, -O2, -O3, IPRA off, no AGPR spilling).  The
-// ordinary kernels stay at -O3 in trace.hip; everything below this block (the host side) exists once, there.
+// WITHOUT the record prefetch of step 0 (-DMI355_TRI_PREFETCH=0, embree_amd/build.py).  Round 5 found that above -O1 the loop around the indirect call loses its rays or
+// faults with ANY callee and compiled this unit at -O1; round 6 bisected the kernel's hand-written pieces at -O3 on the GPU (profiles/r06_device_filter.md): SGPR lane masks,
+// the DPP scan and the "undefined register" asm are innocent, the prefetched triangle records in flight across the call are not.  The ordinary kernels keep the prefetch
+// (they call nothing); everything below this block (the host side) exists once, in trace.hip.
 namespace mi355 {
-void* fptr_kernel(bool any, bool robust) {
-  if (robust) return any ? (void*)trace_kernel_q<true, false, true, false, 2> : (void*)trace_kernel_q<false, false, true, false, 2>;
-  return any ? (void*)trace_kernel_q<true, false, false, false, 2> : (void*)trace_kernel_q<false, false, false, false, 2>;
+template <bool INST> static void* fptr_kernel_i(bool any, bool robust) {
+  if (robust) return any ? (void*)trace_kernel_q<true, false, true, INST, 2> : (void*)trace_kernel_q<false, false, true, INST, 2>;
+  return any ? (void*)trace_kernel_q<true, false, false, INST, 2> : (void*)trace_kernel_q<false, false, false, INST, 2>;
 }
+void* fptr_kernel(bool any, bool robust, bool inst) { return inst ? fptr_kernel_i<true>(any, robust) : fptr_kernel_i<false>(any, robust); }   // (round 6: scenes with instances too)
 }  // namespace mi355
 #else
 // ------------------------------------------------------------------------------------- host side
 namespace mi355 {
-void* fptr_kernel(bool any, bool robust);                       // the FILT == 2 kernels (device filter functions): trace_fptr.hip
+void* fptr_kernel(bool any, bool robust, bool inst);            // the FILT == 2 kernels (device filter functions): trace_fptr.hip
 
 typedef void (*TraceFn)(TraceArgs);
 static uint32_t log2floor_u32(uint32_t v) { uint32_t l = 0; while ((2u << l) <= v) l++; return l; }
@@ -1197,7 +1209,7 @@ template <bool INST> static TraceFn pick_stats_i(bool any, bool robust) {       
   return any ? trace_kernel_q<true, true, false, INST, true> : trace_kernel_q<false, true, false, INST, true>;
 }
 static TraceFn pick_kernel(bool any, bool stats, bool robust, bool inst, bool filt, bool fptr = false) {
-  if (fptr) return (TraceFn)fptr_kernel(any, robust);            // (a filter function: scenes without instances only, checked by the caller; compiled in trace_fptr.hip)
+  if (fptr) return (TraceFn)fptr_kernel(any, robust, inst);      // (a filter function of the query: compiled in trace_fptr.hip)
   if (stats) return inst ? pick_stats_i<true>(any, robust) : pick_stats_i<false>(any, robust);
   if (inst) return filt ? pick_kernel_if<true, true>(any, robust) : pick_kernel_if<true, false>(any, robust);
   return filt ? pick_kernel_if<false, true>(any, robust) : pick_kernel_if<false, false>(any, robust);
@@ -1231,7 +1243,6 @@ static int launch_trace_locked(Bvh* b, TraceScratch* sc, void* d_rays, uint32_t 
   if (stride < (any ? 48u : 96u) || (stride & 15u) || ((uintptr_t)d_rays & 15u)) return set_error(hipErrorInvalidValue, "ray array must be 16-byte aligned with a 16-byte-multiple stride");
   if (count > 0xFFF00000u) return set_error(hipErrorInvalidValue, "more than 0xFFF00000 rays in one launch (the hand-out arithmetic is 32-bit)");
   HIP_TRY(hipSetDevice(b->device));
-  if (fc && fc->fn && b->d_insts) return set_error(hipErrorNotSupported, "device filter functions are not supported in scenes with instances");
   const TraceFn fn = pick_kernel(any, statsOut != nullptr, b->robust, b->d_insts != nullptr, b->d_rules != nullptr, fc && fc->fn != 0ull);
   const uint32_t maxBlocks = resident_blocks(b, fn);
   uint32_t blocks = (count + BLOCK - 1) / BLOCK;
@@ -1277,13 +1288,32 @@ static int launch_trace_locked(Bvh* b, TraceScratch* sc, void* d_rays, uint32_t 
   { const char* e = getenv("MI355_TRACE_ITER_CAP"); const long v = e ? atol(e) : 0; a.iterCap = v > 0 && v < (long)ITER_CAP ? (uint32_t)v : ITER_CAP; }
   a.status = sc->statusDev;
   { const char* e = getenv("MI355_TRACE_HELPERS"); a.helpers = e && atoi(e) == 0 ? 0u : 1u; }   // tail helpers (step 1b) on unless MI355_TRACE_HELPERS=0
+  a.touch = nullptr; a.touchTriWord = 0u;
   if (statsOut) {
     HIP_TRY(hipMemsetAsync(sc->stats, 0, 32 * sizeof(uint64_t), s));
     a.stats = (unsigned long long*)sc->stats;
+    // the unique nodes / triangle records this launch fetches (out[18], out[19]): a bit each, set by the counting kernel -- the COMPULSORY bytes of the launch, what a
+    // perfect cache in front of the memory would still have to read once (bench.py: roofline.compulsory_bytes)
+    const size_t nodeWords = ((size_t)b->info.num_nodes + 31u) / 32u + 1u, triWords = ((size_t)b->info.num_triangles + 31u) / 32u + 1u;
+    uint32_t* d_touch = nullptr;
+    if (hipMalloc((void**)&d_touch, (nodeWords + triWords) * 4u) == hipSuccess) {
+      HIP_TRY(hipMemsetAsync(d_touch, 0, (nodeWords + triWords) * 4u, s));
+      a.touch = d_touch; a.touchTriWord = (uint32_t)nodeWords;
+    } else (void)hipGetLastError();
     hipLaunchKernelGGL(fn, dim3(blocks), dim3(BLOCK), 0, s, a);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(statsOut, sc->stats, 32 * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    if (d_touch) {
+      std::vector<uint32_t> h(nodeWords + triWords);
+      const int ce = mi355_memcpy_d2h(h.data(), d_touch, h.size() * 4u);   // (staged: the GPU never maps pageable host memory)
+      hipFree(d_touch);
+      if (ce) return ce;
+      uint64_t un = 0, ut = 0;
+      for (size_t i = 0; i < nodeWords; i++) un += (uint64_t)__builtin_popcount(h[i]);
+      for (size_t i = nodeWords; i < h.size(); i++) ut += (uint64_t)__builtin_popcount(h[i]);
+      statsOut[18] = un; statsOut[19] = ut;
+    }
     return 0;
   }
   if (evStart) HIP_TRY(hipEventRecord(evStart, s));
@@ -1304,7 +1334,7 @@ static int launch_trace(Bvh* b, void* d_rays, uint32_t count, size_t stride, boo
 }
 
 typedef void (*PacketFn)(PacketTraceArgs);
-static int launch_trace_coherent(Bvh* b, void* d_rays, uint32_t count, size_t stride, bool any, hipStream_t s) {
+static int launch_trace_coherent(Bvh* b, void* d_rays, uint32_t count, size_t stride, bool any, hipStream_t s, bool noMemory = false) {
   if (count == 0) return 0;
   if (stride < (any ? 48u : 96u) || (stride & 15u) || ((uintptr_t)d_rays & 15u)) return set_error(hipErrorInvalidValue, "ray array must be 16-byte aligned with a 16-byte-multiple stride");
   HIP_TRY(hipSetDevice(b->device));
@@ -1337,7 +1367,7 @@ static int launch_trace_coherent(Bvh* b, void* d_rays, uint32_t count, size_t st
   // batches on one scene keeps sampling, because sending a coherent batch to the per-lane kernel costs far more than a sample does.)
   static const bool remember = env_u32("MI355_PACKET_REMEMBER", 1, 0, 1) != 0u;
   static const uint32_t sampleMin = env_u32("MI355_PACKET_SAMPLE_MIN", 1024, 0, 0x7FFFFFFF);   // packets: smaller batches are traced in one launch
-  if (remember && packets >= sampleMin && packets >= 4u * PACKET_SAMPLE) {
+  if (remember && !noMemory && packets >= sampleMin && packets >= 4u * PACKET_SAMPLE) {
     const uint32_t said = sc->statusHost[STATUS_COHERENT];     // the last sampled launch's verdict, once it has run (0: not yet, or taken already)
     if (said) { sc->statusHost[STATUS_COHERENT] = 0u; sc->divergeStreak = said == 2u ? sc->divergeStreak + 1u : 0u; }
     if (sc->divergeStreak >= 3u && (++sc->coherentCalls & 15u) != 0u)
@@ -1425,7 +1455,7 @@ int mi355_trace_any(mi355_bvh_t bvh, void* d, uint32_t n, size_t stride, void* s
 int mi355_trace_query(mi355_bvh_t bvh, void* d, uint32_t n, size_t stride, int any_hit, uint32_t query_flags, void* stream) {
   mi355::Bvh* b = (mi355::Bvh*)bvh;
   // RTC_RAY_QUERY_FLAG_COHERENT: the wave-packet kernel (not for scenes with instances: a packet cannot change space lane by lane)
-  if ((query_flags & MI355_QUERY_COHERENT) && !b->d_insts) return mi355::launch_trace_coherent(b, d, n, stride, any_hit != 0, (hipStream_t)stream);
+  if ((query_flags & MI355_QUERY_COHERENT) && !b->d_insts) return mi355::launch_trace_coherent(b, d, n, stride, any_hit != 0, (hipStream_t)stream, (query_flags & MI355_QUERY_COHERENT_NO_MEMORY) != 0u);
   return mi355::launch_trace(b, d, n, stride, any_hit != 0, (hipStream_t)stream, nullptr);
 }
 int mi355_trace_query_filtered(mi355_bvh_t bvh, void* d, uint32_t n, size_t stride, int any_hit, uint32_t query_flags, uint64_t filter_fn, void* filter_ctx, void* stream) {

@@ -158,6 +158,10 @@ MI355_API int mi355_trace_any(mi355_bvh_t bvh, void* d_ray, uint32_t count, size
    bvh_intersector_hybrid.cpp:374-533): consecutive rays are expected to take similar paths; the launch then uses the wave-packet kernel, in which
    the 64 rays of a wavefront walk the tree TOGETHER (one node fetch for all of them).  Results are those of the incoherent kernels. */
 #define MI355_QUERY_COHERENT 0x10000u
+/* with MI355_QUERY_COHERENT: every large coherent query samples its packets (every 32nd packet first) before it decides between the packet and the per-lane kernel, whatever
+   earlier queries on this (tree, stream) found -- rtcNewDevice("coherent_memory=0").  Default: three samples in a row that found their packets apart are remembered and the
+   next 15 coherent queries go to the per-lane kernel unsampled (what a renderer that passes the flag for incoherent batches wants; the answers are the same either way). */
+#define MI355_QUERY_COHERENT_NO_MEMORY 0x40000000u
 MI355_API int mi355_trace_query(mi355_bvh_t bvh, void* d_rays, uint32_t count, size_t byte_stride, int any_hit, uint32_t query_flags, void* stream);
 /* The same query with a filter FUNCTION on the device (the reference's GPU path: runIntersectionFilter1SYCL / runOcclusionFilter1SYCL, kernels/geometry/filter_sycl.h:12-120,
    the function pointer of RTCIntersectArguments::filter / RTCOccludedArguments::filter called from inside the traversal).  filter_fn is the ADDRESS of a
@@ -194,7 +198,8 @@ MI355_API int mi355_trace_any_packet(mi355_bvh_t bvh, const int* d_valid, void* 
    (per wave); out[0] / (64 * out[6]) is the SIMD utilisation of the node step; out[8..11] = lane-iterations spent
    without a ray / waiting for the retire batch / waiting for the triangle queue to drain / blocked on unqueued
    triangle bits; out[12] = node visits that found no child, out[14] = shader clocks (summed over the waves) spent in the ray hand-out block,
-   out[15] = hand-out events, out[16] = shader clocks of the whole loop, out[17] = of the node step.  any_hit != 0 selects the occlusion kernel.
+   out[15] = hand-out events, out[16] = shader clocks of the whole loop, out[17] = of the node step; out[18] / out[19] = DISTINCT nodes / triangle records fetched (a bit
+   per record, set by the counting kernel: the compulsory bytes of the launch).  any_hit != 0 selects the occlusion kernel.
    The rays ARE traced (results written). */
 MI355_API int mi355_trace_stats(mi355_bvh_t bvh, void* d_rays, uint32_t count, size_t byte_stride, int any_hit,
                                 uint64_t out[32]);

@@ -29,7 +29,7 @@ print("calls / rejected / userptr sum:", counters.download(np.uint64), "changed 
 FILTER_FN = C.CFUNCTYPE(None, C.c_void_p)
 def host_rule(p):
     a = C.cast(p, C.POINTER(api.FilterArgs)).contents if hasattr(api, "FilterArgs") else None
-if os.environ.get("ROBUST"):
+if os.environ.get("ROBUST") or os.environ.get("SMALL_ONLY"):
     sys.exit(0)
 
 # ---- what the call costs: the bench workload (crown stand-in, 2^20 diffuse rays) without a function, and with this one enforced on every candidate

@@ -116,3 +116,230 @@ def test_property_table_tells_what_is_built(api, dev):
         assert get(p) == 0, p
     assert get(142) == 1                                           # RTC_DEVICE_PROPERTY_HIP_DEVICE (extension)
     dev.check()
+
+
+# ------------------------------------------------------------------------------------------- the launch shape must not show in the answers
+@pytest.mark.parametrize("any_hit", [False, True])
+def test_small_batches_give_the_bytes_of_the_full_batch(api, dev, any_hit):
+    """A batch that fits the lane slots of the resident grid takes the STATIC launch shape (trace.hip: R rays per wave, no cursor, no atomics, the lanes without a ray help
+    from the first iteration on); larger ones the persistent grid with the cursor hand-out.  Closest hit = the minimum over all accepted candidates of (t bits, triangle),
+    occlusion = any accepted candidate: neither depends on which lane or wave traced a ray, so the first n rays of a batch, launched alone, must come back as the first n
+    records of the whole batch's launch -- byte for byte, for every n on either side of every shape boundary (16 / 32 rays per wave, 2^16 rays, ragged last waves, one ray)."""
+    L = api.load()
+    meshes = W.synthetic_crown(num_phi=48)
+    s = api.make_scene(dev, meshes)
+    prim = W.crown_camera_rays(meshes, 512, 512)
+    s.intersect1M(prim)
+    rays = W.diffuse_bounce_rays(prim, meshes, seed=3)            # 2^18 incoherent rays: more than the static shape takes
+    src = rays_of(rays) if any_hit else rays
+    dt, rec = (RAY_DTYPE, 48) if any_hit else (RAYHIT_DTYPE, 96)
+    query = s.occluded1M_device if any_hit else s.intersect1M_device
+    d = api.DeviceArray.from_numpy(src)
+    query(d.ptr, src.shape[0])
+    L.mi355_device_synchronize(0)
+    full = d.download(dt)
+    assert (np.isneginf(full["tfar"]).mean() > 0.3) if any_hit else ((full["geomID"] != INVALID_ID).mean() > 0.9)
+    for n in (1, 15, 16, 17, 1000, 4096, 32768, 32769, 40001, 65536, 65537, 131072, 200000):
+        L.mi355_memcpy_h2d(d.ptr, src.ctypes.data, n * rec)
+        query(d.ptr, n)
+        L.mi355_device_synchronize(0)
+        assert s.trace_status() == 0
+        assert d.download(dt, n).tobytes() == full[:n].tobytes(), "the first %d rays launched alone differ from their records in the full batch" % n
+    d.free()
+    s.release()
+
+
+def test_counting_kernel_reports_distinct_nodes_and_triangles(api, dev):
+    """mi355_trace_stats out[18] / out[19]: the DISTINCT nodes / triangle records a launch fetches (one bit per record, set by the counting kernel) -- what bench.py's
+    roofline.compulsory_bytes is made of.  Bounds that must hold: 0 < distinct <= visits, distinct <= what the tree has; a batch traced twice touches the same set; one
+    ray touches exactly as many distinct nodes as it visits."""
+    meshes = W.synthetic_crown(num_phi=32)
+    s = api.make_scene(dev, meshes)
+    info = s.info()
+    prim = W.crown_camera_rays(meshes, 128, 128)
+    d = api.DeviceArray.from_numpy(prim)
+    a = s.trace_stats(d.ptr, prim.shape[0], 96)
+    assert 0 < a["unique_nodes"] <= min(a["nodes"], info["num_nodes"]) and 0 < a["unique_tris"] <= min(a["tris"], info["num_triangles"])
+    api.load().mi355_memcpy_h2d(d.ptr, prim.ctypes.data, prim.nbytes)
+    b = s.trace_stats(d.ptr, prim.shape[0], 96)
+    assert (a["unique_nodes"], a["unique_tris"], a["nodes"], a["tris"]) == (b["unique_nodes"], b["unique_tris"], b["nodes"], b["tris"])
+    api.load().mi355_memcpy_h2d(d.ptr, prim.ctypes.data, 96)
+    one = s.trace_stats(d.ptr, 1, 96)
+    assert one["unique_nodes"] == one["nodes"] and one["unique_tris"] == one["tris"] and one["nodes"] >= 1
+    d.free()
+    s.release()
+
+
+def test_commit_is_bit_identical_across_rebuilds_and_qualities_keep_their_hashes(api, dev):
+    """The round's builder changes (the area statistics of the outlier cut taken by primref_gen, four items per thread in primref_gen / tri_records, DPP block scans) move no
+    byte of any tree: MEDIUM and HIGH commits of a scene WITH outliers (a room around noisy spheres) repeated four times give identical node and triangle arrays, and the SAH
+    the builder reports is the one of round 5 (305.88 for the bench's scene is checked by bench.py's line; here: a smaller crown)."""
+    meshes = W.synthetic_crown(num_phi=40)
+    for quality in (None, api.RTC_BUILD_QUALITY_HIGH):
+        s = api.make_scene(dev, meshes, quality=quality)
+        n0, t0 = s.download_bvh()
+        sah0 = s.info()["sah"]
+        assert s.info()["num_presplit"] > 0 or quality is None
+        for _ in range(3):
+            s.touch()
+            s.commit()
+            n1, t1 = s.download_bvh()
+            assert n1.tobytes() == n0.tobytes() and t1.tobytes() == t0.tobytes() and s.info()["sah"] == sah0
+        s.release()
+
+
+def test_user_data_change_reaches_the_device_filter_function(api, ref):
+    """with device_filter_functions=1 the user pointer of a geometry that enabled the argument filter travels to the GPU in the rule table at commit.
+    rtcSetGeometryUserData did not mark anything modified, so rtcCommitScene returned early and the function kept seeing the OLD pointer.  Now a changed pointer counts as a
+    changed rule: after set + commit the function (tests/dev_filter.hip adds args->geometryUserPtr into a device counter) sees the new one."""
+    from tests.test_gpu_round3 import _rule_scene_meshes, _rule_rays
+    devfilter = os.path.join(ROOT, "tests", "golden", "_bin", "libdevfilter.so")
+    assert os.path.exists(devfilter), "tests/golden/_bin/libdevfilter.so is missing: __graft_entry__.build() step 6"
+    L = api.load()
+    lib = C.CDLL(devfilter)
+    lib.devfilter_address.restype = C.c_uint64
+    fn = lib.devfilter_address()
+    assert fn != 0
+    meshes, rays = _rule_scene_meshes(), _rule_rays()
+    fdev = api.Device("gpu=0,device_filter_functions=1")
+    s = api.make_scene(fdev, meshes)
+    hg = L.rtcGetGeometry(s.h, 0)
+    L.rtcSetGeometryEnableFilterFunctionFromArguments(hg, True)
+    counters = api.DeviceArray.from_numpy(np.zeros(3, np.uint64))
+
+    def run(user):
+        L.rtcSetGeometryUserData(hg, C.c_void_p(user))
+        s.commit()
+        L.mi355_memcpy_h2d(counters.ptr, np.zeros(3, np.uint64).ctypes.data, 24)
+        d = api.DeviceArray.from_numpy(rays)
+        qa = api.QueryArguments(None, 0)
+        qa.filter, qa.context = C.c_void_p(fn), C.c_void_p(counters.ptr)
+        s.intersect1M_device(d.ptr, rays.shape[0], args=qa)
+        L.mi355_device_synchronize(0)
+        d.free()
+        c = counters.download(np.uint64)
+        return int(c[0]), int(c[2])
+    calls_a, sum_a = run(0x1000)
+    calls_b, sum_b = run(0x2000)
+    assert calls_a > 0 and calls_a == calls_b
+    assert sum_a == calls_a * 0x1000 and sum_b == calls_b * 0x2000, "the device filter function still sees the old user pointer: %x / %d calls" % (sum_b, calls_b)
+    counters.free()
+    s.release()
+    fdev.release()
+
+
+# ------------------------------------------------------------------------------------------- VERDICT r05 item 6: device filter functions in instanced scenes, at -O3
+@pytest.mark.parametrize("flags", [0, 4])                       # fast, RTC_SCENE_FLAG_ROBUST
+def test_device_filter_function_in_an_instanced_scene_vs_reference_callback(api, ref, flags):
+    """Round 5 refused a __device__ filter function in scenes with instances (hipErrorNotSupported) and compiled the calling kernels at -O1.  Round 6: the calling kernels are
+    built at -O3 without the record prefetch (what breaks them above -O1: profiles/r06_device_filter.md) and exist for instanced scenes as well; the function sees the
+    candidate's primID / geomID inside the instanced scene and the instance's id in hit.instID[0] (kernels/geometry/filter_sycl.h:12-120, instance_stack.h:19-50).  Checker:
+    the REAL reference running the same rule (reject (primID + 2 geomID) % 5 == 1) as the argument filter callback of an enforcing query over the same two-level scene."""
+    from tests.test_gpu_round3 import _rule_scene_meshes, _rule_rays, _tri_t64
+    devfilter = os.path.join(ROOT, "tests", "golden", "_bin", "libdevfilter.so")
+    assert os.path.exists(devfilter), "tests/golden/_bin/libdevfilter.so is missing: __graft_entry__.build() step 6"
+    L = api.load()
+    lib = C.CDLL(devfilter)
+    lib.devfilter_address.restype = C.c_uint64
+    fn = lib.devfilter_address()
+    assert fn != 0
+    meshes, rays = _rule_scene_meshes(), _rule_rays()
+    xf = [[1, 0, 0, 0, 1, 0, 0, 0, 1, 0.0, 0, 0], [0.8, 0, 0, 0, 0.8, 0, 0, 0, 0.8, 0.45, 0.1, -0.05]]
+    fdev = api.Device("gpu=0,device_filter_functions=1")
+    obj = api.make_scene(fdev, meshes[:2], flags=flags)
+    top = api.Scene(fdev, flags)
+    for x in xf:
+        top.add_instance(obj, x)
+    top.add_triangle_mesh(*meshes[2])
+    top.commit()
+    R = ref.RefScene(flags=flags)
+    Robj = R.new_object(flags=flags)
+    for v, t in meshes[:2]:
+        Robj.add_mesh(v, t)
+    Robj.commit()
+    for x in xf:
+        R.add_instance(Robj, x)
+    R.add_mesh(*meshes[2])
+    R.commit()
+    assert R.error() == 0
+    plain = rays.copy()
+    top.intersect1M(plain)
+    counters = api.DeviceArray.from_numpy(np.zeros(3, np.uint64))
+    enforce = api.RTC_RAY_QUERY_FLAG_INVOKE_ARGUMENT_FILTER
+
+    def device_query(any_hit):
+        src = rays_of(rays) if any_hit else rays
+        d = api.DeviceArray.from_numpy(src)
+        qa = api.QueryArguments(None, enforce)
+        qa.filter, qa.context = C.c_void_p(fn), C.c_void_p(counters.ptr)
+        (top.occluded1M_device if any_hit else top.intersect1M_device)(d.ptr, src.shape[0], args=qa)
+        L.mi355_device_synchronize(0)
+        assert top.trace_status() == 0
+        out = d.download(RAY_DTYPE if any_hit else RAYHIT_DTYPE)
+        d.free()
+        return out
+    want = rays.copy()
+    R.intersect1_args(want, arg_rule=True, flags=enforce)
+    got = device_query(False)
+    same = (got["geomID"] == want["geomID"]) & (got["primID"] == want["primID"]) & (got["instID"] == want["instID"])
+    hit = want["geomID"] != INVALID_ID
+    assert ((got["geomID"] != INVALID_ID) == hit).mean() > 0.998 and same.mean() > 0.995, "IDs differ on %d of %d rays" % (int((~same).sum()), rays.shape[0])   # (exact-t ties between the two instances' copies are legal)
+    m = same & hit
+    assert (np.abs(got["tfar"][m] - want["tfar"][m]) <= 1e-4 * np.abs(want["tfar"][m])).all()
+    assert int(((got["primID"] != plain["primID"]) | (got["geomID"] != plain["geomID"]) | (got["instID"] != plain["instID"])).sum()) > 500, "the function rejected next to nothing"
+    calls = counters.download(np.uint64)
+    assert calls[0] > 0 and 0 < calls[1] <= calls[0]
+    wr = rays_of(rays)
+    R.occluded1_args(wr, arg_rule=True, flags=enforce)
+    gr = device_query(True)
+    compare_occluded(gr["tfar"], wr["tfar"], rays_of(rays)["tfar"], max_flip_frac=2e-3, label="device filter function in an instanced scene, occlusion")
+    R.close(); Robj.close()
+    counters.free(); top.release(); obj.release(); fdev.release()
+
+
+# ------------------------------------------------------------------------------------------- VERDICT r05 item 8: RTC_RAY_QUERY_FLAG_COHERENT is a hint with a memory -- say so, and let it be switched off
+def test_coherent_flag_on_an_alternating_stream_with_and_without_its_memory(api):
+    """RTC_RAY_QUERY_FLAG_COHERENT sends a batch to the wave-packet kernel; large batches sample every 32nd packet first and hand the batch to the per-lane kernel when the
+    sample's packets fall apart.  Three such verdicts in a row are REMEMBERED per (tree, stream): the next 15 flagged queries skip the sample -- right for a renderer that sets
+    the flag on everything, wrong-footed by one that alternates coherent primary batches and incoherent bounce batches on ONE stream (the memory never settles: every bounce
+    batch pays its sample, or -- after three bounce batches in a row -- a primary batch is sent to the per-lane kernel).  rtcNewDevice("coherent_memory=0") makes every query
+    decide on its own sample.  The ANSWERS never depend on any of this: byte-identical to the unflagged query for every interleaving, with and without the memory.  The
+    timings are printed (INTEGRATION.md names the knob); the one bound asserted is that no interleaving costs a flagged stream more than twice the unflagged one."""
+    import time
+    L = api.load()
+    meshes = W.synthetic_crown(num_phi=64)
+    out = {}
+    for cfg in ("gpu=0", "gpu=0,coherent_memory=0"):
+        d_ = api.Device(cfg)
+        s = api.make_scene(d_, meshes)
+        prim = W.crown_camera_rays(meshes, 512, 512)
+        hit = prim.copy(); s.intersect1M(hit)
+        bounce = W.diffuse_bounce_rays(hit, meshes, seed=5)
+        dp, db = api.DeviceArray.from_numpy(prim), api.DeviceArray.from_numpy(bounce)
+        wp, wb = api.DeviceArray(prim.nbytes), api.DeviceArray(bounce.nbytes)
+        st = C.c_void_p(); L.mi355_stream_create(0, C.byref(st))
+        want_p = want_b = None
+        for flagged in (False, True):
+            qa = api.QueryArguments(None, api.RTC_RAY_QUERY_FLAG_COHERENT if flagged else 0)
+            for order in ("pbpbpbpbpbpb", "bbbbpbbbbpbbbbp", "pppbpppbpppb"):
+                L.mi355_synchronize(st)
+                t0 = time.perf_counter()
+                for ch in order:
+                    src, dst, n = (dp, wp, prim) if ch == "p" else (db, wb, bounce)
+                    L.mi355_memcpy_d2d_async(dst.ptr, src.ptr, n.nbytes, st)
+                    s.intersect1M_device(dst.ptr, n.shape[0], stream=st, args=qa)
+                L.mi355_synchronize(st)
+                out[(cfg, flagged, order)] = (time.perf_counter() - t0) * 1e3
+                assert s.trace_status(st) == 0
+                rp, rb = wp.download(RAYHIT_DTYPE), wb.download(RAYHIT_DTYPE)
+                if want_p is None:
+                    want_p, want_b = rp, rb
+                assert rp.tobytes() == want_p.tobytes() and rb.tobytes() == want_b.tobytes(), "flag %s, order %s, %s: the answers moved" % (flagged, order, cfg)
+        for a_ in (dp, db, wp, wb):
+            a_.free()
+        s.release(); d_.release()
+    for k, v in sorted(out.items()):
+        print("coherent stream cfg=%s flag=%s order=%s: %.2f ms" % (k[0], k[1], k[2], v))
+    for (cfg, flagged, order), v in out.items():
+        if flagged:
+            assert v <= 2.0 * out[(cfg, False, order)] + 0.5, "flagged stream %s (%s): %.2f ms against %.2f ms unflagged" % (order, cfg, v, out[(cfg, False, order)])
