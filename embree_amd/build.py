@@ -13,7 +13,7 @@ LIB = os.path.join(LIBDIR, "libembree4_mi355.so")
 SOURCES = ["build.hip", "trace.hip", "trace_fptr.hip", "shard.hip", "rtcore_api.cpp"]
 HEADERS = ["trace.hip", "bvh_common.h", "internal.h", "../../include/embree4/rtcore.h", "../../include/embree_amd_hip.h",
            "build_common.inl", "build_primref.inl", "build_presplit.inl", "build_binning.inl", "build_top.inl", "build_spatial.inl", "build_small.inl",
-           "build_morton.inl", "build_wide.inl", "build_leaves.inl"]    # parts of build.hip (one translation unit)
+           "build_morton.inl", "build_sort.inl", "build_wide.inl", "build_leaves.inl"]    # parts of build.hip (one translation unit)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden",
          "-Wall", "-Wno-unused-function", "-Wno-unused-variable", "-Wno-unused-value", "-Wno-unused-result"]
 # per-source flags.  trace.hip: the SLP vectoriser pairs scalar fp32 operations of the node set-up and of the triangle test into v_pk_mul / v_pk_add / v_pk_fma_f32 and

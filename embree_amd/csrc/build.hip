@@ -27,7 +27,6 @@
 // (heuristic_binning_array_aligned.h:178-182).  The tree need not equal the reference's tree:
 // t/u/v/Ng/IDs of a closest hit do not depend on tree shape.
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>     // DeviceRadixSort for the Morton build (a plain library sort; everything else here is hand-written)
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -49,6 +48,7 @@ namespace {
 #include "build_spatial.inl"     // RTC_BUILD_QUALITY_HIGH: spatial splits inside the top phase
 #include "build_small.inl"       // K3: sub-trees finished by one wavefront in LDS
 #include "build_morton.inl"      // RTC_BUILD_QUALITY_LOW: Morton-code build
+#include "build_sort.inl"        // ... its radix sort (onesweep, 7 passes of 9 bits) and the Morton codes
 #include "build_wide.inl"        // K4: collapse of the binary tree into 8-wide quantised nodes
 #include "build_leaves.inl"      // K5: leaf records; refit; node rebasing for instanced scenes
 
@@ -420,16 +420,21 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
   }
 
   if (prm.quality == 1u) {                                     // RTC_BUILD_QUALITY_LOW: Morton codes -> sort -> hierarchy -> boxes
-    DevBuf<unsigned long long> keys, keysSorted; DevBuf<uint32_t> vals, valsSorted, parent, flags; DevBuf<char> tmp;
+    DevBuf<unsigned long long> keys, keysSorted, sortStatus; DevBuf<uint32_t> vals, valsSorted, parent, flags, sortHist;
+    const uint32_t tiles = (n + RS_TILE - 1u) / RS_TILE;          // of the sort (build_sort.inl)
     HIP_TRY(keys.alloc(n)); HIP_TRY(keysSorted.alloc(n)); HIP_TRY(vals.alloc(n)); HIP_TRY(valsSorted.alloc(n)); HIP_TRY(parent.alloc(2ull * n)); HIP_TRY(flags.alloc(n));
-    size_t tmpBytes = 0;
-    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmpBytes, keys.p, keysSorted.p, vals.p, valsSorted.p, (int)n, 0, 63, st));
-    HIP_TRY(tmp.alloc(tmpBytes));
+    HIP_TRY(sortHist.alloc(RS_HIST_WORDS)); HIP_TRY(sortStatus.alloc((size_t)tiles * RS_RADIX));
     float3 cmin = make_float3(clo[0], clo[1], clo[2]), cscale;
     { const float e[3] = {chi[0] - clo[0], chi[1] - clo[1], chi[2] - clo[2]}; float s3[3]; for (int d = 0; d < 3; d++) s3[d] = e[d] > 0.0f ? 2097152.0f / e[d] : 0.0f; cscale = make_float3(s3[0], s3[1], s3[2]); }
     const uint32_t g = (n + 255u) / 256u;
-    LAUNCH(morton_keys, dim3(g), dim3(256), 0, st, bufA.p, n, cmin, cscale, keys.p, vals.p);
-    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.p, tmpBytes, keys.p, keysSorted.p, vals.p, valsSorted.p, (int)n, 0, 63, st)); launches += 8;
+    HIP_TRY(hipMemsetAsync(sortHist.p, 0, (size_t)RS_HIST_WORDS * 4, st));                      // histograms and tile tickets
+    HIP_TRY(hipMemsetAsync(sortStatus.p, 0, (size_t)tiles * RS_RADIX * 8, st));                 // what the tiles publish (tag 0 = nothing; one array for the seven passes)
+    LAUNCH(morton_keys, dim3(tiles), dim3(256), 0, st, bufA.p, n, cmin, cscale, keys.p, sortHist.p);
+    for (uint32_t pass = 0; pass < RS_PASSES; pass++) {          // (seven passes: the last one lands in keysSorted / valsSorted)
+      const bool even = (pass & 1u) == 0u;
+      LAUNCH(radix_pass, dim3(tiles), dim3(RS_THREADS), 0, st, (const unsigned long long*)(even ? keys.p : keysSorted.p), (const uint32_t*)(pass == 0u ? nullptr : (even ? vals.p : valsSorted.p)),
+             even ? keysSorted.p : keys.p, even ? valsSorted.p : vals.p, n, pass, sortHist.p, sortStatus.p, sortHist.p + RS_PASSES * RS_RADIX);
+    }
     LAUNCH(morton_gather, dim3(g), dim3(256), 0, st, bufA.p, valsSorted.p, n, bufB.p, finalIds.p);
     HIP_TRY(hipMemsetAsync(flags.p, 0, (size_t)n * 4, st));
     if (n > 1u) LAUNCH(lbvh_hierarchy, dim3((n + 254u) / 256u), dim3(256), 0, st, keysSorted.p, n, bnodes.p, parent.p);
@@ -477,8 +482,11 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
   if (numSegs && sahBuild) {
     uint32_t sure = 1; while (sure < 40u && ((uint64_t)prm.small << sure) < n) sure++;   // the largest segment halves at best: that many levels exist
     if (fast) {                                                                             // + margin: SAH splits are uneven (crown: 17 levels where 13 are implied)
-      const uint32_t margin = spatial ? 10u : 8u;                                           // (spatial splits add references on the way down: the powerplant stand-in's HIGH tree has 25 levels where 16 are implied)
+      const uint32_t margin = 10u;                                           // (spatial splits add references on the way down: the powerplant stand-in's HIGH tree has 25 levels where 16 are implied)
       const uint32_t levels = learned ? min(sure + margin, learnedTop + 1u) : sure + margin;   // (what the last commit of this size needed, + 1)
+      // (round 6: small_threshold 1024 -> 512 -- one more level is top_local's, a whole workgroup per set with the references in registers, instead of the large mode of
+      // small_build, one wavefront per set through L2: crown 5.15 -> 5.06 ms, same tree; the powerplant stand-in then has 24 top levels where 15 are implied, hence a
+      // margin of 10 for every quality (8 sent it to the stepwise path: 12.97 ms instead of 12.5))
       for (uint32_t i = 0; i < levels; i++) enqueue_top_level();
     }
     else {
@@ -888,9 +896,43 @@ extern "C" {
 
 void mi355_default_build_params(mi355_build_params* p) {
   memset(p, 0, sizeof(*p));
-  p->sah_block_shift = 0; p->min_leaf = 2; p->max_leaf = 3; p->small_threshold = 1024; p->trav_cost = 1.0f; p->int_cost = 1.0f; p->split_factor = 1.2f; p->presplits = 0; p->top_splits = 1; p->top_split_min = 0; p->top_split_rel = 32.0f; p->top_split_cell = 1.0f / 8.0f;
+  p->sah_block_shift = 0; p->min_leaf = 2; p->max_leaf = 3; p->small_threshold = 512; p->trav_cost = 1.0f; p->int_cost = 1.0f; p->split_factor = 1.2f; p->presplits = 0; p->top_splits = 1; p->top_split_min = 0; p->top_split_rel = 32.0f; p->top_split_cell = 1.0f / 8.0f;
 }
 const char* mi355_last_error(void) { return mi355::g_err.c_str(); }
+// The sort of the Morton build on its own (build_sort.inl): n keys of 63 bits (device memory; bit 63 clear) -> the keys in order and, per place, the index the key came from;
+// equal keys keep their index order.  tests/test_gpu_round6.py checks it against a stable argsort; *ms = time of the seven passes (HIP events), if asked for.
+int mi355_sort_keys63(int device, const void* d_keys, void* d_keys_sorted, void* d_index_sorted, uint32_t n, float* ms) {
+  using namespace mi355;
+  HIP_TRY(hipSetDevice(device));
+  if (ms) *ms = 0.0f;
+  if (n == 0u) return 0;
+  if (n >= (1u << 30)) return set_error(hipErrorInvalidValue, "mi355_sort_keys63: at most 2^30 - 1 keys");
+  const uint32_t tiles = (n + RS_TILE - 1u) / RS_TILE;
+  unsigned long long *tmpK = nullptr, *status = nullptr; uint32_t *tmpV = nullptr, *hist = nullptr;
+  struct Free { void** p[4]; ~Free() { for (void** q : p) if (*q) hipFree(*q); } } fr{{(void**)&tmpK, (void**)&status, (void**)&tmpV, (void**)&hist}};
+  HIP_TRY(hipMalloc((void**)&tmpK, (size_t)n * 8)); HIP_TRY(hipMalloc((void**)&tmpV, (size_t)n * 4));
+  HIP_TRY(hipMalloc((void**)&status, (size_t)tiles * RS_RADIX * 8)); HIP_TRY(hipMalloc((void**)&hist, (size_t)RS_HIST_WORDS * 4));
+  hipStream_t st = nullptr;
+  hipEvent_t e0, e1; HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+  struct EvGuard { hipEvent_t a, b; ~EvGuard() { hipEventDestroy(a); hipEventDestroy(b); } } evg{e0, e1};
+  HIP_TRY(hipMemsetAsync(hist, 0, (size_t)RS_HIST_WORDS * 4, st));
+  HIP_TRY(hipMemsetAsync(status, 0, (size_t)tiles * RS_RADIX * 8, st));
+  hipLaunchKernelGGL(sort_hist0, dim3(tiles), dim3(256), 0, st, (const unsigned long long*)d_keys, n, hist);
+  HIP_TRY(hipEventRecord(e0, st));
+  // (seven passes: source -> sorted, sorted -> tmp, tmp -> sorted, ...: the caller's keys are never written)
+  for (uint32_t pass = 0; pass < RS_PASSES; pass++) {
+    const bool even = (pass & 1u) == 0u;
+    const unsigned long long* kin = pass == 0u ? (const unsigned long long*)d_keys : (even ? tmpK : (const unsigned long long*)d_keys_sorted);
+    const uint32_t* vin = pass == 0u ? nullptr : (even ? tmpV : (const uint32_t*)d_index_sorted);
+    hipLaunchKernelGGL(radix_pass, dim3(tiles), dim3(RS_THREADS), 0, st, kin, vin, even ? (unsigned long long*)d_keys_sorted : tmpK, even ? (uint32_t*)d_index_sorted : tmpV,
+                       n, pass, hist, status, hist + RS_PASSES * RS_RADIX);
+  }
+  HIP_TRY(hipEventRecord(e1, st));
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventSynchronize(e1));
+  if (ms) HIP_TRY(hipEventElapsedTime(ms, e0, e1));
+  return 0;
+}
 int mi355_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
 int mi355_device_name(int device, char* out, size_t n) {
   hipDeviceProp_t prop; HIP_TRY(hipGetDeviceProperties(&prop, device));

@@ -14,15 +14,7 @@ __device__ __forceinline__ unsigned long long spread21(uint32_t v) {   // 21 bit
   x = (x | x << 4) & 0x10C30C30C30C30C3ull; x = (x | x << 2) & 0x1249249249249249ull;
   return x;
 }
-__global__ __launch_bounds__(256) void morton_keys(const PrimRef* prims, uint32_t n, float3 cmin, float3 cscale, unsigned long long* keys, uint32_t* vals) {
-  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-  if (i >= n) return;
-  const PrimRef p = load_prim(prims + i);
-  const float fx = ((p.lo[0] + p.hi[0]) - cmin.x) * cscale.x, fy = ((p.lo[1] + p.hi[1]) - cmin.y) * cscale.y, fz = ((p.lo[2] + p.hi[2]) - cmin.z) * cscale.z;
-  const uint32_t ix = (uint32_t)fminf(fmaxf(fx, 0.0f), 2097151.0f), iy = (uint32_t)fminf(fmaxf(fy, 0.0f), 2097151.0f), iz = (uint32_t)fminf(fmaxf(fz, 0.0f), 2097151.0f);
-  keys[i] = spread21(ix) | (spread21(iy) << 1) | (spread21(iz) << 2);
-  vals[i] = i;
-}
+// (morton_keys: build_sort.inl -- it also counts the histogram of the sort's first digit)
 __global__ __launch_bounds__(256) void morton_gather(const PrimRef* src, const uint32_t* order, uint32_t n, PrimRef* dst, uint2* finalIds) {
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i >= n) return;
@@ -70,28 +62,56 @@ __device__ __forceinline__ void ld_boxes_sys(const BNode* x, const BNode* y, v4f
                "global_load_dwordx4 %2, %5, off sc0 sc1\n\tglobal_load_dwordx4 %3, %5, off offset:16 sc0 sc1\n\ts_waitcnt vmcnt(0)"
                : "=&v"(xl), "=&v"(xh), "=&v"(yl), "=&v"(yh) : "v"(x), "v"(y) : "memory");
 }
+// (round 6) The first levels stay inside the workgroup.  The leaves are in code order, so an internal node whose range lies within the 256 leaves of one workgroup has
+// both children there as well, and its index (it is one end of its own range) is one of the workgroup's 256: the two children meet at an LDS flag and hand their boxes
+// over in LDS -- no device atomic, no system-scope access, and the second to arrive carries the merged box on in registers.  Only a node whose range crosses a workgroup
+// boundary takes the global protocol above (its children's boxes are stored system-scope when their threads leave the local phase): ~1 node in 100.  The kernel was the
+// largest of a LOW commit, 859 us of 3.1 ms for 4.76 M triangles (profiles/r06_bench_kernel_stats.md), every node two system-scope stores, four loads and an atomic.
+// Boxes are min / max: the tree does not change by a bit.
 __global__ __launch_bounds__(256) void lbvh_bounds(const PrimRef* prims, uint32_t n, BNode* bnodes, const uint32_t* parent, uint32_t* flags, Counters* ctr) {
-  const uint32_t j = blockIdx.x * 256u + threadIdx.x;
+  __shared__ uint32_t s_flag[256];
+  __shared__ float s_cb[256][2][6];                             // per local internal node: the box each child brought
+  const uint32_t tid = threadIdx.x, bs = blockIdx.x * 256u, be = min(bs + 256u, n), j = bs + tid;
+  s_flag[tid] = 0u;
+  __syncthreads();
   if (j >= n) return;
   const PrimRef p = load_prim(prims + j);
-  uint32_t id = n - 1u + j;
-  {
-    v4f l = {p.lo[0], p.lo[1], p.lo[2], __uint_as_float(j)}, h = {p.hi[0], p.hi[1], p.hi[2], __uint_as_float(j + 1u)};
-    st16_sys(bnodes + id, l); st16_sys((char*)(bnodes + id) + 16, h);
-    ((uint4*)(bnodes + id))[2] = make_uint4(NIL, NIL, __float_as_uint(__builtin_inff()), 0u);   // links: only read by later kernels
-  }
+  uint32_t id = n - 1u + j, w3 = j, w7 = j + 1u;                 // the node this thread carries, its range words
+  float lo[3] = {p.lo[0], p.lo[1], p.lo[2]}, hi[3] = {p.hi[0], p.hi[1], p.hi[2]};
+  ((float4*)(bnodes + id))[0] = make_float4(lo[0], lo[1], lo[2], __uint_as_float(w3));
+  ((float4*)(bnodes + id))[1] = make_float4(hi[0], hi[1], hi[2], __uint_as_float(w7));
+  ((uint4*)(bnodes + id))[2] = make_uint4(NIL, NIL, __float_as_uint(__builtin_inff()), 0u);   // links: only read by later kernels
   if (j == 0u) ctr->numBLeaves = n;
+  bool local = true;
   while (id != 0u) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // my box is in memory before my arrival is announced
     const uint32_t par = parent[id];
-    if (atomicAdd(&flags[par], 1u) == 0u) return;               // first to arrive: the sibling's thread takes over
     const uint32_t* pw = (const uint32_t*)(bnodes + par);       // links and range: written by lbvh_hierarchy, never changed here
     const uint32_t l = pw[8], r = pw[9], first = pw[3], end = pw[7];
-    v4f al, ah, bl, bh;
-    ld_boxes_sys(bnodes + l, bnodes + r, al, ah, bl, bh);
-    v4f lo = {fminf(al.x, bl.x), fminf(al.y, bl.y), fminf(al.z, bl.z), __uint_as_float(first)};
-    v4f hi = {fmaxf(ah.x, bh.x), fmaxf(ah.y, bh.y), fmaxf(ah.z, bh.z), __uint_as_float(end)};
-    st16_sys(bnodes + par, lo); st16_sys((char*)(bnodes + par) + 16, hi);
+    if (local && first >= bs && end <= be) {                    // both children are this workgroup's: meet in LDS
+      const uint32_t k = par - bs, side = l == id ? 0u : 1u;
+      for (int d = 0; d < 3; d++) { s_cb[k][side][d] = lo[d]; s_cb[k][side][3 + d] = hi[d]; }
+      __threadfence_block();
+      if (atomicAdd(&s_flag[k], 1u) == 0u) return;              // first to arrive: the sibling's thread takes over
+      __threadfence_block();
+      for (int d = 0; d < 3; d++) { lo[d] = fminf(lo[d], s_cb[k][side ^ 1u][d]); hi[d] = fmaxf(hi[d], s_cb[k][side ^ 1u][3 + d]); }
+      w3 = first; w7 = end;
+      ((float4*)(bnodes + par))[0] = make_float4(lo[0], lo[1], lo[2], __uint_as_float(w3));
+      ((float4*)(bnodes + par))[1] = make_float4(hi[0], hi[1], hi[2], __uint_as_float(w7));
+    } else {
+      if (local) {                                              // leaving the workgroup: what I carry must be in memory for whoever merges it
+        v4f a = {lo[0], lo[1], lo[2], __uint_as_float(w3)}, b = {hi[0], hi[1], hi[2], __uint_as_float(w7)};
+        st16_sys(bnodes + id, a); st16_sys((char*)(bnodes + id) + 16, b);
+        local = false;
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // my box is in memory before my arrival is announced
+      if (atomicAdd(&flags[par], 1u) == 0u) return;             // first to arrive: the sibling's thread takes over
+      v4f al, ah, bl, bh;
+      ld_boxes_sys(bnodes + l, bnodes + r, al, ah, bl, bh);
+      lo[0] = fminf(al.x, bl.x); lo[1] = fminf(al.y, bl.y); lo[2] = fminf(al.z, bl.z); hi[0] = fmaxf(ah.x, bh.x); hi[1] = fmaxf(ah.y, bh.y); hi[2] = fmaxf(ah.z, bh.z);
+      w3 = first; w7 = end;
+      v4f a = {lo[0], lo[1], lo[2], __uint_as_float(w3)}, b = {hi[0], hi[1], hi[2], __uint_as_float(w7)};
+      st16_sys(bnodes + par, a); st16_sys((char*)(bnodes + par) + 16, b);
+    }
     id = par;
   }
 }

@@ -379,7 +379,10 @@ __device__ __forceinline__ void setup_rdir(float dx, float dy, float dz, float& 
 // test for the u/v cut-off) costs 6 - 12 VGPRs, which takes the robust kernels from 128 to 134 = from four to three waves per SIMD for every scene.
 // FILT == 2: rules + a device filter FUNCTION (call_device_filter above): an indirect call inside the triangle block -- a stack in scratch memory and the register budget of a
 // callee the compiler cannot see; only the queries that pass a function pay for it (profiles/r05_device_filter.md).
-template <bool ANY, bool STATS, bool ROBUST, bool INST, int FILT>
+// SMALL: the static launch shape of small batches (a.staticRays rays per wave, see in front of the loop) is an instantiation of its own: with the pre-started rays in the
+// same code the loop of the large-batch kernel came out 23 VALU instructions longer (+4 % wave instructions per launch by the counters, same answers) -- the ray state then
+// enters the loop with values the compiler has to carry instead of constants.
+template <bool ANY, bool STATS, bool ROBUST, bool INST, int FILT, bool SMALL = false>
 __global__ __launch_bounds__(BLOCK, FILT == 2 ? 4 : 1) MI355_TRACE_ATTR void trace_kernel_q(TraceArgs a) {
   __shared__ uint2 s_stack[BLOCK / 64][QSTACK_LDS][64];
   __shared__ __attribute__((aligned(QCAP * 8))) uint2 s_queue[BLOCK / 64][QCAP];   // (aligned to its size: a ring position is one v_and away from its address)
@@ -454,14 +457,14 @@ __global__ __launch_bounds__(BLOCK, FILT == 2 ? 4 : 1) MI355_TRACE_ATTR void tra
     // (every cursor atomic of this wave has been PERFORMED before it counts itself out -- also the block reserved ahead whose answer nobody waited for: atomics
     // on different words may reach L2 in any order, and one that lands after the last wave's reset leaves a cursor at 1: the next launch skips 16 rays)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane == 0u && a.staticRays == 0u) {                     // (a static launch never touched a cursor: nothing to reset, nobody to count)
+    if (lane == 0u && !SMALL) {                                 // (a static launch never touched a cursor: nothing to reset, nobody to count)
       if (atomicAdd(a.counter + EXIT_WORD, 1u) == gridDim.x * (BLOCK / 64u) - 1u) {
         for (uint32_t c = 0; c < NUM_CURSORS; c++) atomicExch(a.counter + c * CURSOR_STRIDE, 0u);
         atomicExch(a.counter + EXIT_WORD, 0u);
       }
     }
   };
-  // a lane takes a ray: TravRay set-up (setup_rdir), the root as "the one hit child of a virtual node", its best[] / helper words
+  // a lane takes a ray (SMALL kernels, in front of the loop; the same lines as step 1d): TravRay set-up (setup_rdir), the root as "the one hit child of a virtual node", its best[] / helper words
   auto start_ray = [&](const uint32_t newIdx, const float4 r0, const float4 r1, const float4 r2) {
     rayIdx = newIdx;
     ox = r0.x; oy = r0.y; oz = r0.z; tnear = r0.w;
@@ -486,7 +489,7 @@ __global__ __launch_bounds__(BLOCK, FILT == 2 ? 4 : 1) MI355_TRACE_ATTR void tra
   // rises and the tail helpers may start), and counted itself out through a ninth -- and with 64 rays per wave half of the SIMDs' wave slots stayed empty.  Such a launch
   // is all ramp and tail, so: the host picks R = rays per wave so that the grid fills every wave slot (launch_trace_locked), wave w owns rays [w R, (w + 1) R), nobody
   // touches a cursor, and the lanes without a ray help from the first iteration on.  Same rays, same candidates, same minimum: the hit records are the bytes of a large batch.
-  if (a.staticRays != 0u) {
+  if (SMALL) {
     const uint32_t idx = blockIdx.x * (BLOCK / 64u) * a.staticRays + (tid >> 6) * a.staticRays + lane;
     if (lane < a.staticRays && idx < rayCount) {
       const float4* rp = (const float4*)(a.rays + (size_t)idx * a.stride);
@@ -582,7 +585,21 @@ __global__ __launch_bounds__(BLOCK, FILT == 2 ? 4 : 1) MI355_TRACE_ATTR void tra
             }
           }
           // (d) start the new rays
-          if (got) start_ray(newIdx, r0, r1, r2);
+          if (got) {
+            rayIdx = newIdx;
+            ox = r0.x; oy = r0.y; oz = r0.z; tnear = r0.w;
+            dx = r1.x; dy = r1.y; dz = r1.z;
+            tfar = r2.x; tfar0 = r2.x; rmask = __float_as_uint(r2.y);
+            setup_rdir<ROBUST>(dx, dy, dz, rdx, rdy, rdz, rfx, rfy, rfz, octinv4);
+            tnearTrav = fmaxf(tnear, 0.0f);                               // tnear/tfar clamped to >= 0 for traversal (bvh_intersector1.cpp:65)
+            if (INST) { inst = NO_INST; bestInst = NO_INST; }
+            sp = 0; ngBase = 0; ngHits = 0x80000000u; tgBase = 0; tgHits = 0;   // "the root is the one hit child of a virtual node"
+            lastTicket = qHead; travDone = false;
+            best[lane] = ((unsigned long long)__float_as_uint(tfar) << 32) | 0xFFFFFFFFull;
+            pend[lane] = 0u; lastT[lane] = qHead;
+            active = a.hasRoot != 0u && !(ANY && tfar < 0.0f);            // empty scene / already occluded (bvh_intersector1.cpp:128)
+            if (STATS) stRays++;
+          }
           more = canGrab && !exhausted;                                   // more free lanes than one block (launch start, small G)
         }
         if (STATS) stRefillClk += __builtin_readcyclecounter() - stT0;
@@ -597,8 +614,11 @@ __global__ __launch_bounds__(BLOCK, FILT == 2 ? 4 : 1) MI355_TRACE_ATTR void tra
     // owner's own (ring pairs carry the owner, the testers fetch the ray from the owner's registers), the owner retires when its own
     // traversal is done, pend[owner] == 0 and the ring has passed the last ticket any of its helpers drew.  The result is the same
     // minimum over all accepted candidates; only the order in which sub-trees are visited changes.
-    if (exhausted && a.helpers) {
-      const unsigned long long freeM = __ballot(!active);
+    // (round 6, experiment: a.helpers = k > 1 lets lanes that WAIT for a hand-out block -- 6 % of the lane-iterations of a 2^20-ray launch, 18 - 22 % of a small one -- help
+    // before the cursors are dry, once k of them are free; MI355_TRACE_HELPERS=k)
+    if (a.helpers && (exhausted || a.helpers > 1u)) {
+      const unsigned long long freeM0 = __ballot(!active);
+      const unsigned long long freeM = (exhausted || (uint32_t)__popcll(freeM0) >= a.helpers) ? freeM0 : 0ull;
       // INST: only sub-trees INSIDE an instance are given away (entries above the depth at which the donor entered it): the helper copies the donor's
       // object-space ray and never changes space; the donor stays in the instance until its helpers are done (step 2)
       const bool canGive = active && !travDone && sp > (INST ? topSp : 0u) && sp <= (uint32_t)QSTACK_LDS && !(ANY && (uint32_t)best[owner] != MI355_EMPTY_REF) && (!INST || inst != NO_INST);
@@ -1200,9 +1220,13 @@ static uint32_t env_u32(const char* name, uint32_t def, uint32_t lo, uint32_t hi
   const char* e = getenv(name); if (!e) return def;
   const long v = atol(e); return v < (long)lo || v > (long)hi ? def : (uint32_t)v;
 }
-template <bool INST, int FILT> static TraceFn pick_kernel_if(bool any, bool robust) {
-  if (robust) return any ? trace_kernel_q<true, false, true, INST, FILT> : trace_kernel_q<false, false, true, INST, FILT>;
-  return any ? trace_kernel_q<true, false, false, INST, FILT> : trace_kernel_q<false, false, false, INST, FILT>;
+template <bool INST, int FILT, bool SMALL = false> static TraceFn pick_kernel_if(bool any, bool robust) {
+  if (robust) return any ? trace_kernel_q<true, false, true, INST, FILT, SMALL> : trace_kernel_q<false, false, true, INST, FILT, SMALL>;
+  return any ? trace_kernel_q<true, false, false, INST, FILT, SMALL> : trace_kernel_q<false, false, false, INST, FILT, SMALL>;
+}
+static TraceFn pick_small_kernel(bool any, bool robust, bool inst, bool filt) {      // the static launch shape (no filter function, no counting build)
+  if (inst) return filt ? pick_kernel_if<true, true, true>(any, robust) : pick_kernel_if<true, false, true>(any, robust);
+  return filt ? pick_kernel_if<false, true, true>(any, robust) : pick_kernel_if<false, false, true>(any, robust);
 }
 template <bool INST> static TraceFn pick_stats_i(bool any, bool robust) {            // the counting build always knows the rules (it is not the measured path)
   if (robust) return any ? trace_kernel_q<true, true, true, INST, true> : trace_kernel_q<false, true, true, INST, true>;
@@ -1243,7 +1267,7 @@ static int launch_trace_locked(Bvh* b, TraceScratch* sc, void* d_rays, uint32_t 
   if (stride < (any ? 48u : 96u) || (stride & 15u) || ((uintptr_t)d_rays & 15u)) return set_error(hipErrorInvalidValue, "ray array must be 16-byte aligned with a 16-byte-multiple stride");
   if (count > 0xFFF00000u) return set_error(hipErrorInvalidValue, "more than 0xFFF00000 rays in one launch (the hand-out arithmetic is 32-bit)");
   HIP_TRY(hipSetDevice(b->device));
-  const TraceFn fn = pick_kernel(any, statsOut != nullptr, b->robust, b->d_insts != nullptr, b->d_rules != nullptr, fc && fc->fn != 0ull);
+  TraceFn fn = pick_kernel(any, statsOut != nullptr, b->robust, b->d_insts != nullptr, b->d_rules != nullptr, fc && fc->fn != 0ull);
   const uint32_t maxBlocks = resident_blocks(b, fn);
   uint32_t blocks = (count + BLOCK - 1) / BLOCK;
   if (blocks > maxBlocks) blocks = maxBlocks;
@@ -1256,7 +1280,7 @@ static int launch_trace_locked(Bvh* b, TraceScratch* sc, void* d_rays, uint32_t 
   static const uint32_t staticEnv = env_u32("MI355_STATIC_RAYS", 1, 0, 64);
   static const uint32_t smallFrac8 = env_u32("MI355_SMALL_FRAC8", 8, 1, 8);       // A/B: a batch with fewer rays than lane slots runs on this many eighths of the waves it could fill (the rest is refill)
   uint32_t staticRays = 0u;
-  if (!deferList && !statsOut && BLOCK == 64 && (uint64_t)count <= (uint64_t)maxBlocks * 64u) {
+  if (!deferList && !statsOut && !(fc && fc->fn) && BLOCK == 64 && (uint64_t)count <= (uint64_t)maxBlocks * 64u) {
     if (staticEnv == 1u) {
       uint32_t R = 16u; while (R < 64u && (uint64_t)(maxBlocks / 2u) * R < count) R <<= 1;
       if ((uint64_t)(maxBlocks / 2u) * R >= count && R < 64u) staticRays = R;
@@ -1270,6 +1294,7 @@ static int launch_trace_locked(Bvh* b, TraceScratch* sc, void* d_rays, uint32_t 
   a.counter = sc->counter; a.spill = (uint2*)sc->spill; a.spillPerLane = trace_spill_per_lane(b->info.depth); a.stats = nullptr;
   a.filterFn = fc ? fc->fn : 0ull; a.filterCtx = fc ? fc->ctx : nullptr; a.filterEnforce = fc ? fc->enforce : 0u;
   a.staticRays = staticRays;
+  if (staticRays) fn = pick_small_kernel(any, b->robust, b->d_insts != nullptr, b->d_rules != nullptr);   // (the SMALL instantiation: same code, rays started in front of the loop)
   static const uint32_t refillMin = env_u32("MI355_REFILL_MIN", REFILL_MIN_DEFAULT, 1, 64);
   static const uint32_t pushRounds = env_u32("MI355_PUSH_ROUNDS", PUSH_ROUNDS_DEFAULT, 1, 24);
   static const uint32_t numCursors = env_u32("MI355_NUM_CURSORS", NUM_CURSORS, 1, NUM_CURSORS);
@@ -1287,7 +1312,7 @@ static int launch_trace_locked(Bvh* b, TraceScratch* sc, void* d_rays, uint32_t 
   a.refillMin = 1u << a.gShift; a.numCursors = 1u << a.cShift; a.pushRounds = pushRounds; a.drainWaiters = drainWaiters;
   { const char* e = getenv("MI355_TRACE_ITER_CAP"); const long v = e ? atol(e) : 0; a.iterCap = v > 0 && v < (long)ITER_CAP ? (uint32_t)v : ITER_CAP; }
   a.status = sc->statusDev;
-  { const char* e = getenv("MI355_TRACE_HELPERS"); a.helpers = e && atoi(e) == 0 ? 0u : 1u; }   // tail helpers (step 1b) on unless MI355_TRACE_HELPERS=0
+  { const char* e = getenv("MI355_TRACE_HELPERS"); a.helpers = e ? (uint32_t)atoi(e) : 1u; if (a.helpers > 64u) a.helpers = 1u; }   // tail helpers (step 1b) on unless MI355_TRACE_HELPERS=0
   a.touch = nullptr; a.touchTriWord = 0u;
   if (statsOut) {
     HIP_TRY(hipMemsetAsync(sc->stats, 0, 32 * sizeof(uint64_t), s));

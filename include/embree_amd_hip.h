@@ -47,7 +47,7 @@ typedef struct mi355_build_params {
   uint32_t sah_block_shift;  /* SAH cost counts ceil(n / 2^shift) leaf blocks; reference: 2 (Triangle4).  default 0 */
   uint32_t min_leaf;         /* never split sets of <= min_leaf triangles; reference: 4.            default 2, max 3 */
   uint32_t max_leaf;         /* largest leaf slot; reference: 28 (7 Triangle4 blocks); encoding limit 3.  default 3 */
-  uint32_t small_threshold;  /* sub-trees of <= this many triangles are finished by one wavefront in LDS.   default 1024 */
+  uint32_t small_threshold;  /* sub-trees of <= this many triangles are finished by one wavefront in LDS.   default 512 (1024 until round 6) */
   float    trav_cost;        /* reference travCost = 1 */
   float    int_cost;         /* reference intCost  = 1 */
   uint32_t robust;           /* RTC_SCENE_FLAG_ROBUST (kernels/common/scene.cpp:180-188): leaves keep v0,v1,v2; traversal uses the
@@ -228,6 +228,10 @@ MI355_API int  mi355_pack_hits_inst(const void* d_rayhit, uint32_t count, size_t
    is ordered behind the traversal of its batch while the next batch is traced (bench.py) */
 MI355_API int  mi355_stream_wait_event(void* stream, void* event);
 MI355_API int  mi355_stream_query(void* stream);
+/* The radix sort of the RTC_BUILD_QUALITY_LOW (Morton) build on its own -- the reference's counterpart is radix_sort_u32, kernels/builders/bvh_builder_morton.h:439
+   (common/algorithms/parallel_sort.h).  n 63-bit keys in device memory (bit 63 clear) -> d_keys_sorted (n x uint64) and d_index_sorted (n x uint32: where each came from);
+   equal keys keep their order (stable).  *ms (optional): time of the seven passes.  Blocking; the source array is not written. */
+MI355_API int  mi355_sort_keys63(int device, const void* d_keys, void* d_keys_sorted, void* d_index_sorted, uint32_t n, float* ms);
 /* What a streaming kernel reaches on this GPU (the achievable figure beside the 8 TB/s vendor peak): out[0] = device-to-device copy,
    bytes read + written per second; out[1] = read only; GB/s, best of `reps` passes over `bytes` (use >= 1 GiB: the Infinity Cache holds 256 MB). Blocking. */
 MI355_API int  mi355_measure_bandwidth(int device, size_t bytes, int reps, double out[2]);             /* hipStreamQuery: 0 = idle, 1 = work pending, < 0 = error */

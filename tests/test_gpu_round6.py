@@ -221,7 +221,9 @@ def test_user_data_change_reaches_the_device_filter_function(api, ref):
         return int(c[0]), int(c[2])
     calls_a, sum_a = run(0x1000)
     calls_b, sum_b = run(0x2000)
-    assert calls_a > 0 and calls_a == calls_b
+    # (the NUMBER of calls is not a constant of the query: a candidate reaches the function only if it is nearer than what its ray has so far, and the order in which a ray's
+    # candidates arrive depends on which wave helped -- 1388 against 1389 calls in one run of round 6; what must hold is that EVERY call saw the pointer of its commit)
+    assert calls_a > 0 and abs(calls_a - calls_b) <= max(4, calls_a // 100)
     assert sum_a == calls_a * 0x1000 and sum_b == calls_b * 0x2000, "the device filter function still sees the old user pointer: %x / %d calls" % (sum_b, calls_b)
     counters.free()
     s.release()
@@ -322,14 +324,18 @@ def test_coherent_flag_on_an_alternating_stream_with_and_without_its_memory(api)
         for flagged in (False, True):
             qa = api.QueryArguments(None, api.RTC_RAY_QUERY_FLAG_COHERENT if flagged else 0)
             for order in ("pbpbpbpbpbpb", "bbbbpbbbbpbbbbp", "pppbpppbpppb"):
-                L.mi355_synchronize(st)
-                t0 = time.perf_counter()
-                for ch in order:
-                    src, dst, n = (dp, wp, prim) if ch == "p" else (db, wb, bounce)
-                    L.mi355_memcpy_d2d_async(dst.ptr, src.ptr, n.nbytes, st)
-                    s.intersect1M_device(dst.ptr, n.shape[0], stream=st, args=qa)
-                L.mi355_synchronize(st)
-                out[(cfg, flagged, order)] = (time.perf_counter() - t0) * 1e3
+                best = None
+                for rep in range(3):                                  # (wall clock on a shared host: one run of round 6 had a lone 6.25 ms among 2.2 ms -- the best of three is the stream's cost)
+                    L.mi355_synchronize(st)
+                    t0 = time.perf_counter()
+                    for ch in order:
+                        src, dst, n = (dp, wp, prim) if ch == "p" else (db, wb, bounce)
+                        L.mi355_memcpy_d2d_async(dst.ptr, src.ptr, n.nbytes, st)
+                        s.intersect1M_device(dst.ptr, n.shape[0], stream=st, args=qa)
+                    L.mi355_synchronize(st)
+                    dt = (time.perf_counter() - t0) * 1e3
+                    best = dt if best is None else min(best, dt)
+                out[(cfg, flagged, order)] = best
                 assert s.trace_status(st) == 0
                 rp, rb = wp.download(RAYHIT_DTYPE), wb.download(RAYHIT_DTYPE)
                 if want_p is None:
@@ -343,3 +349,48 @@ def test_coherent_flag_on_an_alternating_stream_with_and_without_its_memory(api)
     for (cfg, flagged, order), v in out.items():
         if flagged:
             assert v <= 2.0 * out[(cfg, False, order)] + 0.5, "flagged stream %s (%s): %.2f ms against %.2f ms unflagged" % (order, cfg, v, out[(cfg, False, order)])
+
+
+# ------------------------------------------------------------------------------------------- the sort of the Morton build is this repository's own
+@pytest.mark.parametrize("case", ["random", "few_values", "sorted", "reversed", "one_bit", "all_equal"])
+@pytest.mark.parametrize("n", [1, 2, 63, 4095, 4096, 4097, 12289, 1000003])
+def test_radix_sort_of_the_morton_build_vs_stable_argsort(api, case, n):
+    """RTC_BUILD_QUALITY_LOW sorted its Morton codes with hipcub::DeviceRadixSort until round 6; the reference has its own radix sort
+    (kernels/builders/bvh_builder_morton.h:439).  build_sort.inl: 7 passes of 9 bits, one kernel per pass with a look-back at the tiles in front.  The sort on its own
+    (mi355_sort_keys63) against numpy's stable argsort: keys in order, equal keys in index order, every index exactly once -- sizes around the tile size of 4096, digit
+    patterns that put all keys of a tile into one bucket, into two, into all."""
+    L = api.load()
+    rng = np.random.default_rng(n * 7 + len(case))
+    if case == "random":
+        keys = rng.integers(0, 1 << 63, n, dtype=np.uint64)
+    elif case == "few_values":
+        keys = rng.choice(rng.integers(0, 1 << 63, 5, dtype=np.uint64), n)
+    elif case == "sorted":
+        keys = np.sort(rng.integers(0, 1 << 63, n, dtype=np.uint64))
+    elif case == "reversed":
+        keys = np.sort(rng.integers(0, 1 << 63, n, dtype=np.uint64))[::-1].copy()
+    elif case == "one_bit":
+        keys = (rng.integers(0, 2, n, dtype=np.uint64) << np.uint64(int(rng.integers(0, 63))))
+    else:
+        keys = np.full(n, 0x1234567890ABCDEF & ((1 << 63) - 1), np.uint64)
+    dk = api.DeviceArray.from_numpy(keys)
+    ok, oi = api.DeviceArray(n * 8), api.DeviceArray(n * 4)
+    ms = C.c_float()
+    assert L.mi355_sort_keys63(0, dk.ptr, ok.ptr, oi.ptr, n, C.byref(ms)) == 0, L.mi355_last_error().decode()
+    got_k, got_i = ok.download(np.uint64), oi.download(np.uint32)
+    want_i = np.argsort(keys, kind="stable").astype(np.uint32)
+    assert np.array_equal(got_i, want_i), "order differs from a stable sort at place %d" % int(np.nonzero(got_i != want_i)[0][0])
+    assert np.array_equal(got_k, keys[want_i])
+    assert np.array_equal(dk.download(np.uint64), keys), "the source array was written"
+    if n >= 1000000:
+        print("radix sort of %d keys (%s): %.3f ms" % (n, case, ms.value))
+    for a_ in (dk, ok, oi):
+        a_.free()
+
+
+def test_low_quality_build_has_no_library_kernel():
+    """the Morton build's translation unit no longer includes hipcub / rocprim: every kernel of every commit is this repository's"""
+    src = os.path.join(ROOT, "embree_amd", "csrc")
+    for f in os.listdir(src):
+        code = "\n".join(line.split("//")[0] for line in open(os.path.join(src, f)).read().split("\n"))     # (comments may name what was replaced)
+        assert "#include <hipcub" not in code and "#include <rocprim" not in code and "hipcub::" not in code and "rocprim::" not in code, f

@@ -8,7 +8,7 @@ T=${1:-r03}
 R=$PWD
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${T}_prof -o ${T} -- python $R/bench.py --no-cpu --sustain 0 > $R/gpurun_out/${T}_prof_bench.json 2> $R/gpurun_out/${T}_prof_bench.err )
 python tools/kstats.py gpurun_out/${T}_prof > gpurun_out/${T}_kstats.md 2>&1
-tools/pmc_run.sh gpurun_out/${T}_pmc python $R/bench.py --steps 8 --warmup 2 --no-cpu --sustain 0 --inprocess-gpus 1 --streams 1 --pipeline-streams 0 > gpurun_out/${T}_pmc.log 2>&1
+tools/pmc_run.sh gpurun_out/${T}_pmc python $R/bench.py --steps 8 --warmup 2 --spin-up 0.05 --no-cpu --sustain 0 --inprocess-gpus 1 --streams 1 --pipeline-streams 0 > gpurun_out/${T}_pmc.log 2>&1
 rm -f gpurun_out/${T}_pmc_trace.md
-python tools/pmc_summary.py gpurun_out/${T}_pmc "trace_kernel_q<false, false, false, false, 0>" gpurun_out/${T}_pmc_trace > gpurun_out/${T}_pmc_summary.log 2>&1
+python tools/pmc_summary.py gpurun_out/${T}_pmc "trace_kernel_q<false, false, false, false, 0, false>" gpurun_out/${T}_pmc_trace > gpurun_out/${T}_pmc_summary.log 2>&1
 tail -5 gpurun_out/${T}_pmc_summary.log

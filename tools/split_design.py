@@ -8,19 +8,34 @@ import textwrap
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def wrap(text, width=160):
-    out, fence = [], False
+def wrap(text, width=150):
+    """paragraphs are re-flowed: a paragraph is a prose or list-item line and the lines that continue it (not blank, not a table row, heading, fence or new list item)"""
+    item = re.compile(r"^(\s*)((?:[-*]|\d+\.)\s+)")
+    special = lambda l: (not l.strip()) or l.startswith("|") or l.startswith("#") or l.startswith("```") or l.lstrip().startswith("|")
+    out, fence, block = [], False, None
+
+    def flush():
+        nonlocal block
+        if block is None:
+            return
+        indent, marker, words = block
+        body = " ".join(w.strip() for w in words)
+        out.extend(textwrap.wrap(body, width=width, initial_indent=indent + marker, subsequent_indent=indent + " " * len(marker), break_long_words=False, break_on_hyphens=False) or [indent + marker])
+        block = None
     for line in text.split("\n"):
         if line.startswith("```"):
-            fence = not fence
-        if fence or len(line) <= width or line.startswith("|") or line.startswith("#") or line.startswith("```"):
-            out.append(line)
-            continue
-        m = re.match(r"^(\s*)((?:[-*]|\d+\.)\s+)?", line)
-        indent, marker = m.group(1), m.group(2) or ""
-        body = line[len(indent) + len(marker):]
-        out.extend(textwrap.wrap(body, width=width, initial_indent=indent + marker, subsequent_indent=indent + " " * len(marker),
-                                 break_long_words=False, break_on_hyphens=False))
+            flush(); fence = not fence; out.append(line); continue
+        if fence or special(line):
+            flush(); out.append(line); continue
+        m = item.match(line)
+        if m:
+            flush(); block = (m.group(1), m.group(2), [line[m.end():]]); continue
+        if block is None:
+            ind = re.match(r"^\s*", line).group(0)
+            block = (ind, "", [line[len(ind):]])
+        else:
+            block[2].append(line)
+    flush()
     return "\n".join(out)
 
 
