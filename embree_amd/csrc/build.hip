@@ -527,7 +527,7 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
     const uint32_t blocks = (uint32_t)((bound + 7u) / 8u) < 8192u ? (uint32_t)((bound + 7u) / 8u) : 8192u;   // = the waves resident at once
     const uint32_t parity = wlevel & 1u;
     LAUNCH(wide_plan, dim3(blocks), dim3(64), 0, st, wc, bnodes.p, plans.p, itemCnt.p, groupSum.p, ctr.p, prm, parity);
-    LAUNCH(wide_scan, dim3(1), dim3(1024), 0, st, groupSum.p, ctr.p, parity, maxWide);
+    LAUNCH(wide_scan, dim3(1), dim3(1024), 0, st, groupSum.p, ctr.p, parity, maxWide, blocks);
     LAUNCH(wide_emit, dim3(blocks), dim3(64), 0, st, wc, bnodes.p, plans.p, itemCnt.p, groupSum.p, wnodes.p, finalIds.p, outIds.p, wn, ctr.p, parity);
     WideItem* t = wc; wc = wn; wn = t; wlevel++;
   };

@@ -19,7 +19,10 @@
 //   * the tile is put in order in LDS first and written out from there: a thread writes key j of the sorted tile, neighbours write neighbours (runs of one
 //     digit are contiguous in the output), instead of 4096 scattered 12-byte stores.
 // Payloads of the first pass are the indices themselves (never read).  Deterministic: where a key lands depends on the keys alone.
-constexpr uint32_t RS_BITS = 9u, RS_RADIX = 1u << RS_BITS, RS_PASSES = 7u, RS_THREADS = 512u, RS_KPT = 8u, RS_TILE = RS_THREADS * RS_KPT, RS_WAVES = RS_THREADS / 64u;
+#ifndef MI355_RS_KPT
+#define MI355_RS_KPT 8                      /* keys per thread: a tile is 512 x this many keys (A/B: tools/build_variant.sh) */
+#endif
+constexpr uint32_t RS_BITS = 9u, RS_RADIX = 1u << RS_BITS, RS_PASSES = 7u, RS_THREADS = 512u, RS_KPT = MI355_RS_KPT, RS_TILE = RS_THREADS * RS_KPT, RS_WAVES = RS_THREADS / 64u;
 constexpr uint32_t RS_AGG = 1u, RS_PREFIX = 2u;                 // flags of a published word (0 = nothing yet): this tile's count / the count of this tile and all before it
 constexpr uint32_t RS_HIST_WORDS = RS_PASSES * RS_RADIX + 8u;   // the seven digit histograms + the tile tickets of the passes (one memset)
 static_assert(RS_THREADS == RS_RADIX, "one thread per digit");
@@ -120,6 +123,10 @@ __global__ __launch_bounds__(RS_THREADS) void radix_pass(const unsigned long lon
   const unsigned long long tag = (unsigned long long)(pass + 1u) << 32;
   unsigned long long* const mine = status + (size_t)tile * RS_RADIX + tid;
   uint32_t excl = 0u;
+#ifdef MI355_RS_SKIP_LOOKBACK                                   /* (timing experiment: wrong places, no waiting) */
+  if (true) excl = tile * cnt;
+  else
+#endif
   if (tile == 0u) rs_publish(mine, tag | ((unsigned long long)RS_PREFIX << 30) | cnt);
   else {
     rs_publish(mine, tag | ((unsigned long long)RS_AGG << 30) | cnt);
@@ -153,7 +160,10 @@ __global__ __launch_bounds__(RS_THREADS) void radix_pass(const unsigned long lon
     if (j < nv) {
       const unsigned long long kk = s_keys[j];
       const uint32_t dst = s_off[rs_digit(kk, pass)] + j;
-      keysOut[dst] = kk; valsOut[dst] = s_vals[j];
+#ifdef MI355_RS_SKIP_WRITE                                      /* (timing experiment) */
+      if (dst == 0xFFFFFFFFu)
+#endif
+      { keysOut[dst] = kk; valsOut[dst] = s_vals[j]; }
     }
   }
 }

@@ -73,14 +73,21 @@ __device__ __forceinline__ BNode load_bnode(const BNode* p) {
   r.left = c.x; r.right = c.y; r.splitSah = __uint_as_float(c.z); r.pad = 0; return r;
 }
 
+// items per workgroup of wide_plan / wide_emit: a multiple of eight (a wavefront takes eight items at a time), the same for both kernels of a level
+__device__ __forceinline__ uint32_t wide_span(uint32_t numItems, uint32_t blocks) { return ((numItems + blocks * 8u - 1u) / (blocks * 8u)) * 8u; }
+
 __global__ __launch_bounds__(64) void wide_plan(const WideItem* items, const BNode* bnodes, WidePlan* plans, uint2* itemCnt, uint2* groupSum,
                                                 Counters* ctr, Params prm, uint32_t parity) {
   const uint32_t numItems = ctr->wideCount[parity];
   const float rootArea = ctr->rootArea;
   const uint32_t lane = threadIdx.x, c = lane & 7u, g = lane >> 3;
   unsigned long long sahAcc = 0ull; uint32_t leafAcc = 0u;      // per-wave partial sums: one atomic per wave at the end (a same-address atomic costs ~2 ns)
-  for (uint32_t base = blockIdx.x * 8u; base < numItems; base += gridDim.x * 8u) {
-    const uint32_t t = base + g; const bool valid = t < numItems;
+  // (round 6) A workgroup owns a CONTIGUOUS run of `per` items (wide_span): it carries the running counts of its run itself and hands wide_scan ONE pair -- the scan is over
+  // <= 8192 workgroups instead of one pair per eight items (37 k for the crown's widest level: 56 us in one workgroup).  Same sums in the same item order: same numbering.
+  const uint32_t per = wide_span(numItems, gridDim.x), first = blockIdx.x * per, end = min(first + per, numItems);
+  uint32_t runI = 0u, runT = 0u;                                // (wave-uniform) inner children / leaf triangles of this workgroup's items so far
+  for (uint32_t base = first; base < end; base += 8u) {
+    const uint32_t t = base + g; const bool valid = t < end;
     WideItem it; it.bnode = 0; it.node = 0; if (valid) it = items[t];
     const BNode root = load_bnode(bnodes + it.bnode);
     // ---- children: lane c holds child c
@@ -149,21 +156,20 @@ __global__ __launch_bounds__(64) void wide_plan(const WideItem* items, const BNo
     const uint32_t ci = valid ? nInner : 0u, ct = valid ? nTri : 0u;          // every lane of a group holds the same pair
     uint32_t xi = ci, xt = ct;
     for (int o = 8; o < 64; o <<= 1) { const uint32_t ui = (uint32_t)__shfl_up((int)xi, o, 64), ut = (uint32_t)__shfl_up((int)xt, o, 64); if (lane >= (uint32_t)o) { xi += ui; xt += ut; } }
-    if (valid && c == 0u) itemCnt[t] = make_uint2(xi - ci, xt - ct);
-    const uint32_t ti = (uint32_t)__shfl((int)xi, 63, 64), tt = (uint32_t)__shfl((int)xt, 63, 64);
-    if (lane == 0u) groupSum[base >> 3] = make_uint2(ti, tt);
+    if (valid && c == 0u) itemCnt[t] = make_uint2(runI + xi - ci, runT + xt - ct);
+    runI += (uint32_t)__builtin_amdgcn_readlane((int)xi, 63); runT += (uint32_t)__builtin_amdgcn_readlane((int)xt, 63);
     leafAcc += (uint32_t)__popcll(__ballot(valid && sHas && sLeaf));
   }
+  if (lane == 0u) groupSum[blockIdx.x] = make_uint2(runI, runT);   // (every workgroup of the grid: wide_scan reads all of them)
   for (int o = 8; o < 64; o <<= 1) sahAcc += (unsigned long long)__shfl_xor((long long)sahAcc, o, 64);   // lanes with c == 0 hold the partial sums
   if (lane == 0u) { if (sahAcc) atomicAdd(&ctr->sahFixed, sahAcc); if (leafAcc) atomicAdd(&ctr->numLeaves, leafAcc); }
 }
 
-// one block: exclusive scan of the per-wave totals in item order; publishes the level's bases and the next level's item count
-__global__ __launch_bounds__(1024) void wide_scan(uint2* groupSum, Counters* ctr, uint32_t parity, uint32_t maxNodes) {
+// one block: exclusive scan of the workgroups' totals in workgroup (= item) order; publishes the level's bases and the next level's item count
+__global__ __launch_bounds__(1024) void wide_scan(uint2* groupSum, Counters* ctr, uint32_t parity, uint32_t maxNodes, uint32_t numGroups) {
   __shared__ uint2 s_part[17];
-  const uint32_t numItems = ctr->wideCount[parity], numGroups = (numItems + 7u) / 8u;
-  // every thread owns a run of `per` consecutive groups (a multiple of 8: four 16-byte loads in flight per step -- one load per step and thread made the
-  // two passes of the widest level 37 dependent L2 round trips each, 91 us)
+  const uint32_t numItems = ctr->wideCount[parity];
+  // every thread owns a run of `per` consecutive workgroups (a multiple of 8: four 16-byte loads in flight per step)
   const uint32_t tid = threadIdx.x, per = ((numGroups + 1023u) / 1024u + 7u) & ~7u, b = min(tid * per, numGroups), e = min(b + per, numGroups);
   uint2 sum = make_uint2(0, 0);
   for (uint32_t i = b; i < e; i += 8u) {
@@ -238,12 +244,14 @@ __global__ __launch_bounds__(64) void wide_emit(const WideItem* items, const BNo
   if (ctr->overflow) return;
   const uint32_t nodeBase = ctr->lvlNodeBase, triLvl = ctr->lvlTriBase;
   const uint32_t lane = threadIdx.x, s = lane & 7u, g = lane >> 3;
-  for (uint32_t base = blockIdx.x * 8u; base < numItems; base += gridDim.x * 8u) {
-    const uint32_t t = base + g; const bool valid = t < numItems;
+  const uint32_t per = wide_span(numItems, gridDim.x), first = blockIdx.x * per, end = min(first + per, numItems);   // the run wide_plan gave this workgroup
+  const uint2 mine = groupSum[blockIdx.x];                     // what the workgroups before this one counted (wide_scan)
+  for (uint32_t base = first; base < end; base += 8u) {
+    const uint32_t t = base + g; const bool valid = t < end;
     uint32_t ch = NIL, imask = 0, leafMask = 0, node = 0; uint2 ofs = make_uint2(0, 0);
     if (valid) {
       ch = plans[t].ch[s]; imask = plans[t].imask; leafMask = plans[t].leafMask; node = items[t].node;
-      const uint2 a = groupSum[base >> 3], b = itemCnt[t]; ofs = make_uint2(a.x + b.x, a.y + b.y);
+      const uint2 b = itemCnt[t]; ofs = make_uint2(mine.x + b.x, mine.y + b.y);
     }
     const bool has = ch != NIL, inner = ((imask >> s) & 1u) != 0u, leaf = ((leafMask >> s) & 1u) != 0u;
     BNode cb{}; if (has) cb = load_bnode(bnodes + ch);

@@ -614,11 +614,8 @@ __global__ __launch_bounds__(BLOCK, FILT == 2 ? 4 : 1) MI355_TRACE_ATTR void tra
     // owner's own (ring pairs carry the owner, the testers fetch the ray from the owner's registers), the owner retires when its own
     // traversal is done, pend[owner] == 0 and the ring has passed the last ticket any of its helpers drew.  The result is the same
     // minimum over all accepted candidates; only the order in which sub-trees are visited changes.
-    // (round 6, experiment: a.helpers = k > 1 lets lanes that WAIT for a hand-out block -- 6 % of the lane-iterations of a 2^20-ray launch, 18 - 22 % of a small one -- help
-    // before the cursors are dry, once k of them are free; MI355_TRACE_HELPERS=k)
-    if (a.helpers && (exhausted || a.helpers > 1u)) {
-      const unsigned long long freeM0 = __ballot(!active);
-      const unsigned long long freeM = (exhausted || (uint32_t)__popcll(freeM0) >= a.helpers) ? freeM0 : 0ull;
+    if (exhausted && a.helpers) {
+      const unsigned long long freeM = __ballot(!active);
       // INST: only sub-trees INSIDE an instance are given away (entries above the depth at which the donor entered it): the helper copies the donor's
       // object-space ray and never changes space; the donor stays in the instance until its helpers are done (step 2)
       const bool canGive = active && !travDone && sp > (INST ? topSp : 0u) && sp <= (uint32_t)QSTACK_LDS && !(ANY && (uint32_t)best[owner] != MI355_EMPTY_REF) && (!INST || inst != NO_INST);
@@ -1312,7 +1309,7 @@ static int launch_trace_locked(Bvh* b, TraceScratch* sc, void* d_rays, uint32_t 
   a.refillMin = 1u << a.gShift; a.numCursors = 1u << a.cShift; a.pushRounds = pushRounds; a.drainWaiters = drainWaiters;
   { const char* e = getenv("MI355_TRACE_ITER_CAP"); const long v = e ? atol(e) : 0; a.iterCap = v > 0 && v < (long)ITER_CAP ? (uint32_t)v : ITER_CAP; }
   a.status = sc->statusDev;
-  { const char* e = getenv("MI355_TRACE_HELPERS"); a.helpers = e ? (uint32_t)atoi(e) : 1u; if (a.helpers > 64u) a.helpers = 1u; }   // tail helpers (step 1b) on unless MI355_TRACE_HELPERS=0
+  { const char* e = getenv("MI355_TRACE_HELPERS"); a.helpers = e && atoi(e) == 0 ? 0u : 1u; }   // tail helpers (step 1b) on unless MI355_TRACE_HELPERS=0
   a.touch = nullptr; a.touchTriWord = 0u;
   if (statsOut) {
     HIP_TRY(hipMemsetAsync(sc->stats, 0, 32 * sizeof(uint64_t), s));
