@@ -97,10 +97,35 @@ __device__ __forceinline__ void bins_clear_copies(uint32_t* bins, uint32_t tid, 
     for (uint32_t c = 0; c < BIN_COPIES; c++) bins[c * COPY_STRIDE + w] = v;
   }
 }
+// (round 6) PAIRS first: lanes 2k and 2k + 1 hold consecutive references, which share a bin more often than not -- then the odd lane bins the union of the two boxes
+// with a count of 2 and the even lane stays out (one quad_perm exchange of the six box words for all three axes, one of the bin index per axis).  The two lanes of a
+// pair work on the SAME copy (copy = lane / 2 mod BIN_COPIES), so what is left to meet on a word are lanes 16 references apart, four per copy instead of eight: the
+// same-word lanes of an atomic instruction are what top_bin waits for (~3 cycles each, profiles/r03_lds_atomics.md).  min / max / add: the bins do not change by a bit.
+// EVERY lane of the wave calls it (valid = holds a reference): the exchange reads the neighbour's registers.
+#ifndef MI355_BIN_PAIRS
+#define MI355_BIN_PAIRS 1
+#endif
 __device__ __forceinline__ void bins_add_copies(uint32_t* bins, const Mapping& m, const PrimRef& p, bool valid, uint32_t lane) {
-  if (!valid) return;
   uint32_t c[6];
   for (int k = 0; k < 3; k++) { c[k] = enc(p.lo[k]); c[3 + k] = enc(p.hi[k]); }
+#if MI355_BIN_PAIRS
+  uint32_t u[6];                                                // the pair's box
+  for (int k = 0; k < 3; k++) { u[k] = min(c[k], dpp_u<0xB1, 0xF>(c[k], c[k])); u[3 + k] = max(c[3 + k], dpp_u<0xB1, 0xF>(c[3 + k], c[3 + k])); }
+  const bool odd = (lane & 1u) != 0u;
+  uint32_t* mine = bins + ((lane >> 1) & (BIN_COPIES - 1u)) * COPY_STRIDE;
+#pragma unroll
+  for (int d = 0; d < 3; d++) {
+    const uint32_t b = valid ? (uint32_t)bin_clamped(p.lo[d] + p.hi[d], m.ofs[d], m.scale[d], m.nb) : 0xFFFFFFFFu - lane;   // (a lane without a reference pairs with nobody)
+    const bool same = dpp_u<0xB1, 0xF>(b, b) == b;
+    if (valid && !(same && !odd)) {
+      uint32_t* e = mine + (d * NBINS + b) * BINW;
+      atomicMin(&e[0], same ? u[0] : c[0]); atomicMin(&e[1], same ? u[1] : c[1]); atomicMin(&e[2], same ? u[2] : c[2]);
+      atomicMax(&e[3], same ? u[3] : c[3]); atomicMax(&e[4], same ? u[4] : c[4]); atomicMax(&e[5], same ? u[5] : c[5]);
+      atomicAdd(&e[6], same ? 2u : 1u);
+    }
+  }
+#else
+  if (!valid) return;
   uint32_t* mine = bins + (lane & (BIN_COPIES - 1u)) * COPY_STRIDE;
 #pragma unroll
   for (int d = 0; d < 3; d++) {
@@ -110,6 +135,7 @@ __device__ __forceinline__ void bins_add_copies(uint32_t* bins, const Mapping& m
     atomicMax(&e[3], c[3]); atomicMax(&e[4], c[4]); atomicMax(&e[5], c[5]);
     atomicAdd(&e[6], 1u);
   }
+#endif
 }
 // every word of copy 0 becomes the fold of its copies (the caller puts a barrier on either side)
 __device__ __forceinline__ void bins_fold_copies(uint32_t* bins, uint32_t tid, uint32_t nthreads) {

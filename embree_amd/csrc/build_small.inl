@@ -23,7 +23,14 @@ __device__ __forceinline__ float unzhi(uint32_t u) { return dec(u); }
 
 // A sub-tree root of <= MICRO triangles, parked by the large mode until the wave has finished its larger sets
 struct MicroRoot { uint32_t begin, nbuf, bnode; float cmin[3], cmax[3]; };   // nbuf = n | buf << 8
-constexpr uint32_t MICRO_ROOTS = 32;                              // (a set of <= 1024 triangles leaves at most 31 of them)
+#ifndef MI355_SMALL_ROOTS
+#define MI355_SMALL_ROOTS 32
+#endif
+#ifndef MI355_SMALL_STACK
+#define MI355_SMALL_STACK 24
+#endif
+constexpr uint32_t MICRO_ROOTS = MI355_SMALL_ROOTS;               // (a set of <= 1024 triangles leaves at most 31 of them, one of <= 512 at most 15; the large mode flushes when the list is full)
+constexpr uint32_t SMALL_STACK = MI355_SMALL_STACK;               // (the wave goes on with the smaller child and pushes the larger: <= log2(small_threshold / 64) <= 10 entries for any threshold the host lets through)
 
 // R: per-wave LDS scratch of 64 * W words (W = 32 words per triangle when min_leaf >= 2, 48 for min_leaf = 1):
 //   the bins are seven PLANES of 64 * W / 8 words -- lo.x, lo.y, lo.z, hi.x, hi.y, hi.z, count -- and the segment that starts at lane b owns the slots
@@ -272,12 +279,15 @@ __device__ void micro_flush(uint32_t* R, unsigned long long* s_key, const MicroR
   MICRO_SYNC();
 }
 
+#ifdef MI355_SMALL_WAVES                                      /* A/B: a register budget for this many waves per SIMD (tools/build_variant.sh) */
+__attribute__((amdgpu_waves_per_eu(MI355_SMALL_WAVES, MI355_SMALL_WAVES)))
+#endif
 __global__ __launch_bounds__(64) void small_build(const SmallEntry* entries, PrimRef* bufA, PrimRef* bufB, BNode* bnodes,
                                                   uint2* finalIds, Counters* ctr, Params prm, uint32_t W) {
   extern __shared__ __attribute__((aligned(16))) uint32_t s_R[];   // max(BINS_WORDS, 64 * W) words: bins / micro scratch
   __shared__ SplitResult s_res;
   __shared__ uint32_t s_acc[2][12];
-  __shared__ StackEntry s_stack[24];
+  __shared__ StackEntry s_stack[SMALL_STACK];
   __shared__ unsigned long long s_key[64];
   __shared__ MicroRoot s_roots[MICRO_ROOTS];
   uint32_t numRoots = 0;

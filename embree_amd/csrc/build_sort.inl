@@ -107,9 +107,17 @@ __global__ __launch_bounds__(RS_THREADS) void radix_pass(const unsigned long lon
   for (uint32_t r = 0; r < RS_KPT; r++) {
     const bool valid = w * (64u * RS_KPT) + r * 64u + lane < nv;
     const uint32_t d = valid ? rs_digit(key[r], pass) : 0u;
-    unsigned long long m = __ballot(valid);
+    // the lanes that hold my digit: for every bit, the lanes whose bit equals mine = ~(ballot ^ x) with x = all ones if my bit is set (v_bfe_i32), in 32-bit halves
+    // (one three-input bit operation per half and bit; a select between ballot and ~ballot on 64-bit lane masks was six instructions per bit)
+    const unsigned long long vm = __ballot(valid);
+    uint32_t mlo = (uint32_t)vm, mhi = (uint32_t)(vm >> 32);
 #pragma unroll
-    for (uint32_t b = 0; b < RS_BITS; b++) { const bool bit = ((d >> b) & 1u) != 0u; const unsigned long long bal = __ballot(bit); m &= bit ? bal : ~bal; }
+    for (uint32_t b = 0; b < RS_BITS; b++) {
+      const uint32_t x = (uint32_t)(-(int)((d >> b) & 1u));
+      const unsigned long long bal = __ballot(x != 0u);
+      mlo &= ((uint32_t)bal ^ ~x); mhi &= ((uint32_t)(bal >> 32) ^ ~x);
+    }
+    const unsigned long long m = ((unsigned long long)mhi << 32) | mlo;
     const uint32_t before = s_whist[w][d];                        // (every lane of a group reads the same word; the group's highest lane then moves it on)
     rank[r] = before + (uint32_t)__popcll(m & lt);
     if (valid && (m >> lane) == 1ull) s_whist[w][d] = before + (uint32_t)__popcll(m);
@@ -130,12 +138,23 @@ __global__ __launch_bounds__(RS_THREADS) void radix_pass(const unsigned long lon
   if (tile == 0u) rs_publish(mine, tag | ((unsigned long long)RS_PREFIX << 30) | cnt);
   else {
     rs_publish(mine, tag | ((unsigned long long)RS_AGG << 30) | cnt);
-    for (uint32_t t = tile; t-- > 0u;) {
-      const unsigned long long* p = status + (size_t)t * RS_RADIX + tid;
-      unsigned long long v = rs_peek(p);
-      while ((uint32_t)(v >> 32) != pass + 1u) { __builtin_amdgcn_s_sleep(1); v = rs_peek(p); }   // (tile t has started -- it drew its ticket before this one -- and publishes before it waits for anybody)
-      excl += (uint32_t)v & 0x3FFFFFFFu;
-      if ((((uint32_t)v >> 30) & 3u) == RS_PREFIX) break;
+    // four tiles back at a time (their words are in flight together: a walk of one dependent load per tile was 12 us of a 60 us pass)
+    bool found = false;
+    for (uint32_t t = tile; t != 0u && !found;) {
+      const uint32_t nw = min(4u, t);
+      unsigned long long v[4];
+#pragma unroll
+      for (uint32_t i = 0; i < 4u; i++) v[i] = i < nw ? rs_peek(status + (size_t)(t - 1u - i) * RS_RADIX + tid) : 0ull;
+#pragma unroll
+      for (uint32_t i = 0; i < 4u; i++) {
+        if (i < nw && !found) {
+          const unsigned long long* p = status + (size_t)(t - 1u - i) * RS_RADIX + tid;
+          while ((uint32_t)(v[i] >> 32) != pass + 1u) { __builtin_amdgcn_s_sleep(1); v[i] = rs_peek(p); }   // (that tile has started -- it drew its ticket before this one -- and publishes before it waits for anybody)
+          excl += (uint32_t)v[i] & 0x3FFFFFFFu;
+          found = (((uint32_t)v[i] >> 30) & 3u) == RS_PREFIX;
+        }
+      }
+      t -= nw;
     }
     rs_publish(mine, tag | ((unsigned long long)RS_PREFIX << 30) | (excl + cnt));
   }

@@ -41,7 +41,11 @@ __global__ __launch_bounds__(256) void top_bin(const Seg* segs, const Chunk* chu
   {
     const uint32_t lane = tid & 63u;
 #pragma unroll 2
-    for (uint32_t i = ck.begin + tid; i < ck.end; i += 256u) bins_add_copies(s_bins, m, load_prim(src + i), true, lane);
+    for (uint32_t i0 = ck.begin; i0 < ck.end; i0 += 256u) {        // (workgroup-uniform trip count: every lane calls bins_add_copies, which exchanges registers inside pairs of lanes)
+      const uint32_t i = i0 + tid; const bool v = i < ck.end;
+      PrimRef r{}; if (v) r = load_prim(src + i);
+      bins_add_copies(s_bins, m, r, v, lane);
+    }
   }
   __syncthreads();
   bins_fold_copies(s_bins, tid, 256u);
