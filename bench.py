@@ -782,7 +782,7 @@ def main():
         e2e = dict(value=round(M / min(times) / 1e6, 1), unit="Mrays/s", ms=round(1e3 * min(times), 3),
                    link_floor_ms=round(link[2], 3) if link_ok else None, frac_of_link_floor=round(link[2] / (1e3 * min(times)), 3) if link_ok else None,
                    link_GBs={"upload": round(link[0], 1), "download": round(link[1], 1)} if link_ok else None,
-                   what="rtcIntersect1M on a pageable host array of %d RTCRayHit: pin + H2D (96 MB) + kernel + D2H (96 MB), pipelined in chunks; best of 3.  link_floor_ms = the same bytes "
+                   what="rtcIntersect1M on a pageable host array of %d RTCRayHit: CPU copy into the library's pinned staging + H2D (96 MB) + kernel + D2H (96 MB) + CPU copy out, pipelined in chunks; best of 3 (round 6: the GPU never maps the caller's pages -- profiles/r06_host_memory_fault.md; the device config host_register=1 restores round 5's registration of the caller's array: 2.9 ms instead of 3.8 - 4.2 on a quiet box).  link_floor_ms = the same bytes "
                         "up from and down to PINNED host memory, both directions at once and nothing else (mi355_measure_host_link): what the host link allows" % M)
     latency = None
     if not shadow and rank == 0:                           # the per-ray entry points are "not the measured path and the report must say so": what one call costs
@@ -909,18 +909,27 @@ def main():
         if roof["frac"] is None:                              # no counters for this build of the kernel: the only live figure is the algorithmic one -- say so instead of leaving the field empty
             roof.update({"bound": "hbm", "achieved": hbm_alg["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_alg["frac"],
                          "frac_is": "NO PMC profile for this kernel source (%s): this is SURVEY 8(d)'s algorithmic-bytes figure against the HBM peak -- cache-served bytes, not the binding resource "
-                                    "(VALU issue: ~0.76 of the region in round 5's profile)" % (pmc_note or "none")})
+                                    "(VALU issue: ~0.71 - 0.76 of the region in the profiles of rounds 5 and 6)" % (pmc_note or "none")})
         # rtcCommitScene against ITS roofline: bytes the build algorithm has to move -- vertices + indices in and references out (primref_gen), every level of
         # the binary binned-SAH build reads the references once to bin them and once to partition them and writes them once (32 B each way), the wide nodes and the
         # leaf records are written once, the leaf records gather their vertices again -- over the GPU time of the commit.  Levels = log2(leaves): what a balanced tree needs.
         b_levels = float(np.log2(max(2, info["num_leaves"])))
         b_bytes = ntri * (48 + 32) + b_levels * ntri * 96.0 + info["num_nodes"] * 80 + ntri * (48 + 48)
         b_s = float(np.min(build_ms)) * 1e-3
-        build_roof = {"bound": "hbm on paper; measured: LDS atomics and wave-instruction issue of the many small sets (profiles/r05_pmc_small_build.md)", "algorithmic_bytes": int(b_bytes),
+        try:                                                   # the commit's HBM-side bytes as the counters see them (tools/commit_traffic.py over PMC passes of tests/gpu_build_only.py)
+            ct = json.load(open(os.path.join(ROOT, "profiles", "r06_commit_traffic.json")))
+        except Exception:
+            ct = None
+        build_roof = {"bound": "hbm on paper; measured: LDS atomics and wave-instruction issue of the many small sets (profiles/r06_pmc_small_build.md: VALU pipes 0.57 busy, LDS bank-conflict ratio 0.51)", "algorithmic_bytes": int(b_bytes),
                       "achieved": round(b_bytes / b_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(b_bytes / b_s / 1e9 / HBM_PEAK_GBS, 4),
                       "frac_of_copy": round(b_bytes / b_s / 1e9 / bw[0], 4) if bw_ok and bw[0] > 0 else None, "dominant_kernel": "small_build",
                       "how": "triangles x (48 read + 32 written) + log2(leaves) = %.1f levels x triangles x (32 binned + 32 read + 32 written) + nodes x 80 + triangles x (48 gathered + 48 written), "
-                             "over the fastest of the timed commits; traffic of the commit as the counters see it: profiles/" % b_levels}
+                             "over the fastest of the timed commits" % b_levels,
+                      "traffic": int(ct["traffic_bytes_per_commit"]) if ct else None,
+                      "traffic_frac": round(ct["traffic_bytes_per_commit"] / b_s / 1e9 / HBM_PEAK_GBS, 4) if ct else None,
+                      "traffic_is": ("FETCH_SIZE x 2 + WRITE_SIZE summed over every kernel of a commit of this scene (profiles/r06_commit_traffic.md: %.2f GB read, %.2f GB written; top_partition + top_bin "
+                                     "are 5.9 GB of it, at 3.4 - 5.3 TB/s each) over this run's commit time: the formula and the counters agree to 2 %% -- what keeps the commit from the HBM roof is not "
+                                     "re-read bytes but the kernels that do not stream (small_build: 1.46 GB in 1.47 ms)" % (ct["read_bytes_per_commit"] / 1e9, ct["write_bytes_per_commit"] / 1e9)) if ct else None}
         weak_value, weak_ms = value, 1e3 * elapsed / args.steps
         strong_is_value = strong is not None                     # N > 1, crown: the LITERAL metric is one 2^20-ray batch over the N GPUs
         out = {

@@ -40,7 +40,6 @@ __global__ __launch_bounds__(256) void top_bin(const Seg* segs, const Chunk* chu
   __syncthreads();
   {
     const uint32_t lane = tid & 63u;
-#pragma unroll 2
     for (uint32_t i0 = ck.begin; i0 < ck.end; i0 += 256u) {        // (workgroup-uniform trip count: every lane calls bins_add_copies, which exchanges registers inside pairs of lanes)
       const uint32_t i = i0 + tid; const bool v = i < ck.end;
       PrimRef r{}; if (v) r = load_prim(src + i);
