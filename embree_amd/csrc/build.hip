@@ -295,17 +295,18 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
   DevBuf<uint32_t> outlierCnt, outlierTile, outlierTotal;      // MEDIUM: grid cells every reference asks for (0 unless it is an outlier), their tile sums / offsets, the total
   DevBuf<OutlierWork> outlierWork;                            // ... the outliers themselves (every one asks for >= 2 cells: at most half the reserve)
   if (topSplits) { HIP_TRY(outlierCnt.alloc(N)); HIP_TRY(outlierTile.alloc(tiles)); HIP_TRY(outlierTotal.alloc(1)); HIP_TRY(outlierWork.alloc((NC - N) / 2u + 16u)); }
+  DevBuf<uint32_t> accTop, binsTop; HIP_TRY(accTop.alloc((size_t)ACC_SETS * ACC_REPL * ACC_STRIDE)); HIP_TRY(binsTop.alloc((size_t)ACC_SETS * ACC_REPL * BINS_WORDS));   // copies of the upper levels' sets' bounds records (build_top.inl, acc_copy)
   DevBuf<uint32_t> chunkCnt; DevBuf<uint2> chunkBase;          // per chunk of a level: its bin counts, then its places in the two children (top_bin -> top_split -> top_partition)
   HIP_TRY(chunkCnt.alloc((size_t)maxChunks * 3u * NBINS)); HIP_TRY(chunkBase.alloc(maxChunks));
-  DevBuf<SegX> segx0, segx1; DevBuf<uint32_t> sbins;            // spatial-split builds: extended ranges of the top phase's sets, their spatial bins
+  DevBuf<SegX> segx0, segx1; DevBuf<uint32_t> sbins, sbinsTop;            // spatial-split builds: extended ranges of the top phase's sets, their spatial bins
   DevBuf<uint32_t> chunkFlag;                                  // ... per chunk: what it sends to either side of a spatial split (spatial_partition)
-  if (spatial) { HIP_TRY(segx0.alloc(maxSegs)); HIP_TRY(segx1.alloc(maxSegs)); HIP_TRY(sbins.alloc((size_t)maxSegs * SBINS_WORDS)); HIP_TRY(chunkFlag.alloc(maxChunks)); }
+  if (spatial) { HIP_TRY(segx0.alloc(maxSegs)); HIP_TRY(segx1.alloc(maxSegs)); HIP_TRY(sbins.alloc((size_t)maxSegs * SBINS_WORDS)); HIP_TRY(sbinsTop.alloc((size_t)ACC_SETS * ACC_REPL * SBINS_WORDS)); HIP_TRY(chunkFlag.alloc(maxChunks)); }
 
   hipEvent_t ev0, ev1; HIP_TRY(hipEventCreate(&ev0)); HIP_TRY(hipEventCreate(&ev1));
   struct EvGuard { hipEvent_t a, b; ~EvGuard() { hipEventDestroy(a); hipEventDestroy(b); } } evg{ev0, ev1};
   if (useGraph) {
     HIP_TRY(hipStreamSynchronize(st));                         // (the geometry table above is in place before anything is captured)
-    const void* ptrs[] = {dGeoms.p, bufA.p, bufB.p, finalIds.p, bnodes.p, segs0.p, segs1.p, bins.p, chunks.p, small.p, ctr.p, w0.p, w1.p, wnodes.p, outIds.p, plans.p, itemCnt.p, groupSum.p, tileCount.p, chunkCnt.p, chunkBase.p, segx0.p, segx1.p, sbins.p, outlierCnt.p, outlierTile.p, outlierTotal.p, outlierWork.p, areaPart.p, (const void*)st};
+    const void* ptrs[] = {dGeoms.p, bufA.p, bufB.p, finalIds.p, bnodes.p, segs0.p, segs1.p, bins.p, chunks.p, small.p, ctr.p, w0.p, w1.p, wnodes.p, outIds.p, plans.p, itemCnt.p, groupSum.p, tileCount.p, chunkCnt.p, chunkBase.p, accTop.p, binsTop.p, segx0.p, segx1.p, sbins.p, sbinsTop.p, outlierCnt.p, outlierTile.p, outlierTotal.p, outlierWork.p, areaPart.p, (const void*)st};
     std::vector<uint64_t> key; for (const void* q : ptrs) key.push_back((uint64_t)(uintptr_t)q);
     uint32_t pw[sizeof(Params) / 4]; memcpy(pw, &prm, sizeof(prm)); for (uint32_t w : pw) key.push_back(w);
     key.push_back(N); key.push_back(gd.size()); key.push_back(bp->robust); key.push_back(spatialMin); key.push_back(NC); { uint32_t w; memcpy(&w, &topSplitRel, 4); key.push_back(w); memcpy(&w, &topSplitCell, 4); key.push_back(w); } key.push_back(topSplits ? 1u : 0u); key.push_back(learned ? (learnedTop << 8) | learnedWide : 0u); key.push_back(learned ? (learnedChunked << 8) | (learnedLocalFirst & 0xFFu) : 0u);
@@ -460,23 +461,23 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
     const uint32_t localMax = local ? CHUNK : 0u, dstBuf = (level & 1u) ? 0u : 1u, forceFallback = level >= 96u ? 1u : 0u;
     if (!chunked) {
       LAUNCH(top_local, dim3(segBound), dim3(256), 0, st, (const Seg*)cur, (const PrimRef*)src, dst, bnodes.p, nxt, small.p, ctr.p, prm, dstBuf, maxSegs, maxSmall, forceFallback, level, 1u);
-      LAUNCH(top_emit, dim3((segBound + 255u) / 256u), dim3(256), 0, st, cur, bnodes.p, nxt, small.p, ctr.p, prm, dstBuf, maxSegs, maxSmall, (const SegX*)nullptr, (SegX*)nullptr, 0xFFFFFFFFu);   // (moves the work lists on)
+      LAUNCH(top_emit, dim3((segBound + 255u) / 256u), dim3(256), 0, st, cur, bnodes.p, nxt, small.p, ctr.p, prm, dstBuf, maxSegs, maxSmall, (const SegX*)nullptr, (SegX*)nullptr, 0xFFFFFFFFu, (const uint32_t*)nullptr);   // (moves the work lists on)
       Seg* t = cur; cur = nxt; nxt = t; level++;
       return;
     }
-    LAUNCH(top_setup, dim3(segBound), dim3(256), 0, st, cur, bins.p, chunks.p, ctr.p, localMax, level, chunkFlag.p);
-    LAUNCH(top_bin, dim3(chunkBound), dim3(256), 0, st, cur, chunks.p, src, bins.p, ctr.p, chunkCnt.p, maxChunks);
-    LAUNCH(top_split, dim3(segBound), dim3(64), 0, st, cur, bins.p, bnodes.p, ctr.p, prm, forceFallback, xcur, (const uint32_t*)chunkCnt.p, chunkBase.p, localMax, maxChunks);
+    LAUNCH(top_setup, dim3(segBound), dim3(256), 0, st, cur, bins.p, chunks.p, ctr.p, localMax, level, chunkFlag.p, binsTop.p);
+    LAUNCH(top_bin, dim3(chunkBound), dim3(256), 0, st, cur, chunks.p, src, bins.p, ctr.p, chunkCnt.p, maxChunks, binsTop.p);
+    LAUNCH(top_split, dim3(segBound), dim3(64), 0, st, cur, bins.p, bnodes.p, ctr.p, prm, forceFallback, xcur, (const uint32_t*)chunkCnt.p, chunkBase.p, localMax, maxChunks, accTop.p, (const uint32_t*)binsTop.p);
     if (spatial) {                                          // sets whose object split leaves overlapping children try a spatial split
-      LAUNCH(spatial_decide, dim3(segBound), dim3(128), 0, st, cur, xcur, bnodes.p, sbins.p, ctr.p, spatialMin);
-      LAUNCH(spatial_bin, dim3(chunkBound), dim3(256), 0, st, cur, xcur, chunks.p, src, dGeoms.p, sbins.p, ctr.p);
-      LAUNCH(spatial_best, dim3(segBound), dim3(64), 0, st, cur, xcur, sbins.p, bnodes.p, ctr.p, prm);
+      LAUNCH(spatial_decide, dim3(segBound), dim3(128), 0, st, cur, xcur, bnodes.p, sbins.p, ctr.p, spatialMin, sbinsTop.p);
+      LAUNCH(spatial_bin, dim3(chunkBound), dim3(256), 0, st, cur, xcur, chunks.p, src, dGeoms.p, sbins.p, ctr.p, sbinsTop.p);
+      LAUNCH(spatial_best, dim3(segBound), dim3(64), 0, st, cur, xcur, sbins.p, bnodes.p, ctr.p, prm, (const uint32_t*)sbinsTop.p);
     }
-    LAUNCH(top_partition, dim3(chunkBound), dim3(256), 0, st, cur, chunks.p, src, dst, ctr.p, (const uint2*)chunkBase.p);
-    if (spatial) LAUNCH(spatial_partition, dim3(chunkBound), dim3(256), 0, st, cur, xcur, chunks.p, src, dst, dGeoms.p, ctr.p, chunkFlag.p);
+    LAUNCH(top_partition, dim3(chunkBound), dim3(256), 0, st, cur, chunks.p, src, dst, ctr.p, (const uint2*)chunkBase.p, accTop.p, spatial ? 1u : 0u);
+    if (spatial) LAUNCH(spatial_partition, dim3(chunkBound), dim3(256), 0, st, cur, xcur, chunks.p, src, dst, dGeoms.p, ctr.p, chunkFlag.p, accTop.p);
     if (local) LAUNCH(top_local, dim3(segBound), dim3(256), 0, st, (const Seg*)cur, (const PrimRef*)src, dst, bnodes.p, nxt, small.p, ctr.p, prm, dstBuf, maxSegs, maxSmall, forceFallback, level, 0u);
     LAUNCH(top_emit, dim3((segBound + 255u) / 256u), dim3(256), 0, st, cur, bnodes.p, nxt, small.p, ctr.p, prm,
-           dstBuf, maxSegs, maxSmall, (const SegX*)xcur, xnxt, localMax);
+           dstBuf, maxSegs, maxSmall, (const SegX*)xcur, xnxt, localMax, (const uint32_t*)accTop.p);
     Seg* t = cur; cur = nxt; nxt = t; SegX* tx = xcur; xcur = xnxt; xnxt = tx; level++;
   };
   if (numSegs && sahBuild) {

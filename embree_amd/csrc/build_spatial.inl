@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void spatial_budgets(PrimRef* prims, uint32_t 
 __global__ void segx_root(SegX* sx, uint32_t extEnd) { SegX x0{}; x0.extEnd = extEnd; sx[0] = x0; }   // the root set owns everything behind the references
 
 // ---- per level, after top_split: does the object split leave overlapping children?  (HeuristicArraySpatialSAH::find, heuristic_spatial_array.h:171-186)
-__global__ void spatial_decide(const Seg* segs, SegX* sx, const BNode* bnodes, uint32_t* sbins, const Counters* ctr, uint32_t minSize) {
+__global__ void spatial_decide(const Seg* segs, SegX* sx, const BNode* bnodes, uint32_t* sbins, const Counters* ctr, uint32_t minSize, uint32_t* sbinsTop) {
   const uint32_t s = blockIdx.x, tid = threadIdx.x;
   if (s >= ctr->numSegs) return;
   const Seg* sg = segs + s; SegX* x = sx + s;
@@ -144,7 +144,12 @@ __global__ void spatial_decide(const Seg* segs, SegX* sx, const BNode* bnodes, u
     x->trySpatial = t; s_try = t;
   }
   __syncthreads();
-  if (s_try) { uint32_t* b = sbins + (size_t)s * SBINS_WORDS; for (uint32_t w = tid; w < (uint32_t)SBINS_WORDS; w += blockDim.x) { const uint32_t k = w % SBINW; b[w] = k < 3 ? ENC_POS_INF : (k < 6 ? ENC_NEG_INF : 0u); } }
+  if (s_try) {
+    // (round 6) levels of at most ACC_SETS sets: the chunks of a set merge into ACC_REPL copies of its spatial bins (as top_bin's, build_top.inl), spatial_best folds them
+    const bool copies = sbinsTop && ctr->numSegs <= ACC_SETS && sg->end - sg->begin > CHUNK;
+    uint32_t* b = copies ? sbinsTop + (size_t)s * ACC_REPL * SBINS_WORDS : sbins + (size_t)s * SBINS_WORDS;
+    for (uint32_t w = tid; w < (uint32_t)SBINS_WORDS * (copies ? ACC_REPL : 1u); w += blockDim.x) { const uint32_t k = (w % (uint32_t)SBINS_WORDS) % SBINW; b[w] = k < 3 ? ENC_POS_INF : (k < 6 ? ENC_NEG_INF : 0u); }
+  }
 }
 
 // ---- SpatialBinInfo::bin2 (heuristic_spatial.h:160-222) over the chunks of the sets that try a spatial split
@@ -190,7 +195,7 @@ __device__ __forceinline__ void spatial_chain(float (&v)[3][3], bool& have, cons
 #endif
 constexpr uint32_t SBIN_COPIES = MI355_SBIN_COPIES, SCOPY_STRIDE = SBINS_WORDS + 1u;
 constexpr uint32_t CHAIN_CAP = CHUNK;                                // every reference of a chunk fits (one task per reference: its axes in the top three bits)
-__global__ __launch_bounds__(256) void spatial_bin(const Seg* segs, const SegX* sx, const Chunk* chunks, const PrimRef* src, const GeomDesc* geoms, uint32_t* sbins, const Counters* ctr) {
+__global__ __launch_bounds__(256) void spatial_bin(const Seg* segs, const SegX* sx, const Chunk* chunks, const PrimRef* src, const GeomDesc* geoms, uint32_t* sbins, const Counters* ctr, uint32_t* sbinsTop) {
   __shared__ uint32_t s_b[SBIN_COPIES * SCOPY_STRIDE];              // private copies of the bins, lane l works on copy l mod SBIN_COPIES (see bins_add_copies); folded below
   __shared__ uint32_t s_chain[CHAIN_CAP];                           // reference index | axes to clip on << 29
   __shared__ uint32_t s_numChains;
@@ -274,6 +279,7 @@ __global__ __launch_bounds__(256) void spatial_bin(const Seg* segs, const SegX* 
   const Seg* sg = segs + ck.seg;
   uint32_t* g = sbins + (size_t)ck.seg * SBINS_WORDS;
   if (first == sg->begin && last == sg->end) { for (uint32_t w = tid; w < (uint32_t)SBINS_WORDS; w += 256u) g[w] = s_b[(w % SBINW) * SSLOTS + w / SBINW]; return; }   // the whole set: these ARE its bins
+  if (sbinsTop && ctr->numSegs <= ACC_SETS) g = sbinsTop + ((size_t)ck.seg * ACC_REPL + (blockIdx.x & (ACC_REPL - 1u))) * SBINS_WORDS;   // (a set of several chunks at an upper level: one of its copies)
   for (uint32_t w = tid; w < (uint32_t)SBINS_WORDS; w += 256u) {
     const uint32_t k = w % SBINW, v = s_b[k * SSLOTS + w / SBINW];
     if (k < 3) { if (v != ENC_POS_INF) atomicMin(&g[w], v); } else if (k < 6) { if (v != ENC_NEG_INF) atomicMax(&g[w], v); } else if (v) atomicAdd(&g[w], v);
@@ -281,13 +287,28 @@ __global__ __launch_bounds__(256) void spatial_bin(const Seg* segs, const SegX* 
 }
 
 // ---- SpatialBinInfo::best (heuristic_spatial.h:285-358) + the decision of find() (:187-198); one wavefront per set, lane d = axis d
-__global__ __launch_bounds__(64) void spatial_best(Seg* segs, SegX* sx, const uint32_t* sbins, BNode* bnodes, const Counters* ctr, Params prm) {
+__global__ __launch_bounds__(64) void spatial_best(Seg* segs, SegX* sx, const uint32_t* sbins, BNode* bnodes, const Counters* ctr, Params prm, const uint32_t* sbinsTop) {
   __shared__ float s_sah[3]; __shared__ uint32_t s_pos[3], s_l[3], s_r[3];
   const uint32_t s = blockIdx.x, lane = threadIdx.x;
   if (s >= ctr->numSegs) return;
   Seg* sg = segs + s; SegX* x = sx + s;
   if (!x->trySpatial) return;
   __shared__ uint32_t s_B[SBINS_WORDS];                            // the set's bins, fetched by the whole wave at once (three lanes walking them in global memory: 13 us per level)
+  if (sbinsTop && ctr->numSegs <= ACC_SETS && sg->end - sg->begin > CHUNK) {          // the fold of the set's copies (all of them asked for before the first is used)
+    constexpr uint32_t PER = (uint32_t)SBINS_WORDS / 64u;
+    uint32_t xx[PER][ACC_REPL];
+#pragma unroll
+    for (uint32_t i = 0; i < PER; i++)
+#pragma unroll
+      for (uint32_t r = 0; r < ACC_REPL; r++) xx[i][r] = sbinsTop[((size_t)s * ACC_REPL + r) * SBINS_WORDS + i * 64u + lane];
+#pragma unroll
+    for (uint32_t i = 0; i < PER; i++) {
+      const uint32_t w = i * 64u + lane, k = w % SBINW; uint32_t v = xx[i][0];
+#pragma unroll
+      for (uint32_t r = 1; r < ACC_REPL; r++) v = k < 3u ? min(v, xx[i][r]) : (k < 6u ? max(v, xx[i][r]) : v + xx[i][r]);
+      s_B[w] = v;
+    }
+  } else
   for (uint32_t w = lane; w < (uint32_t)SBINS_WORDS; w += 64u) s_B[w] = sbins[(size_t)s * SBINS_WORDS + w];
   __syncthreads();
   const uint32_t* B = s_B;
@@ -361,7 +382,7 @@ __device__ __forceinline__ void spatial_sides(const PrimRef& r, uint32_t dim, in
     }
   } else { toL = sbin(0.5f * (rlo + rhi), ofs, scale) < pos; toR = !toL; }   // whole, to the side its centre lies on
 }
-__global__ __launch_bounds__(256) void spatial_partition(Seg* segs, const SegX* sx, const Chunk* chunks, const PrimRef* src, PrimRef* dst, const GeomDesc* geoms, Counters* ctr, uint32_t* chunkFlag) {
+__global__ __launch_bounds__(256) void spatial_partition(Seg* segs, const SegX* sx, const Chunk* chunks, const PrimRef* src, PrimRef* dst, const GeomDesc* geoms, Counters* ctr, uint32_t* chunkFlag, uint32_t* accTop) {
   __shared__ uint32_t s_cnt[CHUNK_ROUNDS][4][2], s_off[CHUNK_ROUNDS][4][2], s_baseL, s_baseR;
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   if (blockIdx.x >= ctr->numChunks) return;
@@ -462,6 +483,7 @@ __global__ __launch_bounds__(256) void spatial_partition(Seg* segs, const SegX* 
   __syncthreads();
   if (tid < 24u) {
     const uint32_t side = tid / 12u, k = tid % 12u, val = s_acc[side][k];
-    if (k % 6u < 3u) { if (val != ENC_POS_INF) atomicMin(&sg->acc[side][k], val); } else { if (val != ENC_NEG_INF) atomicMax(&sg->acc[side][k], val); }
+    uint32_t* const a = acc_copy(accTop, ctr->numSegs, sg, ck.seg, blockIdx.x) + side * 12u + k;
+    if (k % 6u < 3u) { if (val != ENC_POS_INF) atomicMin(a, val); } else { if (val != ENC_NEG_INF) atomicMax(a, val); }
   }
 }

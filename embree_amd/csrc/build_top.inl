@@ -1,8 +1,9 @@
 // build_top.inl -- K2: level-synchronous top phase.
 // Part of build.hip (included inside its anonymous namespace); see the header of build.hip for the pipeline.
 // ------------------------------------------------------------------------------------ K2 top phase
+constexpr uint32_t ACC_SETS = 16u, ACC_REPL = 8u, ACC_STRIDE = 32u;   // levels of at most ACC_SETS sets: ACC_REPL copies of a set's bins (top_bin) and of its children's bounds record (acc_copy; ACC_STRIDE words per copy, 24 used: 128 bytes)
 // localMax: sets of at most this many references are top_local's at this level (0: none are), the four kernels of the chunked path leave them alone
-__global__ __launch_bounds__(256) void top_setup(Seg* segs, uint32_t* bins, Chunk* chunks, Counters* ctr, uint32_t localMax, uint32_t level, uint32_t* chunkFlag) {
+__global__ __launch_bounds__(256) void top_setup(Seg* segs, uint32_t* bins, Chunk* chunks, Counters* ctr, uint32_t localMax, uint32_t level, uint32_t* chunkFlag, uint32_t* binsTop) {
   __shared__ uint32_t s_base;
   const uint32_t s = blockIdx.x, tid = threadIdx.x;
   if (s >= ctr->numSegs) return;                                // the grid is an upper bound (2^level segments at most)
@@ -11,7 +12,10 @@ __global__ __launch_bounds__(256) void top_setup(Seg* segs, uint32_t* bins, Chun
   if (n <= localMax) return;
   if (tid == 0u) ctr->chunkedLevels = level + 1u;               // (every writer of a level writes the same value; levels are launches, in order)
   const uint32_t nch = (n + CHUNK - 1u) / CHUNK;
-  if (nch > 1u) bins_clear(bins + (size_t)s * BINS_WORDS, tid, 256u);   // (a set of one chunk: top_bin writes its bins as they are -- clearing them was 54 MB per level of a HIGH commit)
+  if (nch > 1u) {                                              // (a set of one chunk: top_bin writes its bins as they are -- clearing them was 54 MB per level of a HIGH commit)
+    if (binsTop && ctr->numSegs <= ACC_SETS) { for (uint32_t r = 0; r < ACC_REPL; r++) bins_clear(binsTop + ((size_t)s * ACC_REPL + r) * BINS_WORDS, tid, 256u); }   // the copies the chunks merge into (top_bin); top_split folds them
+    else bins_clear(bins + (size_t)s * BINS_WORDS, tid, 256u);
+  }
   if (tid == 0) {
     const Mapping m = make_mapping(n, sg->cmin, sg->cmax);
     for (int d = 0; d < 3; d++) { sg->ofs[d] = m.ofs[d]; sg->scale[d] = m.scale[d]; }
@@ -29,7 +33,7 @@ __global__ __launch_bounds__(256) void top_setup(Seg* segs, uint32_t* bins, Chun
 
 // chunkCnt: per chunk, how many of its references fell into every bin and the bins before it (3 x NBINS words): top_split turns them into the chunk's places in the two children,
 // so that where a reference lands does not depend on which chunk reached a cursor first (top_partition)
-__global__ __launch_bounds__(256) void top_bin(const Seg* segs, const Chunk* chunks, const PrimRef* src, uint32_t* bins, const Counters* ctr, uint32_t* chunkCnt, uint32_t chunkStride) {
+__global__ __launch_bounds__(256) void top_bin(const Seg* segs, const Chunk* chunks, const PrimRef* src, uint32_t* bins, const Counters* ctr, uint32_t* chunkCnt, uint32_t chunkStride, uint32_t* binsTop) {
   __shared__ uint32_t s_bins[BIN_COPIES * COPY_STRIDE];
   const uint32_t tid = threadIdx.x;
   if (blockIdx.x >= ctr->numChunks) return;
@@ -59,6 +63,9 @@ __global__ __launch_bounds__(256) void top_bin(const Seg* segs, const Chunk* chu
     for (uint32_t w = tid; w < (uint32_t)BINS_WORDS; w += 256u) g[w] = s_bins[w];
     return;
   }
+  // (round 6) at the upper levels -- while a level has at most ACC_SETS sets -- a chunk merges into one of ACC_REPL copies of its set's bins: 2325 chunks x 672 atomics on
+  // the 42 cache lines of ONE set were what the root's level of top_bin ended on (65 us where the levels of many sets take 40)
+  if (binsTop && ctr->numSegs <= ACC_SETS) g = binsTop + ((size_t)ck.seg * ACC_REPL + (blockIdx.x & (ACC_REPL - 1u))) * BINS_WORDS;
   for (uint32_t w = tid; w < (uint32_t)BINS_WORDS; w += 256u) {      // BinInfoT::merge :312-321
     const uint32_t k = w % BINW, cnt = s_bins[w - k + 6];
     if (cnt == 0u) continue;
@@ -66,13 +73,35 @@ __global__ __launch_bounds__(256) void top_bin(const Seg* segs, const Chunk* chu
   }
 }
 
+// (round 6) The children's bounds of a set are min / max atomics of every chunk on ONE record: at the upper levels -- the root's level has 2325 chunks -- 12 to 24 atomics
+// per chunk on the same cache line are what the partition kernels end on (top_partition 90 us at the root's level, 57 where the sets are many).  While a level has at most
+// ACC_SETS sets, a chunk works on one of ACC_REPL copies of its set's record, each on a line of its own (accTop); top_split clears them, top_emit folds them.  min / max: the
+// bounds do not change by a bit.
+__device__ __forceinline__ uint32_t* acc_copy(uint32_t* accTop, uint32_t numSegs, Seg* sg, uint32_t seg, uint32_t chunk) {
+  return (accTop && numSegs <= ACC_SETS) ? accTop + ((size_t)seg * ACC_REPL + (chunk & (ACC_REPL - 1u))) * ACC_STRIDE : &sg->acc[0][0];
+}
+// the twelve words of one side of a set's record, folded over the copies (all copies are asked for before the first is used: one round trip)
+__device__ __forceinline__ void acc_folded(const uint32_t* accTop, uint32_t numSegs, const Seg* sg, uint32_t seg, uint32_t side, uint32_t (&v)[12]) {
+  for (uint32_t k = 0; k < 12u; k++) v[k] = sg->acc[side][k];
+  if (accTop && numSegs <= ACC_SETS) {
+    uint32_t x[ACC_REPL][12];
+#pragma unroll
+    for (uint32_t r = 0; r < ACC_REPL; r++)
+#pragma unroll
+      for (uint32_t k = 0; k < 12u; k++) x[r][k] = accTop[((size_t)seg * ACC_REPL + r) * ACC_STRIDE + side * 12u + k];
+#pragma unroll
+    for (uint32_t r = 0; r < ACC_REPL; r++)
+#pragma unroll
+      for (uint32_t k = 0; k < 12u; k++) v[k] = (k % 6u) < 3u ? min(v[k], x[r][k]) : max(v[k], x[r][k]);
+  }
+}
 struct SegX;                                                    // build_spatial.inl: extended ranges of spatial-split builds (nullptr otherwise)
 __device__ __forceinline__ uint32_t segx_ext_end(const SegX* sx, uint32_t s);
 __device__ __forceinline__ void segx_object_split(SegX* sx, uint32_t s, uint32_t capL, float sah);
 __device__ __forceinline__ uint32_t segx_cap_left(const SegX* sx, uint32_t s);
 __device__ __forceinline__ void segx_child(SegX* nx, uint32_t k, uint32_t extEnd);
 __global__ __launch_bounds__(64) void top_split(Seg* segs, const uint32_t* bins, BNode* bnodes, Counters* ctr, Params prm, uint32_t forceFallback, SegX* sx,
-                                                const uint32_t* chunkCnt, uint2* chunkBase, uint32_t localMax, uint32_t chunkStride) {
+                                                const uint32_t* chunkCnt, uint2* chunkBase, uint32_t localMax, uint32_t chunkStride, uint32_t* accTop, const uint32_t* binsTop) {
   __shared__ SplitResult s_res;
   __shared__ uint32_t s_plan[4];                                // fallback, dim, pos, capacity of the left child
   const uint32_t s = blockIdx.x, lane = threadIdx.x;
@@ -80,7 +109,28 @@ __global__ __launch_bounds__(64) void top_split(Seg* segs, const uint32_t* bins,
   Seg* sg = segs + s;
   if (sg->end - sg->begin <= localMax) return;
   Mapping m; for (int d = 0; d < 3; d++) { m.ofs[d] = sg->ofs[d]; m.scale[d] = sg->scale[d]; } m.nb = sg->nb;
-  sah_best_wave(bins + (size_t)s * BINS_WORDS, m, prm.shift, &s_res, lane);
+  __shared__ uint32_t s_fold[BINS_WORDS];
+  const bool folded = binsTop && ctr->numSegs <= ACC_SETS && sg->end - sg->begin > CHUNK;   // (block-uniform) the set's bins = the fold of their copies (top_bin)
+  if (folded) {
+    constexpr uint32_t PER = ((uint32_t)BINS_WORDS + 63u) / 64u;    // words per lane: all their copies are asked for before the first one is used (one round trip, not eleven)
+    uint32_t x[PER][ACC_REPL];
+#pragma unroll
+    for (uint32_t i = 0; i < PER; i++) {
+      const uint32_t w = i * 64u + lane;
+#pragma unroll
+      for (uint32_t r = 0; r < ACC_REPL; r++) x[i][r] = w < (uint32_t)BINS_WORDS ? binsTop[((size_t)s * ACC_REPL + r) * BINS_WORDS + w] : 0u;
+    }
+#pragma unroll
+    for (uint32_t i = 0; i < PER; i++) {
+      const uint32_t w = i * 64u + lane, k = w % BINW;
+      uint32_t v = x[i][0];
+#pragma unroll
+      for (uint32_t r = 1; r < ACC_REPL; r++) v = k < 3u ? min(v, x[i][r]) : (k < 6u ? max(v, x[i][r]) : v + x[i][r]);
+      if (w < (uint32_t)BINS_WORDS) s_fold[w] = v;
+    }
+    __syncthreads();
+  }
+  sah_best_wave(folded ? (const uint32_t*)s_fold : bins + (size_t)s * BINS_WORDS, m, prm.shift, &s_res, lane);
   __syncthreads();
   if (lane == 0) {
     const uint32_t begin = sg->begin, end = sg->end, n = end - begin;
@@ -104,6 +154,8 @@ __global__ __launch_bounds__(64) void top_split(Seg* segs, const uint32_t* bins,
     for (int side = 0; side < 2; side++) for (int k = 0; k < 12; k++) sg->acc[side][k] = (k % 6 < 3) ? ENC_POS_INF : ENC_NEG_INF;
     s_plan[0] = fallback ? 1u : 0u; s_plan[1] = fallback ? 0u : (uint32_t)r.dim; s_plan[2] = (uint32_t)r.pos; s_plan[3] = capL;
   }
+  if (accTop && ctr->numSegs <= ACC_SETS)                        // the copies of this set's bounds record (acc_copy)
+    for (uint32_t w = lane; w < ACC_REPL * ACC_STRIDE; w += 64u) { const uint32_t k = (w % ACC_STRIDE) % 12u; accTop[(size_t)s * ACC_REPL * ACC_STRIDE + w] = (k % 6u < 3u) ? ENC_POS_INF : ENC_NEG_INF; }
   __syncthreads();
   // Where every chunk of the set writes its left and its right references: an exclusive scan, in chunk order, of the per-chunk bin counts of top_bin.
   // (A cursor advanced with atomics hands the places out in the order the chunks ARRIVE: the sets come out the same, their order does not -- and a later
@@ -131,7 +183,7 @@ __global__ __launch_bounds__(64) void top_split(Seg* segs, const uint32_t* bins,
   }
 }
 
-__global__ __launch_bounds__(256) void top_partition(Seg* segs, const Chunk* chunks, const PrimRef* src, PrimRef* dst, const Counters* ctr, const uint2* chunkBase) {
+__global__ __launch_bounds__(256) void top_partition(Seg* segs, const Chunk* chunks, const PrimRef* src, PrimRef* dst, const Counters* ctr, const uint2* chunkBase, uint32_t* accTop, uint32_t countCursors) {
   __shared__ uint32_t s_cnt[CHUNK_ROUNDS][4][2], s_off[CHUNK_ROUNDS][4][2], s_acc[2][12], s_baseL, s_baseR;
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   if (blockIdx.x >= ctr->numChunks) return;
@@ -174,8 +226,10 @@ __global__ __launch_bounds__(256) void top_partition(Seg* segs, const Chunk* chu
   if (tid == 0) {
     uint32_t l = 0, rr = 0;
     for (int r = 0; r < CHUNK_ROUNDS; r++) for (int w = 0; w < 4; w++) { s_off[r][w][0] = l; s_off[r][w][1] = rr; l += s_cnt[r][w][0]; rr += s_cnt[r][w][1]; }
-    if (l) atomicAdd(&sg->curL, l);                              // (the cursors only COUNT here: top_emit of spatial-split builds reads them)
-    if (rr) atomicAdd(&sg->curR, rr);
+    if (countCursors) {                                          // (the cursors only COUNT here: top_emit of spatial-split builds reads them -- nobody else, and two same-word atomics per chunk are not free)
+      if (l) atomicAdd(&sg->curL, l);
+      if (rr) atomicAdd(&sg->curR, rr);
+    }
     const uint2 base = chunkBase[blockIdx.x];                    // this chunk's places, in chunk order (top_split)
     s_baseL = base.x; s_baseR = base.y;
   }
@@ -194,7 +248,8 @@ __global__ __launch_bounds__(256) void top_partition(Seg* segs, const Chunk* chu
   }
   if (tid < 24) {
     const uint32_t side = tid / 12, k = tid % 12, v = s_acc[side][k];
-    if (k % 6 < 3) { if (v != ENC_POS_INF) atomicMin(&sg->acc[side][k], v); } else { if (v != ENC_NEG_INF) atomicMax(&sg->acc[side][k], v); }
+    uint32_t* const a = acc_copy(accTop, ctr->numSegs, sg, ck.seg, blockIdx.x) + side * 12u + k;
+    if (k % 6 < 3) { if (v != ENC_POS_INF) atomicMin(a, v); } else { if (v != ENC_NEG_INF) atomicMax(a, v); }
   }
 }
 
@@ -338,8 +393,9 @@ __global__ __launch_bounds__(256) void top_local(const Seg* segs, const PrimRef*
 }
 
 __global__ void top_emit(const Seg* segs, BNode* bnodes, Seg* next, SmallEntry* small, Counters* ctr,
-                         Params prm, uint32_t dstBuf, uint32_t maxNext, uint32_t maxSmall, const SegX* sx, SegX* nx, uint32_t localMax) {
+                         Params prm, uint32_t dstBuf, uint32_t maxNext, uint32_t maxSmall, const SegX* sx, SegX* nx, uint32_t localMax, const uint32_t* accTop) {
   const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t numSegsNow = ctr->numSegs;
   if (s < ctr->numSegs && segs[s].end - segs[s].begin > localMax) {
   const Seg* sg = segs + s;
   const uint32_t capL = sx ? segx_cap_left(sx, s) : sg->nL;
@@ -351,8 +407,9 @@ __global__ void top_emit(const Seg* segs, BNode* bnodes, Seg* next, SmallEntry* 
     const uint32_t childExtEnd = sx ? (side ? segx_ext_end(sx, s) : sg->begin + capL) : e;
     const uint32_t child = side ? sg->childR : sg->childL;
     float cmin[3], cmax[3];
-    for (int d = 0; d < 3; d++) { cmin[d] = dec(sg->acc[side][d]); cmax[d] = dec(sg->acc[side][3 + d]); }
-    if (sg->flags & 3u) for (int d = 0; d < 3; d++) { bnodes[child].lo[d] = dec(sg->acc[side][6 + d]); bnodes[child].hi[d] = dec(sg->acc[side][9 + d]); }
+    uint32_t av[12]; acc_folded(accTop, numSegsNow, sg, s, (uint32_t)side, av);
+    for (int d = 0; d < 3; d++) { cmin[d] = dec(av[d]); cmax[d] = dec(av[3 + d]); }
+    if (sg->flags & 3u) for (int d = 0; d < 3; d++) { bnodes[child].lo[d] = dec(av[6 + d]); bnodes[child].hi[d] = dec(av[9 + d]); }
     if (sg->flags & 2u) { bnodes[child].begin = b; bnodes[child].end = e; }
     top_emit_child(b, e, child, cmin, cmax, next, small, ctr, prm, dstBuf, maxNext, maxSmall, nx, childExtEnd);
   }
