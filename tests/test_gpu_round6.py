@@ -388,6 +388,26 @@ def test_radix_sort_of_the_morton_build_vs_stable_argsort(api, case, n):
         a_.free()
 
 
+@pytest.mark.parametrize("case", ["random", "few_values"])
+def test_radix_sort_at_sixteen_million_keys(api, case):
+    """4097 tiles: every workgroup of a pass looks back over tiles that are still running (512 are resident at a time); the order must still be the stable one."""
+    L = api.load()
+    n = (1 << 24) + 5
+    rng = np.random.default_rng(11)
+    keys = rng.integers(0, 1 << 63, n, dtype=np.uint64) if case == "random" else rng.choice(rng.integers(0, 1 << 63, 300, dtype=np.uint64), n)
+    dk = api.DeviceArray.from_numpy(keys)
+    ok, oi = api.DeviceArray(n * 8), api.DeviceArray(n * 4)
+    ms = C.c_float()
+    assert L.mi355_sort_keys63(0, dk.ptr, ok.ptr, oi.ptr, n, C.byref(ms)) == 0, L.mi355_last_error().decode()
+    got_i = oi.download(np.uint32)
+    want_i = np.argsort(keys, kind="stable").astype(np.uint32)
+    assert np.array_equal(got_i, want_i)
+    assert np.array_equal(ok.download(np.uint64), keys[want_i])
+    print("radix sort of %d keys (%s): %.3f ms" % (n, case, ms.value))
+    for a_ in (dk, ok, oi):
+        a_.free()
+
+
 def test_low_quality_build_has_no_library_kernel():
     """the Morton build's translation unit no longer includes hipcub / rocprim: every kernel of every commit is this repository's"""
     src = os.path.join(ROOT, "embree_amd", "csrc")
