@@ -330,21 +330,19 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
     const uint32_t ctiles = (NC + 255u) / 256u;                  // tiles of the compaction: the references and, behind them, the reserve for outlier pieces
     if (topSplits) {                                             // references that dwarf all others are cut into grid pieces (build_presplit.inl): holes and originals become "invalid"
       LAUNCH(outlier_stats, dim3(1), dim3(1024), 0, st, (const AreaPart*)areaPart.p, genBlocks, ctr.p);
-      LAUNCH(outlier_mark, dim3(tiles), dim3(256), 0, st, bufA.p, N, ctr.p, topSplitRel, topSplitCell, outlierCnt.p, outlierTile.p);
+      LAUNCH(outlier_mark, dim3(tiles), dim3(256), 0, st, bufA.p, N, ctr.p, topSplitRel, topSplitCell, outlierCnt.p, outlierTile.p, tileCount.p);
       LAUNCH(presplit_scan, dim3(1), dim3(1024), 0, st, outlierTile.p, tiles, outlierTotal.p);
-      LAUNCH(outlier_emit, dim3(tiles), dim3(256), 0, st, bufA.p, N, NC - N, outlierCnt.p, outlierTile.p, outlierTotal.p, ctr.p, outlierWork.p);
+      LAUNCH(outlier_emit, dim3(tiles), dim3(256), 0, st, bufA.p, N, NC - N, outlierCnt.p, outlierTile.p, outlierTotal.p, ctr.p, outlierWork.p, tileCount.p);
       LAUNCH(outlier_clip, dim3(1024), dim3(256), 0, st, bufA.p, NC - N, dGeoms.p, outlierTotal.p, ctr.p, outlierWork.p, topSplitRel, topSplitCell);
       LAUNCH(outlier_retire, dim3(16), dim3(256), 0, st, bufA.p, NC - N, outlierTotal.p, (const Counters*)ctr.p, outlierWork.p);
     }
     // invalid triangles (and the holes of the outlier grid) are squeezed out on the device, if there are any; then the root
-    LAUNCH(compact_count, dim3(ctiles), dim3(256), 0, st, bufA.p, NC, tileCount.p, ctr.p, N);
+    // (with the outlier cut the tiles in front of the one N falls into are counted already: outlier_mark / outlier_emit)
+    const uint32_t ctile0 = topSplits ? N / 256u : 0u;
+    LAUNCH(compact_count, dim3(ctiles - ctile0), dim3(256), 0, st, bufA.p, NC, tileCount.p, ctr.p, N, ctile0);
     LAUNCH(compact_scan, dim3(1), dim3(1024), 0, st, tileCount.p, ctiles, ctr.p, 1u);
     LAUNCH(compact_scatter, dim3(ctiles), dim3(256), 0, st, bufA.p, NC, tileCount.p, bufB.p, ctr.p, N);
     LAUNCH(compact_copyback, dim3(ctiles < 2048u ? ctiles : 2048u), dim3(256), 0, st, bufB.p, bufA.p, ctr.p);
-    if (topSplits) {                                             // pieces have other centres than their triangles: the centroid box is measured again (only if something was cut)
-      LAUNCH(centroid_reset, dim3(1), dim3(64), 0, st, ctr.p);
-      LAUNCH(centroid_bounds_guarded, dim3(tiles < 1024u ? tiles : 1024u), dim3(256), 0, st, bufA.p, ctr.p);
-    }
     LAUNCH(root_setup, dim3(1), dim3(1), 0, st, ctr.p, bnodes.p, segs0.p, small.p, N, prm.small);
     numSegs = N > prm.small ? 1u : 0u;
     if (prm.spatial && numSegs) {                                 // split budgets of the references; the root set owns everything behind them
@@ -356,7 +354,7 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
     SYNC_READ(h);
     h.numPrims = N - h.numInvalid;
     if (h.numInvalid) {                                          // rare: squeeze the invalid triangles out (stable)
-      LAUNCH(compact_count, dim3(tiles), dim3(256), 0, st, bufA.p, N, tileCount.p, (const Counters*)nullptr, N);
+      LAUNCH(compact_count, dim3(tiles), dim3(256), 0, st, bufA.p, N, tileCount.p, (const Counters*)nullptr, N, 0u);
       LAUNCH(compact_scan, dim3(1), dim3(1024), 0, st, tileCount.p, tiles, ctr.p, 0u);
       LAUNCH(compact_scatter, dim3(tiles), dim3(256), 0, st, bufA.p, N, tileCount.p, bufB.p, (const Counters*)nullptr, N);
       HIP_TRY(hipGetLastError());
@@ -400,7 +398,7 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
     // root binary node + first work item
     BNode rootB{}; for (int d = 0; d < 3; d++) { rootB.lo[d] = glo[d]; rootB.hi[d] = ghi[d]; } rootB.begin = 0; rootB.end = n; rootB.left = rootB.right = NIL; rootB.splitSah = INFINITY;
     HIP_TRY(hipMemcpyAsync(bnodes.p, &rootB, sizeof(rootB), hipMemcpyHostToDevice, st));
-    h.numBLeaves = 0; h.numSegsNext = 0; h.numChunks = 0; h.numSmall = 0; h.numSegs = (n > prm.small && prm.quality != 1u) ? 1u : 0u; h.topLevels = 0;   // (LOW has no top phase: a work list that nobody empties would read as "unfinished" to wide_root)
+    h.numSegsNext = 0; h.numChunks = 0; h.numSmall = 0; h.numSegs = (n > prm.small && prm.quality != 1u) ? 1u : 0u; h.topLevels = 0;   // (LOW has no top phase: a work list that nobody empties would read as "unfinished" to wide_root)
     h.rootArea = fmaf(ghi[0] - glo[0], (ghi[1] - glo[1]) + (ghi[2] - glo[2]), (ghi[1] - glo[1]) * (ghi[2] - glo[2]));
     h.areaFixed = 0ull;
     if (n > prm.small) {
@@ -535,7 +533,9 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
   if (fast) {
     // the depth of the wide tree is unknown here: 16 levels cover every scene measured so far (crown 12, powerplant 13); a deeper tree is finished below
     // (every level enqueued beyond the last one costs three empty launches, ~14 us)
-    { const uint32_t levels = learned && learnedWide ? min(16u, learnedWide + 1u) : 16u; for (uint32_t i = 0; i < levels; i++) enqueue_wide_level(); }
+    // (a commit that knows the depth the commits of its kind needed enqueues exactly that many levels: a deeper tree is finished level by level below -- one more round trip and
+    // the leaf records written again, once, after which the kind's depth has grown -- where a level of margin cost EVERY commit three empty launches, ~17 us)
+    { const uint32_t levels = learned && learnedWide ? min(16u, learnedWide) : 16u; for (uint32_t i = 0; i < levels; i++) enqueue_wide_level(); }
     if (capturing) {                                             // end of the captured sequence: instantiate, keep, run
       hipGraph_t graph = nullptr;
       const hipError_t e = hipStreamEndCapture(st, &graph);
@@ -622,9 +622,11 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
   HIP_TRY(hipEventRecord(ev1, st)); HIP_TRY(hipEventSynchronize(ev1)); syncs++;
   float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
   bvh->root = h.rootRef;
-  info.root_ref = h.rootRef; info.num_nodes = numNodes; info.num_leaves = h.numLeaves; info.num_binary_nodes = 2ull * h.numBLeaves - 1ull;
+  unsigned long long sahFixed = 0ull; uint32_t numLeaves = 0u, numBLeaves = 0u;            // the statistics every workgroup reported to its stripe (Counters::Stripe)
+  for (uint32_t r = 0; r < Counters::STRIPES; r++) { sahFixed += h.stripe[r].sahFixed; numLeaves += h.stripe[r].numLeaves; numBLeaves += h.stripe[r].numBLeaves; }
+  info.root_ref = h.rootRef; info.num_nodes = numNodes; info.num_leaves = numLeaves; info.num_binary_nodes = 2ull * numBLeaves - 1ull;
   info.bytes_nodes = (uint64_t)numNodes * sizeof(CNode); info.bytes_triangles = (uint64_t)n * sizeof(TriRec);
-  info.sah = (float)((double)h.sahFixed / 16777216.0) + (numNodes ? prm.travCost : 0.0f); info.build_ms = ms; info.depth = depth;
+  info.sah = (float)((double)sahFixed / 16777216.0) + (numNodes ? prm.travCost : 0.0f); info.build_ms = ms; info.depth = depth;
   info.num_launches = launches; info.num_host_syncs = syncs;
   guard.ok = true; *out = bvh;
   return 0;

@@ -42,11 +42,11 @@ struct SmallEntry { uint32_t begin, end, bnode, buf; float cmin[3], cmax[3]; };
 struct Chunk { uint32_t seg, begin, end; };
 struct WideItem { uint32_t bnode, node; };
 struct Counters {
-  uint32_t numPrims, numBLeaves, numSegsNext, numChunks, numSmall, numWide, numWideNext, numLeaves;
+  uint32_t numPrims, pad_a, pad_d, numChunks, pad_e, numWide, numWideNext, pad_b;
   uint32_t bounds[12];                          // scene geom lo/hi + centroid lo/hi (ordered uint)
   uint32_t overflow, rootRef, numTrisOut, numInvalid;
   uint32_t numSegs, topLevels, wideDepth, lvlNodeBase, lvlTriBase, wideCount[2];      // level loops are driven from the device: no host readback per level
-  unsigned long long sahFixed;                    // SAH statistics, 2^-24 fixed point (order-independent sum)
+  unsigned long long pad_c;
   float rootArea;                                 // half area of the scene bounds (SAH statistics are relative to it); written by root_setup
   uint32_t numOutliers;                           // MEDIUM builds: references cut up front because their box dwarfs the average one (build_presplit.inl, outlier_*)
   unsigned long long areaFixed;                   // spatial-split builds: sum of the references' box areas / scene area, 2^-32 fixed point (build_spatial.inl)
@@ -57,8 +57,22 @@ struct Counters {
   unsigned long long outlierWork;                 // outlier_emit -> outlier_clip: outliers listed << 32 | 256-cell chunks handed out so far (ONE atomic: list order = chunk order)
   uint32_t chunkedLevels, localFirst;             // top phase: levels that had a set of more than CHUNK references; the first level with a smaller one (top_local's) -- what the next commit enqueues
   uint32_t padC[2];
-  unsigned long long smTime[4];                   // -DSM_TIME: wave cycles small_build spent binning / pricing / partitioning / in the micro mode
+  unsigned long long smTime[4];                  // -DSM_TIME: wave cycles small_build spent binning / pricing / partitioning / in the micro mode
   uint32_t lvlStart[64];                          // first node of every level of the wide tree (numbering is breadth first): what a refit walks bottom-up
+  alignas(128) uint32_t numSmall; uint32_t numSegsNext;   // lengths of the work lists the top phase appends to, on a line of their own: top_local appends twice per workgroup, and every
+                                                  // one of its thousands of workgroups reads numSegs first (top_local 383 -> 358 us per commit with the appends off that line)
+  // Words that EVERY workgroup of a large grid sends an atomic to.  Atomic instructions on ONE cache line are served one after the other, ~10 ns each when they come from all
+  // CUs (MI355X_MICROARCH.md "fanin"): the 8192 workgroups of a large level of wide_plan ended on 2 x 8192 of them -- ~80 us of the 175 us of the widest level, 250 us per
+  // commit (found when both words were moved onto ONE line: 577 -> 850 us) -- and outlier_mark with six words per workgroup on one line took 140 us instead of 25.  A
+  // workgroup therefore reports to stripe[blockIdx mod STRIPES], a line of its own per stripe; sums and min / max do not care, whoever needs the value folds the stripes.
+  struct alignas(128) Stripe {
+    unsigned long long sahFixed;                  // SAH statistics of the wide tree, 2^-24 fixed point (order-independent sum): wide_plan
+    uint32_t numLeaves;                           // leaf slots of the wide tree: wide_plan
+    uint32_t numBLeaves;                          // leaves of the binary tree: small_build (LOW: stripe 0 holds n)
+    uint32_t cb2[6];                              // MEDIUM builds that cut outliers: centroid lo/hi over the references that stay (outlier_mark) and the pieces (outlier_clip): the root's centroid box if anything was cut
+  };
+  static constexpr uint32_t STRIPES = 64u;
+  Stripe stripe[STRIPES];
 };
 struct Params { uint32_t shift, minLeaf, maxLeaf, small; float travCost, intCost; uint32_t quality, spatial; };
 
@@ -126,6 +140,29 @@ __device__ __forceinline__ uint2 block_exclusive_scan_1024_u2(uint2 v, uint2* s_
   __syncthreads();                                               // (s_w may be used again at once)
   return make_uint2(base.x + incl.x - v.x, base.y + incl.y - v.y);
 }
+// Eight consecutive words of a thread's run as TWO 16-byte loads / stores (a run starts at a multiple of eight words of a 256-byte aligned array whose allocation is padded
+// to 256 bytes: reading the words behind `e` is harmless, they are replaced by `fill`).  The single-workgroup scans are bound by the address path of their ONE CU -- a
+// scattered one-word load costs it a clock per lane: presplit_scan over the crown's 18,605 tiles was 2 x 384 wave-loads of 64 addresses = 27.7 us, compact_scan 30.1 us.
+__device__ __forceinline__ void load8_fill(const uint32_t* p, uint32_t i, uint32_t e, uint32_t fill, uint32_t (&x)[8]) {
+  uint4 a = make_uint4(fill, fill, fill, fill), b = a;
+  if (i < e) a = ((const uint4*)(p + i))[0];
+  if (i + 4u < e) b = ((const uint4*)(p + i))[1];
+  x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
+#pragma unroll
+  for (uint32_t k = 0; k < 8u; k++) if (i + k >= e) x[k] = fill;
+}
+__device__ __forceinline__ void store8_upto(uint32_t* p, uint32_t i, uint32_t e, const uint32_t (&y)[8]) {
+  if (i + 8u <= e) { ((uint4*)(p + i))[0] = make_uint4(y[0], y[1], y[2], y[3]); ((uint4*)(p + i))[1] = make_uint4(y[4], y[5], y[6], y[7]); }
+  else {
+#pragma unroll
+    for (uint32_t k = 0; k < 8u; k++) if (i + k < e) p[i + k] = y[k];
+  }
+}
+// min / max atomics of a workgroup's result on a word that EVERY workgroup of the grid reports to: only a value that improves on what the word holds is sent.  What the load
+// returns may be older than the word (another XCD's atomic on its way): then the atomic is sent although it changes nothing -- never the other way round, the word only moves
+// in one direction.  (18,605 workgroups x 6 atomics on one cache line are ~80 us at the ~0.75 ns a same-line atomic costs, profiles/r06_top_level_atomics.md.)
+__device__ __forceinline__ void atomic_min_if_less(uint32_t* p, uint32_t v) { if (v < __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(p, v); }
+__device__ __forceinline__ void atomic_max_if_more(uint32_t* p, uint32_t v) { if (v > __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(p, v); }
 // s[0..1024) becomes its exclusive scan, the total is returned to every thread
 __device__ __forceinline__ uint32_t block_exclusive_scan_1024(uint32_t* s, uint32_t tid) {
   __shared__ uint2 s_w[17];

@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void lbvh_bounds(const PrimRef* prims, uint32_
   ((float4*)(bnodes + id))[0] = make_float4(lo[0], lo[1], lo[2], __uint_as_float(w3));
   ((float4*)(bnodes + id))[1] = make_float4(hi[0], hi[1], hi[2], __uint_as_float(w7));
   ((uint4*)(bnodes + id))[2] = make_uint4(NIL, NIL, __float_as_uint(__builtin_inff()), 0u);   // links: only read by later kernels
-  if (j == 0u) ctr->numBLeaves = n;
+  if (j == 0u) ctr->stripe[0].numBLeaves = n;
   bool local = true;
   while (id != 0u) {
     const uint32_t par = parent[id];

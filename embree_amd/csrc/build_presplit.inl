@@ -148,10 +148,8 @@ __global__ __launch_bounds__(1024) void presplit_scan(uint32_t* tileSum, uint32_
   __shared__ uint32_t s_part[1024];
   const uint32_t tid = threadIdx.x, per = ((numTiles + 1023u) / 1024u + 7u) & ~7u, b = min(tid * per, numTiles), e = min(b + per, numTiles);
   uint32_t sum = 0;
-  for (uint32_t i = b; i < e; i += 8u) {                         // eight loads in flight per step (see wide_scan)
-    uint32_t x[8];
-#pragma unroll
-    for (uint32_t k = 0; k < 8u; k++) x[k] = i + k < e ? tileSum[i + k] : 0u;
+  for (uint32_t i = b; i < e; i += 8u) {                         // eight words per step as two 16-byte loads (load8_fill, build_common.inl)
+    uint32_t x[8]; load8_fill(tileSum, i, e, 0u, x);
 #pragma unroll
     for (uint32_t k = 0; k < 8u; k++) sum += x[k];
   }
@@ -160,11 +158,10 @@ __global__ __launch_bounds__(1024) void presplit_scan(uint32_t* tileSum, uint32_
   if (tid == 0) total[0] = totalAll;
   uint32_t run = s_part[tid];
   for (uint32_t i = b; i < e; i += 8u) {
-    uint32_t x[8];
+    uint32_t x[8], y[8]; load8_fill(tileSum, i, e, 0u, x);
 #pragma unroll
-    for (uint32_t k = 0; k < 8u; k++) x[k] = i + k < e ? tileSum[i + k] : 0u;
-#pragma unroll
-    for (uint32_t k = 0; k < 8u; k++) if (i + k < e) { tileSum[i + k] = run; run += x[k]; }
+    for (uint32_t k = 0; k < 8u; k++) { y[k] = run; run += x[k]; }
+    store8_upto(tileSum, i, e, y);
   }
 }
 // piece 0 replaces the reference, the others go behind the n original references at the scanned offset
@@ -210,7 +207,8 @@ __global__ __launch_bounds__(256) void centroid_bounds(const PrimRef* prims, uin
 //   presplit_scan  places behind the references, in reference order (no atomic decides an index: rebuilds are bit-identical)
 //   outlier_emit   the triangle is clipped against every cell (Sutherland-Hodgman, 6 planes); a cell it really crosses gets a reference of the SAME triangle
 //                  with the clipped polygon's box (widened by 4 ulp, clamped to cell and box), an empty cell leaves a hole; the original is dropped
-//   the stable compaction that squeezes out invalid triangles (compact_*) squeezes out the holes; centroid_bounds recomputes the centroid box.
+//   the stable compaction that squeezes out invalid triangles (compact_*) squeezes out the holes; the root takes the centroid box outlier_mark (the references
+//   that stay) and outlier_clip (the pieces) measured on the way (ctr->cb2).
 // Everything after that is the ordinary binned-SAH build over a few more references (crown stand-in: 12 triangles -> 3,3 k pieces, +0.07 %).  If the
 // outliers' cells do not fit the reserve (N / 16 + 65536 places) nothing is cut: thousands of long pipe triangles are not what this is for.
 constexpr int OUTLIER_MAX_AXIS = 32;
@@ -249,21 +247,35 @@ __device__ __forceinline__ uint32_t outlier_cells(const PrimRef& r, const Counte
   }
   return total;
 }
-__global__ __launch_bounds__(256) void outlier_mark(const PrimRef* prims, uint32_t n, const Counters* ctr, float minRel, float cellFrac, uint32_t* cnt, uint32_t* tileSum) {
-  __shared__ uint32_t s_w[4];
+// (round 6) While it has the references in its registers this kernel also takes (a) the number of valid references of every tile -- what compact_count would read them a
+// third time for (tileCount; outlier_emit takes the cut ones off) -- and (b) the centroid box of the references that are NOT cut (ctr->cb2; outlier_clip adds the pieces'):
+// what centroid_bounds_guarded read the whole array a fourth time for.  min / max over the same set: the root's centroid box does not change by a bit.
+__global__ __launch_bounds__(256) void outlier_mark(const PrimRef* prims, uint32_t n, Counters* ctr, float minRel, float cellFrac, uint32_t* cnt, uint32_t* tileSum, uint32_t* tileCount) {
+  __shared__ uint32_t s_w[4], s_v[4], s_acc[6];
   const uint32_t tid = threadIdx.x, i = blockIdx.x * 256u + tid;
-  uint32_t c = 0u;
+  if (tid < 6u) s_acc[tid] = tid < 3u ? 0xFFFFFFFFu : 0u;
+  uint32_t c = 0u; bool valid = false;
+  uint32_t acc[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
   if (i < n) {
     const PrimRef r = load_prim(prims + i);
     uint32_t nc[3]; float cell[3];
     const uint32_t cells = outlier_cells(r, ctr, minRel, cellFrac, nc, cell);
     c = cells > 1u ? cells : 0u;
     cnt[i] = c;
+    valid = r.geom != NIL;
+    if (valid && c == 0u) for (int d = 0; d < 3; d++) { const uint32_t c2 = enc(r.lo[d] + r.hi[d]); acc[d] = c2; acc[3 + d] = c2; }
   }
   uint32_t x = c; for (int o = 32; o > 0; o >>= 1) x += (uint32_t)__shfl_down((int)x, o, 64);
-  if ((tid & 63u) == 0u) s_w[tid >> 6] = x;
+  const uint32_t nv = (uint32_t)__popcll(__ballot(valid));
+  if ((tid & 63u) == 0u) { s_w[tid >> 6] = x; s_v[tid >> 6] = nv; }
+  __syncthreads();                                               // (s_acc is initialised as well)
+  for (int k = 0; k < 6; k++) {
+    const uint32_t y = k < 3 ? wave_umin63(acc[k]) : wave_umax63(acc[k]);
+    if ((tid & 63u) == 63u) { if (k < 3) atomicMin(&s_acc[k], y); else atomicMax(&s_acc[k], y); }
+  }
+  if (tid == 0u) { tileSum[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3]; tileCount[blockIdx.x] = s_v[0] + s_v[1] + s_v[2] + s_v[3]; }
   __syncthreads();
-  if (tid == 0u) tileSum[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+  if (tid < 6u) { uint32_t* a = &ctr->stripe[blockIdx.x % Counters::STRIPES].cb2[tid]; const uint32_t v = s_acc[tid]; if (tid < 3u) { if (v != 0xFFFFFFFFu) atomicMin(a, v); } else { if (v != 0u) atomicMax(a, v); } }
 }
 // Sutherland-Hodgman: the polygon in `p` (n vertices) against the half space x[axis] <= pos (keepLess) or >= pos; returns the new vertex count (<= n + 1)
 __device__ int clip_halfspace(float (*p)[3], int n, int axis, float pos, bool keepLess) {
@@ -286,7 +298,7 @@ __device__ int clip_halfspace(float (*p)[3], int n, int axis, float pos, bool ke
 // alone: 204 us of a 6.2 ms commit.)  Places come from the scans, so which workgroup clips what does not matter: rebuilds stay bit-identical.
 struct OutlierWork { uint32_t src, base, cells, chunk0; };
 __global__ __launch_bounds__(256) void outlier_emit(PrimRef* prims, uint32_t n, uint32_t cap, const uint32_t* cnt, const uint32_t* tileOfs, const uint32_t* total,
-                                                    Counters* ctr, OutlierWork* work) {
+                                                    Counters* ctr, OutlierWork* work, uint32_t* tileCount) {
   __shared__ uint32_t s_scan[256];
   const uint32_t tid = threadIdx.x, i = blockIdx.x * 256u + tid;
   const uint32_t tot = total[0];
@@ -294,7 +306,9 @@ __global__ __launch_bounds__(256) void outlier_emit(PrimRef* prims, uint32_t n, 
   if (tot > cap) { if (blockIdx.x == 0u && tid == 0u) ctr->outlierSkip = 1u; return; }          // too many / too large outliers for the reserve: nothing is cut
   if (blockIdx.x == 0u && tid == 0u) ctr->outlierCells = tot;
   const uint32_t c = i < n ? cnt[i] : 0u;
-  if (__syncthreads_or(c != 0u) == 0) return;                                                    // no outlier in this tile (all but a dozen of the 18,605 tiles of the crown stand-in)
+  const int cutHere = __syncthreads_count(c != 0u);
+  if (cutHere == 0) return;                                                                      // no outlier in this tile (all but a dozen of the 18,605 tiles of the crown stand-in)
+  if (tid == 0u) tileCount[blockIdx.x] -= (uint32_t)cutHere;                                     // (outlier_mark counted them as valid: outlier_retire takes them out, the compaction squeezes them out)
   s_scan[tid] = c;
   __syncthreads();
   for (uint32_t o = 1; o < 256u; o <<= 1) { uint32_t x = 0; if (tid >= o) x = s_scan[tid - o]; __syncthreads(); s_scan[tid] += x; __syncthreads(); }
@@ -307,10 +321,12 @@ __global__ __launch_bounds__(256) void outlier_emit(PrimRef* prims, uint32_t n, 
 }
 __global__ __launch_bounds__(256) void outlier_clip(PrimRef* prims, uint32_t cap, const GeomDesc* geoms, const uint32_t* total, Counters* ctr, const OutlierWork* work,
                                                     float minRel, float cellFrac) {
-  __shared__ uint32_t s_pieces, s_holes;
+  __shared__ uint32_t s_pieces, s_holes, s_acc[6];
   const uint32_t tid = threadIdx.x;
   const uint32_t tot = total[0];
   if (tot == 0u || tot > cap) return;
+  if (tid < 6u) s_acc[tid] = tid < 3u ? 0xFFFFFFFFu : 0u;
+  uint32_t acc[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};                            // centroid box of this thread's pieces (ctr->cb2, see outlier_mark)
   const unsigned long long w = ctr->outlierWork;                                                 // (final: outlier_emit is over)
   const uint32_t numWork = (uint32_t)(w >> 32), numChunks = (uint32_t)w;
   if (tid == 0u) { s_pieces = 0u; s_holes = 0u; }
@@ -343,6 +359,7 @@ __global__ __launch_bounds__(256) void outlier_clip(PrimRef* prims, uint32_t cap
         for (int d = 0; d < 3; d++) {                                                            // interpolated points: 4 ulp of their magnitude, then the cell and the triangle's own box
           const float e = 4.76837158e-7f * fmaxf(fabsf(blo[d]), fabsf(bhi[d]));
           o.lo[d] = fmaxf(fmaxf(blo[d] - e, lo[d] - e), ref.lo[d]); o.hi[d] = fminf(fminf(bhi[d] + e, hi[d] + e), ref.hi[d]);
+          const uint32_t c2 = enc(o.lo[d] + o.hi[d]); acc[d] = min(acc[d], c2); acc[3 + d] = max(acc[3 + d], c2);
         }
         pieces++;
       } else { o.geom = NIL; holes++; }                                                          // the triangle does not cross this cell: a hole, squeezed out by the compaction
@@ -352,8 +369,10 @@ __global__ __launch_bounds__(256) void outlier_clip(PrimRef* prims, uint32_t cap
   }
   if (pieces) atomicAdd(&s_pieces, pieces);
   if (holes) atomicAdd(&s_holes, holes);
+  if (pieces) for (int k = 0; k < 6; k++) { if (k < 3) atomicMin(&s_acc[k], acc[k]); else atomicMax(&s_acc[k], acc[k]); }   // (a few dozen workgroups of a commit get here at all)
   __syncthreads();
   if (tid == 0u && (s_pieces | s_holes | cut)) { atomicAdd(&ctr->outlierPieces, s_pieces); atomicAdd(&ctr->numOutliers, cut); atomicAdd(&ctr->numInvalid, s_holes + cut); }
+  if (tid < 6u && s_pieces) { uint32_t* a = &ctr->stripe[blockIdx.x % Counters::STRIPES].cb2[tid]; if (tid < 3u) atomicMin(a, s_acc[tid]); else atomicMax(a, s_acc[tid]); }
 }
 // the originals go once every chunk has read them: their pieces stand for them
 __global__ __launch_bounds__(256) void outlier_retire(PrimRef* prims, uint32_t cap, const uint32_t* total, const Counters* ctr, const OutlierWork* work) {
@@ -363,29 +382,4 @@ __global__ __launch_bounds__(256) void outlier_retire(PrimRef* prims, uint32_t c
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < numWork; i += gridDim.x * 256u) {
     PrimRef dead = load_prim(prims + work[i].src); dead.geom = NIL; store_prim(prims + work[i].src, dead);
   }
-}
-__global__ void centroid_reset(Counters* ctr) {                 // the pieces' centres are not the triangles': the centroid box is measured again (centroid_bounds)
-  if (threadIdx.x == 0u && blockIdx.x == 0u && ctr->outlierPieces != 0u) for (int k = 6; k < 12; k++) ctr->bounds[k] = k < 9 ? ENC_POS_INF : ENC_NEG_INF;
-}
-__global__ __launch_bounds__(256) void centroid_bounds_guarded(const PrimRef* prims, Counters* ctr) {
-  if (ctr->outlierPieces == 0u) return;
-  __shared__ uint32_t s_acc[6];
-  if (threadIdx.x < 6u) s_acc[threadIdx.x] = threadIdx.x < 3u ? 0xFFFFFFFFu : 0u;
-  __syncthreads();
-  const uint32_t n = ctr->numPrims;
-  uint32_t acc[6]; for (int k = 0; k < 6; k++) acc[k] = k < 3 ? 0xFFFFFFFFu : 0u;
-  const uint32_t stride = gridDim.x * 256u;
-  for (uint32_t p0 = blockIdx.x * 256u + threadIdx.x; p0 < n; p0 += 4u * stride) {   // (four loads in flight, see outlier_area)
-    PrimRef r[4]; bool v[4];
-#pragma unroll
-    for (uint32_t k = 0; k < 4u; k++) { v[k] = p0 + k * stride < n; if (v[k]) r[k] = load_prim(prims + p0 + k * stride); }
-#pragma unroll
-    for (uint32_t k = 0; k < 4u; k++) if (v[k]) for (int d = 0; d < 3; d++) { const uint32_t c2 = enc(r[k].lo[d] + r[k].hi[d]); acc[d] = min(acc[d], c2); acc[3 + d] = max(acc[3 + d], c2); }
-  }
-  for (int k = 0; k < 6; k++) {
-    const uint32_t x = k < 3 ? wave_umin63(acc[k]) : wave_umax63(acc[k]);
-    if ((threadIdx.x & 63u) == 63u) { if (k < 3) atomicMin(&s_acc[k], x); else atomicMax(&s_acc[k], x); }
-  }
-  __syncthreads();
-  if (threadIdx.x < 6u) { if (threadIdx.x < 3u) atomicMin(&ctr->bounds[6 + threadIdx.x], s_acc[threadIdx.x]); else atomicMax(&ctr->bounds[6 + threadIdx.x], s_acc[threadIdx.x]); }
 }

@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void primref_gen(const GeomDesc* geoms, uint32
   const unsigned long long bad = __ballot(nInvalid != 0u);
   if (bad != 0ull && nInvalid) atomicAdd(&ctr->numInvalid, nInvalid);
   __syncthreads();
-  if (tid < 12) { if (tid % 6 < 3) atomicMin(&ctr->bounds[tid], s_acc[tid]); else atomicMax(&ctr->bounds[tid], s_acc[tid]); }
+  if (tid < 12) { if (tid % 6 < 3) atomic_min_if_less(&ctr->bounds[tid], s_acc[tid]); else atomic_max_if_more(&ctr->bounds[tid], s_acc[tid]); }   // (4096 workgroups, twelve words of one line: only what improves them)
   if (tid == 0u && areaPart) { AreaPart ap; ap.area = ((s_area[0] + s_area[1]) + s_area[2]) + s_area[3]; ap.count = (unsigned long long)s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3]; areaPart[blockIdx.x] = ap; }
 }
 
@@ -100,29 +100,30 @@ __global__ void build_begin(Counters* ctr) {
   for (uint32_t i = t; i < sizeof(Counters) / 4u; i += blockDim.x) w[i] = 0u;
   __syncthreads();
   if (t < 12u) ctr->bounds[t] = (t % 6u < 3u) ? ENC_POS_INF : ENC_NEG_INF;
+  for (uint32_t i = t; i < Counters::STRIPES * 6u; i += blockDim.x) ctr->stripe[i / 6u].cb2[i % 6u] = (i % 6u) < 3u ? ENC_POS_INF : ENC_NEG_INF;   // (the stripes' sums start at zero: cleared above)
   if (t == 0u) { ctr->rootRef = MI355_EMPTY_REF; ctr->localFirst = 0xFFFFFFFFu; }
 }
 
 // rare path: stable compaction of the valid PrimRefs (tile = 256 consecutive entries).  `ctr` != nullptr: the commit runs without a host round trip
 // after primref_gen, so the kernels are always enqueued and return at once when there is nothing to squeeze out.
 // (one-round-trip commits with outlier pieces behind the references: `n` is the capacity, what is really there ends at base + ctr->outlierCells)
-__global__ __launch_bounds__(256) void compact_count(const PrimRef* in, uint32_t n, uint32_t* tileCount, const Counters* ctr, uint32_t base) {
+// firstTile: the tiles in front of it have been counted already (MEDIUM commits with the outlier cut: outlier_mark counts the valid references of every tile while it looks
+// at them, outlier_emit takes the cut ones off -- this kernel then only covers the tile N falls into and the reserve behind it, not 152 MB of references a third time)
+__global__ __launch_bounds__(256) void compact_count(const PrimRef* in, uint32_t n, uint32_t* tileCount, const Counters* ctr, uint32_t base, uint32_t firstTile) {
   if (ctr && ctr->numInvalid == 0u) return;
   if (ctr) n = min(n, base + ctr->outlierCells);
-  const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+  const uint32_t tile = firstTile + blockIdx.x, p = tile * 256u + threadIdx.x;
   const bool ok = p < n && in[p].geom != NIL;
   const int c = __syncthreads_count(ok);
-  if (threadIdx.x == 0) tileCount[blockIdx.x] = (uint32_t)c;
+  if (threadIdx.x == 0) tileCount[tile] = (uint32_t)c;
 }
 __global__ __launch_bounds__(1024) void compact_scan(uint32_t* tileCount, uint32_t numTiles, Counters* ctr, uint32_t guarded) {
   __shared__ uint32_t s_part[1024], s_first[1024];
   if (guarded && ctr->numInvalid == 0u) return;
   const uint32_t tid = threadIdx.x, per = ((numTiles + 1023u) / 1024u + 7u) & ~7u, b = min(tid * per, numTiles), e = min(b + per, numTiles);
   uint32_t sum = 0, first = 0xFFFFFFFFu;                       // first tile that is not completely valid: nothing in front of it moves
-  for (uint32_t i = b; i < e; i += 8u) {                         // eight loads in flight per step (see wide_scan)
-    uint32_t x[8];
-#pragma unroll
-    for (uint32_t k = 0; k < 8u; k++) x[k] = i + k < e ? tileCount[i + k] : 256u;
+  for (uint32_t i = b; i < e; i += 8u) {                         // eight words per step as two 16-byte loads (load8_fill)
+    uint32_t x[8]; load8_fill(tileCount, i, e, 256u, x);
 #pragma unroll
     for (uint32_t k = 0; k < 8u; k++) { if (i + k < e) sum += x[k]; if (x[k] != 256u && first == 0xFFFFFFFFu) first = i + k; }
   }
@@ -132,11 +133,10 @@ __global__ __launch_bounds__(1024) void compact_scan(uint32_t* tileCount, uint32
   if (tid == 0) { const uint32_t f = s_first[0]; ctr->numPrims = total; ctr->compactFrom = f == 0xFFFFFFFFu ? total : f * 256u; }
   uint32_t run = s_part[tid];
   for (uint32_t i = b; i < e; i += 8u) {
-    uint32_t x[8];
+    uint32_t x[8], y[8]; load8_fill(tileCount, i, e, 0u, x);
 #pragma unroll
-    for (uint32_t k = 0; k < 8u; k++) x[k] = i + k < e ? tileCount[i + k] : 0u;
-#pragma unroll
-    for (uint32_t k = 0; k < 8u; k++) if (i + k < e) { tileCount[i + k] = run; run += x[k]; }
+    for (uint32_t k = 0; k < 8u; k++) { y[k] = run; run += x[k]; }
+    store8_upto(tileCount, i, e, y);
   }
 }
 __global__ __launch_bounds__(256) void compact_scatter(const PrimRef* in, uint32_t n, const uint32_t* tileOfs, PrimRef* out, const Counters* ctr, uint32_t base) {
@@ -169,8 +169,15 @@ __global__ void root_setup(Counters* ctr, BNode* bnodes, Seg* segs0, SmallEntry*
   ctr->numPrims = n;
   float glo[3], ghi[3], clo[3], chi[3];
   for (int d = 0; d < 3; d++) { glo[d] = dec(ctr->bounds[d]); ghi[d] = dec(ctr->bounds[3 + d]); clo[d] = dec(ctr->bounds[6 + d]); chi[d] = dec(ctr->bounds[9 + d]); }
+  // pieces have other centres than their triangles: if anything was cut, the centroid box is the one outlier_mark and outlier_clip measured over the references that stay
+  // and the pieces (was: centroid_reset + centroid_bounds_guarded, a pass of its own over the compacted array: 45 us of a 4.75 ms commit)
+  if (ctr->outlierPieces != 0u) {
+    uint32_t c2[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
+    for (uint32_t r = 0; r < Counters::STRIPES; r++) for (int k = 0; k < 6; k++) { const uint32_t v = ctr->stripe[r].cb2[k]; c2[k] = k < 3 ? min(c2[k], v) : max(c2[k], v); }
+    for (int d = 0; d < 3; d++) { clo[d] = dec(c2[d]); chi[d] = dec(c2[3 + d]); ctr->bounds[6 + d] = c2[d]; ctr->bounds[9 + d] = c2[3 + d]; }
+  }
   ctr->rootArea = n ? fmaf(ghi[0] - glo[0], (ghi[1] - glo[1]) + (ghi[2] - glo[2]), (ghi[1] - glo[1]) * (ghi[2] - glo[2])) : 0.0f;
-  ctr->numBLeaves = 0; ctr->numSegsNext = 0; ctr->numChunks = 0; ctr->numSmall = 0; ctr->numSegs = 0; ctr->topLevels = 0;
+  ctr->numSegsNext = 0; ctr->numChunks = 0; ctr->numSmall = 0; ctr->numSegs = 0; ctr->topLevels = 0;
   if (n == 0u) return;
   BNode rootB{}; for (int d = 0; d < 3; d++) { rootB.lo[d] = glo[d]; rootB.hi[d] = ghi[d]; } rootB.begin = 0; rootB.end = n; rootB.left = rootB.right = NIL; rootB.splitSah = __builtin_inff();
   bnodes[0] = rootB;

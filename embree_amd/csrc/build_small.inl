@@ -275,7 +275,7 @@ __device__ void micro_flush(uint32_t* R, unsigned long long* s_key, const MicroR
       segB = X[512] & 0xFFu; segE = X[512] >> 8; node = X[576]; gsb = X[640];
     }
   }
-  if (lane == 0u && leaves) atomicAdd(&ctr->numBLeaves, leaves);
+  if (lane == 0u && leaves) atomicAdd(&ctr->stripe[blockIdx.x % Counters::STRIPES].numBLeaves, leaves);
   MICRO_SYNC();
 }
 

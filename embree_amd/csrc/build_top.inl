@@ -304,7 +304,7 @@ __global__ __launch_bounds__(256) void top_local(const Seg* segs, const PrimRef*
   const uint32_t numSegs = ctr->numSegs;
   const uint32_t begin = s < numSegs ? sg->begin : 0u, end = s < numSegs ? sg->end : 0u, n = end - begin;
   if (s < numSegs && n <= CHUNK) {                               // (workgroup-uniform)
-    if (tid == 0u) atomicMin(&ctr->localFirst, level);
+    if (tid == 0u && level < __hip_atomic_load(&ctr->localFirst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&ctr->localFirst, level);   // (thousands of workgroups per level: only the first few send it)
     float cmn[3], cmx[3]; for (int d = 0; d < 3; d++) { cmn[d] = sg->cmin[d]; cmx[d] = sg->cmax[d]; }
     const Mapping m = make_mapping(n, cmn, cmx);
     bins_clear_copies(s_bins, tid, 256u);

@@ -44,7 +44,7 @@ __global__ void wide_root(WideItem* items, Counters* ctr) {
   // nothing may walk that tree -- leaf ids from whatever the arena held sent tri_records to wild addresses (a rare abort in the test suite, found in round 4).
   const bool unfinished = ctr->numSegs != 0u || ctr->overflow != 0u;
   const bool any = ctr->numPrims != 0u && !unfinished;         // (a scene whose triangles are all invalid has no tree)
-  ctr->rootRef = any ? 0u : MI355_EMPTY_REF; ctr->numWide = any ? 1u : 0u; ctr->wideCount[0] = any ? 1u : 0u; ctr->wideCount[1] = 0; ctr->wideDepth = 0; ctr->lvlStart[0] = 0; ctr->numLeaves = 0; ctr->numTrisOut = 0; ctr->sahFixed = 0ull;
+  ctr->rootRef = any ? 0u : MI355_EMPTY_REF; ctr->numWide = any ? 1u : 0u; ctr->wideCount[0] = any ? 1u : 0u; ctr->wideCount[1] = 0; ctr->wideDepth = 0; ctr->lvlStart[0] = 0; ctr->numTrisOut = 0;   // (leaf count and SAH sum: the stripes, zero since build_begin)
 }
 
 template <typename T> __device__ __forceinline__ T grp_get(T v, uint32_t lane, uint32_t idx) { return __shfl(v, (int)((lane & ~7u) | idx), 64); }
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(64) void wide_plan(const WideItem* items, const BNo
   }
   if (lane == 0u) groupSum[blockIdx.x] = make_uint2(runI, runT);   // (every workgroup of the grid: wide_scan reads all of them)
   for (int o = 8; o < 64; o <<= 1) sahAcc += (unsigned long long)__shfl_xor((long long)sahAcc, o, 64);   // lanes with c == 0 hold the partial sums
-  if (lane == 0u) { if (sahAcc) atomicAdd(&ctr->sahFixed, sahAcc); if (leafAcc) atomicAdd(&ctr->numLeaves, leafAcc); }
+  if (lane == 0u) { Counters::Stripe* sp = &ctr->stripe[blockIdx.x % Counters::STRIPES]; if (sahAcc) atomicAdd(&sp->sahFixed, sahAcc); if (leafAcc) atomicAdd(&sp->numLeaves, leafAcc); }   // (a stripe per 128 workgroups: see Counters)
 }
 
 // one block: exclusive scan of the workgroups' totals in workgroup (= item) order; publishes the level's bases and the next level's item count
