@@ -343,7 +343,7 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
     LAUNCH(compact_scan, dim3(1), dim3(1024), 0, st, tileCount.p, ctiles, ctr.p, 1u);
     LAUNCH(compact_scatter, dim3(ctiles), dim3(256), 0, st, bufA.p, NC, tileCount.p, bufB.p, ctr.p, N);
     LAUNCH(compact_copyback, dim3(ctiles < 2048u ? ctiles : 2048u), dim3(256), 0, st, bufB.p, bufA.p, ctr.p);
-    LAUNCH(root_setup, dim3(1), dim3(1), 0, st, ctr.p, bnodes.p, segs0.p, small.p, N, prm.small);
+    LAUNCH(root_setup, dim3(1), dim3(64), 0, st, ctr.p, bnodes.p, segs0.p, small.p, N, prm.small);
     numSegs = N > prm.small ? 1u : 0u;
     if (prm.spatial && numSegs) {                                 // split budgets of the references; the root set owns everything behind them
       LAUNCH(spatial_area_sum, dim3(tiles < 2048u ? tiles : 2048u), dim3(256), 0, st, bufA.p, N, ctr.p, 1u);
@@ -351,6 +351,7 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
       LAUNCH(segx_root, dim3(1), dim3(1), 0, st, segx0.p, NC);
     }
   } else {
+    LAUNCH(bounds_fold, dim3(1), dim3(64), 0, st, ctr.p);
     SYNC_READ(h);
     h.numPrims = N - h.numInvalid;
     if (h.numInvalid) {                                          // rare: squeeze the invalid triangles out (stable)

@@ -42,7 +42,7 @@ struct SmallEntry { uint32_t begin, end, bnode, buf; float cmin[3], cmax[3]; };
 struct Chunk { uint32_t seg, begin, end; };
 struct WideItem { uint32_t bnode, node; };
 struct Counters {
-  uint32_t numPrims, pad_a, pad_d, numChunks, pad_e, numWide, numWideNext, pad_b;
+  uint32_t numPrims, pad_a, pad_d, pad_f, pad_e, numWide, numWideNext, pad_b;
   uint32_t bounds[12];                          // scene geom lo/hi + centroid lo/hi (ordered uint)
   uint32_t overflow, rootRef, numTrisOut, numInvalid;
   uint32_t numSegs, topLevels, wideDepth, lvlNodeBase, lvlTriBase, wideCount[2];      // level loops are driven from the device: no host readback per level
@@ -59,8 +59,9 @@ struct Counters {
   uint32_t padC[2];
   unsigned long long smTime[4];                  // -DSM_TIME: wave cycles small_build spent binning / pricing / partitioning / in the micro mode
   uint32_t lvlStart[64];                          // first node of every level of the wide tree (numbering is breadth first): what a refit walks bottom-up
-  alignas(128) uint32_t numSmall; uint32_t numSegsNext;   // lengths of the work lists the top phase appends to, on a line of their own: top_local appends twice per workgroup, and every
-                                                  // one of its thousands of workgroups reads numSegs first (top_local 383 -> 358 us per commit with the appends off that line)
+  alignas(128) uint32_t numSmall; uint32_t numSegsNext; uint32_t numChunks;   // lengths of the work lists the top phase appends to, on a line of their own: top_local appends twice per workgroup, and every
+                                                  // one of its thousands of workgroups reads numSegs first (top_local 383 -> 358 us per commit with the appends off that line;
+                                                  // the two lengths on a line EACH: top_emit 129 -> 191 us, top_local unchanged -- they stay together)
   // Words that EVERY workgroup of a large grid sends an atomic to.  Atomic instructions on ONE cache line are served one after the other, ~10 ns each when they come from all
   // CUs (MI355X_MICROARCH.md "fanin"): the 8192 workgroups of a large level of wide_plan ended on 2 x 8192 of them -- ~80 us of the 175 us of the widest level, 250 us per
   // commit (found when both words were moved onto ONE line: 577 -> 850 us) -- and outlier_mark with six words per workgroup on one line took 140 us instead of 25.  A
@@ -70,10 +71,21 @@ struct Counters {
     uint32_t numLeaves;                           // leaf slots of the wide tree: wide_plan
     uint32_t numBLeaves;                          // leaves of the binary tree: small_build (LOW: stripe 0 holds n)
     uint32_t cb2[6];                              // MEDIUM builds that cut outliers: centroid lo/hi over the references that stay (outlier_mark) and the pieces (outlier_clip): the root's centroid box if anything was cut
+    uint32_t bounds[12];                          // what primref_gen's workgroups found (scene geom lo/hi + centroid lo/hi): folded into Counters::bounds by fold_bounds (outlier_stats / root_setup / bounds_fold)
   };
   static constexpr uint32_t STRIPES = 64u;
   Stripe stripe[STRIPES];
 };
+// word k of the scene bounds = the fold of what primref_gen's workgroups left in their stripes (idempotent: may run more than once)
+__device__ __forceinline__ void fold_bounds(Counters* ctr, uint32_t k) {
+  uint32_t x[Counters::STRIPES];
+#pragma unroll
+  for (uint32_t r = 0; r < Counters::STRIPES; r++) x[r] = ctr->stripe[r].bounds[k];   // (all loads before the first use: one round trip)
+  uint32_t v = ctr->bounds[k];
+#pragma unroll
+  for (uint32_t r = 0; r < Counters::STRIPES; r++) v = (k % 6u) < 3u ? (x[r] < v ? x[r] : v) : (x[r] > v ? x[r] : v);
+  ctr->bounds[k] = v;
+}
 struct Params { uint32_t shift, minLeaf, maxLeaf, small; float travCost, intCost; uint32_t quality, spatial; };
 
 // order-preserving float <-> uint so that integer atomicMin/Max reduce floats exactly
@@ -158,11 +170,6 @@ __device__ __forceinline__ void store8_upto(uint32_t* p, uint32_t i, uint32_t e,
     for (uint32_t k = 0; k < 8u; k++) if (i + k < e) p[i + k] = y[k];
   }
 }
-// min / max atomics of a workgroup's result on a word that EVERY workgroup of the grid reports to: only a value that improves on what the word holds is sent.  What the load
-// returns may be older than the word (another XCD's atomic on its way): then the atomic is sent although it changes nothing -- never the other way round, the word only moves
-// in one direction.  (18,605 workgroups x 6 atomics on one cache line are ~80 us at the ~0.75 ns a same-line atomic costs, profiles/r06_top_level_atomics.md.)
-__device__ __forceinline__ void atomic_min_if_less(uint32_t* p, uint32_t v) { if (v < __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(p, v); }
-__device__ __forceinline__ void atomic_max_if_more(uint32_t* p, uint32_t v) { if (v > __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(p, v); }
 // s[0..1024) becomes its exclusive scan, the total is returned to every thread
 __device__ __forceinline__ uint32_t block_exclusive_scan_1024(uint32_t* s, uint32_t tid) {
   __shared__ uint2 s_w[17];

@@ -220,6 +220,7 @@ __device__ __forceinline__ float ctr_root_area2(const Counters* ctr, float (&ext
 __global__ __launch_bounds__(1024) void outlier_stats(const AreaPart* part, uint32_t numParts, Counters* ctr) {
   __shared__ double s_a[1024]; __shared__ unsigned long long s_c[1024];
   const uint32_t tid = threadIdx.x, per = (numParts + 1023u) / 1024u, b = min(tid * per, numParts), e = min(b + per, numParts);
+  if (tid < 12u) fold_bounds(ctr, tid);                          // (the scene bounds outlier_mark reads: primref_gen's stripes)
   double a = 0.0; unsigned long long c = 0ull;
   for (uint32_t i = b; i < e; i++) { a += part[i].area; c += part[i].count; }
   s_a[tid] = a; s_c[tid] = c; __syncthreads();

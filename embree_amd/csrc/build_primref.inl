@@ -89,7 +89,10 @@ __global__ __launch_bounds__(256) void primref_gen(const GeomDesc* geoms, uint32
   const unsigned long long bad = __ballot(nInvalid != 0u);
   if (bad != 0ull && nInvalid) atomicAdd(&ctr->numInvalid, nInvalid);
   __syncthreads();
-  if (tid < 12) { if (tid % 6 < 3) atomic_min_if_less(&ctr->bounds[tid], s_acc[tid]); else atomic_max_if_more(&ctr->bounds[tid], s_acc[tid]); }   // (4096 workgroups, twelve words of one line: only what improves them)
+  if (tid < 12) {                                                // (4096 workgroups: each to its stripe, see Counters::stripe; fold_bounds makes Counters::bounds of them)
+    uint32_t* a = &ctr->stripe[blockIdx.x % Counters::STRIPES].bounds[tid]; const uint32_t v = s_acc[tid];
+    if (tid % 6 < 3) { if (v != ENC_POS_INF) atomicMin(a, v); } else { if (v != ENC_NEG_INF) atomicMax(a, v); }
+  }
   if (tid == 0u && areaPart) { AreaPart ap; ap.area = ((s_area[0] + s_area[1]) + s_area[2]) + s_area[3]; ap.count = (unsigned long long)s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3]; areaPart[blockIdx.x] = ap; }
 }
 
@@ -101,6 +104,7 @@ __global__ void build_begin(Counters* ctr) {
   __syncthreads();
   if (t < 12u) ctr->bounds[t] = (t % 6u < 3u) ? ENC_POS_INF : ENC_NEG_INF;
   for (uint32_t i = t; i < Counters::STRIPES * 6u; i += blockDim.x) ctr->stripe[i / 6u].cb2[i % 6u] = (i % 6u) < 3u ? ENC_POS_INF : ENC_NEG_INF;   // (the stripes' sums start at zero: cleared above)
+  for (uint32_t i = t; i < Counters::STRIPES * 12u; i += blockDim.x) ctr->stripe[i / 12u].bounds[i % 12u] = (i % 6u) < 3u ? ENC_POS_INF : ENC_NEG_INF;
   if (t == 0u) { ctr->rootRef = MI355_EMPTY_REF; ctr->localFirst = 0xFFFFFFFFu; }
 }
 
@@ -163,8 +167,12 @@ __global__ __launch_bounds__(256) void compact_copyback(const PrimRef* in, PrimR
 // Root of the binary tree and the first work item, made on the device from what primref_gen (and the compaction) left in the counters: the commit
 // needs no host round trip to learn the scene bounds or the number of valid triangles (the reference: PrimInfo pinfo = createPrimRefArray(...),
 // bvh_builder_sah.cpp:136, then BVHBuilderBinnedSAH::build(pinfo) -- one address space, no round trip there either).
-__global__ void root_setup(Counters* ctr, BNode* bnodes, Seg* segs0, SmallEntry* small, uint32_t totalPrims, uint32_t smallThreshold) {
-  if (threadIdx.x != 0u || blockIdx.x != 0u) return;
+__global__ void bounds_fold(Counters* ctr) { if (blockIdx.x == 0u && threadIdx.x < 12u) fold_bounds(ctr, threadIdx.x); }   // (stepwise path: the host reads the bounds next)
+__global__ void root_setup(Counters* ctr, BNode* bnodes, Seg* segs0, SmallEntry* small, uint32_t totalPrims, uint32_t smallThreshold) {   // one workgroup of 64 threads
+  if (blockIdx.x != 0u) return;
+  if (threadIdx.x < 12u) fold_bounds(ctr, threadIdx.x);          // (commits without the outlier cut: nobody has folded primref_gen's stripes yet)
+  __syncthreads();
+  if (threadIdx.x != 0u) return;
   const uint32_t n = ctr->numInvalid ? ctr->numPrims : totalPrims;
   ctr->numPrims = n;
   float glo[3], ghi[3], clo[3], chi[3];
