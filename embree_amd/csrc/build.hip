@@ -464,7 +464,8 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
       Seg* t = cur; cur = nxt; nxt = t; level++;
       return;
     }
-    LAUNCH(top_setup, dim3(segBound), dim3(256), 0, st, cur, bins.p, chunks.p, ctr.p, localMax, level, chunkFlag.p, binsTop.p);
+    const uint32_t listBlocks = (segBound + SETUP_SEGS - 1u) / SETUP_SEGS;
+    LAUNCH(top_setup, dim3(listBlocks + segBound), dim3(256), 0, st, cur, bins.p, chunks.p, ctr.p, localMax, level, chunkFlag.p, binsTop.p, listBlocks);
     LAUNCH(top_bin, dim3(chunkBound), dim3(256), 0, st, cur, chunks.p, src, bins.p, ctr.p, chunkCnt.p, maxChunks, binsTop.p);
     LAUNCH(top_split, dim3(segBound), dim3(64), 0, st, cur, bins.p, bnodes.p, ctr.p, prm, forceFallback, xcur, (const uint32_t*)chunkCnt.p, chunkBase.p, localMax, maxChunks, accTop.p, (const uint32_t*)binsTop.p);
     if (spatial) {                                          // sets whose object split leaves overlapping children try a spatial split

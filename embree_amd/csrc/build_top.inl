@@ -2,32 +2,60 @@
 // Part of build.hip (included inside its anonymous namespace); see the header of build.hip for the pipeline.
 // ------------------------------------------------------------------------------------ K2 top phase
 constexpr uint32_t ACC_SETS = 16u, ACC_REPL = 8u, ACC_STRIDE = 32u;   // levels of at most ACC_SETS sets: ACC_REPL copies of a set's bins (top_bin) and of its children's bounds record (acc_copy; ACC_STRIDE words per copy, 24 used: 128 bytes)
-// localMax: sets of at most this many references are top_local's at this level (0: none are), the four kernels of the chunked path leave them alone
-__global__ __launch_bounds__(256) void top_setup(Seg* segs, uint32_t* bins, Chunk* chunks, Counters* ctr, uint32_t localMax, uint32_t level, uint32_t* chunkFlag, uint32_t* binsTop) {
-  __shared__ uint32_t s_base;
-  const uint32_t s = blockIdx.x, tid = threadIdx.x;
-  if (s >= ctr->numSegs) return;                                // the grid is an upper bound (2^level segments at most)
-  Seg* sg = segs + s;
-  const uint32_t begin = sg->begin, end = sg->end, n = end - begin;
-  if (n <= localMax) return;
-  if (tid == 0u) ctr->chunkedLevels = level + 1u;               // (every writer of a level writes the same value; levels are launches, in order)
-  const uint32_t nch = (n + CHUNK - 1u) / CHUNK;
-  if (nch > 1u) {                                              // (a set of one chunk: top_bin writes its bins as they are -- clearing them was 54 MB per level of a HIGH commit)
-    if (binsTop && ctr->numSegs <= ACC_SETS) { for (uint32_t r = 0; r < ACC_REPL; r++) bins_clear(binsTop + ((size_t)s * ACC_REPL + r) * BINS_WORDS, tid, 256u); }   // the copies the chunks merge into (top_bin); top_split folds them
+// localMax: sets of at most this many references are top_local's at this level (0: none are), the four kernels of the chunked path leave them alone.
+// A workgroup sets up SETUP_SEGS sets: a lane per set takes its bin mapping and the number of its chunks, ONE atomic per workgroup reserves the chunks of all of them
+// (was: a workgroup and a returning atomic per set -- at the levels of a HIGH commit where every one of ~10,000 sets takes the chunked path those atomics, ~10 ns each on
+// one word, were the kernel: 100 us a level, 300 us of a 10.5 ms commit), then the 256 threads write the chunk list.
+constexpr uint32_t SETUP_SEGS = 64u;
+__global__ __launch_bounds__(256) void top_setup(Seg* segs, uint32_t* bins, Chunk* chunks, Counters* ctr, uint32_t localMax, uint32_t level, uint32_t* chunkFlag, uint32_t* binsTop, uint32_t listBlocks) {
+  __shared__ uint32_t s_begin[SETUP_SEGS], s_end[SETUP_SEGS], s_c0[SETUP_SEGS], s_pre[SETUP_SEGS + 1u];
+  const uint32_t tid = threadIdx.x, numSegs = ctr->numSegs;
+  // the grid: listBlocks workgroups that reserve and write the chunk lists of SETUP_SEGS sets each, then one workgroup PER SET that clears the bins of a set of several
+  // chunks (the copies the chunks merge into, at the upper levels: 8 x 2.7 KB per set -- all of a level's clears in 36 workgroups took 40 us where 2325 take 5)
+  if (blockIdx.x >= listBlocks) {
+    const uint32_t s = blockIdx.x - listBlocks;
+    if (s >= numSegs) return;
+    const uint32_t n = segs[s].end - segs[s].begin;
+    if (n <= localMax || n <= CHUNK) return;                     // (a set of one chunk: top_bin writes its bins as they are -- clearing them was 54 MB per level of a HIGH commit)
+    if (binsTop && numSegs <= ACC_SETS) { for (uint32_t r = 0; r < ACC_REPL; r++) bins_clear(binsTop + ((size_t)s * ACC_REPL + r) * BINS_WORDS, tid, 256u); }   // the copies the chunks merge into (top_bin); top_split folds them
     else bins_clear(bins + (size_t)s * BINS_WORDS, tid, 256u);
+    return;
   }
-  if (tid == 0) {
-    const Mapping m = make_mapping(n, sg->cmin, sg->cmax);
-    for (int d = 0; d < 3; d++) { sg->ofs[d] = m.ofs[d]; sg->scale[d] = m.scale[d]; }
-    sg->nb = m.nb;
-    s_base = atomicAdd(&ctr->numChunks, nch);
-    sg->chunk0 = s_base;
+  const uint32_t s0 = blockIdx.x * SETUP_SEGS;
+  if (s0 >= numSegs) return;                                    // the grid is an upper bound (2^level segments at most)
+  if (tid < SETUP_SEGS) {                                       // (wave 0, all of its lanes: the scan below needs them)
+    const uint32_t s = s0 + tid;
+    uint32_t begin = 0u, end = 0u, nch = 0u;
+    if (s < numSegs) {
+      Seg* sg = segs + s;
+      begin = sg->begin; end = sg->end;
+      const uint32_t n = end - begin;
+      if (n > localMax) {
+        nch = (n + CHUNK - 1u) / CHUNK;
+        const Mapping m = make_mapping(n, sg->cmin, sg->cmax);
+        for (int d = 0; d < 3; d++) { sg->ofs[d] = m.ofs[d]; sg->scale[d] = m.scale[d]; }
+        sg->nb = m.nb;
+      }
+    }
+    const uint32_t incl = wave_incl_scan_u32(nch), total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    uint32_t base = 0u;
+    if (tid == 0u && total != 0u) { base = atomicAdd(&ctr->numChunks, total); ctr->chunkedLevels = level + 1u; }   // (every writer of a level writes the same value; levels are launches, in order)
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    const uint32_t c0 = base + incl - nch;
+    if (nch != 0u) segs[s].chunk0 = c0;
+    s_begin[tid] = begin; s_end[tid] = end; s_c0[tid] = c0; s_pre[tid] = incl - nch;
+    if (tid == SETUP_SEGS - 1u) s_pre[SETUP_SEGS] = incl;
   }
   __syncthreads();
-  for (uint32_t c = tid; c < nch; c += 256u) {
-    Chunk ck; ck.seg = s; ck.begin = begin + c * CHUNK; ck.end = min(ck.begin + CHUNK, end);
-    chunks[s_base + c] = ck;
-    if (chunkFlag) chunkFlag[s_base + c] = 0u;                    // spatial-split builds: "this chunk has not said yet how many references it sends to either side" (spatial_partition)
+  const uint32_t total = s_pre[SETUP_SEGS];
+  for (uint32_t j = tid; j < total; j += 256u) {                  // chunk j of this workgroup's sets: the last set whose first chunk is <= j
+    uint32_t l = 0u;
+#pragma unroll
+    for (uint32_t step = SETUP_SEGS / 2u; step != 0u; step >>= 1) if (s_pre[l + step] <= j) l += step;
+    const uint32_t c = j - s_pre[l];
+    Chunk ck; ck.seg = s0 + l; ck.begin = s_begin[l] + c * CHUNK; ck.end = min(ck.begin + CHUNK, s_end[l]);
+    chunks[s_c0[l] + c] = ck;
+    if (chunkFlag) chunkFlag[s_c0[l] + c] = 0u;                   // spatial-split builds: "this chunk has not said yet how many references it sends to either side" (spatial_partition)
   }
 }
 
