@@ -473,7 +473,7 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
       LAUNCH(spatial_bin, dim3(chunkBound), dim3(256), 0, st, cur, xcur, chunks.p, src, dGeoms.p, sbins.p, ctr.p, sbinsTop.p);
       LAUNCH(spatial_best, dim3(segBound), dim3(64), 0, st, cur, xcur, sbins.p, bnodes.p, ctr.p, prm, (const uint32_t*)sbinsTop.p);
     }
-    LAUNCH(top_partition, dim3(chunkBound), dim3(256), 0, st, cur, chunks.p, src, dst, ctr.p, (const uint2*)chunkBase.p, accTop.p, spatial ? 1u : 0u);
+    LAUNCH(top_partition, dim3(chunkBound), dim3(256), 0, st, cur, chunks.p, src, dst, ctr.p, (const uint2*)chunkBase.p, accTop.p);
     if (spatial) LAUNCH(spatial_partition, dim3(chunkBound), dim3(256), 0, st, cur, xcur, chunks.p, src, dst, dGeoms.p, ctr.p, chunkFlag.p, accTop.p);
     if (local) LAUNCH(top_local, dim3(segBound), dim3(256), 0, st, (const Seg*)cur, (const PrimRef*)src, dst, bnodes.p, nxt, small.p, ctr.p, prm, dstBuf, maxSegs, maxSmall, forceFallback, level, 0u);
     LAUNCH(top_emit, dim3((segBound + 255u) / 256u), dim3(256), 0, st, cur, bnodes.p, nxt, small.p, ctr.p, prm,

@@ -383,7 +383,7 @@ __device__ __forceinline__ void spatial_sides(const PrimRef& r, uint32_t dim, in
   } else { toL = sbin(0.5f * (rlo + rhi), ofs, scale) < pos; toR = !toL; }   // whole, to the side its centre lies on
 }
 __global__ __launch_bounds__(256) void spatial_partition(Seg* segs, const SegX* sx, const Chunk* chunks, const PrimRef* src, PrimRef* dst, const GeomDesc* geoms, Counters* ctr, uint32_t* chunkFlag, uint32_t* accTop) {
-  __shared__ uint32_t s_cnt[CHUNK_ROUNDS][4][2], s_off[CHUNK_ROUNDS][4][2], s_baseL, s_baseR;
+  __shared__ uint32_t s_cnt[CHUNK_ROUNDS][4][2], s_off[CHUNK_ROUNDS][4][2], s_baseL, s_baseR, s_mineL, s_mineR;
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   if (blockIdx.x >= ctr->numChunks) return;
   const Chunk ck = chunks[blockIdx.x];
@@ -413,8 +413,7 @@ __global__ __launch_bounds__(256) void spatial_partition(Seg* segs, const SegX* 
     // Reserving the places with the set's cursors handed them out in the order the chunks ARRIVED: the children held the same references in another order
     // from run to run, and what a median split further down cuts off depends on the order (two leaves of a HIGH tree swapped a triangle between commits).
     __hip_atomic_store(chunkFlag + blockIdx.x, 0x80000000u | (l << 12) | rr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (l) atomicAdd(&sg->curL, l);                                // (the cursors only COUNT: top_emit reads the children's ends from them)
-    if (rr) atomicAdd(&sg->curR, rr);
+    s_mineL = l; s_mineR = rr;
     s_baseL = sg->begin; s_baseR = sg->begin + x->capL;
   }
   __syncthreads();
@@ -432,6 +431,9 @@ __global__ __launch_bounds__(256) void spatial_partition(Seg* segs, const SegX* 
     if (lane == 0u && (pl | pr)) { atomicAdd(&s_baseL, pl); atomicAdd(&s_baseR, pr); }
   }
   __syncthreads();
+  // where the children end (top_emit reads it): the set's LAST chunk knows -- its own places end there.  (Every chunk used to add its counts to the set's cursors: two
+  // atomics per chunk on the line all chunks of the set read their plane from, 2 x 2325 of them at the root's level.)
+  if (tid == 0u && ck.end == sg->end) { sg->curL = s_baseL + s_mineL; sg->curR = s_baseR + s_mineR; }
   uint32_t acc[2][12];                                           // this thread's share of the children's centroid / geometry bounds (ordered uint), folded across the wave at the end
   for (int side = 0; side < 2; side++) for (int k = 0; k < 12; k++) acc[side][k] = (k % 6 < 3) ? ENC_POS_INF : ENC_NEG_INF;
   const unsigned long long lt = (1ull << lane) - 1ull;

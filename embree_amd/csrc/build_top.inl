@@ -178,7 +178,9 @@ __global__ __launch_bounds__(64) void top_split(Seg* segs, const uint32_t* bins,
     for (int d = 0; d < 3; d++) { L.lo[d] = r.llo[d]; L.hi[d] = r.lhi[d]; R.lo[d] = r.rlo[d]; R.hi[d] = r.rhi[d]; }
     bnodes[idL] = L; bnodes[idR] = R;
     sg->flags = fallback ? 1u : 0u; sg->dim = fallback ? 0u : (uint32_t)r.dim; sg->pos = fallback ? capL : (uint32_t)r.pos; sg->nL = nL;   // (median split: pos = where the right child starts, see top_partition)
-    sg->childL = idL; sg->childR = idR; sg->curL = begin; sg->curR = begin + capL;
+    // where the children END (top_emit of spatial-split builds reads it): an object split creates no reference, so the ends are known here.  (They were counted: two atomics
+    // per chunk on the set's line -- the line every chunk of the set reads its plane from; a set that splits spatially after all is counted by spatial_partition's last chunk.)
+    sg->childL = idL; sg->childR = idR; sg->curL = begin + nL; sg->curR = begin + capL + (n - nL);
     for (int side = 0; side < 2; side++) for (int k = 0; k < 12; k++) sg->acc[side][k] = (k % 6 < 3) ? ENC_POS_INF : ENC_NEG_INF;
     s_plan[0] = fallback ? 1u : 0u; s_plan[1] = fallback ? 0u : (uint32_t)r.dim; s_plan[2] = (uint32_t)r.pos; s_plan[3] = capL;
   }
@@ -211,7 +213,7 @@ __global__ __launch_bounds__(64) void top_split(Seg* segs, const uint32_t* bins,
   }
 }
 
-__global__ __launch_bounds__(256) void top_partition(Seg* segs, const Chunk* chunks, const PrimRef* src, PrimRef* dst, const Counters* ctr, const uint2* chunkBase, uint32_t* accTop, uint32_t countCursors) {
+__global__ __launch_bounds__(256) void top_partition(Seg* segs, const Chunk* chunks, const PrimRef* src, PrimRef* dst, const Counters* ctr, const uint2* chunkBase, uint32_t* accTop) {
   __shared__ uint32_t s_cnt[CHUNK_ROUNDS][4][2], s_off[CHUNK_ROUNDS][4][2], s_acc[2][12], s_baseL, s_baseR;
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   if (blockIdx.x >= ctr->numChunks) return;
@@ -254,10 +256,6 @@ __global__ __launch_bounds__(256) void top_partition(Seg* segs, const Chunk* chu
   if (tid == 0) {
     uint32_t l = 0, rr = 0;
     for (int r = 0; r < CHUNK_ROUNDS; r++) for (int w = 0; w < 4; w++) { s_off[r][w][0] = l; s_off[r][w][1] = rr; l += s_cnt[r][w][0]; rr += s_cnt[r][w][1]; }
-    if (countCursors) {                                          // (the cursors only COUNT here: top_emit of spatial-split builds reads them -- nobody else, and two same-word atomics per chunk are not free)
-      if (l) atomicAdd(&sg->curL, l);
-      if (rr) atomicAdd(&sg->curR, rr);
-    }
     const uint2 base = chunkBase[blockIdx.x];                    // this chunk's places, in chunk order (top_split)
     s_baseL = base.x; s_baseR = base.y;
   }
