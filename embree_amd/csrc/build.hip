@@ -72,14 +72,14 @@ struct Arena {
   // triangle count alone: bench.py commits its scene MEDIUM, then HIGH, then MEDIUM again, and every other commit found the counts of the other quality, failed and ran
   // twice.  Within a kind the counts only GROW (maximum of what the commits of that kind needed; first top_local level: minimum): two scenes of one kind that need different
   // depths, committed in turn, cost the shallower one a few empty launches instead of costing the deeper one a second commit every time.
-  struct Learned { uint64_t kind = 0; uint32_t top = 0, wide = 0, chunked = 0, localFirst = 255u; uint64_t used = 0; };
+  struct Learned { uint64_t kind = 0; uint32_t top = 0, wide = 0, chunked = 0, localFirst = 255u, nodes = 0; uint64_t used = 0; };   // nodes: wide nodes of the last commit of the kind (sizes the tree's node buffer up front)
   Learned learned[8]; uint64_t learnedClock = 0;               // (eight kinds per device, the least recently used one is replaced)
   Learned* find_learned(uint64_t kind) { for (auto& l : learned) if (l.kind == kind && l.top != 0u) { l.used = ++learnedClock; return &l; } return nullptr; }
-  void learn(uint64_t kind, uint32_t top, uint32_t wide, uint32_t chunked, uint32_t localFirst) {
+  void learn(uint64_t kind, uint32_t top, uint32_t wide, uint32_t chunked, uint32_t localFirst, uint32_t nodes) {
     Learned* l = find_learned(kind);
     if (!l) { l = &learned[0]; for (auto& c : learned) if (c.used < l->used) l = &c; *l = Learned(); l->kind = kind; }
     l->top = top > l->top ? top : l->top; l->wide = wide > l->wide ? wide : l->wide; l->chunked = chunked > l->chunked ? chunked : l->chunked;
-    l->localFirst = localFirst < l->localFirst ? localFirst : l->localFirst; l->used = ++learnedClock;
+    l->localFirst = localFirst < l->localFirst ? localFirst : l->localFirst; l->nodes = nodes; l->used = ++learnedClock;
   }
   void drop_graph() { if (graphExec) { hipGraphExecDestroy(graphExec); graphExec = nullptr; } graphKey.clear(); }
   void reset() { for (auto& b : blocks) b.used = 0; }
@@ -257,6 +257,7 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
   const bool learned = lc != nullptr;
   const uint32_t learnedTop = lc ? lc->top : 0u, learnedWide = lc ? lc->wide : 0u, learnedChunked = lc ? lc->chunked : 0u, learnedLocalFirst = lc ? lc->localFirst : 0u;
   uint32_t launches = 0, syncs = 0;
+  uint32_t preCap = 0;                                          // nodes the tree's own node buffer was sized for before the commit knew its node count (tri_records copies them), 0 = not
   bool replay = false, capturing = false;                       // fast path: the launches below are replayed from the cached graph / are being captured into one
   // MI355_BUILD_DEBUG=1: every launch is named on stderr and waited for (finds the kernel behind a device fault; use with MI355_BUILD_GRAPH=0)
   static const bool envDebug = getenv("MI355_BUILD_DEBUG") != nullptr;
@@ -552,7 +553,16 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
     // the leaf records can be written as soon as the leaf order is known; their array is sized by the upper bound N
     bvh->d_tris = output_alloc(device, (size_t)NC * sizeof(TriRec) + 128, &bvh->trisCap);
     if (!bvh->d_tris) return set_error(hipErrorOutOfMemory, "leaf record array");
-    LAUNCH(tri_records, dim3((NC + 1023u) / 1024u), dim3(256), 0, st, outIds.p, NC, dGeoms.p, (TriRec*)bvh->d_tris, bp->robust ? 1u : 0u, (const Counters*)ctr.p);
+    // the node array leaves the arena beside the record gathers if the last commit of this kind said how large it gets (tri_records; + 1/64 of slack)
+    if (lc && lc->nodes) {
+      preCap = lc->nodes + lc->nodes / 64u + 256u;
+      bvh->d_nodes = output_alloc(device, (size_t)preCap * sizeof(CNode), &bvh->nodesCap);
+      if (!bvh->d_nodes) { preCap = 0u; bvh->nodesCap = 0; }
+    }
+    const uint32_t triBlocks = (NC + 1023u) / 1024u;
+    const uint32_t copyBlocks = preCap ? 1024u : 0u;
+    LAUNCH(tri_records, dim3(copyBlocks + triBlocks), dim3(256), 0, st, outIds.p, NC, dGeoms.p, (TriRec*)bvh->d_tris, bp->robust ? 1u : 0u, (const Counters*)ctr.p,
+           (const uint4*)wnodes.p, (uint4*)bvh->d_nodes, preCap, copyBlocks);
     SYNC_READ(h);                                                // the ONE round trip of the commit
     // (the overflow word is written with atomicMax -- a later kernel's 1 / 2 / 3 no longer hides a 4 -- and a wait that timed out (2^20 naps: heavy sharing of the GPU,
     // preemption) is a reason to run the commit AGAIN on the stepwise path, not an error; only if that one times out as well does the host report it)
@@ -570,7 +580,7 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
     }
     n = h.numPrims;
     info.num_presplit = h.outlierPieces > h.numOutliers ? h.outlierPieces - h.numOutliers : 0u;   // leaf records beyond one per triangle: the pieces of the cut outliers
-    if (n == 0) { output_free(device, bvh->d_tris, bvh->trisCap); bvh->d_tris = nullptr; bvh->trisCap = 0; info.num_launches = launches; info.num_host_syncs = syncs; guard.ok = true; *out = bvh; return 0; }
+    if (n == 0) { output_free(device, bvh->d_tris, bvh->trisCap); bvh->d_tris = nullptr; bvh->trisCap = 0; if (bvh->d_nodes) { output_free(device, bvh->d_nodes, bvh->nodesCap); bvh->d_nodes = nullptr; bvh->nodesCap = 0; } info.num_launches = launches; info.num_host_syncs = syncs; guard.ok = true; *out = bvh; return 0; }
     for (int d = 0; d < 3; d++) { info.bounds_lower[d] = decf(h.bounds[d]); info.bounds_upper[d] = decf(h.bounds[3 + d]); }
     info.top_levels = h.topLevels;
     bool redoLeaves = false;
@@ -578,11 +588,11 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
       for (uint32_t i = 0; i < 4u; i++) enqueue_wide_level();
       SYNC_READ(h);
       if (h.overflow) return set_error(hipErrorOutOfMemory, "wide node pool overflow");
-      redoLeaves = true;
+      redoLeaves = true; preCap = 0u;                            // (the nodes copied beside the first tri_records were not all of them)
     }
     if (spatial) { info.num_presplit = h.numTrisOut > n ? h.numTrisOut - n : 0u; n = h.numTrisOut; }   // the references the spatial splits created are leaf entries like any other
-    arena->learn(kind, h.topLevels, h.wideDepth, h.chunkedLevels, h.localFirst < 255u ? h.localFirst : 255u);   // (a tree deeper than the wide levels enqueued is finished below either way)
-    if (redoLeaves) LAUNCH(tri_records, dim3((NC + 1023u) / 1024u), dim3(256), 0, st, outIds.p, NC, dGeoms.p, (TriRec*)bvh->d_tris, bp->robust ? 1u : 0u, (const Counters*)ctr.p);
+    arena->learn(kind, h.topLevels, h.wideDepth, h.chunkedLevels, h.localFirst < 255u ? h.localFirst : 255u, h.numWide);   // (a tree deeper than the wide levels enqueued is finished below either way)
+    if (redoLeaves) LAUNCH(tri_records, dim3((NC + 1023u) / 1024u), dim3(256), 0, st, outIds.p, NC, dGeoms.p, (TriRec*)bvh->d_tris, bp->robust ? 1u : 0u, (const Counters*)ctr.p, (const uint4*)nullptr, (uint4*)nullptr, 0u, 0u);
   } else {
     for (uint32_t i = 0; i < 8u; i++) enqueue_wide_level();
     for (;;) {
@@ -594,7 +604,7 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
     if (spatial) { info.num_presplit = h.numTrisOut > n ? h.numTrisOut - n : 0u; n = h.numTrisOut; }   // the references the splits created are leaf entries like any other
     bvh->d_tris = output_alloc(device, (size_t)n * sizeof(TriRec) + 128, &bvh->trisCap);
     if (!bvh->d_tris) return set_error(hipErrorOutOfMemory, "leaf record array");
-    LAUNCH(tri_records, dim3((n + 1023u) / 1024u), dim3(256), 0, st, outIds.p, n, dGeoms.p, (TriRec*)bvh->d_tris, bp->robust ? 1u : 0u, (const Counters*)nullptr);
+    LAUNCH(tri_records, dim3((n + 1023u) / 1024u), dim3(256), 0, st, outIds.p, n, dGeoms.p, (TriRec*)bvh->d_tris, bp->robust ? 1u : 0u, (const Counters*)nullptr, (const uint4*)nullptr, (uint4*)nullptr, 0u, 0u);
   }
   info.num_triangles = n;
 #ifdef SM_TIME
@@ -607,7 +617,8 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
 
   // ---- final node array (exact size)
   const uint32_t numNodes = h.numWide;
-  if (numNodes) {
+  if (bvh->d_nodes && !(preCap && numNodes && numNodes <= preCap)) { output_free(device, bvh->d_nodes, bvh->nodesCap); bvh->d_nodes = nullptr; bvh->nodesCap = 0; }   // (sized up front, too small or not filled)
+  if (numNodes && !bvh->d_nodes) {
     bvh->d_nodes = output_alloc(device, (size_t)numNodes * sizeof(CNode), &bvh->nodesCap);
     if (!bvh->d_nodes) return set_error(hipErrorOutOfMemory, "node array");
     HIP_TRY(hipMemcpyAsync(bvh->d_nodes, wnodes.p, (size_t)numNodes * sizeof(CNode), hipMemcpyDeviceToDevice, st));
@@ -674,7 +685,7 @@ static int refit_impl(Bvh* bvh, const mi355_mesh* meshes, uint32_t numMeshes, hi
   HIP_TRY(hipEventRecord(ev0, st));
   HIP_TRY(hipMemcpyAsync(dGeoms.p, gd.data(), gd.size() * sizeof(GeomDesc), hipMemcpyHostToDevice, st));
   HIP_TRY(hipMemsetAsync(flag.p, 0, 4, st));
-  hipLaunchKernelGGL(tri_records, dim3((n + 1023u) / 1024u), dim3(256), 0, st, (const uint2*)bvh->d_ids, n, dGeoms.p, (TriRec*)bvh->d_tris, bvh->robust ? 1u : 0u, (const Counters*)nullptr);
+  hipLaunchKernelGGL(tri_records, dim3((n + 1023u) / 1024u), dim3(256), 0, st, (const uint2*)bvh->d_ids, n, dGeoms.p, (TriRec*)bvh->d_tris, bvh->robust ? 1u : 0u, (const Counters*)nullptr, (const uint4*)nullptr, (uint4*)nullptr, 0u, 0u);
   for (size_t l = bvh->lvlStart.size() - 1; l-- > 0;) {        // deepest level first
     const uint32_t first = bvh->lvlStart[l], count = bvh->lvlStart[l + 1] - first;
     if (!count) continue;

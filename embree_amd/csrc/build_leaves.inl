@@ -3,13 +3,31 @@
 // --------------------------------------------------------------------------------- K5 tri_records
 // (round 6) Four records per thread -- record k * 256 + i of a tile of 1024 is thread i's -- with the ids, then the geometry entries and indices, then the vertices of all
 // four in flight together: one record per thread was a chain of four dependent round trips (id, geometry table, indices, vertices), 130 us for 228 MB written.
-__global__ __launch_bounds__(256) void tri_records(const uint2* finalIds, uint32_t n, const GeomDesc* geoms, TriRec* out, uint32_t robust, const Counters* ctr) {
+// (round 6) copyBlocks != 0: the FIRST copyBlocks workgroups copy the finished node array out of the build arena into the tree's own buffer, which the host sized from what
+// the last commit of this kind needed -- the copy used to wait for the host to learn the node count (a round trip of ~30 us with the GPU idle, then a 24 us copy behind this
+// kernel); now it runs beside the record gathers, which leave the memory pipes idle.  More nodes than the buffer holds: nothing is copied, the host copies as before.
+__global__ __launch_bounds__(256) void tri_records(const uint2* finalIds, uint32_t n, const GeomDesc* geoms, TriRec* out, uint32_t robust, const Counters* ctr,
+                                                   const uint4* nodeSrc, uint4* nodeDst, uint32_t nodeCap, uint32_t copyBlocks) {
+  if (blockIdx.x < copyBlocks) {
+    const uint32_t numNodes = ctr->numWide;
+    if (numNodes > nodeCap) return;
+    const uint32_t words = numNodes * 5u, stride = copyBlocks * 256u;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < words; i += 4u * stride) {   // (four 16-byte loads in flight)
+      uint4 x[4];
+#pragma unroll
+      for (uint32_t k = 0; k < 4u; k++) if (i + k * stride < words) x[k] = nodeSrc[i + k * stride];
+#pragma unroll
+      for (uint32_t k = 0; k < 4u; k++) if (i + k * stride < words) nodeDst[i + k * stride] = x[k];
+    }
+    return;
+  }
+  const uint32_t block = blockIdx.x - copyBlocks;
   // ctr: the grid is an upper bound, the number of leaf records is on the device: what the wide collapse has numbered so far.  Of a tree deeper than the levels
   // enqueued with this launch that is a part only -- the ids behind it are whatever the arena held (a device fault, found when tree buffers began to be
   // recycled); the host runs the remaining levels and launches this kernel again
   const uint32_t count = ctr ? ctr->numTrisOut : n;
-  const uint32_t base = blockIdx.x * 1024u + threadIdx.x;
-  if (blockIdx.x * 1024u >= count) return;
+  const uint32_t base = block * 1024u + threadIdx.x;
+  if (block * 1024u >= count) return;
   uint2 id[4]; bool on[4];
 #pragma unroll
   for (int k = 0; k < 4; k++) { const uint32_t i = base + (uint32_t)k * 256u; on[k] = i < count; id[k] = make_uint2(0u, 0u); if (on[k]) id[k] = finalIds[i]; }
