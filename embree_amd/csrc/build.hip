@@ -402,7 +402,6 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
     HIP_TRY(hipMemcpyAsync(bnodes.p, &rootB, sizeof(rootB), hipMemcpyHostToDevice, st));
     h.numSegsNext = 0; h.numChunks = 0; h.numSmall = 0; h.numSegs = (n > prm.small && prm.quality != 1u) ? 1u : 0u; h.topLevels = 0;   // (LOW has no top phase: a work list that nobody empties would read as "unfinished" to wide_root)
     h.rootArea = fmaf(ghi[0] - glo[0], (ghi[1] - glo[1]) + (ghi[2] - glo[2]), (ghi[1] - glo[1]) * (ghi[2] - glo[2]));
-    h.areaFixed = 0ull;
     if (n > prm.small) {
       Seg s0{}; s0.begin = 0; s0.end = n; s0.bnode = 0; for (int d = 0; d < 3; d++) { s0.cmin[d] = clo[d]; s0.cmax[d] = chi[d]; }
       HIP_TRY(hipMemcpyAsync(segs0.p, &s0, sizeof(s0), hipMemcpyHostToDevice, st)); numSegs = 1;

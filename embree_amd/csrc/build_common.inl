@@ -49,7 +49,7 @@ struct Counters {
   unsigned long long pad_c;
   float rootArea;                                 // half area of the scene bounds (SAH statistics are relative to it); written by root_setup
   uint32_t numOutliers;                           // MEDIUM builds: references cut up front because their box dwarfs the average one (build_presplit.inl, outlier_*)
-  unsigned long long areaFixed;                   // spatial-split builds: sum of the references' box areas / scene area, 2^-32 fixed point (build_spatial.inl)
+  unsigned long long pad_g;
   double areaSum;                                 // MEDIUM builds: sum of the valid references' box areas (primref_gen's per-workgroup parts added in index order by outlier_stats)
   uint32_t compactFrom;                           // stable compaction: first position that moves (everything before the first hole stays where it is)
   uint32_t outlierCells, outlierPieces, outlierValid, outlierSkip;   // ... the places reserved for their pieces behind the references, the pieces that exist, the valid references counted, 1 = too many
@@ -71,6 +71,7 @@ struct Counters {
     uint32_t numLeaves;                           // leaf slots of the wide tree: wide_plan
     uint32_t numBLeaves;                          // leaves of the binary tree: small_build (LOW: stripe 0 holds n)
     uint32_t cb2[6];                              // MEDIUM builds that cut outliers: centroid lo/hi over the references that stay (outlier_mark) and the pieces (outlier_clip): the root's centroid box if anything was cut
+    unsigned long long areaFixed;                 // spatial-split builds: sum of the references' box areas / scene area, 2^-32 fixed point (spatial_area_sum; spatial_budgets folds the stripes)
     uint32_t bounds[12];                          // what primref_gen's workgroups found (scene geom lo/hi + centroid lo/hi): folded into Counters::bounds by fold_bounds (outlier_stats / root_setup / bounds_fold)
   };
   static constexpr uint32_t STRIPES = 64u;

@@ -97,14 +97,21 @@ __global__ __launch_bounds__(256) void spatial_area_sum(const PrimRef* prims, ui
   for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
   if ((threadIdx.x & 63u) == 0u) s_w[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0u) atomicAdd(&ctr->areaFixed, s_w[0] + s_w[1] + s_w[2] + s_w[3]);
+  if (threadIdx.x == 0u) atomicAdd(&ctr->stripe[blockIdx.x % Counters::STRIPES].areaFixed, s_w[0] + s_w[1] + s_w[2] + s_w[3]);   // (<= 2048 workgroups on one word were half of this kernel: see Counters::stripe)
 }
 __global__ __launch_bounds__(256) void spatial_budgets(PrimRef* prims, uint32_t n, const Counters* ctr, uint32_t fromCtr) {
+  __shared__ unsigned long long s_sum;
   if (fromCtr) { if (ctr->numSegs == 0u) return; n = ctr->numPrims; }
+  if (threadIdx.x < 64u) {                                                         // the sum spatial_area_sum left in the stripes (an integer sum: any order)
+    unsigned long long v = threadIdx.x < Counters::STRIPES ? ctr->stripe[threadIdx.x].areaFixed : 0ull;
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if (threadIdx.x == 0u) s_sum = v;
+  }
+  __syncthreads();
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i >= n) return;
   const float rootArea2 = 2.0f * ctr->rootArea;
-  const double sumRel = (double)ctr->areaFixed / 4294967296.0;                     // sum of the boxes' areas / scene area
+  const double sumRel = (double)s_sum / 4294967296.0;                              // sum of the boxes' areas / scene area
   PrimRef r = load_prim(prims + i);
   const float a = 2.0f * half_area3(r.hi[0] - r.lo[0], r.hi[1] - r.lo[1], r.hi[2] - r.lo[2]);
   int k = 1;
