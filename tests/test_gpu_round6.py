@@ -188,6 +188,62 @@ def test_commit_is_bit_identical_across_rebuilds_and_qualities_keep_their_hashes
         s.release()
 
 
+def test_outlier_cut_together_with_invalid_triangles_vs_reference(api, dev, ref):
+    """Round 6, last session: the front end of a MEDIUM commit no longer reads the references three more times -- outlier_mark counts the valid references of every 256-tile for
+    the compaction (outlier_emit takes the cut ones off, compact_count covers only the tile N falls into and the reserve) and measures the centroid box of what stays
+    (outlier_clip adds the pieces').  The case that needs all of it at once: a scene WITH outliers (the room of the crown stand-in) AND invalid triangles -- NaN vertices in
+    the first tile, in the middle, and in the very tile the room's triangles sit in.  Answers against the real reference (which skips the same triangles), the reference count,
+    and bit-identical rebuilds; the same scene without the cut (top_splits=0) must give the same hits."""
+    meshes = [(v.copy(), t.copy()) for v, t in W.synthetic_crown(num_phi=40)]
+    ntri = W.num_triangles(meshes)
+    rng = np.random.default_rng(77)
+    bad = 0
+    for gi in (0, len(meshes) // 2, len(meshes) - 1):              # the last geometry is the room (the outliers)
+        v, t = meshes[gi]
+        extra = np.array([[np.nan, 0, 0], [3e18, 1, 1]], np.float32)
+        base = v.shape[0]
+        v2 = np.concatenate([v, extra])
+        t2 = t.copy()
+        pick = [0, t.shape[0] // 2] if t.shape[0] > 16 else [0]
+        for k, j in enumerate(pick):
+            t2[j, k % 3] = base + (k & 1); bad += 1                 # one corner becomes NaN / huge: the triangle is skipped (like the reference's isvalid)
+        meshes[gi] = (v2, t2)
+    plain = api.Device("gpu=0,top_splits=0")
+    s = api.make_scene(dev, meshes)
+    p = api.make_scene(plain, meshes)
+    info, pinfo = s.info(), p.info()
+    assert pinfo["num_presplit"] == 0 and pinfo["num_triangles"] == ntri - bad
+    assert info["num_presplit"] > 0 and info["num_triangles"] - info["num_presplit"] == ntri - bad, (info["num_triangles"], info["num_presplit"], ntri, bad)
+    R = ref.RefScene("threads=4")
+    for v, t in meshes:
+        R.add_mesh(v, t)
+    R.commit()
+    assert R.error() == 0
+    from tests.test_gpu_round4 import tri_t_of
+    tri_t = tri_t_of(meshes)
+    prim = W.crown_camera_rays(meshes, 192, 192)
+    want, got, gotp = prim.copy(), prim.copy(), prim.copy()
+    R.intersect1(want)
+    s.intersect1M(got)
+    p.intersect1M(gotp)
+    compare_closest(got, want, prim, tri_t, label="outliers + invalid, primary")
+    compare_closest(got, gotp, prim, tri_t, label="cut vs uncut tree, primary")   # the cut changes the tree, not the answers (an exact-t tie may name the other triangle)
+    bounce = W.diffuse_bounce_rays(want, meshes)
+    want, got, gotp = bounce.copy(), bounce.copy(), bounce.copy()
+    R.intersect1(want)
+    s.intersect1M(got)
+    p.intersect1M(gotp)
+    compare_closest(got, want, bounce, tri_t, label="outliers + invalid, bounce")
+    compare_closest(got, gotp, bounce, tri_t, label="cut vs uncut tree, bounce")
+    n0, t0 = s.download_bvh()
+    for _ in range(3):                                             # (the second commit of the kind also takes the learned node-buffer path: tri_records copies the nodes out)
+        s.touch()
+        s.commit()
+        n1, t1 = s.download_bvh()
+        assert n1.tobytes() == n0.tobytes() and t1.tobytes() == t0.tobytes() and s.info()["num_nodes"] == info["num_nodes"]
+    s.release(); p.release()
+
+
 def test_user_data_change_reaches_the_device_filter_function(api, ref):
     """with device_filter_functions=1 the user pointer of a geometry that enabled the argument filter travels to the GPU in the rule table at commit.
     rtcSetGeometryUserData did not mark anything modified, so rtcCommitScene returned early and the function kept seeing the OLD pointer.  Now a changed pointer counts as a
