@@ -284,7 +284,8 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
   DevBuf<Chunk> chunks; DevBuf<SmallEntry> small; DevBuf<Counters> ctr; DevBuf<WideItem> w0, w1; DevBuf<CNode> wnodes; DevBuf<uint2> outIds;
   HIP_TRY(bufA.alloc(NC)); HIP_TRY(bufB.alloc(NC)); HIP_TRY(finalIds.alloc(NC)); HIP_TRY(bnodes.alloc(2ull * NC + 2));
   HIP_TRY(segs0.alloc(maxSegs)); HIP_TRY(segs1.alloc(maxSegs)); HIP_TRY(bins.alloc((size_t)maxSegs * BINS_WORDS));
-  HIP_TRY(chunks.alloc(maxChunks)); HIP_TRY(small.alloc(maxSmall)); HIP_TRY(ctr.alloc(1));
+  HIP_TRY(chunks.alloc(maxChunks)); HIP_TRY(small.alloc((size_t)maxSmall + maxSmall / 10u + 8u)); HIP_TRY(ctr.alloc(1));   // (+ 4 bytes per entry behind the list: their sizes, side by side)
+  DevBuf<uint32_t> smallOrder; HIP_TRY(smallOrder.alloc(maxSmall));   // the list's indices, largest sub-tree first (small_order)
   HIP_TRY(w0.alloc(maxWide)); HIP_TRY(w1.alloc(maxWide)); HIP_TRY(wnodes.alloc(maxWide)); HIP_TRY(outIds.alloc(NC));
   const uint32_t maxLevelItems = NC / 2u + 64u;                 // the nodes of one level are disjoint sub-trees of >= 2 triangles each
   DevBuf<WidePlan> plans; DevBuf<uint2> itemCnt, groupSum; DevBuf<uint32_t> tileCount;
@@ -307,7 +308,7 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
   struct EvGuard { hipEvent_t a, b; ~EvGuard() { hipEventDestroy(a); hipEventDestroy(b); } } evg{ev0, ev1};
   if (useGraph) {
     HIP_TRY(hipStreamSynchronize(st));                         // (the geometry table above is in place before anything is captured)
-    const void* ptrs[] = {dGeoms.p, bufA.p, bufB.p, finalIds.p, bnodes.p, segs0.p, segs1.p, bins.p, chunks.p, small.p, ctr.p, w0.p, w1.p, wnodes.p, outIds.p, plans.p, itemCnt.p, groupSum.p, tileCount.p, chunkCnt.p, chunkBase.p, accTop.p, binsTop.p, segx0.p, segx1.p, sbins.p, sbinsTop.p, outlierCnt.p, outlierTile.p, outlierTotal.p, outlierWork.p, areaPart.p, (const void*)st};
+    const void* ptrs[] = {dGeoms.p, bufA.p, bufB.p, finalIds.p, bnodes.p, segs0.p, segs1.p, bins.p, chunks.p, small.p, ctr.p, w0.p, w1.p, wnodes.p, outIds.p, plans.p, itemCnt.p, groupSum.p, tileCount.p, chunkCnt.p, chunkBase.p, accTop.p, binsTop.p, segx0.p, segx1.p, sbins.p, sbinsTop.p, outlierCnt.p, outlierTile.p, outlierTotal.p, outlierWork.p, areaPart.p, smallOrder.p, (const void*)st};
     std::vector<uint64_t> key; for (const void* q : ptrs) key.push_back((uint64_t)(uintptr_t)q);
     uint32_t pw[sizeof(Params) / 4]; memcpy(pw, &prm, sizeof(prm)); for (uint32_t w : pw) key.push_back(w);
     key.push_back(N); key.push_back(gd.size()); key.push_back(bp->robust); key.push_back(spatialMin); key.push_back(NC); { uint32_t w; memcpy(&w, &topSplitRel, 4); key.push_back(w); memcpy(&w, &topSplitCell, 4); key.push_back(w); } key.push_back(topSplits ? 1u : 0u); key.push_back(learned ? (learnedTop << 8) | learnedWide : 0u); key.push_back(learned ? (learnedChunked << 8) | (learnedLocalFirst & 0xFFu) : 0u);
@@ -509,12 +510,14 @@ static int build_impl(int device, const mi355_mesh* meshes, uint32_t numMeshes, 
   if (fast) {
     // every small entry covers > small / 2^k ... triangles: at most one entry per top-phase leaf; the list cannot be longer than maxSmall (top_emit raises overflow)
     const uint32_t bound = N > prm.small ? maxSmall : 1u;
-    LAUNCH(small_build, dim3(bound), dim3(64), smallLds, st, small.p, bufA.p, bufB.p, bnodes.p, finalIds.p, ctr.p, prm, microW);
+    static const bool envOrder = !(getenv("MI355_SMALL_ORDER") && atoi(getenv("MI355_SMALL_ORDER")) == 0);   // A/B: 0 = the list as it is
+    if (envOrder && N > prm.small) LAUNCH(small_order, dim3(1), dim3(1024), 0, st, (const SmallEntry*)small.p, (const Counters*)ctr.p, smallOrder.p, maxSmall, prm.small);
+    LAUNCH(small_build, dim3(bound), dim3(64), smallLds, st, small.p, bufA.p, bufB.p, bnodes.p, finalIds.p, ctr.p, prm, microW, envOrder && N > prm.small ? (const uint32_t*)smallOrder.p : (const uint32_t*)nullptr);
   } else {
     info.top_levels = h.topLevels;
     numSmall = sahBuild ? h.numSmall : 0u;
     if (numSmall > maxSmall) return set_error(hipErrorOutOfMemory, "small list overflow");
-    if (numSmall) LAUNCH(small_build, dim3(numSmall), dim3(64), smallLds, st, small.p, bufA.p, bufB.p, bnodes.p, finalIds.p, ctr.p, prm, microW);
+    if (numSmall) LAUNCH(small_build, dim3(numSmall), dim3(64), smallLds, st, small.p, bufA.p, bufB.p, bnodes.p, finalIds.p, ctr.p, prm, microW, (const uint32_t*)nullptr);
   }
   HIP_TRY(hipGetLastError());
 

@@ -279,11 +279,28 @@ __device__ void micro_flush(uint32_t* R, unsigned long long* s_key, const MicroR
   MICRO_SYNC();
 }
 
+// The order the sub-trees are taken in: LARGEST FIRST.  A sub-tree is one wavefront's for 100 - 500 us and the list is ~3.8 of them per wave slot of the chip; taken in the
+// order the top phase happened to append them, the kernel ends with a few 500-triangle sets that started last while the other slots stand empty (2.5 of 3.5 waves per SIMD
+// resident on average over the kernel, profiles/r06_pmc_small_build.md).  One workgroup sorts the list's INDICES by size class (128 classes, counting sort in LDS); the order
+// within a class is whatever the atomics give -- no tree depends on which wave builds which sub-tree (implicit numbering, disjoint ranges).
+__global__ __launch_bounds__(1024) void small_order(const SmallEntry* entries, const Counters* ctr, uint32_t* order, uint32_t maxSmall, uint32_t small) {
+  __shared__ uint32_t s_cnt[128], s_off[128];
+  const uint32_t tid = threadIdx.x, num = min(ctr->numSmall, maxSmall);
+  const uint32_t* size = (const uint32_t*)(entries + maxSmall);   // the entries' sizes, side by side (top_emit_child_at)
+  if (tid < 128u) s_cnt[tid] = 0u;
+  __syncthreads();
+  for (uint32_t i = tid; i < num; i += 1024u) atomicAdd(&s_cnt[min(127u, (size[i] * 127u) / small)], 1u);
+  __syncthreads();
+  if (tid < 128u) { uint32_t run = 0u; for (uint32_t c = tid + 1u; c < 128u; c++) run += s_cnt[c]; s_off[tid] = run; }   // (the larger classes come first)
+  __syncthreads();
+  for (uint32_t i = tid; i < num; i += 1024u) order[atomicAdd(&s_off[min(127u, (size[i] * 127u) / small)], 1u)] = i;
+}
+
 #ifdef MI355_SMALL_WAVES                                      /* A/B: a register budget for this many waves per SIMD (tools/build_variant.sh) */
 __attribute__((amdgpu_waves_per_eu(MI355_SMALL_WAVES, MI355_SMALL_WAVES)))
 #endif
 __global__ __launch_bounds__(64) void small_build(const SmallEntry* entries, PrimRef* bufA, PrimRef* bufB, BNode* bnodes,
-                                                  uint2* finalIds, Counters* ctr, Params prm, uint32_t W) {
+                                                  uint2* finalIds, Counters* ctr, Params prm, uint32_t W, const uint32_t* order) {
   extern __shared__ __attribute__((aligned(16))) uint32_t s_R[];   // max(BINS_WORDS, 64 * W) words: bins / micro scratch
   __shared__ SplitResult s_res;
   __shared__ uint32_t s_acc[2][12];
@@ -294,7 +311,7 @@ __global__ __launch_bounds__(64) void small_build(const SmallEntry* entries, Pri
   uint32_t* const s_bins = s_R;
   const uint32_t lane = threadIdx.x;
   if (blockIdx.x >= ctr->numSmall) return;                       // the grid is an upper bound (the host does not read the list's length back)
-  const SmallEntry e0 = entries[blockIdx.x];
+  const SmallEntry e0 = entries[order ? order[blockIdx.x] : blockIdx.x];
   StackEntry cur; cur.begin = e0.begin; cur.end = e0.end; cur.bnode = e0.bnode; cur.buf = e0.buf;
   for (int d = 0; d < 3; d++) { cur.cmin[d] = e0.cmin[d]; cur.cmax[d] = e0.cmax[d]; }
   uint32_t sp = 0;

@@ -301,6 +301,7 @@ __device__ __forceinline__ void top_emit_child(uint32_t b, uint32_t e, uint32_t 
     SmallEntry se; se.begin = b; se.end = e; se.bnode = child; se.buf = dstBuf;
     for (int d = 0; d < 3; d++) { se.cmin[d] = cmin[d]; se.cmax[d] = cmax[d]; }
     small[k] = se;
+    ((uint32_t*)(small + maxSmall))[k] = e - b;                   // the sizes again, side by side behind the list: what small_order sorts by (one coalesced read instead of 40-byte strides)
   } else {
     const uint32_t k = atomicAdd(&ctr->numSegsNext, 1u);
     if (k >= maxNext) { atomicMax(&ctr->overflow, 1u); return; }
