@@ -920,7 +920,7 @@ def main():
             ct = json.load(open(os.path.join(ROOT, "profiles", "r06_commit_traffic.json")))
         except Exception:
             ct = None
-        build_roof = {"bound": "hbm on paper; measured: LDS atomics and wave-instruction issue of the many small sets (profiles/r06_pmc_small_build.md: VALU pipes 0.57 busy, LDS bank-conflict ratio 0.51)", "algorithmic_bytes": int(b_bytes),
+        build_roof = {"bound": "hbm on paper; measured: LDS atomics and wave-instruction issue of the many small sets (profiles/r06_pmc_small_build.md: VALU pipes 0.61 busy, LDS bank-conflict ratio 0.51)", "algorithmic_bytes": int(b_bytes),
                       "achieved": round(b_bytes / b_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(b_bytes / b_s / 1e9 / HBM_PEAK_GBS, 4),
                       "frac_of_copy": round(b_bytes / b_s / 1e9 / bw[0], 4) if bw_ok and bw[0] > 0 else None, "dominant_kernel": "small_build",
                       "how": "triangles x (48 read + 32 written) + log2(leaves) = %.1f levels x triangles x (32 binned + 32 read + 32 written) + nodes x 80 + triangles x (48 gathered + 48 written), "
