@@ -68,6 +68,7 @@ struct Device : RefCounted {
                                                              // is the address of a __device__ function (include/embree4/rtcore.h, "device filter functions"); off: a non-NULL filter there is an error
   bool pollSmall = true;                                     // config key small_poll=0: a blocking single-ray call sleeps on the stream instead of polling it (A/B)
   bool smallInPlace = true;                                  // config key small_in_place=0: small host queries go through device staging like the others (A/B)
+  bool packedLink = true;                                    // config key packed_link=0: host-array queries send whole records both ways (rounds 1 - 5) instead of 48 bytes up and only the written fields down
   unsigned pipelineMin = 262144, pipelineChunk = 131072;   // host-array queries of at least pipelineMin rays are cut into chunks of pipelineChunk rays (config keys host_pipeline_min / host_pipeline_chunk)
   mi355_build_params build;
   RTCErrorFunction errorFn = nullptr; void* errorFnPtr = nullptr;
@@ -136,22 +137,25 @@ void core_check(int rc, const char* what) {
 // hipHostMalloc'ed staging buffers (really pinned, not userptr), filled and drained by the CPU -- several threads for large arrays (copy_pool below).  "host_register=1"
 // in the device config restores the registration of the caller's array (faster on a quiet box: the link instead of the CPU's memcpy is the limit).
 struct CopyPool {                                              // a few threads that do nothing but memcpy: one 96 MB array at ~10 GB/s per thread is 10 ms, the link moves it in 2
+  // (MI355_COPY_THREADS: 2 helpers + the caller since the packed link of round 6 -- 3.0 ms per 2^20 closest-hit rays against 3.3 / 3.7 / 3.9 with 4 / 6 / 10 on a box that
+  // gives the process 16 CPUs: gpurun_out/r06zw, r06zx; six were the default of the whole-record copies)
   static constexpr size_t MIN_PART = (size_t)1 << 20;
-  struct Job { char* dst; const char* src; size_t n; std::atomic<int>* left; };
+  typedef void (*RangeFn)(void* ctx, size_t begin, size_t end);   // (a job of run(): items [begin, end) of whatever ctx describes)
+  struct Job { char* dst; const char* src; size_t n; std::atomic<int>* left; RangeFn fn = nullptr; void* ctx = nullptr; };
   std::mutex mtx; std::condition_variable cv; std::vector<Job> jobs; std::vector<std::thread> workers; bool stop = false;
   void start(unsigned n) {
     for (unsigned i = 0; i < n; i++) workers.emplace_back([this]() {
       for (;;) {
         Job j;
         { std::unique_lock<std::mutex> lk(mtx); cv.wait(lk, [this]() { return stop || !jobs.empty(); }); if (stop && jobs.empty()) return; j = jobs.back(); jobs.pop_back(); }
-        memcpy(j.dst, j.src, j.n);
+        if (j.fn) j.fn(j.ctx, (size_t)j.dst, (size_t)j.dst + j.n); else memcpy(j.dst, j.src, j.n);
         j.left->fetch_sub(1, std::memory_order_release);
       }
     });
   }
   ~CopyPool() { { std::lock_guard<std::mutex> lk(mtx); stop = true; } cv.notify_all(); for (auto& t : workers) t.join(); }
   void copy(void* dst, const void* src, size_t n) {
-    static const unsigned want = []() { const char* e = getenv("MI355_COPY_THREADS"); const long v = e ? atol(e) : 6; return (unsigned)(v < 0 ? 0 : (v > 32 ? 32 : v)); }();
+    static const unsigned want = []() { const char* e = getenv("MI355_COPY_THREADS"); const long v = e ? atol(e) : 2; return (unsigned)(v < 0 ? 0 : (v > 32 ? 32 : v)); }();
     if (n < 2 * MIN_PART || want == 0) { memcpy(dst, src, n); return; }
     { std::lock_guard<std::mutex> lk(mtx); if (workers.empty()) start(want); }
     size_t parts = n / MIN_PART; if (parts > workers.size() + 1) parts = workers.size() + 1;
@@ -162,6 +166,20 @@ struct CopyPool {                                              // a few threads 
       for (; ofs < n; ofs += per) { left.fetch_add(1, std::memory_order_relaxed); jobs.push_back({(char*)dst + ofs, (const char*)src + ofs, n - ofs < per ? n - ofs : per, &left}); } }
     cv.notify_all();
     memcpy(dst, src, per < n ? per : n);
+    while (left.load(std::memory_order_acquire) != 0) std::this_thread::yield();
+  }
+  // fn(ctx, begin, end) over the items [0, n), `bytesPerItem` of memory traffic each, cut like copy() cuts its bytes (the caller takes the first part itself)
+  void run(RangeFn fn, void* ctx, size_t n, size_t bytesPerItem) {
+    static const unsigned want = []() { const char* e = getenv("MI355_COPY_THREADS"); const long v = e ? atol(e) : 2; return (unsigned)(v < 0 ? 0 : (v > 32 ? 32 : v)); }();
+    if (n * bytesPerItem < 2 * MIN_PART || want == 0) { fn(ctx, 0, n); return; }
+    { std::lock_guard<std::mutex> lk(mtx); if (workers.empty()) start(want); }
+    size_t parts = n * bytesPerItem / MIN_PART; if (parts > workers.size() + 1) parts = workers.size() + 1;
+    const size_t per = (n + parts - 1) / parts;
+    std::atomic<int> left{0};
+    { std::lock_guard<std::mutex> lk(mtx);
+      for (size_t b = per; b < n; b += per) { left.fetch_add(1, std::memory_order_relaxed); Job j{(char*)b, nullptr, n - b < per ? n - b : per, &left, fn, ctx}; jobs.push_back(j); } }
+    cv.notify_all();
+    fn(ctx, 0, per < n ? per : n);
     while (left.load(std::memory_order_acquire) != 0) std::this_thread::yield();
   }
 };
@@ -329,6 +347,7 @@ struct Replica {
   std::mutex pipeMtx;                                       // one pipelined query per replica at a time: the four streams, the events and the streams' status words are shared
   char* pinUp[2] = {nullptr, nullptr}; char* pinDown[2] = {nullptr, nullptr}; size_t pinCap = 0;   // ... and the pinned staging of the chunks (staged_query): two on the way up, two on the way down
   hipEvent_t pinUpEv[2] = {nullptr, nullptr}, pinDownEv[2] = {nullptr, nullptr};
+  char* packUp[2] = {nullptr, nullptr}; char* packDown[2] = {nullptr, nullptr}; size_t packCap = 0; hipEvent_t packUpEv[2] = {nullptr, nullptr};   // ... and, on the device, the packed chunks of a query that sends only what is read / written (staged_query)
   struct Staging { char* d = nullptr; size_t cap = 0; char* h = nullptr; char* hd = nullptr; };   // h / hd: 4 KiB of pinned host memory and its device address
   std::map<size_t, Staging> staging;
   static constexpr size_t SMALL_BYTES = 4096;               // queries of up to this many bytes (rtcIntersect1 .. a few dozen rays) are traced in place in pinned host memory
@@ -379,6 +398,7 @@ struct Replica {
     for (int k = 0; k < PIPE; k++) if (pipe[k]) hipStreamDestroy(pipe[k]);
     for (int k = 0; k < 2; k++) { if (pinUp[k]) hipHostFree(pinUp[k]); if (pinDown[k]) hipHostFree(pinDown[k]); if (pinUpEv[k]) hipEventDestroy(pinUpEv[k]); if (pinDownEv[k]) hipEventDestroy(pinDownEv[k]); pinUp[k] = pinDown[k] = nullptr; }
     for (hipEvent_t e : pipeEvents) hipEventDestroy(e);
+    for (int k = 0; k < 2; k++) { if (packUp[k]) hipFree(packUp[k]); if (packDown[k]) hipFree(packDown[k]); if (packUpEv[k]) hipEventDestroy(packUpEv[k]); packUp[k] = packDown[k] = nullptr; packUpEv[k] = nullptr; } packCap = 0;
     if (shardStream) hipStreamDestroy(shardStream);
     if (smallStream) hipStreamDestroy(smallStream);
     if (shardIn) hipEventDestroy(shardIn);
@@ -650,6 +670,7 @@ void parse_config(Device* d, const char* cfg) {
     else if (k == "instance_refit") d->noInstanceRefit = atoi(v.c_str()) == 0;
     else if (k == "instance_refit_max") d->instanceRefitMax = (unsigned)atol(v.c_str());
     else if (k == "coherent_memory") d->coherentMemory = atoi(v.c_str()) != 0;
+    else if (k == "packed_link") d->packedLink = atoi(v.c_str()) != 0;
     else if (k == "host_register") d->hostRegister = atoi(v.c_str()) != 0;                           // the caller's ray arrays are hipHostRegister'ed for the duration of a query (see "host memory never meets the GPU")
     else if (k == "host_in_place") d->hostInPlace = atoi(v.c_str()) != 0;                             // rtcIntersect1M / rtcOccluded1M on large host arrays: trace them in place over the host link
     else if (k == "top_split_rel") d->build.top_split_rel = (float)atof(v.c_str());
@@ -692,7 +713,103 @@ static int trace_launch(const Scene* s, mi355_bvh_t b, void* d, unsigned n, size
 // The default since round 6: the same pipeline -- upload stream, two compute streams, download stream, an event between each -- but what the link reads and writes are
 // four pinned buffers of this replica (two chunks on the way up, two on the way down); the calling thread fills and drains them with the CPU (copy_pool: several threads
 // for a 12 MB chunk) while the GPU works on the chunks in between.  The caller's array is never registered and never seen by the GPU.
+// (round 6, last session) What crosses the link is what the kernels read and write, not the records: 48 bytes per ray on the way up (the RTCRay part, packed by the CPU while
+// it fills the pinned buffer, put back at `stride` by mi355_unpack_rays), and on the way down the fields a query writes -- 32 bytes per ray of a closest-hit query (48 with
+// instances), 4 of an occlusion query (mi355_pack_hits / _inst / _occluded) -- which the CPU writes into the caller's records of the rays that HIT; a miss leaves the caller's
+// record alone, as the reference does.  192 -> 80 MB over the link for 2^20 closest-hit rays, 96 -> 52 for occlusion rays, and half the bytes through the CPU's caches.
+struct PackCtx { char* packed; char* recs; size_t stride; };
+static void pack_rays_range(void* c, size_t b, size_t e) {           // caller's records -> 48 packed bytes each
+  const PackCtx& x = *(const PackCtx*)c;
+  for (size_t i = b; i < e; i++) memcpy(x.packed + i * 48u, x.recs + i * x.stride, 48u);
+}
+static void scatter_hits_range(void* c, size_t b, size_t e) {        // { tfar, u, v, primID | geomID, Ng } of the rays that hit -> the caller's RTCRayHit
+  const PackCtx& x = *(const PackCtx*)c;
+  for (size_t i = b; i < e; i++) {
+    const uint32_t* p = (const uint32_t*)(x.packed + i * 32u);
+    if (p[4] == RTC_INVALID_GEOMETRY_ID) continue;
+    uint32_t* r = (uint32_t*)(x.recs + i * x.stride);
+    r[8] = p[0]; r[12] = p[5]; r[13] = p[6]; r[14] = p[7]; r[15] = p[1]; r[16] = p[2]; r[17] = p[3]; r[18] = p[4]; r[19] = RTC_INVALID_GEOMETRY_ID; r[20] = RTC_INVALID_GEOMETRY_ID;   // (no instances: instID[0] / instPrimID[0] as the kernel writes them)
+  }
+}
+static void scatter_hits_inst_range(void* c, size_t b, size_t e) {   // ... + { instID[0], instPrimID[0] }
+  const PackCtx& x = *(const PackCtx*)c;
+  for (size_t i = b; i < e; i++) {
+    const uint32_t* p = (const uint32_t*)(x.packed + i * 48u);
+    if (p[4] == RTC_INVALID_GEOMETRY_ID) continue;
+    uint32_t* r = (uint32_t*)(x.recs + i * x.stride);
+    r[8] = p[0]; r[12] = p[5]; r[13] = p[6]; r[14] = p[7]; r[15] = p[1]; r[16] = p[2]; r[17] = p[3]; r[18] = p[4]; r[19] = p[8]; r[20] = p[9];
+  }
+}
+static void scatter_occluded_range(void* c, size_t b, size_t e) {    // tfar = -inf of the rays that are occluded -> the caller's RTCRay
+  const PackCtx& x = *(const PackCtx*)c;
+  for (size_t i = b; i < e; i++) { const uint32_t t = ((const uint32_t*)x.packed)[i]; if (t == 0xFF800000u) ((uint32_t*)(x.recs + i * x.stride))[8] = t; }
+}
+static void staged_query_packed(Scene* s, Replica& r, char* data, char* d, unsigned M, size_t stride, bool any, unsigned qflags) {
+  std::lock_guard<std::mutex> pipeLock(r.pipeMtx);
+  mi355_bvh_t b = r.bvh;
+  const bool inst = r.bvh != r.flat;                            // (a scene with instances reports instID[0] / instPrimID[0] as well)
+  const size_t down = any ? 4u : (inst ? 48u : 32u);
+  const unsigned chunk = M < s->device->pipelineMin ? M : s->device->pipelineChunk, nchunks = (M + chunk - 1u) / chunk;
+  const size_t upBytes = (size_t)chunk * 48u, downBytes = (size_t)chunk * down;
+  hipStream_t up, dn, comp[2];
+  std::vector<hipEvent_t> ev;
+  { std::lock_guard<std::mutex> lk(r.mtx);
+    for (int k = 0; k < Replica::PIPE; k++) if (!r.pipe[k]) hip_check(hipStreamCreateWithFlags(&r.pipe[k], hipStreamNonBlocking), "hipStreamCreate");
+    while (r.pipeEvents.size() < 2u * (size_t)nchunks) { hipEvent_t e; hip_check(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate"); r.pipeEvents.push_back(e); }
+    if (r.pinCap < upBytes) {                                    // (the pinned buffers of the whole-record path serve: 48 bytes per ray is what its occlusion queries need at least)
+      for (int k = 0; k < 2; k++) { if (r.pinUp[k]) hipHostFree(r.pinUp[k]); if (r.pinDown[k]) hipHostFree(r.pinDown[k]); r.pinUp[k] = r.pinDown[k] = nullptr; }
+      r.pinCap = 0;
+      const size_t cap = upBytes + upBytes / 4 + 4096;
+      for (int k = 0; k < 2; k++) { void* h = nullptr; hip_check(hipHostMalloc(&h, cap, hipHostMallocPortable), "hipHostMalloc(ray staging)"); r.pinUp[k] = (char*)h;
+                                    h = nullptr; hip_check(hipHostMalloc(&h, cap, hipHostMallocPortable), "hipHostMalloc(ray staging)"); r.pinDown[k] = (char*)h; }
+      r.pinCap = cap;
+    }
+    if (r.packCap < upBytes) {
+      hip_check(hipSetDevice(r.gpu), "hipSetDevice");
+      for (int k = 0; k < 2; k++) { if (r.packUp[k]) hipFree(r.packUp[k]); if (r.packDown[k]) hipFree(r.packDown[k]); r.packUp[k] = r.packDown[k] = nullptr; }
+      r.packCap = 0;
+      const size_t cap = upBytes + upBytes / 4 + 4096;
+      for (int k = 0; k < 2; k++) { core_check(mi355_malloc_retry(r.gpu, cap, (void**)&r.packUp[k]), "hipMalloc(packed rays)"); core_check(mi355_malloc_retry(r.gpu, cap, (void**)&r.packDown[k]), "hipMalloc(packed results)"); }
+      r.packCap = cap;
+    }
+    for (int k = 0; k < 2; k++) { if (!r.pinUpEv[k]) hip_check(hipEventCreateWithFlags(&r.pinUpEv[k], hipEventDisableTiming), "hipEventCreate");
+                                  if (!r.pinDownEv[k]) hip_check(hipEventCreateWithFlags(&r.pinDownEv[k], hipEventDisableTiming), "hipEventCreate");
+                                  if (!r.packUpEv[k]) hip_check(hipEventCreateWithFlags(&r.packUpEv[k], hipEventDisableTiming), "hipEventCreate"); }
+    up = r.pipe[0]; dn = r.pipe[1]; comp[0] = r.pipe[2]; comp[1] = r.pipe[3]; ev = r.pipeEvents; }
+  (void)downBytes;
+  auto span = [&](unsigned c, size_t& ofs, unsigned& n) { const unsigned first = c * chunk; n = M - first < chunk ? M - first : chunk; ofs = (size_t)first * stride; };
+  auto drain = [&](unsigned c) {                               // chunk c's results have come down into their pinned buffer: into the caller's records of the rays that hit
+    size_t ofs; unsigned n; span(c, ofs, n);
+    hip_check(hipEventSynchronize(r.pinDownEv[c & 1u]), "hipEventSynchronize");
+    PackCtx x{r.pinDown[c & 1u], data + ofs, stride};
+    copy_pool().run(any ? scatter_occluded_range : (inst ? scatter_hits_inst_range : scatter_hits_range), &x, n, down + 44u);
+  };
+  for (unsigned c = 0; c < nchunks; c++) {
+    size_t ofs; unsigned n; span(c, ofs, n);
+    const unsigned k = c & 1u; hipStream_t q = comp[k];
+    if (c >= 2) hip_check(hipEventSynchronize(r.pinUpEv[k]), "hipEventSynchronize");     // (the upload of chunk c - 2 has left this buffer)
+    { PackCtx x{r.pinUp[k], data + ofs, stride}; copy_pool().run(pack_rays_range, &x, n, 96u); }
+    if (c >= 2) hip_check(hipStreamWaitEvent(up, r.packUpEv[k], 0), "hipStreamWaitEvent");   // (chunk c - 2's packed rays have been put into their records: packUp[k] may be written again)
+    hip_check(hipMemcpyAsync(r.packUp[k], r.pinUp[k], (size_t)n * 48u, hipMemcpyHostToDevice, up), "hipMemcpyAsync(rays H2D)");
+    hip_check(hipEventRecord(r.pinUpEv[k], up), "hipEventRecord");
+    hip_check(hipEventRecord(ev[2u * c], up), "hipEventRecord"); hip_check(hipStreamWaitEvent(q, ev[2u * c], 0), "hipStreamWaitEvent");
+    core_check(mi355_unpack_rays(r.packUp[k], n, d + ofs, stride, any ? 0 : 1, q), "unpack rays");
+    hip_check(hipEventRecord(r.packUpEv[k], q), "hipEventRecord");
+    core_check(trace_launch(s, b, d + ofs, n, stride, any, qflags, q), "trace");
+    if (c >= 2) { hip_check(hipStreamWaitEvent(q, r.pinDownEv[k], 0), "hipStreamWaitEvent"); }   // (chunk c - 2's results have left packDown[k])
+    core_check(any ? mi355_pack_occluded(d + ofs, n, stride, r.packDown[k], q) : (inst ? mi355_pack_hits_inst(d + ofs, n, stride, r.packDown[k], q) : mi355_pack_hits(d + ofs, n, stride, r.packDown[k], q)), "pack results");
+    hip_check(hipEventRecord(ev[2u * c + 1u], q), "hipEventRecord"); hip_check(hipStreamWaitEvent(dn, ev[2u * c + 1u], 0), "hipStreamWaitEvent");
+    if (c >= 2) drain(c - 2);                                   // (its pinned buffer is the one chunk c comes down into)
+    hip_check(hipMemcpyAsync(r.pinDown[k], r.packDown[k], (size_t)n * down, hipMemcpyDeviceToHost, dn), "hipMemcpyAsync(results D2H)");
+    hip_check(hipEventRecord(r.pinDownEv[k], dn), "hipEventRecord");
+  }
+  if (nchunks >= 2) drain(nchunks - 2);
+  drain(nchunks - 1);
+  check_trace_status(b, comp[0]); if (nchunks > 1) check_trace_status(b, comp[1]);
+}
+
 static void staged_query(Scene* s, Replica& r, char* data, char* d, unsigned M, size_t stride, bool any, unsigned qflags) {
+  if (s->device->packedLink && M >= 1024u && !(stride & 15u)) { staged_query_packed(s, r, data, d, M, stride, any, qflags); return; }
   std::lock_guard<std::mutex> pipeLock(r.pipeMtx);
   mi355_bvh_t b = r.bvh;
   const size_t rec = any ? 48 : 96;

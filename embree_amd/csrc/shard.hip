@@ -54,6 +54,18 @@ __global__ void pack_occluded_kernel(const char* rays, uint32_t count, uint32_t 
     out[i] = *(const uint32_t*)(rays + (size_t)i * stride + 32);
 }
 
+// The way UP of a host-array query that sends only what the kernels read (rtcore_api.cpp, staged_query): 48 bytes per ray -- org, tnear, dir, time, tfar, mask, id, flags --
+// arrive packed and are put where the traversal expects them, at `stride`; a closest-hit record also gets geomID = RTC_INVALID_GEOMETRY_ID, which is how the way down tells a
+// miss (nothing to write back: the reference leaves the caller's hit fields alone) from a hit.
+__global__ void unpack_rays_kernel(const uint4* packed, uint32_t count, char* recs, uint32_t stride, uint32_t closest) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+    const uint4 a = packed[3 * (size_t)i], b = packed[3 * (size_t)i + 1], c = packed[3 * (size_t)i + 2];
+    char* r = recs + (size_t)i * stride;
+    *(uint4*)r = a; *(uint4*)(r + 16) = b; *(uint4*)(r + 32) = c;
+    if (closest) *(uint32_t*)(r + 72) = 0xFFFFFFFFu;
+  }
+}
+
 // ---- achievable HBM bandwidth of THIS box ("also measure an on-device copy/read kernel and report the fraction against both").  Grid-stride
 // 16-byte accesses, 8 independent loads in flight per lane, far more workgroups than CUs; the buffers are larger than the 256 MB Infinity Cache.
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -145,6 +157,14 @@ int mi355_pack_hits_inst(const void* d_rayhit, uint32_t count, size_t stride, vo
   if (stride < 96 || (stride & 15u) || ((uintptr_t)d_rayhit & 15u) || ((uintptr_t)d_out & 15u)) return mi355::set_error(hipErrorInvalidValue, "mi355_pack_hits_inst: 16-byte aligned RTCRayHit records expected");
   const uint32_t blocks = (count + 255u) / 256u < 4096u ? (count + 255u) / 256u : 4096u;
   hipLaunchKernelGGL(pack_hits_inst_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const char*)d_rayhit, count, (uint32_t)stride, (uint4*)d_out);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+int mi355_unpack_rays(const void* d_packed, uint32_t count, void* d_records, size_t stride, int closest, void* stream) {
+  if (count == 0) return 0;
+  if (stride < (closest ? 96u : 48u) || (stride & 15u) || ((uintptr_t)d_records & 15u) || ((uintptr_t)d_packed & 15u)) return mi355::set_error(hipErrorInvalidValue, "mi355_unpack_rays: 16-byte aligned records expected");
+  const uint32_t blocks = (count + 255u) / 256u < 4096u ? (count + 255u) / 256u : 4096u;
+  hipLaunchKernelGGL(unpack_rays_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint4*)d_packed, count, (char*)d_records, (uint32_t)stride, closest ? 1u : 0u);
   HIP_TRY(hipGetLastError());
   return 0;
 }

@@ -224,6 +224,11 @@ MI355_API int  mi355_pack_hits(const void* d_rayhit, uint32_t count, size_t byte
 MI355_API int  mi355_pack_occluded(const void* d_ray, uint32_t count, size_t byte_stride, void* d_out, void* stream);
 /* closest hits of scenes with instances: 48 B per ray = the 32 bytes above + { instID[0], instPrimID[0], 0, 0 } (RTCHit, include/embree4/rtcore.h) */
 MI355_API int  mi355_pack_hits_inst(const void* d_rayhit, uint32_t count, size_t byte_stride, void* d_out, void* stream);
+/* The way UP of a host-array query that sends only what the kernels read: `count` packed 48-byte RTCRay parts (org, tnear, dir, time, tfar, mask, id, flags) are put at
+   d_records + i * byte_stride; closest != 0: the record's geomID becomes RTC_INVALID_GEOMETRY_ID (a miss stays recognisable on the way down).  With mi355_pack_hits / _inst /
+   mi355_pack_occluded on the way down a host array crosses the link with 48 + 32 (48, 4) bytes per ray instead of 96 (48) each way (rtcIntersect1M / rtcOccluded1M of
+   include/embree4/rtcore.h on host memory; the reference reads the caller's memory in place, kernels/common/rtcore.cpp). */
+MI355_API int  mi355_unpack_rays(const void* d_packed, uint32_t count, void* d_records, size_t byte_stride, int closest, void* stream);
 /* hipStreamWaitEvent: work enqueued on `stream` after this call waits for `event` (a handle of mi355_event_create) -- how a gather on a communication stream
    is ordered behind the traversal of its batch while the next batch is traced (bench.py) */
 MI355_API int  mi355_stream_wait_event(void* stream, void* event);
