@@ -48,7 +48,7 @@ mi355_bvh_destroy mi355_bvh_build_instanced mi355_bvh_refit mi355_bvh_refit_inst
 mi355_trace_query mi355_trace_closest_packet mi355_trace_any_packet mi355_trace_stats mi355_trace_timed mi355_trace_status mi355_malloc mi355_malloc_retry mi355_free mi355_memcpy_h2d
 mi355_memcpy_d2h mi355_synchronize mi355_device_synchronize mi355_memcpy_d2d_async mi355_stream_create
 mi355_stream_destroy mi355_event_create mi355_event_record mi355_event_elapsed_ms mi355_event_destroy
-mi355_comm_unique_id mi355_comm_init mi355_comm_destroy mi355_comm_allgather mi355_comm_gather mi355_pack_hits mi355_pack_hits_inst mi355_pack_occluded mi355_stream_query mi355_stream_wait_event mi355_measure_bandwidth mi355_measure_host_link mi355_trace_query_filtered mi355_sort_keys63""".split()
+mi355_comm_unique_id mi355_comm_init mi355_comm_destroy mi355_comm_allgather mi355_comm_gather mi355_pack_hits mi355_pack_hits_inst mi355_pack_occluded mi355_unpack_rays mi355_stream_query mi355_stream_wait_event mi355_measure_bandwidth mi355_measure_host_link mi355_trace_query_filtered mi355_sort_keys63""".split()
 
 
 class FilterArguments(C.Structure):            # RTCFilterFunctionNArguments
@@ -249,6 +249,7 @@ def load():
     L.mi355_pack_hits.argtypes = [vp, u32, sz, vp, vp]
     L.mi355_pack_occluded.argtypes = [vp, u32, sz, vp, vp]
     L.mi355_pack_hits_inst.argtypes = [vp, u32, sz, vp, vp]
+    L.mi355_unpack_rays.argtypes = [vp, u32, vp, sz, C.c_int, vp]
     L.mi355_stream_wait_event.argtypes = [vp, vp]
     L.mi355_stream_query.argtypes = [vp]
     L.mi355_measure_bandwidth.argtypes = [C.c_int, sz, C.c_int, C.POINTER(C.c_double)]

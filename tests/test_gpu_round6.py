@@ -244,6 +244,50 @@ def test_outlier_cut_together_with_invalid_triangles_vs_reference(api, dev, ref)
     s.release(); p.release()
 
 
+@pytest.mark.parametrize("instanced", [False, True])
+def test_host_arrays_cross_the_link_packed_and_leave_misses_alone(api, instanced):
+    """Round 6, last session: a host-array query sends 48 bytes per ray up and only the fields the query writes down (packed_link, the default; rtcore_api.cpp
+    staged_query_packed) -- the caller's records are written by the CPU, and only those of the rays that HIT: a miss must leave the hit fields exactly as the caller passed
+    them (the reference's rtcIntersect1 never touches the hit of a ray that misses; kernels/geometry/intersector_epilog.h:235-300 writes on a hit only), whatever they hold.
+    Records with garbage in their hit fields, rays that hit, miss, are inactive (tnear > tfar) or NaN: byte-identical to the whole-record path (packed_link=0), chunked
+    (a batch above host_pipeline_min) and unchunked, closest hit and occlusion, with and without instances (the 48-byte form of the results)."""
+    from embree_amd.rtypes import make_rayhits
+    rng = np.random.default_rng(31)
+    n = 300000                                                     # (> host_pipeline_min: three chunks, the last one ragged)
+    org = np.stack([rng.uniform(-2.0, 14.0, n), rng.uniform(-2.0, 2.0, n), np.full(n, -5.0)], -1).astype(np.float32)
+    dirs = np.tile(np.array([0, 0, 1], np.float32), (n, 1)); dirs[:, :2] += rng.normal(0.0, 0.05, (n, 2)).astype(np.float32)
+    rays = make_rayhits(org, dirs)
+    rays["tnear"][::97] = 50.0; rays["tfar"][::97] = 10.0           # inactive
+    rays["dir_x"][5::211] = np.nan                                  # NaN rays: no hit, nothing written
+    for f, v in (("Ng_x", 7.0), ("Ng_y", -3.0), ("Ng_z", 1e30), ("u", 9.0), ("v", 11.0)): rays[f] = np.float32(v)
+    rays["primID"] = 12345; rays["geomID"] = 777; rays["instID"] = 55          # what a careless caller leaves in the hit part
+    out = {}
+    for cfg in ("gpu=0,packed_link=0", "gpu=0"):
+        dev = api.Device(cfg)
+        obj = api.make_scene(dev, [W.triangle_sphere(np.zeros(3, np.float32), 1.0, 24)])
+        if instanced:
+            top = api.Scene(dev)
+            for k in range(5):
+                top.add_instance(obj, np.array([1, 0, 0, 0, 1, 0, 0, 0, 1, 3.0 * k, 0, 0], np.float32))
+            top.commit()
+        else:
+            top = obj
+        a = rays.copy(); top.intersect1M(a)
+        b = rays[:5000].copy(); top.intersect1M(b)                 # (one chunk)
+        c = rays_of(rays); top.occluded1M(c)
+        out[cfg] = (a, b, c)
+        if instanced: top.release()
+        obj.release()
+    w, p = out["gpu=0,packed_link=0"], out["gpu=0"]
+    hit = w[0]["geomID"] != 777
+    assert 0.02 < hit.mean() < 0.95 and (w[0]["geomID"][hit] == 0).all()                       # (the whole-record path leaves 777 where a ray missed: the kernel wrote nothing)
+    if instanced: assert len(set(w[0]["instID"][hit].tolist())) == 5
+    assert (w[0]["Ng_z"][~hit] == np.float32(1e30)).all() and (w[0]["primID"][~hit] == 12345).all()
+    for k in range(3):
+        assert p[k].tobytes() == w[k].tobytes(), "packed link differs from the whole-record path (%s)" % ("closest, chunked", "closest, one chunk", "occluded")[k]
+    assert (w[2]["tfar"] == -np.inf).sum() > 0.02 * n
+
+
 def test_user_data_change_reaches_the_device_filter_function(api, ref):
     """with device_filter_functions=1 the user pointer of a geometry that enabled the argument filter travels to the GPU in the rule table at commit.
     rtcSetGeometryUserData did not mark anything modified, so rtcCommitScene returned early and the function kept seeing the OLD pointer.  Now a changed pointer counts as a
