@@ -137,8 +137,9 @@ void core_check(int rc, const char* what) {
 // hipHostMalloc'ed staging buffers (really pinned, not userptr), filled and drained by the CPU -- several threads for large arrays (copy_pool below).  "host_register=1"
 // in the device config restores the registration of the caller's array (faster on a quiet box: the link instead of the CPU's memcpy is the limit).
 struct CopyPool {                                              // a few threads that do nothing but memcpy: one 96 MB array at ~10 GB/s per thread is 10 ms, the link moves it in 2
-  // (MI355_COPY_THREADS: 2 helpers + the caller since the packed link of round 6 -- 3.0 ms per 2^20 closest-hit rays against 3.3 / 3.7 / 3.9 with 4 / 6 / 10 on a box that
-  // gives the process 16 CPUs: gpurun_out/r06zw, r06zx; six were the default of the whole-record copies)
+  // (MI355_COPY_THREADS: 4 helpers + the caller.  On boxes that give the process 16 CPUs of 256 the best count moves with whatever else runs there: 2^20 closest-hit rays
+  // through the packed link took 3.0 / 3.3 / 3.7 / 3.9 ms with 2 / 4 / 6 / 10 helpers in a process of its own (gpurun_out/r06zw, r06zx) and 3.5 / 3.0 / 3.4 ms with
+  // 2 / 6 / 12 inside bench.py, whose reference worker pool is alive (r06zy); whole records: 4.3 ms either way)
   static constexpr size_t MIN_PART = (size_t)1 << 20;
   typedef void (*RangeFn)(void* ctx, size_t begin, size_t end);   // (a job of run(): items [begin, end) of whatever ctx describes)
   struct Job { char* dst; const char* src; size_t n; std::atomic<int>* left; RangeFn fn = nullptr; void* ctx = nullptr; };
@@ -155,7 +156,7 @@ struct CopyPool {                                              // a few threads 
   }
   ~CopyPool() { { std::lock_guard<std::mutex> lk(mtx); stop = true; } cv.notify_all(); for (auto& t : workers) t.join(); }
   void copy(void* dst, const void* src, size_t n) {
-    static const unsigned want = []() { const char* e = getenv("MI355_COPY_THREADS"); const long v = e ? atol(e) : 2; return (unsigned)(v < 0 ? 0 : (v > 32 ? 32 : v)); }();
+    static const unsigned want = []() { const char* e = getenv("MI355_COPY_THREADS"); const long v = e ? atol(e) : 4; return (unsigned)(v < 0 ? 0 : (v > 32 ? 32 : v)); }();
     if (n < 2 * MIN_PART || want == 0) { memcpy(dst, src, n); return; }
     { std::lock_guard<std::mutex> lk(mtx); if (workers.empty()) start(want); }
     size_t parts = n / MIN_PART; if (parts > workers.size() + 1) parts = workers.size() + 1;
@@ -170,7 +171,7 @@ struct CopyPool {                                              // a few threads 
   }
   // fn(ctx, begin, end) over the items [0, n), `bytesPerItem` of memory traffic each, cut like copy() cuts its bytes (the caller takes the first part itself)
   void run(RangeFn fn, void* ctx, size_t n, size_t bytesPerItem) {
-    static const unsigned want = []() { const char* e = getenv("MI355_COPY_THREADS"); const long v = e ? atol(e) : 2; return (unsigned)(v < 0 ? 0 : (v > 32 ? 32 : v)); }();
+    static const unsigned want = []() { const char* e = getenv("MI355_COPY_THREADS"); const long v = e ? atol(e) : 4; return (unsigned)(v < 0 ? 0 : (v > 32 ? 32 : v)); }();
     if (n * bytesPerItem < 2 * MIN_PART || want == 0) { fn(ctx, 0, n); return; }
     { std::lock_guard<std::mutex> lk(mtx); if (workers.empty()) start(want); }
     size_t parts = n * bytesPerItem / MIN_PART; if (parts > workers.size() + 1) parts = workers.size() + 1;
@@ -809,7 +810,8 @@ static void staged_query_packed(Scene* s, Replica& r, char* data, char* d, unsig
 }
 
 static void staged_query(Scene* s, Replica& r, char* data, char* d, unsigned M, size_t stride, bool any, unsigned qflags) {
-  if (s->device->packedLink && M >= 1024u && !(stride & 15u)) { staged_query_packed(s, r, data, d, M, stride, any, qflags); return; }
+  static const bool envPacked = !(getenv("MI355_PACKED_LINK") && atoi(getenv("MI355_PACKED_LINK")) == 0);   // (A/B without touching the device config)
+  if (envPacked && s->device->packedLink && M >= 1024u && !(stride & 15u)) { staged_query_packed(s, r, data, d, M, stride, any, qflags); return; }
   std::lock_guard<std::mutex> pipeLock(r.pipeMtx);
   mi355_bvh_t b = r.bvh;
   const size_t rec = any ? 48 : 96;
