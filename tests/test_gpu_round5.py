@@ -135,6 +135,12 @@ VERIFY_OUT_OF_SCOPE = {
     "intersection_filter.subdiv": "the same filter over a SUBDIVISION plane (addSubdivPlane, :2796); the triangle half of the group is in VERIFY_MUST_PASS",
     "regression_static|dynamic(_build_join|_memory_monitor)": "random scenes of all geometry types incl. hair, subdivision, motion blur (rtcore_regression_*_thread, :4700-5100)",
     "geometry_state_tests / scene_modified_geometry_tests": "cast RTCGeometry / RTCScene handles to the reference's internal classes (:4480-4600)",
+    "sphere_filter_multi_hit_tests": "two RTC_GEOMETRY_TYPE_SPHERE_POINT geometries (:4644-4654)",
+    "backface_culling / nan_test / inf_test": "registered only when RTC_DEVICE_PROPERTY_BACKFACE_CULLING_ENABLED / _IGNORE_INVALID_RAYS_ENABLED answer 1 (:6485, :6643): build options that are "
+                                              "OFF in the reference's default build and here (both answer 0); invalid rays are covered by inactive_rays and tests/test_gpu_parity.py",
+    "memory_consumption / embree_reported_memory / benchmarks": "measurements of the reference's own allocators and build times (memory_consumption only above --intensity 1, :6414), no pass / fail of API behaviour",
+    "parallel_for_exception_test1-7": "the test program's own tasking system (common/algorithms/parallel_for.h), nothing of the library is called (:5441-5640)",
+    "small_triangle_hit_test": "commented out in the reference (:6625)",
 }
 
 
