@@ -1,0 +1,21 @@
+#!/bin/bash
+# round 6, last session: touch-ahead (tools/patches/r06_touch_ahead.patch) -- lanes ask for the first and last word of the node they will open in the NEXT iteration at the end of
+# this one: 1 = the lanes that will descend, 2 = also the lanes that will pop.  Batch sweep (lone launches, bytes compared with the full batch) + the bench's value / pipelined.
+cd "$GRAFT_REPO_ROOT" || exit 1
+O=gpurun_out/r06_touch; mkdir -p $O; rm -rf $O/*
+for round in 1 2; do
+for V in base touch1 touch2; do
+  LIBV=embree_amd/lib/variant_$V.so; [ $V = base ] && LIBV=embree_amd/lib/libembree4_mi355.so
+  MI355_LIB=$LIBV timeout 300 python tests/gpu_batch_sweep.py --lo 14 --hi 21 --reps 30 --tag $V 2>&1 | grep -a "SWEEP\|rror\|fault" >> $O/sweep.log
+done; done
+for V in base touch1 touch2 base touch2; do
+  LIBV=embree_amd/lib/variant_$V.so; [ $V = base ] && LIBV=embree_amd/lib/libembree4_mi355.so
+  MI355_LIB=$LIBV timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu --sustain 0 > $O/bench_$V.json 2> $O/bench_$V.err
+  python - <<PY >> $O/bench.log
+import json
+try:
+    d=json.loads(open("$O/bench_$V.json").read().strip().splitlines()[-1]); print("$V value %.0f pipelined %.0f small %s parity %s" % (d["value"], d["pipelined"]["value"], [(l["rays"], l["us"]) for l in d["small_batch"]["legs"]], d.get("parity_vs_reference", {}).get("unexplained")))
+except Exception as e: print("$V bench failed", e)
+PY
+done
+cat $O/sweep.log; cat $O/bench.log
