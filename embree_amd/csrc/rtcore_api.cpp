@@ -25,6 +25,7 @@
 #include <string>
 #include <thread>
 #include <vector>
+#include <emmintrin.h>
 #include "../../include/embree4/rtcore.h"
 #include "../../include/embree_amd_hip.h"
 
@@ -721,6 +722,18 @@ static int trace_launch(const Scene* s, mi355_bvh_t b, void* d, unsigned n, size
 struct PackCtx { char* packed; char* recs; size_t stride; };
 static void pack_rays_range(void* c, size_t b, size_t e) {           // caller's records -> 48 packed bytes each
   const PackCtx& x = *(const PackCtx*)c;
+  static const bool stream = !(getenv("MI355_PACK_NT") && atoi(getenv("MI355_PACK_NT")) == 0);
+  if (stream && !((uintptr_t)x.packed & 15u)) {
+    // streaming stores: the pinned buffer is read next by the copy engine, not by this core -- written around the caches its lines are not fetched first (48 of the
+    // 192 bytes per ray the packing moved through memory) and do not evict the caller's records
+    for (size_t i = b; i < e; i++) {
+      const __m128i* src = (const __m128i*)(x.recs + i * x.stride); __m128i* dst = (__m128i*)(x.packed + i * 48u);
+      const __m128i a0 = _mm_loadu_si128(src), a1 = _mm_loadu_si128(src + 1), a2 = _mm_loadu_si128(src + 2);
+      _mm_stream_si128(dst, a0); _mm_stream_si128(dst + 1, a1); _mm_stream_si128(dst + 2, a2);
+    }
+    _mm_sfence();                                              // (in order before whatever tells the copy engine to start)
+    return;
+  }
   for (size_t i = b; i < e; i++) memcpy(x.packed + i * 48u, x.recs + i * x.stride, 48u);
 }
 static void scatter_hits_range(void* c, size_t b, size_t e) {        // { tfar, u, v, primID | geomID, Ng } of the rays that hit -> the caller's RTCRayHit
