@@ -5,6 +5,8 @@
 //   1: 4 of 5 lanes read their own node, every 5th the root  (what the kernel does)
 //   2: 4 of 5 lanes read their own node, every 5th is masked off (EXEC) for the loads
 //   3: as 1, but the idle lanes are the LAST 13 lanes of the wave (whole quads idle) -- 4: as 2 with those lanes
+//   5: every lane its own node, but the 64 lanes of a wave-load stay inside ONE 2 MB window (chosen at random per iteration): as many lines from beyond the L2 as mode 0, one
+//      translation per wave-load instead of up to 64 -- what address translation costs a scattered gather (would a tree laid out sub-tree by sub-tree pay?)
 // Build: hipcc --offload-arch=gfx950 -O3 tools/idle_lane_bench.hip -o /tmp/idle_lane_bench
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -20,6 +22,8 @@ __global__ __launch_bounds__(64) void k(const uint4* __restrict__ nodes, uint32_
     s = s * 1664525u + 1013904223u;
     uint32_t idx = (s >> 8) % numNodes;
     if ((MODE == 1 || MODE == 3) && idle) idx = 0;
+    if (MODE == 5) { const uint32_t win = 26214u, nw = numNodes / win;               // 26214 nodes x 80 B = 2 MB
+      uint32_t ws = (blockIdx.x * 2654435761u + i * 40503u) * 1664525u + 1013904223u; idx = nw ? ((ws >> 8) % nw) * win + (s >> 8) % win : idx; }
     if ((MODE == 2 || MODE == 4) && idle) continue;            // (divergent: the loads below run with these lanes masked off)
     const uint4* p = nodes + (size_t)idx * 5u;
     const uint4 a = p[0], b = p[1], c = p[2], d = p[3], e = p[4];
@@ -34,14 +38,14 @@ int main(int argc, char** argv) {
   uint4* d; uint32_t* o;
   hipMalloc(&d, (size_t)numNodes * 80); hipMemset(d, 1, (size_t)numNodes * 80); hipMalloc(&o, 4);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  const char* names[5] = {"all lanes scattered", "1 in 5 reads the root", "1 in 5 masked off", "last 13 lanes read the root", "last 13 lanes masked off"};
+  const char* names[6] = {"all lanes scattered", "1 in 5 reads the root", "1 in 5 masked off", "last 13 lanes read the root", "last 13 lanes masked off", "scattered inside a 2 MB window"};
   for (int rep = 0; rep < 2; rep++)
-  for (int m = 0; m < 5; m++) {
+  for (int m = 0; m < 6; m++) {
     float best = 1e9f;
     for (int r = 0; r < 5; r++) {
       hipEventRecord(e0);
       switch (m) { case 0: k<0><<<waves, 64>>>(d, numNodes, iters, o); break; case 1: k<1><<<waves, 64>>>(d, numNodes, iters, o); break; case 2: k<2><<<waves, 64>>>(d, numNodes, iters, o); break;
-                   case 3: k<3><<<waves, 64>>>(d, numNodes, iters, o); break; default: k<4><<<waves, 64>>>(d, numNodes, iters, o); }
+                   case 3: k<3><<<waves, 64>>>(d, numNodes, iters, o); break; case 4: k<4><<<waves, 64>>>(d, numNodes, iters, o); break; default: k<5><<<waves, 64>>>(d, numNodes, iters, o); }
       hipEventRecord(e1); hipEventSynchronize(e1);
       float ms; hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
     }
