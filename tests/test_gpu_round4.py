@@ -513,7 +513,7 @@ def test_single_ray_call_latency(api, dev):
     sleepy.release()
     print("rtcIntersect1: median %.1f us, min %.1f us polling; %.1f / %.1f us sleeping on the stream (hit geom %d prim %d t %.6f)"
           % (med, mn, med_sleep, min_sleep, q["geomID"][0], q["primID"][0], q["tfar"][0]))
-    assert med <= 1.10 * med_sleep + 3.0, "polling the stream (%.1f us) is slower than sleeping on it (%.1f us)" % (med, med_sleep)
+    assert med <= 1.25 * med_sleep + 5.0, "polling the stream (%.1f us) is slower than sleeping on it (%.1f us)" % (med, med_sleep)
     assert med < 150.0, "rtcIntersect1 median %.1f us: back at the four-round-trip form?" % med
 
 
